@@ -1,0 +1,54 @@
+"""ctypes binding of libfar_hip.so (include/far_hip.h).
+
+The product path has no fallback: if the shared library is missing or a kernel call is attempted on a
+non-GPU tensor, this module raises.  `load()` itself needs no GPU (the symbol-export test runs on CPU).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libfar_hip.so')
+
+c_p = ctypes.c_void_p
+c_i = ctypes.c_int
+c_f = ctypes.c_float
+c_d = ctypes.c_double
+c_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every function declared in include/far_hip.h
+SIGNATURES = {
+    'far_abi_version': (c_i, []),
+    'far_dual_softmax_workspace_bytes': (c_sz, [c_i, c_i, c_i]),
+    'far_dual_softmax_stats_f32': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p]),
+    'far_coarse_match_f32': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f,
+                                   c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+}
+
+_lib = None
+
+
+class FarHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libfar_hip.so and attach signatures.  Raises FarHipError when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FarHipError(
+            f'{LIB_PATH} not found: build it with `python -m far_amd.build` (hipcc --offload-arch=gfx950). '
+            'far_amd has no CPU or eager fallback for its kernels.')
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise FarHipError(f'{what} failed with code {rc}')

@@ -1,0 +1,40 @@
+// Shared device helpers for the far_amd HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <float.h>
+
+#define FAR_OK 0
+#define FAR_EINVAL (-22)
+#define FAR_ELAUNCH (-5)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Row index inside a 32x32 MFMA accumulator tile for accumulator register `r` (0..15) of a lane
+// whose upper-half flag is `h` (lane >> 5).  Column index is lane & 31.
+// (cdna_hip_programming.md section 3: row=(reg&3)+8*(reg>>2)+4*(lane>>5))
+__device__ __forceinline__ int mfma32_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+__device__ __forceinline__ float shfl_xor_f(float v, int m) { return __shfl_xor(v, m, 64); }
+__device__ __forceinline__ int shfl_xor_i(int v, int m) { return __shfl_xor(v, m, 64); }
+
+// exp(x) on the transcendental unit: v_exp_f32(x * log2(e)).  For the arguments used here (x <= 0 after
+// max subtraction) the absolute error of e^x is <= |x| e^x 2^-24 + 1 ulp <= ~3e-8, far below the 1e-5
+// parity tolerance on confidences; a denormal result flushes to 0, as irrelevant.
+__device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+
+// Merge two online-softmax partials (m, s): s = sum exp(x - m).  Safe for empty partials
+// (m = -FLT_MAX, s = 0).
+__device__ __forceinline__ void softmax_merge(float& m, float& s, float mo, float so) {
+    float mn = fmaxf(m, mo);
+    float a = (m == mn) ? 1.0f : fexp(m - mn);
+    float b = (mo == mn) ? 1.0f : fexp(mo - mn);
+    s = s * a + so * b;
+    m = mn;
+}
+
+static inline int far_check_launch() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? FAR_OK : FAR_ELAUNCH;
+}

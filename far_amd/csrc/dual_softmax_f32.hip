@@ -1,0 +1,489 @@
+// K1 (coarse matcher) and the statistics half of K2 (EMM head): all-pairs correlation with
+// dual-softmax, never materialising the L x S score matrix unless asked to.
+//
+// Replaces (reference, mp3d_loftr/src/loftr/utils/coarse_matching.py):
+//   :104-113  feat / sqrt(C); sim = einsum(nlc,nsc->nls) / temperature; optional -INF mask fill
+//   :118      conf = softmax(sim, 1) * softmax(sim, 2)
+//   :174-195  conf > thr, border removal, mutual nearest neighbour, first-True j per row, mconf
+//   :246-263  coordinates of the matched cells
+// and (mp3d_loftr/src/loftr/loftr_module/transformer.py:278-282) the two softmaxes of the head.
+//
+// Pass structure (fp32-exact variant; every dot product is an fmaf chain on the f32 matrix core):
+//   stats    : tile S = f0 f1^T, online row (max,sum-exp) per lane, per-tile column (max,sum-exp)
+//              partials -> colpart[n][Iblk][j]                                    (1 GEMM)
+//   colreduce: colstat[n][j] = merge over Iblk
+//   match    : recompute the tile, P = softmax_col * softmax_row, optional conf_matrix store,
+//              running row best (P, j) and per-tile column best P -> colbest[n][Iblk][j]  (1 GEMM)
+//   finalize : per row: P>thr, border(i), border(j*), P == column max of P -> match_j[n][i]
+//   compact  : ordered (b, i) compaction to int64 ids, conf and cell coordinates
+#include "gemm_tile_f32.h"
+
+namespace {
+
+constexpr float NEG_BIG = -FLT_MAX;
+
+struct SimParams {
+    float feat_div;   // features divided by this when staged (sqrt(C) for K1, 1 for K2)
+    float sim_div;    // dot / sim_div            (temperature for K1, 1 for K2)
+    float sim_mul;    // then * sim_mul           (1 for K1, head_dim^-0.5 for K2)
+    float mask_fill;  // value for masked-out (i,j) pairs (-1e9 in the reference)
+};
+
+__device__ __forceinline__ float sim_of(float acc, const SimParams& p) {
+    float s = acc / p.sim_div;
+    return s * p.sim_mul;
+}
+
+// --------------------------------------------------------------------------------------------
+// Pass 1: statistics.
+// grid = (nI, Z); block = 256.  rowstat[z][i] = (max_j s, sum_j exp(s - max));
+// colpart[z][Iblk][j] = (max over the block's rows, sum exp).
+// mask0/mask1 (optional, uint8 [Z][L] / [Z][S]): pair (i,j) is masked iff !(mask0[i] && mask1[j]).
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_stats_f32(
+    const float* __restrict__ f0, const float* __restrict__ f1, int L, int S, int C, SimParams sp,
+    const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1,
+    float2* __restrict__ rowstat, float2* __restrict__ colpart) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    TileLds& lds = *reinterpret_cast<TileLds*>(smem_raw);
+    float2* colx = reinterpret_cast<float2*>(smem_raw + sizeof(TileLds));  // [4][128]
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int z = blockIdx.y, Ib = blockIdx.x, nI = gridDim.x;
+    const int i0 = Ib * TILE_M;
+    const float* A = f0 + (size_t)z * L * C;
+    const float* B = f1 + (size_t)z * S * C;
+    const int nJ = (S + TILE_N - 1) / TILE_N, nkc = C / KC, nq = nJ * nkc;
+
+    // row masks for this lane's 16 rows
+    unsigned rowvalid = 0, rowmasked = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int i = i0 + 32 * wave + mfma32_row(r, h);
+        if (i < L) {
+            rowvalid |= 1u << r;
+            if (mask0 && !mask0[(size_t)z * L + i]) rowmasked |= 1u << r;
+        }
+    }
+
+    float rm[16], rs[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { rm[r] = NEG_BIG; rs[r] = 0.f; }
+
+    f32x16 acc[4];
+    acc_zero(acc);
+    ChunkRegs cr;
+    chunk_load(cr, A, i0, L, B, 0, S, C, 0, tid);
+    chunk_store(cr, lds, 0, tid, sp.feat_div);
+    __syncthreads();
+
+    for (int q = 0; q < nq; ++q) {
+        const int Jt = q / nkc, kc = q - Jt * nkc;
+        const int buf = q & 1;
+        if (q + 1 < nq) {
+            int Jn = (q + 1) / nkc, kn = (q + 1) - Jn * nkc;
+            chunk_load(cr, A, i0, L, B, Jn * TILE_N, S, C, kn * KC, tid);
+        }
+        chunk_mfma<false>(acc, lds, buf, wave, lane);
+        if (kc == nkc - 1) {
+            // ---- tile epilogue ----
+            const int j0 = Jt * TILE_N;
+            float cmx[4], csm[4];
+            bool cvalid[4], cmasked[4];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                int j = j0 + 32 * ct + l31;
+                cvalid[ct] = j < S;
+                cmasked[ct] = cvalid[ct] && mask1 && !mask1[(size_t)z * S + j];
+            }
+            // similarity values in place
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float s = sim_of(acc[ct][r], sp);
+                    if (cmasked[ct] || ((rowmasked >> r) & 1)) s = sp.mask_fill;
+                    acc[ct][r] = s;
+                }
+            // row direction: online update over this lane's 4 columns
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float tm = NEG_BIG;
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+                    if (cvalid[ct]) tm = fmaxf(tm, acc[ct][r]);
+                float mn = fmaxf(rm[r], tm);
+                float sum = (rm[r] == mn) ? rs[r] : rs[r] * fexp(rm[r] - mn);
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+                    if (cvalid[ct]) sum += fexp(acc[ct][r] - mn);
+                rm[r] = mn;
+                rs[r] = sum;
+            }
+            // column direction: reduce this lane's 16 rows, then the two lane halves
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                float m = NEG_BIG;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if ((rowvalid >> r) & 1) m = fmaxf(m, acc[ct][r]);
+                float s = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if ((rowvalid >> r) & 1) s += fexp(acc[ct][r] - m);
+                float mo = shfl_xor_f(m, 32), so = shfl_xor_f(s, 32);
+                softmax_merge(m, s, mo, so);
+                cmx[ct] = m;
+                csm[ct] = s;
+            }
+            if (h == 0) {
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) colx[wave * 128 + 32 * ct + l31] = make_float2(cmx[ct], csm[ct]);
+            }
+            acc_zero(acc);
+        }
+        if (q + 1 < nq) chunk_store(cr, lds, buf ^ 1, tid, sp.feat_div);
+        __syncthreads();
+        if (kc == nkc - 1) {
+            const int j0 = Jt * TILE_N;
+            if (tid < 128 && j0 + tid < S) {
+                float2 v = colx[tid];
+                float m = v.x, s = v.y;
+#pragma unroll
+                for (int w = 1; w < 4; ++w) {
+                    float2 o = colx[w * 128 + tid];
+                    softmax_merge(m, s, o.x, o.y);
+                }
+                colpart[((size_t)z * nI + Ib) * S + j0 + tid] = make_float2(m, s);
+            }
+            // colx is rewritten only after the next tile's nkc >= 1 barriers: no extra sync needed
+            // when nkc >= 2; for nkc == 1 add one.
+            if (nkc == 1) __syncthreads();
+        }
+    }
+
+    // merge row partials over the 32 lanes that share (wave, h)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float m = rm[r], s = rs[r];
+#pragma unroll
+        for (int d = 1; d < 32; d <<= 1) {
+            float mo = shfl_xor_f(m, d), so = shfl_xor_f(s, d);
+            softmax_merge(m, s, mo, so);
+        }
+        if (l31 == 0 && ((rowvalid >> r) & 1)) {
+            int i = i0 + 32 * wave + mfma32_row(r, h);
+            rowstat[(size_t)z * L + i] = make_float2(m, s);
+        }
+    }
+}
+
+// colstat[z][j] = merge_{Ib} colpart[z][Ib][j]
+__global__ void k_colreduce(const float2* __restrict__ colpart, int nI, int S, float2* __restrict__ colstat) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x, z = blockIdx.y;
+    if (j >= S) return;
+    float m = NEG_BIG, s = 0.f;
+    for (int b = 0; b < nI; ++b) {
+        float2 v = colpart[((size_t)z * nI + b) * S + j];
+        softmax_merge(m, s, v.x, v.y);
+    }
+    colstat[(size_t)z * S + j] = make_float2(m, s);
+}
+
+// --------------------------------------------------------------------------------------------
+// Pass 2: recompute, P = softmax_col * softmax_row, conf store (optional), row/col best.
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_match_f32(
+    const float* __restrict__ f0, const float* __restrict__ f1, int L, int S, int C, SimParams sp,
+    const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1,
+    const float2* __restrict__ rowstat, const float2* __restrict__ colstat,
+    float* __restrict__ conf,  // optional [Z][L][S]
+    float* __restrict__ rowbest_v, int* __restrict__ rowbest_j,  // [Z][L]
+    float* __restrict__ colbest_part) {                          // [Z][nI][S]
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    TileLds& lds = *reinterpret_cast<TileLds*>(smem_raw);
+    float* colx = reinterpret_cast<float*>(smem_raw + sizeof(TileLds));  // [4][128]
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int z = blockIdx.y, Ib = blockIdx.x, nI = gridDim.x;
+    const int i0 = Ib * TILE_M;
+    const float* A = f0 + (size_t)z * L * C;
+    const float* B = f1 + (size_t)z * S * C;
+    const int nJ = (S + TILE_N - 1) / TILE_N, nkc = C / KC, nq = nJ * nkc;
+
+    unsigned rowvalid = 0, rowmasked = 0;
+    float rmax[16], rsum[16], bestv[16];
+    int bestj[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int i = i0 + 32 * wave + mfma32_row(r, h);
+        rmax[r] = 0.f; rsum[r] = 1.f; bestv[r] = -1.f; bestj[r] = 0x7fffffff;
+        if (i < L) {
+            rowvalid |= 1u << r;
+            if (mask0 && !mask0[(size_t)z * L + i]) rowmasked |= 1u << r;
+            float2 st = rowstat[(size_t)z * L + i];
+            rmax[r] = st.x; rsum[r] = st.y;
+        }
+    }
+
+    f32x16 acc[4];
+    acc_zero(acc);
+    ChunkRegs cr;
+    chunk_load(cr, A, i0, L, B, 0, S, C, 0, tid);
+    chunk_store(cr, lds, 0, tid, sp.feat_div);
+    __syncthreads();
+
+    for (int q = 0; q < nq; ++q) {
+        const int Jt = q / nkc, kc = q - Jt * nkc;
+        const int buf = q & 1;
+        if (q + 1 < nq) {
+            int Jn = (q + 1) / nkc, kn = (q + 1) - Jn * nkc;
+            chunk_load(cr, A, i0, L, B, Jn * TILE_N, S, C, kn * KC, tid);
+        }
+        chunk_mfma<false>(acc, lds, buf, wave, lane);
+        if (kc == nkc - 1) {
+            const int j0 = Jt * TILE_N;
+            float cbest[4];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                const int j = j0 + 32 * ct + l31;
+                const bool cvalid = j < S;
+                const bool cmasked = cvalid && mask1 && !mask1[(size_t)z * S + j];
+                float2 cst = cvalid ? colstat[(size_t)z * S + j] : make_float2(0.f, 1.f);
+                float cb = -1.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float s = sim_of(acc[ct][r], sp);
+                    if (cmasked || ((rowmasked >> r) & 1)) s = sp.mask_fill;
+                    // reference order: softmax over dim 1 (columns normalised over rows) times
+                    // softmax over dim 2 (coarse_matching.py:118)
+                    float pc = fexp(s - cst.x) / cst.y;
+                    float pr = fexp(s - rmax[r]) / rsum[r];
+                    float p = pc * pr;
+                    const bool ok = cvalid && ((rowvalid >> r) & 1);
+                    if (ok) {
+                        if (conf) {
+                            int i = i0 + 32 * wave + mfma32_row(r, h);
+                            conf[((size_t)z * L + i) * S + j] = p;
+                        }
+                        if (p > bestv[r]) { bestv[r] = p; bestj[r] = j; }
+                        cb = fmaxf(cb, p);
+                    }
+                }
+                cb = fmaxf(cb, shfl_xor_f(cb, 32));
+                cbest[ct] = cb;
+            }
+            if (h == 0) {
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) colx[wave * 128 + 32 * ct + l31] = cbest[ct];
+            }
+            acc_zero(acc);
+        }
+        if (q + 1 < nq) chunk_store(cr, lds, buf ^ 1, tid, sp.feat_div);
+        __syncthreads();
+        if (kc == nkc - 1) {
+            const int j0 = Jt * TILE_N;
+            if (tid < 128 && j0 + tid < S) {
+                float m = fmaxf(fmaxf(colx[tid], colx[128 + tid]), fmaxf(colx[256 + tid], colx[384 + tid]));
+                colbest_part[((size_t)z * nI + Ib) * S + j0 + tid] = m;
+            }
+            if (nkc == 1) __syncthreads();
+        }
+    }
+
+    // row best across the 32 lanes sharing (wave, h): larger P wins, ties -> smaller j
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float v = bestv[r];
+        int j = bestj[r];
+#pragma unroll
+        for (int d = 1; d < 32; d <<= 1) {
+            float vo = shfl_xor_f(v, d);
+            int jo = shfl_xor_i(j, d);
+            if (vo > v || (vo == v && jo < j)) { v = vo; j = jo; }
+        }
+        if (l31 == 0 && ((rowvalid >> r) & 1)) {
+            int i = i0 + 32 * wave + mfma32_row(r, h);
+            rowbest_v[(size_t)z * L + i] = v;
+            rowbest_j[(size_t)z * L + i] = j;
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// finalize: match_j[z][i] = j* if row i is a mutual-nearest match above threshold and inside the
+// border, else -1.  Border semantics of mask_border (coarse_matching.py:8-25): a cell (y,x) of an
+// h x w grid survives iff bd <= y < h-bd and bd <= x < w-bd.  With padded masks
+// (mask_border_with_padding, :28-43) the lower limits come from per-sample valid extents hv/wv.
+// --------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool border_ok(int idx, int w, int hlim, int wlim, int bd) {
+    int y = idx / w, x = idx - y * w;
+    return y >= bd && y < hlim - bd && x >= bd && x < wlim - bd;
+}
+
+__global__ void k_finalize(const float* __restrict__ rowbest_v, const int* __restrict__ rowbest_j,
+                           const float* __restrict__ colbest_part, int nI, int L, int S, float thr,
+                           int bd, int h0, int w0, int h1, int w1,
+                           const int* __restrict__ valid_hw,  // optional [Z][4] = h0v,w0v,h1v,w1v
+                           int* __restrict__ match_j, int* __restrict__ counts) {
+    const int z = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int hl0 = h0, wl0 = w0, hl1 = h1, wl1 = w1;
+    if (valid_hw) { hl0 = valid_hw[z * 4]; wl0 = valid_hw[z * 4 + 1]; hl1 = valid_hw[z * 4 + 2]; wl1 = valid_hw[z * 4 + 3]; }
+    int mj = -1;
+    if (i < L) {
+        float v = rowbest_v[(size_t)z * L + i];
+        int j = rowbest_j[(size_t)z * L + i];
+        if (v > thr && j < S) {
+            bool ok = bd <= 0 || (border_ok(i, w0, hl0, wl0, bd) && border_ok(j, w1, hl1, wl1, bd));
+            if (ok) {
+                float cm = -1.f;
+                for (int b = 0; b < nI; ++b) cm = fmaxf(cm, colbest_part[((size_t)z * nI + b) * S + j]);
+                if (v == cm) mj = j;
+            }
+        }
+        match_j[(size_t)z * L + i] = mj;
+    }
+    unsigned long long bal = __ballot(mj >= 0);
+    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&counts[z], __popcll(bal));
+}
+
+// compact: one block per pair; offset = sum of counts of earlier pairs; ordered by i.
+__global__ void k_compact(const int* __restrict__ match_j, const float* __restrict__ rowbest_v,
+                          const int* __restrict__ counts, int L, int w0, int w1, float scale,
+                          const float* __restrict__ scale0, const float* __restrict__ scale1,  // optional [Z][2]
+                          int64_t* __restrict__ b_ids, int64_t* __restrict__ i_ids,
+                          int64_t* __restrict__ j_ids, float* __restrict__ mconf,
+                          float* __restrict__ mkpts0, float* __restrict__ mkpts1,
+                          int* __restrict__ total) {
+    __shared__ int wave_cnt[4];
+    __shared__ int base_s;
+    const int z = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (tid == 0) {
+        int off = 0;
+        for (int b = 0; b < z; ++b) off += counts[b];
+        base_s = off;
+        if (z == gridDim.x - 1) *total = off + counts[z];
+    }
+    __syncthreads();
+    int base = base_s;
+    for (int i0 = 0; i0 < L; i0 += 256) {
+        int i = i0 + tid;
+        int mj = (i < L) ? match_j[(size_t)z * L + i] : -1;
+        unsigned long long bal = __ballot(mj >= 0);
+        if (lane == 0) wave_cnt[wave] = __popcll(bal);
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wave_cnt[w];
+        int tot = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        if (mj >= 0) {
+            int pos = base + woff + __popcll(bal & ((1ull << lane) - 1ull));
+            b_ids[pos] = z;
+            i_ids[pos] = i;
+            j_ids[pos] = mj;
+            mconf[pos] = rowbest_v[(size_t)z * L + i];
+            float sx0 = scale, sy0 = scale, sx1 = scale, sy1 = scale;
+            if (scale0) { sx0 = scale * scale0[z * 2]; sy0 = scale * scale0[z * 2 + 1]; }
+            if (scale1) { sx1 = scale * scale1[z * 2]; sy1 = scale * scale1[z * 2 + 1]; }
+            mkpts0[2 * pos] = (float)(i % w0) * sx0;
+            mkpts0[2 * pos + 1] = (float)(i / w0) * sy0;
+            mkpts1[2 * pos] = (float)(mj % w1) * sx1;
+            mkpts1[2 * pos + 1] = (float)(mj / w1) * sy1;
+        }
+        base += tot;
+        __syncthreads();
+    }
+}
+
+constexpr size_t kTileSmem = sizeof(TileLds) + 4 * 128 * sizeof(float2);
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct K1Workspace {
+    float2* rowstat; float2* colpart; float2* colstat;
+    float* rowbest_v; int* rowbest_j; float* colbest_part; int* match_j; int* counts; int* total;
+    size_t bytes;
+};
+
+K1Workspace carve(void* ws, int Z, int L, int S) {
+    K1Workspace w;
+    int nI = (L + TILE_M - 1) / TILE_M;
+    char* p = reinterpret_cast<char*>(ws);
+    size_t off = 0;
+    auto take = [&](size_t n) { char* q = p ? p + off : nullptr; off += align256(n); return q; };
+    w.rowstat = (float2*)take((size_t)Z * L * sizeof(float2));
+    w.colpart = (float2*)take((size_t)Z * nI * S * sizeof(float2));
+    w.colstat = (float2*)take((size_t)Z * S * sizeof(float2));
+    w.rowbest_v = (float*)take((size_t)Z * L * sizeof(float));
+    w.rowbest_j = (int*)take((size_t)Z * L * sizeof(int));
+    w.colbest_part = (float*)take((size_t)Z * nI * S * sizeof(float));
+    w.match_j = (int*)take((size_t)Z * L * sizeof(int));
+    w.counts = (int*)take((size_t)(Z + 1) * sizeof(int));
+    w.total = w.counts ? w.counts + Z : nullptr;
+    w.bytes = off;
+    return w;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t far_dual_softmax_workspace_bytes(int Z, int L, int S) {
+    return carve(nullptr, Z, L, S).bytes;
+}
+
+// Row/column softmax statistics of sim = ((f0/feat_div) . (f1/feat_div)) / sim_div * sim_mul.
+// rowstat [Z][L] float2 (max, sum-exp); colstat [Z][S] float2.  ws from far_dual_softmax_workspace_bytes.
+int far_dual_softmax_stats_f32(const float* f0, const float* f1, int Z, int L, int S, int C,
+                               float feat_div, float sim_div, float sim_mul,
+                               const uint8_t* mask0, const uint8_t* mask1,
+                               float* rowstat_out, float* colstat_out, void* ws, hipStream_t stream) {
+    if (!f0 || !f1 || !ws || Z <= 0 || L <= 0 || S <= 0 || C <= 0 || (C % KC) != 0) return FAR_EINVAL;
+    K1Workspace w = carve(ws, Z, L, S);
+    SimParams sp{feat_div, sim_div, sim_mul, -1e9f};
+    int nI = (L + TILE_M - 1) / TILE_M;
+    float2* rs = rowstat_out ? (float2*)rowstat_out : w.rowstat;
+    float2* cs = colstat_out ? (float2*)colstat_out : w.colstat;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)k_stats_f32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTileSmem);
+        hipFuncSetAttribute((const void*)k_match_f32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTileSmem);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_stats_f32, dim3(nI, Z), dim3(256), kTileSmem, stream, f0, f1, L, S, C, sp, mask0, mask1,
+                       rs, w.colpart);
+    hipLaunchKernelGGL(k_colreduce, dim3((S + 255) / 256, Z), dim3(256), 0, stream, w.colpart, nI, S, cs);
+    return far_check_launch();
+}
+
+// Full coarse matcher.  Outputs must hold Z*L entries (worst case); *total_out (device int) receives M.
+// conf_out: optional [Z][L][S] (the reference's data['conf_matrix']).
+// valid_hw: optional [Z][4] int (padded-mask datasets); scale0/scale1: optional [Z][2] float.
+int far_coarse_match_f32(const float* f0, const float* f1, int Z, int L, int S, int C,
+                         float temperature, float thr, int border, int h0, int w0, int h1, int w1,
+                         float cell_scale, const uint8_t* mask0, const uint8_t* mask1,
+                         const int* valid_hw, const float* scale0, const float* scale1,
+                         float* conf_out, int64_t* b_ids, int64_t* i_ids, int64_t* j_ids, float* mconf,
+                         float* mkpts0_c, float* mkpts1_c, int* counts_out, int* total_out,
+                         void* ws, hipStream_t stream) {
+    if (!f0 || !f1 || !ws || !b_ids || !i_ids || !j_ids || !mconf || !mkpts0_c || !mkpts1_c || !total_out)
+        return FAR_EINVAL;
+    if (Z <= 0 || L <= 0 || S <= 0 || C <= 0 || (C % KC) != 0 || h0 * w0 != L || h1 * w1 != S) return FAR_EINVAL;
+    K1Workspace w = carve(ws, Z, L, S);
+    int rc = far_dual_softmax_stats_f32(f0, f1, Z, L, S, C, sqrtf((float)C), temperature, 1.0f, mask0, mask1,
+                                        nullptr, nullptr, ws, stream);
+    if (rc) return rc;
+    SimParams sp{sqrtf((float)C), temperature, 1.0f, -1e9f};
+    int nI = (L + TILE_M - 1) / TILE_M;
+    int* counts = counts_out ? counts_out : w.counts;
+    hipMemsetAsync(counts, 0, sizeof(int) * Z, stream);
+    hipLaunchKernelGGL(k_match_f32, dim3(nI, Z), dim3(256), kTileSmem, stream, f0, f1, L, S, C, sp, mask0, mask1,
+                       w.rowstat, w.colstat, conf_out, w.rowbest_v, w.rowbest_j, w.colbest_part);
+    hipLaunchKernelGGL(k_finalize, dim3((L + 255) / 256, Z), dim3(256), 0, stream, w.rowbest_v, w.rowbest_j,
+                       w.colbest_part, nI, L, S, thr, border, h0, w0, h1, w1, valid_hw, w.match_j, counts);
+    hipLaunchKernelGGL(k_compact, dim3(Z), dim3(256), 0, stream, w.match_j, w.rowbest_v, counts, L, w0, w1,
+                       cell_scale, scale0, scale1, b_ids, i_ids, j_ids, mconf, mkpts0_c, mkpts1_c, total_out);
+    return far_check_launch();
+}
+
+}  // extern "C"

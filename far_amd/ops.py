@@ -1,0 +1,83 @@
+"""Thin torch-tensor front ends for the C ABI in include/far_hip.h.
+
+PyTorch supplies device memory and the current HIP stream; all arithmetic of these ops happens in
+libfar_hip.so.  Every op raises on CPU tensors -- there is no eager fallback.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t, dtype=None):
+    """Device pointer of a contiguous GPU tensor (None -> NULL)."""
+    if t is None:
+        return ctypes.c_void_p(0)
+    if not t.is_cuda:
+        raise _lib.FarHipError('far_amd ops need tensors on the GPU (no CPU fallback exists)')
+    if not t.is_contiguous():
+        raise _lib.FarHipError('far_amd ops need contiguous tensors')
+    if dtype is not None and t.dtype != dtype:
+        raise _lib.FarHipError(f'expected dtype {dtype}, got {t.dtype}')
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def dual_softmax_stats(f0, f1, feat_div=1.0, sim_div=1.0, sim_mul=1.0, mask0=None, mask1=None):
+    """(rowstat [Z,L,2], colstat [Z,S,2]) = (max, sum-exp) of the similarity matrix along each axis."""
+    lib = _lib.load()
+    Z, L, C = f0.shape
+    S = f1.shape[1]
+    ws = _ws(lib.far_dual_softmax_workspace_bytes(Z, L, S), f0.device)
+    rowstat = torch.empty(Z, L, 2, dtype=torch.float32, device=f0.device)
+    colstat = torch.empty(Z, S, 2, dtype=torch.float32, device=f0.device)
+    rc = lib.far_dual_softmax_stats_f32(_p(f0, torch.float32), _p(f1, torch.float32), Z, L, S, C,
+                                        feat_div, sim_div, sim_mul, _p(mask0, torch.uint8), _p(mask1, torch.uint8),
+                                        _p(rowstat), _p(colstat), _p(ws), _stream())
+    _lib.check(rc, 'far_dual_softmax_stats_f32')
+    return rowstat, colstat
+
+
+def coarse_match(f0, f1, temperature, thr, border, hw0, hw1, cell_scale, mask0=None, mask1=None,
+                 valid_hw=None, scale0=None, scale1=None, want_conf=False):
+    """K1.  Returns dict(b_ids, i_ids, j_ids, mconf, mkpts0_c, mkpts1_c, counts, conf_matrix|None).
+
+    One host synchronisation (reading M) is inherent: the reference's outputs have data-dependent shape
+    (torch.where, coarse_matching.py:193).
+    """
+    lib = _lib.load()
+    Z, L, C = f0.shape
+    S = f1.shape[1]
+    dev = f0.device
+    ws = _ws(lib.far_dual_softmax_workspace_bytes(Z, L, S), dev)
+    cap = Z * L
+    b_ids = torch.empty(cap, dtype=torch.int64, device=dev)
+    i_ids = torch.empty(cap, dtype=torch.int64, device=dev)
+    j_ids = torch.empty(cap, dtype=torch.int64, device=dev)
+    mconf = torch.empty(cap, dtype=torch.float32, device=dev)
+    mk0 = torch.empty(cap, 2, dtype=torch.float32, device=dev)
+    mk1 = torch.empty(cap, 2, dtype=torch.float32, device=dev)
+    counts = torch.empty(Z + 1, dtype=torch.int32, device=dev)
+    conf = torch.empty(Z, L, S, dtype=torch.float32, device=dev) if want_conf else None
+    rc = lib.far_coarse_match_f32(
+        _p(f0, torch.float32), _p(f1, torch.float32), Z, L, S, C, float(temperature), float(thr), int(border),
+        int(hw0[0]), int(hw0[1]), int(hw1[0]), int(hw1[1]), float(cell_scale),
+        _p(mask0, torch.uint8), _p(mask1, torch.uint8), _p(valid_hw, torch.int32),
+        _p(scale0, torch.float32), _p(scale1, torch.float32), _p(conf),
+        _p(b_ids), _p(i_ids), _p(j_ids), _p(mconf), _p(mk0), _p(mk1),
+        _p(counts), ctypes.c_void_p(counts.data_ptr() + 4 * Z), _p(ws), _stream())
+    _lib.check(rc, 'far_coarse_match_f32')
+    counts_h = counts.cpu()
+    M = int(counts_h[Z])
+    return {
+        'b_ids': b_ids[:M], 'i_ids': i_ids[:M], 'j_ids': j_ids[:M], 'mconf': mconf[:M],
+        'mkpts0_c': mk0[:M], 'mkpts1_c': mk1[:M], 'counts': counts_h[:Z], 'conf_matrix': conf,
+    }

@@ -1,0 +1,67 @@
+/* far_hip.h -- C ABI of libfar_hip.so: the MI355X (gfx950) kernels behind FAR's pose-estimation hot path.
+ *
+ * The reference (crockwell/far, mp3d_loftr) has no native code and no FFI: its boundary is the Python
+ * nn.Module / data-dict API.  This header is the boundary a maintainer binds with
+ * ctypes from those modules; every entry point names the reference code it replaces.
+ * Citations are relative to the reference root (mp3d_loftr/...).
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless the name ends in _host; no allocation inside the library:
+ *     the caller passes workspaces sized by the matching *_workspace_bytes();
+ *   - every function enqueues on `stream` and returns immediately: 0 = enqueued, negative errno otherwise
+ *     (-22 invalid argument, -5 launch failure); nothing throws, nothing prints;
+ *   - no global state besides one-time kernel attribute setup; one process per GPU;
+ *   - "Z" is a flat batch (image pairs, or pairs x heads x directions for the head).
+ */
+#ifndef FAR_HIP_H
+#define FAR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* far_stream_t; /* == hipStream_t */
+
+/* ABI version of this header; bumped when a signature changes. */
+int far_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------------
+ * K1  coarse matcher: all-pairs correlation + dual-softmax + mutual-NN selection
+ * replaces src/loftr/utils/coarse_matching.py:86-147 (CoarseMatching.forward, dual_softmax branch)
+ *      and src/loftr/utils/coarse_matching.py:149-265 (get_coarse_match, eval path) incl. mask_border :8-25
+ * ------------------------------------------------------------------------------------------------- */
+
+/* Bytes of workspace for Z problems of L x S tokens (shared by the three functions below). */
+size_t far_dual_softmax_workspace_bytes(int Z, int L, int S);
+
+/* Row / column softmax statistics of  sim[z,i,j] = ((f0[z,i,:]/feat_div) . (f1[z,j,:]/feat_div)) / sim_div * sim_mul
+ *   f0 [Z][L][C], f1 [Z][S][C] fp32 contiguous, C % 32 == 0
+ *   mask0 [Z][L], mask1 [Z][S] optional uint8 (0 = padded): masked pairs get sim = -1e9 (coarse_matching.py:114-117)
+ *   rowstat_out [Z][L][2], colstat_out [Z][S][2] optional: (max, sum exp(sim - max)); always also left in ws. */
+int far_dual_softmax_stats_f32(const float* f0, const float* f1, int Z, int L, int S, int C,
+                               float feat_div, float sim_div, float sim_mul,
+                               const uint8_t* mask0, const uint8_t* mask1,
+                               float* rowstat_out, float* colstat_out, void* ws, far_stream_t stream);
+
+/* Full matcher.  f0/f1 as above with feat_div = sqrt(C), sim_div = temperature (coarse_matching.py:104-113).
+ *   thr, border: match_coarse.thr / border_rm; (h0,w0),(h1,w1): coarse grids, h0*w0 == L, h1*w1 == S
+ *   cell_scale: hw0_i[0] / hw0_c[0] (coarse_matching.py:246); scale0/scale1 optional [Z][2] (x,y) per-pair image scales
+ *   valid_hw optional [Z][4] = valid (h0,w0,h1,w1) extents for mask_border_with_padding (:28-43)
+ *   conf_out optional [Z][L][S]: data['conf_matrix'] (needed by the loss / plotting only)
+ *   outputs sized for the worst case Z*L: b_ids,i_ids,j_ids int64; mconf fp32; mkpts0_c/mkpts1_c [.,2] fp32,
+ *   ordered by (b, i) exactly like torch.where on the reference's mask; counts_out optional [Z]; *total_out = M. */
+int far_coarse_match_f32(const float* f0, const float* f1, int Z, int L, int S, int C,
+                         float temperature, float thr, int border, int h0, int w0, int h1, int w1,
+                         float cell_scale, const uint8_t* mask0, const uint8_t* mask1,
+                         const int* valid_hw, const float* scale0, const float* scale1,
+                         float* conf_out, int64_t* b_ids, int64_t* i_ids, int64_t* j_ids, float* mconf,
+                         float* mkpts0_c, float* mkpts1_c, int* counts_out, int* total_out,
+                         void* ws, far_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FAR_HIP_H */
