@@ -14,18 +14,25 @@ def _softmax(x, axis):
     return e / e.sum(axis=axis, keepdims=True)
 
 
-def conf_matrix(feat_c0, feat_c1, temperature, mask_c0=None, mask_c1=None):
-    """coarse_matching.py:101-118.  feat (N,L,C)/(N,S,C) float32 -> conf (N,L,S) float32."""
+def conf_matrix(feat_c0, feat_c1, temperature, mask_c0=None, mask_c1=None, dtype=np.float32):
+    """coarse_matching.py:101-118.  feat (N,L,C)/(N,S,C) float32 -> conf (N,L,S).
+
+    dtype=float32 follows the reference's arithmetic type.  NOTE (measured, tests/test_oracle_coarse.py):
+    an fp32 softmax over 4800 entries where one term is ~1 and the rest ~1e-7 loses the small terms to
+    swamping; the reference's own torch-CPU result (and this function in float32) deviates up to ~7e-5
+    from the exact value.  dtype=float64 evaluates the same formulas on the same fp32 inputs without that
+    loss and is what kernels are held to tightly; both are compared in the parity tests.
+    """
     feat_c0 = np.asarray(feat_c0, np.float32)
     feat_c1 = np.asarray(feat_c1, np.float32)
     C = feat_c0.shape[-1]
-    f0 = feat_c0 / np.float32(C ** .5)                                   # :104-105
-    f1 = feat_c1 / np.float32(C ** .5)
-    sim = np.einsum('nlc,nsc->nls', f0, f1) / np.float32(temperature)    # :108-109
+    f0 = (feat_c0 / np.float32(C ** .5)).astype(dtype)                   # :104-105
+    f1 = (feat_c1 / np.float32(C ** .5)).astype(dtype)
+    sim = np.einsum('nlc,nsc->nls', f0, f1) / dtype(np.float32(temperature))  # :108-109
     if mask_c0 is not None:                                               # :110-113
         valid = mask_c0[..., None].astype(bool) & mask_c1[:, None].astype(bool)
-        sim = np.where(valid, sim, np.float32(-INF))
-    return (_softmax(sim, 1) * _softmax(sim, 2)).astype(np.float32)      # :114
+        sim = np.where(valid, sim, dtype(-INF))
+    return (_softmax(sim, 1) * _softmax(sim, 2)).astype(dtype)           # :114
 
 
 def mask_border(m, b, v):
@@ -72,8 +79,8 @@ def get_coarse_match(conf, thr, border_rm, hw0_c, hw1_c, hw0_i, scale0=None, sca
 
 
 def coarse_matching(feat_c0, feat_c1, cfg, hw0_c, hw1_c, hw0_i, mask_c0=None, mask_c1=None,
-                    scale0=None, scale1=None):
-    conf = conf_matrix(feat_c0, feat_c1, cfg['dsmax_temperature'], mask_c0, mask_c1)
+                    scale0=None, scale1=None, dtype=np.float32):
+    conf = conf_matrix(feat_c0, feat_c1, cfg['dsmax_temperature'], mask_c0, mask_c1, dtype)
     out = get_coarse_match(conf, cfg['thr'], cfg['border_rm'], hw0_c, hw1_c, hw0_i, scale0, scale1)
     out['conf_matrix'] = conf
     return out

@@ -7,6 +7,7 @@ from tests.util import correlated_features
 
 pytestmark = pytest.mark.gpu
 
+ATOL64 = 1e-5
 CFG = dict(thr=0.2, border_rm=2, dsmax_temperature=0.1)
 
 
@@ -21,6 +22,7 @@ def _run(f0, f1, hw, want_conf, border=2, thr=0.2):
 def _check(f0, f1, hw, full_conf):
     from oracle import coarse as oc
     ref = oc.coarse_matching(f0, f1, CFG, hw, hw, (hw[0] * 8, hw[1] * 8))
+    ref64 = oc.coarse_matching(f0, f1, CFG, hw, hw, (hw[0] * 8, hw[1] * 8), dtype=np.float64)
     got = _run(f0, f1, hw, want_conf=full_conf)
     # indices are only well defined away from the discontinuities: require the margin on the oracle side
     rg, cg, tg = oc.margins(ref['conf_matrix'], CFG['thr'])
@@ -29,11 +31,18 @@ def _check(f0, f1, hw, full_conf):
     for k in ['b_ids', 'i_ids', 'j_ids']:
         assert got[k].dtype == torch.int64
         np.testing.assert_array_equal(got[k].cpu().numpy(), ref[k])
-    np.testing.assert_allclose(got['mconf'].cpu().numpy(), ref['mconf'], atol=1e-5, rtol=0)
+    # tolerance vs the fp32 restatement = the fp32 reference's own deviation from exact arithmetic
+    # (softmax swamping, see oracle/coarse.py); vs the float64 evaluation the kernel is held much tighter.
+    np.testing.assert_allclose(got['mconf'].cpu().numpy(), ref['mconf'], atol=2e-4, rtol=0)
+    np.testing.assert_array_equal(ref64['i_ids'], ref['i_ids'])
+    np.testing.assert_allclose(got['mconf'].cpu().numpy(), ref64['mconf'], atol=ATOL64, rtol=0)
     np.testing.assert_array_equal(got['mkpts0_c'].cpu().numpy(), ref['mkpts0_c'])
     np.testing.assert_array_equal(got['mkpts1_c'].cpu().numpy(), ref['mkpts1_c'])
     if full_conf:
-        np.testing.assert_allclose(got['conf_matrix'].cpu().numpy(), ref['conf_matrix'], atol=1e-5, rtol=0)
+        np.testing.assert_allclose(got['conf_matrix'].cpu().numpy(), ref['conf_matrix'], atol=2e-4, rtol=0)
+        err = np.abs(got['conf_matrix'].cpu().numpy() - ref64['conf_matrix']).max()
+        print('max |conf - float64 oracle| =', err)
+        assert err <= ATOL64
     return len(ref['b_ids'])
 
 
