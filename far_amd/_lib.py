@@ -14,6 +14,7 @@ c_i = ctypes.c_int
 c_f = ctypes.c_float
 c_d = ctypes.c_double
 c_sz = ctypes.c_size_t
+c_l = ctypes.c_long
 
 # name -> (restype, argtypes); must list every function declared in include/far_hip.h
 SIGNATURES = {
@@ -22,6 +23,11 @@ SIGNATURES = {
     'far_dual_softmax_stats_f32': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p]),
     'far_coarse_match_f32': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f,
                                    c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    'far_emm_pv_f32': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_p]),
+    'far_fine_gather_f32': (c_i, [c_p, c_l, c_l, c_l, c_l, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
+    'far_fine_expect_f32': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_f, c_p, c_p, c_p, c_p, c_p]),
+    'far_linear_attention_workspace_bytes': (c_sz, [c_i, c_i, c_i, c_i]),
+    'far_linear_attention_f32': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_p, c_p, c_p]),
 }
 
 _lib = None

@@ -81,3 +81,69 @@ def coarse_match(f0, f1, temperature, thr, border, hw0, hw1, cell_scale, mask0=N
         'b_ids': b_ids[:M], 'i_ids': i_ids[:M], 'j_ids': j_ids[:M], 'mconf': mconf[:M],
         'mkpts0_c': mk0[:M], 'mkpts1_c': mk1[:M], 'counts': counts_h[:Z], 'conf_matrix': conf,
     }
+
+
+def emm_bilinear(q, k, v, pos, scale):
+    """K2.  q, k, v: (Z, N, 64) fp32; pos: (N, 6).  Returns F (Z, 70, 70) = v~^T (P v~), v~ = [v | pos],
+    P = softmax(s, -1) * softmax(s, -2), s = (q k^T) * scale   (transformer.py:275-292)."""
+    lib = _lib.load()
+    Z, N, D = q.shape
+    rowstat, colstat = dual_softmax_stats(q, k, 1.0, 1.0, scale)
+    T = torch.empty(Z, N, 70, dtype=torch.float32, device=q.device)
+    rc = lib.far_emm_pv_f32(_p(q, torch.float32), _p(k, torch.float32), _p(v, torch.float32), _p(pos, torch.float32),
+                            Z, N, D, float(scale), _p(rowstat), _p(colstat), _p(T), _stream())
+    _lib.check(rc, 'far_emm_pv_f32')
+    vt = torch.cat([v, pos.unsqueeze(0).expand(Z, -1, -1)], dim=2)  # (Z, N, 70)
+    return torch.bmm(vt.transpose(1, 2), T), T
+
+
+def fine_gather(feat_f, b_ids, cell_ids, wc, W, stride):
+    """K3a.  feat_f: (N, C, Hf, Wf) fp32 in any strided layout (channels_last is the fast one).
+    Returns (M, W*W, C): the windows F.unfold would have produced at the matched cells."""
+    lib = _lib.load()
+    M = int(b_ids.shape[0])
+    N, C, Hf, Wf = feat_f.shape
+    out = torch.empty(M, W * W, C, dtype=torch.float32, device=feat_f.device)
+    if M == 0:
+        return out
+    if not feat_f.is_cuda or feat_f.dtype != torch.float32:
+        raise _lib.FarHipError('fine_gather needs an fp32 GPU feature map')
+    sn, sc, sh, sw = feat_f.stride()
+    rc = lib.far_fine_gather_f32(ctypes.c_void_p(feat_f.data_ptr()), sn, sc, sh, sw, C, Hf, Wf,
+                                 _p(b_ids, torch.int64), _p(cell_ids, torch.int64), int(wc), int(W), int(stride), M,
+                                 _p(out), _stream())
+    _lib.check(rc, 'far_fine_gather_f32')
+    return out
+
+
+def fine_expect(feat0, feat1, mkpts1_c, win_scale, scale1=None, b_ids=None):
+    """K3b.  feat0/feat1: (M, WW, C).  Returns expec_f (M, 3), mkpts1_f (M, 2)."""
+    lib = _lib.load()
+    M, WW, C = feat0.shape
+    W = int(round(WW ** 0.5))
+    expec = torch.empty(M, 3, dtype=torch.float32, device=feat0.device)
+    mk1 = torch.empty(M, 2, dtype=torch.float32, device=feat0.device)
+    if M == 0:
+        return expec, mk1
+    rc = lib.far_fine_expect_f32(_p(feat0, torch.float32), _p(feat1, torch.float32), M, W, C,
+                                 _p(mkpts1_c, torch.float32), float(win_scale), _p(scale1, torch.float32),
+                                 _p(b_ids, torch.int64), _p(expec), _p(mk1), _stream())
+    _lib.check(rc, 'far_fine_expect_f32')
+    return expec, mk1
+
+
+def linear_attention(q, k, v, nhead, q_mask=None, kv_mask=None, eps=1e-6):
+    """K5.  q: (N, L, C), k, v: (N, S, C) raw projections; returns (N, L, C) (heads concatenated)."""
+    lib = _lib.load()
+    N, L, C = q.shape
+    S = k.shape[1]
+    D = C // nhead
+    out = torch.empty(N, L, C, dtype=torch.float32, device=q.device)
+    if N == 0:
+        return out
+    ws = _ws(lib.far_linear_attention_workspace_bytes(N, S, nhead, D), q.device)
+    rc = lib.far_linear_attention_f32(_p(q, torch.float32), _p(k, torch.float32), _p(v, torch.float32), N, L, S,
+                                      nhead, D, _p(q_mask, torch.uint8), _p(kv_mask, torch.uint8), float(eps),
+                                      _p(out), _p(ws), _stream())
+    _lib.check(rc, 'far_linear_attention_f32')
+    return out

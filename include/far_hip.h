@@ -61,6 +61,50 @@ int far_coarse_match_f32(const float* f0, const float* f1, int Z, int L, int S, 
                          float* mkpts0_c, float* mkpts1_c, int* counts_out, int* total_out,
                          void* ws, far_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * K2  EMM head: bilinear dual-softmax attention  F = v~^T (softmax_row(s) * softmax_col(s)) v~
+ * replaces src/loftr/loftr_module/transformer.py:275-292 (CrossAttention.forward), one call per direction
+ * ------------------------------------------------------------------------------------------------- */
+
+/* T[z] = P[z] @ [v[z] | pos]  (Z, N, 70), P = softmax over keys * softmax over queries of s = (q k^T) * scale.
+ *   q, k, v [Z][N][64] fp32 contiguous (Z = pairs x heads); pos [N][6] fp32, shared (transformer.py:183-248)
+ *   rowstat/colstat [Z][N][2]: from far_dual_softmax_stats_f32(q, k, feat_div=1, sim_div=1, sim_mul=scale)
+ *   The caller finishes F[z] = [v|pos]^T T[z] (70 x N x 70) with a library GEMM. */
+int far_emm_pv_f32(const float* q, const float* k, const float* v, const float* pos, int Z, int N, int D,
+                   float scale, const float* rowstat, const float* colstat, float* T_out, far_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * K3  fine level: window gather + sub-pixel expectation
+ * replaces src/loftr/loftr_module/fine_preprocess.py:40-47 (F.unfold + [b_ids, i_ids] gather)
+ *      and src/loftr/utils/fine_matching.py:43-54, :64-76 (FineMatching.forward / get_fine_match)
+ * ------------------------------------------------------------------------------------------------- */
+
+/* out[m][ky*W+kx][c] = feat[b_ids[m]][c][y0*stride - W/2 + ky][x0*stride - W/2 + kx] (0 outside),
+ * (y0,x0) = divmod(cell_ids[m], wc).  feat is addressed with ELEMENT strides (sn,sc,sh,sw) so NCHW and
+ * channels_last maps both work; logical shape [*, C, Hf, Wf]; out [M][W*W][C].  M == 0 is a no-op. */
+int far_fine_gather_f32(const float* feat, long sn, long sc, long sh, long sw, int C, int Hf, int Wf,
+                        const int64_t* b_ids, const int64_t* cell_ids, int wc, int W, int stride, int M,
+                        float* out, far_stream_t stream);
+
+/* feat0/feat1 [M][W*W][C] (after the fine transformer).  expec_f [M][3] = (E[x], E[y], std) in normalised
+ * window coordinates; mkpts1_f [M][2] = mkpts1_c + E[xy] * win_scale (* scale1[b_ids[m]] when scale1 != NULL),
+ * win_scale = (W // 2) * (hw0_i[0] / hw0_f[0]). */
+int far_fine_expect_f32(const float* feat0, const float* feat1, int M, int W, int C, const float* mkpts1_c,
+                        float win_scale, const float* scale1, const int64_t* b_ids, float* expec_f,
+                        float* mkpts1_f, far_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * K5  linear attention core of LoFTREncoderLayer
+ * replaces src/loftr/loftr_module/linear_attention.py:31-50 (LinearAttention.forward)
+ * ------------------------------------------------------------------------------------------------- */
+size_t far_linear_attention_workspace_bytes(int N, int S, int H, int D);
+
+/* q [N][L][H*D], k, v [N][S][H*D] raw projections (the elu+1 feature map is applied inside);
+ * q_mask [N][L], kv_mask [N][S] optional uint8; eps = 1e-6; D in {16, 32}; out [N][L][H*D]. */
+int far_linear_attention_f32(const float* q, const float* k, const float* v, int N, int L, int S, int H, int D,
+                             const uint8_t* q_mask, const uint8_t* kv_mask, float eps, float* out, void* ws,
+                             far_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,34 @@
+"""K2 parity on the GPU: far_emm_pv_f32 (+ stats) through the C ABI vs oracle/head.py."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(Z, N, seed, qk_amp=2.0):
+    rng = np.random.default_rng(seed)
+    q = (qk_amp * rng.standard_normal((Z, N, 64))).astype(np.float32)
+    k = (qk_amp * rng.standard_normal((Z, N, 64))).astype(np.float32)
+    v = rng.standard_normal((Z, N, 64)).astype(np.float32)
+    pos = rng.uniform(-1, 1, (N, 6)).astype(np.float32)
+    pos[:, 5] = 1
+    return q, k, v, pos
+
+
+@pytest.mark.parametrize('Z,N', [(3, 192), (2, 221), (1, 4800)])
+def test_emm_bilinear(Z, N):
+    from far_amd import ops
+    from oracle import head as oh
+    q, k, v, pos = _inputs(Z, N, seed=N)
+    F, T = ops.emm_bilinear(*(torch.from_numpy(a).cuda() for a in (q, k, v, pos)), 0.125)
+    torch.cuda.synchronize()
+    vt = np.concatenate([v, np.broadcast_to(pos, (Z, N, 6))], axis=2)
+    Fref, A = oh.bilinear_attention(q, k, vt, 0.125, dtype=np.float64)
+    Tref = A @ vt.astype(np.float64)
+    np.testing.assert_allclose(T.cpu().numpy(), Tref, atol=2e-5 * np.abs(Tref).max(), rtol=1e-4)
+    # regression-logit tolerance of north_star is 1e-3 relative; hold the 70x70 blocks much tighter
+    np.testing.assert_allclose(F.cpu().numpy(), Fref, atol=1e-4 * np.abs(Fref).max(), rtol=1e-3)
+    F32, _ = oh.bilinear_attention(q, k, vt, 0.125, dtype=np.float32)
+    print('max|F - f64| / max|F| =', np.abs(F.cpu().numpy() - Fref).max() / np.abs(Fref).max(),
+          ' fp32-restatement vs f64:', np.abs(F32 - Fref).max() / np.abs(Fref).max())

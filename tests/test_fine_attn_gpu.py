@@ -1,0 +1,66 @@
+"""K3 / K5 parity on the GPU through the C ABI vs oracle/fine.py, oracle/attention.py."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('channels_last', [False, True])
+def test_fine_gather(channels_last):
+    from far_amd import ops
+    from oracle import fine as of
+    rng = np.random.default_rng(0)
+    N, C, Hf, Wf, wc = 2, 128, 48, 64, 16
+    feat = rng.standard_normal((N, C, Hf, Wf)).astype(np.float32)
+    M = 300
+    b = np.sort(rng.integers(0, N, M)).astype(np.int64)
+    cells = rng.integers(0, 12 * 16, M).astype(np.int64)
+    cells[:4] = [0, 15, 11 * 16, 12 * 16 - 1]  # corners: zero padding on two sides
+    t = torch.from_numpy(feat).cuda()
+    if channels_last:
+        t = t.contiguous(memory_format=torch.channels_last)
+    got = ops.fine_gather(t, torch.from_numpy(b).cuda(), torch.from_numpy(cells).cuda(), wc, 5, 4)
+    ref = of.unfold_windows(feat, b, cells, wc, 5, 4)
+    np.testing.assert_array_equal(got.cpu().numpy(), ref)  # a gather: bit exact
+    # and against torch's own unfold on the device (the op the reference calls)
+    unf = torch.nn.functional.unfold(torch.from_numpy(feat), (5, 5), stride=4, padding=2)
+    unf = unf.view(N, C, 25, -1).permute(0, 3, 2, 1)[torch.from_numpy(b), torch.from_numpy(cells)]
+    np.testing.assert_array_equal(got.cpu().numpy(), unf.numpy())
+
+
+def test_fine_gather_empty():
+    from far_amd import ops
+    t = torch.zeros(1, 128, 8, 8, device='cuda')
+    e = torch.zeros(0, dtype=torch.int64, device='cuda')
+    assert ops.fine_gather(t, e, e, 2, 5, 4).shape == (0, 25, 128)
+
+
+def test_fine_expect():
+    from far_amd import ops
+    from oracle import fine as of
+    rng = np.random.default_rng(1)
+    M, WW, C = 777, 25, 128
+    f0 = rng.standard_normal((M, WW, C)).astype(np.float32)
+    f1 = rng.standard_normal((M, WW, C)).astype(np.float32)
+    f1[:50] = f0[:50, 12:13, :] * (rng.random((50, WW, 1)) > 0.8)  # peaked heatmaps
+    mk = (rng.integers(0, 80, (M, 2)) * 8).astype(np.float32)
+    expec, mk1 = ops.fine_expect(*(torch.from_numpy(a).cuda() for a in (f0, f1, mk)), 4.0)
+    e64, m64 = of.fine_matching(f0, f1, mk, 4.0, dtype=np.float64)
+    e32, m32 = of.fine_matching(f0, f1, mk, 4.0, dtype=np.float32)
+    np.testing.assert_allclose(expec.cpu().numpy(), e64, atol=2e-5, rtol=0)
+    np.testing.assert_allclose(mk1.cpu().numpy(), m64, atol=1e-4, rtol=0)
+    np.testing.assert_allclose(expec.cpu().numpy(), e32, atol=1e-4, rtol=0)
+
+
+@pytest.mark.parametrize('N,L,S,C', [(2, 4800, 4800, 256), (3, 100, 333, 256), (700, 25, 25, 128)])
+def test_linear_attention(N, L, S, C):
+    from far_amd import ops
+    from oracle import attention as oa
+    rng = np.random.default_rng(2)
+    q = rng.standard_normal((N, L, C)).astype(np.float32)
+    k = rng.standard_normal((N, S, C)).astype(np.float32)
+    v = rng.standard_normal((N, S, C)).astype(np.float32)
+    got = ops.linear_attention(*(torch.from_numpy(a).cuda() for a in (q, k, v)), 8).cpu().numpy()
+    ref = oa.linear_attention(q, k, v, 8, dtype=np.float64)
+    np.testing.assert_allclose(got, ref, atol=1e-5 * np.abs(ref).max(), rtol=1e-4)
