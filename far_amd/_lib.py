@@ -15,6 +15,7 @@ c_f = ctypes.c_float
 c_d = ctypes.c_double
 c_sz = ctypes.c_size_t
 c_l = ctypes.c_long
+c_u32 = ctypes.c_uint32
 
 # name -> (restype, argtypes); must list every function declared in include/far_hip.h
 SIGNATURES = {
@@ -28,6 +29,9 @@ SIGNATURES = {
     'far_fine_expect_f32': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_f, c_p, c_p, c_p, c_p, c_p]),
     'far_linear_attention_workspace_bytes': (c_sz, [c_i, c_i, c_i, c_i]),
     'far_linear_attention_f32': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_p, c_p, c_p]),
+    'far_solver_workspace_bytes': (c_sz, [c_i, c_i, c_i, c_i]),
+    'far_solver_f64': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_d, c_i, c_u32, c_p]
+                       + [c_p] * 14 + [c_p, c_p]),
 }
 
 _lib = None

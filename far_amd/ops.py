@@ -147,3 +147,43 @@ def linear_attention(q, k, v, nhead, q_mask=None, kv_mask=None, eps=1e-6):
                                       _p(out), _p(ws), _stream())
     _lib.check(rc, 'far_linear_attention_f32')
     return out
+
+
+def solve_pose_batch(kpts0, kpts1, offsets_host, K0, K1, inl_th, many_thr, priorRT=None, pcl=None,
+                     prior_lambda=0.3, H=2048, seed=0, samples=None, debug=False):
+    """K4.  kpts0/kpts1: (Mtot, 2) fp32 GPU; offsets_host: python list / CPU int tensor of B+1 offsets;
+    K0/K1: (B, 3, 3) float64 GPU; inl_th: (B,) float64 GPU; priorRT: (B, 3, 4) fp32 GPU or None.
+    Returns a dict of GPU tensors (R, t, E float64; mask uint8; status/num_after/tight/ultra/n_cheir/best int32)."""
+    lib = _lib.load()
+    dev = K0.device
+    offs = torch.as_tensor(offsets_host, dtype=torch.int32)
+    B = offs.numel() - 1
+    Mtot = int(offs[-1])
+    Mmax = int((offs[1:] - offs[:-1]).max()) if B > 0 else 0
+    offs_d = offs.to(dev)
+    P = 0 if pcl is None else int(pcl.shape[0])
+    ws = _ws(lib.far_solver_workspace_bytes(B, Mtot, H, P), dev)
+    f64, i32 = torch.float64, torch.int32
+    out = {
+        'R': torch.empty(B, 3, 3, dtype=f64, device=dev), 't': torch.empty(B, 3, dtype=f64, device=dev),
+        'E': torch.empty(B, 3, 3, dtype=f64, device=dev), 'mask': torch.empty(Mtot, dtype=torch.uint8, device=dev),
+        'status': torch.empty(B, dtype=i32, device=dev), 'num_after': torch.empty(B, dtype=i32, device=dev),
+        'tight': torch.empty(B, dtype=i32, device=dev), 'ultra': torch.empty(B, dtype=i32, device=dev),
+        'n_cheir': torch.empty(B, dtype=i32, device=dev), 'best': torch.empty(B, dtype=i32, device=dev),
+    }
+    dbg = {}
+    if debug:
+        dbg = {'F_all': torch.empty(B, H, 3, 3, dtype=f64, device=dev), 'count_all': torch.empty(B, H, dtype=i32, device=dev),
+               'score_all': torch.empty(B, H, dtype=f64, device=dev), 'samples': torch.empty(B, H, 8, dtype=i32, device=dev)}
+    rc = lib.far_solver_f64(
+        _p(kpts0, torch.float32) if Mtot else ctypes.c_void_p(0), _p(kpts1, torch.float32) if Mtot else ctypes.c_void_p(0),
+        _p(offs_d), B, Mtot, Mmax, _p(K0.contiguous(), f64), _p(K1.contiguous(), f64), _p(inl_th, f64), int(bool(many_thr)),
+        _p(priorRT, torch.float32), _p(pcl, torch.float32), P, float(prior_lambda), int(H), int(seed) & 0xffffffff,
+        _p(samples, torch.int32),
+        _p(out['R']), _p(out['t']), _p(out['E']), _p(out['mask']), _p(out['status']), _p(out['num_after']),
+        _p(out['tight']), _p(out['ultra']), _p(out['n_cheir']), _p(out['best']),
+        _p(dbg.get('F_all')), _p(dbg.get('count_all')), _p(dbg.get('score_all')), _p(dbg.get('samples')),
+        _p(ws), _stream())
+    _lib.check(rc, 'far_solver_f64')
+    out.update(dbg)
+    return out

@@ -105,6 +105,37 @@ int far_linear_attention_f32(const float* q, const float* k, const float* v, int
                              const uint8_t* q_mask, const uint8_t* kv_mask, float eps, float* out, void* ws,
                              far_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * K4  batched essential-matrix solver (hypothesise / verify / decompose / cheirality), float64
+ * replaces src/utils/metrics.py:80-174 (estimate_pose), third_party/prior_ransac/ransac.py:340-442
+ *      (RANSAC.forward + verify + get_prior_estimate), cv_geometry.py:713-833 (run_8point),
+ *      essential.py:99-139 (decompose_essential_matrix), cv::recoverPose (src/utils/cv2_fcns.py:147-319)
+ * ------------------------------------------------------------------------------------------------- */
+size_t far_solver_workspace_bytes(int B, int Mtot, int H, int P);
+
+/* B pairs; pair b owns correspondences [offsets[b], offsets[b+1]) of the concatenated arrays.
+ *   kpts0, kpts1  [Mtot][2] fp32 pixel coordinates (mkpts0_f / mkpts1_f); offsets [B+1] int32; Mmax = max count
+ *   K0, K1        [B][9] float64 row-major intrinsics
+ *   inl_th        [B] float64: squared-Sampson inlier threshold in normalised coordinates
+ *                 (3e-7 for prior_ransac: metrics.py:117; (thresh/mean f)^2 for the plain RANSAC branch: :94)
+ *   many_thr      != 0: also count inliers at inl_th/10 and /100 (ransac.py:284-287)
+ *   priorRT       optional [B][12] fp32 (3x4 row-major): enables biased sampling (ransac.py:358-371) and the
+ *                 prior score -err^2/prior_lambda over the P-point cloud pcl [P][3] fp32 (ransac.py:203-231,:397)
+ *   H, seed       hypotheses per pair and sampling seed; samples_in optional [B][H][8] int32 overrides sampling
+ * outputs (all device): R_out [B][9], t_out [B][3], E_out [B][9] float64; mask_out [Mtot] uint8 (inliers that
+ *   also pass cheirality, as cv2.recoverPose leaves its in/out mask); status_out [B] (1 = pose valid, 0 = the
+ *   reference's `ret is None`); num_after_out, n_tight_out, n_ultra_out, n_cheir_out, best_out [B] int32.
+ *   Optional debug outputs (NULL to skip): F_all_out [B][H][9], count_all_out [B][H], score_all_out [B][H],
+ *   samples_out [B][H][8]. */
+int far_solver_f64(const float* kpts0, const float* kpts1, const int* offsets, int B, int Mtot, int Mmax,
+                   const double* K0, const double* K1, const double* inl_th, int many_thr,
+                   const float* priorRT, const float* pcl, int P, double prior_lambda,
+                   int H, uint32_t seed, const int* samples_in,
+                   double* R_out, double* t_out, double* E_out, uint8_t* mask_out, int* status_out,
+                   int* num_after_out, int* n_tight_out, int* n_ultra_out, int* n_cheir_out, int* best_out,
+                   double* F_all_out, int* count_all_out, double* score_all_out, int* samples_out,
+                   void* ws, far_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,321 @@
+"""Oracle for K4: the batched essential-matrix solver (test infrastructure only, see oracle/__init__.py).
+
+What it restates (citations relative to mp3d_loftr/):
+  estimate_pose dispatch / normalisation / threshold     src/utils/metrics.py:80-174
+  batched hypothesise-and-verify with pose prior          third_party/prior_ransac/ransac.py:340-442
+      bias weights :358-371, prior score :203-231 + :395-400, verify :256-292, remove_bad_models :303-308
+  normalized 8-point                                      third_party/prior_ransac/cv_geometry.py:713-833
+  E decomposition                                         third_party/prior_ransac/essential.py:99-139
+  cheirality = cv::recoverPose                            C++ quoted in src/utils/cv2_fcns.py:147-319
+
+Arithmetic type: float64 on the reference's float32 inputs.  The reference runs this path in float32
+(torch) / float64 (OpenCV); the GPU kernels run it in float64 so that inlier masks are reproducible
+bit-for-bit; the float32 reference agrees with this file to its own round-off (tests/test_oracle_solver.py,
+golden vectors from the reference's run_8point / decompose_essential_matrix / RANSAC.verify).
+
+Deliberate, documented differences from what the reference EXECUTES:
+  * minimal solver = the reference's own normalized 8-point `run_8point` on 8-point samples, in place of
+    OpenCV's 5-point (`run_5point_cv2`, cv2 absent and not reproducible);
+  * sampling uses a counter-based integer hash (sample_indices below) instead of numpy's MT19937 /
+    torch.rand: same distributions (uniform without replacement; biased with replacement), own stream;
+  * hypotheses whose sample repeats a correspondence are rejected (see estimate_pose);
+  * where the reference's result depends on LAPACK's arbitrary singular-vector signs (which two of the
+    four (R, t) candidates enter the prior score, essential.py:116-139 + ransac.py:213-229), a fixed
+    convention is used: the right null vector of E has its largest-magnitude component positive.
+PARITY UNPINNED pieces (third-party, absent): kornia sampson/symmetrical epipolar distance, cv2.recoverPose,
+cv2.triangulatePoints -- restated from published definitions / the quoted C++.
+"""
+import numpy as np
+
+U32 = np.uint32
+
+
+# ----------------------------------------------------------------------------------------------------
+# sampling (own definition, mirrored bit-for-bit by far_amd/csrc/solver_f64.hip)
+# ----------------------------------------------------------------------------------------------------
+def mix32(x):
+    x = np.asarray(x, dtype=np.uint32)
+    with np.errstate(over='ignore'):
+        x = x ^ (x >> U32(16))
+        x = x * U32(0x7feb352d)
+        x = x ^ (x >> U32(15))
+        x = x * U32(0x846ca68b)
+        x = x ^ (x >> U32(16))
+    return x
+
+
+def hash_u32(seed, b, h, s):
+    with np.errstate(over='ignore'):
+        key = mix32(U32(seed) ^ np.asarray(b, np.uint32))
+        key = mix32(key + np.asarray(h, np.uint32) * U32(0x9E3779B1))
+        return mix32(key + np.asarray(s, np.uint32) * U32(0x85EBCA77))
+
+
+def quantize_weights(w):
+    """Bias weights -> integers (so the CDF is order-independent): floor((w + 1e-4) * 2^16), at least 1."""
+    q = np.floor((np.asarray(w, np.float64) + 1e-4) * 65536.0)
+    return np.maximum(q, 1).astype(np.uint32)
+
+
+def sample_indices(seed, b, H, M, ss=8, wq=None):
+    """(H, ss) int32 sample indices for pair b.
+
+    wq None: uniform WITHOUT replacement (reference: rand.topk, ransac.py:173-174).
+    wq (M,) uint32: weighted WITH replacement by integer CDF (reference: np.random.choice(p=w), :169)."""
+    h = np.arange(H, dtype=np.uint32)[:, None]
+    s = np.arange(ss, dtype=np.uint32)[None, :]
+    u = hash_u32(seed, b, h, s)                         # (H, ss)
+    if wq is not None:
+        cdf = np.cumsum(wq.astype(np.uint64)).astype(np.uint64)
+        r = u.astype(np.uint64) % cdf[-1]
+        return np.searchsorted(cdf, r, side='right').astype(np.int32)
+    out = np.zeros((H, ss), np.int32)
+    for k in range(ss):
+        if M - k <= 0:
+            out[:, k] = 0
+            continue
+        r = (u[:, k] % U32(M - k)).astype(np.int32)
+        # map rank r among the not-yet-chosen indices: add 1 for every previously chosen index <= current
+        prev = np.sort(out[:, :k], axis=1)
+        for j in range(k):
+            r = r + (prev[:, j] <= r)
+        out[:, k] = r
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------
+# geometry helpers
+# ----------------------------------------------------------------------------------------------------
+def cross_matrix(t):
+    t = np.asarray(t, np.float64)
+    z = np.zeros_like(t[..., 0])
+    return np.stack([z, -t[..., 2], t[..., 1], t[..., 2], z, -t[..., 0], -t[..., 1], t[..., 0], z],
+                    -1).reshape(t.shape[:-1] + (3, 3))
+
+
+def _h(p):
+    return np.concatenate([p, np.ones(p.shape[:-1] + (1,), p.dtype)], -1)
+
+
+def sampson_distance(p1, p2, F):
+    """kornia sampson_epipolar_distance(squared=True).  p (M,2); F (...,3,3) -> (..., M)."""
+    x1, x2 = _h(np.asarray(p1, np.float64)), _h(np.asarray(p2, np.float64))
+    l1 = x1 @ np.swapaxes(F, -1, -2)          # F x1
+    l2 = x2 @ F                               # F^T x2
+    num = (x2 * l1).sum(-1) ** 2
+    den = l1[..., 0] ** 2 + l1[..., 1] ** 2 + l2[..., 0] ** 2 + l2[..., 1] ** 2
+    with np.errstate(divide='ignore', invalid='ignore'):
+        return num / den
+
+
+def symmetric_epipolar_distance(p1, p2, F):
+    """kornia symmetrical_epipolar_distance(squared=True)."""
+    x1, x2 = _h(np.asarray(p1, np.float64)), _h(np.asarray(p2, np.float64))
+    l1 = x1 @ np.swapaxes(F, -1, -2)
+    l2 = x2 @ F
+    num = (x2 * l1).sum(-1) ** 2
+    with np.errstate(divide='ignore', invalid='ignore'):
+        inv = 1.0 / (l1[..., 0] ** 2 + l1[..., 1] ** 2) + 1.0 / (l2[..., 0] ** 2 + l2[..., 1] ** 2)
+        return num * inv
+
+
+def normalize_points(p, eps=1e-8):
+    """cv_geometry.py:713-750.  p (B,N,2) -> (p_norm (B,N,2), T (B,3,3))."""
+    mean = p.mean(1, keepdims=True)
+    scale = np.sqrt(((p - mean) ** 2).sum(-1)).mean(-1)
+    scale = np.sqrt(2.0) / (scale + eps)
+    T = np.zeros((p.shape[0], 3, 3))
+    T[:, 0, 0] = scale
+    T[:, 1, 1] = scale
+    T[:, 0, 2] = -scale * mean[:, 0, 0]
+    T[:, 1, 2] = -scale * mean[:, 0, 1]
+    T[:, 2, 2] = 1
+    pn = p * scale[:, None, None] + T[:, None, :2, 2]
+    return pn, T
+
+
+def run_8point(p1, p2):
+    """cv_geometry.py:772-833 with unit weights.  p (B,N>=8,2) float -> F (B,3,3)."""
+    p1 = np.asarray(p1, np.float64)
+    p2 = np.asarray(p2, np.float64)
+    n1, T1 = normalize_points(p1)
+    n2, T2 = normalize_points(p2)
+    x1, y1 = n1[..., 0:1], n1[..., 1:2]
+    x2, y2 = n2[..., 0:1], n2[..., 1:2]
+    X = np.concatenate([x2 * x1, x2 * y1, x2, y2 * x1, y2 * y1, y2, x1, y1, np.ones_like(x1)], -1)   # :810
+    A = np.swapaxes(X, -1, -2) @ X                                                                    # :814
+    _, _, Vh = np.linalg.svd(A)                                                                       # :820
+    Fm = Vh[:, -1, :].reshape(-1, 3, 3)                                                               # :821
+    U, S, Vh2 = np.linalg.svd(Fm)                                                                     # :824
+    S = S * np.array([1.0, 1.0, 0.0])
+    Fp = U @ (S[:, :, None] * Vh2)                                                                    # :827
+    Fe = np.swapaxes(T2, -1, -2) @ (Fp @ T1)                                                          # :828
+    nv = Fe[:, 2:3, 2:3]                                                                              # :753-769
+    with np.errstate(divide='ignore', invalid='ignore'):
+        return np.where(np.abs(nv) > 1e-8, Fe / (nv + 1e-8), Fe)
+
+
+def decompose_essential(E):
+    """essential.py:99-139 with the fixed sign convention of this build.  E (...,3,3) -> R1, R2, t(...,3)."""
+    E = np.asarray(E, np.float64)
+    shp = E.shape[:-2]
+    E2 = E.reshape(-1, 3, 3)
+    _, S, Vh = np.linalg.svd(E2)
+    V = np.swapaxes(Vh, -1, -2).copy()
+    # convention: null vector v3 has its largest-|component| positive; (v1, v2, v3) right-handed
+    v3 = V[:, :, 2]
+    k = np.abs(v3).argmax(1)
+    sgn = np.sign(v3[np.arange(len(v3)), k])
+    sgn[sgn == 0] = 1
+    V[:, :, 2] *= sgn[:, None]
+    detV = np.linalg.det(V)
+    V[:, :, 0] *= np.where(detV < 0, -1.0, 1.0)[:, None]
+    with np.errstate(divide='ignore', invalid='ignore'):
+        u1 = (E2 @ V[:, :, 0:1])[..., 0]
+        u1 = u1 / np.linalg.norm(u1, axis=-1, keepdims=True)
+        u2 = (E2 @ V[:, :, 1:2])[..., 0]
+        u2 = u2 / np.linalg.norm(u2, axis=-1, keepdims=True)
+    u3 = np.cross(u1, u2)
+    U = np.stack([u1, u2, u3], -1)
+    W = np.array([[0., -1., 0.], [1., 0., 0.], [0., 0., 1.]])
+    R1 = U @ W @ np.swapaxes(V, -1, -2)
+    R2 = U @ W.T @ np.swapaxes(V, -1, -2)
+    return R1.reshape(shp + (3, 3)), R2.reshape(shp + (3, 3)), u3.reshape(shp + (3,))
+
+
+def prior_E(RT):
+    """ransac.py:63-71 (returns E) after setup_prior's in-place t normalisation (:183).  RT (3,4)."""
+    RT = np.asarray(RT, np.float32).astype(np.float64)       # torch.FloatTensor(priorRT), metrics.py:109
+    t = RT[:, 3] / np.linalg.norm(RT[:, 3])
+    return cross_matrix(t) @ RT[:, :3], np.concatenate([RT[:, :3], t[:, None]], 1)
+
+
+def prior_score(F, RTn, pcl, lam=0.3):
+    """ransac.py:203-231 + :395-398 (use_noexp_prior_scoring).  F (H,3,3); RTn (3,4) normalised prior."""
+    R1, R2, t = decompose_essential(F)
+    tgt = pcl @ RTn[:, :3].T + RTn[:, 3]                                   # (P,3)
+    def err(R):
+        x = np.einsum('hij,pj->hpi', R, pcl) + t[:, None, :]
+        return np.abs(x - tgt[None]).reshape(len(F), -1).mean(1)
+    e = np.minimum(err(R1), err(R2))
+    return -e ** 2 / lam
+
+
+# ----------------------------------------------------------------------------------------------------
+# cheirality (cv::recoverPose)
+# ----------------------------------------------------------------------------------------------------
+def triangulate(P0, P1, x0, x1):
+    """cv::triangulatePoints: per point, the right singular vector of the 4x4 DLT matrix for the smallest
+    singular value.  P (3,4); x (M,2) -> (M,4) homogeneous (sign arbitrary, only sign-free tests follow)."""
+    M = len(x0)
+    A = np.empty((M, 4, 4))
+    A[:, 0] = x0[:, 0:1] * P0[2] - P0[0]
+    A[:, 1] = x0[:, 1:2] * P0[2] - P0[1]
+    A[:, 2] = x1[:, 0:1] * P1[2] - P1[0]
+    A[:, 3] = x1[:, 1:2] * P1[2] - P1[1]
+    _, _, Vh = np.linalg.svd(A)
+    return Vh[:, 3, :]
+
+
+def recover_pose(E, x0, x1, mask, dist=1e9):
+    """cv2_fcns.py:147-319 with K = I.  x (M,2) float64 normalised; mask (M,) bool.
+    Returns n, R (3,3), t (3,), mask_out (M,) bool."""
+    R1, R2, t = decompose_essential(E)
+    P0 = np.eye(3, 4)
+    cands = [(R1, t), (R2, t), (R1, -t), (R2, -t)]
+    masks = []
+    for R, tt in cands:
+        P = np.concatenate([R, tt[:, None]], 1)
+        Q = triangulate(P0, P, x0, x1)
+        with np.errstate(divide='ignore', invalid='ignore'):
+            m = (Q[:, 2] * Q[:, 3]) > 0
+            Qn = Q / Q[:, 3:4]
+            m &= Qn[:, 2] < dist
+            Q2 = Qn @ P.T
+            m &= Q2[:, 2] > 0
+            m &= Q2[:, 2] < dist
+        masks.append(m & mask)
+    good = [int(m.sum()) for m in masks]
+    g1, g2, g3, g4 = good
+    if g1 >= g2 and g1 >= g3 and g1 >= g4:
+        c = 0
+    elif g2 >= g1 and g2 >= g3 and g2 >= g4:
+        c = 1
+    elif g3 >= g1 and g3 >= g2 and g3 >= g4:
+        c = 2
+    else:
+        c = 3
+    return good[c], cands[c][0], cands[c][1], masks[c]
+
+
+# ----------------------------------------------------------------------------------------------------
+# the solver behind estimate_pose
+# ----------------------------------------------------------------------------------------------------
+def normalize_keypoints(kpts0, kpts1, K0, K1):
+    """metrics.py:88-89: float32 pixels, float64 intrinsics -> float64 normalised coordinates."""
+    k0 = (np.asarray(kpts0, np.float32).astype(np.float64) - K0[[0, 1], [2, 2]][None]) / K0[[0, 1], [0, 1]][None]
+    k1 = (np.asarray(kpts1, np.float32).astype(np.float64) - K1[[0, 1], [2, 2]][None]) / K1[[0, 1], [0, 1]][None]
+    return k0, k1
+
+
+def estimate_pose(kpts0, kpts1, K0, K1, thresh, solver='ransac', priorRT=None, seed=0, pair=0, H=2048,
+                  pcl=None, samples=None):
+    """Mirror of metrics.py:80-174.  Returns (ret, num_after, inl_tight, inl_ultra, debug) where
+    ret = None | (R (3,3), t (3,), mask (M,) bool, E (3,3))."""
+    M = len(kpts0)
+    if M < 5:                                                        # :83-85
+        return None, 0, 0, 0, {}
+    K0 = np.asarray(K0, np.float64)
+    K1 = np.asarray(K1, np.float64)
+    kn0, kn1 = normalize_keypoints(kpts0, kpts1, K0, K1)
+    ransac_thr = thresh / np.mean([K0[0, 0], K1[1, 1], K0[0, 0], K1[1, 1]])   # :94
+    kp1 = kn0.astype(np.float32).astype(np.float64)                  # torch.FloatTensor(kpts0_norm) :124-125
+    kp2 = kn1.astype(np.float32).astype(np.float64)
+    use_prior = solver == 'prior_ransac' and priorRT is not None     # :100
+    many_thr = use_prior or solver == 'prior_ransac_noprior'
+    inl_th = 3e-7 if many_thr else ransac_thr ** 2                   # :117 / cv2 RANSAC squared Sampson thr
+    wq = None
+    RTn = None
+    if use_prior:
+        Ep, RTn = prior_E(priorRT)
+        d = symmetric_epipolar_distance(kp1, kp2, Ep)                # ransac.py:364
+        w = np.exp(-d / 0.1)                                         # :366 (bias_sigma_sq = 0.1)
+        w = np.where(np.isfinite(w), w, 0.0)
+        wq = quantize_weights(w)
+    if samples is None:
+        if M < 8:
+            return None, 0, 0, 0, {}
+        samples = sample_indices(seed, pair, H, M, 8, wq)
+    F = run_8point(kp1[samples], kp2[samples])                       # (H,3,3)
+    diag = np.abs(np.stack([F[:, 0, 0], F[:, 1, 1], F[:, 2, 2]], 1))
+    valid = np.nan_to_num(diag, nan=0.0).min(1) > 1e-4               # ransac.py:306-307
+    valid &= np.isfinite(F).all((1, 2))
+    # a sample that repeats a correspondence (possible under biased sampling WITH replacement, ransac.py:169-171)
+    # gives a rank-deficient system whose "null vector" is an arbitrary member of a >=2-dim null space (LAPACK
+    # dependent in the reference): rejected here so that the result is well defined.
+    ssort = np.sort(samples, axis=1)
+    valid &= ~(ssort[:, 1:] == ssort[:, :-1]).any(1)
+    err = sampson_distance(kp1, kp2, F)                              # (H,M)  ransac.py:273-276
+    count = (err <= inl_th).sum(1)
+    score = count.astype(np.float64)
+    if use_prior:
+        if pcl is None:
+            raise ValueError('prior mode needs the 300-point cloud')
+        ps = prior_score(np.where(valid[:, None, None], F, np.eye(3)), RTn, np.asarray(pcl, np.float64))
+        score = score + ps
+    score = np.where(valid, score, -np.inf)
+    dbg = {'samples': samples, 'F': F, 'valid': valid, 'count': count, 'score': score, 'wq': wq}
+    if not valid.any():
+        return None, 0, 0, 0, dbg
+    best = int(np.argmax(score))                                     # first max
+    dbg['best'] = best
+    if not score[best] > 8.0:                                        # ransac.py:409 (best_score_total init)
+        return None, 0, 0, 0, dbg
+    E = F[best]
+    mask = err[best] <= inl_th
+    tight = int((err[best] <= inl_th / 10.0).sum()) if many_thr else 0       # :284-287, metrics.py:96,129
+    ultra = int((err[best] <= inl_th / 100.0).sum()) if many_thr else 0
+    n, R, t, mask2 = recover_pose(E, kn0, kn1, mask)                 # metrics.py:164-165
+    if n <= 0:                                                       # :166
+        return None, int(mask2.sum()), tight, ultra, dbg
+    return (R, t, mask2, E), int(mask2.sum()), tight, ultra, dbg

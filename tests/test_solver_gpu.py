@@ -1,0 +1,103 @@
+"""K4 parity on the GPU: far_solver_f64 through the C ABI vs oracle/solver.py (float64, bit-exact masks)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import two_view_scene
+
+pytestmark = pytest.mark.gpu
+
+H = 512
+
+
+def _run(scenes, mode, priors=None, pcl=None, seed=11, H=H, samples=None, thresh=0.5):
+    from far_amd import ops
+    k0 = np.concatenate([s[0] for s in scenes])
+    k1 = np.concatenate([s[1] for s in scenes])
+    offs = np.concatenate([[0], np.cumsum([len(s[0]) for s in scenes])]).astype(np.int32)
+    K = np.stack([s[2] for s in scenes])
+    many = mode != 'ransac'
+    thr = np.array([3e-7 if many else (thresh / np.mean([k[0, 0], k[1, 1], k[0, 0], k[1, 1]])) ** 2 for k in K])
+    cu = lambda a, dt=None: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    out = ops.solve_pose_batch(cu(k0), cu(k1), offs, cu(K), cu(K), cu(thr), many,
+                               priorRT=cu(priors.astype(np.float32)) if priors is not None else None,
+                               pcl=cu(pcl), H=H, seed=seed, samples=cu(samples), debug=True)
+    torch.cuda.synchronize()
+    return {k: v.cpu().numpy() for k, v in out.items()}, offs
+
+
+def _compare(scenes, mode, priors=None, pcl=None, seed=11):
+    from oracle import solver as osv
+    got, offs = _run(scenes, mode, priors, pcl, seed)
+    for b, (k0, k1, K, Rgt, tgt) in enumerate(scenes):
+        pr = None if priors is None else priors[b]
+        solver = {'ransac': 'ransac', 'prior': 'prior_ransac', 'noprior': 'prior_ransac_noprior'}[mode]
+        ret, nafter, tight, ultra, dbg = osv.estimate_pose(k0, k1, K, K, 0.5, solver=solver, priorRT=pr, seed=seed,
+                                                            pair=b, H=H, pcl=pcl)
+        np.testing.assert_array_equal(got['samples'][b], dbg['samples'])          # integer path: bit exact
+        v = dbg['valid']
+        # well-conditioned hypotheses agree to float64 round-off; judge on the Sampson counts, which is what
+        # the selection consumes, and on F for the winning model
+        same = got['count_all'][b][v] == dbg['count'][v]
+        assert same.mean() > 0.995, same.mean()
+        assert np.all(np.isinf(got['score_all'][b][~v]))
+        assert got['best'][b] == dbg['best']
+        np.testing.assert_allclose(got['E'][b], dbg['F'][dbg['best']], rtol=1e-7, atol=1e-9)
+        sl = slice(offs[b], offs[b + 1])
+        assert (ret is not None) == bool(got['status'][b])
+        if ret is not None:
+            R, t, mask, E = ret
+            np.testing.assert_array_equal(got['mask'][sl].astype(bool), mask)      # inlier mask: bit exact
+            assert np.linalg.norm(got['R'][b] - R) < 1e-8 and np.linalg.norm(got['t'][b] - t) < 1e-8
+            # and it is a sane pose
+            assert np.linalg.norm(R - Rgt) < 0.05, np.linalg.norm(R - Rgt)
+            assert min(np.linalg.norm(t - tgt), np.linalg.norm(t + tgt)) < 0.15
+        assert got['num_after'][b] == nafter and got['tight'][b] == tight and got['ultra'][b] == ultra
+
+
+def test_ransac_branch():
+    scenes = [two_view_scene(M, seed=s) for s, M in enumerate([300, 1000, 64, 2000])]
+    _compare(scenes, 'ransac')
+
+
+def test_noprior_branch():
+    scenes = [two_view_scene(M, seed=10 + s, outlier_frac=0.5) for s, M in enumerate([500, 800])]
+    _compare(scenes, 'noprior')
+
+
+def test_prior_branch():
+    rng = np.random.default_rng(0)                                     # metrics.py:103 (np.random.seed(0) upstream)
+    pcl = rng.uniform(-3.0, 3.0, (300, 3)).astype(np.float32)
+    scenes = [two_view_scene(M, seed=20 + s, outlier_frac=0.4) for s, M in enumerate([400, 1200, 900])]
+    priors = []
+    for (_, _, _, R, t) in scenes:
+        d = 0.05 * rng.standard_normal(3)
+        Rn = R @ (np.eye(3) + np.array([[0, -d[2], d[1]], [d[2], 0, -d[0]], [-d[1], d[0], 0]]))
+        priors.append(np.concatenate([Rn, (2.5 * t + 0.05 * rng.standard_normal(3))[:, None]], 1))
+    _compare(scenes, 'prior', np.stack(priors), pcl)
+
+
+def test_degenerate_inputs():
+    # fewer than 8 correspondences and an empty pair: status 0, nothing crashes (metrics.py:83-85 analogue)
+    s_ok = two_view_scene(200, seed=3)
+    s_few = tuple(a[:6] if i < 2 else a for i, a in enumerate(two_view_scene(50, seed=4)))
+    s_none = tuple(a[:0] if i < 2 else a for i, a in enumerate(two_view_scene(50, seed=5)))
+    got, offs = _run([s_few, s_ok, s_none], 'ransac')
+    assert list(got['status']) == [0, 1, 0]
+    assert got['num_after'][0] == 0 and got['num_after'][2] == 0
+    assert got['mask'][offs[0]:offs[1]].sum() == 0
+
+
+def test_explicit_samples_match_reference_style_call():
+    # same hypothesis index sets fed to both sides (the protocol for parity with run_8point)
+    from oracle import solver as osv
+    sc = two_view_scene(700, seed=33, outlier_frac=0.2)
+    rng = np.random.default_rng(1)
+    samples = np.stack([rng.choice(len(sc[0]), 8, replace=False) for _ in range(H)]).astype(np.int32)
+    got, _ = _run([sc], 'noprior', samples=samples[None])
+    kn0, kn1 = osv.normalize_keypoints(sc[0], sc[1], sc[2], sc[2])
+    kp1 = kn0.astype(np.float32).astype(np.float64)
+    kp2 = kn1.astype(np.float32).astype(np.float64)
+    F = osv.run_8point(kp1[samples], kp2[samples])
+    err = np.abs(got['F_all'][0] - F).reshape(H, -1).max(1) / np.abs(F).reshape(H, -1).max(1)
+    assert np.median(err) < 1e-10 and (err < 1e-6).mean() > 0.97, (np.median(err), (err < 1e-6).mean())

@@ -19,3 +19,35 @@ def correlated_features(N, hw, C, seed=0, amp=1.2, noise=0.1, frac=1.0):
             f1[n][bad] = (amp * rng.standard_normal((k, C))).astype(np.float32)
     f1 = (f1 + noise * rng.standard_normal(f1.shape)).astype(np.float32)
     return f0, f1, perms
+
+
+def two_view_scene(M, seed=0, outlier_frac=0.3, noise_px=0.3, K=None):
+    """Synthetic calibrated two-view correspondences (pixels, float32) with ground-truth pose.
+    Returns kpts0, kpts1 (M,2) float32, K (3,3) float64, R_gt, t_gt (unit)."""
+    rng = np.random.default_rng(seed)
+    if K is None:
+        K = np.array([[517.97, 0, 320.], [0, 517.97, 240.], [0, 0, 1.]])
+    ang = rng.uniform(-0.4, 0.4, 3)
+    cx, sx = np.cos(ang[0]), np.sin(ang[0])
+    cy, sy = np.cos(ang[1]), np.sin(ang[1])
+    cz, sz = np.cos(ang[2]), np.sin(ang[2])
+    R = (np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]]) @ np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+         @ np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]]))
+    t = rng.uniform(-1, 1, 3)
+    t[2] *= 0.3
+    X = np.stack([rng.uniform(-3, 3, 4 * M), rng.uniform(-2, 2, 4 * M), rng.uniform(2, 8, 4 * M)], 1)
+    X2 = X @ R.T + t
+    p0 = X @ K.T
+    p0 = p0[:, :2] / p0[:, 2:]
+    p1 = X2 @ K.T
+    p1 = p1[:, :2] / p1[:, 2:]
+    ok = (X2[:, 2] > 0.5) & (p0[:, 0] > 0) & (p0[:, 0] < 640) & (p0[:, 1] > 0) & (p0[:, 1] < 480) \
+        & (p1[:, 0] > 0) & (p1[:, 0] < 640) & (p1[:, 1] > 0) & (p1[:, 1] < 480)
+    p0, p1 = p0[ok][:M], p1[ok][:M]
+    M = len(p0)
+    p1 = p1 + noise_px * rng.standard_normal(p1.shape)
+    nout = int(outlier_frac * M)
+    if nout:
+        idx = rng.choice(M, nout, replace=False)
+        p1[idx] = np.stack([rng.uniform(0, 640, nout), rng.uniform(0, 480, nout)], 1)
+    return p0.astype(np.float32), p1.astype(np.float32), K, R, t / np.linalg.norm(t)
