@@ -1,0 +1,48 @@
+"""Default model configuration: the dict the reference hands to LoFTR(config=...), i.e.
+lower_config(cfg)['loftr'] (mp3d_loftr/src/lightning/lightning_loftr.py:40-50) for the FAR evaluation
+setting (mp3d_loftr/scripts/eval_matterport.sh:27-37, demo.py:58-99).  Plain data, same keys/values."""
+import copy
+
+FAR_EVAL_CONFIG = {
+    'backbone_type': 'ResNetFPN',
+    'resolution': (8, 2),
+    'fine_window_size': 5,
+    'fine_concat_coarse_feat': True,
+    'resnetfpn': {'initial_dim': 128, 'block_dims': [128, 196, 256]},
+    'coarse': {'d_model': 256, 'd_ffn': 256, 'nhead': 8, 'layer_names': ['self', 'cross'] * 3,
+               'attention': 'linear', 'temp_bug_fix': True},
+    'match_coarse': {'thr': 0.2, 'border_rm': 2, 'match_type': 'dual_softmax', 'dsmax_temperature': 0.1,
+                     'skh_iters': 3, 'skh_init_bin_score': 1.0, 'skh_prefilter': False,
+                     'train_coarse_percent': 0.2, 'train_pad_num_gt_min': 200, 'sparse_spvs': True},
+    'fine': {'d_model': 128, 'd_ffn': 128, 'nhead': 8, 'layer_names': ['self', 'cross'], 'attention': 'linear'},
+    'regress': {'d_model': 256, 'd_ffn': 256, 'nhead': 8, 'layer_names': ['self', 'cross'], 'attention': 'linear',
+                'temp_bug_fix': False, 'use_pos_embedding': True, 'regress_use_num_corres': True,
+                'save_mlp_feats': False, 'use_simple_moe': True, 'use_2wt': True, 'use_5050_weight': False,
+                'use_1wt': False, 'scale_8pt': True, 'save_gating_weights': False},
+    'predict_translation_scale': False,
+    'regress_rt': True,
+    'regress_loftr_layers': 1,
+    'from_saved_preds': None,
+    'solver': 'prior_ransac',
+    'use_many_ransac_thr': True,
+    'fine_pred_steps': 2,
+    'training': False,
+}
+
+
+def far_eval_config():
+    return copy.deepcopy(FAR_EVAL_CONFIG)
+
+
+class TrainerCfg:
+    """The two TRAINER fields spvs_RT reads (src/loftr/utils/supervision.py:192-193)."""
+    RANSAC_PIXEL_THR = 0.5
+    RANSAC_CONF = 0.99999
+
+
+class RunCfg:
+    """Minimal stand-in for the yacs node handed to compute_supervision_RT: config.TRAINER.*, config.LOFTR.SOLVER."""
+
+    def __init__(self, solver='prior_ransac', fine_pred_steps=2):
+        self.TRAINER = TrainerCfg()
+        self.LOFTR = type('L', (), {'SOLVER': solver, 'FINE_PRED_STEPS': fine_pred_steps})()

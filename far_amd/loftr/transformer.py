@@ -1,0 +1,277 @@
+"""LoFTR encoder stack and the EMM regression head, on the far_amd kernels.
+
+Mirrors the module/parameter structure of mp3d_loftr/src/loftr/loftr_module/transformer.py so that reference
+checkpoints load unchanged:
+  LoFTREncoderLayer :12-67, LocalFeatureTransformer :69-112, get_positional_encodings :183-248,
+  CrossAttention :250-303, CrossBlock :305-348, LocalFeatureTransformerRegressor :350-499
+and of mp3d_loftr/src/loftr/loftr_module/vit_layers/mlp.py:8-28 (Mlp).
+The attention cores run in libfar_hip.so: K5 (linear attention) and K2 (bilinear dual-softmax, never
+materialising the (B, 4, 4800, 4800) score tensors); Linear / LayerNorm / GELU stay on the vendor path.
+
+Batch semantics: the reference head is batch-size-1 only (its pairing reshape :339-341 and the gate
+broadcasts :466-469 break for B > 1).  Here B pairs are processed as B
+independent B = 1 problems stacked along dim 0; for B = 1 every tensor has the reference's shape.
+"""
+import copy
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..pose6d import pose_mean_6d, pose_std_6d
+
+
+class LinearAttention(nn.Module):
+    """Module-shaped handle on K5 (reference: linear_attention.py:12-52)."""
+
+    def __init__(self, eps=1e-6, use_num_corres=False):
+        super().__init__()
+        self.eps = eps
+
+    def forward(self, queries, keys, values, q_mask=None, kv_mask=None, loftr_preds=None):
+        N, L, H, D = queries.shape
+        S = keys.shape[1]
+        as_u8 = lambda m: None if m is None else m.to(torch.uint8).contiguous()
+        out = ops.linear_attention(queries.reshape(N, L, H * D), keys.reshape(N, S, H * D),
+                                   values.reshape(N, S, H * D), H, as_u8(q_mask), as_u8(kv_mask), self.eps)
+        return out.view(N, L, H, D)
+
+
+class LoFTREncoderLayer(nn.Module):
+    def __init__(self, d_model, nhead, attention='linear', use_num_corres=False):
+        super().__init__()
+        if attention != 'linear':
+            raise NotImplementedError("only attention='linear' (the FAR configuration) has a kernel")
+        self.dim = d_model // nhead
+        self.nhead = nhead
+        self.q_proj = nn.Linear(d_model, d_model, bias=False)
+        self.k_proj = nn.Linear(d_model, d_model, bias=False)
+        self.v_proj = nn.Linear(d_model, d_model, bias=False)
+        self.attention = LinearAttention(use_num_corres=use_num_corres)
+        self.merge = nn.Linear(d_model, d_model, bias=False)
+        self.mlp = nn.Sequential(
+            nn.Linear(d_model * 2, d_model * 2, bias=False),
+            nn.ReLU(True),
+            nn.Linear(d_model * 2, d_model, bias=False),
+        )
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+
+    def forward(self, x, source, x_mask=None, source_mask=None, loftr_preds=None):
+        bs = x.size(0)
+        q = self.q_proj(x).view(bs, -1, self.nhead, self.dim)
+        k = self.k_proj(source).view(bs, -1, self.nhead, self.dim)
+        v = self.v_proj(source).view(bs, -1, self.nhead, self.dim)
+        msg = self.attention(q, k, v, q_mask=x_mask, kv_mask=source_mask, loftr_preds=loftr_preds)
+        msg = self.norm1(self.merge(msg.view(bs, -1, self.nhead * self.dim)))
+        msg = self.norm2(self.mlp(torch.cat([x, msg], dim=2)))
+        return x + msg
+
+
+class LocalFeatureTransformer(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.d_model = config['d_model']
+        self.nhead = config['nhead']
+        self.layer_names = config['layer_names']
+        if 'regress_use_num_corres' not in config:
+            config['regress_use_num_corres'] = False
+        layer = LoFTREncoderLayer(config['d_model'], config['nhead'], config['attention'],
+                                  config['regress_use_num_corres'])
+        self.layers = nn.ModuleList([copy.deepcopy(layer) for _ in range(len(self.layer_names))])
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def forward(self, feat0, feat1, mask0=None, mask1=None, loftr_preds=None, inv_loftr_preds=None):
+        assert self.d_model == feat0.size(2), "the feature number of src and transformer must be equal"
+        for layer, name in zip(self.layers, self.layer_names):
+            if name == 'self':
+                feat0 = layer(feat0, feat0, mask0, mask0, inv_loftr_preds)
+                feat1 = layer(feat1, feat1, mask1, mask1, loftr_preds)
+            elif name == 'cross':
+                feat0 = layer(feat0, feat1, mask0, mask1, inv_loftr_preds)
+                feat1 = layer(feat1, feat0, mask1, mask0, loftr_preds)  # uses the UPDATED feat0 (:107-108)
+            else:
+                raise KeyError(name)
+        return feat0, feat1
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features or in_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
+
+    def forward(self, x):
+        return self.fc2(self.act(self.fc1(x)))
+
+
+def positional_table(h=60, w=80):
+    """(h*w, 6) fp32 table [y^2, x^2, xy, y, x, 1] of K^-1-normalised cell coordinates.
+
+    Same arithmetic as get_positional_encodings (transformer.py:183-248) with its hard-coded intrinsics
+    (:194-196), minus the 4800-iteration Python loop (:236-240): evaluated once, vectorised."""
+    fx, fy, cx, cy = (torch.tensor(v, dtype=torch.float32) for v in (517 / 9, 517 / 8, 40., 30.))
+    hpix, wpix = cy * 2, cx * 2
+    K = torch.zeros(3, 3)
+    K[0, 0] = (fx / wpix) * 2
+    K[1, 1] = (fy / hpix) * 2
+    K[0, 2] = (cx / wpix) * 2 - 1
+    K[1, 2] = (cy / hpix) * 2 - 1
+    K[2, 2] = 1
+    Kinv = torch.inverse(K)
+    ys = torch.linspace(-1, 1, steps=h)
+    xs = torch.linspace(-1, 1, steps=w)
+    gy, gx = torch.meshgrid(ys, xs, indexing='ij')                # n = j*w + k  ->  (ys[j], xs[k])
+    pts = torch.stack([gx.reshape(-1), gy.reshape(-1), torch.ones(h * w)], 0)   # (3, h*w)
+    wv = Kinv @ pts
+    p4 = wv[0] / wv[2]
+    p3 = wv[1] / wv[2]
+    return torch.stack([p3 * p3, p4 * p4, p3 * p4, p3, p4, torch.ones_like(p3)], dim=1).contiguous()
+
+
+class CrossAttention(nn.Module):
+    def __init__(self, dim, num_heads=8, qkv_bias=False, attn_drop=0., proj_drop=0.):
+        super().__init__()
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj_fundamental = nn.Linear(dim + 6 * num_heads, dim)
+        self.register_buffer('pos6', positional_table(), persistent=False)
+
+    def forward(self, x1, x2, intrinsics=None, loftr_preds=None, inv_loftr_preds=None):
+        B, N, C = x1.shape
+        h, d = self.num_heads, C // self.num_heads
+        # (2, B, N, 3, h, d) -> (3, 2, B, h, N, d): one packed copy feeds both directions of K2
+        qkv = self.qkv(torch.stack([x1, x2], 0)).reshape(2, B, N, 3, h, d).permute(3, 0, 1, 4, 2, 5).contiguous()
+        q, k, v = qkv[0], qkv[1], qkv[2]                           # each (2, B, h, N, d); index 0 = image 1
+        # direction 1: attn_1 = q2 k1^T, contracted with v1 (:275,:291); direction 2: q1 k2^T with v2 (:276,:292)
+        qq = torch.stack([q[1], q[0]], 0).reshape(2 * B * h, N, d)
+        kk = k.reshape(2 * B * h, N, d)
+        vv = v.reshape(2 * B * h, N, d)
+        if self.pos6.shape[0] != N:
+            raise ValueError(f'the head is tied to a 60x80 coarse grid (N=4800), got N={N} (transformer.py:194)')
+        F, _ = ops.emm_bilinear(qq, kk, vv, self.pos6, self.scale)  # (2Bh, 70, 70)
+        F = F.view(2, B, h, d + 6, d + 6)
+        # raw reshape of (B, h, 70, 70) to (B, 280, 70), then transpose (:294-295)
+        f1 = F[0].reshape(B, C + 6 * h, (C + 6 * h) // h).transpose(-2, -1)
+        f2 = F[1].reshape(B, C + 6 * h, (C + 6 * h) // h).transpose(-2, -1)
+        f2 = self.proj_fundamental(f2)
+        f1 = self.proj_fundamental(f1)
+        return f2, f1                                              # flipped on purpose (:301-303)
+
+
+def _init_vit(m):
+    # the non-jax branch of the reference's _init_vit_weights (:151-181)
+    if isinstance(m, nn.Linear):
+        nn.init.trunc_normal_(m.weight, std=.02)
+        if m.bias is not None:
+            nn.init.zeros_(m.bias)
+    elif isinstance(m, nn.LayerNorm):
+        nn.init.zeros_(m.bias)
+        nn.init.ones_(m.weight)
+
+
+class CrossBlock(nn.Module):
+    def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, drop=0., attn_drop=0., drop_path=0.,
+                 act_layer=nn.GELU, norm_layer=nn.LayerNorm, use_pos_embedding=False, distilled=False):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.cross_attn = CrossAttention(dim, num_heads=num_heads, qkv_bias=qkv_bias)
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer)
+        self.h, self.w = 60, 80
+        self.pos_embed = 0
+        if use_pos_embedding:
+            self.pos_embed = nn.Parameter(torch.zeros(1, self.h * self.w, 256))
+            nn.init.trunc_normal_(self.pos_embed, std=.02)
+        self.apply(_init_vit)
+
+    def forward(self, x, intrinsics=None, loftr_preds=None, inv_loftr_preds=None):
+        """x = cat([feat0, feat1], dim=0): (2B, N, C).  Returns (2B, 70, C), rows (2b, 2b+1) = pair b."""
+        b_s, h_w, nf = x.shape
+        B = b_s // 2
+        x = x + self.pos_embed
+        x1_in, x2_in = x[:B], x[B:]           # == x.reshape(-1, 2, h_w, nf)[:, 0/1] for the reference's B = 1
+        f1, f2 = self.cross_attn(self.norm1(x1_in), self.norm1(x2_in), intrinsics=intrinsics,
+                                 loftr_preds=loftr_preds, inv_loftr_preds=inv_loftr_preds)
+        f = torch.cat([f1.unsqueeze(1), f2.unsqueeze(1)], dim=1).reshape(b_s, -1, nf)
+        return f + self.mlp(self.norm2(f))
+
+
+class LocalFeatureTransformerRegressor(nn.Module):
+    """LoFTR layer(s) + EMM head + solver/regressor gate (transformer.py:350-499)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        num_heads, feat_size, pos_enc = 4, 256, 6
+        pose_size_in = pose_size = 9
+        self.pose_size = pose_size
+        if config['regress']['regress_use_num_corres']:
+            pose_size_in += 1
+        if config['use_many_ransac_thr']:
+            pose_size_in += 3
+        self.pose_size_in = pose_size_in
+        self.H = int(num_heads * 2 * (feat_size // num_heads + pos_enc) * (feat_size // num_heads))   # 35840
+        self.H2 = 512
+        rc = config['regress']
+        if rc['use_simple_moe']:
+            self.encoder = nn.Sequential(nn.Linear(self.H, self.H2), nn.ReLU(), nn.Linear(self.H2, self.H2))
+            n_gate = 1 if rc['use_1wt'] else (2 if rc['use_2wt'] else pose_size)
+            self.moe_predictor = nn.Sequential(
+                nn.Linear(self.H + pose_size + pose_size_in, self.H2), nn.ReLU(),
+                nn.Linear(self.H2, self.H2), nn.ReLU(),
+                nn.Linear(self.H2, n_gate), nn.Sigmoid())
+            self.pose_regressor_simple_moe = nn.Sequential(
+                nn.Linear(self.H2, self.H2), nn.ReLU(), nn.Linear(self.H2, pose_size))
+        else:
+            self.pose_regressor = nn.Sequential(
+                nn.Linear(self.H, self.H2), nn.ReLU(), nn.Linear(self.H2, self.H2), nn.ReLU(),
+                nn.Linear(self.H2, pose_size))
+        self.norm = partial(nn.LayerNorm, eps=1e-6)(feat_size)
+        self.emm = CrossBlock(dim=feat_size, num_heads=num_heads, qkv_bias=True,
+                              use_pos_embedding=rc['use_pos_embedding'])
+        if config['regress_loftr_layers'] > 0:
+            self.loftr = LocalFeatureTransformer(config['regress'])
+
+    def forward_emm(self, feat0, feat1, loftr_preds=None, inv_loftr_preds=None):
+        B = feat0.shape[0]
+        x = self.emm(torch.cat([feat0, feat1], dim=0), loftr_preds=loftr_preds, inv_loftr_preds=inv_loftr_preds)
+        features = self.norm(x).reshape([B, -1])
+        rc = self.config['regress']
+        if not rc['use_simple_moe']:
+            return self.pose_regressor(features), (features if rc['save_mlp_feats'] else None), None
+        mean_t, std_t = pose_mean_6d[:3].to(features.device), pose_std_6d[:3].to(features.device)
+        pred_reg_6d = self.pose_regressor_simple_moe(self.encoder(features))
+        pred_reg_t = pred_reg_6d[..., :3]
+        loftr_pred_t = loftr_preds[..., :3]
+        if rc['scale_8pt']:
+            # give the solver's unit translation the regressor's length (:436-446)
+            solver_t = loftr_pred_t * std_t + mean_t
+            reg_t = pred_reg_t * std_t + mean_t
+            solver_t = solver_t * torch.linalg.norm(reg_t, dim=-1, keepdim=True) \
+                / torch.clamp(torch.linalg.norm(solver_t, dim=-1, keepdim=True), 1e-3, 100)
+            loftr_pred_t = (solver_t - mean_t) / std_t
+        extra = self.pose_size_in - self.pose_size
+        loftr_pred_R = loftr_preds[..., 3:-extra] if extra > 0 else loftr_preds[..., 3:]   # :452-455
+        gate = self.moe_predictor(torch.cat([features, pred_reg_6d, loftr_preds], dim=-1))
+        if rc['use_2wt']:
+            if rc['use_5050_weight']:
+                raise NotImplementedError('use_5050_weight is a debugging branch in the reference (:461-464)')
+            w_t, w_r = gate[..., 0:1], gate[..., 1:2]
+        else:
+            w_t = w_r = gate[..., 0:1]
+        pred_T = w_t * pred_reg_t + (1 - w_t) * loftr_pred_t                               # :466
+        pred_R = w_r * pred_reg_6d[..., 3:] + (1 - w_r) * loftr_pred_R                     # :467
+        pose = torch.cat([pred_T, pred_R], dim=-1)
+        return pose, (features if rc['save_mlp_feats'] else None), gate
+
+    def forward(self, feat0, feat1, loftr_preds=None, inv_loftr_preds=None, mask0=None, mask1=None, F=None):
+        if self.config['regress_loftr_layers'] > 0:
+            feat0, feat1 = self.loftr(feat0, feat1, loftr_preds=loftr_preds, inv_loftr_preds=inv_loftr_preds)
+        return self.forward_emm(feat0, feat1, loftr_preds, inv_loftr_preds)

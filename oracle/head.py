@@ -30,8 +30,9 @@ def positional_encodings(h=60, w=80, dtype=np.float32):
     K = np.zeros((3, 3), f32)
     K[0, 0], K[1, 1], K[0, 2], K[1, 2], K[2, 2] = fxn, fyn, cxn, cyn, 1
     Kinv = np.linalg.inv(K.astype(np.float64)).astype(f32)   # torch.inverse in fp32; exact here (diagonal)
-    ys = np.linspace(-1, 1, h, dtype=np.float64).astype(f32)   # torch.linspace(-1,1,steps) fp32
-    xs = np.linspace(-1, 1, w, dtype=np.float64).astype(f32)
+    import torch
+    ys = torch.linspace(-1, 1, steps=h).numpy()                # :198-199 (torch's fp32 linspace, not numpy's)
+    xs = torch.linspace(-1, 1, steps=w).numpy()
     p3 = np.empty(h * w, f32)
     p4 = np.empty(h * w, f32)
     for j in range(h):

@@ -51,3 +51,4 @@ def two_view_scene(M, seed=0, outlier_frac=0.3, noise_px=0.3, K=None):
         idx = rng.choice(M, nout, replace=False)
         p1[idx] = np.stack([rng.uniform(0, 640, nout), rng.uniform(0, 480, nout)], 1)
     return p0.astype(np.float32), p1.astype(np.float32), K, R, t / np.linalg.norm(t)
+
