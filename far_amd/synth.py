@@ -70,7 +70,7 @@ def load_synthetic(model, seed=0):
     return model
 
 
-def synth_image_pair(N, seed=0, hw=(480, 640), disparities=(32, 40, 48), noise=0.01):
+def synth_image_pair(N, seed=0, hw=(480, 640), disparities=(8, 40, 72), noise=0.01):
     """N grayscale pairs in [0,1], float32 (N,1,H,W).  image1 is image0 displaced in x by a different
     disparity in each horizontal band (a lateral camera translation in front of a few depth planes), so the
     two-view geometry is well posed; disparities are multiples of the coarse cell (8 px)."""

@@ -1,0 +1,159 @@
+"""End-to-end parity on the GPU: far_amd.LoFTR + the evaluation call order vs the reference goldens and vs the
+oracle's full path, on synthetic 640x480 pairs with the synthetic checkpoint."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from far_amd import synth
+from far_amd.config import far_eval_config
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+@pytest.fixture(scope='module')
+def model():
+    from far_amd.loftr import LoFTR
+    m = LoFTR(far_eval_config()).eval()
+    synth.load_synthetic(m, seed=0)
+    return m.cuda()
+
+
+def _batch(N, seed):
+    im0, im1 = synth.synth_image_pair(N, seed=seed)
+    K = torch.from_numpy(np.stack([synth.MP3D_K] * N)).cuda()
+    return {'image0': torch.from_numpy(im0).cuda(), 'image1': torch.from_numpy(im1).cuda(), 'K0': K, 'K1': K.clone(),
+            'dataset_name': ['mp3d']}, im0, im1
+
+
+def test_matcher_vs_reference_golden(model):
+    g = np.load(os.path.join(G, 'g7_full.npz'))
+    data, _, _ = _batch(1, 0)
+    with torch.no_grad():
+        model(data)
+    np.testing.assert_allclose(data['feats_c'][:, ::16, ::7, ::9].cpu().numpy(), g['feats_c_sample'], atol=2e-3, rtol=1e-3)
+    np.testing.assert_allclose(data['featmap0'][0, ::97].cpu().numpy(), g['featmap0_sample'], atol=3e-3, rtol=1e-3)
+    gi, gj = data['i_ids'].cpu().numpy(), data['j_ids'].cpu().numpy()
+    got = dict(zip(gi.tolist(), gj.tolist()))
+    ref = dict(zip(g['i_ids'].tolist(), g['j_ids'].tolist()))
+    safe = (np.abs(g['rowmax'] - 0.2) > 2e-3) & (g['rowgap'] > 2e-3)
+    for i in np.nonzero(safe)[0]:
+        assert (i in got) == (i in ref), i
+        if i in got:
+            assert got[i] == ref[i]
+    common = [i for i in ref if i in got]
+    assert len(common) > 0.98 * len(ref) > 1000
+    a = np.array([{i: n for n, i in enumerate(gi.tolist())}[i] for i in common])
+    b = np.array([{i: n for n, i in enumerate(g['i_ids'].tolist())}[i] for i in common])
+    np.testing.assert_allclose(data['mconf'].cpu().numpy()[a], g['mconf'][b], atol=5e-3, rtol=0)
+    np.testing.assert_allclose(data['mkpts1_f'].cpu().numpy()[a], g['mkpts1_f'][b], atol=2e-2, rtol=0)
+    np.testing.assert_allclose(data['expec_f'].cpu().numpy()[a], g['expec_f'][b], atol=5e-3, rtol=0)
+
+
+def test_head_vs_reference_golden(model):
+    g = np.load(os.path.join(G, 'g4_head.npz'))
+    rng = np.random.default_rng(14)
+    f0 = rng.standard_normal((1, 4800, 256)).astype(np.float32)
+    f1 = (0.5 * f0 + rng.standard_normal((1, 4800, 256))).astype(np.float32)
+    n = g['counts']
+    data = {'featmap0': torch.from_numpy(f0).cuda(), 'featmap1': torch.from_numpy(f1).cuda(),
+            'loftr_rt': torch.from_numpy(g['loftr_rt']).cuda(), 'num_correspondences': torch.tensor([int(n[0])]).cuda(),
+            'num_correspondences_before_ransac': torch.tensor([int(n[1])]).cuda(),
+            'inliers_best_tight': torch.tensor([int(n[2])]).cuda(), 'inliers_best_ultra_tight': torch.tensor([int(n[3])]).cuda()}
+    with torch.no_grad():
+        emm = model.loftr_regress.emm
+        blk = emm(torch.cat([data['featmap0'], data['featmap1']], 0)).cpu().numpy()
+        _, _, _, _, lp, ilp = model.preprocess_helper(data)
+        model.forward_rt_prediction(data)
+    sc = np.abs(g['block_out']).max()
+    np.testing.assert_allclose(blk, g['block_out'], atol=2e-4 * sc, rtol=1e-3)
+    np.testing.assert_allclose(lp.cpu().numpy(), g['loftr_preds_6d'], atol=1e-6, rtol=1e-6)
+    np.testing.assert_allclose(ilp.cpu().numpy(), g['inv_loftr_preds_6d'], atol=1e-5, rtol=1e-5)
+    reg = data['regressed_rt'].cpu().numpy()
+    assert reg.shape == (1, 9) and data['expec_rt'].shape == (9,) and data['priorRT'].shape == (3, 4)
+    # north_star: regression logits within 1e-3 relative (fp32)
+    np.testing.assert_allclose(reg, g['regressed_rt'], atol=1e-3 * np.abs(g['regressed_rt']).max(), rtol=1e-3)
+    np.testing.assert_allclose(data['priorRT'], g['priorRT'], atol=2e-3, rtol=1e-3)
+
+
+def test_full_step_vs_oracle(model):
+    """matcher -> solver -> head -> solver(prior) -> head on 2 pairs.  Each stage is checked against the oracle
+    on the SAME inputs (the GPU's own upstream outputs): discrete decisions (RANSAC argmax) are only
+    comparable that way; the matcher stage is compared set-wise against the oracle's own matcher."""
+    from far_amd.config import RunCfg
+    from far_amd.supervision import compute_supervision_RT
+    from oracle import head as oh
+    from oracle import model as om
+    from oracle import solver as osv
+    cfg = far_eval_config()
+    data, im0, im1 = _batch(2, 21)
+    run = RunCfg('prior_ransac', 2)
+    Hn, seed = 512, 3
+    man = json.load(open(os.path.join(G, 'g8_state_dict_manifest.json')))
+    w = om.Weights(synth.synthetic_state_dict({k: tuple(v) for k, v in man.items()}))
+    pcl = np.random.RandomState(0).uniform(low=-3.0, high=3.0, size=(300, 3)).astype(np.float32)
+    pos = oh.positional_encodings()
+    K = synth.MP3D_K
+    with torch.no_grad():
+        model(data)
+    odata = om.matcher_forward(w, cfg, im0, im1)
+    gm = set(zip(data['b_ids'].tolist(), data['i_ids'].tolist(), data['j_ids'].tolist()))
+    rm = set(zip(odata['b_ids'].tolist(), odata['i_ids'].tolist(), odata['j_ids'].tolist()))
+    assert len(gm & rm) > 0.99 * len(rm) > 2000
+    np.testing.assert_allclose(data['featmap0'].cpu().numpy(), odata['featmap0'], atol=5e-3, rtol=1e-3)
+    mk0, mk1 = data['mkpts0_f'].cpu().numpy(), data['mkpts1_f'].cpu().numpy()
+    bids = data['m_bids'].cpu().numpy()
+    f0, f1 = data['featmap0'].cpu().numpy(), data['featmap1'].cpu().numpy()
+    prior = None
+    for rnd in range(2):
+        data['translation_scale'] = None
+        compute_supervision_RT(data, run, H=Hn, seed=seed)
+        rt = data['loftr_rt'].cpu().numpy()
+        assert rt.shape == (2, 3, 4) and data['loftr_rt'].dtype == torch.float64
+        cnt = {k: data[k].cpu().numpy() for k in ['num_correspondences', 'num_correspondences_before_ransac',
+                                                  'inliers_best_tight', 'inliers_best_ultra_tight']}
+        mask = data['solver_inlier_mask'].cpu().numpy().astype(bool)
+        for b in range(2):
+            sel = bids == b
+            ret, na, ti, ul, _ = osv.estimate_pose(mk0[sel], mk1[sel], K, K, 0.5, solver='prior_ransac',
+                                                   priorRT=None if prior is None else prior[b], seed=seed, pair=b,
+                                                   H=Hn, pcl=pcl)
+            R, t, m, E = ret
+            assert np.linalg.norm(rt[b] - np.concatenate([R, t[:, None]], 1)) < 1e-4      # north_star: 1e-4 Frobenius
+            np.testing.assert_array_equal(mask[sel], m)                                     # bit-exact inlier mask
+            assert (cnt['num_correspondences'][b], cnt['inliers_best_tight'][b], cnt['inliers_best_ultra_tight'][b]) \
+                == (na, ti, ul)
+            assert cnt['num_correspondences_before_ransac'][b] == sel.sum()
+            # (pose sanity against ground truth lives in test_solver_gpu.py on real 3-D scenes; the banded
+            #  image pairs here have the usual small-baseline translation/rotation ambiguity)
+            assert abs(np.linalg.det(R) - 1) < 1e-9 and abs(np.linalg.norm(t) - 1) < 1e-9
+        with torch.no_grad():
+            model.forward_rt_prediction(data)
+        reg = data['regressed_rt'].cpu().numpy()
+        prior = np.asarray(data['priorRT'])
+        assert reg.shape == (2, 9) and prior.shape == (2, 3, 4)
+        for b in range(2):
+            lp, ilp = om.preprocess_helper(cfg, rt[b], cnt['num_correspondences'][b],
+                                           cnt['num_correspondences_before_ransac'][b], cnt['inliers_best_tight'][b],
+                                           cnt['inliers_best_ultra_tight'][b])
+            oreg, gate, _ = om.head_forward(w, cfg, f0[b:b + 1], f1[b:b + 1], lp, ilp, pos)
+            np.testing.assert_allclose(reg[b], oreg[0], atol=1e-3 * np.abs(oreg).max(), rtol=1e-3)
+            np.testing.assert_allclose(prior[b], om.prior_from_regressed(oreg), atol=2e-3, rtol=1e-3)
+    # data-dict contract
+    for k in ['conf_matrix', 'b_ids', 'i_ids', 'j_ids', 'gt_mask', 'm_bids', 'mkpts0_c', 'mkpts1_c', 'mconf', 'W',
+              'expec_f', 'mkpts0_f', 'mkpts1_f', 'featmap0', 'featmap1', 'mask_c0', 'mask_c1', 'translation_scale',
+              'loftr_rt', 'expec_rt', 'expec_e', 'num_correspondences', 'num_correspondences_before_ransac',
+              'num_correspondences_after_ransac', 'inliers_best_tight', 'inliers_best_ultra_tight', 'regressed_rt',
+              'priorRT', 'bs', 'hw0_i', 'hw0_c', 'hw0_f']:
+        assert k in data, k
+
+
+def test_pipeline_call_order_runs(model):
+    from far_amd.pipeline import test_step
+    data, _, _ = _batch(3, 5)
+    test_step(model, data, H=256)
+    assert data['regressed_rt'].shape == (3, 9) and torch.isfinite(data['regressed_rt']).all()
+    assert data['loftr_rt'].shape == (3, 3, 4)
