@@ -1,0 +1,203 @@
+#!/usr/bin/env python
+"""bench.py -- image-pairs/sec of FAR's pose-estimation hot path (match + solve + regress) at 640x480.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched under
+torch.distributed.run with one rank per GPU.  One "step" = one pass of the full evaluation path
+(far_amd.pipeline.test_step == lightning_loftr.py:325-343) over one batch of 32 synthetic pairs per GPU
+(BASELINE.json configs[1]: "Matterport3D eval, batch 32 pairs @ 640x480, 1xMI355X"), inputs resident in HBM.
+Pairs are independent: ranks shard them with no data-path collective ("weak" scaling); the only collective is
+the MAX over ranks of the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PAIRS_PER_GPU = 32
+L = S = 4800
+C = 256
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
+F32_MFMA_PEAK_TFLOPS = 157.3     # dense f32-input MFMA peak (same guide)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--pairs', type=int, default=PAIRS_PER_GPU, help='pairs per GPU per step')
+    ap.add_argument('--hyp', type=int, default=2048, help='RANSAC hypotheses per pair (metrics.py:120)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-pairs', type=int, default=1)
+    return ap.parse_args()
+
+
+def event_time_ms(fn, iters=5, warm=2):
+    """Average duration of fn() measured with HIP events on the stream the kernels are launched on
+    (torch's current stream, which is the stream handed to every far_* call)."""
+    for _ in range(warm):
+        fn()
+    st = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(iters):
+        fn()
+    e1.record(st)
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def kernel_rooflines(n_pairs):
+    """Isolated timings of the hand-written kernels at the bench shapes -> roofline entries.
+    Algorithmic work per image pair:
+      K1 stats / K1 match : 2*L*S*C flops each = 11.80 GFLOP (one correlation pass)
+      K2 stats            : 2 dirs * 4 heads * 2*N*N*64   = 23.59 GFLOP
+      K2 pv               : 23.59 (scores) + 2 dirs*4 heads*2*N*N*70 (P v~) = 49.4 GFLOP
+    """
+    from far_amd import ops
+    dev = 'cuda'
+    g = torch.Generator(device=dev).manual_seed(1)
+    f0 = 1.2 * torch.randn(n_pairs, L, C, device=dev, generator=g)
+    f1 = f0[:, torch.randperm(L, device=dev, generator=g)] + 0.1 * torch.randn(n_pairs, L, C, device=dev, generator=g)
+    out = {}
+    t = event_time_ms(lambda: ops.dual_softmax_stats(f0, f1, 16.0, 0.1, 1.0))
+    fl = 2.0 * L * S * C * n_pairs
+    out['k_stats_f32[K1]'] = dict(ms=t, tflops=fl / t / 1e9, frac=fl / t / 1e9 / F32_MFMA_PEAK_TFLOPS)
+    t2 = event_time_ms(lambda: ops.coarse_match(f0, f1, 0.1, 0.2, 2, (60, 80), (60, 80), 8.0))
+    out['far_coarse_match_f32[K1 all passes]'] = dict(ms=t2, tflops=fl / t2 / 1e9, frac=fl / t2 / 1e9 / F32_MFMA_PEAK_TFLOPS)
+    tm = event_time_ms(lambda: ops.coarse_match(f0[:8], f1[:8], 0.1, 0.2, 2, (60, 80), (60, 80), 8.0, want_conf=True))
+    by = (4.0 * L * S + 4.0 * (L + S) * C) * min(8, n_pairs)
+    out['far_coarse_match_f32[K1 materialising conf_matrix, 8 pairs]'] = dict(ms=tm, gbs=by / tm / 1e6, frac=by / tm / 1e6 / HBM_PEAK_GBS)
+    del f0, f1
+    Z = n_pairs * 8
+    q = torch.randn(Z, L, 64, device=dev, generator=g)
+    k = torch.randn(Z, L, 64, device=dev, generator=g)
+    v = torch.randn(Z, L, 64, device=dev, generator=g)
+    pos = torch.rand(L, 6, device=dev, generator=g)
+    t3 = event_time_ms(lambda: ops.dual_softmax_stats(q, k, 1.0, 1.0, 0.125), iters=3, warm=1)
+    fl3 = 2.0 * L * L * 64 * Z
+    out['k_stats_f32[K2]'] = dict(ms=t3, tflops=fl3 / t3 / 1e9, frac=fl3 / t3 / 1e9 / F32_MFMA_PEAK_TFLOPS)
+    rs, cs = ops.dual_softmax_stats(q, k, 1.0, 1.0, 0.125)
+    T = torch.empty(Z, L, 70, device=dev)
+    from far_amd import _lib
+    lib = _lib.load()
+    import ctypes
+
+    def pv():
+        lib.far_emm_pv_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), pos.data_ptr(), Z, L, 64, ctypes.c_float(0.125),
+                           rs.data_ptr(), cs.data_ptr(), T.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    t4 = event_time_ms(pv, iters=3, warm=1)
+    fl4 = (2.0 * L * L * 64 + 2.0 * L * L * 70) * Z
+    out['k_emm_pv_f32[K2]'] = dict(ms=t4, tflops=fl4 / t4 / 1e9, frac=fl4 / t4 / 1e9 / F32_MFMA_PEAK_TFLOPS)
+    return out
+
+
+def cpu_baseline(n_pairs, hyp):
+    """The oracle (CPU restatement of the reference path, oracle/model.py) timed on this box's host cores."""
+    import json as _json
+    from far_amd import synth
+    from far_amd.config import far_eval_config
+    from oracle import model as om
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    man = _json.load(open(os.path.join(ROOT, 'tests', 'golden', 'g8_state_dict_manifest.json')))
+    w = om.Weights(synth.synthetic_state_dict({k: tuple(v) for k, v in man.items()}))
+    im0, im1 = synth.synth_image_pair(n_pairs, seed=4242)
+    K = np.stack([synth.MP3D_K] * n_pairs)
+    t0 = time.time()
+    om.test_step(w, far_eval_config(), im0, im1, K, K, seed=0, H=hyp)
+    dt = time.time() - t0
+    return {'value': n_pairs / dt, 'unit': 'image-pairs/sec', 'cores': cores, 'kind': 'port',
+            'sample': f'{n_pairs} pair(s) of the same synthetic 640x480 workload through oracle/model.py:test_step '
+                      f'(numpy + torch-CPU fp32, solver float64, H={hyp}), {dt:.1f} s wall'}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+    from far_amd import synth
+    from far_amd.config import far_eval_config
+    from far_amd.loftr import LoFTR
+    from far_amd.pipeline import test_step
+
+    cfg = far_eval_config()
+    model = LoFTR(cfg).eval()
+    synth.load_synthetic(model, seed=0)
+    model = model.to(dev)
+    im0, im1 = synth.synth_image_pair(a.pairs, seed=1234 + rank)
+    K = torch.from_numpy(np.stack([synth.MP3D_K] * a.pairs)).to(dev)
+    base = {'image0': torch.from_numpy(im0).to(dev), 'image1': torch.from_numpy(im1).to(dev), 'K0': K, 'K1': K.clone(),
+            'dataset_name': ['mp3d']}
+
+    def step():
+        batch = dict(base)
+        test_step(model, batch, H=a.hyp, seed=0)
+        return batch
+
+    for _ in range(a.warmup):
+        last = step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        last = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    matches = float(last['b_ids'].numel()) / a.pairs
+    ok_frac = float(last['solver_status'].float().mean().item())
+
+    if rank == 0:
+        kr = kernel_rooflines(a.pairs)
+        dom = max((k for k in kr if 'tflops' in kr[k] and not k.startswith('far_')), key=lambda k: kr[k]['ms'])
+        roof = {'kernel': dom, 'bound': 'mfma', 'achieved': round(kr[dom]['tflops'], 2), 'peak': F32_MFMA_PEAK_TFLOPS,
+                'unit': 'TFLOP/s', 'frac': round(kr[dom]['frac'], 4), 'traffic': None,
+                'launch_ms': round(kr[dom]['ms'], 3),
+                'note': 'f32-input MFMA (exact fp32) peak; algorithmic flops per launch / event-timed launch duration'}
+        res = {
+            'metric': 'image-pairs/sec (match+solve+regress) at 640x480',
+            'value': round(world * a.pairs * a.steps / dt, 3), 'unit': 'image-pairs/sec',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(1000 * dt / a.steps, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'Matterport3D-shaped eval (BASELINE configs[1]): batch 32 pairs @ 640x480 per GPU, '
+                                   'LoFTR match + 8-pt prior-RANSAC solve (x2 rounds) + EMM head (x2), seeded random weights',
+                       'pairs_per_gpu': a.pairs, 'hypotheses': a.hyp, 'fine_pred_steps': 2,
+                       'matches_per_pair': round(matches, 1), 'solver_success_frac': ok_frac,
+                       'parallelism': f'dp{world} (independent pairs, no data-path collective)'},
+            'roofline': roof,
+            'kernels': {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in kr.items()},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline(a.cpu_pairs, a.hyp)
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

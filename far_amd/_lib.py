@@ -20,6 +20,7 @@ c_u32 = ctypes.c_uint32
 # name -> (restype, argtypes); must list every function declared in include/far_hip.h
 SIGNATURES = {
     'far_abi_version': (c_i, []),
+    'far_last_hip_error': (c_i, []),
     'far_dual_softmax_workspace_bytes': (c_sz, [c_i, c_i, c_i]),
     'far_dual_softmax_stats_f32': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p]),
     'far_coarse_match_f32': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f,
@@ -50,6 +51,11 @@ def load():
         raise FarHipError(
             f'{LIB_PATH} not found: build it with `python -m far_amd.build` (hipcc --offload-arch=gfx950). '
             'far_amd has no CPU or eager fallback for its kernels.')
+    # PyTorch-ROCm wheels bundle their own libamdhip64.so.  The HIP runtime that owns torch's streams and
+    # allocations must be the one this library binds to, so torch is imported (and its runtime mapped) BEFORE
+    # the dlopen: a libfar_hip.so loaded first would pull in /opt/rocm's copy and later launches on torch's
+    # streams fail with hipErrorNoDevice (observed; see INTEGRATION.md "load order").
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
@@ -61,4 +67,5 @@ def load():
 
 def check(rc, what):
     if rc != 0:
-        raise FarHipError(f'{what} failed with code {rc}')
+        detail = f' (hipError_t {_lib.far_last_hip_error()})' if (rc == -5 and _lib is not None) else ''
+        raise FarHipError(f'{what} failed with code {rc}{detail}')

@@ -34,7 +34,15 @@ __device__ __forceinline__ void softmax_merge(float& m, float& s, float mo, floa
     m = mn;
 }
 
+// Vendor libraries (rocBLAS / hipBLASLt kernel lookups) can leave a benign error in HIP's per-thread "last error"
+// slot; every entry point clears it first so that far_check_launch() only reports this library's own launches.
+static inline void far_clear_errors() { (void)hipGetLastError(); }
+
+extern "C" int far_last_hip_error(void);
+void far_record_hip_error(int e);
+
 static inline int far_check_launch() {
     hipError_t e = hipGetLastError();
+    if (e != hipSuccess) far_record_hip_error((int)e);
     return e == hipSuccess ? FAR_OK : FAR_ELAUNCH;
 }

@@ -438,6 +438,7 @@ int far_dual_softmax_stats_f32(const float* f0, const float* f1, int Z, int L, i
                                float feat_div, float sim_div, float sim_mul,
                                const uint8_t* mask0, const uint8_t* mask1,
                                float* rowstat_out, float* colstat_out, void* ws, hipStream_t stream) {
+    far_clear_errors();
     if (!f0 || !f1 || !ws || Z <= 0 || L <= 0 || S <= 0 || C <= 0 || (C % KC) != 0) return FAR_EINVAL;
     K1Workspace w = carve(ws, Z, L, S);
     SimParams sp{feat_div, sim_div, sim_mul, -1e9f};
@@ -466,6 +467,7 @@ int far_coarse_match_f32(const float* f0, const float* f1, int Z, int L, int S, 
                          float* conf_out, int64_t* b_ids, int64_t* i_ids, int64_t* j_ids, float* mconf,
                          float* mkpts0_c, float* mkpts1_c, int* counts_out, int* total_out,
                          void* ws, hipStream_t stream) {
+    far_clear_errors();
     if (!f0 || !f1 || !ws || !b_ids || !i_ids || !j_ids || !mconf || !mkpts0_c || !mkpts1_c || !total_out)
         return FAR_EINVAL;
     if (Z <= 0 || L <= 0 || S <= 0 || C <= 0 || (C % KC) != 0 || h0 * w0 != L || h1 * w1 != S) return FAR_EINVAL;

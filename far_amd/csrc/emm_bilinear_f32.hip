@@ -171,6 +171,7 @@ extern "C" {
 //   (feat_div = 1, sim_div = 1, sim_mul = scale);  T_out [Z][N][70].
 int far_emm_pv_f32(const float* q, const float* k, const float* v, const float* pos, int Z, int N, int D,
                    float scale, const float* rowstat, const float* colstat, float* T_out, hipStream_t stream) {
+    far_clear_errors();
     if (!q || !k || !v || !pos || !rowstat || !colstat || !T_out || Z <= 0 || N <= 0 || D != EM_D) return FAR_EINVAL;
     static bool attr_set = false;
     if (!attr_set) {

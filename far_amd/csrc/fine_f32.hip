@@ -96,6 +96,7 @@ extern "C" {
 int far_fine_gather_f32(const float* feat, long sn, long sc, long sh, long sw, int C, int Hf, int Wf,
                         const int64_t* b_ids, const int64_t* cell_ids, int wc, int W, int stride, int M,
                         float* out, hipStream_t stream) {
+    far_clear_errors();
     if (M == 0) return FAR_OK;
     if (!feat || !b_ids || !cell_ids || !out || M < 0 || C <= 0 || W <= 0 || (W & 1) == 0 || wc <= 0) return FAR_EINVAL;
     hipLaunchKernelGGL(k_fine_gather, dim3(M), dim3(256), 0, stream, feat, sn, sc, sh, sw, C, Hf, Wf, b_ids, cell_ids,
@@ -107,6 +108,7 @@ int far_fine_gather_f32(const float* feat, long sn, long sc, long sh, long sw, i
 int far_fine_expect_f32(const float* feat0, const float* feat1, int M, int W, int C, const float* mkpts1_c,
                         float win_scale, const float* scale1, const int64_t* b_ids, float* expec_f,
                         float* mkpts1_f, hipStream_t stream) {
+    far_clear_errors();
     if (M == 0) return FAR_OK;
     if (!feat0 || !feat1 || !mkpts1_c || !expec_f || !mkpts1_f || M < 0 || W <= 0 || W * W > 64 || C <= 0)
         return FAR_EINVAL;

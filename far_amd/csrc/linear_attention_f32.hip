@@ -164,6 +164,7 @@ size_t far_linear_attention_workspace_bytes(int N, int S, int H, int D) {
 int far_linear_attention_f32(const float* q, const float* k, const float* v, int N, int L, int S, int H, int D,
                              const uint8_t* q_mask, const uint8_t* kv_mask, float eps, float* out, void* ws,
                              hipStream_t stream) {
+    far_clear_errors();
     if (N == 0) return FAR_OK;
     if (!q || !k || !v || !out || !ws || N < 0 || L <= 0 || S <= 0) return FAR_EINVAL;
     const int HD = H * D;

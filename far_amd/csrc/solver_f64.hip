@@ -713,6 +713,7 @@ int far_solver_f64(const float* kpts0, const float* kpts1, const int* offsets, i
                    int* num_after_out, int* n_tight_out, int* n_ultra_out, int* n_cheir_out, int* best_out,
                    double* F_all_out, int* count_all_out, double* score_all_out, int* samples_out,
                    void* ws, hipStream_t stream) {
+    far_clear_errors();
     if (B <= 0) return FAR_OK;
     if (!offsets || !K0 || !K1 || !inl_th || !R_out || !t_out || !E_out || !mask_out || !status_out ||
         !num_after_out || !n_tight_out || !n_ultra_out || !n_cheir_out || !best_out || !ws || H <= 0 || Mtot < 0)

@@ -27,6 +27,8 @@ typedef struct ihipStream_t* far_stream_t; /* == hipStream_t */
 
 /* ABI version of this header; bumped when a signature changes. */
 int far_abi_version(void);
+/* hipError_t of the most recent failed launch on the calling thread (0 = none): detail behind a -5 return. */
+int far_last_hip_error(void);
 
 /* ---------------------------------------------------------------------------------------------------
  * K1  coarse matcher: all-pairs correlation + dual-softmax + mutual-NN selection
