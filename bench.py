@@ -106,6 +106,7 @@ def cpu_baseline(n_pairs, hyp):
     from far_amd.config import far_eval_config
     from oracle import model as om
     cores = os.cpu_count() or 1
+    cores = min(cores, 32)   # more threads only add synchronisation overhead to these CPU ops
     torch.set_num_threads(cores)
     man = _json.load(open(os.path.join(ROOT, 'tests', 'golden', 'g8_state_dict_manifest.json')))
     w = om.Weights(synth.synthetic_state_dict({k: tuple(v) for k, v in man.items()}))
@@ -164,10 +165,8 @@ def main():
         last = step()
     fence()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    from far_amd import parallel
+    dt = parallel.max_over_ranks(dt, device=dev)          # the slowest rank defines the step time
     matches = float(last['b_ids'].numel()) / a.pairs
     ok_frac = float(last['solver_status'].float().mean().item())
 

@@ -28,7 +28,7 @@ def conf_matrix(feat_c0, feat_c1, temperature, mask_c0=None, mask_c1=None, dtype
     C = feat_c0.shape[-1]
     f0 = (feat_c0 / np.float32(C ** .5)).astype(dtype)                   # :104-105
     f1 = (feat_c1 / np.float32(C ** .5)).astype(dtype)
-    sim = np.einsum('nlc,nsc->nls', f0, f1) / dtype(np.float32(temperature))  # :108-109
+    sim = np.matmul(f0, np.swapaxes(f1, 1, 2)) / dtype(np.float32(temperature))  # :108-109 (einsum nlc,nsc->nls)
     if mask_c0 is not None:                                               # :110-113
         valid = mask_c0[..., None].astype(bool) & mask_c1[:, None].astype(bool)
         sim = np.where(valid, sim, dtype(-INF))

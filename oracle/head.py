@@ -54,7 +54,10 @@ def bilinear_attention(q, k, vt, scale, dtype=np.float32):
 
     attn = (q @ k^T) * scale; A = softmax(attn, -1) * softmax(attn, -2); F = (vt^T @ A) @ vt.
     """
-    q, k, vt = (np.asarray(a).astype(dtype) for a in (q, k, vt))
-    attn = (q @ np.swapaxes(k, -1, -2)) * dtype(scale)
-    A = _softmax(attn, -1) * _softmax(attn, -2)
-    return (np.swapaxes(vt, -1, -2) @ A) @ vt, A
+    import torch
+    td = torch.float64 if np.dtype(dtype) == np.float64 else torch.float32
+    q, k, vt = (torch.from_numpy(np.ascontiguousarray(np.asarray(a))).to(td) for a in (q, k, vt))
+    attn = (q @ k.transpose(-1, -2)) * scale                      # torch-CPU ops: the reference's own operators,
+    A = attn.softmax(dim=-1) * attn.softmax(dim=-2)               # multi-threaded (this is the cpu_baseline's hot spot)
+    F = (vt.transpose(-1, -2) @ A) @ vt
+    return F.numpy(), A.numpy()

@@ -91,3 +91,51 @@ def test_permutation_recovered_batch():
             return (y >= 2) & (y < 58) & (x >= 2) & (x < 78)
         expect = np.nonzero(interior(np.arange(4800)) & interior(inv))[0]
         np.testing.assert_array_equal(i[sel], expect)
+
+
+def test_padding_masks_and_image_scales():
+    """mask_c0/mask_c1 (-1e9 fill, coarse_matching.py:110-113), mask_border_with_padding (:28-43) and
+    scale0/scale1 (:247-254): exercised against a torch restatement of those reference lines."""
+    from far_amd import ops
+    rng = np.random.default_rng(9)
+    N, hw, C = 2, (12, 16), 64
+    f0, f1, _ = correlated_features(N, hw, C, seed=4, amp=2.0)
+    L = hw[0] * hw[1]
+    m0 = np.zeros((N, hw[0], hw[1]), bool)
+    m1 = np.zeros((N, hw[0], hw[1]), bool)
+    ext = [(10, 13, 12, 16), (12, 16, 9, 14)]
+    for n, (h0, w0, h1, w1) in enumerate(ext):
+        m0[n, :h0, :w0] = True
+        m1[n, :h1, :w1] = True
+    sc0 = rng.uniform(0.8, 1.3, (N, 2)).astype(np.float32)
+    sc1 = rng.uniform(0.8, 1.3, (N, 2)).astype(np.float32)
+    # reference arithmetic in float64
+    a = torch.from_numpy(f0).double() / C ** .5
+    b = torch.from_numpy(f1).double() / C ** .5
+    sim = torch.einsum('nlc,nsc->nls', a, b) / 0.1
+    valid = torch.from_numpy(m0.reshape(N, L))[..., None] & torch.from_numpy(m1.reshape(N, L))[:, None]
+    sim = sim.masked_fill(~valid, -1e9)
+    conf = sim.softmax(1) * sim.softmax(2)
+    mask = (conf > 0.2).reshape(N, *hw, *hw).clone()
+    bd = 2
+    mask[:, :bd] = False; mask[:, :, :bd] = False; mask[:, :, :, :bd] = False; mask[:, :, :, :, :bd] = False
+    for n, (h0, w0, h1, w1) in enumerate(ext):
+        mask[n, h0 - bd:] = False; mask[n, :, w0 - bd:] = False
+        mask[n, :, :, h1 - bd:] = False; mask[n, :, :, :, w1 - bd:] = False
+    mask = mask.reshape(N, L, L) & (conf == conf.max(2, keepdim=True)[0]) & (conf == conf.max(1, keepdim=True)[0])
+    mv, aj = mask.max(2)
+    bi, ii = torch.where(mv)
+    jj = aj[bi, ii]
+    vh = torch.tensor(ext, dtype=torch.int32).cuda()
+    got = ops.coarse_match(torch.from_numpy(f0).cuda(), torch.from_numpy(f1).cuda(), 0.1, 0.2, bd, hw, hw, 8.0,
+                           mask0=torch.from_numpy(m0.reshape(N, L).astype(np.uint8)).cuda(),
+                           mask1=torch.from_numpy(m1.reshape(N, L).astype(np.uint8)).cuda(), valid_hw=vh,
+                           scale0=torch.from_numpy(sc0).cuda(), scale1=torch.from_numpy(sc1).cuda())
+    assert len(bi) > 20
+    np.testing.assert_array_equal(got['b_ids'].cpu().numpy(), bi.numpy())
+    np.testing.assert_array_equal(got['i_ids'].cpu().numpy(), ii.numpy())
+    np.testing.assert_array_equal(got['j_ids'].cpu().numpy(), jj.numpy())
+    mk0 = torch.stack([ii % hw[1], ii // hw[1]], 1) * (8.0 * torch.from_numpy(sc0)[bi])
+    mk1 = torch.stack([jj % hw[1], jj // hw[1]], 1) * (8.0 * torch.from_numpy(sc1)[bi])
+    np.testing.assert_allclose(got['mkpts0_c'].cpu().numpy(), mk0.numpy(), rtol=1e-6)
+    np.testing.assert_allclose(got['mkpts1_c'].cpu().numpy(), mk1.numpy(), rtol=1e-6)

@@ -157,3 +157,35 @@ def test_pipeline_call_order_runs(model):
     test_step(model, data, H=256)
     assert data['regressed_rt'].shape == (3, 9) and torch.isfinite(data['regressed_rt']).all()
     assert data['loftr_rt'].shape == (3, 3, 4)
+
+
+def test_cached_prediction_mode_head_only():
+    """BASELINE config 4 / `--from_saved_preds`: the matcher is not constructed (loftr.py:20); the dataset supplies
+    featmap0/1 + the solver outputs, and only forward_rt_prediction runs (lightning_loftr.py:326,334)."""
+    from far_amd.loftr import LoFTR
+    cfg = far_eval_config()
+    cfg['from_saved_preds'] = 'loftr_preds'
+    m = LoFTR(cfg).eval()
+    assert not hasattr(m, 'backbone') and not hasattr(m, 'coarse_matching')
+    man = json.load(open(os.path.join(G, 'g8_state_dict_manifest.json')))
+    sd = synth.synthetic_state_dict({k: tuple(v) for k, v in man.items() if k.startswith('loftr_regress.')})
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m = m.cuda()
+    g = np.load(os.path.join(G, 'g4_head.npz'))
+    rng = np.random.default_rng(14)
+    f0 = rng.standard_normal((1, 4800, 256)).astype(np.float32)
+    f1 = (0.5 * f0 + rng.standard_normal((1, 4800, 256))).astype(np.float32)
+    B = 3
+    n = g['counts']
+    rep = lambda a: torch.from_numpy(a).cuda().repeat(B, 1, 1)
+    data = {'featmap0': rep(f0), 'featmap1': rep(f1), 'loftr_rt': torch.from_numpy(g['loftr_rt']).cuda().repeat(B, 1, 1),
+            'num_correspondences': torch.tensor([int(n[0])] * B).cuda(),
+            'num_correspondences_before_ransac': torch.tensor([int(n[1])] * B).cuda(),
+            'inliers_best_tight': torch.tensor([int(n[2])] * B).cuda(),
+            'inliers_best_ultra_tight': torch.tensor([int(n[3])] * B).cuda()}
+    with torch.no_grad():
+        m.forward_rt_prediction(data)
+    reg = data['regressed_rt'].cpu().numpy()
+    assert reg.shape == (B, 9)
+    for b in range(B):       # a batch of B is B independent B = 1 runs (SURVEY.md section 0 fact 4)
+        np.testing.assert_allclose(reg[b:b + 1], g['regressed_rt'], atol=1e-3 * np.abs(g['regressed_rt']).max(), rtol=1e-3)
