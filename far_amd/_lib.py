@@ -21,6 +21,7 @@ c_u32 = ctypes.c_uint32
 SIGNATURES = {
     'far_abi_version': (c_i, []),
     'far_last_hip_error': (c_i, []),
+    'far_set_tuning': (c_i, [c_i, c_i]),
     'far_dual_softmax_workspace_bytes': (c_sz, [c_i, c_i, c_i]),
     'far_dual_softmax_stats_f32': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p]),
     'far_coarse_match_f32': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f,

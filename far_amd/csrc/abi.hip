@@ -7,3 +7,13 @@ void far_record_hip_error(int e) { g_last_hip_error = e; }
 extern "C" int far_abi_version(void) { return 1; }
 // hipError_t of the most recent failed launch on this thread (0 = none); for diagnostics after a -5 return.
 extern "C" int far_last_hip_error(void) { return g_last_hip_error; }
+
+// Tuning knobs for A/B experiments (speed only; never change results).  key 0: bit mask of kernels that use
+// wave-slot priority staggering (1 = k_stats, 2 = k_match, 4 = k_emm_pv).
+static int g_tuning[8] = {3, 0, 0, 0, 0, 0, 0, 0};
+extern "C" int far_set_tuning(int key, int value) {
+    if (key < 0 || key >= 8) return FAR_EINVAL;
+    g_tuning[key] = value;
+    return FAR_OK;
+}
+int far_get_tuning(int key) { return (key >= 0 && key < 8) ? g_tuning[key] : 0; }

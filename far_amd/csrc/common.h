@@ -24,6 +24,26 @@ __device__ __forceinline__ int shfl_xor_i(int v, int m) { return __shfl_xor(v, m
 // parity tolerance on confidences; a denormal result flushes to 0, as irrelevant.
 __device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
 
+// Two workgroups of an MFMA-bound kernel share each SIMD (one wave each).  Left alone they drift into lockstep:
+// both waves sit in their MFMA phase together (pipe shared, each at half speed), then both in their VALU/LDS tail
+// together (pipe idle).  Giving the wave in the even hardware slot a higher issue priority makes the pipe go to
+// one wave at a time, so one wave's tail overlaps the other's MFMAs.  Speed only; correctness never depends on it.
+__device__ __forceinline__ void stagger_priority_by_wave_slot(int enable) {
+    if (!enable) return;
+    // HW_REG_HW_ID (id 4): WAVE_ID in bits [3:0]
+    unsigned hwid = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4);
+    if ((hwid & 1u) == 0) __builtin_amdgcn_s_setprio(2);
+}
+
+// x / d for a loop-invariant divisor d, given r = 1.0f / d (IEEE).  q = fl(x r); e = fma(-d, q, x); q' = fma(e, r, q)
+// is the correctly rounded quotient (Markstein) except for divisors whose significand is all ones; 3 instructions
+// instead of the ~10 of the generic v_div_* sequence.
+__device__ __forceinline__ float fdiv_by(float x, float d, float r) {
+    float q = x * r;
+    float e = fmaf(-d, q, x);
+    return fmaf(e, r, q);
+}
+
 // Merge two online-softmax partials (m, s): s = sum exp(x - m).  Safe for empty partials
 // (m = -FLT_MAX, s = 0).
 __device__ __forceinline__ void softmax_merge(float& m, float& s, float mo, float so) {
@@ -39,6 +59,7 @@ __device__ __forceinline__ void softmax_merge(float& m, float& s, float mo, floa
 static inline void far_clear_errors() { (void)hipGetLastError(); }
 
 extern "C" int far_last_hip_error(void);
+int far_get_tuning(int key);
 void far_record_hip_error(int e);
 
 static inline int far_check_launch() {

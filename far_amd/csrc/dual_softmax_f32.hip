@@ -23,14 +23,35 @@ namespace {
 constexpr float NEG_BIG = -FLT_MAX;
 
 struct SimParams {
-    float feat_div;   // features divided by this when staged (sqrt(C) for K1, 1 for K2)
-    float sim_div;    // dot / sim_div            (temperature for K1, 1 for K2)
+    float feat_div;   // features divided by this when staged; 1 when the scaling is folded into acc_scale
+    float acc_scale;  // exact power-of-two factor applied to the dot product (1/feat_div^2 when folded, else 1)
+    float sim_div;    // then / sim_div           (temperature for K1, 1 for K2)
+    float sim_rcp;    // 1 / sim_div (IEEE), for the 3-instruction exact division
     float sim_mul;    // then * sim_mul           (1 for K1, head_dim^-0.5 for K2)
     float mask_fill;  // value for masked-out (i,j) pairs (-1e9 in the reference)
+    int stagger;      // tuning: wave-slot priority staggering on/off
 };
 
+// The reference divides both feature maps by sqrt(C) before the contraction (coarse_matching.py:104-105).  When
+// sqrt(C) is a power of two that scaling commutes exactly with every rounding of the fmaf chain, so it is applied
+// once to the accumulator instead of to 2 x 32 floats per thread per chunk: bit-identical, far fewer instructions.
+inline SimParams make_sim(float feat_div, float sim_div, float sim_mul) {
+    SimParams p;
+    int e;
+    float m = frexpf(feat_div, &e);
+    bool pow2 = (m == 0.5f);
+    p.feat_div = pow2 ? 1.0f : feat_div;
+    p.acc_scale = pow2 ? 1.0f / (feat_div * feat_div) : 1.0f;
+    p.sim_div = sim_div;
+    p.sim_rcp = 1.0f / sim_div;
+    p.sim_mul = sim_mul;
+    p.mask_fill = -1e9f;
+    p.stagger = 0;
+    return p;
+}
+
 __device__ __forceinline__ float sim_of(float acc, const SimParams& p) {
-    float s = acc / p.sim_div;
+    float s = fdiv_by(acc * p.acc_scale, p.sim_div, p.sim_rcp);
     return s * p.sim_mul;
 }
 
@@ -66,6 +87,7 @@ __global__ __launch_bounds__(256, 2) void k_stats_f32(
         }
     }
 
+    stagger_priority_by_wave_slot(sp.stagger);
     float rm[16], rs[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { rm[r] = NEG_BIG; rs[r] = 0.f; }
@@ -222,10 +244,11 @@ __global__ __launch_bounds__(256, 2) void k_match_f32(
             rowvalid |= 1u << r;
             if (mask0 && !mask0[(size_t)z * L + i]) rowmasked |= 1u << r;
             float2 st = rowstat[(size_t)z * L + i];
-            rmax[r] = st.x; rsum[r] = st.y;
+            rmax[r] = st.x; rsum[r] = 1.0f / st.y;   // rsum holds the reciprocal of the row sum
         }
     }
 
+    stagger_priority_by_wave_slot(sp.stagger);
     f32x16 acc[4];
     acc_zero(acc);
     ChunkRegs cr;
@@ -250,6 +273,7 @@ __global__ __launch_bounds__(256, 2) void k_match_f32(
                 const bool cvalid = j < S;
                 const bool cmasked = cvalid && mask1 && !mask1[(size_t)z * S + j];
                 float2 cst = cvalid ? colstat[(size_t)z * S + j] : make_float2(0.f, 1.f);
+                const float cinv = 1.0f / cst.y;
                 float cb = -1.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -257,8 +281,10 @@ __global__ __launch_bounds__(256, 2) void k_match_f32(
                     if (cmasked || ((rowmasked >> r) & 1)) s = sp.mask_fill;
                     // reference order: softmax over dim 1 (columns normalised over rows) times
                     // softmax over dim 2 (coarse_matching.py:118)
-                    float pc = fexp(s - cst.x) / cst.y;
-                    float pr = fexp(s - rmax[r]) / rsum[r];
+                    // softmax = exp(s - max) * (1 / sum): the reciprocal is IEEE, the product is within 1 ulp of
+                    // the reference's division
+                    float pc = fexp(s - cst.x) * cinv;
+                    float pr = fexp(s - rmax[r]) * rsum[r];
                     float p = pc * pr;
                     const bool ok = cvalid && ((rowvalid >> r) & 1);
                     if (ok) {
@@ -441,7 +467,8 @@ int far_dual_softmax_stats_f32(const float* f0, const float* f1, int Z, int L, i
     far_clear_errors();
     if (!f0 || !f1 || !ws || Z <= 0 || L <= 0 || S <= 0 || C <= 0 || (C % KC) != 0) return FAR_EINVAL;
     K1Workspace w = carve(ws, Z, L, S);
-    SimParams sp{feat_div, sim_div, sim_mul, -1e9f};
+    SimParams sp = make_sim(feat_div, sim_div, sim_mul);
+    sp.stagger = far_get_tuning(0) & 1;
     int nI = (L + TILE_M - 1) / TILE_M;
     float2* rs = rowstat_out ? (float2*)rowstat_out : w.rowstat;
     float2* cs = colstat_out ? (float2*)colstat_out : w.colstat;
@@ -475,7 +502,8 @@ int far_coarse_match_f32(const float* f0, const float* f1, int Z, int L, int S, 
     int rc = far_dual_softmax_stats_f32(f0, f1, Z, L, S, C, sqrtf((float)C), temperature, 1.0f, mask0, mask1,
                                         nullptr, nullptr, ws, stream);
     if (rc) return rc;
-    SimParams sp{sqrtf((float)C), temperature, 1.0f, -1e9f};
+    SimParams sp = make_sim(sqrtf((float)C), temperature, 1.0f);
+    sp.stagger = (far_get_tuning(0) >> 1) & 1;
     int nI = (L + TILE_M - 1) / TILE_M;
     int* counts = counts_out ? counts_out : w.counts;
     hipMemsetAsync(counts, 0, sizeof(int) * Z, stream);

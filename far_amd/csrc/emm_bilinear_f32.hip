@@ -34,7 +34,8 @@ __global__ __launch_bounds__(256, 2) void k_emm_pv_f32(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     const float* __restrict__ pos,  // [N][6]
     int N, float scale, const float2* __restrict__ rowstat, const float2* __restrict__ colstat,
-    float* __restrict__ T) {        // [Z][N][70]
+    float* __restrict__ T,          // [Z][N][70]
+    int stagger) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     EmmLds& lds = *reinterpret_cast<EmmLds*>(smem_raw);
 
@@ -54,12 +55,18 @@ __global__ __launch_bounds__(256, 2) void k_emm_pv_f32(
         else qa[g] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     float2 rst = ivalid ? rowstat[(size_t)z * N + irow] : make_float2(0.f, 1.f);
+    const float rinv = 1.0f / rst.y;
 
-    f32x16 tacc[3];
+    stagger_priority_by_wave_slot(stagger);
+    // T[:, 0:64] accumulates on the matrix core (2 tiles); the 6 positional columns T[:, 64:70] are accumulated
+    // on the VALU in the MFMA shadow: in this orientation a lane owns ONE query row, so they cost 6 registers,
+    // and a third (mostly padding) MFMA tile is avoided.
+    f32x16 tacc[2];
 #pragma unroll
-    for (int bt = 0; bt < 3; ++bt)
+    for (int bt = 0; bt < 2; ++bt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) tacc[bt][r] = 0.f;
+    float tpos[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     const int nJ = (N + 127) / 128;
     for (int Jt = 0; Jt < nJ; ++Jt) {
@@ -92,72 +99,92 @@ __global__ __launch_bounds__(256, 2) void k_emm_pv_f32(
             *reinterpret_cast<float4*>(&lds.v[row * EM_VS + 64 + 4 * half]) = pv;
             if (tid < 128) {
                 int jj = j0 + tid;
-                lds.cst[tid] = jj < N ? colstat[(size_t)z * N + jj] : make_float2(0.f, 1.f);
+                float2 c = jj < N ? colstat[(size_t)z * N + jj] : make_float2(0.f, 1.f);
+                lds.cst[tid] = make_float2(c.x, 1.0f / c.y);   // (max, 1 / sum)
             }
         }
         __syncthreads();
 
-        // ---- scores, transposed: D[m = j][n = i] ----
-        f32x16 acc[4];
+        // The 128-key tile is processed as two 64-key halves so that only two score accumulators (32 registers)
+        // are live at a time; two independent MFMA chains are exactly enough to cover the 64-cycle
+        // dependent-accumulator latency of v_mfma_f32_32x32x2_f32.
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            const int jb = 64 * half;                                  // first key row of this half inside the tile
+            // ---- scores, transposed: D[m = j][n = i] ----
+            f32x16 acc[2];
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
+            for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
-        const float* krow = &lds.k[l31 * EM_KS + 4 * h];
+                for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+            const float* krow = &lds.k[(jb + l31) * EM_KS + 4 * h];
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            f32x4 kb[4];
+            for (int g = 0; g < 8; ++g) {
+                f32x4 kb[2];
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) kb[ct] = *reinterpret_cast<const f32x4*>(krow + ct * 32 * EM_KS + 8 * g);
+                for (int ct = 0; ct < 2; ++ct) kb[ct] = *reinterpret_cast<const f32x4*>(krow + ct * 32 * EM_KS + 8 * g);
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
+                for (int c = 0; c < 4; ++c)
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct)
-                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(kb[ct][c], qa[g][c], acc[ct], 0, 0, 0);
+                    for (int ct = 0; ct < 2; ++ct)
+                        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(kb[ct][c], qa[g][c], acc[ct], 0, 0, 0);
+            }
+
+            // ---- P in place: lane holds i = l31, j = j0 + jb + 32ct + mfma32_row(r, h) ----
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int jl = jb + 32 * ct + mfma32_row(r, h);
+                    const float2 cs = lds.cst[jl];
+                    float s = acc[ct][r] * scale;                       // transformer.py:275
+                    float pr = fexp(s - rst.x) * rinv;                  // softmax(dim=-1): over keys j
+                    float pc = fexp(s - cs.x) * cs.y;                   // softmax(dim=-2): over queries i (cs.y = 1/sum)
+                    float p = pr * pc;                                  // :281
+                    acc[ct][r] = (ivalid && (j0 + jl) < N) ? p : 0.f;
+                }
+
+            // ---- T[i][b] += sum_j P[i][j] v~[j][b]: A = P (from registers), B = v~ tile from LDS ----
+            // MFMA step (ct, t): k-pair = { j = 32ct + mfma32_row(t, 0), j = 32ct + mfma32_row(t, 1) }
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const int jl = jb + 32 * ct + mfma32_row(t, h);
+                    const float* vrow = &lds.v[jl * EM_VS];
+                    const float b0 = vrow[l31];
+                    const float b1 = vrow[32 + l31];
+                    const float pj = acc[ct][t];
+                    tacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pj, b0, tacc[0], 0, 0, 0);
+                    tacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pj, b1, tacc[1], 0, 0, 0);
+                    const f32x4 pa = *reinterpret_cast<const f32x4*>(vrow + 64);  // broadcast reads (same j per half-wave)
+                    const float2 pb = *reinterpret_cast<const float2*>(vrow + 68);
+                    tpos[0] = fmaf(pj, pa[0], tpos[0]);
+                    tpos[1] = fmaf(pj, pa[1], tpos[1]);
+                    tpos[2] = fmaf(pj, pa[2], tpos[2]);
+                    tpos[3] = fmaf(pj, pa[3], tpos[3]);
+                    tpos[4] = fmaf(pj, pb.x, tpos[4]);
+                    tpos[5] = fmaf(pj, pb.y, tpos[5]);
+                }
         }
-
-        // ---- P in place: lane holds i = l31, j = j0 + 32ct + mfma32_row(r, h) ----
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int jl = 32 * ct + mfma32_row(r, h);
-                float2 cs = lds.cst[jl];
-                float s = acc[ct][r] * scale;                       // transformer.py:275
-                float pr = fexp(s - rst.x) / rst.y;                 // softmax(dim=-1): over keys j
-                float pc = fexp(s - cs.x) / cs.y;                   // softmax(dim=-2): over queries i
-                float p = pr * pc;                                  // :281
-                acc[ct][r] = (ivalid && (j0 + jl) < N) ? p : 0.f;
-            }
-
-        // ---- T[i][b] += sum_j P[i][j] v~[j][b]: A = P (from registers), B = v~ tile from LDS ----
-        // MFMA step (ct, t): k-pair = { j = 32ct + mfma32_row(t, 0), j = 32ct + mfma32_row(t, 1) }
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int jl = 32 * ct + mfma32_row(t, h);
-                const float* vrow = &lds.v[jl * EM_VS];
-                float b0 = vrow[l31];
-                float b1 = vrow[32 + l31];
-                float b2 = vrow[l31 < 8 ? 64 + l31 : 64];  // columns 64..71 valid in LDS; others unused
-                tacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[ct][t], b0, tacc[0], 0, 0, 0);
-                tacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[ct][t], b1, tacc[1], 0, 0, 0);
-                tacc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[ct][t], b2, tacc[2], 0, 0, 0);
-            }
     }
 
     // ---- store T: lane holds column b = 32bt + l31, rows i = i0 + 32 wave + mfma32_row(r, h) ----
 #pragma unroll
-    for (int bt = 0; bt < 3; ++bt) {
+    for (int bt = 0; bt < 2; ++bt) {
         int b = 32 * bt + l31;
-        if (b < EM_DV) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int i = i0 + 32 * wave + mfma32_row(r, h);
-                if (i < N) T[((size_t)z * N + i) * EM_DV + b] = tacc[bt][r];
-            }
+        for (int r = 0; r < 16; ++r) {
+            int i = i0 + 32 * wave + mfma32_row(r, h);
+            if (i < N) T[((size_t)z * N + i) * EM_DV + b] = tacc[bt][r];
         }
+    }
+    // positional columns: this lane summed its half (h) of the keys for query row irow
+#pragma unroll
+    for (int c = 0; c < 6; ++c) tpos[c] += shfl_xor_f(tpos[c], 32);
+    if (h == 0 && ivalid) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) T[((size_t)z * N + irow) * EM_DV + 64 + c] = tpos[c];
     }
 }
 
@@ -179,7 +206,7 @@ int far_emm_pv_f32(const float* q, const float* k, const float* v, const float* 
         attr_set = true;
     }
     hipLaunchKernelGGL(k_emm_pv_f32, dim3((N + 127) / 128, Z), dim3(256), sizeof(EmmLds), stream, q, k, v, pos, N,
-                       scale, (const float2*)rowstat, (const float2*)colstat, T_out);
+                       scale, (const float2*)rowstat, (const float2*)colstat, T_out, (far_get_tuning(0) >> 2) & 1);
     return far_check_launch();
 }
 

@@ -238,11 +238,34 @@ class LocalFeatureTransformerRegressor(nn.Module):
                               use_pos_embedding=rc['use_pos_embedding'])
         if config['regress_loftr_layers'] > 0:
             self.loftr = LocalFeatureTransformer(config['regress'])
+        # The evaluation loop calls the head FINE_PRED_STEPS times on the SAME coarse features; only the 13 solver
+        # numbers change between calls (lightning_loftr.py:338-343).  Everything up to `features` (2 LoFTR layers,
+        # K2, CrossBlock, LayerNorm) does not depend on them -- LinearAttention ignores loftr_preds
+        # (linear_attention.py:20) -- so it is computed once per feature pair and kept resident.  Inference only.
+        self.cache_features = True
+        self._feat_cache = None
 
-    def forward_emm(self, feat0, feat1, loftr_preds=None, inv_loftr_preds=None):
-        B = feat0.shape[0]
-        x = self.emm(torch.cat([feat0, feat1], dim=0), loftr_preds=loftr_preds, inv_loftr_preds=inv_loftr_preds)
+    def _features(self, feat0, feat1, loftr_preds, inv_loftr_preds):
+        key = None
+        if self.cache_features and not torch.is_grad_enabled():
+            key = (feat0.data_ptr(), feat1.data_ptr(), feat0._version, feat1._version, tuple(feat0.shape))
+            if self._feat_cache is not None and self._feat_cache[0] == key:
+                return self._feat_cache[1]
+        f0, f1 = feat0, feat1
+        if self.config['regress_loftr_layers'] > 0:
+            f0, f1 = self.loftr(f0, f1, loftr_preds=loftr_preds, inv_loftr_preds=inv_loftr_preds)
+        B = f0.shape[0]
+        x = self.emm(torch.cat([f0, f1], dim=0), loftr_preds=loftr_preds, inv_loftr_preds=inv_loftr_preds)
         features = self.norm(x).reshape([B, -1])
+        # hold references to the inputs so that their storage (hence data_ptr) cannot be recycled while cached
+        self._feat_cache = (key, features, feat0, feat1) if key is not None else None
+        return features
+
+    def forward_emm(self, feat0, feat1, loftr_preds=None, inv_loftr_preds=None, features=None):
+        if features is None:
+            B = feat0.shape[0]
+            x = self.emm(torch.cat([feat0, feat1], dim=0), loftr_preds=loftr_preds, inv_loftr_preds=inv_loftr_preds)
+            features = self.norm(x).reshape([B, -1])
         rc = self.config['regress']
         if not rc['use_simple_moe']:
             return self.pose_regressor(features), (features if rc['save_mlp_feats'] else None), None
@@ -272,6 +295,5 @@ class LocalFeatureTransformerRegressor(nn.Module):
         return pose, (features if rc['save_mlp_feats'] else None), gate
 
     def forward(self, feat0, feat1, loftr_preds=None, inv_loftr_preds=None, mask0=None, mask1=None, F=None):
-        if self.config['regress_loftr_layers'] > 0:
-            feat0, feat1 = self.loftr(feat0, feat1, loftr_preds=loftr_preds, inv_loftr_preds=inv_loftr_preds)
-        return self.forward_emm(feat0, feat1, loftr_preds, inv_loftr_preds)
+        features = self._features(feat0, feat1, loftr_preds, inv_loftr_preds)
+        return self.forward_emm(feat0, feat1, loftr_preds, inv_loftr_preds, features=features)

@@ -29,6 +29,9 @@ typedef struct ihipStream_t* far_stream_t; /* == hipStream_t */
 int far_abi_version(void);
 /* hipError_t of the most recent failed launch on the calling thread (0 = none): detail behind a -5 return. */
 int far_last_hip_error(void);
+/* Tuning knobs for A/B experiments; they change speed only, never results.  key 0 = bit mask of kernels using
+ * wave-slot issue-priority staggering (1 k_stats, 2 k_match, 4 k_emm_pv). */
+int far_set_tuning(int key, int value);
 
 /* ---------------------------------------------------------------------------------------------------
  * K1  coarse matcher: all-pairs correlation + dual-softmax + mutual-NN selection

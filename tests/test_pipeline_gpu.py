@@ -189,3 +189,26 @@ def test_cached_prediction_mode_head_only():
     assert reg.shape == (B, 9)
     for b in range(B):       # a batch of B is B independent B = 1 runs
         np.testing.assert_allclose(reg[b:b + 1], g['regressed_rt'], atol=1e-3 * np.abs(g['regressed_rt']).max(), rtol=1e-3)
+
+
+def test_head_feature_cache_is_exact(model):
+    """The second head call of a step reuses the pair features; results must be bit-identical to recomputing."""
+    rng = np.random.default_rng(3)
+    f0 = torch.from_numpy(rng.standard_normal((2, 4800, 256)).astype(np.float32)).cuda()
+    f1 = torch.from_numpy(rng.standard_normal((2, 4800, 256)).astype(np.float32)).cuda()
+    lp = torch.from_numpy(rng.standard_normal((2, 13)).astype(np.float32)).cuda()
+    lp2 = torch.from_numpy(rng.standard_normal((2, 13)).astype(np.float32)).cuda()
+    reg = model.loftr_regress
+    with torch.no_grad():
+        reg.cache_features = False
+        a1 = reg(f0, f1, loftr_preds=lp, inv_loftr_preds=lp)[0].clone()
+        a2 = reg(f0, f1, loftr_preds=lp2, inv_loftr_preds=lp2)[0].clone()
+        reg.cache_features = True
+        reg._feat_cache = None
+        b1 = reg(f0, f1, loftr_preds=lp, inv_loftr_preds=lp)[0].clone()
+        b2 = reg(f0, f1, loftr_preds=lp2, inv_loftr_preds=lp2)[0].clone()      # served from the cache
+        assert reg._feat_cache is not None
+        f0.add_(1.0)                                                           # in-place change must invalidate
+        b3 = reg(f0, f1, loftr_preds=lp, inv_loftr_preds=lp)[0]
+    assert torch.equal(a1, b1) and torch.equal(a2, b2)
+    assert not torch.equal(b3, b1)

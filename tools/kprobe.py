@@ -1,0 +1,34 @@
+"""Run the hand-written kernels in isolation at bench shapes (for rocprofv3 --pmc / --kernel-trace passes)."""
+import ctypes, sys
+sys.path.insert(0, '.')
+import torch
+from far_amd import ops, _lib
+
+which = sys.argv[1] if len(sys.argv) > 1 else 'all'
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+it = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+dev = 'cuda'
+g = torch.Generator(device=dev).manual_seed(1)
+L = 4800
+if which in ('k1', 'all'):
+    f0 = 1.2 * torch.randn(n, L, 256, device=dev, generator=g)
+    f1 = f0[:, torch.randperm(L, device=dev, generator=g)] + 0.1 * torch.randn(n, L, 256, device=dev, generator=g)
+    for _ in range(it):
+        ops.coarse_match(f0, f1, 0.1, 0.2, 2, (60, 80), (60, 80), 8.0)
+if which in ('k1conf', 'all'):
+    f0 = 1.2 * torch.randn(n, L, 256, device=dev, generator=g)
+    f1 = f0[:, torch.randperm(L, device=dev, generator=g)] + 0.1 * torch.randn(n, L, 256, device=dev, generator=g)
+    for _ in range(it):
+        ops.coarse_match(f0, f1, 0.1, 0.2, 2, (60, 80), (60, 80), 8.0, want_conf=True)
+if which in ('k2', 'all'):
+    Z = n * 8
+    q = torch.randn(Z, L, 64, device=dev, generator=g); k = torch.randn(Z, L, 64, device=dev, generator=g)
+    v = torch.randn(Z, L, 64, device=dev, generator=g); pos = torch.rand(L, 6, device=dev, generator=g)
+    for _ in range(it):
+        ops.emm_bilinear(q, k, v, pos, 0.125)
+if which in ('k5', 'all'):
+    q = torch.randn(2 * n, L, 256, device=dev, generator=g); k = torch.randn(2 * n, L, 256, device=dev, generator=g)
+    v = torch.randn(2 * n, L, 256, device=dev, generator=g)
+    for _ in range(it):
+        ops.linear_attention(q, k, v, 8)
+torch.cuda.synchronize()
