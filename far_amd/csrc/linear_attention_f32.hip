@@ -5,68 +5,86 @@
 //   KV = einsum(nshd,nshv->nhdv, K, values);  Z = 1 / (einsum(nlhd,nhd->nlh, Q, K.sum(1)) + eps)
 //   out = einsum(nlhd,nhdv,nlh->nlhv, Q, KV, Z) * S
 // Inputs are the raw projections q [N][L][H*D], k, v [N][S][H*D]; the feature map (elu+1), the 1/S and *S
-// scalings and the normaliser are fused.  Two kernels: a token-chunked reduction producing KV and K.sum
-// (deterministic two-level sum, no atomics) and a streaming apply.
+// scalings and the normaliser are fused.  Two streaming kernels (KV / K.sum per token chunk, then apply) plus a
+// tiny fixed-order reduction over chunks (deterministic, no atomics).
 #include "common.h"
 
 namespace {
 
 __device__ __forceinline__ float elu1(float x) { return (x > 0.f ? x : expm1f(x)) + 1.f; }  // F.elu(x) + 1
 
-constexpr int LA_TOK = 16;  // tokens staged per step
+// ---------------------------------------------------------------------------------------------------------
+// Both kernels put the per-head 32x32 (or 16x16) contractions on the exact-f32 matrix core so that what is left
+// is the HBM stream of q / k / v / out:
+//   D = 32: v_mfma_f32_32x32x2_f32   (lane = (col = lane & 31, kk = lane >> 5), 2 tokens or 2 channels per MFMA)
+//   D = 16: v_mfma_f32_16x16x4_f32   (lane = (col = lane & 15, kk = lane >> 4), 4 per MFMA)
+// ---------------------------------------------------------------------------------------------------------
+template <int D> struct Mf;
+template <> struct Mf<32> {
+    typedef f32x16 acc_t;
+    static constexpr int NACC = 16, KPER = 2, SHIFT = 5;
+    __device__ static __forceinline__ acc_t mma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+    __device__ static __forceinline__ int row(int r, int kk) { return (r & 3) + 8 * (r >> 2) + 4 * kk; }
+};
+template <> struct Mf<16> {
+    typedef f32x4 acc_t;
+    static constexpr int NACC = 4, KPER = 4, SHIFT = 4;
+    __device__ static __forceinline__ acc_t mma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    __device__ static __forceinline__ int row(int r, int kk) { return 4 * kk + r; }
+};
 
-// grid (nchunk, N), block HD threads.  Thread t = (h, d) accumulates KV[h][d][0..D) and ksum[h][d] over its
-// chunk of tokens.  part: [N][nchunk][HD][D+1]  (last column = ksum).
+// KV[h][d][v] = sum_s K'[s][h,d] * (V[s][h,v] / S),  ksum[h][d] = sum_s K'[s][h,d]  over one token chunk.
+// One wave per (n, chunk, head): D[m = d][n = v] += A[d][k = token] B[k = token][v]; both operands are read
+// straight from global memory with the head's D channels across the lanes (2 x 128 B or 4 x 64 B per load).
+// part: [N][nchunk][H*D][D+1] (last column = ksum).
 template <int D>
-__global__ void k_la_kv_partial(const float* __restrict__ k, const float* __restrict__ v,
-                                const uint8_t* __restrict__ kv_mask,  // optional [N][S]
-                                int S, int HD, int tok_per_chunk, int nchunk, float* __restrict__ part) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* vs = sm;  // [LA_TOK][HD]
-    const int t = threadIdx.x, n = blockIdx.x / nchunk, ch = blockIdx.x - n * nchunk;
-    const int hbase = (t / D) * D;
+__global__ __launch_bounds__(256) void k_la_kv_partial(const float* __restrict__ k, const float* __restrict__ v,
+                                                       const uint8_t* __restrict__ kv_mask, int N, int S, int H,
+                                                       int tok_per_chunk, int nchunk, float* __restrict__ part) {
+    typedef Mf<D> M;
+    const int lane = threadIdx.x & 63, col = lane & (D - 1), kk = lane >> M::SHIFT;
+    const long unit = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long units = (long)N * nchunk * H;
+    if (unit >= units) return;
+    const int h = (int)(unit % H);
+    const int ch = (int)((unit / H) % nchunk);
+    const int n = (int)(unit / ((long)H * nchunk));
+    const int HD = H * D;
     const int s0 = ch * tok_per_chunk, s1 = min(S, s0 + tok_per_chunk);
-    float acc[D];
-#pragma unroll
-    for (int i = 0; i < D; ++i) acc[i] = 0.f;
-    float ksum = 0.f;
     const float fS = (float)S;
-    for (int sb = s0; sb < s1; sb += LA_TOK) {
-        const int nt = min(LA_TOK, s1 - sb);
-        float kf[LA_TOK];
-        __syncthreads();
+    typename M::acc_t acc;
 #pragma unroll
-        for (int i = 0; i < LA_TOK; ++i) {
-            float kk = 0.f, vv = 0.f;
-            if (i < nt) {
-                size_t off = ((size_t)n * S + sb + i) * HD + t;
-                float m = (kv_mask && !kv_mask[(size_t)n * S + sb + i]) ? 0.f : 1.f;
-                kk = elu1(k[off]) * m;
-                vv = (v[off] * m) / fS;   // values / v_length (linear_attention.py:43)
-            }
-            kf[i] = kk;
-            vs[i * HD + t] = vv;
+    for (int r = 0; r < M::NACC; ++r) acc[r] = 0.f;
+    float ks = 0.f;
+    const float* kp = k + ((size_t)n * S) * HD + h * D + col;
+    const float* vp = v + ((size_t)n * S) * HD + h * D + col;
+    constexpr int U = 8;   // token groups in flight
+    for (int sb = s0; sb < s1; sb += U * M::KPER) {
+        float a[U], b[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int s = sb + u * M::KPER + kk;
+            a[u] = 0.f; b[u] = 0.f;
+            if (s < s1) { a[u] = kp[(size_t)s * HD]; b[u] = vp[(size_t)s * HD]; }
         }
-        __syncthreads();
 #pragma unroll
-        for (int i = 0; i < LA_TOK; ++i) {
-            const float kk = kf[i];
-            ksum += kk;
-            const float4* vr = reinterpret_cast<const float4*>(&vs[i * HD + hbase]);
-#pragma unroll
-            for (int c = 0; c < D / 4; ++c) {
-                float4 x = vr[c];
-                acc[4 * c + 0] = fmaf(kk, x.x, acc[4 * c + 0]);
-                acc[4 * c + 1] = fmaf(kk, x.y, acc[4 * c + 1]);
-                acc[4 * c + 2] = fmaf(kk, x.z, acc[4 * c + 2]);
-                acc[4 * c + 3] = fmaf(kk, x.w, acc[4 * c + 3]);
-            }
+        for (int u = 0; u < U; ++u) {
+            const int s = sb + u * M::KPER + kk;
+            float m = 1.f;
+            if (kv_mask && s < s1) m = kv_mask[(size_t)n * S + s] ? 1.f : 0.f;
+            const float ka = (s < s1) ? elu1(a[u]) * m : 0.f;
+            const float vb = (b[u] * m) / fS;                       // values / v_length (linear_attention.py:43)
+            ks += ka;
+            acc = M::mma(ka, vb, acc);
         }
     }
-    float* o = part + (((size_t)n * nchunk + ch) * HD + t) * (D + 1);
+    // ksum: add the token-parity classes held by the different lane groups
 #pragma unroll
-    for (int i = 0; i < D; ++i) o[i] = acc[i];
-    o[D] = ksum;
+    for (int d = D; d < 64; d <<= 1) ks += shfl_xor_f(ks, d);
+    float* o = part + (((size_t)n * nchunk + ch) * HD + h * D) * (D + 1);
+#pragma unroll
+    for (int r = 0; r < M::NACC; ++r) o[(size_t)M::row(r, kk) * (D + 1) + col] = acc[r];
+    if (kk == 0) o[(size_t)col * (D + 1) + D] = ks;
 }
 
 // kv[n][HD][D+1] = sum over chunks (fixed order).
@@ -79,52 +97,65 @@ __global__ void k_la_kv_reduce(const float* __restrict__ part, int nchunk, int p
     kv[(size_t)n * per_n + e] = s;
 }
 
-// grid (ceil(L / tok_per_block), N), block HD threads; thread (h, vch) keeps the KV column KV[h][:, vch]
-// and ksum[h][:] in registers and streams tokens.
+// out[l][h,v] = (sum_d Q'[l][h,d] KV[h][d][v]) / (sum_d Q'[l][h,d] ksum[h][d] + eps) * S.
+// One wave per (n, head, block of token tiles): D[m = token][n = v]; A = Q' loaded as contiguous channel runs per
+// lane, B = the head's KV columns held in registers for the whole block; the normaliser comes from a second MFMA
+// against a B whose columns all equal ksum, so it lands in the same (token, v) register layout as the numerator.
 template <int D>
-__global__ void k_la_apply(const float* __restrict__ q, const float* __restrict__ kv,
-                           const uint8_t* __restrict__ q_mask,  // optional [N][L]
-                           int L, int S, int HD, int tok_per_block, float eps, float* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* qs = sm;  // [LA_TOK][HD]
-    const int nblk = (L + tok_per_block - 1) / tok_per_block;
-    const int t = threadIdx.x, n = blockIdx.x / nblk, bx = blockIdx.x - n * nblk;
-    const int h = t / D, vch = t - h * D, hbase = h * D;
-    float kvc[D], ks[D];
-    const float* kvn = kv + (size_t)n * HD * (D + 1);
+__global__ __launch_bounds__(256) void k_la_apply(const float* __restrict__ q, const float* __restrict__ kv,
+                                                  const uint8_t* __restrict__ q_mask, int N, int L, int S, int H,
+                                                  int tiles_per_unit, float eps, float* __restrict__ out) {
+    typedef Mf<D> M;
+    constexpr int TT = D;                     // tokens per tile (32 or 16)
+    constexpr int NK = D / M::KPER;           // MFMA steps per tile (16 or 4) = channels per lane
+    const int lane = threadIdx.x & 63, col = lane & (D - 1), kk = lane >> M::SHIFT;
+    const int ntile = (L + TT - 1) / TT, nblk = (ntile + tiles_per_unit - 1) / tiles_per_unit;
+    const long unit = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (unit >= (long)N * nblk * H) return;
+    const int h = (int)(unit % H);
+    const int tb = (int)((unit / H) % nblk);
+    const int n = (int)(unit / ((long)H * nblk));
+    const int HD = H * D;
+    // B operands: this lane's channels are d = NK*kk + t, t = 0..NK-1
+    float bkv[NK], bks[NK];
+    const float* kvn = kv + ((size_t)n * HD + h * D) * (D + 1);
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-        kvc[d] = kvn[(size_t)(hbase + d) * (D + 1) + vch];
-        ks[d] = kvn[(size_t)(hbase + d) * (D + 1) + D];
+    for (int t = 0; t < NK; ++t) {
+        bkv[t] = kvn[(size_t)(NK * kk + t) * (D + 1) + col];
+        bks[t] = kvn[(size_t)(NK * kk + t) * (D + 1) + D];
     }
-    const int l0 = bx * tok_per_block, l1 = min(L, l0 + tok_per_block);
     const float fS = (float)S;
-    for (int lb = l0; lb < l1; lb += LA_TOK) {
-        const int nt = min(LA_TOK, l1 - lb);
-        __syncthreads();
+    for (int ti = tb * tiles_per_unit; ti < min(ntile, (tb + 1) * tiles_per_unit); ++ti) {
+        const int l = ti * TT + col;          // the token this lane feeds into the A operand
+        float qa[NK];
 #pragma unroll
-        for (int i = 0; i < LA_TOK; ++i) {
-            float qq = 0.f;
-            if (i < nt) {
-                float m = (q_mask && !q_mask[(size_t)n * L + lb + i]) ? 0.f : 1.f;
-                qq = elu1(q[((size_t)n * L + lb + i) * HD + t]) * m;
+        for (int t = 0; t < NK; ++t) qa[t] = 0.f;
+        if (l < L) {
+            const float* qp = q + ((size_t)n * L + l) * HD + h * D + NK * kk;
+            float m = 1.f;
+            if (q_mask) m = q_mask[(size_t)n * L + l] ? 1.f : 0.f;
+#pragma unroll
+            for (int t4 = 0; t4 < NK / 4; ++t4) {
+                const float4 x = *reinterpret_cast<const float4*>(qp + 4 * t4);
+                qa[4 * t4 + 0] = elu1(x.x) * m; qa[4 * t4 + 1] = elu1(x.y) * m;
+                qa[4 * t4 + 2] = elu1(x.z) * m; qa[4 * t4 + 3] = elu1(x.w) * m;
             }
-            qs[i * HD + t] = qq;
         }
-        __syncthreads();
-        for (int i = 0; i < nt; ++i) {
-            const float4* qr = reinterpret_cast<const float4*>(&qs[i * HD + hbase]);
-            float num = 0.f, den = 0.f;
+        typename M::acc_t num, den;
 #pragma unroll
-            for (int c = 0; c < D / 4; ++c) {
-                float4 x = qr[c];
-                num = fmaf(x.x, kvc[4 * c + 0], num); den = fmaf(x.x, ks[4 * c + 0], den);
-                num = fmaf(x.y, kvc[4 * c + 1], num); den = fmaf(x.y, ks[4 * c + 1], den);
-                num = fmaf(x.z, kvc[4 * c + 2], num); den = fmaf(x.z, ks[4 * c + 2], den);
-                num = fmaf(x.w, kvc[4 * c + 3], num); den = fmaf(x.w, ks[4 * c + 3], den);
+        for (int r = 0; r < M::NACC; ++r) { num[r] = 0.f; den[r] = 0.f; }
+#pragma unroll
+        for (int t = 0; t < NK; ++t) {
+            num = M::mma(qa[t], bkv[t], num);
+            den = M::mma(qa[t], bks[t], den);
+        }
+#pragma unroll
+        for (int r = 0; r < M::NACC; ++r) {
+            const int lo = ti * TT + M::row(r, kk);
+            if (lo < L) {
+                const float zz = 1.0f / (den[r] + eps);                              // linear_attention.py:46
+                out[((size_t)n * L + lo) * HD + h * D + col] = (num[r] * zz) * fS;   // :50
             }
-            float zz = 1.0f / (den + eps);                          // linear_attention.py:46
-            out[((size_t)n * L + lb + i) * HD + t] = (num * zz) * fS;  // :50
         }
     }
 }
@@ -133,20 +164,22 @@ template <int D>
 int launch_la(const float* q, const float* k, const float* v, int N, int L, int S, int H, const uint8_t* q_mask,
               const uint8_t* kv_mask, float eps, float* out, float* ws, hipStream_t stream) {
     const int HD = H * D;
-    // chunking: ~64 tokens per chunk keeps >= 64 blocks per image pair side at S = 4800
-    int tok_per_chunk = S >= 1024 ? 64 : S;
+    int tok_per_chunk = S >= 1024 ? 320 : S;
     int nchunk = (S + tok_per_chunk - 1) / tok_per_chunk;
     size_t per_n = (size_t)HD * (D + 1);
     float* part = ws;
     float* kv = ws + (size_t)N * nchunk * per_n;
-    size_t smem = (size_t)LA_TOK * HD * sizeof(float);
-    hipLaunchKernelGGL(k_la_kv_partial<D>, dim3(nchunk * N), dim3(HD), smem, stream, k, v, kv_mask, S, HD,
+    long units = (long)N * nchunk * H;
+    hipLaunchKernelGGL(k_la_kv_partial<D>, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, stream, k, v, kv_mask, N, S, H,
                        tok_per_chunk, nchunk, part);
     hipLaunchKernelGGL(k_la_kv_reduce, dim3((int)((per_n + 255) / 256) * N), dim3(256), 0, stream, part, nchunk,
                        (int)per_n, kv);
-    int tok_per_block = L >= 1024 ? 64 : L;
-    hipLaunchKernelGGL(k_la_apply<D>, dim3(((L + tok_per_block - 1) / tok_per_block) * N), dim3(HD), smem, stream, q, kv,
-                       q_mask, L, S, HD, tok_per_block, eps, out);
+    const int ntile = (L + D - 1) / D;
+    int tiles_per_unit = ntile >= 64 ? 8 : ntile;
+    int nblk = (ntile + tiles_per_unit - 1) / tiles_per_unit;
+    long aunits = (long)N * nblk * H;
+    hipLaunchKernelGGL(k_la_apply<D>, dim3((unsigned)((aunits + 3) / 4)), dim3(256), 0, stream, q, kv, q_mask, N, L, S, H,
+                       tiles_per_unit, eps, out);
     return far_check_launch();
 }
 
@@ -155,7 +188,7 @@ int launch_la(const float* q, const float* k, const float* v, int N, int L, int 
 extern "C" {
 
 size_t far_linear_attention_workspace_bytes(int N, int S, int H, int D) {
-    int tok_per_chunk = S >= 1024 ? 64 : S;
+    int tok_per_chunk = S >= 1024 ? 320 : S;
     int nchunk = (S + tok_per_chunk - 1) / tok_per_chunk;
     return ((size_t)N * nchunk + N) * (size_t)H * D * (D + 1) * sizeof(float);
 }
