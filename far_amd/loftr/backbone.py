@@ -4,6 +4,9 @@ Mirrors the architecture and PARAMETER NAMES of mp3d_loftr/src/loftr/backbone/re
 (BasicBlock, ResNetFPN_8_2) so reference checkpoints load.  The convolutions stay on the vendor path
 (MIOpen through torch) -- SURVEY.md section 2.1 #2: not a custom kernel; run it channels_last / bf16 for speed.
 """
+import contextlib
+
+import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -57,16 +60,23 @@ class ResNetFPN_8_2(nn.Module):
                 nn.init.constant_(m.weight, 1)
                 nn.init.constant_(m.bias, 0)
 
+    # Optional reduced precision for the fine (1/2-resolution) FPN branch only.  The coarse map x3_out -- the only
+    # input of the discrete matching decisions -- always comes from the fp32 trunk; the fine map only feeds the
+    # sub-pixel expectation.  None (default) = everything fp32 = the parity configuration.
+    fine_branch_dtype = None
+
     def forward(self, x):
         x0 = self.relu(self.bn1(self.conv1(x)))
         x1 = self.layer1(x0)
         x2 = self.layer2(x1)
         x3 = self.layer3(x2)
         x3_out = self.layer3_outconv(x3)
-        up3 = F.interpolate(x3_out, scale_factor=2., mode='bilinear', align_corners=True)
-        x2_out = self.layer2_outconv2(self.layer2_outconv(x2) + up3)
-        up2 = F.interpolate(x2_out, scale_factor=2., mode='bilinear', align_corners=True)
-        x1_out = self.layer1_outconv2(self.layer1_outconv(x1) + up2)
+        dt = self.fine_branch_dtype
+        with (torch.autocast('cuda', dtype=dt) if dt is not None else contextlib.nullcontext()):
+            up3 = F.interpolate(x3_out, scale_factor=2., mode='bilinear', align_corners=True)
+            x2_out = self.layer2_outconv2(self.layer2_outconv(x2) + up3)
+            up2 = F.interpolate(x2_out, scale_factor=2., mode='bilinear', align_corners=True)
+            x1_out = self.layer1_outconv2(self.layer1_outconv(x1) + up2)
         return [x3_out, x1_out]
 
 

@@ -64,9 +64,15 @@ class LoFTREncoderLayer(nn.Module):
         k = self.k_proj(source).view(bs, -1, self.nhead, self.dim)
         v = self.v_proj(source).view(bs, -1, self.nhead, self.dim)
         msg = self.attention(q, k, v, q_mask=x_mask, kv_mask=source_mask, loftr_preds=loftr_preds)
-        msg = self.norm1(self.merge(msg.view(bs, -1, self.nhead * self.dim)))
-        msg = self.norm2(self.mlp(torch.cat([x, msg], dim=2)))
-        return x + msg
+        msg = self.merge(msg.view(bs, -1, self.nhead * self.dim))
+        msg = ops.layernorm(msg, self.norm1.weight, self.norm1.bias, self.norm1.eps)                       # :61
+        # mlp[0](cat[x, msg]) without materialising the concatenation: the weight is split column-wise (:64)
+        C = x.shape[-1]
+        w0 = self.mlp[0].weight
+        h = torch.addmm(torch.mm(x.reshape(-1, C), w0[:, :C].t()), msg.reshape(-1, C), w0[:, C:].t())
+        h = self.mlp[2](torch.relu_(h)).view_as(x)
+        # norm2 and the residual `x + message` in one pass (:65-67)
+        return ops.layernorm(h, self.norm2.weight, self.norm2.bias, self.norm2.eps, residual=x.contiguous())
 
 
 class LocalFeatureTransformer(nn.Module):
@@ -197,7 +203,8 @@ class CrossBlock(nn.Module):
         B = b_s // 2
         x = x + self.pos_embed
         x1_in, x2_in = x[:B], x[B:]           # == x.reshape(-1, 2, h_w, nf)[:, 0/1] for the reference's B = 1
-        f1, f2 = self.cross_attn(self.norm1(x1_in), self.norm1(x2_in), intrinsics=intrinsics,
+        n1 = lambda t: ops.layernorm(t.contiguous(), self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        f1, f2 = self.cross_attn(n1(x1_in), n1(x2_in), intrinsics=intrinsics,
                                  loftr_preds=loftr_preds, inv_loftr_preds=inv_loftr_preds)
         f = torch.cat([f1.unsqueeze(1), f2.unsqueeze(1)], dim=1).reshape(b_s, -1, nf)
         return f + self.mlp(self.norm2(f))

@@ -187,3 +187,15 @@ def solve_pose_batch(kpts0, kpts1, offsets_host, K0, K1, inl_th, many_thr, prior
     _lib.check(rc, 'far_solver_f64')
     out.update(dbg)
     return out
+
+
+def layernorm(x, weight, bias, eps=1e-5, residual=None):
+    """K6.  LayerNorm over the last dim (+ residual).  x: (..., C) fp32 contiguous GPU tensor."""
+    lib = _lib.load()
+    C = x.shape[-1]
+    rows = x.numel() // C
+    y = torch.empty_like(x)
+    rc = lib.far_layernorm_f32(_p(x, torch.float32), _p(weight, torch.float32), _p(bias, torch.float32),
+                               _p(residual, torch.float32), rows, C, float(eps), _p(y), _stream())
+    _lib.check(rc, 'far_layernorm_f32')
+    return y

@@ -111,6 +111,15 @@ int far_linear_attention_f32(const float* q, const float* k, const float* v, int
                              far_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * K6  LayerNorm (+ fused residual) of the encoder layers and the head
+ * replaces src/loftr/loftr_module/transformer.py:61, :65-67 (norm1; norm2 + `x + message`), :342, :346, :426
+ * ------------------------------------------------------------------------------------------------- */
+
+/* y[r][:] = LayerNorm(x[r][:]; eps) * gamma + beta (+ res[r][:] when res != NULL).  x, res, y [rows][C] fp32. */
+int far_layernorm_f32(const float* x, const float* gamma, const float* beta, const float* res, long rows, int C,
+                      float eps, float* y, far_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * K4  batched essential-matrix solver (hypothesise / verify / decompose / cheirality), float64
  * replaces src/utils/metrics.py:80-174 (estimate_pose), third_party/prior_ransac/ransac.py:340-442
  *      (RANSAC.forward + verify + get_prior_estimate), cv_geometry.py:713-833 (run_8point),

@@ -64,3 +64,20 @@ def test_linear_attention(N, L, S, C):
     got = ops.linear_attention(*(torch.from_numpy(a).cuda() for a in (q, k, v)), 8).cpu().numpy()
     ref = oa.linear_attention(q, k, v, 8, dtype=np.float64)
     np.testing.assert_allclose(got, ref, atol=1e-5 * np.abs(ref).max(), rtol=1e-4)
+
+
+@pytest.mark.parametrize('rows,C,res', [(4800 * 3, 256, True), (1000, 256, False), (777 * 25, 128, True), (33, 512, False), (10, 200, True)])
+def test_layernorm(rows, C, res):
+    from far_amd import ops
+    rng = np.random.default_rng(C + rows)
+    x = (3 * rng.standard_normal((rows, C)) + 0.5).astype(np.float32)
+    g = rng.uniform(0.5, 1.5, C).astype(np.float32)
+    b = rng.standard_normal(C).astype(np.float32)
+    r = rng.standard_normal((rows, C)).astype(np.float32) if res else None
+    cu = lambda a: None if a is None else torch.from_numpy(a).cuda()
+    got = ops.layernorm(cu(x), cu(g), cu(b), 1e-5, cu(r)).cpu().numpy()
+    x64 = x.astype(np.float64)
+    ref = (x64 - x64.mean(1, keepdims=True)) / np.sqrt(x64.var(1, keepdims=True) + 1e-5) * g + b
+    if res:
+        ref = ref + r
+    np.testing.assert_allclose(got, ref, atol=2e-6 * np.abs(ref).max(), rtol=1e-5)

@@ -25,7 +25,15 @@ def run(dt):
     return d, tb
 
 d32, t32 = run(torch.float32)
-d16, t16 = run(torch.bfloat16)
+for fd in [torch.float16, torch.bfloat16]:
+    m.backbone.fine_branch_dtype = fd
+    df, tf = run(torch.float32)
+    print('fine-branch', fd, 'backbone ms %.1f (fp32 %.1f)' % (tf * 1e3, t32 * 1e3))
+    print('   coarse identical:', torch.equal(df['feats_c'], d32['feats_c']), ' ids identical:', torch.equal(df['i_ids'], d32['i_ids']) and torch.equal(df['j_ids'], d32['j_ids']))
+    print('   featmap_f rel dev', ((df['featmap_f0'].float() - d32['featmap_f0']).norm() / d32['featmap_f0'].norm()).item())
+    print('   mkpts1_f max abs dev px', (df['mkpts1_f'] - d32['mkpts1_f']).abs().max().item(), 'mean', (df['mkpts1_f'] - d32['mkpts1_f']).abs().mean().item())
+m.backbone.fine_branch_dtype = None
+d16, t16 = run(torch.float16)
 print('backbone ms fp32 %.1f bf16 %.1f' % (t32 * 1e3, t16 * 1e3))
 fc32, fc16 = d32['feats_c'], d16['feats_c']
 print('feats_c rel dev', ((fc32 - fc16).norm() / fc32.norm()).item())
