@@ -99,6 +99,24 @@ def kernel_rooflines(n_pairs):
     return out
 
 
+def pmc_traffic(kernel_label, n_pairs):
+    """HBM/fabric bytes per launch of the dominant kernel, from the committed PMC passes
+    (profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 x2 read correction).
+    Counters cannot be collected inside this process; the value is only reported when the committed measurement
+    was taken at the same launch geometry (batch 32), otherwise null."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+    if not os.path.exists(path) or n_pairs != 32:
+        return None
+    per = json.load(open(path))['per_launch']
+    name = kernel_label.split('[')[0]
+    grid = {'k_emm_pv_f32': 38 * n_pairs * 8 * 256, 'k_stats_f32': None}.get(name)
+    if name == 'k_stats_f32':
+        grid = 38 * n_pairs * (8 if 'K2' in kernel_label else 1) * 256
+    ent = per.get(f'{name}|grid={grid}')
+    return None if ent is None else {'bytes': ent['total_bytes'], 'read_bytes': ent['read_bytes'],
+                                     'write_bytes': ent['write_bytes'], 'source': 'profiles/r01_pmc_traffic.json'}
+
+
 def cpu_baseline(n_pairs, hyp):
     """The oracle (CPU restatement of the reference path, oracle/model.py) timed on this box's host cores."""
     import json as _json
@@ -174,7 +192,7 @@ def main():
         kr = kernel_rooflines(a.pairs)
         dom = max((k for k in kr if 'tflops' in kr[k] and not k.startswith('far_')), key=lambda k: kr[k]['ms'])
         roof = {'kernel': dom, 'bound': 'mfma', 'achieved': round(kr[dom]['tflops'], 2), 'peak': F32_MFMA_PEAK_TFLOPS,
-                'unit': 'TFLOP/s', 'frac': round(kr[dom]['frac'], 4), 'traffic': None,
+                'unit': 'TFLOP/s', 'frac': round(kr[dom]['frac'], 4), 'traffic': pmc_traffic(dom, a.pairs),
                 'launch_ms': round(kr[dom]['ms'], 3),
                 'note': 'f32-input MFMA (exact fp32) peak; algorithmic flops per launch / event-timed launch duration'}
         res = {

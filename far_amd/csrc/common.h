@@ -35,6 +35,22 @@ __device__ __forceinline__ void stagger_priority_by_wave_slot(int enable) {
     if ((hwid & 1u) == 0) __builtin_amdgcn_s_setprio(2);
 }
 
+// XCD-aware block -> (problem z, row block Ib) mapping for the tiled correlation kernels (1-D grid of nI * Z blocks).
+// Hardware places block b on XCD b % 8 (observed, speed only).  All nI row blocks of one problem re-read the same
+// column-side operand, so they are steered to ONE XCD's L2: measured HBM/fabric fetch of k_match_f32 at batch 32 was
+// 22x the algorithmic bytes with the naive (Ib fastest) order.  Falls back to the plain order when Z % 8 != 0.
+__device__ __forceinline__ void tile_coords(int nI, int Z, int& z, int& Ib) {
+    const int id = blockIdx.x;
+    if ((Z & 7) == 0) {
+        const int xcd = id & 7, li = id >> 3;
+        z = xcd + 8 * (li / nI);
+        Ib = li % nI;
+    } else {
+        z = id / nI;
+        Ib = id - z * nI;
+    }
+}
+
 // x / d for a loop-invariant divisor d, given r = 1.0f / d (IEEE).  q = fl(x r); e = fma(-d, q, x); q' = fma(e, r, q)
 // is the correctly rounded quotient (Markstein) except for divisors whose significand is all ones; 3 instructions
 // instead of the ~10 of the generic v_div_* sequence.

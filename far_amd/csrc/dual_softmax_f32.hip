@@ -62,7 +62,7 @@ __device__ __forceinline__ float sim_of(float acc, const SimParams& p) {
 // mask0/mask1 (optional, uint8 [Z][L] / [Z][S]): pair (i,j) is masked iff !(mask0[i] && mask1[j]).
 // --------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void k_stats_f32(
-    const float* __restrict__ f0, const float* __restrict__ f1, int L, int S, int C, SimParams sp,
+    const float* __restrict__ f0, const float* __restrict__ f1, int Z, int L, int S, int C, SimParams sp,
     const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1,
     float2* __restrict__ rowstat, float2* __restrict__ colpart) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -70,7 +70,9 @@ __global__ __launch_bounds__(256, 2) void k_stats_f32(
     float2* colx = reinterpret_cast<float2*>(smem_raw + sizeof(TileLds));  // [4][128]
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
-    const int z = blockIdx.y, Ib = blockIdx.x, nI = gridDim.x;
+    const int nI = (L + TILE_M - 1) / TILE_M;
+    int z, Ib;
+    tile_coords(nI, Z, z, Ib);
     const int i0 = Ib * TILE_M;
     const float* A = f0 + (size_t)z * L * C;
     const float* B = f1 + (size_t)z * S * C;
@@ -216,7 +218,7 @@ __global__ void k_colreduce(const float2* __restrict__ colpart, int nI, int S, f
 // Pass 2: recompute, P = softmax_col * softmax_row, conf store (optional), row/col best.
 // --------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void k_match_f32(
-    const float* __restrict__ f0, const float* __restrict__ f1, int L, int S, int C, SimParams sp,
+    const float* __restrict__ f0, const float* __restrict__ f1, int Z, int L, int S, int C, SimParams sp,
     const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1,
     const float2* __restrict__ rowstat, const float2* __restrict__ colstat,
     float* __restrict__ conf,  // optional [Z][L][S]
@@ -227,7 +229,9 @@ __global__ __launch_bounds__(256, 2) void k_match_f32(
     float* colx = reinterpret_cast<float*>(smem_raw + sizeof(TileLds));  // [4][128]
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
-    const int z = blockIdx.y, Ib = blockIdx.x, nI = gridDim.x;
+    const int nI = (L + TILE_M - 1) / TILE_M;
+    int z, Ib;
+    tile_coords(nI, Z, z, Ib);
     const int i0 = Ib * TILE_M;
     const float* A = f0 + (size_t)z * L * C;
     const float* B = f1 + (size_t)z * S * C;
@@ -478,7 +482,7 @@ int far_dual_softmax_stats_f32(const float* f0, const float* f1, int Z, int L, i
         hipFuncSetAttribute((const void*)k_match_f32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTileSmem);
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_stats_f32, dim3(nI, Z), dim3(256), kTileSmem, stream, f0, f1, L, S, C, sp, mask0, mask1,
+    hipLaunchKernelGGL(k_stats_f32, dim3(nI * Z), dim3(256), kTileSmem, stream, f0, f1, Z, L, S, C, sp, mask0, mask1,
                        rs, w.colpart);
     hipLaunchKernelGGL(k_colreduce, dim3((S + 255) / 256, Z), dim3(256), 0, stream, w.colpart, nI, S, cs);
     return far_check_launch();
@@ -507,7 +511,7 @@ int far_coarse_match_f32(const float* f0, const float* f1, int Z, int L, int S, 
     int nI = (L + TILE_M - 1) / TILE_M;
     int* counts = counts_out ? counts_out : w.counts;
     hipMemsetAsync(counts, 0, sizeof(int) * Z, stream);
-    hipLaunchKernelGGL(k_match_f32, dim3(nI, Z), dim3(256), kTileSmem, stream, f0, f1, L, S, C, sp, mask0, mask1,
+    hipLaunchKernelGGL(k_match_f32, dim3(nI * Z), dim3(256), kTileSmem, stream, f0, f1, Z, L, S, C, sp, mask0, mask1,
                        w.rowstat, w.colstat, conf_out, w.rowbest_v, w.rowbest_j, w.colbest_part);
     hipLaunchKernelGGL(k_finalize, dim3((L + 255) / 256, Z), dim3(256), 0, stream, w.rowbest_v, w.rowbest_j,
                        w.colbest_part, nI, L, S, thr, border, h0, w0, h1, w1, valid_hw, w.match_j, counts);

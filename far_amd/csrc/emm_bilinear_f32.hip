@@ -33,14 +33,16 @@ struct EmmLds {
 __global__ __launch_bounds__(256, 2) void k_emm_pv_f32(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     const float* __restrict__ pos,  // [N][6]
-    int N, float scale, const float2* __restrict__ rowstat, const float2* __restrict__ colstat,
+    int Z, int N, float scale, const float2* __restrict__ rowstat, const float2* __restrict__ colstat,
     float* __restrict__ T,          // [Z][N][70]
     int stagger) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     EmmLds& lds = *reinterpret_cast<EmmLds*>(smem_raw);
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
-    const int z = blockIdx.y, i0 = blockIdx.x * 128;
+    int z, Ib;
+    tile_coords((N + 127) / 128, Z, z, Ib);
+    const int i0 = Ib * 128;
     const float* Q = q + (size_t)z * N * EM_D;
     const float* K = k + (size_t)z * N * EM_D;
     const float* V = v + (size_t)z * N * EM_D;
@@ -205,7 +207,7 @@ int far_emm_pv_f32(const float* q, const float* k, const float* v, const float* 
         hipFuncSetAttribute((const void*)k_emm_pv_f32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(EmmLds));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_emm_pv_f32, dim3((N + 127) / 128, Z), dim3(256), sizeof(EmmLds), stream, q, k, v, pos, N,
+    hipLaunchKernelGGL(k_emm_pv_f32, dim3(((N + 127) / 128) * Z), dim3(256), sizeof(EmmLds), stream, q, k, v, pos, Z, N,
                        scale, (const float2*)rowstat, (const float2*)colstat, T_out, (far_get_tuning(0) >> 2) & 1);
     return far_check_launch();
 }

@@ -1,0 +1,36 @@
+"""HBM/fabric traffic per launch from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), corrected as
+MI355X_MICROARCH.md "HBM" prescribes: FETCH_SIZE counts 128-B requests at 64 B on gfx950 -> x2 (calibrated here on
+k_la_kv_partial / k_la_apply, whose byte counts are known exactly: 629 MB and 315 MB read, measured 2 x 307,261 KB
+and 2 x 158,943 KB); WRITE_SIZE matched the known byte counts 1:1.  Units of both counters: KiB.
+Usage: python tools/pmc_traffic.py fetch.db write.db > profiles/rNN_pmc_traffic.json"""
+import json
+import sqlite3
+import sys
+
+
+def load(path, counter):
+    cur = sqlite3.connect(path).cursor()
+    rows = cur.execute("select kernel_name, grid_size, avg(value), count(*) from counters_collection "
+                       "where counter_name=? group by kernel_name, grid_size", (counter,)).fetchall()
+    return {(k, g): (v, n) for k, g, v, n in rows}
+
+
+def short(name):
+    for key in ['k_stats_f32', 'k_match_f32', 'k_emm_pv_f32', 'k_la_kv_partial<32>', 'k_la_apply<32>', 'k_layernorm']:
+        if key in name:
+            return key
+    return None
+
+
+if __name__ == '__main__':
+    f, w = load(sys.argv[1], 'FETCH_SIZE'), load(sys.argv[2], 'WRITE_SIZE')
+    out = {}
+    for (k, g), (fv, n) in f.items():
+        s = short(k)
+        if s is None or (k, g) not in w:
+            continue
+        rd = 2.0 * fv * 1024
+        wr = w[(k, g)][0] * 1024
+        out[f'{s}|grid={g}'] = {'read_bytes': round(rd), 'write_bytes': round(wr), 'total_bytes': round(rd + wr), 'launches': n}
+    json.dump({'method': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on tools/kprobe.py all 32 2; '
+                         'read = 2 x FETCH_SIZE KiB, write = WRITE_SIZE KiB', 'per_launch': out}, sys.stdout, indent=1)
