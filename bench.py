@@ -187,6 +187,22 @@ def main():
     dt = parallel.max_over_ranks(dt, device=dev)          # the slowest rank defines the step time
     matches = float(last['b_ids'].numel()) / a.pairs
     ok_frac = float(last['solver_status'].float().mean().item())
+    # pose error of the solver and of the blended head output against the synthetic ground truth
+    # (pure lateral translation, no rotation): informational -- the banded synthetic pairs carry the usual
+    # small-baseline translation/rotation ambiguity; accuracy on Matterport needs the real checkpoint + data.
+    from far_amd import metrics as fm
+    from far_amd.pose6d import pose_mean_6d, pose_std_6d, rotation_6d_to_matrix
+    T_gt = torch.eye(4, dtype=torch.float64, device=dev).repeat(a.pairs, 1, 1)
+    T_gt[:, 0, 3] = -1.0
+    rt = last['loftr_rt'].reshape(-1, 3, 4)
+    te, Re, _ = fm.relative_pose_error_batch(T_gt, rt[:, :, :3], rt[:, :, 3])
+    reg = last['regressed_rt'].detach().float().cpu()
+    Rr = rotation_6d_to_matrix(reg[:, 3:] * pose_std_6d[3:] + pose_mean_6d[3:])
+    tr = reg[:, :3] * pose_std_6d[:3] + pose_mean_6d[:3]
+    te2, Re2, _ = fm.relative_pose_error_batch(T_gt.cpu(), Rr, tr)
+    pose_err = {'solver_median_R_deg': round(float(Re.median()), 3), 'solver_median_t_deg': round(float(te.median()), 3),
+                'head_median_R_deg': round(float(Re2.median()), 3), 'head_median_t_deg': round(float(te2.median()), 3),
+                'note': 'vs synthetic GT (R=I, t=-x); random-weight head; Matterport accuracy pending (no ckpt/data offline)'}
 
     if rank == 0:
         kr = kernel_rooflines(a.pairs)
@@ -203,7 +219,7 @@ def main():
             'config': {'workload': 'Matterport3D-shaped eval (BASELINE configs[1]): batch 32 pairs @ 640x480 per GPU, '
                                    'LoFTR match + 8-pt prior-RANSAC solve (x2 rounds) + EMM head (x2), seeded random weights',
                        'pairs_per_gpu': a.pairs, 'hypotheses': a.hyp, 'fine_pred_steps': 2,
-                       'matches_per_pair': round(matches, 1), 'solver_success_frac': ok_frac,
+                       'matches_per_pair': round(matches, 1), 'solver_success_frac': ok_frac, 'pose_error': pose_err,
                        'parallelism': f'dp{world} (independent pairs, no data-path collective)'},
             'roofline': roof,
             'kernels': {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in kr.items()},

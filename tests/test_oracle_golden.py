@@ -249,3 +249,18 @@ def test_g8_state_dict_manifest_matches_reference():
     assert sum(p.numel() for p in m.parameters()) == 51092731
     # checkpoints are stored under 'matcher.' (lightning_loftr.py:58-75): the prefix strip must work
     m.load_state_dict({'matcher.' + k: v for k, v in sd.items()})
+
+
+# ------------------------------------------------------------------------------------------------ G9
+def test_g9_pose_metrics_oracle_and_product():
+    from far_amd import metrics as fm
+    from oracle import metrics as omx
+    g = load('g9_metrics')
+    for b in range(len(g['T'])):
+        np.testing.assert_allclose(omx.relative_pose_error(g['T'][b], g['R'][b], g['t'][b]), g['errs'][b], rtol=1e-12, atol=1e-10)
+    te, Re, ta = fm.relative_pose_error_batch(torch.from_numpy(g['T']), torch.from_numpy(g['R']), torch.from_numpy(g['t']))
+    np.testing.assert_allclose(np.stack([te.numpy(), Re.numpy(), ta.numpy()], 1), g['errs'], rtol=1e-7, atol=2e-5)   # acos near 0 deg amplifies 1-ulp differences of the trace
+    auc = fm.error_auc(np.maximum(g['errs'][:, 0], g['errs'][:, 1]))
+    np.testing.assert_allclose([auc['auc@5'], auc['auc@10'], auc['auc@20']], g['auc'], rtol=1e-12)
+    agg = fm.aggregate_pose_metrics(g['errs'][:, 0], g['errs'][:, 1], g['errs'][:, 2], np.ones(len(g['T'])))
+    assert agg['dset size'] == len(g['T']) and agg['rot median err'] == np.round(np.median(g['errs'][:, 1]), 2)

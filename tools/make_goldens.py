@@ -205,6 +205,25 @@ def g7_full(m):
          featmap_f0_sample=data['featmap_f0'][:, ::16, ::31, ::37].numpy())
 
 
+def g9_metrics():
+    """relative_pose_error (metrics.py:17-36) and error_auc (:307-324)."""
+    from src.utils.metrics import relative_pose_error, error_auc
+    rng = np.random.default_rng(19)
+    B = 40
+    Ts, Rs, ts, out = [], [], [], []
+    for b in range(B):
+        _, _, _, Rg, tg = two_view_scene(20, seed=100 + b)
+        _, _, _, Re, te = two_view_scene(20, seed=100 + b + (b % 3))
+        T = np.eye(4); T[:3, :3] = Rg; T[:3, 3] = tg * rng.uniform(0.5, 3)
+        te = te * rng.uniform(0.5, 3) * (1 if b % 4 else -1)
+        Ts.append(T); Rs.append(Re); ts.append(te)
+        out.append(relative_pose_error(T, Re, te, ignore_gt_t_thr=0.0))
+    out = np.array(out, np.float64)
+    auc = error_auc(np.maximum(out[:, 0], out[:, 1]), [5, 10, 20])
+    save('g9_metrics', T=np.stack(Ts), R=np.stack(Rs), t=np.stack(ts), errs=out,
+         auc=np.array([auc['auc@5'], auc['auc@10'], auc['auc@20']]))
+
+
 def g8_manifest(m):
     man = {k: list(v.shape) for k, v in m.state_dict().items()}
     with open(os.path.join(OUT, 'g8_state_dict_manifest.json'), 'w') as f:
@@ -215,7 +234,11 @@ def g8_manifest(m):
 if __name__ == '__main__':
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == 'g9':
+        g9_metrics()
+        sys.exit(0)
     g1_coarse()
+    g9_metrics()
     g5_solver()
     g6_pose6d()
     model, _ = ref_model()
