@@ -3,6 +3,7 @@
 import torch
 import torch.nn as nn
 
+from .. import autograd_ops as ag
 from .. import ops
 
 
@@ -25,9 +26,8 @@ class CoarseMatching(nn.Module):
     def forward(self, feat_c0, feat_c1, data, mask_c0=None, mask_c1=None):
         """feat_c0 [N, L, C], feat_c1 [N, S, C]; updates data with conf_matrix (optional), b_ids, i_ids,
         j_ids, gt_mask, m_bids, mkpts0_c, mkpts1_c, mconf (coarse_matching.py:144-147, :243-263)."""
-        if self.training:
-            raise NotImplementedError('training-time sampling/padding (coarse_matching.py:199-240) and the '
-                                      'backward of K1 are not implemented in this round')
+        if self.training or ag.needs_grad(feat_c0, feat_c1):
+            return self._forward_train(feat_c0, feat_c1, data, mask_c0, mask_c1)
         hw0, hw1 = data['hw0_c'], data['hw1_c']
         valid_hw = None
         as_u8 = lambda m: None if m is None else m.to(torch.uint8).contiguous()
@@ -51,3 +51,58 @@ class CoarseMatching(nn.Module):
             'mkpts0_c': out['mkpts0_c'], 'mkpts1_c': out['mkpts1_c'], 'mconf': mconf,
             'match_counts': out['counts'],   # per-pair M (host), reused by the batched solver
         })
+
+    # ------------------------------------------------------------------------------------------------------
+    # training: conf_matrix must exist and be differentiable (focal loss, loftr_loss.py:307-311); K1 is
+    # forward-only this round, so the matrix comes from the vendor ops and the selection/sampling below is torch.
+    # ------------------------------------------------------------------------------------------------------
+    def _forward_train(self, feat_c0, feat_c1, data, mask_c0=None, mask_c1=None):
+        if 'mask0' in data:
+            raise NotImplementedError('padded-mask datasets are not wired into the training path yet')
+        conf = ag.conf_matrix(feat_c0, feat_c1, self.temperature, mask_c0, mask_c1)
+        data.update({'conf_matrix': conf})
+        data.update(**self._get_coarse_match_train(conf.detach(), data))
+
+    @torch.no_grad()
+    def _get_coarse_match_train(self, conf, data):
+        """coarse_matching.py:149-265 including the training-time sampling / GT padding (:199-240).  The two
+        torch.randint draws are issued in the reference's order with the reference's arguments, so a seeded
+        generator reproduces its choices."""
+        N, L, S = conf.shape
+        h0, w0 = data['hw0_c']
+        h1, w1 = data['hw1_c']
+        dev = conf.device
+        mask = (conf > self.thr).view(N, h0, w0, h1, w1).clone()
+        b = self.border_rm
+        if b > 0:
+            mask[:, :b] = False; mask[:, :, :b] = False; mask[:, :, :, :b] = False; mask[:, :, :, :, :b] = False
+            mask[:, -b:] = False; mask[:, :, -b:] = False; mask[:, :, :, -b:] = False; mask[:, :, :, :, -b:] = False
+        mask = mask.view(N, L, S)
+        mask = mask * (conf == conf.max(dim=2, keepdim=True)[0]) * (conf == conf.max(dim=1, keepdim=True)[0])
+        mask_v, all_j = mask.max(dim=2)
+        b_ids, i_ids = torch.where(mask_v)
+        j_ids = all_j[b_ids, i_ids]
+        mconf = conf[b_ids, i_ids, j_ids]
+        if self.training:
+            n_train = int(N * max(L, S) * self.train_coarse_percent)                       # :205-210
+            n_pred = len(b_ids)
+            assert self.train_pad_num_gt_min < n_train, "min-num-gt-pad should be less than num-train-matches"
+            if n_pred <= n_train - self.train_pad_num_gt_min:                              # :216-222
+                pred_idx = torch.arange(n_pred, device=dev)
+            else:
+                pred_idx = torch.randint(n_pred, (n_train - self.train_pad_num_gt_min,), device=dev)
+            gt_idx = torch.randint(len(data['spv_b_ids']), (max(n_train - n_pred, self.train_pad_num_gt_min),),
+                                   device=dev)                                             # :225-229
+            zeros = torch.zeros(len(data['spv_b_ids']), device=dev)                        # :230
+            b_ids = torch.cat([b_ids[pred_idx], data['spv_b_ids'][gt_idx]])
+            i_ids = torch.cat([i_ids[pred_idx], data['spv_i_ids'][gt_idx]])
+            j_ids = torch.cat([j_ids[pred_idx], data['spv_j_ids'][gt_idx]])
+            mconf = torch.cat([mconf[pred_idx], zeros[gt_idx]])
+        scale = data['hw0_i'][0] / data['hw0_c'][0]
+        s0 = scale * data['scale0'][b_ids] if 'scale0' in data else scale
+        s1 = scale * data['scale1'][b_ids] if 'scale1' in data else scale
+        mk0 = torch.stack([i_ids % w0, torch.div(i_ids, w0, rounding_mode='floor')], dim=1) * s0
+        mk1 = torch.stack([j_ids % w1, torch.div(j_ids, w1, rounding_mode='floor')], dim=1) * s1
+        keep = mconf != 0
+        return {'b_ids': b_ids, 'i_ids': i_ids, 'j_ids': j_ids, 'gt_mask': mconf == 0, 'm_bids': b_ids[keep],
+                'mkpts0_c': mk0[keep], 'mkpts1_c': mk1[keep], 'mconf': mconf[keep]}

@@ -3,6 +3,7 @@
 import torch
 import torch.nn as nn
 
+from .. import autograd_ops as ag
 from .. import ops
 
 
@@ -30,8 +31,12 @@ class FinePreprocess(nn.Module):
             e = torch.empty(0, W ** 2, self.d_model_f, device=feat_f0.device)
             return e, e.clone()
         # direct gather of the M x 25 x C window values instead of unfolding both full maps (:40-47)
-        w0 = ops.fine_gather(feat_f0.float(), b, i, data['hw0_c'][1], W, stride)
-        w1 = ops.fine_gather(feat_f1.float(), b, j, data['hw1_c'][1], W, stride)
+        if ag.needs_grad(feat_f0, feat_f1):
+            w0 = ag.fine_windows(feat_f0, b, i, W, stride)
+            w1 = ag.fine_windows(feat_f1, b, j, W, stride)
+        else:
+            w0 = ops.fine_gather(feat_f0.float(), b, i, data['hw0_c'][1], W, stride)
+            w1 = ops.fine_gather(feat_f1.float(), b, j, data['hw1_c'][1], W, stride)
         if self.cat_c_feat:
             c_win = self.down_proj(torch.cat([feat_c0[b, i], feat_c1[b, j]], 0))     # [2M, C]
             both = torch.cat([torch.cat([w0, w1], 0), c_win.unsqueeze(1).expand(-1, W ** 2, -1)], -1)

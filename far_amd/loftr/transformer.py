@@ -18,6 +18,7 @@ from functools import partial
 import torch
 import torch.nn as nn
 
+from .. import autograd_ops as ag
 from .. import ops
 from ..pose6d import pose_mean_6d, pose_std_6d
 
@@ -32,6 +33,9 @@ class LinearAttention(nn.Module):
     def forward(self, queries, keys, values, q_mask=None, kv_mask=None, loftr_preds=None):
         N, L, H, D = queries.shape
         S = keys.shape[1]
+        if ag.needs_grad(queries, keys, values):      # training: vendor ops + autograd (kernels are forward-only)
+            return ag.linear_attention(queries.reshape(N, L, H * D), keys.reshape(N, S, H * D),
+                                       values.reshape(N, S, H * D), H, q_mask, kv_mask, self.eps).view(N, L, H, D)
         as_u8 = lambda m: None if m is None else m.to(torch.uint8).contiguous()
         out = ops.linear_attention(queries.reshape(N, L, H * D), keys.reshape(N, S, H * D),
                                    values.reshape(N, S, H * D), H, as_u8(q_mask), as_u8(kv_mask), self.eps)
@@ -65,6 +69,9 @@ class LoFTREncoderLayer(nn.Module):
         v = self.v_proj(source).view(bs, -1, self.nhead, self.dim)
         msg = self.attention(q, k, v, q_mask=x_mask, kv_mask=source_mask, loftr_preds=loftr_preds)
         msg = self.merge(msg.view(bs, -1, self.nhead * self.dim))
+        if ag.needs_grad(msg, x, self.norm1.weight):
+            msg = self.norm2(self.mlp(torch.cat([x, self.norm1(msg)], dim=2)))                             # :61-66
+            return x + msg
         msg = ops.layernorm(msg, self.norm1.weight, self.norm1.bias, self.norm1.eps)                       # :61
         # mlp[0](cat[x, msg]) without materialising the concatenation: the weight is split column-wise (:64)
         C = x.shape[-1]
@@ -161,7 +168,10 @@ class CrossAttention(nn.Module):
         vv = v.reshape(2 * B * h, N, d)
         if self.pos6.shape[0] != N:
             raise ValueError(f'the head is tied to a 60x80 coarse grid (N=4800), got N={N} (transformer.py:194)')
-        F, _ = ops.emm_bilinear(qq, kk, vv, self.pos6, self.scale)  # (2Bh, 70, 70)
+        if ag.needs_grad(qq, kk, vv):
+            F = ag.bilinear_attention(qq, kk, vv, self.pos6, self.scale)
+        else:
+            F, _ = ops.emm_bilinear(qq, kk, vv, self.pos6, self.scale)  # (2Bh, 70, 70)
         F = F.view(2, B, h, d + 6, d + 6)
         # raw reshape of (B, h, 70, 70) to (B, 280, 70), then transpose (:294-295)
         f1 = F[0].reshape(B, C + 6 * h, (C + 6 * h) // h).transpose(-2, -1)
@@ -203,7 +213,10 @@ class CrossBlock(nn.Module):
         B = b_s // 2
         x = x + self.pos_embed
         x1_in, x2_in = x[:B], x[B:]           # == x.reshape(-1, 2, h_w, nf)[:, 0/1] for the reference's B = 1
-        n1 = lambda t: ops.layernorm(t.contiguous(), self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        if ag.needs_grad(x, self.norm1.weight):
+            n1 = self.norm1
+        else:
+            n1 = lambda t: ops.layernorm(t.contiguous(), self.norm1.weight, self.norm1.bias, self.norm1.eps)
         f1, f2 = self.cross_attn(n1(x1_in), n1(x2_in), intrinsics=intrinsics,
                                  loftr_preds=loftr_preds, inv_loftr_preds=inv_loftr_preds)
         f = torch.cat([f1.unsqueeze(1), f2.unsqueeze(1)], dim=1).reshape(b_s, -1, nf)

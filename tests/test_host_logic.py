@@ -43,8 +43,9 @@ def test_config_matches_far_eval_setting():
     assert r.TRAINER.RANSAC_PIXEL_THR == 0.5 and r.LOFTR.SOLVER == 'prior_ransac'
 
 
-def test_training_mode_raises_instead_of_guessing():
+def test_inference_on_cpu_raises_instead_of_falling_back():
+    # no grad, eval mode, CPU tensors: the kernel path is the only path and it needs the GPU
     from far_amd.loftr import CoarseMatching
-    m = CoarseMatching(far_eval_config()['match_coarse']).train()
-    with pytest.raises(NotImplementedError):
+    m = CoarseMatching(far_eval_config()['match_coarse']).eval()
+    with torch.no_grad(), pytest.raises(_lib.FarHipError):
         m(torch.zeros(1, 4, 32), torch.zeros(1, 4, 32), {'hw0_c': (2, 2), 'hw1_c': (2, 2), 'hw0_i': (16, 16)})

@@ -212,3 +212,41 @@ def test_head_feature_cache_is_exact(model):
         b3 = reg(f0, f1, loftr_preds=lp, inv_loftr_preds=lp)[0]
     assert torch.equal(a1, b1) and torch.equal(a2, b2)
     assert not torch.equal(b3, b1)
+
+
+def test_training_step_on_gpu(model):
+    """Training-mode forward + backward on the GPU (differentiable vendor-op path, far_amd/autograd_ops.py) against
+    golden G10 from the reference: the sampling-independent quantities must agree; all gradients must be finite."""
+    import copy
+    import importlib
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(G), '..', 'tests'))
+    from tests.test_training_cpu import _train_helpers
+    h = _train_helpers()
+    g = np.load(os.path.join(G, 'g10_training.npz'))
+    m = copy.deepcopy(model)
+    im0, im1, ii, jj, rt = h.train_inputs()
+    data = {'image0': torch.from_numpy(im0).cuda(), 'image1': torch.from_numpy(im1).cuda(),
+            'spv_b_ids': torch.zeros(len(ii), dtype=torch.int64).cuda(), 'spv_i_ids': torch.from_numpy(ii).cuda(),
+            'spv_j_ids': torch.from_numpy(jj).cuda()}
+    m.train()
+    torch.manual_seed(123)
+    m(data, train=True)
+    assert data['conf_matrix'].requires_grad and data['expec_f'].requires_grad
+    data.update({'loftr_rt': torch.from_numpy(rt).cuda(), 'num_correspondences': torch.tensor([731]).cuda(),
+                 'num_correspondences_before_ransac': torch.tensor([1500]).cuda(),
+                 'inliers_best_tight': torch.tensor([410]).cuda(), 'inliers_best_ultra_tight': torch.tensor([57]).cuda()})
+    m.forward_rt_prediction(data)
+    loss_c = -torch.log(data['conf_matrix'][0, data['spv_i_ids'], data['spv_j_ids']] + 1e-6).mean()
+    loss_rt = data['regressed_rt'].pow(2).sum()
+    (loss_c + data['expec_f'].pow(2).mean() + loss_rt).backward()
+    np.testing.assert_allclose(loss_c.item(), g['losses'][0], rtol=1e-3)
+    np.testing.assert_allclose(loss_rt.item(), g['losses'][2], rtol=5e-3)
+    np.testing.assert_allclose(data['regressed_rt'].detach().cpu().numpy(), g['regressed_rt'],
+                               atol=2e-3 * np.abs(g['regressed_rt']).max(), rtol=2e-3)
+    n_grad = 0
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            assert torch.isfinite(p.grad).all(), k
+            n_grad += 1
+    assert n_grad >= 230

@@ -1,0 +1,116 @@
+"""Training path (BASELINE configs[2]) on CPU: the differentiable vendor-op path of far_amd vs golden G10, which
+tools/make_goldens.py produced by running the REFERENCE's training-mode forward + backward.  Also a 2-rank gloo DDP
+step (gradient all-reduce = the one exchange step of the path).  The HIP kernels are forward-only this round; this
+is the path train.py would execute (far_amd/autograd_ops.py)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from far_amd import synth
+from far_amd.config import far_eval_config
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
+G = os.path.join(ROOT, 'tests', 'golden')
+
+
+def _train_helpers():
+    """train_inputs / train_step / GRAD_KEYS are shared with the golden generator; import them without running it
+    (the reference shim is only needed when the module's __main__ runs)."""
+    import importlib.util
+    import types
+    src = open(os.path.join(ROOT, 'tools', 'make_goldens.py')).read()
+    start = src.index('def train_inputs():')
+    end = src.index('def g10_training(m):')
+    mod = types.ModuleType('train_helpers')
+    mod.__dict__.update({'np': np, 'torch': torch, 'synth': synth})
+    exec(src[start:end], mod.__dict__)
+    return mod
+
+
+@pytest.mark.timeout(900)
+def test_training_forward_backward_matches_reference():
+    from far_amd.loftr import LoFTR
+    h = _train_helpers()
+    g = np.load(os.path.join(G, 'g10_training.npz'))
+    m = LoFTR(far_eval_config())
+    synth.load_synthetic(m, seed=0)
+    im0, im1, ii, jj, rt = h.train_inputs()
+    data, losses = h.train_step(m, im0, im1, ii, jj, rt)
+    # the training-time sampling (two randint draws) reproduces the reference's choice under the same seed
+    for k in ['b_ids', 'i_ids', 'j_ids']:
+        np.testing.assert_array_equal(data[k].numpy(), g[k])
+    assert len(data['mconf']) == int(g['n_mconf'])
+    np.testing.assert_allclose([l.item() for l in losses], g['losses'], rtol=2e-4)
+    np.testing.assert_allclose(data['expec_f'][:64].detach().numpy(), g['expec_f_head'], atol=2e-4)
+    np.testing.assert_allclose(data['regressed_rt'].detach().numpy(), g['regressed_rt'],
+                               atol=1e-3 * np.abs(g['regressed_rt']).max(), rtol=1e-3)
+    P = dict(m.named_parameters())
+    for n, k in enumerate(h.GRAD_KEYS):
+        gr = P[k].grad
+        assert gr is not None, k
+        np.testing.assert_allclose(gr.norm().item(), g['grad_norms'][n], rtol=5e-3, err_msg=k)
+        s = gr.reshape(-1)[:: max(1, gr.numel() // 8)][:8].numpy()
+        np.testing.assert_allclose(s, g['grad_samples'][n], rtol=2e-2, atol=2e-3 * np.abs(g['grad_samples'][n]).max() + 1e-7, err_msg=k)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _ddp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from far_amd.loftr import LoFTR
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        cfg = far_eval_config()
+        cfg['regress_rt'] = False                      # matcher only: keeps the CPU test small
+        cfg['coarse']['layer_names'] = ['self', 'cross']
+        m = LoFTR(cfg)
+        synth.load_synthetic(m, seed=0)
+        m.train()
+        ddp = DDP(m)                                   # gradient all-reduce over the process group
+        im0, im1 = synth.synth_image_pair(1, seed=50 + rank, hw=(96, 128), disparities=(8,))   # a DIFFERENT pair per rank
+        ii = torch.arange(12 * 16)
+        data = {'image0': torch.from_numpy(im0), 'image1': torch.from_numpy(im1),
+                'spv_b_ids': torch.zeros(len(ii), dtype=torch.int64), 'spv_i_ids': ii, 'spv_j_ids': ii}
+        m.coarse_matching.train_pad_num_gt_min = 8
+        ddp(data, train=True)
+        loss = -torch.log(data['conf_matrix'][0, ii, ii] + 1e-6).mean() + data['expec_f'].pow(2).mean()
+        loss.backward()
+        g = m.loftr_coarse.layers[0].q_proj.weight.grad
+        gb = m.backbone.conv1.weight.grad
+        q.put((rank, float(loss), float(g.double().sum()), float(g.norm()), float(gb.norm())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_ddp_two_ranks_gloo_gradient_allreduce():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=500) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, l0, s0, n0, b0), (_, l1, s1, n1, b1) = res
+    assert l0 != l1                                      # different data per rank ...
+    assert s0 == pytest.approx(s1, rel=1e-6) and n0 == pytest.approx(n1, rel=1e-6)   # ... identical averaged grads
+    assert b0 == pytest.approx(b1, rel=1e-6) and n0 > 0

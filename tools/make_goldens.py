@@ -224,6 +224,69 @@ def g9_metrics():
          auc=np.array([auc['auc@5'], auc['auc@10'], auc['auc@20']]))
 
 
+def train_inputs():
+    """Shared by the generator and tests/test_training_cpu.py: one synthetic pair, GT coarse matches from the known
+    band disparities, fake solver outputs."""
+    im0, im1 = synth.synth_image_pair(1, seed=0)
+    disp = (8, 40, 72)
+    ii, jj = [], []
+    for y in range(60):
+        d = disp[min(2, (y * 8) // 160)] // 8
+        for x in range(80):
+            if 0 <= x - d < 80:
+                ii.append(y * 80 + x)
+                jj.append(y * 80 + x - d)
+    ang = 0.3
+    R = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+    rt = np.concatenate([R, np.array([0.6, -0.1, 0.79])[:, None]], 1)
+    return im0, im1, np.array(ii, np.int64), np.array(jj, np.int64), rt
+
+
+GRAD_KEYS = ['backbone.conv1.weight', 'backbone.layer1.0.conv1.weight', 'backbone.layer3.1.bn2.weight',
+             'backbone.layer3_outconv.weight', 'backbone.layer1_outconv2.3.weight',
+             'loftr_coarse.layers.0.q_proj.weight', 'loftr_coarse.layers.5.mlp.2.weight', 'loftr_coarse.layers.3.norm1.bias',
+             'fine_preprocess.merge_feat.weight', 'loftr_fine.layers.1.v_proj.weight',
+             'loftr_regress.loftr.layers.0.k_proj.weight', 'loftr_regress.emm.cross_attn.qkv.weight',
+             'loftr_regress.emm.pos_embed', 'loftr_regress.encoder.0.weight', 'loftr_regress.moe_predictor.4.weight',
+             'loftr_regress.pose_regressor_simple_moe.2.bias']
+
+
+def train_step(m, im0, im1, ii, jj, rt):
+    """One training-mode forward + backward with a synthetic loss touching conf_matrix, expec_f and regressed_rt."""
+    data = {'image0': torch.from_numpy(im0), 'image1': torch.from_numpy(im1),
+            'spv_b_ids': torch.zeros(len(ii), dtype=torch.int64), 'spv_i_ids': torch.from_numpy(ii),
+            'spv_j_ids': torch.from_numpy(jj)}
+    m.train()
+    torch.manual_seed(123)
+    m(data, train=True)
+    data.update({'loftr_rt': torch.from_numpy(rt), 'num_correspondences': torch.tensor([731]),
+                 'num_correspondences_before_ransac': torch.tensor([1500]), 'inliers_best_tight': torch.tensor([410]),
+                 'inliers_best_ultra_tight': torch.tensor([57])})
+    m.forward_rt_prediction(data)
+    conf = data['conf_matrix']
+    loss_c = -torch.log(conf[0, data['spv_i_ids'], data['spv_j_ids']] + 1e-6).mean()
+    loss_f = data['expec_f'].pow(2).mean()
+    loss_rt = data['regressed_rt'].pow(2).sum()
+    loss = loss_c + loss_f + loss_rt
+    m.zero_grad()
+    loss.backward()
+    return data, (loss_c, loss_f, loss_rt)
+
+
+def g10_training(m):
+    """Training-mode forward/backward through the reference: CoarseMatching train sampling (coarse_matching.py:199-240),
+    differentiable conf_matrix / expec_f / regressed_rt, parameter gradients."""
+    im0, im1, ii, jj, rt = train_inputs()
+    data, losses = train_step(m, im0, im1, ii, jj, rt)
+    P = dict(m.named_parameters())
+    gn = np.array([P[k].grad.norm().item() for k in GRAD_KEYS])
+    gs = np.stack([P[k].grad.reshape(-1)[:: max(1, P[k].numel() // 8)][:8].numpy() for k in GRAD_KEYS])
+    save('g10_training', losses=np.array([l.item() for l in losses]), b_ids=data['b_ids'].numpy(), i_ids=data['i_ids'].numpy(),
+         j_ids=data['j_ids'].numpy(), n_mconf=len(data['mconf']), expec_f_head=data['expec_f'][:64].detach().numpy(),
+         regressed_rt=data['regressed_rt'].detach().numpy(), grad_norms=gn, grad_samples=gs)
+    m.eval()
+
+
 def g8_manifest(m):
     man = {k: list(v.shape) for k, v in m.state_dict().items()}
     with open(os.path.join(OUT, 'g8_state_dict_manifest.json'), 'w') as f:
@@ -237,6 +300,9 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'g9':
         g9_metrics()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'g10':
+        g10_training(ref_model()[0])
+        sys.exit(0)
     g1_coarse()
     g9_metrics()
     g5_solver()
@@ -247,3 +313,4 @@ if __name__ == '__main__':
     g3_encoder(model)
     g4_head(model)
     g7_full(model)
+    g10_training(model)
