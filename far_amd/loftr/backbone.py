@@ -10,6 +10,19 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import ops
+
+
+def _fold(bn):
+    """Inference BatchNorm as a per-channel affine map: y = x * scale + shift."""
+    scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+    return scale.contiguous(), (bn.bias - bn.running_mean * scale).contiguous()
+
+
+def _fused_ok(m, x):
+    """The fused epilogues (K7/K8) apply to inference on fp32 channels_last GPU tensors only."""
+    return (not m.training) and (not torch.is_grad_enabled()) and x.is_cuda and x.dtype == torch.float32
+
 
 def _c1(i, o, s=1):
     return nn.Conv2d(i, o, 1, stride=s, padding=0, bias=False)
@@ -30,6 +43,12 @@ class BasicBlock(nn.Module):
         self.downsample = None if stride == 1 else nn.Sequential(_c1(in_planes, planes, stride), nn.BatchNorm2d(planes))
 
     def forward(self, x):
+        if _fused_ok(self, x):
+            y = ops.affine_act(self.conv1(x), *_fold(self.bn1), act='relu')
+            y = self.conv2(y)
+            if self.downsample is not None:
+                x = ops.affine_act(self.downsample[0](x), *_fold(self.downsample[1]), act='none')
+            return ops.affine_act(y, *_fold(self.bn2), residual=x, act='relu')       # relu(x + bn2(conv2(.)))
         y = self.bn2(self.conv2(self.relu(self.bn1(self.conv1(x)))))
         if self.downsample is not None:
             x = self.downsample(x)
@@ -65,7 +84,23 @@ class ResNetFPN_8_2(nn.Module):
     # sub-pixel expectation.  None (default) = everything fp32 = the parity configuration.
     fine_branch_dtype = None
 
+    def _forward_fused(self, x):
+        x0 = ops.affine_act(self.conv1(x), *_fold(self.bn1), act='relu')
+        x1 = self.layer1(x0)
+        x2 = self.layer2(x1)
+        x3 = self.layer3(x2)
+        x3_out = self.layer3_outconv(x3)
+        o2, o1 = self.layer2_outconv2, self.layer1_outconv2
+        y = ops.upsample2x_add(x3_out, self.layer2_outconv(x2))
+        y = ops.affine_act(o2[0](y), *_fold(o2[1]), act='leaky', slope=o2[2].negative_slope)
+        x2_out = o2[3](y)
+        y = ops.upsample2x_add(x2_out, self.layer1_outconv(x1))
+        y = ops.affine_act(o1[0](y), *_fold(o1[1]), act='leaky', slope=o1[2].negative_slope)
+        return [x3_out, o1[3](y)]
+
     def forward(self, x):
+        if self.fine_branch_dtype is None and _fused_ok(self, x):
+            return self._forward_fused(x)
         x0 = self.relu(self.bn1(self.conv1(x)))
         x1 = self.layer1(x0)
         x2 = self.layer2(x1)

@@ -49,7 +49,8 @@ class LoFTR(nn.Module):
             x = torch.cat([data['image0'], data['image1']], dim=0)
             if self.backbone_dtype != torch.float32:
                 x = x.to(self.backbone_dtype)
-            x = x.contiguous(memory_format=torch.channels_last)
+            if self.backbone_dtype != torch.float32:
+                x = x.contiguous(memory_format=torch.channels_last)   # half-precision convs prefer NHWC
             with torch.autocast('cuda', dtype=self.backbone_dtype, enabled=self.backbone_dtype != torch.float32):
                 feats_c, feats_f = self.backbone(x)
             feats_c, feats_f = feats_c.float(), feats_f.float()

@@ -199,3 +199,56 @@ def layernorm(x, weight, bias, eps=1e-5, residual=None):
                                _p(residual, torch.float32), rows, C, float(eps), _p(y), _stream())
     _lib.check(rc, 'far_layernorm_f32')
     return y
+
+
+def _layout(t):
+    """0 = contiguous NCHW, 1 = channels_last memory; anything else is re-laid out as NCHW by the caller."""
+    if t.is_contiguous():
+        return 0
+    if t.is_contiguous(memory_format=torch.channels_last):
+        return 1
+    return -1
+
+
+def _same_layout(ts):
+    """Bring 4-D fp32 GPU tensors to one memory layout (the first tensor's, NCHW if it has neither)."""
+    for t in ts:
+        if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 4:
+            raise _lib.FarHipError('backbone epilogues need fp32 GPU (N, C, H, W) tensors')
+    lay = _layout(ts[0])
+    if lay < 0:
+        lay = 0
+    fmt = torch.channels_last if lay == 1 else torch.contiguous_format
+    return lay, [t if _layout(t) == lay else t.contiguous(memory_format=fmt) for t in ts]
+
+
+def affine_act(x, scale, shift, residual=None, act='relu', slope=0.01, inplace=True):
+    """K7.  y = act(x * scale[c] + shift[c] (+ residual)) for x (N, C, H, W) in NCHW or channels_last memory."""
+    lib = _lib.load()
+    N, C, H, W = x.shape
+    lay, ts = _same_layout([x] + ([residual] if residual is not None else []))
+    x = ts[0]
+    residual = ts[1] if residual is not None else None
+    if (lay == 0 and (H * W) % 4) or (lay == 1 and C % 4):
+        raise _lib.FarHipError('affine_act needs HW % 4 == 0 (NCHW) or C % 4 == 0 (channels_last)')
+    y = x if inplace else torch.empty_like(x)
+    code = {'none': 0, 'relu': 1, 'leaky': 2}[act]
+    rc = lib.far_affine_act_f32(ctypes.c_void_p(x.data_ptr()), _p(scale, torch.float32), _p(shift, torch.float32),
+                                ctypes.c_void_p(residual.data_ptr() if residual is not None else 0),
+                                N, C, H * W, lay, code, float(slope), ctypes.c_void_p(y.data_ptr()), _stream())
+    _lib.check(rc, 'far_affine_act_f32')
+    return y
+
+
+def upsample2x_add(lo, hi):
+    """K8.  hi + F.interpolate(lo, scale_factor=2, mode='bilinear', align_corners=True)."""
+    lib = _lib.load()
+    N, C, h, w = lo.shape
+    if tuple(hi.shape) != (N, C, 2 * h, 2 * w):
+        raise _lib.FarHipError(f'upsample2x_add shape mismatch {tuple(lo.shape)} vs {tuple(hi.shape)}')
+    lay, (hi, lo) = _same_layout([hi, lo])
+    out = torch.empty_like(hi)
+    rc = lib.far_upsample2x_add_f32(ctypes.c_void_p(lo.data_ptr()), ctypes.c_void_p(hi.data_ptr()), N, h, w, C, lay,
+                                    ctypes.c_void_p(out.data_ptr()), _stream())
+    _lib.check(rc, 'far_upsample2x_add_f32')
+    return out

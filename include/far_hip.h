@@ -120,6 +120,21 @@ int far_layernorm_f32(const float* x, const float* gamma, const float* beta, con
                       float eps, float* y, far_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * K7 / K8  backbone epilogues (inference): folded BatchNorm + residual + activation; FPN upsample + add
+ * replaces the elementwise passes of src/loftr/backbone/resnet_fpn.py:32-40, :80-91, :103, :110-116
+ * ------------------------------------------------------------------------------------------------- */
+
+/* y = act(x * scale[c] + shift[c] (+ res)) on activations [N][C][H][W]: nhwc = 0 contiguous NCHW (HW % 4 == 0),
+ * nhwc = 1 channels_last memory (C % 4 == 0).  act: 0 none, 1 ReLU, 2 LeakyReLU(slope).  y may alias x. */
+int far_affine_act_f32(const float* x, const float* scale, const float* shift, const float* res, long N, int C,
+                       long HW, int nhwc, int act, float slope, float* y, far_stream_t stream);
+
+/* out = hi + bilinear 2x upsample (align_corners = True) of lo; lo [N][C][h][w], hi/out [N][C][2h][2w], both in the
+ * layout selected by nhwc (0: NCHW, w even; 1: channels_last, C % 4 == 0). */
+int far_upsample2x_add_f32(const float* lo, const float* hi, int N, int h, int w, int C, int nhwc, float* out,
+                           far_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * K4  batched essential-matrix solver (hypothesise / verify / decompose / cheirality), float64
  * replaces src/utils/metrics.py:80-174 (estimate_pose), third_party/prior_ransac/ransac.py:340-442
  *      (RANSAC.forward + verify + get_prior_estimate), cv_geometry.py:713-833 (run_8point),

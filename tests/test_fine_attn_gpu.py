@@ -81,3 +81,28 @@ def test_layernorm(rows, C, res):
     if res:
         ref = ref + r
     np.testing.assert_allclose(got, ref, atol=2e-6 * np.abs(ref).max(), rtol=1e-5)
+
+
+@pytest.mark.parametrize('fmt', [torch.contiguous_format, torch.channels_last])
+def test_backbone_epilogues_match_torch(fmt):
+    """K7 (folded BN + residual + activation) and K8 (2x bilinear upsample + add) vs the torch ops they replace."""
+    from far_amd import ops
+    import torch.nn.functional as F
+    g = torch.Generator(device='cuda').manual_seed(0)
+    N, C, H, W = 3, 196, 30, 40
+    x = torch.randn(N, C, H, W, device='cuda', generator=g).contiguous(memory_format=fmt)
+    r = torch.randn(N, C, H, W, device='cuda', generator=g).contiguous(memory_format=fmt)
+    bn = torch.nn.BatchNorm2d(C).cuda().eval()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(); bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2.0)
+        scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+        shift = bn.bias - bn.running_mean * scale
+        for act, fn in [('relu', F.relu), ('none', lambda t: t), ('leaky', lambda t: F.leaky_relu(t, 0.01))]:
+            for res in [None, r]:
+                ref = fn(bn(x) + (res if res is not None else 0))
+                got = ops.affine_act(x, scale, shift, residual=res, act=act, inplace=False)
+                assert got.is_contiguous(memory_format=fmt)
+                torch.testing.assert_close(got, ref, atol=2e-6, rtol=1e-5)
+        lo = torch.randn(N, C, 15, 20, device='cuda', generator=g).contiguous(memory_format=fmt)
+        ref = x + F.interpolate(lo, scale_factor=2., mode='bilinear', align_corners=True)
+        torch.testing.assert_close(ops.upsample2x_add(lo, x), ref, atol=2e-6, rtol=1e-5)
