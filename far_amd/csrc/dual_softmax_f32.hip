@@ -202,6 +202,153 @@ __global__ __launch_bounds__(256, 2) void k_stats_f32(
     }
 }
 
+// --------------------------------------------------------------------------------------------
+// Pass 1, 64-channel variant (the head's q/k, C = 64, no masks, no feature scaling).
+// The row-side panel (32 rows x 64 channels per wave) lives in registers for the whole sweep; only the column-side
+// tile is staged in LDS (128 x 64 floats, single buffer, 35 KB), processed as two 64-column halves with two
+// accumulators.  ~120 VGPRs and 39 KB LDS -> 4 workgroups per CU, so the statistics VALU work of one wave runs in
+// the MFMA shadow of three others.  Same outputs as k_stats_f32.
+// --------------------------------------------------------------------------------------------
+constexpr int S64_KS = 68;   // LDS row stride (floats): 17 16-byte slots, odd -> conflict-free ds_read_b128
+
+__global__ __launch_bounds__(256, 3) void k_stats_c64_f32(
+    const float* __restrict__ f0, const float* __restrict__ f1, int Z, int L, int S, SimParams sp,
+    float2* __restrict__ rowstat, float2* __restrict__ colpart) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* kt = reinterpret_cast<float*>(smem_raw);                                   // [128][68]
+    float2* colx = reinterpret_cast<float2*>(smem_raw + 128 * S64_KS * sizeof(float));  // [4][64]
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int nI = (L + TILE_M - 1) / TILE_M;
+    int z, Ib;
+    tile_coords(nI, Z, z, Ib);
+    const int i0 = Ib * TILE_M;
+    const float* A = f0 + (size_t)z * L * 64;
+    const float* B = f1 + (size_t)z * S * 64;
+
+    // A fragment: row i = i0 + 32 wave + l31, channels {8g + 4h .. +3}
+    const int irow = i0 + 32 * wave + l31;
+    f32x4 qa[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g)
+        qa[g] = irow < L ? *reinterpret_cast<const f32x4*>(A + (size_t)irow * 64 + 8 * g + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
+
+    unsigned rowvalid = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        if (i0 + 32 * wave + mfma32_row(r, h) < L) rowvalid |= 1u << r;
+    float rm[16], rs[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { rm[r] = NEG_BIG; rs[r] = 0.f; }
+
+    const int nJ = (S + TILE_N - 1) / TILE_N;
+    for (int Jt = 0; Jt < nJ; ++Jt) {
+        const int j0 = Jt * TILE_N;
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int idx = tid + 256 * p, row = idx >> 4, slot = idx & 15;
+            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j0 + row < S) kv = *reinterpret_cast<const float4*>(B + (size_t)(j0 + row) * 64 + slot * 4);
+            *reinterpret_cast<float4*>(&kt[row * S64_KS + slot * 4]) = kv;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            const int jb = 64 * half;
+            f32x16 acc[2];
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+            const float* krow = &kt[(jb + l31) * S64_KS + 4 * h];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                f32x4 kb[2];
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) kb[ct] = *reinterpret_cast<const f32x4*>(krow + ct * 32 * S64_KS + 8 * g);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct)
+                        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[g][c], kb[ct][c], acc[ct], 0, 0, 0);
+            }
+            // lane holds column j = j0 + jb + 32 ct + l31, rows i0 + 32 wave + mfma32_row(r, h)
+            bool cvalid[2];
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) cvalid[ct] = (j0 + jb + 32 * ct + l31) < S;
+            if (sp.sim_div == 1.0f && sp.acc_scale == 1.0f) {      // the head: s = dot * scale, nothing else
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[ct][r] = acc[ct][r] * sp.sim_mul;
+            } else {
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[ct][r] = sim_of(acc[ct][r], sp);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float tm = NEG_BIG;
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+                    if (cvalid[ct]) tm = fmaxf(tm, acc[ct][r]);
+                const float mn = fmaxf(rm[r], tm);
+                float sum = (rm[r] == mn) ? rs[r] : rs[r] * fexp(rm[r] - mn);
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+                    if (cvalid[ct]) sum += fexp(acc[ct][r] - mn);
+                rm[r] = mn;
+                rs[r] = sum;
+            }
+            float cmx[2], csm[2];
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                float m = NEG_BIG;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if ((rowvalid >> r) & 1) m = fmaxf(m, acc[ct][r]);
+                float s = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if ((rowvalid >> r) & 1) s += fexp(acc[ct][r] - m);
+                const float mo = shfl_xor_f(m, 32), so = shfl_xor_f(s, 32);
+                softmax_merge(m, s, mo, so);
+                cmx[ct] = m;
+                csm[ct] = s;
+            }
+            __syncthreads();                        // colx free (previous half's readers are done)
+            if (h == 0) {
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) colx[wave * 64 + 32 * ct + l31] = make_float2(cmx[ct], csm[ct]);
+            }
+            __syncthreads();
+            if (tid < 64 && j0 + jb + tid < S) {
+                float2 v = colx[tid];
+                float m = v.x, s = v.y;
+#pragma unroll
+                for (int w = 1; w < 4; ++w) {
+                    const float2 o = colx[w * 64 + tid];
+                    softmax_merge(m, s, o.x, o.y);
+                }
+                colpart[((size_t)z * nI + Ib) * S + j0 + jb + tid] = make_float2(m, s);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float m = rm[r], s = rs[r];
+#pragma unroll
+        for (int d = 1; d < 32; d <<= 1) {
+            const float mo = shfl_xor_f(m, d), so = shfl_xor_f(s, d);
+            softmax_merge(m, s, mo, so);
+        }
+        if (l31 == 0 && ((rowvalid >> r) & 1))
+            rowstat[(size_t)z * L + i0 + 32 * wave + mfma32_row(r, h)] = make_float2(m, s);
+    }
+}
+
 // colstat[z][j] = merge_{Ib} colpart[z][Ib][j]
 __global__ void k_colreduce(const float2* __restrict__ colpart, int nI, int S, float2* __restrict__ colstat) {
     int j = blockIdx.x * blockDim.x + threadIdx.x, z = blockIdx.y;
@@ -482,8 +629,13 @@ int far_dual_softmax_stats_f32(const float* f0, const float* f1, int Z, int L, i
         hipFuncSetAttribute((const void*)k_match_f32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTileSmem);
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_stats_f32, dim3(nI * Z), dim3(256), kTileSmem, stream, f0, f1, Z, L, S, C, sp, mask0, mask1,
-                       rs, w.colpart);
+    if (C == 64 && sp.feat_div == 1.0f && !mask0 && !mask1 && far_get_tuning(1) == 0) {
+        const size_t smem = 128 * S64_KS * sizeof(float) + 4 * 64 * sizeof(float2);
+        hipLaunchKernelGGL(k_stats_c64_f32, dim3(nI * Z), dim3(256), smem, stream, f0, f1, Z, L, S, sp, rs, w.colpart);
+    } else {
+        hipLaunchKernelGGL(k_stats_f32, dim3(nI * Z), dim3(256), kTileSmem, stream, f0, f1, Z, L, S, C, sp, mask0, mask1,
+                           rs, w.colpart);
+    }
     hipLaunchKernelGGL(k_colreduce, dim3((S + 255) / 256, Z), dim3(256), 0, stream, w.colpart, nI, S, cs);
     return far_check_launch();
 }
