@@ -154,6 +154,8 @@ def main():
     from far_amd.loftr import LoFTR
     from far_amd.pipeline import test_step
 
+    if os.environ.get('FAR_CUDNN_BENCHMARK') == '1':
+        torch.backends.cudnn.benchmark = True      # MIOpen exhaustive solver search (experiment switch)
     cfg = far_eval_config()
     model = LoFTR(cfg).eval()
     synth.load_synthetic(model, seed=0)

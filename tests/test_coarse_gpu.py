@@ -139,3 +139,10 @@ def test_padding_masks_and_image_scales():
     mk1 = torch.stack([jj % hw[1], jj // hw[1]], 1) * (8.0 * torch.from_numpy(sc1)[bi])
     np.testing.assert_allclose(got['mkpts0_c'].cpu().numpy(), mk0.numpy(), rtol=1e-6)
     np.testing.assert_allclose(got['mkpts1_c'].cpu().numpy(), mk1.numpy(), rtol=1e-6)
+
+
+def test_mapfree_grid_544x720():
+    # BASELINE configs[4]: 544x720 images -> 68x90 coarse grid, L = S = 6120 (not a multiple of the 128 tile)
+    f0, f1, _ = correlated_features(2, (68, 90), 256, seed=11, amp=1.3, frac=0.9)
+    M = _check(f0, f1, (68, 90), False)
+    assert M > 6000

@@ -250,3 +250,24 @@ def test_training_step_on_gpu(model):
             assert torch.isfinite(p.grad).all(), k
             n_grad += 1
     assert n_grad == sum(1 for _ in m.parameters()) == 189      # every parameter receives a gradient
+
+
+def test_pair_without_matches_in_a_batch(model):
+    """A blank pair inside a batch: no coarse matches for it, the solver reports failure for that pair and the
+    reference's identity fallback applies (supervision.py:221-224); the other pair is unaffected."""
+    from far_amd.pipeline import test_step
+    data, _, _ = _batch(2, 9)
+    solo, _, _ = _batch(2, 9)
+    data['image0'][1].zero_()
+    data['image1'][1].zero_()
+    test_step(model, data, H=256)
+    counts = [int(c) for c in data['match_counts']]
+    assert counts[0] > 1000 and counts[1] == 0
+    rt = data['loftr_rt'].cpu().numpy()
+    np.testing.assert_array_equal(rt[1], np.concatenate([np.eye(3), np.zeros((3, 1))], 1))
+    assert int(data['solver_status'][1]) == 0 and int(data['num_correspondences'][1]) == 0
+    assert torch.isfinite(data['regressed_rt']).all()
+    # pair 0 of the mixed batch == pair 0 of a normal batch (pairs are independent problems)
+    test_step(model, solo, H=256)
+    assert np.linalg.norm(rt[0] - solo['loftr_rt'][0].cpu().numpy()) < 1e-9
+    torch.testing.assert_close(data['regressed_rt'][0], solo['regressed_rt'][0], atol=1e-5, rtol=1e-4)

@@ -101,3 +101,24 @@ def test_explicit_samples_match_reference_style_call():
     F = osv.run_8point(kp1[samples], kp2[samples])
     err = np.abs(got['F_all'][0] - F).reshape(H, -1).max(1) / np.abs(F).reshape(H, -1).max(1)
     assert np.median(err) < 1e-10 and (err < 1e-6).mean() > 0.97, (np.median(err), (err < 1e-6).mean())
+
+
+def test_cached_path_batch_256():
+    """BASELINE configs[3]: solver on cached correspondences, batch 256, M <= 2000, H = 2048 (one launch set)."""
+    from oracle import solver as osv
+    rng = np.random.default_rng(7)
+    B = 256
+    Ms = rng.integers(100, 2000, B)
+    scenes = [two_view_scene(int(M), seed=1000 + b, outlier_frac=0.3) for b, M in enumerate(Ms)]
+    got, offs = _run(scenes, 'noprior', H=2048)
+    assert got['status'].mean() > 0.97
+    for b in [0, 37, 128, 255]:
+        k0, k1, K, Rgt, tgt = scenes[b]
+        ret, nafter, tight, ultra, dbg = osv.estimate_pose(k0, k1, K, K, 0.5, solver='prior_ransac_noprior', seed=11,
+                                                            pair=b, H=2048)
+        assert got['best'][b] == dbg['best']
+        np.testing.assert_array_equal(got['mask'][offs[b]:offs[b + 1]].astype(bool), ret[2])
+        assert np.linalg.norm(got['R'][b] - ret[0]) < 1e-8 and got['num_after'][b] == nafter
+    # accuracy over the batch against ground truth
+    Rerr = np.array([np.linalg.norm(got['R'][b] - scenes[b][3]) for b in range(B) if got['status'][b]])
+    assert np.median(Rerr) < 0.02
