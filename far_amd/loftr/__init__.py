@@ -1,5 +1,3 @@
-from .loftr import LoFTR  # noqa: F401
+from .model import LoFTR, PositionEncodingSine  # noqa: F401
 from .transformer import LocalFeatureTransformer, LocalFeatureTransformerRegressor  # noqa: F401
-from .fine_preprocess import FinePreprocess  # noqa: F401
-from .coarse_matching import CoarseMatching  # noqa: F401
-from .fine_matching import FineMatching  # noqa: F401
+from .stages import CoarseMatching, FineMatching, FinePreprocess  # noqa: F401

@@ -1,0 +1,174 @@
+"""The drop-in module: same constructor dict, methods, data-dict protocol and parameter names as
+mp3d_loftr/src/loftr/loftr.py (LoFTR :14-211), with the hot operators on libfar_hip.so.
+
+  forward(data)                          -> forward_feature_extraction + forward_correspondence_prediction
+  forward_rt_prediction(data)            -> EMM head, writes regressed_rt / expec_rt / priorRT
+All results are side effects on the caller's `data` dict.
+Batched use: loftr_rt may be (3, 4) [reference, B = 1] or (B, 3, 4); count tensors (1,) or (B,).
+
+(PositionEncodingSine lives here too: 2-D sinusoidal position encoding added to the 1/8 feature map. Mirrors mp3d_loftr/src/loftr/utils/position_encoding.py:6-42 (same buffer name `pe`, non-persistent).)
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ..pose6d import compute_normalized_6d, pose_mean_6d, pose_std_6d, rotation_6d_to_matrix
+from .backbone import build_backbone
+from .stages import CoarseMatching, FineMatching, FinePreprocess
+from .transformer import LocalFeatureTransformer, LocalFeatureTransformerRegressor
+
+
+class PositionEncodingSine(nn.Module):
+    def __init__(self, d_model, max_shape=(256, 256), temp_bug_fix=True):
+        super().__init__()
+        ys = torch.ones(max_shape).cumsum(0).float().unsqueeze(0)
+        xs = torch.ones(max_shape).cumsum(1).float().unsqueeze(0)
+        k = torch.arange(0, d_model // 2, 2).float()
+        if temp_bug_fix:
+            div = torch.exp(k * (-math.log(10000.0) / (d_model // 2)))
+        else:  # the historical operator-precedence variant kept by the reference (:28-29)
+            div = torch.exp(k * (-math.log(10000.0) / d_model // 2))
+        div = div[:, None, None]
+        pe = torch.zeros((d_model, *max_shape))
+        pe[0::4] = torch.sin(xs * div)
+        pe[1::4] = torch.cos(xs * div)
+        pe[2::4] = torch.sin(ys * div)
+        pe[3::4] = torch.cos(ys * div)
+        self.register_buffer('pe', pe.unsqueeze(0), persistent=False)
+
+    def forward(self, x):
+        return x + self.pe[:, :, :x.size(2), :x.size(3)]
+
+
+def _tokens(fmap, pos_enc):
+    """(N, C, H, W) coarse map -> (N, H*W, C) tokens with the sinusoidal encoding added ('n c h w -> n (h w) c')."""
+    return pos_enc(fmap).flatten(2).transpose(1, 2).contiguous()
+
+
+class LoFTR(nn.Module):
+    """Reference interface (loftr.py:14-211): forward / forward_feature_extraction /
+    forward_correspondence_prediction / forward_rt_prediction / preprocess_helper / load_state_dict."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        save = config.get('save_preds')
+        has_matcher = config['from_saved_preds'] is None or (save is not None and 'ground_truth' in save)
+        if has_matcher:                                                       # loftr.py:20-27
+            if config.get('predict_translation_scale'):
+                raise NotImplementedError('predict_translation_scale is off in every FAR script (loftr.py:29-53)')
+            cc = config['coarse']
+            self.backbone = build_backbone(config)
+            self.pos_encoding = PositionEncodingSine(cc['d_model'], temp_bug_fix=cc['temp_bug_fix'])
+            self.loftr_coarse = LocalFeatureTransformer(cc)
+            self.coarse_matching = CoarseMatching(config['match_coarse'])
+            self.fine_preprocess = FinePreprocess(config)
+            self.loftr_fine = LocalFeatureTransformer(config["fine"])
+            self.fine_matching = FineMatching(config)
+        if config['regress_rt']:
+            self.loftr_regress = LocalFeatureTransformerRegressor(config)
+        # optional half precision for the convolutional backbone only (vendor path); fp32 = parity configuration
+        self.backbone_dtype = torch.float32
+
+    # -------------------------------------------------------------------------------------------------
+    # stage 1: local feature CNN on both images at once (loftr.py:56-89)
+    # -------------------------------------------------------------------------------------------------
+    def _run_backbone(self, images):
+        half = self.backbone_dtype != torch.float32
+        if half:
+            images = images.to(self.backbone_dtype).contiguous(memory_format=torch.channels_last)
+        with torch.autocast('cuda', dtype=self.backbone_dtype, enabled=half):
+            coarse, fine = self.backbone(images)
+        return coarse.float(), fine.float()
+
+    def forward_feature_extraction(self, data):
+        im0, im1 = data['image0'], data['image1']
+        n = im0.size(0)
+        data.update(bs=n, hw0_i=im0.shape[2:], hw1_i=im1.shape[2:])
+        if im0.shape[2:] == im1.shape[2:]:
+            feats_c, feats_f = self._run_backbone(torch.cat([im0, im1], dim=0))
+            c0, c1 = feats_c.split(n)
+            f0, f1 = feats_f.split(n)
+        else:                                                                  # different input shapes (:76-77)
+            (c0, f0), (c1, f1) = self._run_backbone(im0), self._run_backbone(im1)
+            feats_c = None
+        data.update(hw0_c=c0.shape[2:], hw1_c=c1.shape[2:], hw0_f=f0.shape[2:], hw1_f=f1.shape[2:],
+                    featmap0=c0, featmap1=c1, featmap_f0=f0, featmap_f1=f1, feats_c=feats_c)
+
+    # -------------------------------------------------------------------------------------------------
+    # stages 2-5: coarse transformer, K1 coarse match, K3 fine refinement (loftr.py:91-135)
+    # -------------------------------------------------------------------------------------------------
+    def forward_correspondence_prediction(self, data, train=False):
+        tok0 = _tokens(data['featmap0'], self.pos_encoding)
+        tok1 = _tokens(data['featmap1'], self.pos_encoding)
+        m0 = m1 = None
+        if 'mask0' in data:
+            m0, m1 = data['mask0'].flatten(-2), data['mask1'].flatten(-2)
+        tok0, tok1 = self.loftr_coarse(tok0, tok1, m0, m1)
+        self.coarse_matching(tok0, tok1, data, mask_c0=m0, mask_c1=m1)
+        win0, win1 = self.fine_preprocess(data['featmap_f0'], data['featmap_f1'], tok0, tok1, data)
+        if win0.size(0) != 0:
+            win0, win1 = self.loftr_fine(win0, win1)
+        self.fine_matching(win0, win1, data, train=train)
+        # the coarse maps are REPLACED by the transformer outputs (N, HW, C): the head consumes these (:129-135)
+        data.update(featmap0=tok0, featmap1=tok1, mask_c0=m0, mask_c1=m1, translation_scale=None)
+
+    # -------------------------------------------------------------------------------------------------
+    # stage 6a: solver pose -> the 13 normalised numbers the head receives, and their inverse-pose twin
+    # (loftr.py:137-171).  Accepts loftr_rt (3, 4) [reference] or (B, 3, 4); counts (1,) or (B,).
+    # -------------------------------------------------------------------------------------------------
+    def preprocess_helper(self, data):
+        f0, f1 = data['featmap0'], data['featmap1']
+        preds = inv_preds = None
+        if self.config['regress']['use_simple_moe']:
+            dev = f0.device
+            rt = data['loftr_rt'].detach().to(dev)
+            rt = rt.unsqueeze(0) if rt.dim() == 2 else rt
+            B = rt.shape[0]
+            last_row = torch.tensor([[[0, 0, 0, 1.]]], device=dev, dtype=rt.dtype).expand(B, -1, -1)
+            rt_inv = torch.linalg.inv(torch.cat([rt, last_row], dim=1))[:, :3, :4]
+            preds = compute_normalized_6d(rt.float())
+            inv_preds = compute_normalized_6d(rt_inv).float()
+            extra = []
+            if self.config['regress']['regress_use_num_corres']:
+                extra.append('num_correspondences')
+            if self.config['use_many_ransac_thr']:
+                extra += ['num_correspondences_before_ransac', 'inliers_best_tight', 'inliers_best_ultra_tight']
+            if extra:                                                          # counts / 500 (:158, :164-166)
+                cnt = torch.cat([data[k].detach().float().to(dev).reshape(B, 1) / 500 for k in extra], -1)
+                preds, inv_preds = torch.cat([preds, cnt], -1), torch.cat([inv_preds, cnt], -1)
+        return f0, f1, data.get('mask_c0'), data.get('mask_c1'), preds, inv_preds
+
+    # -------------------------------------------------------------------------------------------------
+    # stage 6: regression head + solver/regressor blend; exports the prior for the next solver round
+    # (loftr.py:173-192)
+    # -------------------------------------------------------------------------------------------------
+    def forward_rt_prediction(self, data):
+        if not self.config['regress_rt']:
+            return
+        f0, f1, m0, m1, preds, inv_preds = self.preprocess_helper(data)
+        pose, mlp_feats, gate = self.loftr_regress(f0, f1, mask0=m0, mask1=m1, loftr_preds=preds,
+                                                   inv_loftr_preds=inv_preds, F=None)
+        data.update(regressed_rt=pose, expec_rt=pose[0])
+        rc = self.config['regress']
+        if rc['save_mlp_feats']:
+            data['mlp_feats'] = mlp_feats
+        if rc['save_gating_weights']:
+            data['gating_reg_weights'] = gate
+        if self.config['solver'] == 'prior_ransac':
+            p = pose.detach().float().cpu()
+            R = rotation_6d_to_matrix(p[:, 3:] * pose_std_6d[3:] + pose_mean_6d[3:]).numpy()
+            t = (p[:, :3] * pose_std_6d[:3] + pose_mean_6d[:3]).numpy()
+            prior = np.concatenate([R, t[:, :, None]], axis=-1)                # (B, 3, 4)
+            data['priorRT'] = prior[0] if len(prior) == 1 else prior
+
+    def forward(self, data, train=False):
+        self.forward_feature_extraction(data)
+        self.forward_correspondence_prediction(data, train=train)
+
+    def load_state_dict(self, state_dict, *args, **kwargs):
+        # Lightning checkpoints carry the 'matcher.' prefix (lightning_loftr.py:58-75, loftr.py:207-211)
+        stripped = {(k[len('matcher.'):] if k.startswith('matcher.') else k): v for k, v in state_dict.items()}
+        return super().load_state_dict(stripped, *args, **kwargs)

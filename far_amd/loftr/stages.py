@@ -1,5 +1,18 @@
-"""CoarseMatching on kernel K1.  Mirrors the interface of mp3d_loftr/src/loftr/utils/coarse_matching.py
-(CoarseMatching :56-265): same constructor dict, same data-dict keys written."""
+"""Matcher stages of the drop-in module on the far_amd kernels: CoarseMatching (K1), FinePreprocess (K3a),
+FineMatching (K3b).  Same class names, constructor dicts and data-dict keys as the reference's
+mp3d_loftr/src/loftr/utils/coarse_matching.py, loftr_module/fine_preprocess.py and utils/fine_matching.py
+(one module here: they are thin front ends over three kernels).
+
+CoarseMatching on kernel K1.  Mirrors the interface of mp3d_loftr/src/loftr/utils/coarse_matching.py
+(CoarseMatching :56-265): same constructor dict, same data-dict keys written.
+
+FinePreprocess on kernel K3a.  Mirrors mp3d_loftr/src/loftr/loftr_module/fine_preprocess.py:7-59
+(same parameters: down_proj, merge_feat).
+
+FineMatching on kernel K3b.  Mirrors mp3d_loftr/src/loftr/utils/fine_matching.py:8-76.
+"""
+import math
+
 import torch
 import torch.nn as nn
 
@@ -7,6 +20,9 @@ from .. import autograd_ops as ag
 from .. import ops
 
 
+# =====================================================================================================
+# coarse level
+# =====================================================================================================
 class CoarseMatching(nn.Module):
     def __init__(self, config):
         super().__init__()
@@ -106,3 +122,77 @@ class CoarseMatching(nn.Module):
         keep = mconf != 0
         return {'b_ids': b_ids, 'i_ids': i_ids, 'j_ids': j_ids, 'gt_mask': mconf == 0, 'm_bids': b_ids[keep],
                 'mkpts0_c': mk0[keep], 'mkpts1_c': mk1[keep], 'mconf': mconf[keep]}
+
+
+# =====================================================================================================
+# fine level
+# =====================================================================================================
+class FinePreprocess(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.cat_c_feat = config['fine_concat_coarse_feat']
+        self.W = config['fine_window_size']
+        d_c, d_f = config['coarse']['d_model'], config['fine']['d_model']
+        self.d_model_f = d_f
+        if self.cat_c_feat:
+            self.down_proj = nn.Linear(d_c, d_f, bias=True)
+            self.merge_feat = nn.Linear(2 * d_f, d_f, bias=True)
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.kaiming_normal_(p, mode="fan_out", nonlinearity="relu")
+
+    def forward(self, feat_f0, feat_f1, feat_c0, feat_c1, data):
+        W = self.W
+        stride = data['hw0_f'][0] // data['hw0_c'][0]
+        data.update({'W': W})
+        b, i, j = data['b_ids'], data['i_ids'], data['j_ids']
+        if b.shape[0] == 0:                                                          # :34-37
+            e = torch.empty(0, W ** 2, self.d_model_f, device=feat_f0.device)
+            return e, e.clone()
+        # direct gather of the M x 25 x C window values instead of unfolding both full maps (:40-47)
+        if ag.needs_grad(feat_f0, feat_f1):
+            w0 = ag.fine_windows(feat_f0, b, i, W, stride)
+            w1 = ag.fine_windows(feat_f1, b, j, W, stride)
+        else:
+            w0 = ops.fine_gather(feat_f0.float(), b, i, data['hw0_c'][1], W, stride)
+            w1 = ops.fine_gather(feat_f1.float(), b, j, data['hw1_c'][1], W, stride)
+        if self.cat_c_feat:
+            c_win = self.down_proj(torch.cat([feat_c0[b, i], feat_c1[b, j]], 0))     # [2M, C]
+            both = torch.cat([torch.cat([w0, w1], 0), c_win.unsqueeze(1).expand(-1, W ** 2, -1)], -1)
+            w0, w1 = torch.chunk(self.merge_feat(both), 2, dim=0)
+        return w0, w1
+
+
+class FineMatching(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+
+    def forward(self, feat_f0, feat_f1, data, train=False):
+        M, WW, C = feat_f0.shape
+        W = int(math.sqrt(WW))
+        scale = data['hw0_i'][0] / data['hw0_f'][0]
+        if M == 0:                                                                   # :33-41
+            assert self.training is False, "M is always >0 when training (coarse_matching.py)"
+            data.update({'expec_f': torch.empty(0, 3, device=feat_f0.device),
+                         'mkpts0_f': data['mkpts0_c'], 'mkpts1_f': data['mkpts1_c']})
+            return
+        if ag.needs_grad(feat_f0, feat_f1):
+            coords, std = ag.fine_expect(feat_f0, feat_f1)
+            data.update({'expec_f': torch.cat([coords, std.unsqueeze(1)], -1)})
+            if not self.config['regress_rt'] or not train or self.config['regress']['use_simple_moe']:
+                with torch.no_grad():
+                    sc1 = scale * data['scale1'][data['b_ids']] if 'scale0' in data else scale
+                    n = len(data['mconf'])
+                    data.update({'mkpts0_f': data['mkpts0_c'],
+                                 'mkpts1_f': data['mkpts1_c'] + (coords * (W // 2) * sc1)[:n]})
+            return
+        s1 = data['scale1'].float().contiguous() if 'scale0' in data else None       # :70
+        expec, mk1 = ops.fine_expect(feat_f0.float().contiguous(), feat_f1.float().contiguous(),
+                                     data['mkpts1_c'].contiguous(), (W // 2) * scale, s1,
+                                     data['b_ids'] if s1 is not None else None)
+        data.update({'expec_f': expec})
+        if not self.config['regress_rt'] or not train or self.config['regress']['use_simple_moe']:   # :59-62
+            n = len(data['mconf'])
+            data.update({'mkpts0_f': data['mkpts0_c'], 'mkpts1_f': mk1[:n]})
