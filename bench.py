@@ -34,6 +34,8 @@ def parse():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--pairs', type=int, default=PAIRS_PER_GPU, help='pairs per GPU per step')
     ap.add_argument('--hyp', type=int, default=2048, help='RANSAC hypotheses per pair (metrics.py:120)')
+    ap.add_argument('--precision', default='fp32', choices=['fp32', 'fp16-fine', 'fp16', 'bf16'],
+                    help='arithmetic of the vendor-path convolutions (far_amd.loftr.LoFTR.set_precision); kernels stay fp32/f64')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-pairs', type=int, default=1)
     return ap.parse_args()
@@ -160,6 +162,7 @@ def main():
     model = LoFTR(cfg).eval()
     synth.load_synthetic(model, seed=0)
     model = model.to(dev)
+    model.set_precision(a.precision)
     im0, im1 = synth.synth_image_pair(a.pairs, seed=1234 + rank)
     K = torch.from_numpy(np.stack([synth.MP3D_K] * a.pairs)).to(dev)
     base = {'image0': torch.from_numpy(im0).to(dev), 'image1': torch.from_numpy(im1).to(dev), 'K0': K, 'K1': K.clone(),
@@ -217,7 +220,8 @@ def main():
             'metric': 'image-pairs/sec (match+solve+regress) at 640x480',
             'value': round(world * a.pairs * a.steps / dt, 3), 'unit': 'image-pairs/sec',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(1000 * dt / a.steps, 3),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32' if a.precision == 'fp32' else f'f32 kernels + {a.precision} convolutions', 'data': 'synthetic',
             'config': {'workload': 'Matterport3D-shaped eval (BASELINE configs[1]): batch 32 pairs @ 640x480 per GPU, '
                                    'LoFTR match + 8-pt prior-RANSAC solve (x2 rounds) + EMM head (x2), seeded random weights',
                        'pairs_per_gpu': a.pairs, 'hypotheses': a.hyp, 'fine_pred_steps': 2,

@@ -84,35 +84,39 @@ class ResNetFPN_8_2(nn.Module):
     # sub-pixel expectation.  None (default) = everything fp32 = the parity configuration.
     fine_branch_dtype = None
 
-    def _forward_fused(self, x):
-        x0 = ops.affine_act(self.conv1(x), *_fold(self.bn1), act='relu')
-        x1 = self.layer1(x0)
+    def _trunk(self, x):
+        if _fused_ok(self, x):
+            x0 = ops.affine_act(self.conv1(x), *_fold(self.bn1), act='relu')
+        else:
+            x0 = self.relu(self.bn1(self.conv1(x)))
+        x1 = self.layer1(x0)            # BasicBlocks pick their own fused / plain path
         x2 = self.layer2(x1)
         x3 = self.layer3(x2)
-        x3_out = self.layer3_outconv(x3)
+        return x1, x2, x3
+
+    def _fpn_fused(self, x1, x2, x3_out):
         o2, o1 = self.layer2_outconv2, self.layer1_outconv2
         y = ops.upsample2x_add(x3_out, self.layer2_outconv(x2))
         y = ops.affine_act(o2[0](y), *_fold(o2[1]), act='leaky', slope=o2[2].negative_slope)
         x2_out = o2[3](y)
         y = ops.upsample2x_add(x2_out, self.layer1_outconv(x1))
         y = ops.affine_act(o1[0](y), *_fold(o1[1]), act='leaky', slope=o1[2].negative_slope)
-        return [x3_out, o1[3](y)]
+        return o1[3](y)
+
+    def _fpn_plain(self, x1, x2, x3_out):
+        up3 = F.interpolate(x3_out, scale_factor=2., mode='bilinear', align_corners=True)
+        x2_out = self.layer2_outconv2(self.layer2_outconv(x2) + up3)
+        up2 = F.interpolate(x2_out, scale_factor=2., mode='bilinear', align_corners=True)
+        return self.layer1_outconv2(self.layer1_outconv(x1) + up2)
 
     def forward(self, x):
-        if self.fine_branch_dtype is None and _fused_ok(self, x):
-            return self._forward_fused(x)
-        x0 = self.relu(self.bn1(self.conv1(x)))
-        x1 = self.layer1(x0)
-        x2 = self.layer2(x1)
-        x3 = self.layer3(x2)
+        x1, x2, x3 = self._trunk(x)
         x3_out = self.layer3_outconv(x3)
         dt = self.fine_branch_dtype
+        if dt is None and _fused_ok(self, x3_out):
+            return [x3_out, self._fpn_fused(x1, x2, x3_out)]
         with (torch.autocast('cuda', dtype=dt) if dt is not None else contextlib.nullcontext()):
-            up3 = F.interpolate(x3_out, scale_factor=2., mode='bilinear', align_corners=True)
-            x2_out = self.layer2_outconv2(self.layer2_outconv(x2) + up3)
-            up2 = F.interpolate(x2_out, scale_factor=2., mode='bilinear', align_corners=True)
-            x1_out = self.layer1_outconv2(self.layer1_outconv(x1) + up2)
-        return [x3_out, x1_out]
+            return [x3_out, self._fpn_plain(x1, x2, x3_out)]
 
 
 def build_backbone(config):

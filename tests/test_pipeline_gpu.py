@@ -271,3 +271,30 @@ def test_pair_without_matches_in_a_batch(model):
     test_step(model, solo, H=256)
     assert np.linalg.norm(rt[0] - solo['loftr_rt'][0].cpu().numpy()) < 1e-9
     torch.testing.assert_close(data['regressed_rt'][0], solo['regressed_rt'][0], atol=1e-5, rtol=1e-4)
+
+
+def test_precision_modes_deviation(model):
+    """The optional half-precision convolution modes against the fp32 path on 4 pairs: 'fp16-fine' must leave every
+    coarse decision bit-identical; 'fp16' is reported by match-set IoU (documented deviation, not parity)."""
+    import copy
+    m = copy.deepcopy(model)
+    data32, _, _ = _batch(4, 31)
+    with torch.no_grad():
+        m.set_precision('fp32')(data32) if False else m(data32)
+        d16f, _, _ = _batch(4, 31)
+        m.set_precision('fp16-fine')
+        m(d16f)
+        d16, _, _ = _batch(4, 31)
+        m.set_precision('fp16')
+        m(d16)
+        m.set_precision('fp32')
+    assert torch.equal(d16f['feats_c'], data32['feats_c'])
+    for k in ['b_ids', 'i_ids', 'j_ids', 'mconf']:
+        assert torch.equal(d16f[k], data32[k]), k
+    dev = (d16f['mkpts1_f'] - data32['mkpts1_f']).abs()
+    assert dev.mean().item() < 0.03 and dev.median().item() < 0.01
+    s32 = set(zip(data32['b_ids'].tolist(), data32['i_ids'].tolist(), data32['j_ids'].tolist()))
+    s16 = set(zip(d16['b_ids'].tolist(), d16['i_ids'].tolist(), d16['j_ids'].tolist()))
+    iou = len(s32 & s16) / len(s32 | s16)
+    print('fp16 backbone match-set IoU', iou)
+    assert iou > 0.95
