@@ -47,7 +47,7 @@ def dual_softmax_stats(f0, f1, feat_div=1.0, sim_div=1.0, sim_mul=1.0, mask0=Non
 
 
 def coarse_match(f0, f1, temperature, thr, border, hw0, hw1, cell_scale, mask0=None, mask1=None,
-                 valid_hw=None, scale0=None, scale1=None, want_conf=False):
+                 valid_hw=None, scale0=None, scale1=None, want_conf=False, bf16=False):
     """K1.  Returns dict(b_ids, i_ids, j_ids, mconf, mkpts0_c, mkpts1_c, counts, conf_matrix|None).
 
     One host synchronisation (reading M) is inherent: the reference's outputs have data-dependent shape
@@ -57,7 +57,8 @@ def coarse_match(f0, f1, temperature, thr, border, hw0, hw1, cell_scale, mask0=N
     Z, L, C = f0.shape
     S = f1.shape[1]
     dev = f0.device
-    ws = _ws(lib.far_dual_softmax_workspace_bytes(Z, L, S), dev)
+    fn = lib.far_coarse_match_bf16 if bf16 else lib.far_coarse_match_f32
+    ws = _ws(lib.far_coarse_match_bf16_workspace_bytes(Z, L, S, C) if bf16 else lib.far_dual_softmax_workspace_bytes(Z, L, S), dev)
     cap = Z * L
     b_ids = torch.empty(cap, dtype=torch.int64, device=dev)
     i_ids = torch.empty(cap, dtype=torch.int64, device=dev)
@@ -67,14 +68,14 @@ def coarse_match(f0, f1, temperature, thr, border, hw0, hw1, cell_scale, mask0=N
     mk1 = torch.empty(cap, 2, dtype=torch.float32, device=dev)
     counts = torch.empty(Z + 1, dtype=torch.int32, device=dev)
     conf = torch.empty(Z, L, S, dtype=torch.float32, device=dev) if want_conf else None
-    rc = lib.far_coarse_match_f32(
+    rc = fn(
         _p(f0, torch.float32), _p(f1, torch.float32), Z, L, S, C, float(temperature), float(thr), int(border),
         int(hw0[0]), int(hw0[1]), int(hw1[0]), int(hw1[1]), float(cell_scale),
         _p(mask0, torch.uint8), _p(mask1, torch.uint8), _p(valid_hw, torch.int32),
         _p(scale0, torch.float32), _p(scale1, torch.float32), _p(conf),
         _p(b_ids), _p(i_ids), _p(j_ids), _p(mconf), _p(mk0), _p(mk1),
         _p(counts), ctypes.c_void_p(counts.data_ptr() + 4 * Z), _p(ws), _stream())
-    _lib.check(rc, 'far_coarse_match_f32')
+    _lib.check(rc, 'far_coarse_match_bf16' if bf16 else 'far_coarse_match_f32')
     counts_h = counts.cpu()
     M = int(counts_h[Z])
     return {

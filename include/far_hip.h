@@ -66,6 +66,18 @@ int far_coarse_match_f32(const float* f0, const float* f1, int Z, int L, int S, 
                          float* mkpts0_c, float* mkpts1_c, int* counts_out, int* total_out,
                          void* ws, far_stream_t stream);
 
+/* bf16-input variant of the matcher: features are rounded to bf16 (RNE) once, the contraction runs on the bf16
+ * matrix core with fp32 accumulation, everything after the dot product is the fp32 code of the exact variant.
+ * Same arguments / outputs as far_coarse_match_f32; C == 256 (the coarse feature width); workspace from the query below. */
+size_t far_coarse_match_bf16_workspace_bytes(int Z, int L, int S, int C);
+int far_coarse_match_bf16(const float* f0, const float* f1, int Z, int L, int S, int C,
+                          float temperature, float thr, int border, int h0, int w0, int h1, int w1,
+                          float cell_scale, const uint8_t* mask0, const uint8_t* mask1,
+                          const int* valid_hw, const float* scale0, const float* scale1,
+                          float* conf_out, int64_t* b_ids, int64_t* i_ids, int64_t* j_ids, float* mconf,
+                          float* mkpts0_c, float* mkpts1_c, int* counts_out, int* total_out,
+                          void* ws, far_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * K2  EMM head: bilinear dual-softmax attention  F = v~^T (softmax_row(s) * softmax_col(s)) v~
  * replaces src/loftr/loftr_module/transformer.py:275-292 (CrossAttention.forward), one call per direction

@@ -146,3 +146,45 @@ def test_mapfree_grid_544x720():
     f0, f1, _ = correlated_features(2, (68, 90), 256, seed=11, amp=1.3, frac=0.9)
     M = _check(f0, f1, (68, 90), False)
     assert M > 6000
+
+
+def _bf16_round(a):
+    u = a.astype(np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7fff + ((u >> 16) & 1)) & 0xffff0000
+    return u.astype(np.uint32).view(np.float32)
+
+
+@pytest.mark.parametrize('N,hw,C', [(2, (12, 16), 256), (1, (60, 80), 256), (2, (13, 17), 256)])
+def test_bf16_variant_is_exact_on_bf16_rounded_inputs(N, hw, C):
+    """far_coarse_match_bf16: the contraction runs on the bf16 matrix core.  Its parity statement is against the
+    oracle evaluated on the SAME bf16-rounded features (bit-exact ids on rows with margin, 1e-5 confidences)."""
+    from far_amd import ops
+    from oracle import coarse as oc
+    f0, f1, _ = correlated_features(N, hw, C, seed=21, amp=1.3 if C == 256 else 2.0, frac=0.85)
+    r0, r1 = _bf16_round(f0), _bf16_round(f1)
+    ref = oc.coarse_matching(r0, r1, CFG, hw, hw, (hw[0] * 8, hw[1] * 8), dtype=np.float64)
+    got = ops.coarse_match(torch.from_numpy(f0).cuda(), torch.from_numpy(f1).cuda(), 0.1, 0.2, 2, hw, hw, 8.0,
+                           want_conf=True, bf16=True)
+    rg, cg, tg = oc.margins(ref['conf_matrix'], 0.2)
+    sel = ref['conf_matrix'].max(axis=2) > 0.05
+    assert rg[sel].min() > 1e-5 and tg[sel].min() > 1e-5
+    for k in ['b_ids', 'i_ids', 'j_ids']:
+        np.testing.assert_array_equal(got[k].cpu().numpy(), ref[k])
+    np.testing.assert_allclose(got['mconf'].cpu().numpy(), ref['mconf'], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(got['conf_matrix'].cpu().numpy(), ref['conf_matrix'], atol=1e-5, rtol=0)
+    assert len(ref['b_ids']) > 50
+
+
+def test_bf16_variant_vs_fp32_path_iou():
+    """Deviation of the bf16 variant from the exact fp32 path (documented, not parity): match-set IoU and the
+    confidence difference on the common matches."""
+    from far_amd import ops
+    f0, f1, _ = correlated_features(4, (60, 80), 256, seed=23, amp=1.2, frac=0.8)
+    a = ops.coarse_match(torch.from_numpy(f0).cuda(), torch.from_numpy(f1).cuda(), 0.1, 0.2, 2, (60, 80), (60, 80), 8.0)
+    b = ops.coarse_match(torch.from_numpy(f0).cuda(), torch.from_numpy(f1).cuda(), 0.1, 0.2, 2, (60, 80), (60, 80), 8.0,
+                         bf16=True)
+    sa = set(zip(a['b_ids'].tolist(), a['i_ids'].tolist(), a['j_ids'].tolist()))
+    sb = set(zip(b['b_ids'].tolist(), b['i_ids'].tolist(), b['j_ids'].tolist()))
+    iou = len(sa & sb) / len(sa | sb)
+    print('bf16 vs fp32 match-set IoU', iou, len(sa), len(sb))
+    assert iou > 0.98

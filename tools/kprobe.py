@@ -20,6 +20,12 @@ if which in ('k1conf', 'all'):
     f1 = f0[:, torch.randperm(L, device=dev, generator=g)] + 0.1 * torch.randn(n, L, 256, device=dev, generator=g)
     for _ in range(it):
         ops.coarse_match(f0, f1, 0.1, 0.2, 2, (60, 80), (60, 80), 8.0, want_conf=True)
+if which in ('k1b',):
+    f0 = 1.2 * torch.randn(n, L, 256, device=dev, generator=g)
+    f1 = f0[:, torch.randperm(L, device=dev, generator=g)] + 0.1 * torch.randn(n, L, 256, device=dev, generator=g)
+    for _ in range(it):
+        ops.coarse_match(f0, f1, 0.1, 0.2, 2, (60, 80), (60, 80), 8.0, bf16=True)
+        ops.coarse_match(f0, f1, 0.1, 0.2, 2, (60, 80), (60, 80), 8.0, bf16=True, want_conf=True)
 if which in ('k2', 'all'):
     Z = n * 8
     q = torch.randn(Z, L, 64, device=dev, generator=g); k = torch.randn(Z, L, 64, device=dev, generator=g)
