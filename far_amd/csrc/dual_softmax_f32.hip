@@ -30,6 +30,7 @@ struct SimParams {
     float sim_mul;    // then * sim_mul           (1 for K1, head_dim^-0.5 for K2)
     float mask_fill;  // value for masked-out (i,j) pairs (-1e9 in the reference)
     int stagger;      // tuning: wave-slot priority staggering on/off
+    float k2;         // acc_scale / sim_div * sim_mul * log2(e): log2-domain score per unit dot product (bf16 path)
 };
 
 // The reference divides both feature maps by sqrt(C) before the contraction (coarse_matching.py:104-105).  When
@@ -47,6 +48,7 @@ inline SimParams make_sim(float feat_div, float sim_div, float sim_mul) {
     p.sim_mul = sim_mul;
     p.mask_fill = -1e9f;
     p.stagger = 0;
+    p.k2 = (float)((double)p.acc_scale / (double)sim_div * (double)sim_mul * 1.4426950408889634);
     return p;
 }
 
@@ -599,6 +601,23 @@ __global__ void k_cvt_bf16(const float4* __restrict__ in, uint2* __restrict__ ou
     }
 }
 
+__device__ __forceinline__ void softmax_merge2(float& m, float& s, float mo, float so) {   // log2-domain partials
+    const float mn = fmaxf(m, mo);
+    s = s * __builtin_amdgcn_exp2f(m - mn) + so * __builtin_amdgcn_exp2f(mo - mn);
+    m = mn;
+}
+
+__global__ void k_colreduce2(const float2* __restrict__ colpart, int nI, int S, float2* __restrict__ colstat) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x, z = blockIdx.y;
+    if (j >= S) return;
+    float m = NEG_BIG, s = 0.f;
+    for (int b = 0; b < nI; ++b) {
+        float2 v = colpart[((size_t)z * nI + b) * S + j];
+        softmax_merge2(m, s, v.x, v.y);
+    }
+    colstat[(size_t)z * S + j] = make_float2(m, s);
+}
+
 typedef __attribute__((address_space(1))) const void* far_gptr_t;
 typedef __attribute__((address_space(3))) void* far_lptr_t;
 
@@ -651,6 +670,58 @@ struct Bf16Tile {
     }
 };
 
+// Statistics of one 32 x 64 half tile held as two accumulators (lane: column 32 ct + l31, rows mfma32_row(r, h)).
+// Works in the log2 domain (one v_exp_f32 per term, no extra multiply).  FULL = no padding, no masks: no selects.
+template <bool FULL>
+__device__ __forceinline__ void stats_half_epilogue(f32x16 (&acc)[2], const SimParams& sp, float (&rm)[16], float (&rs)[16],
+                                                    float (&cmx)[2], float (&csm)[2], unsigned rowvalid, unsigned rowmasked,
+                                                    const bool* cvalid, const bool* cmasked) {
+    const float fill2 = sp.mask_fill * 1.44269504088896341f;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float s = acc[ct][r] * sp.k2;
+            if (!FULL) { if (cmasked[ct] || ((rowmasked >> r) & 1)) s = fill2; }
+            acc[ct][r] = s;
+        }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float tm;
+        if (FULL) tm = fmaxf(acc[0][r], acc[1][r]);
+        else {
+            tm = NEG_BIG;
+            if (cvalid[0]) tm = fmaxf(tm, acc[0][r]);
+            if (cvalid[1]) tm = fmaxf(tm, acc[1][r]);
+        }
+        const float mn = fmaxf(rm[r], tm);
+        float sum = rs[r] * __builtin_amdgcn_exp2f(rm[r] - mn);       // rm = -FLT_MAX initially: 2^-inf = 0, rs = 0
+        if (FULL) sum += __builtin_amdgcn_exp2f(acc[0][r] - mn) + __builtin_amdgcn_exp2f(acc[1][r] - mn);
+        else {
+            if (cvalid[0]) sum += __builtin_amdgcn_exp2f(acc[0][r] - mn);
+            if (cvalid[1]) sum += __builtin_amdgcn_exp2f(acc[1][r] - mn);
+        }
+        rm[r] = mn;
+        rs[r] = sum;
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        float m = NEG_BIG;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (FULL || ((rowvalid >> r) & 1)) m = fmaxf(m, acc[ct][r]);
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (FULL || ((rowvalid >> r) & 1)) s += __builtin_amdgcn_exp2f(acc[ct][r] - m);
+        const float mo = shfl_xor_f(m, 32), so = shfl_xor_f(s, 32);
+        const float mn = fmaxf(m, mo);
+        s = s * __builtin_amdgcn_exp2f(m - mn) + so * __builtin_amdgcn_exp2f(mo - mn);
+        cmx[ct] = mn;
+        csm[ct] = s;
+    }
+}
+
 template <int NS>
 __global__ __launch_bounds__(256, 2) void k_stats_bf16(
     const uint16_t* __restrict__ f0, const uint16_t* __restrict__ f1, int Z, int L, int S, SimParams sp,
@@ -697,50 +768,21 @@ __global__ __launch_bounds__(256, 2) void k_stats_bf16(
             f32x16 acc[2];
             tile.mma_half(acc, cur, l31, h);
             const int j0 = jh, jb = 0;
-            bool cvalid[2], cmasked[2];
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) {
-                const int j = j0 + jb + 32 * ct + l31;
-                cvalid[ct] = j < S;
-                cmasked[ct] = cvalid[ct] && mask1 && !mask1[(size_t)z * S + j];
-            }
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float s = sim_of(acc[ct][r], sp);
-                    if (cmasked[ct] || ((rowmasked >> r) & 1)) s = sp.mask_fill;
-                    acc[ct][r] = s;
-                }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float tm = NEG_BIG;
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
-                    if (cvalid[ct]) tm = fmaxf(tm, acc[ct][r]);
-                const float mn = fmaxf(rm[r], tm);
-                float sum = (rm[r] == mn) ? rs[r] : rs[r] * fexp(rm[r] - mn);
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
-                    if (cvalid[ct]) sum += fexp(acc[ct][r] - mn);
-                rm[r] = mn;
-                rs[r] = sum;
-            }
             float cmx[2], csm[2];
+            // log2-domain scores: s2 = dot * (acc_scale / temperature * log2 e); statistics are (max2, sum 2^(s2-max2))
+            // must be WAVE-UNIFORM: the epilogue exchanges values across the lanes of the wave (half swap)
+            const bool full = (jh + 64 <= S) && (i0 + 32 * wave + 32 <= L) && !mask0 && !mask1;
+            if (full) {
+                stats_half_epilogue<true>(acc, sp, rm, rs, cmx, csm, 0xffffu, 0u, nullptr, nullptr);
+            } else {
+                bool cvalid[2], cmasked[2];
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct) {
-                float m = NEG_BIG;
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if ((rowvalid >> r) & 1) m = fmaxf(m, acc[ct][r]);
-                float s = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if ((rowvalid >> r) & 1) s += fexp(acc[ct][r] - m);
-                const float mo = shfl_xor_f(m, 32), so = shfl_xor_f(s, 32);
-                softmax_merge(m, s, mo, so);
-                cmx[ct] = m;
-                csm[ct] = s;
+                for (int ct = 0; ct < 2; ++ct) {
+                    const int j = j0 + jb + 32 * ct + l31;
+                    cvalid[ct] = j < S;
+                    cmasked[ct] = cvalid[ct] && mask1 && !mask1[(size_t)z * S + j];
+                }
+                stats_half_epilogue<false>(acc, sp, rm, rs, cmx, csm, rowvalid, rowmasked, cvalid, cmasked);
             }
             if (h == 0) {
 #pragma unroll
@@ -754,7 +796,7 @@ __global__ __launch_bounds__(256, 2) void k_stats_bf16(
 #pragma unroll
                 for (int w = 1; w < 4; ++w) {
                     const float2 o = colh[w * 64 + tid];
-                    softmax_merge(m, s, o.x, o.y);
+                    softmax_merge2(m, s, o.x, o.y);
                 }
                 colpart[((size_t)z * nI + Ib) * S + j0 + jb + tid] = make_float2(m, s);
             }
@@ -766,7 +808,7 @@ __global__ __launch_bounds__(256, 2) void k_stats_bf16(
 #pragma unroll
         for (int d = 1; d < 32; d <<= 1) {
             const float mo = shfl_xor_f(m, d), so = shfl_xor_f(s, d);
-            softmax_merge(m, s, mo, so);
+            softmax_merge2(m, s, mo, so);
         }
         if (l31 == 0 && ((rowvalid >> r) & 1))
             rowstat[(size_t)z * L + i0 + 32 * wave + mfma32_row(r, h)] = make_float2(m, s);
@@ -830,9 +872,9 @@ __global__ __launch_bounds__(256, 2) void k_match_bf16(
                 float cb = -1.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float s = sim_of(acc[ct][r], sp);
-                    if (cmasked || ((rowmasked >> r) & 1)) s = sp.mask_fill;
-                    const float p = (fexp(s - cst.x) * cinv) * (fexp(s - rmax[r]) * rinv[r]);
+                    float s = acc[ct][r] * sp.k2;                                   // log2 domain (statistics too)
+                    if (cmasked || ((rowmasked >> r) & 1)) s = sp.mask_fill * 1.44269504088896341f;
+                    const float p = (__builtin_amdgcn_exp2f(s - cst.x) * cinv) * (__builtin_amdgcn_exp2f(s - rmax[r]) * rinv[r]);
                     if (cvalid && ((rowvalid >> r) & 1)) {
                         if (conf) conf[((size_t)z * L + i0 + 32 * wave + mfma32_row(r, h)) * S + j] = p;
                         if (p > bestv[r]) { bestv[r] = p; bestj[r] = j; }
@@ -1007,7 +1049,7 @@ int far_coarse_match_bf16(const float* f0, const float* f1, int Z, int L, int S,
 #define FAR_BF16_LAUNCH(NS)                                                                                          \
     hipLaunchKernelGGL(k_stats_bf16<NS>, dim3(nI * Z), dim3(256), smem, stream, f0b, f1b, Z, L, S, sp, mask0, mask1, \
                        w.rowstat, w.colpart);                                                                        \
-    hipLaunchKernelGGL(k_colreduce, dim3((S + 255) / 256, Z), dim3(256), 0, stream, w.colpart, nI, S, w.colstat);    \
+    hipLaunchKernelGGL(k_colreduce2, dim3((S + 255) / 256, Z), dim3(256), 0, stream, w.colpart, nI, S, w.colstat);   \
     hipLaunchKernelGGL(k_match_bf16<NS>, dim3(nI * Z), dim3(256), smem, stream, f0b, f1b, Z, L, S, sp, mask0, mask1, \
                        w.rowstat, w.colstat, conf_out, w.rowbest_v, w.rowbest_j, w.colbest_part);
     FAR_BF16_LAUNCH(16)

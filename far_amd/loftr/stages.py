@@ -38,6 +38,9 @@ class CoarseMatching(nn.Module):
         # data['conf_matrix'] (92 MB / pair) is consumed only by the coarse loss and by plotting
         # (loftr_loss.py:307-311); it is materialised when training or when asked for explicitly.
         self.materialize_conf = False
+        # contraction on the bf16 matrix core (far_coarse_match_bf16): 4x faster, exact on bf16-rounded features,
+        # match-set IoU vs the fp32 path reported by tests/test_coarse_gpu.py; off = the fp32 parity configuration
+        self.bf16 = False
 
     def forward(self, feat_c0, feat_c1, data, mask_c0=None, mask_c1=None):
         """feat_c0 [N, L, C], feat_c1 [N, S, C]; updates data with conf_matrix (optional), b_ids, i_ids,
@@ -57,7 +60,7 @@ class CoarseMatching(nn.Module):
         s1 = data['scale1'].float().contiguous() if 'scale1' in data else None
         out = ops.coarse_match(feat_c0.float().contiguous(), feat_c1.float().contiguous(), self.temperature,
                                self.thr, self.border_rm, hw0, hw1, scale, as_u8(mask_c0), as_u8(mask_c1),
-                               valid_hw, s0, s1, want_conf=self.materialize_conf)
+                               valid_hw, s0, s1, want_conf=self.materialize_conf, bf16=self.bf16)
         mconf = out['mconf']
         data.update({
             'conf_matrix': out['conf_matrix'],
