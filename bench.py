@@ -37,7 +37,7 @@ def parse():
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'fp16-fine', 'fp16', 'bf16'],
                     help='arithmetic of the vendor-path convolutions (far_amd.loftr.LoFTR.set_precision); kernels stay fp32/f64')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-pairs', type=int, default=1)
+    ap.add_argument('--cpu-pairs', type=int, default=3)
     return ap.parse_args()
 
 
