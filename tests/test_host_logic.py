@@ -49,3 +49,19 @@ def test_inference_on_cpu_raises_instead_of_falling_back():
     m = CoarseMatching(far_eval_config()['match_coarse']).eval()
     with torch.no_grad(), pytest.raises(_lib.FarHipError):
         m(torch.zeros(1, 4, 32), torch.zeros(1, 4, 32), {'hw0_c': (2, 2), 'hw1_c': (2, 2), 'hw0_i': (16, 16)})
+
+
+def test_cached_prediction_format_roundtrip(tmp_path):
+    from far_amd import cache_io
+    g = torch.Generator().manual_seed(0)
+    B = 3
+    data = {'loftr_rt': torch.randn(B, 3, 4, generator=g, dtype=torch.float64), 'num_correspondences': torch.tensor([5, 700, 0]),
+            'featmap0': torch.randn(B, 4800, 256, generator=g), 'featmap1': torch.randn(B, 4800, 256, generator=g)}
+    cache_io.save_batch(str(tmp_path), 'test', [7, 8, 11], data)
+    # the reference's reader side: one .pt per quantity per pair id (interiornet_streetlearn.py:108-118)
+    one = torch.load(str(tmp_path / 'test' / 'coarse_features' / '8.pt'))
+    assert one.shape == (2, 4800, 256) and torch.equal(one[1], data['featmap1'][1])
+    assert torch.load(str(tmp_path / 'test' / 'loftr_preds' / '11.pt')).shape == (3, 4)
+    back = cache_io.load_batch(str(tmp_path), 'test', [11, 7])
+    assert torch.equal(back['loftr_rt'], data['loftr_rt'][[2, 0]]) and back['num_correspondences'].tolist() == [0, 5]
+    assert torch.equal(back['featmap0'], data['featmap0'][[2, 0]]) and back['inliers_best_tight'].tolist() == [0, 0]

@@ -122,3 +122,26 @@ def test_cached_path_batch_256():
     # accuracy over the batch against ground truth
     Rerr = np.array([np.linalg.norm(got['R'][b] - scenes[b][3]) for b in range(B) if got['status'][b]])
     assert np.median(Rerr) < 0.02
+
+
+def test_estimate_pose_single_pair_contract():
+    """far_amd.solver.estimate_pose keeps the reference's signature and return contract (metrics.py:80-174, :169)."""
+    from far_amd.solver import estimate_pose
+    k0, k1, K, Rgt, tgt = two_view_scene(500, seed=77)
+    Kt = torch.from_numpy(K).cuda()
+    ret, n_after, tight, ultra = estimate_pose(torch.from_numpy(k0).cuda(), torch.from_numpy(k1).cuda(), Kt, Kt, 0.5,
+                                               conf=0.99999, solver='prior_ransac', priorRT=None)
+    R, t, mask, E = ret
+    assert R.is_cuda and R.dtype == torch.float64 and R.shape == (3, 3) and t.shape == (3,) and t.is_cuda
+    assert isinstance(mask, np.ndarray) and mask.dtype == bool and mask.shape == (500,)
+    assert (not E.is_cuda) and E.dtype == torch.float64 and E.shape == (3, 3)
+    assert int(n_after) == int(mask.sum()) and tight == 0 and ultra == 0       # plain-RANSAC branch (metrics.py:96-97)
+    assert np.linalg.norm(R.cpu().numpy() - Rgt) < 0.05
+    prior = np.concatenate([Rgt, (2 * tgt)[:, None]], 1)
+    ret2, n2, tight2, ultra2 = estimate_pose(torch.from_numpy(k0).cuda(), torch.from_numpy(k1).cuda(), Kt, Kt, 0.5,
+                                             solver='prior_ransac', priorRT=prior,
+                                             translation_scale=torch.tensor(2.5, dtype=torch.float64))
+    assert ret2 is not None and tight2 >= ultra2 > 0
+    assert abs(float(ret2[1].norm()) - 2.5) < 1e-9                              # t *= translation_scale (:167-168)
+    # fewer than 5 correspondences -> (None, 0, 0, 0) without touching the GPU (:83-85)
+    assert estimate_pose(torch.from_numpy(k0[:4]).cuda(), torch.from_numpy(k1[:4]).cuda(), Kt, Kt, 0.5) == (None, 0, 0, 0)
