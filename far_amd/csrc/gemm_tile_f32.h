@@ -68,12 +68,8 @@ __device__ __forceinline__ void chunk_store(const ChunkRegs& r, TileLds& lds, in
     }
 }
 
-// acc[ct] (+)= tile product for one 32-channel chunk.
-// SWAP=false: D[m = row token][n = col token]: lane holds column token 32ct+(lane&31),
-//             row tokens 32w + mfma32_row(reg, h).
-// SWAP=true : D[m = col token][n = row token]: lane holds row token 32w+(lane&31),
-//             column tokens 32ct + mfma32_row(reg, h).
-template <bool SWAP>
+// acc[ct] (+)= tile product for one 32-channel chunk: D[m = row token][n = col token]; a lane holds column token
+// 32ct + (lane & 31) and row tokens 32w + mfma32_row(reg, h).
 __device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[4], const TileLds& lds, int buf, int wave,
                                            int lane) {
     const int l31 = lane & 31, h = lane >> 5;
@@ -90,10 +86,7 @@ __device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[4], const TileLds& lds,
         for (int c = 0; c < 4; ++c) {
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {
-                if (SWAP)
-                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[ct][c], av[c], acc[ct], 0, 0, 0);
-                else
-                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c], bv[ct][c], acc[ct], 0, 0, 0);
+                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c], bv[ct][c], acc[ct], 0, 0, 0);
             }
         }
     }
