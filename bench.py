@@ -35,7 +35,7 @@ def parse():
     ap.add_argument('--pairs', type=int, default=PAIRS_PER_GPU, help='pairs per GPU per step')
     ap.add_argument('--hyp', type=int, default=2048, help='RANSAC hypotheses per pair (metrics.py:120)')
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'fp16-fine', 'fp16', 'bf16'],
-                    help='arithmetic of the vendor-path convolutions (far_amd.loftr.LoFTR.set_precision); kernels stay fp32/f64')
+                    help='backbone convolution arithmetic (far_amd.loftr.LoFTR.set_precision): fp32 = split-fp16 operand pairs (fp32-grade)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-pairs', type=int, default=3)
     return ap.parse_args()

@@ -1,0 +1,460 @@
+// K9: implicit-GEMM convolution / linear layer on the f16 matrix cores with SPLIT-PRECISION operands
+// (fp32 tensors in and out, fp32 accumulation), with the inference BatchNorm / bias, the activation and the residual
+// add fused into the epilogue.
+//
+// Replaces, for inference, the 3x3 and 1x1 stride-1 convolutions of the ResNet-FPN backbone
+//   mp3d_loftr/src/loftr/backbone/resnet_fpn.py:5-12   (conv1x1 / conv3x3)
+//                                               :15-43 (BasicBlock: conv -> bn -> relu -> conv -> bn -> +x -> relu)
+//                                               :101-119 (ResNetFPN_8_2.forward: layer*_outconv, layer*_outconv2)
+// and nn.Linear layers (a 1x1 convolution over a [rows][K] matrix).  These are 55 % (convolutions) + 17 % (linear
+// layers) of the fp32 step on the vendor libraries, whose fp32 kernels cannot use the 16x faster f16 matrix rate.
+//
+// Numerics.  Every fp32 operand v is scaled by a power of two and split as v = hi + lo with hi = fp16(v),
+// lo = fp16(v - hi): 22 significand bits, |v - hi - lo| <= 2^-24 |v| (down to the fp16 subnormal floor, which the
+// scaling keeps ~2^-29 of the activation scale).  The product uses three MFMAs, hi.hi + hi.lo + lo.hi (each f16 x f16
+// product is exact in fp32; the dropped lo.lo term is <= 2^-24 |a||b|), accumulated in fp32 by the matrix core:
+// fp32-grade results (measured against a float64 convolution in tests/test_conv_gpu.py, next to the vendor fp32
+// Winograd kernel's error) at 16/3 of the fp32 MFMA rate.  SPLIT = false keeps only hi (plain fp16 operands).
+//
+// Tiling (gfx950).  Workgroup = 4 waves, every wave owns 64 output pixels (4 tile rows x 16 columns; 64 consecutive
+// rows for 1x1 / linear) x 128 output channels = 2 x 4 accumulator tiles of 32x32x16 f16 MFMAs (128 registers).
+// Cout <= 128: 4 x 1 waves, WG tile 256 pixels x 128 channels; wider: 2 x 2 waves, 128 pixels x 256 channels.
+// K loop: input-channel chunks of 32; inside a chunk the KS*KS taps; inside a tap two 16-channel k-steps = "phases".
+//  * pixels: per chunk the (TH+2) x (16+2) input halo is read ONCE from HBM (fp32, requested three taps early into
+//    registers), split and written to LDS after the chunk's last phase; all 9 taps read it at shifted addresses
+//    (80-byte pixel stride, 256-byte-aligned rows: conflict-free ds_read_b128 fragment reads).
+//  * weights: per phase one NT x 16-channel slab (pre-split and pre-swizzled by far_conv_pack_f32 in execution order,
+//    so the global image IS the LDS image and the source pointer just advances) streams in by LDS-DMA
+//    (global_load_lds_dwordx4) into a ring of three slabs, two phases ahead (counted vmcnt + raw s_barrier: the
+//    barrier never drains the DMA queue).  One barrier per phase.
+//  * per phase and wave: 12 ds_read_b128 fragment reads (the pixel fragments one phase ahead, the weight fragments in
+//    two halves, the second behind the first half's MFMAs) and 24 MFMAs (split) / 8 (plain).
+// Measured on MI355X (64 images, tools/conv_probe.py): 3x3 layers 270-380 TFLOP/s fp32-equivalent (0.8-1.2 PFLOP/s of
+// f16 MFMA issue, ~47 % of the matrix peak) including the fused epilogue, against 100-125 TFLOP/s for the vendor
+// fp32 Winograd convolution alone.
+#include "common.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int TW = 16;                  // output tile columns of the 3x3 kernels (rows: 4 per pixel-wave)
+constexpr int A_PXB = 80;               // LDS bytes per staged pixel per plane: 32 fp16 channels + 16 B pad
+constexpr float ACT_SCALE = 16.0f;      // activations are scaled by 2^4 before the split (see far_conv_nhwc_f32)
+
+// LDS image of the staged input pixels of one 32-channel chunk.  3x3: the (TH+2) x (16+2) halo, row stride rounded
+// up to a multiple of 256 B so that, with the odd 5-slot pixel stride, every 16-lane group of a ds_read_b128
+// fragment read (lanes {0-3,12-15,20-27}, ... = 8 pixels of one tile row + 8 of the next) hits 16 distinct slots.
+template <int KS, int MW>
+struct Geo {
+    static constexpr int TH = 4 * MW;
+    static constexpr int HW = TW + KS - 1, HH = TH + KS - 1;
+    static constexpr int PX = KS == 1 ? 64 * MW : HW * HH;       // staged pixels per chunk
+    static constexpr int ROWB = KS == 1 ? 0 : (HW * A_PXB + 255) / 256 * 256;
+    static constexpr int A_PLANE = KS == 1 ? PX * A_PXB : HH * ROWB;
+    static constexpr int ITEMS = PX * 4;                          // (pixel, 8-channel group) staging items
+    __device__ static constexpr int px_off(int hy, int hx) { return hy * ROWB + hx * A_PXB; }
+};
+
+struct ConvArgs {
+    const float* x;
+    const unsigned char* w;      // packed weights (far_conv_pack_f32)
+    const float* scale;          // [Cout] multiplies the accumulator (BN scale / 1, with the operand scaling folded in)
+    const float* shift;          // [Cout] or null
+    const float* res;            // residual, same layout as y, or null
+    float* y;
+    long npix;                   // N * H * W
+    long ntiles;                 // blocks along x
+    int H, W, Cin, Cout, tilesX, tilesY, nchunks, nblkY, act;
+    float slope;
+};
+
+__device__ __forceinline__ void split8(const float4& u, const float4& v, f16x8& hi, f16x8& lo) {
+    const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float s = x[i] * ACT_SCALE;
+        const _Float16 hh = (_Float16)s;
+        hi[i] = hh;
+        lo[i] = (_Float16)(s - (float)hh);
+    }
+}
+
+// Register staging of one chunk's input pixels: item i = (pixel i >> 2, 8-channel group i & 3).
+template <int ITERS>
+struct Stage {
+    float4 v[ITERS][2];
+};
+
+struct TilePos {
+    int img, oy0, ox0;
+    long pix0;
+};
+
+template <int KS, int MW, int NTHR, int ITERS>
+__device__ __forceinline__ void stage_load(Stage<ITERS>& st, const ConvArgs& p, const TilePos& tp, int chunk, int tid) {
+    using G = Geo<KS, MW>;
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int i = tid + NTHR * it;
+        const int hp = i >> 2, g = i & 3;
+        const int c0 = 32 * chunk + 8 * g;
+        bool ok = i < G::ITEMS;
+        long pix;
+        if (KS == 1) {
+            pix = tp.pix0 + hp;
+            ok = ok && pix < p.npix;
+        } else {
+            const int hy = hp / G::HW, hx = hp - hy * G::HW;
+            const int iy = tp.oy0 - KS / 2 + hy, ix = tp.ox0 - KS / 2 + hx;
+            ok = ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            pix = ((long)tp.img * p.H + iy) * p.W + ix;
+        }
+        // unconditional 16-byte loads from a clamped (always valid) address, zeroed by select: no exec-mask branches
+        const bool ok0 = ok && c0 < p.Cin, ok1 = ok && c0 + 4 < p.Cin;
+        const float* src0 = ok0 ? p.x + pix * p.Cin + c0 : p.x;
+        const float* src1 = ok1 ? p.x + pix * p.Cin + c0 + 4 : p.x;
+        const float4 u = *reinterpret_cast<const float4*>(src0), w = *reinterpret_cast<const float4*>(src1);
+        st.v[it][0] = make_float4(ok0 ? u.x : 0.f, ok0 ? u.y : 0.f, ok0 ? u.z : 0.f, ok0 ? u.w : 0.f);
+        st.v[it][1] = make_float4(ok1 ? w.x : 0.f, ok1 ? w.y : 0.f, ok1 ? w.z : 0.f, ok1 ? w.w : 0.f);
+    }
+}
+
+template <int KS, int MW, int NTHR, int ITERS, bool SPLIT>
+__device__ __forceinline__ void stage_store(const Stage<ITERS>& st, unsigned char* As, int tid) {
+    using G = Geo<KS, MW>;
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int i = tid + NTHR * it;
+        if (i < G::ITEMS) {
+            const int hp = i >> 2, g = i & 3;
+            int off;
+            if (KS == 1) off = hp * A_PXB;
+            else { const int hy = hp / G::HW; off = G::px_off(hy, hp - hy * G::HW); }
+            f16x8 hi, lo;
+            split8(st.v[it][0], st.v[it][1], hi, lo);
+            *reinterpret_cast<f16x8*>(As + off + g * 16) = hi;
+            if (SPLIT) *reinterpret_cast<f16x8*>(As + G::A_PLANE + off + g * 16) = lo;
+        }
+    }
+}
+
+// Workgroup = MW x NW waves: wave (wm, wn) owns 64 pixels (4 tile rows x 16) x 32 NTW output channels.
+template <int KS, int MW, int NW, int NTW, bool SPLIT>
+__global__ __launch_bounds__(64 * MW * NW, 2) void k_conv(const ConvArgs p) {
+    using G = Geo<KS, MW>;
+    constexpr int NTHR = 64 * MW * NW;
+    constexpr int PLANES = SPLIT ? 2 : 1;
+    constexpr int TAPS = KS * KS;
+    constexpr int NT = 32 * NTW * NW;                // output channels per workgroup
+    constexpr int A_BUF = PLANES * G::A_PLANE;
+    constexpr int B_PLANE = NT * 32;                 // one 16-channel k-step of the weight slab
+    constexpr int B_BUF = PLANES * B_PLANE;
+    constexpr int B_ITERS = (B_BUF + NTHR * 16 - 1) / (NTHR * 16);   // DMA rounds per slab (the last may be partial)
+    constexpr int ITERS = (G::ITEMS + NTHR - 1) / NTHR;
+    constexpr int LOAD_TAP = TAPS >= 3 ? TAPS - 3 : 0;   // the next chunk's pixels are requested this early
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const As = smem;
+    unsigned char* const Bs = smem + A_BUF;          // ring of 3 slabs
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / NW, wn = wave % NW, l31 = lane & 31, h = lane >> 5;
+
+    // ---- which output tile.  Hardware places block b on XCD b % 8: give each XCD a contiguous range of tiles so
+    // that the halos shared by neighbouring tiles are re-read from that XCD's L2.
+    long t = blockIdx.x;
+    if ((p.ntiles & 7) == 0) t = (t & 7) * (p.ntiles >> 3) + (t >> 3);
+    TilePos tp{0, 0, 0, 0};
+    if (KS == 1) {
+        tp.pix0 = t * (64 * MW);
+    } else {
+        const int tx = (int)(t % p.tilesX);
+        t /= p.tilesX;
+        const int ty = (int)(t % p.tilesY);
+        tp.img = (int)(t / p.tilesY);
+        tp.oy0 = ty * G::TH;
+        tp.ox0 = tx * TW;
+    }
+    const int by = blockIdx.y;
+    const int cout_w = by * NT + 32 * NTW * wn;                       // first output channel of this wave
+
+    // ---- weight slabs, stored in execution order [chunk][tap][k-step][cout block]: the LDS-DMA source pointer of
+    // the prefetch just advances by one slab per phase (two when the all-padding last k-step is skipped).
+    const int nchunks = p.nchunks;
+    const int last_nks = (p.Cin - 32 * (nchunks - 1)) > 16 ? 2 : 1;
+    const size_t slab_stride = (size_t)p.nblkY * B_BUF;
+    const unsigned char* wsrc = p.w + (size_t)by * B_BUF + tid * 16;
+    int pc = 0, pt = 0, pk = 0, pslot = 0;          // (chunk, tap, k-step) of the next slab to request, ring slot
+    auto prefetch = [&]() {
+        if (pc < nchunks) {
+            unsigned char* dst = Bs + pslot * B_BUF + wave * 1024;
+#pragma unroll
+            for (int j = 0; j < B_ITERS; ++j)
+                if ((j + 1) * NTHR * 16 <= B_BUF || j * NTHR * 16 + wave * 1024 < B_BUF)       // wave-uniform
+                    __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + j * (NTHR * 16)), (lptr_t)(dst + j * (NTHR * 16)), 16, 0, 0);
+            pslot = pslot == 2 ? 0 : pslot + 1;
+            const int nks = pc == nchunks - 1 ? last_nks : 2;
+            wsrc += slab_stride;
+            if (++pk == nks) {
+                if (nks == 1) wsrc += slab_stride;
+                pk = 0;
+                if (++pt == TAPS) { pt = 0; ++pc; }
+            }
+        }
+    };
+
+    // ---- per-lane fragment offsets
+    int a_off[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int mtile = 2 * wm + mt;
+        if (KS == 1) a_off[mt] = (32 * mtile + l31) * A_PXB + h * 16;
+        else a_off[mt] = G::px_off(2 * mtile + (l31 >> 4), l31 & 15) + h * 16;
+    }
+    // weight row n of the slab: 2 slots of 8 channels, slot ^= (n >> 3) & 1 (conflict-free fragment reads)
+    const int b_off = (32 * NTW * wn + l31) * 32 + ((h ^ ((l31 >> 3) & 1)) * 16);
+
+    f32x16 acc[2][NTW];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    // ---- prologue: pixels of chunk 0, weight slabs of phases 0 and 1 (the ring runs two phases ahead)
+    Stage<ITERS> st;
+    stage_load<KS, MW, NTHR, ITERS>(st, p, tp, 0, tid);
+    prefetch();
+    prefetch();
+    stage_store<KS, MW, NTHR, ITERS, SPLIT>(st, As, tid);
+
+    // Fragment registers.  The pixel (A) fragments of a phase are read during the previous phase; the weight (B)
+    // fragments in two halves of NTW / 2 column tiles, the second half behind the first half's MFMAs.
+    constexpr int NH = NTW / 2;
+    constexpr bool APRE = ITERS <= 3;      // pixel fragments one phase ahead (needs 16 more registers)
+    f16x8 ah[2], al[2], ahn[2], aln[2], bh[2][NH], bl[2][NH];
+    auto read_a = [&](f16x8 (&xh)[2], f16x8 (&xl)[2], int tap, int ks) {
+        const int tapoff = KS == 1 ? 0 : G::px_off(tap / KS, tap % KS);
+        const unsigned char* A = As + tapoff + ks * 32;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            xh[mt] = *reinterpret_cast<const f16x8*>(A + a_off[mt]);
+            if (SPLIT) xl[mt] = *reinterpret_cast<const f16x8*>(A + G::A_PLANE + a_off[mt]);
+        }
+    };
+    auto read_b = [&](int half, const unsigned char* B) {
+#pragma unroll
+        for (int q = 0; q < NH; ++q) {
+            bh[half][q] = *reinterpret_cast<const f16x8*>(B + (half * NH + q) * 32 * 32);
+            if (SPLIT) bl[half][q] = *reinterpret_cast<const f16x8*>(B + B_PLANE + (half * NH + q) * 32 * 32);
+        }
+    };
+    auto mma_half = [&](int half) {
+#pragma unroll
+        for (int q = 0; q < NH; ++q)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                acc[mt][half * NH + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[half][q], acc[mt][half * NH + q], 0, 0, 0);
+        if (SPLIT) {
+#pragma unroll
+            for (int q = 0; q < NH; ++q)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    acc[mt][half * NH + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[half][q], acc[mt][half * NH + q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < NH; ++q)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    acc[mt][half * NH + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[half][q], acc[mt][half * NH + q], 0, 0, 0);
+        }
+    };
+
+    int slot = 0;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int nks = chunk == nchunks - 1 ? last_nks : 2;
+        for (int tap = 0; tap < TAPS; ++tap) {
+            for (int ks = 0; ks < nks; ++ks) {
+                const bool first = tap == 0 && ks == 0;                       // first phase of a chunk
+                const bool last = tap == TAPS - 1 && ks == nks - 1;           // last phase of a chunk
+                // this phase's slab has landed once at most the younger slab's DMAs are outstanding
+                if (pc < nchunks || pslot != (slot == 2 ? 0 : slot + 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B_ITERS) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                const unsigned char* B = Bs + slot * B_BUF + b_off;
+                read_b(0, B);
+                if (first || !APRE) read_a(ah, al, tap, ks);
+                __builtin_amdgcn_sched_barrier(0);
+                prefetch();
+                if (tap == LOAD_TAP && ks == 0 && chunk + 1 < nchunks) stage_load<KS, MW, NTHR, ITERS>(st, p, tp, chunk + 1, tid);
+                read_b(1, B);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_half(0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (APRE && !last) {
+                    const int ntap = ks + 1 == nks ? tap + 1 : tap, nk = ks + 1 == nks ? 0 : ks + 1;
+                    read_a(ahn, aln, ntap, nk);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mma_half(1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) if (APRE) { ah[mt] = ahn[mt]; al[mt] = aln[mt]; }
+                slot = slot == 2 ? 0 : slot + 1;
+            }
+        }
+        if (chunk + 1 < nchunks) {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done with this chunk's pixels
+            stage_store<KS, MW, NTHR, ITERS, SPLIT>(st, As, tid);
+        }
+    }
+
+    // ---- epilogue: y = act(acc * scale[c] + shift[c] + res)
+    const float* __restrict__ resp = p.res;
+    float* __restrict__ yp = p.y;
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        const int co = cout_w + 32 * nt + l31;
+        if (co >= p.Cout) continue;
+        const float sc = p.scale[co], sh = p.shift ? p.shift[co] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int mtile = 2 * wm + mt;
+            long off[16];
+            float rv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int prow = mfma32_row(r, h);
+                off[r] = -1;
+                if (KS == 1) {
+                    const long pix = tp.pix0 + 32 * mtile + prow;
+                    if (pix < p.npix) off[r] = pix * p.Cout + co;
+                } else {
+                    const int oy = tp.oy0 + 2 * mtile + (prow >> 4), ox = tp.ox0 + (prow & 15);
+                    if (oy < p.H && ox < p.W) off[r] = (((long)tp.img * p.H + oy) * p.W + ox) * p.Cout + co;
+                }
+                rv[r] = (resp && off[r] >= 0) ? resp[off[r]] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[mt][nt][r] * sc + sh + rv[r];
+                if (p.act == 1) v = fmaxf(v, 0.f);
+                else if (p.act == 2) v = v > 0.f ? v : v * p.slope;
+                if (off[r] >= 0) yp[off[r]] = v;
+            }
+        }
+    }
+}
+
+// Packs torch-layout weights [Cout][Cin][KS][KS] (or [Cout][Cin] for linear) into the LDS image the kernel DMAs, in
+// execution order: [chunk][tap][k-step][cout block][plane][NT rows][2 slots of 8 channels, slot ^= (row >> 3) & 1]
+// fp16, scaled by 2^w_exp.
+__global__ void k_conv_pack(const float* __restrict__ w, int Cin, int Cout, int taps, int nchunks, int nblkY, int NT,
+                            int planes, float wmul, _Float16* __restrict__ out) {
+    const long total = (long)taps * nchunks * 2 * nblkY * NT * 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long t = i;
+        const int s = (int)(t & 1); t >>= 1;
+        const int nn = (int)(t % NT); t /= NT;
+        const int by = (int)(t % nblkY); t /= nblkY;
+        const int ks = (int)(t & 1); t >>= 1;
+        const int tap = (int)(t % taps);
+        const int chunk = (int)(t / taps);
+        const int n = by * NT + nn;
+        _Float16* dst = out + (((((size_t)(chunk * taps + tap) * 2 + ks) * nblkY + by) * planes) * NT + nn) * 16 +
+                        ((s ^ ((nn >> 3) & 1)) * 8);
+        for (int e = 0; e < 8; ++e) {
+            const int ch = 32 * chunk + 16 * ks + 8 * s + e;
+            float v = 0.f;
+            if (n < Cout && ch < Cin) v = w[((size_t)n * Cin + ch) * taps + tap] * wmul;
+            const _Float16 hh = (_Float16)v;
+            dst[e] = hh;
+            if (planes == 2) dst[(size_t)NT * 16 + e] = (_Float16)(v - (float)hh);
+        }
+    }
+}
+
+// Tile configuration by output width: up to 128 channels -> 256 pixels x 128 channels (4 x 1 waves), wider ->
+// 128 pixels x 256 channels per block (2 x 2 waves); every wave owns 64 pixels x 128 channels.  (Measured on
+// MI355X: 8-wave workgroups of the same wave tile and 64-channel wave tiles were equal or slower.)
+struct TileCfg { int mw, nw, nt; };
+inline TileCfg cfg_for(int Cout) { return Cout <= 128 ? TileCfg{4, 1, 128} : TileCfg{2, 2, 256}; }
+
+template <int KS, int MW, int NW, int NTW, bool SPLIT>
+int launch_conv(const ConvArgs& a, dim3 grid, hipStream_t stream) {
+    using G = Geo<KS, MW>;
+    constexpr int PLANES = SPLIT ? 2 : 1;
+    constexpr int smem = PLANES * G::A_PLANE + 3 * PLANES * 32 * NTW * NW * 32;
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute((const void*)k_conv<KS, MW, NW, NTW, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+            return far_check_launch();
+        configured = true;
+    }
+    hipLaunchKernelGGL((k_conv<KS, MW, NW, NTW, SPLIT>), grid, dim3(64 * MW * NW), smem, stream, a);
+    return far_check_launch();
+}
+
+template <int KS, bool SPLIT>
+int launch_cfg(const TileCfg& c, const ConvArgs& a, dim3 grid, hipStream_t stream) {
+    if (c.mw == 4) return launch_conv<KS, 4, 1, 4, SPLIT>(a, grid, stream);
+    return launch_conv<KS, 2, 2, 4, SPLIT>(a, grid, stream);
+}
+
+}  // namespace
+
+extern "C" {
+
+// Bytes of the packed weight image for a [Cout][Cin][ksize][ksize] weight (split = 1: hi + lo planes).
+size_t far_conv_packed_bytes(int Cin, int Cout, int ksize, int split) {
+    if (Cin <= 0 || Cout <= 0 || (ksize != 1 && ksize != 3)) return 0;
+    const int NT = cfg_for(Cout).nt;
+    const size_t nchunks = (Cin + 31) / 32, nblkY = (Cout + NT - 1) / NT;
+    return (size_t)ksize * ksize * nchunks * nblkY * (split ? 2 : 1) * NT * 64;
+}
+
+// w: torch layout [Cout][Cin][ksize][ksize] fp32.  Every weight is multiplied by 2^w_exp before the fp16 split
+// (choose w_exp so that max|w| 2^w_exp is in [2^13, 2^15): the lo parts stay fp16-normal); the caller folds
+// 2^-(w_exp + 4) into the `scale` vector passed to far_conv_nhwc_f32.
+int far_conv_pack_f32(const float* w, int Cin, int Cout, int ksize, int w_exp, int split, void* packed, hipStream_t stream) {
+    far_clear_errors();
+    if (!w || !packed || far_conv_packed_bytes(Cin, Cout, ksize, split) == 0 || w_exp < -60 || w_exp > 60) return FAR_EINVAL;
+    const int NT = cfg_for(Cout).nt;
+    const int nchunks = (Cin + 31) / 32, nblkY = (Cout + NT - 1) / NT;
+    hipLaunchKernelGGL(k_conv_pack, dim3(512), dim3(256), 0, stream, w, Cin, Cout, ksize * ksize, nchunks, nblkY, NT,
+                       split ? 2 : 1, ldexpf(1.0f, w_exp), (_Float16*)packed);
+    return far_check_launch();
+}
+
+// y[n][oy][ox][co] = act(scale[co] * sum_{ky,kx,ci} x[n][oy+ky-p][ox+kx-p][ci] * W[co][ci][ky][kx] + shift[co] + res)
+// x [N][H][W][Cin], res / y [N][H][W][Cout] fp32 NHWC contiguous, stride 1, zero padding ksize/2; Cin % 4 == 0.
+// `scale` must include 2^-(w_exp + 4).  act: 0 none, 1 ReLU, 2 LeakyReLU(slope).  A linear layer is ksize = 1 with
+// N = H = 1, W = rows.  y must alias neither x nor res.
+int far_conv_nhwc_f32(const float* x, const void* packed, const float* scale, const float* shift, const float* res,
+                      long N, int H, int W, int Cin, int Cout, int ksize, int act, float slope, int split, float* y,
+                      hipStream_t stream) {
+    far_clear_errors();
+    if (N == 0) return FAR_OK;
+    if (!x || !packed || !scale || !y || N < 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) || Cout <= 0 ||
+        (ksize != 1 && ksize != 3) || act < 0 || act > 2 || x == y)
+        return FAR_EINVAL;
+    ConvArgs a;
+    a.x = x; a.w = (const unsigned char*)packed; a.scale = scale; a.shift = shift; a.res = res; a.y = y;
+    a.npix = N * H * W; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    const TileCfg c = cfg_for(Cout);
+    const int th = 4 * c.mw;
+    a.tilesX = (W + TW - 1) / TW; a.tilesY = (H + th - 1) / th;
+    a.nchunks = (Cin + 31) / 32;
+    a.nblkY = (Cout + c.nt - 1) / c.nt;
+    a.act = act; a.slope = slope;
+    const long nbx = ksize == 1 ? (a.npix + 64 * c.mw - 1) / (64 * c.mw) : N * a.tilesX * a.tilesY;
+    a.ntiles = nbx;
+    if (nbx > 0x7fffffffL) return FAR_EINVAL;
+    dim3 grid((unsigned)nbx, (unsigned)a.nblkY);
+    if (ksize == 3) return split ? launch_cfg<3, true>(c, a, grid, stream) : launch_cfg<3, false>(c, a, grid, stream);
+    return split ? launch_cfg<1, true>(c, a, grid, stream) : launch_cfg<1, false>(c, a, grid, stream);
+}
+
+}  // extern "C"

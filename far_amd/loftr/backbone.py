@@ -1,11 +1,13 @@
 """ResNet-18-style FPN producing the 1/8 (256 ch) and 1/2 (128 ch) maps.
 
 Mirrors the architecture and PARAMETER NAMES of mp3d_loftr/src/loftr/backbone/resnet_fpn.py:15-119
-(BasicBlock, ResNetFPN_8_2) so reference checkpoints load.  The convolutions stay on the vendor path
-(MIOpen through torch) -- SURVEY.md section 2.1 #2: not a custom kernel; run it channels_last / bf16 for speed.
-"""
-import contextlib
+(BasicBlock, ResNetFPN_8_2) so reference checkpoints load.
 
+Inference in fp32 on the GPU runs `_forward_fused`: NHWC activations end to end, the stem on K10, every stride-1
+3x3 / 1x1 convolution on K9 (split-fp16 implicit GEMM with BatchNorm, activation and residual add fused into the
+epilogue), the FPN upsample-add on K8; only the two stride-2 3x3 convolutions stay on the vendor library.
+Training (gradients) and the optional half-precision modes run the plain torch modules.
+"""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -20,8 +22,25 @@ def _fold(bn):
 
 
 def _fused_ok(m, x):
-    """The fused epilogues (K7/K8) apply to inference on fp32 channels_last GPU tensors only."""
+    """The kernel path (K10 / K9 / K8 / K7) serves inference on fp32 GPU tensors."""
     return (not m.training) and (not torch.is_grad_enabled()) and x.is_cuda and x.dtype == torch.float32
+
+
+class _PackCache:
+    """K9 weight images per convolution, rebuilt when a parameter or BatchNorm buffer it was folded from changes."""
+
+    def __init__(self):
+        self._store = {}
+
+    def get(self, key, conv, bn=None, split=True):
+        ts = [conv.weight] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
+        stamp = tuple((t.data_ptr(), t._version) for t in ts) + (split,)
+        hit = self._store.get(key)
+        if hit is None or hit[0] != stamp:
+            scale, shift = _fold(bn) if bn is not None else (None, None)
+            hit = (stamp, ops.PackedConv(conv.weight, scale, shift, split=split))
+            self._store[key] = hit
+        return hit[1]
 
 
 def _c1(i, o, s=1):
@@ -42,13 +61,7 @@ class BasicBlock(nn.Module):
         self.relu = nn.ReLU(inplace=True)
         self.downsample = None if stride == 1 else nn.Sequential(_c1(in_planes, planes, stride), nn.BatchNorm2d(planes))
 
-    def forward(self, x):
-        if _fused_ok(self, x):
-            y = ops.affine_act(self.conv1(x), *_fold(self.bn1), act='relu')
-            y = self.conv2(y)
-            if self.downsample is not None:
-                x = ops.affine_act(self.downsample[0](x), *_fold(self.downsample[1]), act='none')
-            return ops.affine_act(y, *_fold(self.bn2), residual=x, act='relu')       # relu(x + bn2(conv2(.)))
+    def forward(self, x):          # reference-style modules: training, CPU, autocast (inference runs _forward_fused)
         y = self.bn2(self.conv2(self.relu(self.bn1(self.conv1(x)))))
         if self.downsample is not None:
             x = self.downsample(x)
@@ -79,44 +92,63 @@ class ResNetFPN_8_2(nn.Module):
                 nn.init.constant_(m.weight, 1)
                 nn.init.constant_(m.bias, 0)
 
-    # Optional reduced precision for the fine (1/2-resolution) FPN branch only.  The coarse map x3_out -- the only
-    # input of the discrete matching decisions -- always comes from the fp32 trunk; the fine map only feeds the
-    # sub-pixel expectation.  None (default) = everything fp32 = the parity configuration.
-    fine_branch_dtype = None
-
-    def _trunk(self, x):
-        if _fused_ok(self, x):
-            x0 = ops.affine_act(self.conv1(x), *_fold(self.bn1), act='relu')
-        else:
-            x0 = self.relu(self.bn1(self.conv1(x)))
-        x1 = self.layer1(x0)            # BasicBlocks pick their own fused / plain path
-        x2 = self.layer2(x1)
-        x3 = self.layer3(x2)
-        return x1, x2, x3
-
-    def _fpn_fused(self, x1, x2, x3_out):
-        o2, o1 = self.layer2_outconv2, self.layer1_outconv2
-        y = ops.upsample2x_add(x3_out, self.layer2_outconv(x2))
-        y = ops.affine_act(o2[0](y), *_fold(o2[1]), act='leaky', slope=o2[2].negative_slope)
-        x2_out = o2[3](y)
-        y = ops.upsample2x_add(x2_out, self.layer1_outconv(x1))
-        y = ops.affine_act(o1[0](y), *_fold(o1[1]), act='leaky', slope=o1[2].negative_slope)
-        return o1[3](y)
-
     def _fpn_plain(self, x1, x2, x3_out):
         up3 = F.interpolate(x3_out, scale_factor=2., mode='bilinear', align_corners=True)
         x2_out = self.layer2_outconv2(self.layer2_outconv(x2) + up3)
         up2 = F.interpolate(x2_out, scale_factor=2., mode='bilinear', align_corners=True)
         return self.layer1_outconv2(self.layer1_outconv(x1) + up2)
 
+    # ---- inference fast path: NHWC activations, K10 + K9 + K8 (tensors below are (N, H, W, C)) ----------------
+    # K9 operand precision: True = split fp16 pairs (fp32-grade, the parity configuration), False = plain fp16.
+    # The coarse map -- the only input of the discrete matching decisions -- depends on the trunk + layer3_outconv
+    # only; the FPN branch feeds the sub-pixel refinement.
+    trunk_split = True
+    fpn_split = True
+
+    def _block_fused(self, name, blk, x, pk):
+        sp = self.trunk_split
+        if blk.downsample is None:
+            y = ops.conv_nhwc(x, pk.get(name + '.conv1', blk.conv1, blk.bn1, sp), act='relu')
+            res = x
+        else:        # stride-2 block: vendor 3x3 stride-2 convolution on the NHWC buffer, K7 epilogue; 1x1 shortcut on K9
+            y = F.conv2d(x.permute(0, 3, 1, 2), blk.conv1.weight.contiguous(memory_format=torch.channels_last),
+                         stride=2, padding=1)
+            y = ops.affine_act(y, *_fold(blk.bn1), act='relu').permute(0, 2, 3, 1)
+            if not y.is_contiguous():
+                y = y.contiguous()
+            res = ops.conv_nhwc(x[:, ::2, ::2, :].contiguous(), pk.get(name + '.down', blk.downsample[0], blk.downsample[1], sp))
+        return ops.conv_nhwc(y, pk.get(name + '.conv2', blk.conv2, blk.bn2, sp), residual=res, act='relu')
+
+    def _forward_fused(self, x):
+        pk = self.__dict__.setdefault('_packs', _PackCache())
+        sp = self.trunk_split
+        x0 = ops.stem7x7(x, self.conv1.weight, *_fold(self.bn1))
+        x1 = self._block_fused('layer1.1', self.layer1[1], self._block_fused('layer1.0', self.layer1[0], x0, pk), pk)
+        x2 = self._block_fused('layer2.1', self.layer2[1], self._block_fused('layer2.0', self.layer2[0], x1, pk), pk)
+        x3 = self._block_fused('layer3.1', self.layer3[1], self._block_fused('layer3.0', self.layer3[0], x2, pk), pk)
+        x3_out = ops.conv_nhwc(x3, pk.get('layer3_outconv', self.layer3_outconv, None, sp))
+        sp = self.fpn_split
+        o2, o1 = self.layer2_outconv2, self.layer1_outconv2
+        y = ops.upsample2x_add(x3_out.permute(0, 3, 1, 2),
+                               ops.conv_nhwc(x2, pk.get('layer2_outconv', self.layer2_outconv, None, sp)).permute(0, 3, 1, 2))
+        y = ops.conv_nhwc(y.permute(0, 2, 3, 1), pk.get('o2.0', o2[0], o2[1], sp), act='leaky', slope=o2[2].negative_slope)
+        x2_out = ops.conv_nhwc(y, pk.get('o2.3', o2[3], None, sp))
+        y = ops.upsample2x_add(x2_out.permute(0, 3, 1, 2),
+                               ops.conv_nhwc(x1, pk.get('layer1_outconv', self.layer1_outconv, None, sp)).permute(0, 3, 1, 2))
+        y = ops.conv_nhwc(y.permute(0, 2, 3, 1), pk.get('o1.0', o1[0], o1[1], sp), act='leaky', slope=o1[2].negative_slope)
+        x1_out = ops.conv_nhwc(y, pk.get('o1.3', o1[3], None, sp))
+        # (N, C, H, W)-shaped views of the NHWC buffers: downstream 'n c h w -> n (h w) c' is then a free view
+        return [x3_out.permute(0, 3, 1, 2), x1_out.permute(0, 3, 1, 2)]
+
     def forward(self, x):
-        x1, x2, x3 = self._trunk(x)
+        if _fused_ok(self, x) and x.shape[1] == 1:
+            return self._forward_fused(x)
+        x0 = self.relu(self.bn1(self.conv1(x)))
+        x1 = self.layer1(x0)
+        x2 = self.layer2(x1)
+        x3 = self.layer3(x2)
         x3_out = self.layer3_outconv(x3)
-        dt = self.fine_branch_dtype
-        if dt is None and _fused_ok(self, x3_out):
-            return [x3_out, self._fpn_fused(x1, x2, x3_out)]
-        with (torch.autocast('cuda', dtype=dt) if dt is not None else contextlib.nullcontext()):
-            return [x3_out, self._fpn_plain(x1, x2, x3_out)]
+        return [x3_out, self._fpn_plain(x1, x2, x3_out)]
 
 
 def build_backbone(config):

@@ -69,21 +69,23 @@ class LoFTR(nn.Module):
             self.fine_matching = FineMatching(config)
         if config['regress_rt']:
             self.loftr_regress = LocalFeatureTransformerRegressor(config)
-        # optional half precision for the convolutional backbone only (vendor path); fp32 = parity configuration
+        # backbone arithmetic, see set_precision; fp32-grade = parity configuration
         self.backbone_dtype = torch.float32
 
     PRECISIONS = ('fp32', 'fp16-fine', 'fp16', 'bf16')
 
     def set_precision(self, mode):
-        """Arithmetic of the vendor-path convolutions (everything else is unaffected):
-          'fp32'      all fp32 -- the parity configuration (default);
-          'fp16-fine' fp32 trunk + fp16 fine (1/2-res) FPN branch: coarse features and match decisions stay
-                      bit-identical, only the sub-pixel refinement input changes (measured: mkpts1_f mean 0.008 px);
-          'fp16' / 'bf16'  the whole backbone under autocast, channels_last."""
+        """Arithmetic of the backbone convolutions (everything else is unaffected):
+          'fp32'      K9 with split-fp16 operand pairs: fp32-grade -- the parity configuration (default);
+          'fp16-fine' split trunk + plain-fp16 operands in the FPN branch: coarse features and match decisions stay
+                      bit-identical, only the sub-pixel refinement input changes;
+          'fp16'      plain fp16 operands everywhere in K9 (fp32 accumulation, fp32 activations);
+          'bf16'      the vendor convolutions under bf16 autocast (reference-style modules), channels_last."""
         if mode not in self.PRECISIONS:
             raise ValueError(f'precision must be one of {self.PRECISIONS}')
-        self.backbone_dtype = {'fp16': torch.float16, 'bf16': torch.bfloat16}.get(mode, torch.float32)
-        self.backbone.fine_branch_dtype = torch.float16 if mode == 'fp16-fine' else None
+        self.backbone_dtype = torch.bfloat16 if mode == 'bf16' else torch.float32
+        self.backbone.trunk_split = mode in ('fp32', 'fp16-fine')
+        self.backbone.fpn_split = mode == 'fp32'
         return self
 
     # -------------------------------------------------------------------------------------------------

@@ -253,3 +253,71 @@ def upsample2x_add(lo, hi):
                                     ctypes.c_void_p(out.data_ptr()), _stream())
     _lib.check(rc, 'far_upsample2x_add_f32')
     return out
+
+
+_ACT = {'none': 0, 'relu': 1, 'leaky': 2}
+_CONV_ACT_EXP = 4          # the kernel scales activations by 2^4 before the fp16 split (conv_igemm_f16s.hip)
+
+
+class PackedConv:
+    """Weights of one convolution / linear layer in K9's packed split-fp16 image, plus the folded epilogue vectors."""
+
+    def __init__(self, weight, scale=None, shift=None, split=True):
+        lib = _lib.load()
+        w = weight.detach()
+        if w.dim() == 2:
+            w = w[:, :, None, None]
+        Cout, Cin, kh, kw = w.shape
+        if kh != kw or kh not in (1, 3):
+            raise _lib.FarHipError(f'K9 supports 1x1 and 3x3 kernels, got {kh}x{kw}')
+        w = w.contiguous().float()
+        amax = float(w.abs().max())                       # one host sync, at pack time only
+        self.w_exp = 14 - (torch.frexp(torch.tensor(amax)).exponent.item() if amax > 0 else 0)
+        self.Cin, self.Cout, self.ksize, self.split = Cin, Cout, kh, bool(split)
+        nbytes = lib.far_conv_packed_bytes(Cin, Cout, kh, int(self.split))
+        self.packed = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+        rc = lib.far_conv_pack_f32(_p(w, torch.float32), Cin, Cout, kh, self.w_exp, int(self.split), _p(self.packed),
+                                   _stream())
+        _lib.check(rc, 'far_conv_pack_f32')
+        unscale = 2.0 ** -(self.w_exp + _CONV_ACT_EXP)
+        s = torch.ones(Cout, device=w.device) if scale is None else scale.detach().float()
+        self.scale = (s * unscale).contiguous()           # power-of-two factor: exact
+        self.shift = None if shift is None else shift.detach().float().contiguous()
+
+
+def conv_nhwc(x, pc, residual=None, act='none', slope=0.01):
+    """K9.  x (N, H, W, Cin) fp32 contiguous -> act(conv(x) * scale + shift (+ residual)) as (N, H, W, Cout)."""
+    lib = _lib.load()
+    N, H, W, Cin = x.shape
+    if Cin != pc.Cin:
+        raise _lib.FarHipError(f'conv_nhwc: input has {Cin} channels, weights expect {pc.Cin}')
+    y = torch.empty(N, H, W, pc.Cout, dtype=torch.float32, device=x.device)
+    rc = lib.far_conv_nhwc_f32(_p(x, torch.float32), _p(pc.packed), _p(pc.scale), _p(pc.shift),
+                               _p(residual, torch.float32), N, H, W, Cin, pc.Cout, pc.ksize, _ACT[act], float(slope),
+                               int(pc.split), _p(y), _stream())
+    _lib.check(rc, 'far_conv_nhwc_f32')
+    return y
+
+
+def linear_f16s(x, pc, residual=None, act='none'):
+    """K9 as a linear layer: x (..., K) fp32 -> act(x W^T * scale + shift (+ residual)) (..., Cout)."""
+    lead = x.shape[:-1]
+    rows = 1
+    for d in lead:
+        rows *= d
+    r = None if residual is None else residual.reshape(1, 1, rows, pc.Cout)
+    return conv_nhwc(x.reshape(1, 1, rows, x.shape[-1]), pc, residual=r, act=act).reshape(*lead, pc.Cout)
+
+
+def stem7x7(img, weight, scale, shift):
+    """K10.  img (N, 1, H, W) fp32 -> relu(bn(conv7x7 stride 2)) as NHWC (N, H/2, W/2, Cout)."""
+    lib = _lib.load()
+    N, one, H, W = img.shape
+    Cout = weight.shape[0]
+    if one != 1 or tuple(weight.shape[1:]) != (1, 7, 7):
+        raise _lib.FarHipError('stem7x7 expects a 1-channel image and a (Cout, 1, 7, 7) weight')
+    y = torch.empty(N, (H + 1) // 2, (W + 1) // 2, Cout, dtype=torch.float32, device=img.device)
+    rc = lib.far_stem7x7_nhwc_f32(_p(img.contiguous(), torch.float32), _p(weight.detach().contiguous(), torch.float32),
+                                  _p(scale, torch.float32), _p(shift, torch.float32), N, H, W, Cout, _p(y), _stream())
+    _lib.check(rc, 'far_stem7x7_nhwc_f32')
+    return y

@@ -147,6 +147,37 @@ int far_upsample2x_add_f32(const float* lo, const float* hi, int N, int h, int w
                            far_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * K9  implicit-GEMM convolution / linear layer on the f16 matrix cores with split-precision operands
+ * replaces (inference) src/loftr/backbone/resnet_fpn.py:5-12 (conv1x1, conv3x3), :15-43 (BasicBlock.forward),
+ *      :101-119 (ResNetFPN_8_2.forward) and the nn.Linear layers of src/loftr/loftr_module/transformer.py:25-35
+ * Every fp32 operand is split v = hi + lo (two fp16), the product is hi.hi + hi.lo + lo.hi accumulated in fp32:
+ * fp32-grade results at 16/3 of the fp32 matrix rate.  split = 0 keeps hi only (plain fp16 operands).
+ * --------------------------------------------------------------------------------------------------- */
+
+/* Bytes of the packed image of a [Cout][Cin][ksize][ksize] weight; ksize 1 or 3; 0 on bad arguments. */
+size_t far_conv_packed_bytes(int Cin, int Cout, int ksize, int split);
+
+/* Packs w (torch layout [Cout][Cin][ksize][ksize] fp32), multiplied by 2^w_exp, into `packed`.  Choose w_exp with
+ * 2^13 <= max|w| 2^w_exp < 2^15 and fold 2^-(w_exp + 4) into the `scale` vector of far_conv_nhwc_f32. */
+int far_conv_pack_f32(const float* w, int Cin, int Cout, int ksize, int w_exp, int split, void* packed,
+                      far_stream_t stream);
+
+/* y = act(scale[co] * conv(x, W)[.., co] + shift[co] (+ res)); x [N][H][W][Cin], res / y [N][H][W][Cout] fp32 NHWC,
+ * stride 1, zero padding ksize / 2, Cin % 4 == 0.  shift, res may be NULL.  act: 0 none, 1 ReLU, 2 LeakyReLU(slope).
+ * A linear layer y = x W^T + b is ksize = 1, N = H = 1, W = rows, shift = b.  y must not alias x. */
+int far_conv_nhwc_f32(const float* x, const void* packed, const float* scale, const float* shift, const float* res,
+                      long N, int H, int W, int Cin, int Cout, int ksize, int act, float slope, int split, float* y,
+                      far_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * K10  backbone stem: 7x7 stride-2 convolution of a 1-channel image + folded BatchNorm + ReLU (exact-f32 MFMA)
+ * replaces src/loftr/backbone/resnet_fpn.py:60-62, :103   x0 = relu(bn1(conv1(x)))
+ * img [N][H][W] fp32, w [Cout][7][7] (torch layout), y [N][(H+1)/2][(W+1)/2][Cout] NHWC; Cout = 64 or 128.
+ * --------------------------------------------------------------------------------------------------- */
+int far_stem7x7_nhwc_f32(const float* img, const float* w, const float* scale, const float* shift, int N, int H, int W,
+                         int Cout, float* y, far_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * K4  batched essential-matrix solver (hypothesise / verify / decompose / cheirality), float64
  * replaces src/utils/metrics.py:80-174 (estimate_pose), third_party/prior_ransac/ransac.py:340-442
  *      (RANSAC.forward + verify + get_prior_estimate), cv_geometry.py:713-833 (run_8point),

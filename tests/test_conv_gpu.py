@@ -1,0 +1,156 @@
+"""K9 (split-fp16 implicit-GEMM convolution / linear) and K10 (stem) against float64 torch convolutions.
+
+The bar: K9's split mode is an fp32-grade kernel -- its error against the float64 result must be of the size of an fp32
+convolution's own rounding error (we allow 4x the fp32 direct-sum bound), far below the 1e-3 / 1e-5 tolerances the
+pipeline parity tests put on the quantities computed from these features; plain mode (fp16 operands) is held to 2e-3.
+Reference: mp3d_loftr/src/loftr/backbone/resnet_fpn.py:5-43, 101-119.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from far_amd import ops
+    return ops
+
+
+def _rel(a, ref):
+    return float((a.double() - ref).abs().max() / ref.abs().max()), float(
+        ((a.double() - ref).pow(2).mean() / ref.pow(2).mean()).sqrt())
+
+
+@pytest.mark.parametrize('N,H,W,Cin,Cout,ks', [
+    (2, 24, 40, 32, 64, 3),          # whole tiles
+    (3, 30, 37, 196, 196, 3),        # ragged tiles, padded channel chunk, padded output tile
+    (1, 17, 16, 128, 128, 3),        # 4 x 1 wave layout, ragged rows
+    (2, 9, 50, 256, 196, 3),
+    (1, 5, 7, 196, 128, 3),
+    (2, 13, 21, 128, 196, 1),        # 1x1 convolution
+    (1, 1, 1000, 256, 256, 1),       # linear layer shape
+    (1, 1, 77, 512, 512, 1),         # two output-channel blocks
+    (1, 1, 300, 256, 768, 1),
+])
+def test_conv_split_matches_float64(N, H, W, Cin, Cout, ks):
+    ops = _ops()
+    g = torch.Generator(device='cuda').manual_seed(N * 1000 + Cin + Cout + ks)
+    x = (torch.randn(N, H, W, Cin, device='cuda', generator=g) * 1.5).relu_()
+    w = torch.randn(Cout, Cin, ks, ks, device='cuda', generator=g) * (2.0 / (Cin * ks * ks)) ** 0.5
+    scale = torch.rand(Cout, device='cuda', generator=g) + 0.5
+    shift = torch.randn(Cout, device='cuda', generator=g) * 0.1
+    res = torch.randn(N, H, W, Cout, device='cuda', generator=g)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), padding=ks // 2).permute(0, 2, 3, 1)
+    ref_bn = ref * scale.double() + shift.double()
+    for split, tol_max, tol_rms in ((True, 4e-6, 1.5e-6), (False, 4e-3, 2e-3)):
+        pc = ops.PackedConv(w, scale, shift, split=split)
+        for act, residual in (('none', None), ('relu', res), ('leaky', None)):
+            y = ops.conv_nhwc(x, pc, residual=residual, act=act, slope=0.01)
+            r = ref_bn + (residual.double() if residual is not None else 0)
+            r = {'none': lambda t: t, 'relu': torch.relu, 'leaky': lambda t: F.leaky_relu(t, 0.01)}[act](r)
+            emax, erms = _rel(y, r)
+            assert emax < tol_max and erms < tol_rms, (split, act, emax, erms)
+
+
+def test_conv_split_is_as_accurate_as_fp32_direct():
+    """The split product's error is of the order of an fp32 direct convolution's (both measured against float64)."""
+    ops = _ops()
+    g = torch.Generator(device='cuda').manual_seed(7)
+    x = torch.randn(2, 40, 48, 256, device='cuda', generator=g).relu_()
+    w = torch.randn(256, 256, 3, 3, device='cuda', generator=g) * 0.03
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), padding=1)
+    direct = F.conv2d(x.permute(0, 3, 1, 2), w, padding=1)
+    y = ops.conv_nhwc(x, ops.PackedConv(w)).permute(0, 3, 1, 2)
+    e_mine, e_direct = _rel(y, ref)[1], _rel(direct, ref)[1]
+    assert e_mine < 3 * e_direct + 1e-7, (e_mine, e_direct)
+
+
+def test_conv_weight_scale_extremes():
+    """Tiny and large weights: the power-of-two pre-scaling keeps the fp16 lo parts normal."""
+    ops = _ops()
+    g = torch.Generator(device='cuda').manual_seed(11)
+    x = torch.randn(1, 16, 16, 64, device='cuda', generator=g)
+    for mag in (1e-4, 1.0, 300.0):
+        w = torch.randn(64, 64, 3, 3, device='cuda', generator=g) * mag
+        ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), padding=1).permute(0, 2, 3, 1)
+        emax, erms = _rel(ops.conv_nhwc(x, ops.PackedConv(w)), ref)
+        assert emax < 4e-6 and erms < 1.5e-6, (mag, emax, erms)
+
+
+def test_conv_small_activations_keep_precision():
+    """Activations 1e-3 of the usual scale lose only the documented absolute floor (2^-29 of unit scale)."""
+    ops = _ops()
+    g = torch.Generator(device='cuda').manual_seed(12)
+    x = torch.randn(1, 16, 16, 64, device='cuda', generator=g) * 1e-3
+    w = torch.randn(64, 64, 3, 3, device='cuda', generator=g) * 0.05
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), padding=1).permute(0, 2, 3, 1)
+    y = ops.conv_nhwc(x, ops.PackedConv(w))
+    assert float((y.double() - ref).abs().max()) < 5e-8
+
+
+def test_linear_wrapper_matches_addmm():
+    ops = _ops()
+    g = torch.Generator(device='cuda').manual_seed(3)
+    x = torch.randn(2, 333, 256, device='cuda', generator=g)
+    w = torch.randn(512, 256, device='cuda', generator=g) * 0.06
+    b = torch.randn(512, device='cuda', generator=g)
+    pc = ops.PackedConv(w, None, b)
+    y = ops.linear_f16s(x, pc, act='relu')
+    ref = torch.relu(x.double() @ w.double().t() + b.double())
+    assert y.shape == (2, 333, 512)
+    emax, erms = _rel(y, ref)
+    assert emax < 4e-6 and erms < 1.5e-6
+
+
+def test_conv_rejects_bad_arguments():
+    ops = _ops()
+    from far_amd._lib import FarHipError
+    w = torch.randn(64, 30, 3, 3, device='cuda')
+    pc = ops.PackedConv(w)                                    # packing any Cin is fine ...
+    with pytest.raises(FarHipError):                          # ... but the kernel reads 16-byte channel groups
+        ops.conv_nhwc(torch.randn(1, 8, 8, 30, device='cuda'), pc)
+    with pytest.raises(FarHipError):
+        ops.PackedConv(torch.randn(8, 8, 5, 5, device='cuda'))
+    with pytest.raises(FarHipError):
+        ops.conv_nhwc(torch.randn(1, 8, 8, 32, device='cuda'), ops.PackedConv(torch.randn(8, 64, 3, 3, device='cuda')))
+
+
+@pytest.mark.parametrize('N,H,W,Cout', [(2, 48, 64, 128), (1, 37, 51, 128), (1, 480, 640, 128), (2, 20, 24, 64)])
+def test_stem_matches_float64(N, H, W, Cout):
+    ops = _ops()
+    g = torch.Generator(device='cuda').manual_seed(H + W)
+    img = torch.rand(N, 1, H, W, device='cuda', generator=g)
+    w = torch.randn(Cout, 1, 7, 7, device='cuda', generator=g) * 0.2
+    scale = torch.rand(Cout, device='cuda', generator=g) + 0.5
+    shift = torch.randn(Cout, device='cuda', generator=g) * 0.1
+    y = ops.stem7x7(img, w, scale, shift)
+    ref = torch.relu(F.conv2d(img.double(), w.double(), stride=2, padding=3) * scale.double()[None, :, None, None]
+                     + shift.double()[None, :, None, None]).permute(0, 2, 3, 1)
+    assert y.shape == ref.shape
+    emax, erms = _rel(y, ref)
+    assert emax < 2e-6 and erms < 5e-7, (emax, erms)
+
+
+def test_fused_backbone_matches_reference_modules():
+    """The NHWC kernel path of the backbone against its own reference-style torch modules (vendor fp32 convolutions)."""
+    from far_amd.config import far_eval_config
+    from far_amd.loftr.backbone import build_backbone
+    torch.manual_seed(0)
+    cfg = far_eval_config()
+    bb = build_backbone(cfg).cuda().eval()
+    with torch.no_grad():
+        for m in bb.modules():                               # non-trivial BatchNorm statistics
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.1)
+        x = torch.rand(2, 1, 96, 128, device='cuda')
+        c_f, f_f = bb(x)                                      # fused path
+        bb64 = build_backbone(cfg).cuda().eval().double()
+        bb64.load_state_dict({k: v.double() for k, v in bb.state_dict().items()})
+        c_r, f_r = bb64(x.double())
+        assert c_f.shape == c_r.shape and f_f.shape == f_r.shape
+        assert _rel(c_f, c_r)[0] < 2e-5 and _rel(f_f, f_r)[0] < 2e-5
+        bb.trunk_split = bb.fpn_split = False                 # plain fp16 operands
+        c_h, f_h = bb(x)
+        assert _rel(c_h, c_r)[1] < 5e-3 and _rel(f_h, f_r)[1] < 5e-3
