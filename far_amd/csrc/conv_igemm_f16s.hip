@@ -59,7 +59,9 @@ struct Geo {
 };
 
 struct ConvArgs {
-    const float* x;
+    const float* x;              // input channels [0, Cin1)
+    const float* x2;             // input channels [Cin1, Cin) (fused concatenation), or null when Cin1 == Cin
+    int Cin1;
     const unsigned char* w;      // packed weights (far_conv_pack_f32)
     const float* scale;          // [Cout] multiplies the accumulator (BN scale / 1, with the operand scaling folded in)
     const float* shift;          // [Cout] or null
@@ -114,8 +116,10 @@ __device__ __forceinline__ void stage_load(Stage<ITERS>& st, const ConvArgs& p, 
         }
         // unconditional 16-byte loads from a clamped (always valid) address, zeroed by select: no exec-mask branches
         const bool ok0 = ok && c0 < p.Cin, ok1 = ok && c0 + 4 < p.Cin;
-        const float* src0 = ok0 ? p.x + pix * p.Cin + c0 : p.x;
-        const float* src1 = ok1 ? p.x + pix * p.Cin + c0 + 4 : p.x;
+        const bool second = c0 >= p.Cin1;                       // Cin1 % 8 == 0: a group never straddles the inputs
+        const float* base = second ? p.x2 + pix * (p.Cin - p.Cin1) + (c0 - p.Cin1) : p.x + pix * p.Cin1 + c0;
+        const float* src0 = ok0 ? base : p.x;
+        const float* src1 = ok1 ? base + 4 : p.x;
         const float4 u = *reinterpret_cast<const float4*>(src0), w = *reinterpret_cast<const float4*>(src1);
         st.v[it][0] = make_float4(ok0 ? u.x : 0.f, ok0 ? u.y : 0.f, ok0 ? u.z : 0.f, ok0 ? u.w : 0.f);
         st.v[it][1] = make_float4(ok1 ? w.x : 0.f, ok1 ? w.y : 0.f, ok1 ? w.z : 0.f, ok1 ? w.w : 0.f);
@@ -429,19 +433,22 @@ int far_conv_pack_f32(const float* w, int Cin, int Cout, int ksize, int w_exp, i
 }
 
 // y[n][oy][ox][co] = act(scale[co] * sum_{ky,kx,ci} x[n][oy+ky-p][ox+kx-p][ci] * W[co][ci][ky][kx] + shift[co] + res)
-// x [N][H][W][Cin], res / y [N][H][W][Cout] fp32 NHWC contiguous, stride 1, zero padding ksize/2; Cin % 4 == 0.
+// x [N][H][W][Cin1] (+ x2 [N][H][W][Cin - Cin1]: the input is their channel concatenation, never materialised;
+// x2 = NULL and Cin1 = Cin for a single input), res / y [N][H][W][Cout] fp32 NHWC contiguous, stride 1, zero padding
+// ksize/2; Cin % 4 == 0, Cin1 % 8 == 0.
 // `scale` must include 2^-(w_exp + 4).  act: 0 none, 1 ReLU, 2 LeakyReLU(slope).  A linear layer is ksize = 1 with
 // N = H = 1, W = rows.  y must alias neither x nor res.
-int far_conv_nhwc_f32(const float* x, const void* packed, const float* scale, const float* shift, const float* res,
-                      long N, int H, int W, int Cin, int Cout, int ksize, int act, float slope, int split, float* y,
-                      hipStream_t stream) {
+int far_conv_nhwc_f32(const float* x, const float* x2, int Cin1, const void* packed, const float* scale,
+                      const float* shift, const float* res, long N, int H, int W, int Cin, int Cout, int ksize, int act,
+                      float slope, int split, float* y, hipStream_t stream) {
     far_clear_errors();
     if (N == 0) return FAR_OK;
     if (!x || !packed || !scale || !y || N < 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) || Cout <= 0 ||
-        (ksize != 1 && ksize != 3) || act < 0 || act > 2 || x == y)
+        (ksize != 1 && ksize != 3) || act < 0 || act > 2 || x == y || x2 == y)
         return FAR_EINVAL;
+    if (x2 ? (Cin1 <= 0 || Cin1 >= Cin || (Cin1 & 7)) : (Cin1 != Cin)) return FAR_EINVAL;
     ConvArgs a;
-    a.x = x; a.w = (const unsigned char*)packed; a.scale = scale; a.shift = shift; a.res = res; a.y = y;
+    a.x = x; a.x2 = x2; a.Cin1 = Cin1; a.w = (const unsigned char*)packed; a.scale = scale; a.shift = shift; a.res = res; a.y = y;
     a.npix = N * H * W; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     const TileCfg c = cfg_for(Cout);
     const int th = 4 * c.mw;

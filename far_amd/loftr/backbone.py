@@ -26,21 +26,16 @@ def _fused_ok(m, x):
     return (not m.training) and (not torch.is_grad_enabled()) and x.is_cuda and x.dtype == torch.float32
 
 
-class _PackCache:
-    """K9 weight images per convolution, rebuilt when a parameter or BatchNorm buffer it was folded from changes."""
-
-    def __init__(self):
-        self._store = {}
+class _PackCache(ops.PackCache):
+    """K9 weight images per convolution with the following BatchNorm folded into the epilogue vectors."""
 
     def get(self, key, conv, bn=None, split=True):
         ts = [conv.weight] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
-        stamp = tuple((t.data_ptr(), t._version) for t in ts) + (split,)
-        hit = self._store.get(key)
-        if hit is None or hit[0] != stamp:
+
+        def build():
             scale, shift = _fold(bn) if bn is not None else (None, None)
-            hit = (stamp, ops.PackedConv(conv.weight, scale, shift, split=split))
-            self._store[key] = hit
-        return hit[1]
+            return ops.PackedConv(conv.weight, scale, shift, split=split)
+        return super().get((key, split), ts, build)
 
 
 def _c1(i, o, s=1):

@@ -6,7 +6,8 @@ checkpoints load unchanged:
   CrossAttention :250-303, CrossBlock :305-348, LocalFeatureTransformerRegressor :350-499
 and of mp3d_loftr/src/loftr/loftr_module/vit_layers/mlp.py:8-28 (Mlp).
 The attention cores run in libfar_hip.so: K5 (linear attention) and K2 (bilinear dual-softmax, never
-materialising the (B, 4, 4800, 4800) score tensors); Linear / LayerNorm / GELU stay on the vendor path.
+materialising the (B, 4, 4800, 4800) score tensors), K6 (LayerNorm) and K9 (the encoder layers' Linear layers);
+the head's Linear / GELU stay on the vendor path.
 
 Batch semantics: the reference head is batch-size-1 only (its pairing reshape :339-341 and the gate
 broadcasts :466-469 break for B > 1).  Here B pairs are processed as B
@@ -64,22 +65,31 @@ class LoFTREncoderLayer(nn.Module):
 
     def forward(self, x, source, x_mask=None, source_mask=None, loftr_preds=None):
         bs = x.size(0)
-        q = self.q_proj(x).view(bs, -1, self.nhead, self.dim)
-        k = self.k_proj(source).view(bs, -1, self.nhead, self.dim)
-        v = self.v_proj(source).view(bs, -1, self.nhead, self.dim)
-        msg = self.attention(q, k, v, q_mask=x_mask, kv_mask=source_mask, loftr_preds=loftr_preds)
-        msg = self.merge(msg.view(bs, -1, self.nhead * self.dim))
-        if ag.needs_grad(msg, x, self.norm1.weight):
+        if ag.needs_grad(x, source, self.norm1.weight) or not x.is_cuda:     # training: reference-style modules
+            q = self.q_proj(x).view(bs, -1, self.nhead, self.dim)
+            k = self.k_proj(source).view(bs, -1, self.nhead, self.dim)
+            v = self.v_proj(source).view(bs, -1, self.nhead, self.dim)
+            msg = self.attention(q, k, v, q_mask=x_mask, kv_mask=source_mask, loftr_preds=loftr_preds)
+            msg = self.merge(msg.view(bs, -1, self.nhead * self.dim))
             msg = self.norm2(self.mlp(torch.cat([x, self.norm1(msg)], dim=2)))                             # :61-66
             return x + msg
+        # inference: the five Linear layers on K9 (split-fp16 operands: fp32-grade, and -- unlike a vendor GEMM whose
+        # kernel is chosen by the row count -- every output row depends on its input row only)
+        pk = self.__dict__.setdefault('_packs', ops.PackCache())
+        lin = lambda name, mod: pk.get(name, [mod.weight], lambda: ops.PackedConv(mod.weight))
+        x = x.contiguous()
+        source = source.contiguous()
+        q = ops.linear_f16s(x, lin('q', self.q_proj)).view(bs, -1, self.nhead, self.dim)
+        k = ops.linear_f16s(source, lin('k', self.k_proj)).view(bs, -1, self.nhead, self.dim)
+        v = ops.linear_f16s(source, lin('v', self.v_proj)).view(bs, -1, self.nhead, self.dim)
+        msg = self.attention(q, k, v, q_mask=x_mask, kv_mask=source_mask, loftr_preds=loftr_preds)
+        msg = ops.linear_f16s(msg.view(bs, -1, self.nhead * self.dim), lin('merge', self.merge))
         msg = ops.layernorm(msg, self.norm1.weight, self.norm1.bias, self.norm1.eps)                       # :61
-        # mlp[0](cat[x, msg]) without materialising the concatenation: the weight is split column-wise (:64)
-        C = x.shape[-1]
-        w0 = self.mlp[0].weight
-        h = torch.addmm(torch.mm(x.reshape(-1, C), w0[:, :C].t()), msg.reshape(-1, C), w0[:, C:].t())
-        h = self.mlp[2](torch.relu_(h)).view_as(x)
+        # mlp[0](cat[x, msg]) reads both inputs in place (:64), ReLU in the epilogue
+        h = ops.linear_f16s(x, lin('mlp0', self.mlp[0]), act='relu', x2=msg)
+        h = ops.linear_f16s(h, lin('mlp2', self.mlp[2]))
         # norm2 and the residual `x + message` in one pass (:65-67)
-        return ops.layernorm(h, self.norm2.weight, self.norm2.bias, self.norm2.eps, residual=x.contiguous())
+        return ops.layernorm(h, self.norm2.weight, self.norm2.bias, self.norm2.eps, residual=x)
 
 
 class LocalFeatureTransformer(nn.Module):

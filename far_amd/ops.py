@@ -285,28 +285,47 @@ class PackedConv:
         self.shift = None if shift is None else shift.detach().float().contiguous()
 
 
-def conv_nhwc(x, pc, residual=None, act='none', slope=0.01):
-    """K9.  x (N, H, W, Cin) fp32 contiguous -> act(conv(x) * scale + shift (+ residual)) as (N, H, W, Cout)."""
+class PackCache:
+    """K9 weight images keyed by name, rebuilt when any tensor they were derived from changes (in-place update,
+    load_state_dict, optimizer step: data_ptr / _version stamp)."""
+
+    def __init__(self):
+        self._store = {}
+
+    def get(self, key, tensors, build):
+        stamp = tuple((t.data_ptr(), t._version) for t in tensors)
+        hit = self._store.get(key)
+        if hit is None or hit[0] != stamp:
+            hit = (stamp, build())
+            self._store[key] = hit
+        return hit[1]
+
+
+def conv_nhwc(x, pc, residual=None, act='none', slope=0.01, x2=None):
+    """K9.  x (N, H, W, Cin) fp32 contiguous -> act(conv(x) * scale + shift (+ residual)) as (N, H, W, Cout).
+    With x2 (N, H, W, C2) the convolution input is cat([x, x2], -1), read in place."""
     lib = _lib.load()
-    N, H, W, Cin = x.shape
-    if Cin != pc.Cin:
+    N, H, W, Cin1 = x.shape
+    Cin = Cin1 + (x2.shape[-1] if x2 is not None else 0)
+    if Cin != pc.Cin or (x2 is not None and tuple(x2.shape[:3]) != (N, H, W)):
         raise _lib.FarHipError(f'conv_nhwc: input has {Cin} channels, weights expect {pc.Cin}')
     y = torch.empty(N, H, W, pc.Cout, dtype=torch.float32, device=x.device)
-    rc = lib.far_conv_nhwc_f32(_p(x, torch.float32), _p(pc.packed), _p(pc.scale), _p(pc.shift),
-                               _p(residual, torch.float32), N, H, W, Cin, pc.Cout, pc.ksize, _ACT[act], float(slope),
-                               int(pc.split), _p(y), _stream())
+    rc = lib.far_conv_nhwc_f32(_p(x, torch.float32), _p(x2, torch.float32), Cin1, _p(pc.packed), _p(pc.scale),
+                               _p(pc.shift), _p(residual, torch.float32), N, H, W, Cin, pc.Cout, pc.ksize, _ACT[act],
+                               float(slope), int(pc.split), _p(y), _stream())
     _lib.check(rc, 'far_conv_nhwc_f32')
     return y
 
 
-def linear_f16s(x, pc, residual=None, act='none'):
-    """K9 as a linear layer: x (..., K) fp32 -> act(x W^T * scale + shift (+ residual)) (..., Cout)."""
+def linear_f16s(x, pc, residual=None, act='none', x2=None):
+    """K9 as a linear layer: x (..., K) fp32 -> act(cat([x, x2], -1) W^T * scale + shift (+ residual)) (..., Cout)."""
     lead = x.shape[:-1]
     rows = 1
     for d in lead:
         rows *= d
     r = None if residual is None else residual.reshape(1, 1, rows, pc.Cout)
-    return conv_nhwc(x.reshape(1, 1, rows, x.shape[-1]), pc, residual=r, act=act).reshape(*lead, pc.Cout)
+    x2 = None if x2 is None else x2.reshape(1, 1, rows, x2.shape[-1])
+    return conv_nhwc(x.reshape(1, 1, rows, x.shape[-1]), pc, residual=r, act=act, x2=x2).reshape(*lead, pc.Cout)
 
 
 def stem7x7(img, weight, scale, shift):

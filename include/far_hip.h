@@ -162,12 +162,14 @@ size_t far_conv_packed_bytes(int Cin, int Cout, int ksize, int split);
 int far_conv_pack_f32(const float* w, int Cin, int Cout, int ksize, int w_exp, int split, void* packed,
                       far_stream_t stream);
 
-/* y = act(scale[co] * conv(x, W)[.., co] + shift[co] (+ res)); x [N][H][W][Cin], res / y [N][H][W][Cout] fp32 NHWC,
- * stride 1, zero padding ksize / 2, Cin % 4 == 0.  shift, res may be NULL.  act: 0 none, 1 ReLU, 2 LeakyReLU(slope).
- * A linear layer y = x W^T + b is ksize = 1, N = H = 1, W = rows, shift = b.  y must not alias x. */
-int far_conv_nhwc_f32(const float* x, const void* packed, const float* scale, const float* shift, const float* res,
-                      long N, int H, int W, int Cin, int Cout, int ksize, int act, float slope, int split, float* y,
-                      far_stream_t stream);
+/* y = act(scale[co] * conv(X, W)[.., co] + shift[co] (+ res)); X = x [N][H][W][Cin1] or, with x2 != NULL, the channel
+ * concatenation [x | x2] (x2 [N][H][W][Cin - Cin1], Cin1 % 8 == 0; never materialised: transformer.py:64 torch.cat);
+ * res / y [N][H][W][Cout] fp32 NHWC, stride 1, zero padding ksize / 2, Cin % 4 == 0.  shift, res may be NULL.
+ * act: 0 none, 1 ReLU, 2 LeakyReLU(slope).  A linear layer y = x W^T + b is ksize = 1, N = H = 1, W = rows, shift = b.
+ * y must alias none of the inputs. */
+int far_conv_nhwc_f32(const float* x, const float* x2, int Cin1, const void* packed, const float* scale,
+                      const float* shift, const float* res, long N, int H, int W, int Cin, int Cout, int ksize, int act,
+                      float slope, int split, float* y, far_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * K10  backbone stem: 7x7 stride-2 convolution of a 1-channel image + folded BatchNorm + ReLU (exact-f32 MFMA)

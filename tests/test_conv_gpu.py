@@ -154,3 +154,22 @@ def test_fused_backbone_matches_reference_modules():
         bb.trunk_split = bb.fpn_split = False                 # plain fp16 operands
         c_h, f_h = bb(x)
         assert _rel(c_h, c_r)[1] < 5e-3 and _rel(f_h, f_r)[1] < 5e-3
+
+
+def test_conv_fused_concat_input():
+    """x2: the convolution input is cat([x, x2], -1) read in place (transformer.py:64)."""
+    ops = _ops()
+    g = torch.Generator(device='cuda').manual_seed(5)
+    x = torch.randn(3, 210, 256, device='cuda', generator=g)
+    m = torch.randn(3, 210, 256, device='cuda', generator=g)
+    w = torch.randn(512, 512, device='cuda', generator=g) * 0.04
+    y = ops.linear_f16s(x, ops.PackedConv(w), act='relu', x2=m)
+    ref = torch.relu(torch.cat([x, m], -1).double() @ w.double().t())
+    emax, erms = _rel(y, ref)
+    assert emax < 4e-6 and erms < 1.5e-6
+    xs = torch.randn(1, 9, 11, 64, device='cuda', generator=g)
+    ms = torch.randn(1, 9, 11, 32, device='cuda', generator=g)
+    w3 = torch.randn(40, 96, 3, 3, device='cuda', generator=g) * 0.05
+    y3 = ops.conv_nhwc(xs, ops.PackedConv(w3), x2=ms)
+    ref3 = F.conv2d(torch.cat([xs, ms], -1).permute(0, 3, 1, 2).double(), w3.double(), padding=1).permute(0, 2, 3, 1)
+    assert _rel(y3, ref3)[0] < 4e-6
