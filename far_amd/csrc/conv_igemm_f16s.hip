@@ -47,10 +47,10 @@ constexpr float ACT_SCALE = 16.0f;      // activations are scaled by 2^4 before 
 // LDS image of the staged input pixels of one 32-channel chunk.  3x3: the (TH+2) x (16+2) halo, row stride rounded
 // up to a multiple of 256 B so that, with the odd 5-slot pixel stride, every 16-lane group of a ds_read_b128
 // fragment read (lanes {0-3,12-15,20-27}, ... = 8 pixels of one tile row + 8 of the next) hits 16 distinct slots.
-template <int KS, int MW>
+template <int KS, int MW, int ST>
 struct Geo {
     static constexpr int TH = 4 * MW;
-    static constexpr int HW = TW + KS - 1, HH = TH + KS - 1;
+    static constexpr int HW = ST * (TW - 1) + KS, HH = ST * (TH - 1) + KS;   // input patch of one output tile
     static constexpr int PX = KS == 1 ? 64 * MW : HW * HH;       // staged pixels per chunk
     static constexpr int ROWB = KS == 1 ? 0 : (HW * A_PXB + 255) / 256 * 256;
     static constexpr int A_PLANE = KS == 1 ? PX * A_PXB : HH * ROWB;
@@ -67,9 +67,9 @@ struct ConvArgs {
     const float* shift;          // [Cout] or null
     const float* res;            // residual, same layout as y, or null
     float* y;
-    long npix;                   // N * H * W
+    long npix;                   // N * Ho * Wo output pixels (= input pixels for 1x1)
     long ntiles;                 // blocks along x
-    int H, W, Cin, Cout, tilesX, tilesY, nchunks, nblkY, act;
+    int H, W, Ho, Wo, Cin, Cout, tilesX, tilesY, nchunks, nblkY, act;   // input H x W, output Ho x Wo
     float slope;
 };
 
@@ -95,9 +95,9 @@ struct TilePos {
     long pix0;
 };
 
-template <int KS, int MW, int NTHR, int ITERS>
+template <int KS, int MW, int ST, int NTHR, int ITERS>
 __device__ __forceinline__ void stage_load(Stage<ITERS>& st, const ConvArgs& p, const TilePos& tp, int chunk, int tid) {
-    using G = Geo<KS, MW>;
+    using G = Geo<KS, MW, ST>;
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int i = tid + NTHR * it;
@@ -110,7 +110,7 @@ __device__ __forceinline__ void stage_load(Stage<ITERS>& st, const ConvArgs& p, 
             ok = ok && pix < p.npix;
         } else {
             const int hy = hp / G::HW, hx = hp - hy * G::HW;
-            const int iy = tp.oy0 - KS / 2 + hy, ix = tp.ox0 - KS / 2 + hx;
+            const int iy = ST * tp.oy0 - KS / 2 + hy, ix = ST * tp.ox0 - KS / 2 + hx;
             ok = ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
             pix = ((long)tp.img * p.H + iy) * p.W + ix;
         }
@@ -126,9 +126,9 @@ __device__ __forceinline__ void stage_load(Stage<ITERS>& st, const ConvArgs& p, 
     }
 }
 
-template <int KS, int MW, int NTHR, int ITERS, bool SPLIT>
+template <int KS, int MW, int ST, int NTHR, int ITERS, bool SPLIT>
 __device__ __forceinline__ void stage_store(const Stage<ITERS>& st, unsigned char* As, int tid) {
-    using G = Geo<KS, MW>;
+    using G = Geo<KS, MW, ST>;
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int i = tid + NTHR * it;
@@ -146,9 +146,9 @@ __device__ __forceinline__ void stage_store(const Stage<ITERS>& st, unsigned cha
 }
 
 // Workgroup = MW x NW waves: wave (wm, wn) owns 64 pixels (4 tile rows x 16) x 32 NTW output channels.
-template <int KS, int MW, int NW, int NTW, bool SPLIT>
-__global__ __launch_bounds__(64 * MW * NW, 2) void k_conv(const ConvArgs p) {
-    using G = Geo<KS, MW>;
+template <int KS, int MW, int NW, int NTW, bool SPLIT, int ST>
+__global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const ConvArgs p) {
+    using G = Geo<KS, MW, ST>;
     constexpr int NTHR = 64 * MW * NW;
     constexpr int PLANES = SPLIT ? 2 : 1;
     constexpr int TAPS = KS * KS;
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(64 * MW * NW, 2) void k_conv(const ConvArgs p) {
     for (int mt = 0; mt < 2; ++mt) {
         const int mtile = 2 * wm + mt;
         if (KS == 1) a_off[mt] = (32 * mtile + l31) * A_PXB + h * 16;
-        else a_off[mt] = G::px_off(2 * mtile + (l31 >> 4), l31 & 15) + h * 16;
+        else a_off[mt] = G::px_off(ST * (2 * mtile + (l31 >> 4)), ST * (l31 & 15)) + h * 16;
     }
     // weight row n of the slab: 2 slots of 8 channels, slot ^= (n >> 3) & 1 (conflict-free fragment reads)
     const int b_off = (32 * NTW * wn + l31) * 32 + ((h ^ ((l31 >> 3) & 1)) * 16);
@@ -230,10 +230,10 @@ __global__ __launch_bounds__(64 * MW * NW, 2) void k_conv(const ConvArgs p) {
 
     // ---- prologue: pixels of chunk 0, weight slabs of phases 0 and 1 (the ring runs two phases ahead)
     Stage<ITERS> st;
-    stage_load<KS, MW, NTHR, ITERS>(st, p, tp, 0, tid);
+    stage_load<KS, MW, ST, NTHR, ITERS>(st, p, tp, 0, tid);
     prefetch();
     prefetch();
-    stage_store<KS, MW, NTHR, ITERS, SPLIT>(st, As, tid);
+    stage_store<KS, MW, ST, NTHR, ITERS, SPLIT>(st, As, tid);
 
     // Fragment registers.  The pixel (A) fragments of a phase are read during the previous phase; the weight (B)
     // fragments in two halves of NTW / 2 column tiles, the second half behind the first half's MFMAs.
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(64 * MW * NW, 2) void k_conv(const ConvArgs p) {
                 if (first || !APRE) read_a(ah, al, tap, ks);
                 __builtin_amdgcn_sched_barrier(0);
                 prefetch();
-                if (tap == LOAD_TAP && ks == 0 && chunk + 1 < nchunks) stage_load<KS, MW, NTHR, ITERS>(st, p, tp, chunk + 1, tid);
+                if (tap == LOAD_TAP && ks == 0 && chunk + 1 < nchunks) stage_load<KS, MW, ST, NTHR, ITERS>(st, p, tp, chunk + 1, tid);
                 read_b(1, B);
                 __builtin_amdgcn_sched_barrier(0);
                 mma_half(0);
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(64 * MW * NW, 2) void k_conv(const ConvArgs p) {
         }
         if (chunk + 1 < nchunks) {
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done with this chunk's pixels
-            stage_store<KS, MW, NTHR, ITERS, SPLIT>(st, As, tid);
+            stage_store<KS, MW, ST, NTHR, ITERS, SPLIT>(st, As, tid);
         }
     }
 
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(64 * MW * NW, 2) void k_conv(const ConvArgs p) {
                     if (pix < p.npix) off[r] = pix * p.Cout + co;
                 } else {
                     const int oy = tp.oy0 + 2 * mtile + (prow >> 4), ox = tp.ox0 + (prow & 15);
-                    if (oy < p.H && ox < p.W) off[r] = (((long)tp.img * p.H + oy) * p.W + ox) * p.Cout + co;
+                    if (oy < p.Ho && ox < p.Wo) off[r] = (((long)tp.img * p.Ho + oy) * p.Wo + ox) * p.Cout + co;
                 }
                 rv[r] = (resp && off[r] >= 0) ? resp[off[r]] : 0.f;
             }
@@ -384,20 +384,20 @@ __global__ void k_conv_pack(const float* __restrict__ w, int Cin, int Cout, int 
 // 128 pixels x 256 channels per block (2 x 2 waves); every wave owns 64 pixels x 128 channels.  (Measured on
 // MI355X: 8-wave workgroups of the same wave tile and 64-channel wave tiles were equal or slower.)
 struct TileCfg { int mw, nw, nt; };
-inline TileCfg cfg_for(int Cout) { return Cout <= 128 ? TileCfg{4, 1, 128} : TileCfg{2, 2, 256}; }
+inline TileCfg cfg_for(int Cout, int stride) { return (Cout <= 128 && stride == 1) ? TileCfg{4, 1, 128} : TileCfg{2, 2, 256}; }
 
-template <int KS, int MW, int NW, int NTW, bool SPLIT>
+template <int KS, int MW, int NW, int NTW, bool SPLIT, int ST = 1>
 int launch_conv(const ConvArgs& a, dim3 grid, hipStream_t stream) {
-    using G = Geo<KS, MW>;
+    using G = Geo<KS, MW, ST>;
     constexpr int PLANES = SPLIT ? 2 : 1;
     constexpr int smem = PLANES * G::A_PLANE + 3 * PLANES * 32 * NTW * NW * 32;
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute((const void*)k_conv<KS, MW, NW, NTW, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)k_conv<KS, MW, NW, NTW, SPLIT, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
             return far_check_launch();
         configured = true;
     }
-    hipLaunchKernelGGL((k_conv<KS, MW, NW, NTW, SPLIT>), grid, dim3(64 * MW * NW), smem, stream, a);
+    hipLaunchKernelGGL((k_conv<KS, MW, NW, NTW, SPLIT, ST>), grid, dim3(64 * MW * NW), smem, stream, a);
     return far_check_launch();
 }
 
@@ -407,14 +407,18 @@ int launch_cfg(const TileCfg& c, const ConvArgs& a, dim3 grid, hipStream_t strea
     return launch_conv<KS, 2, 2, 4, SPLIT>(a, grid, stream);
 }
 
+// 3x3 stride 2: the (2*8+1) x (2*16+1) input patch takes 94 KB of LDS -> one workgroup per CU (and up to 512 registers)
+template <bool SPLIT>
+int launch_stride2(const ConvArgs& a, dim3 grid, hipStream_t stream) { return launch_conv<3, 2, 2, 4, SPLIT, 2>(a, grid, stream); }
+
 }  // namespace
 
 extern "C" {
 
 // Bytes of the packed weight image for a [Cout][Cin][ksize][ksize] weight (split = 1: hi + lo planes).
-size_t far_conv_packed_bytes(int Cin, int Cout, int ksize, int split) {
-    if (Cin <= 0 || Cout <= 0 || (ksize != 1 && ksize != 3)) return 0;
-    const int NT = cfg_for(Cout).nt;
+size_t far_conv_packed_bytes(int Cin, int Cout, int ksize, int stride, int split) {
+    if (Cin <= 0 || Cout <= 0 || (ksize != 1 && ksize != 3) || stride < 1 || stride > 2 || (stride == 2 && ksize != 3)) return 0;
+    const int NT = cfg_for(Cout, stride).nt;
     const size_t nchunks = (Cin + 31) / 32, nblkY = (Cout + NT - 1) / NT;
     return (size_t)ksize * ksize * nchunks * nblkY * (split ? 2 : 1) * NT * 64;
 }
@@ -422,37 +426,40 @@ size_t far_conv_packed_bytes(int Cin, int Cout, int ksize, int split) {
 // w: torch layout [Cout][Cin][ksize][ksize] fp32.  Every weight is multiplied by 2^w_exp before the fp16 split
 // (choose w_exp so that max|w| 2^w_exp is in [2^13, 2^15): the lo parts stay fp16-normal); the caller folds
 // 2^-(w_exp + 4) into the `scale` vector passed to far_conv_nhwc_f32.
-int far_conv_pack_f32(const float* w, int Cin, int Cout, int ksize, int w_exp, int split, void* packed, hipStream_t stream) {
+int far_conv_pack_f32(const float* w, int Cin, int Cout, int ksize, int stride, int w_exp, int split, void* packed,
+                      hipStream_t stream) {
     far_clear_errors();
-    if (!w || !packed || far_conv_packed_bytes(Cin, Cout, ksize, split) == 0 || w_exp < -60 || w_exp > 60) return FAR_EINVAL;
-    const int NT = cfg_for(Cout).nt;
+    if (!w || !packed || far_conv_packed_bytes(Cin, Cout, ksize, stride, split) == 0 || w_exp < -60 || w_exp > 60) return FAR_EINVAL;
+    const int NT = cfg_for(Cout, stride).nt;
     const int nchunks = (Cin + 31) / 32, nblkY = (Cout + NT - 1) / NT;
     hipLaunchKernelGGL(k_conv_pack, dim3(512), dim3(256), 0, stream, w, Cin, Cout, ksize * ksize, nchunks, nblkY, NT,
                        split ? 2 : 1, ldexpf(1.0f, w_exp), (_Float16*)packed);
     return far_check_launch();
 }
 
-// y[n][oy][ox][co] = act(scale[co] * sum_{ky,kx,ci} x[n][oy+ky-p][ox+kx-p][ci] * W[co][ci][ky][kx] + shift[co] + res)
-// x [N][H][W][Cin1] (+ x2 [N][H][W][Cin - Cin1]: the input is their channel concatenation, never materialised;
-// x2 = NULL and Cin1 = Cin for a single input), res / y [N][H][W][Cout] fp32 NHWC contiguous, stride 1, zero padding
-// ksize/2; Cin % 4 == 0, Cin1 % 8 == 0.
+// y[n][oy][ox][co] = act(scale[co] * sum_{ky,kx,ci} X[n][s oy+ky-p][s ox+kx-p][ci] * W[co][ci][ky][kx] + shift[co] + res)
+// X = x [N][H][W][Cin1] (+ x2 [N][H][W][Cin - Cin1]: the input is their channel concatenation, never materialised;
+// x2 = NULL and Cin1 = Cin for a single input); res / y [N][Ho][Wo][Cout] with Ho = (H - 1) / s + 1 (zero padding
+// p = ksize / 2), all fp32 NHWC contiguous; stride s = 1, or 2 for ksize 3; Cin % 4 == 0, Cin1 % 8 == 0.
 // `scale` must include 2^-(w_exp + 4).  act: 0 none, 1 ReLU, 2 LeakyReLU(slope).  A linear layer is ksize = 1 with
-// N = H = 1, W = rows.  y must alias neither x nor res.
+// N = H = 1, W = rows.  y must alias none of the inputs.
 int far_conv_nhwc_f32(const float* x, const float* x2, int Cin1, const void* packed, const float* scale,
-                      const float* shift, const float* res, long N, int H, int W, int Cin, int Cout, int ksize, int act,
-                      float slope, int split, float* y, hipStream_t stream) {
+                      const float* shift, const float* res, long N, int H, int W, int Cin, int Cout, int ksize,
+                      int stride, int act, float slope, int split, float* y, hipStream_t stream) {
     far_clear_errors();
     if (N == 0) return FAR_OK;
     if (!x || !packed || !scale || !y || N < 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) || Cout <= 0 ||
-        (ksize != 1 && ksize != 3) || act < 0 || act > 2 || x == y || x2 == y)
+        (ksize != 1 && ksize != 3) || stride < 1 || stride > 2 || (stride == 2 && ksize != 3) || act < 0 || act > 2 ||
+        x == y || x2 == y)
         return FAR_EINVAL;
     if (x2 ? (Cin1 <= 0 || Cin1 >= Cin || (Cin1 & 7)) : (Cin1 != Cin)) return FAR_EINVAL;
     ConvArgs a;
     a.x = x; a.x2 = x2; a.Cin1 = Cin1; a.w = (const unsigned char*)packed; a.scale = scale; a.shift = shift; a.res = res; a.y = y;
-    a.npix = N * H * W; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
-    const TileCfg c = cfg_for(Cout);
+    a.H = H; a.W = W; a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1; a.Cin = Cin; a.Cout = Cout;
+    a.npix = N * a.Ho * a.Wo;
+    const TileCfg c = cfg_for(Cout, stride);
     const int th = 4 * c.mw;
-    a.tilesX = (W + TW - 1) / TW; a.tilesY = (H + th - 1) / th;
+    a.tilesX = (a.Wo + TW - 1) / TW; a.tilesY = (a.Ho + th - 1) / th;
     a.nchunks = (Cin + 31) / 32;
     a.nblkY = (Cout + c.nt - 1) / c.nt;
     a.act = act; a.slope = slope;
@@ -460,6 +467,7 @@ int far_conv_nhwc_f32(const float* x, const float* x2, int Cin1, const void* pac
     a.ntiles = nbx;
     if (nbx > 0x7fffffffL) return FAR_EINVAL;
     dim3 grid((unsigned)nbx, (unsigned)a.nblkY);
+    if (stride == 2) return split ? launch_stride2<true>(a, grid, stream) : launch_stride2<false>(a, grid, stream);
     if (ksize == 3) return split ? launch_cfg<3, true>(c, a, grid, stream) : launch_cfg<3, false>(c, a, grid, stream);
     return split ? launch_cfg<1, true>(c, a, grid, stream) : launch_cfg<1, false>(c, a, grid, stream);
 }

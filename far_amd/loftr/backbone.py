@@ -3,9 +3,9 @@
 Mirrors the architecture and PARAMETER NAMES of mp3d_loftr/src/loftr/backbone/resnet_fpn.py:15-119
 (BasicBlock, ResNetFPN_8_2) so reference checkpoints load.
 
-Inference in fp32 on the GPU runs `_forward_fused`: NHWC activations end to end, the stem on K10, every stride-1
-3x3 / 1x1 convolution on K9 (split-fp16 implicit GEMM with BatchNorm, activation and residual add fused into the
-epilogue), the FPN upsample-add on K8; only the two stride-2 3x3 convolutions stay on the vendor library.
+Inference in fp32 on the GPU runs `_forward_fused`: NHWC activations end to end, the stem on K10, every 3x3 / 1x1
+convolution on K9 (split-fp16 implicit GEMM with BatchNorm, activation and residual add fused into the epilogue), the
+FPN upsample-add on K8: no vendor convolution is left on the inference path.
 Training (gradients) and the optional half-precision modes run the plain torch modules.
 """
 import torch
@@ -34,7 +34,8 @@ class _PackCache(ops.PackCache):
 
         def build():
             scale, shift = _fold(bn) if bn is not None else (None, None)
-            return ops.PackedConv(conv.weight, scale, shift, split=split)
+            stride = conv.stride[0] if conv.kernel_size[0] == 3 else 1      # 1x1 stride 2: the caller subsamples
+            return ops.PackedConv(conv.weight, scale, shift, split=split, stride=stride)
         return super().get((key, split), ts, build)
 
 
@@ -102,15 +103,10 @@ class ResNetFPN_8_2(nn.Module):
 
     def _block_fused(self, name, blk, x, pk):
         sp = self.trunk_split
+        y = ops.conv_nhwc(x, pk.get(name + '.conv1', blk.conv1, blk.bn1, sp), act='relu')      # stride 1 or 2
         if blk.downsample is None:
-            y = ops.conv_nhwc(x, pk.get(name + '.conv1', blk.conv1, blk.bn1, sp), act='relu')
             res = x
-        else:        # stride-2 block: vendor 3x3 stride-2 convolution on the NHWC buffer, K7 epilogue; 1x1 shortcut on K9
-            y = F.conv2d(x.permute(0, 3, 1, 2), blk.conv1.weight.contiguous(memory_format=torch.channels_last),
-                         stride=2, padding=1)
-            y = ops.affine_act(y, *_fold(blk.bn1), act='relu').permute(0, 2, 3, 1)
-            if not y.is_contiguous():
-                y = y.contiguous()
+        else:        # 1x1 stride-2 shortcut: K9 on the subsampled pixels, its BatchNorm folded
             res = ops.conv_nhwc(x[:, ::2, ::2, :].contiguous(), pk.get(name + '.down', blk.downsample[0], blk.downsample[1], sp))
         return ops.conv_nhwc(y, pk.get(name + '.conv2', blk.conv2, blk.bn2, sp), residual=res, act='relu')
 

@@ -262,7 +262,7 @@ _CONV_ACT_EXP = 4          # the kernel scales activations by 2^4 before the fp1
 class PackedConv:
     """Weights of one convolution / linear layer in K9's packed split-fp16 image, plus the folded epilogue vectors."""
 
-    def __init__(self, weight, scale=None, shift=None, split=True):
+    def __init__(self, weight, scale=None, shift=None, split=True, stride=1):
         lib = _lib.load()
         w = weight.detach()
         if w.dim() == 2:
@@ -273,10 +273,12 @@ class PackedConv:
         w = w.contiguous().float()
         amax = float(w.abs().max())                       # one host sync, at pack time only
         self.w_exp = 14 - (torch.frexp(torch.tensor(amax)).exponent.item() if amax > 0 else 0)
-        self.Cin, self.Cout, self.ksize, self.split = Cin, Cout, kh, bool(split)
-        nbytes = lib.far_conv_packed_bytes(Cin, Cout, kh, int(self.split))
+        if stride not in (1, 2) or (stride == 2 and kh != 3):
+            raise _lib.FarHipError('K9 supports stride 1, and stride 2 for 3x3 kernels')
+        self.Cin, self.Cout, self.ksize, self.split, self.stride = Cin, Cout, kh, bool(split), stride
+        nbytes = lib.far_conv_packed_bytes(Cin, Cout, kh, stride, int(self.split))
         self.packed = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
-        rc = lib.far_conv_pack_f32(_p(w, torch.float32), Cin, Cout, kh, self.w_exp, int(self.split), _p(self.packed),
+        rc = lib.far_conv_pack_f32(_p(w, torch.float32), Cin, Cout, kh, stride, self.w_exp, int(self.split), _p(self.packed),
                                    _stream())
         _lib.check(rc, 'far_conv_pack_f32')
         unscale = 2.0 ** -(self.w_exp + _CONV_ACT_EXP)
@@ -309,9 +311,10 @@ def conv_nhwc(x, pc, residual=None, act='none', slope=0.01, x2=None):
     Cin = Cin1 + (x2.shape[-1] if x2 is not None else 0)
     if Cin != pc.Cin or (x2 is not None and tuple(x2.shape[:3]) != (N, H, W)):
         raise _lib.FarHipError(f'conv_nhwc: input has {Cin} channels, weights expect {pc.Cin}')
-    y = torch.empty(N, H, W, pc.Cout, dtype=torch.float32, device=x.device)
+    st = pc.stride
+    y = torch.empty(N, (H - 1) // st + 1, (W - 1) // st + 1, pc.Cout, dtype=torch.float32, device=x.device)
     rc = lib.far_conv_nhwc_f32(_p(x, torch.float32), _p(x2, torch.float32), Cin1, _p(pc.packed), _p(pc.scale),
-                               _p(pc.shift), _p(residual, torch.float32), N, H, W, Cin, pc.Cout, pc.ksize, _ACT[act],
+                               _p(pc.shift), _p(residual, torch.float32), N, H, W, Cin, pc.Cout, pc.ksize, st, _ACT[act],
                                float(slope), int(pc.split), _p(y), _stream())
     _lib.check(rc, 'far_conv_nhwc_f32')
     return y

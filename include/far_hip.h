@@ -154,22 +154,24 @@ int far_upsample2x_add_f32(const float* lo, const float* hi, int N, int h, int w
  * fp32-grade results at 16/3 of the fp32 matrix rate.  split = 0 keeps hi only (plain fp16 operands).
  * --------------------------------------------------------------------------------------------------- */
 
-/* Bytes of the packed image of a [Cout][Cin][ksize][ksize] weight; ksize 1 or 3; 0 on bad arguments. */
-size_t far_conv_packed_bytes(int Cin, int Cout, int ksize, int split);
+/* Bytes of the packed image of a [Cout][Cin][ksize][ksize] weight; ksize 1 or 3, stride 1 (or 2 with ksize 3: the
+ * image depends on the tile shape the kernel uses for that stride); 0 on bad arguments. */
+size_t far_conv_packed_bytes(int Cin, int Cout, int ksize, int stride, int split);
 
 /* Packs w (torch layout [Cout][Cin][ksize][ksize] fp32), multiplied by 2^w_exp, into `packed`.  Choose w_exp with
  * 2^13 <= max|w| 2^w_exp < 2^15 and fold 2^-(w_exp + 4) into the `scale` vector of far_conv_nhwc_f32. */
-int far_conv_pack_f32(const float* w, int Cin, int Cout, int ksize, int w_exp, int split, void* packed,
+int far_conv_pack_f32(const float* w, int Cin, int Cout, int ksize, int stride, int w_exp, int split, void* packed,
                       far_stream_t stream);
 
 /* y = act(scale[co] * conv(X, W)[.., co] + shift[co] (+ res)); X = x [N][H][W][Cin1] or, with x2 != NULL, the channel
  * concatenation [x | x2] (x2 [N][H][W][Cin - Cin1], Cin1 % 8 == 0; never materialised: transformer.py:64 torch.cat);
- * res / y [N][H][W][Cout] fp32 NHWC, stride 1, zero padding ksize / 2, Cin % 4 == 0.  shift, res may be NULL.
+ * res / y [N][Ho][Wo][Cout], Ho = (H - 1) / stride + 1; fp32 NHWC, zero padding ksize / 2, Cin % 4 == 0; stride 1, or
+ * 2 with ksize 3 (resnet_fpn.py:19 conv3x3(in_planes, planes, stride)).  shift, res may be NULL.
  * act: 0 none, 1 ReLU, 2 LeakyReLU(slope).  A linear layer y = x W^T + b is ksize = 1, N = H = 1, W = rows, shift = b.
  * y must alias none of the inputs. */
 int far_conv_nhwc_f32(const float* x, const float* x2, int Cin1, const void* packed, const float* scale,
-                      const float* shift, const float* res, long N, int H, int W, int Cin, int Cout, int ksize, int act,
-                      float slope, int split, float* y, far_stream_t stream);
+                      const float* shift, const float* res, long N, int H, int W, int Cin, int Cout, int ksize,
+                      int stride, int act, float slope, int split, float* y, far_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * K10  backbone stem: 7x7 stride-2 convolution of a 1-channel image + folded BatchNorm + ReLU (exact-f32 MFMA)

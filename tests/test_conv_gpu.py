@@ -53,6 +53,22 @@ def test_conv_split_matches_float64(N, H, W, Cin, Cout, ks):
             assert emax < tol_max and erms < tol_rms, (split, act, emax, erms)
 
 
+@pytest.mark.parametrize('N,H,W,Cin,Cout', [(2, 48, 64, 128, 196), (1, 31, 45, 196, 256), (1, 16, 16, 64, 64), (2, 9, 7, 32, 40)])
+def test_conv_stride2_matches_float64(N, H, W, Cin, Cout):
+    ops = _ops()
+    g = torch.Generator(device='cuda').manual_seed(Cin + Cout + H)
+    x = torch.randn(N, H, W, Cin, device='cuda', generator=g).relu_()
+    w = torch.randn(Cout, Cin, 3, 3, device='cuda', generator=g) * (2.0 / (Cin * 9)) ** 0.5
+    scale = torch.rand(Cout, device='cuda', generator=g) + 0.5
+    shift = torch.randn(Cout, device='cuda', generator=g) * 0.1
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), stride=2, padding=1).permute(0, 2, 3, 1)
+    ref = torch.relu(ref * scale.double() + shift.double())
+    y = ops.conv_nhwc(x, ops.PackedConv(w, scale, shift, stride=2), act='relu')
+    assert y.shape == ref.shape
+    emax, erms = _rel(y, ref)
+    assert emax < 4e-6 and erms < 1.5e-6, (emax, erms)
+
+
 def test_conv_split_is_as_accurate_as_fp32_direct():
     """The split product's error is of the order of an fp32 direct convolution's (both measured against float64)."""
     ops = _ops()
