@@ -69,6 +69,7 @@ struct ConvArgs {
     float* y;
     long npix;                   // N * Ho * Wo output pixels (= input pixels for 1x1)
     long ntiles;                 // blocks along x
+    int Csub;                    // output channels per output plane (Cout: one NHWC tensor)
     int H, W, Ho, Wo, Cin, Cout, tilesX, tilesY, nchunks, nblkY, act;   // input H x W, output Ho x Wo
     float slope;
 };
@@ -141,6 +142,50 @@ __device__ __forceinline__ void stage_store(const Stage<ITERS>& st, unsigned cha
             split8(st.v[it][0], st.v[it][1], hi, lo);
             *reinterpret_cast<f16x8*>(As + off + g * 16) = hi;
             if (SPLIT) *reinterpret_cast<f16x8*>(As + G::A_PLANE + off + g * 16) = lo;
+        }
+    }
+}
+
+// Epilogue: y = act(acc * scale[c] + shift[c] + res).  A lane holds output channel
+// cout_w + 32 nt + l31 of 16 pixels per accumulator tile; the residual values of a tile are all requested before the
+// first store.  Output channel co lands in plane co / Csub of y ([Cout / Csub][pixels][Csub]; Csub = Cout: plain NHWC).
+template <int KS, int NTW>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const f32x16 (&acc)[2][NTW], const TilePos& tp,
+                                              int cout_w, int wm, int l31, int h) {
+    const float* __restrict__ resp = p.res;
+    float* __restrict__ yp = p.y;
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        const int co = cout_w + 32 * nt + l31;
+        if (co >= p.Cout) continue;
+        const float sc = p.scale[co], sh = p.shift ? p.shift[co] : 0.f;
+        const int plane = co / p.Csub;
+        const long cbase = (long)plane * p.npix * p.Csub + (co - plane * p.Csub);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int mtile = 2 * wm + mt;
+            long off[16];
+            float rv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int prow = mfma32_row(r, h);
+                off[r] = -1;
+                if (KS == 1) {
+                    const long pix = tp.pix0 + 32 * mtile + prow;
+                    if (pix < p.npix) off[r] = pix * p.Csub + cbase;
+                } else {
+                    const int oy = tp.oy0 + 2 * mtile + (prow >> 4), ox = tp.ox0 + (prow & 15);
+                    if (oy < p.Ho && ox < p.Wo) off[r] = (((long)tp.img * p.Ho + oy) * p.Wo + ox) * p.Csub + cbase;
+                }
+                rv[r] = (resp && off[r] >= 0) ? resp[off[r]] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[mt][nt][r] * sc + sh + rv[r];
+                if (p.act == 1) v = fmaxf(v, 0.f);
+                else if (p.act == 2) v = v > 0.f ? v : v * p.slope;
+                if (off[r] >= 0) yp[off[r]] = v;
+            }
         }
     }
 }
@@ -315,41 +360,7 @@ __global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const 
         }
     }
 
-    // ---- epilogue: y = act(acc * scale[c] + shift[c] + res)
-    const float* __restrict__ resp = p.res;
-    float* __restrict__ yp = p.y;
-#pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) {
-        const int co = cout_w + 32 * nt + l31;
-        if (co >= p.Cout) continue;
-        const float sc = p.scale[co], sh = p.shift ? p.shift[co] : 0.f;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const int mtile = 2 * wm + mt;
-            long off[16];
-            float rv[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int prow = mfma32_row(r, h);
-                off[r] = -1;
-                if (KS == 1) {
-                    const long pix = tp.pix0 + 32 * mtile + prow;
-                    if (pix < p.npix) off[r] = pix * p.Cout + co;
-                } else {
-                    const int oy = tp.oy0 + 2 * mtile + (prow >> 4), ox = tp.ox0 + (prow & 15);
-                    if (oy < p.Ho && ox < p.Wo) off[r] = (((long)tp.img * p.Ho + oy) * p.Wo + ox) * p.Cout + co;
-                }
-                rv[r] = (resp && off[r] >= 0) ? resp[off[r]] : 0.f;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = acc[mt][nt][r] * sc + sh + rv[r];
-                if (p.act == 1) v = fmaxf(v, 0.f);
-                else if (p.act == 2) v = v > 0.f ? v : v * p.slope;
-                if (off[r] >= 0) yp[off[r]] = v;
-            }
-        }
-    }
+    conv_epilogue<KS, NTW>(p, acc, tp, cout_w, wm, l31, h);
 }
 
 // Packs torch-layout weights [Cout][Cin][KS][KS] (or [Cout][Cin] for linear) into the LDS image the kernel DMAs, in
@@ -442,20 +453,22 @@ int far_conv_pack_f32(const float* w, int Cin, int Cout, int ksize, int stride, 
 // x2 = NULL and Cin1 = Cin for a single input); res / y [N][Ho][Wo][Cout] with Ho = (H - 1) / s + 1 (zero padding
 // p = ksize / 2), all fp32 NHWC contiguous; stride s = 1, or 2 for ksize 3; Cin % 4 == 0, Cin1 % 8 == 0.
 // `scale` must include 2^-(w_exp + 4).  act: 0 none, 1 ReLU, 2 LeakyReLU(slope).  A linear layer is ksize = 1 with
-// N = H = 1, W = rows.  y must alias none of the inputs.
+// N = H = 1, W = rows.  out_planes > 1: output channel co goes to plane co / (Cout / out_planes) of y, laid out
+// [out_planes][N][Ho][Wo][Cout / out_planes] (fused projections, e.g. q | k | v); res, if given, has y's layout.
+// y must alias none of the inputs.
 int far_conv_nhwc_f32(const float* x, const float* x2, int Cin1, const void* packed, const float* scale,
                       const float* shift, const float* res, long N, int H, int W, int Cin, int Cout, int ksize,
-                      int stride, int act, float slope, int split, float* y, hipStream_t stream) {
+                      int stride, int act, float slope, int split, int out_planes, float* y, hipStream_t stream) {
     far_clear_errors();
     if (N == 0) return FAR_OK;
     if (!x || !packed || !scale || !y || N < 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) || Cout <= 0 ||
         (ksize != 1 && ksize != 3) || stride < 1 || stride > 2 || (stride == 2 && ksize != 3) || act < 0 || act > 2 ||
-        x == y || x2 == y)
+        x == y || x2 == y || out_planes < 1 || Cout % out_planes)
         return FAR_EINVAL;
     if (x2 ? (Cin1 <= 0 || Cin1 >= Cin || (Cin1 & 7)) : (Cin1 != Cin)) return FAR_EINVAL;
     ConvArgs a;
     a.x = x; a.x2 = x2; a.Cin1 = Cin1; a.w = (const unsigned char*)packed; a.scale = scale; a.shift = shift; a.res = res; a.y = y;
-    a.H = H; a.W = W; a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1; a.Cin = Cin; a.Cout = Cout;
+    a.H = H; a.W = W; a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1; a.Cin = Cin; a.Cout = Cout; a.Csub = Cout / out_planes;
     a.npix = N * a.Ho * a.Wo;
     const TileCfg c = cfg_for(Cout, stride);
     const int th = 4 * c.mw;

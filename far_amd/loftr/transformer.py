@@ -76,12 +76,22 @@ class LoFTREncoderLayer(nn.Module):
         # inference: the five Linear layers on K9 (split-fp16 operands: fp32-grade, and -- unlike a vendor GEMM whose
         # kernel is chosen by the row count -- every output row depends on its input row only)
         pk = self.__dict__.setdefault('_packs', ops.PackCache())
-        lin = lambda name, mod: pk.get(name, [mod.weight], lambda: ops.PackedConv(mod.weight))
+        lin = lambda name, *mods: pk.get(name, [m.weight for m in mods],
+                                         lambda: ops.PackedConv(torch.cat([m.weight for m in mods], 0)))
         x = x.contiguous()
+        heads = lambda t: t.view(bs, -1, self.nhead, self.dim)
+        fuse = self.nhead * self.dim >= 256     # measured: fusing pays at d_model 256 (wide tiles), not at 128
         source = source.contiguous()
-        q = ops.linear_f16s(x, lin('q', self.q_proj)).view(bs, -1, self.nhead, self.dim)
-        k = ops.linear_f16s(source, lin('k', self.k_proj)).view(bs, -1, self.nhead, self.dim)
-        v = ops.linear_f16s(source, lin('v', self.v_proj)).view(bs, -1, self.nhead, self.dim)
+        if fuse and source is x:  # self attention: q | k | v of the one input in a single launch, three output tensors
+            q, k, v = ops.linear_f16s(x, lin('qkv', self.q_proj, self.k_proj, self.v_proj), out_planes=3)
+        elif fuse:
+            q = ops.linear_f16s(x, lin('q', self.q_proj))
+            k, v = ops.linear_f16s(source, lin('kv', self.k_proj, self.v_proj), out_planes=2)
+        else:
+            q = ops.linear_f16s(x, lin('q', self.q_proj))
+            k = ops.linear_f16s(source, lin('k', self.k_proj))
+            v = ops.linear_f16s(source, lin('v', self.v_proj))
+        q, k, v = heads(q), heads(k), heads(v)
         msg = self.attention(q, k, v, q_mask=x_mask, kv_mask=source_mask, loftr_preds=loftr_preds)
         msg = ops.linear_f16s(msg.view(bs, -1, self.nhead * self.dim), lin('merge', self.merge))
         msg = ops.layernorm(msg, self.norm1.weight, self.norm1.bias, self.norm1.eps)                       # :61

@@ -303,32 +303,38 @@ class PackCache:
         return hit[1]
 
 
-def conv_nhwc(x, pc, residual=None, act='none', slope=0.01, x2=None):
+def conv_nhwc(x, pc, residual=None, act='none', slope=0.01, x2=None, out_planes=1):
     """K9.  x (N, H, W, Cin) fp32 contiguous -> act(conv(x) * scale + shift (+ residual)) as (N, H, W, Cout).
-    With x2 (N, H, W, C2) the convolution input is cat([x, x2], -1), read in place."""
+    With x2 (N, H, W, C2) the convolution input is cat([x, x2], -1), read in place.  out_planes = P > 1 returns
+    (P, N, H, W, Cout / P): the output channels split into P separate contiguous tensors."""
     lib = _lib.load()
     N, H, W, Cin1 = x.shape
     Cin = Cin1 + (x2.shape[-1] if x2 is not None else 0)
     if Cin != pc.Cin or (x2 is not None and tuple(x2.shape[:3]) != (N, H, W)):
         raise _lib.FarHipError(f'conv_nhwc: input has {Cin} channels, weights expect {pc.Cin}')
     st = pc.stride
-    y = torch.empty(N, (H - 1) // st + 1, (W - 1) // st + 1, pc.Cout, dtype=torch.float32, device=x.device)
+    if pc.Cout % out_planes:
+        raise _lib.FarHipError('conv_nhwc: out_planes must divide the output channel count')
+    shape = (N, (H - 1) // st + 1, (W - 1) // st + 1, pc.Cout // out_planes)
+    y = torch.empty((out_planes,) + shape if out_planes > 1 else shape, dtype=torch.float32, device=x.device)
     rc = lib.far_conv_nhwc_f32(_p(x, torch.float32), _p(x2, torch.float32), Cin1, _p(pc.packed), _p(pc.scale),
                                _p(pc.shift), _p(residual, torch.float32), N, H, W, Cin, pc.Cout, pc.ksize, st, _ACT[act],
-                               float(slope), int(pc.split), _p(y), _stream())
+                               float(slope), int(pc.split), int(out_planes), _p(y), _stream())
     _lib.check(rc, 'far_conv_nhwc_f32')
     return y
 
 
-def linear_f16s(x, pc, residual=None, act='none', x2=None):
-    """K9 as a linear layer: x (..., K) fp32 -> act(cat([x, x2], -1) W^T * scale + shift (+ residual)) (..., Cout)."""
+def linear_f16s(x, pc, residual=None, act='none', x2=None, out_planes=1):
+    """K9 as a linear layer: x (..., K) fp32 -> act(cat([x, x2], -1) W^T * scale + shift (+ residual)) (..., Cout);
+    out_planes = P > 1: (P, ..., Cout / P), e.g. the q / k / v projections of one input in one launch."""
     lead = x.shape[:-1]
     rows = 1
     for d in lead:
         rows *= d
     r = None if residual is None else residual.reshape(1, 1, rows, pc.Cout)
     x2 = None if x2 is None else x2.reshape(1, 1, rows, x2.shape[-1])
-    return conv_nhwc(x.reshape(1, 1, rows, x.shape[-1]), pc, residual=r, act=act, x2=x2).reshape(*lead, pc.Cout)
+    y = conv_nhwc(x.reshape(1, 1, rows, x.shape[-1]), pc, residual=r, act=act, x2=x2, out_planes=out_planes)
+    return y.reshape(*lead, pc.Cout) if out_planes == 1 else y.reshape(out_planes, *lead, pc.Cout // out_planes)
 
 
 def stem7x7(img, weight, scale, shift):

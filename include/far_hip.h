@@ -168,10 +168,12 @@ int far_conv_pack_f32(const float* w, int Cin, int Cout, int ksize, int stride, 
  * res / y [N][Ho][Wo][Cout], Ho = (H - 1) / stride + 1; fp32 NHWC, zero padding ksize / 2, Cin % 4 == 0; stride 1, or
  * 2 with ksize 3 (resnet_fpn.py:19 conv3x3(in_planes, planes, stride)).  shift, res may be NULL.
  * act: 0 none, 1 ReLU, 2 LeakyReLU(slope).  A linear layer y = x W^T + b is ksize = 1, N = H = 1, W = rows, shift = b.
+ * out_planes > 1 splits the output channels into that many separate contiguous tensors, y = [out_planes][N][Ho][Wo]
+ * [Cout / out_planes] (fused projections: transformer.py:45-47 q_proj / k_proj / v_proj in one launch).
  * y must alias none of the inputs. */
 int far_conv_nhwc_f32(const float* x, const float* x2, int Cin1, const void* packed, const float* scale,
                       const float* shift, const float* res, long N, int H, int W, int Cin, int Cout, int ksize,
-                      int stride, int act, float slope, int split, float* y, far_stream_t stream);
+                      int stride, int act, float slope, int split, int out_planes, float* y, far_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * K10  backbone stem: 7x7 stride-2 convolution of a 1-channel image + folded BatchNorm + ReLU (exact-f32 MFMA)

@@ -189,3 +189,16 @@ def test_conv_fused_concat_input():
     y3 = ops.conv_nhwc(xs, ops.PackedConv(w3), x2=ms)
     ref3 = F.conv2d(torch.cat([xs, ms], -1).permute(0, 3, 1, 2).double(), w3.double(), padding=1).permute(0, 2, 3, 1)
     assert _rel(y3, ref3)[0] < 4e-6
+
+
+def test_linear_output_planes():
+    """out_planes: fused q | k | v projections land in separate contiguous tensors."""
+    ops = _ops()
+    g = torch.Generator(device='cuda').manual_seed(8)
+    for K, P, Csub in ((256, 3, 256), (128, 3, 128), (256, 2, 256)):
+        x = torch.randn(2, 301, K, device='cuda', generator=g)
+        w = torch.randn(P * Csub, K, device='cuda', generator=g) * 0.05
+        y = ops.linear_f16s(x, ops.PackedConv(w), out_planes=P)
+        assert y.shape == (P, 2, 301, Csub) and y.is_contiguous()
+        ref = (x.double() @ w.double().t()).view(2, 301, P, Csub).permute(2, 0, 1, 3)
+        assert _rel(y, ref)[0] < 4e-6
