@@ -37,4 +37,15 @@ if which in ('k5', 'all'):
     v = torch.randn(2 * n, L, 256, device=dev, generator=g)
     for _ in range(it):
         ops.linear_attention(q, k, v, 8)
+if which in ('k9', 'all'):
+    x = torch.randn(2 * n, 240, 320, 196, device=dev, generator=g).relu_()
+    w = torch.randn(196, 196, 3, 3, device=dev, generator=g) * 0.03
+    pc = ops.PackedConv(w, torch.ones(196, device=dev), torch.zeros(196, device=dev))
+    for _ in range(it):
+        ops.conv_nhwc(x, pc, act='relu')
+    del x
+    r = torch.randn(1, 1, n * L, 256, device=dev, generator=g)
+    pl = ops.PackedConv(torch.randn(256, 256, device=dev, generator=g) * 0.05)
+    for _ in range(it):
+        ops.conv_nhwc(r, pl)
 torch.cuda.synchronize()

@@ -16,7 +16,8 @@ def load(path, counter):
 
 
 def short(name):
-    for key in ['k_stats_f32', 'k_match_f32', 'k_emm_pv_f32', 'k_la_kv_partial<32>', 'k_la_apply<32>', 'k_layernorm']:
+    for key in ['k_stats_f32', 'k_match_f32', 'k_emm_pv_f32', 'k_la_kv_partial<32>', 'k_la_apply<32>', 'k_layernorm',
+                'k_conv<3, 2, 2, 4, true, 1>', 'k_conv<1, 2, 2, 4, true, 1>']:
         if key in name:
             return key
     return None
@@ -32,5 +33,5 @@ if __name__ == '__main__':
         rd = 2.0 * fv * 1024
         wr = w[(k, g)][0] * 1024
         out[f'{s}|grid={g}'] = {'read_bytes': round(rd), 'write_bytes': round(wr), 'total_bytes': round(rd + wr), 'launches': n}
-    json.dump({'method': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on tools/kprobe.py all 32 2; '
+    json.dump({'method': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on tools/kprobe.py all 32 2 (+ k9 32 2); '
                          'read = 2 x FETCH_SIZE KiB, write = WRITE_SIZE KiB', 'per_launch': out}, sys.stdout, indent=1)
