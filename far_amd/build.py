@@ -13,7 +13,7 @@ LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libfar_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off',
-         '-Wno-unused-result', '-Wno-unused-value', '-I', CSRC]
+         '-Wno-unused-result', '-Wno-unused-value', '-I', CSRC] + os.environ.get('FAR_EXTRA_HIPCC_FLAGS', '').split()
 
 
 def sources():
