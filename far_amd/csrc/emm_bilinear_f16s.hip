@@ -1,0 +1,356 @@
+// K2 on the f16 matrix cores with split-precision operands: the bilinear dual-softmax attention of the EMM head.
+//
+// Same operator as emm_bilinear_f32.hip (reference: mp3d_loftr/src/loftr/loftr_module/transformer.py:275-292):
+//   T = P [v | pos],  P = softmax(s, keys) * softmax(s, queries),  s = (q k^T) * scale          (Z, N, 70)
+// but the two contractions run at the f16 matrix rate with fp32-grade operands: every fp32 value is split
+// v = hi + lo (two fp16) and a product is hi.hi + hi.lo + lo.hi accumulated in fp32 (conv_igemm_f16s.hip explains
+// the numerics).  The exact-f32 MFMA variant spends 64 cycles per 32x32x2 step; this one 3 x 32 cycles per 32x32x16.
+//
+// Launches of one call (all on the caller's stream, workspace from the caller):
+//   k_prep_qk      q, k -> fp16 hi / lo planes, scaled by 2^4 (exact), written in the LDS image (16-byte slots
+//                  XOR-swizzled per row) so that a 64-row tile is one linear LDS-DMA copy
+//   k_rowstats x2  log2-domain softmax statistics (max, sum 2^(x - max)) of every row of s: once with (q, k) for the
+//                  softmax over keys, once with (k, q) for the softmax over queries -- no cross-lane reductions:
+//                  in the transposed score tile D[m = column][n = row] a lane owns one row
+//   k_prep_v       [v | pos] / colsum, transposed to [96 columns][keys] fp16 hi / lo tiles in LDS-image order, keys
+//                  permuted inside each group of 32 into the k-order in which the accumulator registers hold P
+//   k_pv           per 128 queries: for every 64-key tile  scores (24 MFMAs) -> p = 2^(2 x - rowmax - colmax + 15)
+//                  (ONE exp per score; 1 / rowsum, 1 / colsum and the 2^-15 are folded into the output scale and into
+//                  v~) -> fp16 hi / lo straight from the accumulator registers -> T += P v~ (36 MFMAs)
+#include "common.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int D = 64;            // head dim
+constexpr int DV = 70;           // v~ width (64 + 6 positional)
+constexpr int DVP = 96;          // padded to 3 MFMA column tiles
+constexpr int KT = 64;           // keys per tile
+constexpr float QK_PRESCALE = 16.0f;     // q, k scaled by 2^4 before the split (their fp16 lo parts stay normal)
+constexpr float V_PRESCALE = 64.0f;      // v~ / colsum scaled by 2^6; p by 2^15 (it is <= 1)
+constexpr float NEG_HUGE = -1.0e30f;
+
+__device__ __forceinline__ void split1(float x, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)x;
+    lo = (_Float16)(x - (float)hi);
+}
+
+// ---- k_prep_qk: x [Z][N][64] fp32 -> hi / lo [Z][Np][64] fp16 (rows >= N zero), 16-byte slot ^= (row >> 1) & 7
+__global__ void k_prep_qk(const float* __restrict__ x, int Z, int N, int Np, _Float16* __restrict__ hi, _Float16* __restrict__ lo) {
+    const long total = (long)Z * Np * 8;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int slot = (int)(t & 7);
+        const long row = t >> 3;
+        const int i = (int)(row % Np);
+        const long z = row / Np;
+        f16x8 vh, vl;
+        if (i < N) {
+            const float4 a = *reinterpret_cast<const float4*>(x + ((size_t)z * N + i) * D + slot * 8);
+            const float4 b = *reinterpret_cast<const float4*>(x + ((size_t)z * N + i) * D + slot * 8 + 4);
+            const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { _Float16 h, l; split1(v[e] * QK_PRESCALE, h, l); vh[e] = h; vl[e] = l; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { vh[e] = (_Float16)0.f; vl[e] = (_Float16)0.f; }
+        }
+        const int s2 = slot ^ ((i >> 1) & 7);
+        *reinterpret_cast<f16x8*>(hi + (size_t)row * D + s2 * 8) = vh;
+        *reinterpret_cast<f16x8*>(lo + (size_t)row * D + s2 * 8) = vl;
+    }
+}
+
+// Fragment of the register-resident ("row") side: row i, channels 16 s + 8 h .. + 7 of both planes (un-swizzled
+// on the way in: `irow` is the row index inside its problem, which the slot XOR was derived from).
+struct RowFrags {
+    f16x8 hi[4], lo[4];
+    __device__ __forceinline__ void load(const _Float16* ph, const _Float16* pl, size_t row, int irow, int h) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int slot = (2 * s + h) ^ ((irow >> 1) & 7);
+            hi[s] = *reinterpret_cast<const f16x8*>(ph + row * D + 8 * slot);
+            lo[s] = *reinterpret_cast<const f16x8*>(pl + row * D + 8 * slot);
+        }
+    }
+};
+
+// One 64-row tile of the swizzled ("column") side in LDS: [plane][64 rows][128 B].  Linear DMA of 2 x 8 KiB.
+constexpr int CT_PLANE = KT * 128;
+__device__ __forceinline__ void dma_col_tile(unsigned char* lds, const _Float16* gh, const _Float16* gl, size_t row0, int tid, int wave) {
+    const unsigned char* sh = reinterpret_cast<const unsigned char*>(gh + row0 * D) + tid * 16;
+    const unsigned char* sl = reinterpret_cast<const unsigned char*>(gl + row0 * D) + tid * 16;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        __builtin_amdgcn_global_load_lds((gptr_t)(sh + j * 4096), (lptr_t)(lds + j * 4096 + wave * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(sl + j * 4096), (lptr_t)(lds + CT_PLANE + j * 4096 + wave * 1024), 16, 0, 0);
+    }
+}
+
+// acc[ct] (32 tile columns x this wave's 32 rows, transposed: D[m = tile row 32 ct + ..][n = row i]) = x(col) . x(row)
+__device__ __forceinline__ void score_tile(f32x16 (&acc)[2], const unsigned char* lds, const RowFrags& rf, int l31, int h) {
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        f16x8 ch[2], cl[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const int row = 32 * ct + l31;
+            const int off = row * 128 + (((2 * s + h) ^ ((row >> 1) & 7)) * 16);
+            ch[ct] = *reinterpret_cast<const f16x8*>(lds + off);
+            cl[ct] = *reinterpret_cast<const f16x8*>(lds + CT_PLANE + off);
+        }
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[ct], rf.hi[s], acc[ct], 0, 0, 0);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[ct], rf.lo[s], acc[ct], 0, 0, 0);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cl[ct], rf.hi[s], acc[ct], 0, 0, 0);
+    }
+}
+
+// ---- k_rowstats: stat[z][i] = (max_j x_ij, sum_j 2^(x_ij - max)),  x = (a_i . b_j) * c1   (log2 domain)
+__global__ __launch_bounds__(256, 3) void k_rowstats(const _Float16* __restrict__ ah, const _Float16* __restrict__ al,
+                                                     const _Float16* __restrict__ bh, const _Float16* __restrict__ bl,
+                                                     int Z, int N, int Np, float c1, float2* __restrict__ stat) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * CT_PLANE];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    int z, Ib;
+    tile_coords(Np / 128, Z, z, Ib);
+    const int irow = Ib * 128 + 32 * wave + l31;
+    RowFrags rf;
+    rf.load(ah, al, (size_t)z * Np + irow, irow, h);
+    float m = NEG_HUGE, sum = 0.f;
+    const int ntile = Np / KT;
+    for (int jt = 0; jt < ntile; ++jt) {
+        __syncthreads();
+        dma_col_tile(lds, bh, bl, (size_t)z * Np + jt * KT, tid, wave);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        f32x16 acc[2];
+        score_tile(acc, lds, rf, l31, h);
+        const bool ragged = (jt + 1) * KT > N;                       // wave-uniform
+        float tm = NEG_HUGE;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float x = acc[ct][r] * c1;
+                if (ragged && jt * KT + 32 * ct + mfma32_row(r, h) >= N) x = NEG_HUGE;
+                acc[ct][r] = x;
+                tm = fmaxf(tm, x);
+            }
+        const float mn = fmaxf(m, tm);
+        float s = sum * __builtin_amdgcn_exp2f(m - mn);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += __builtin_amdgcn_exp2f(acc[ct][r] - mn);
+        m = mn;
+        sum = s;
+    }
+    // the two half-waves hold the two key halves of the same rows
+    const float mo = shfl_xor_f(m, 32), so = shfl_xor_f(sum, 32);
+    const float mn = fmaxf(m, mo);
+    const float st = sum * __builtin_amdgcn_exp2f(m - mn) + so * __builtin_amdgcn_exp2f(mo - mn);
+    if (h == 0 && irow < N) stat[(size_t)z * N + irow] = make_float2(mn, st);
+}
+
+// ---- k_prep_v: v~^T / colsum in LDS-image tiles: out[plane][z][jt][96 b][8 slots ^ ((b >> 1) & 7)][8 keys (permuted)]
+// position p = 8 g + e of a 32-key group holds key  16 (g >> 1) + 4 (g & 1) + (e < 4 ? e : e + 4)
+__global__ __launch_bounds__(256) void k_prep_v(const float* __restrict__ v, const float* __restrict__ pos,
+                                               const float2* __restrict__ colstat, int Z, int N, int Np,
+                                               _Float16* __restrict__ oh, _Float16* __restrict__ ol,
+                                               float* __restrict__ cmax) {
+    __shared__ float tile[KT][DV + 3];
+    const int ntile = Np / KT;
+    const int z = blockIdx.x / ntile, jt = blockIdx.x - z * ntile;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < KT * DV; i += 256) {
+        const int r = i / DV, c = i - r * DV;
+        const int j = jt * KT + r;
+        float x = 0.f;
+        if (j < N) {
+            x = c < D ? v[((size_t)z * N + j) * D + c] : pos[(size_t)j * 6 + (c - D)];
+            x = x / colstat[(size_t)z * N + j].y * V_PRESCALE;
+        }
+        tile[r][c] = x;
+    }
+    if (tid < KT) {                                      // dense column maxima; keys past N get +huge -> p = 0
+        const int j = jt * KT + tid;
+        cmax[(size_t)z * Np + j] = j < N ? colstat[(size_t)z * N + j].x : -NEG_HUGE;
+    }
+    __syncthreads();
+    const size_t base = ((size_t)z * ntile + jt) * DVP * KT;
+    for (int i = tid; i < DVP * 8; i += 256) {
+        const int b = i >> 3, slot = i & 7;                // slot = 4 ct + g
+        const int ct = slot >> 2, g = slot & 3;
+        f16x8 vh, vl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int key = 32 * ct + 16 * (g >> 1) + 4 * (g & 1) + (e < 4 ? e : e + 4);
+            const float x = b < DV ? tile[key][b] : 0.f;
+            _Float16 hh, ll;
+            split1(x, hh, ll);
+            vh[e] = hh; vl[e] = ll;
+        }
+        const size_t o = base + (size_t)b * KT + ((slot ^ ((b >> 1) & 7)) * 8);
+        *reinterpret_cast<f16x8*>(oh + o) = vh;
+        *reinterpret_cast<f16x8*>(ol + o) = vl;
+    }
+}
+
+// ---- k_pv: T[z][i][:] = (2^-15 / rowsum_i) * sum_j 2^(2 x_ij - rowmax_i - colmax_j + 15) * (v~_j / colsum_j)
+constexpr int VT_PLANE = DVP * 128;     // one v~^T tile plane: 96 rows x 64 keys fp16
+__global__ __launch_bounds__(256, 2) void k_pv(const _Float16* __restrict__ qh, const _Float16* __restrict__ ql,
+                                               const _Float16* __restrict__ kh, const _Float16* __restrict__ kl,
+                                               const _Float16* __restrict__ vh, const _Float16* __restrict__ vl,
+                                               const float2* __restrict__ rowstat, const float* __restrict__ cmax,
+                                               int Z, int N, int Np, float c1, float* __restrict__ T) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * CT_PLANE + 2 * VT_PLANE];
+    unsigned char* const ldv = lds + 2 * CT_PLANE;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    int z, Ib;
+    tile_coords(Np / 128, Z, z, Ib);
+    const int i0 = Ib * 128 + 32 * wave;
+    const int irow = i0 + l31;
+    RowFrags rf;
+    rf.load(qh, ql, (size_t)z * Np + irow, irow, h);
+    const float2 rst = irow < N ? rowstat[(size_t)z * N + irow] : make_float2(0.f, 1.f);
+    const float c2 = 2.0f * c1;
+    const float rterm = 15.0f - rst.x;
+
+    f32x16 tacc[3];
+#pragma unroll
+    for (int bt = 0; bt < 3; ++bt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tacc[bt][r] = 0.f;
+
+    const int ntile = Np / KT;
+    const unsigned char* vsrc_h = reinterpret_cast<const unsigned char*>(vh + (size_t)z * ntile * DVP * KT) + tid * 16;
+    const unsigned char* vsrc_l = reinterpret_cast<const unsigned char*>(vl + (size_t)z * ntile * DVP * KT) + tid * 16;
+    for (int jt = 0; jt < ntile; ++jt) {
+        __syncthreads();
+        dma_col_tile(lds, kh, kl, (size_t)z * Np + jt * KT, tid, wave);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(vsrc_h + (size_t)jt * VT_PLANE + j * 4096), (lptr_t)(ldv + j * 4096 + wave * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(vsrc_l + (size_t)jt * VT_PLANE + j * 4096), (lptr_t)(ldv + VT_PLANE + j * 4096 + wave * 1024), 16, 0, 0);
+        }
+        // column maxima of this lane's keys: j = jt*64 + 32 ct + 8 q + 4 h + (0..3)
+        float cm[2][16];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const float4 c = *reinterpret_cast<const float4*>(cmax + (size_t)z * Np + jt * KT + 32 * ct + 8 * q4 + 4 * h);
+                cm[ct][4 * q4 + 0] = c.x; cm[ct][4 * q4 + 1] = c.y; cm[ct][4 * q4 + 2] = c.z; cm[ct][4 * q4 + 3] = c.w;
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        f32x16 acc[2];
+        score_tile(acc, lds, rf, l31, h);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                // p for this lane's 8 keys of MFMA (ct, u): accumulator registers 8 u .. 8 u + 7
+                f16x8 ph, pl;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int r = 8 * u + e;
+                    const float pe = __builtin_amdgcn_exp2f(fmaf(acc[ct][r], c2, rterm) - cm[ct][r]);
+                    _Float16 hh, ll;
+                    split1(pe, hh, ll);
+                    ph[e] = hh; pl[e] = ll;
+                }
+                const int slot = 4 * ct + 2 * u + h;
+#pragma unroll
+                for (int bt = 0; bt < 3; ++bt) {
+                    const int b = 32 * bt + l31;
+                    const int off = b * 128 + ((slot ^ ((b >> 1) & 7)) * 16);
+                    const f16x8 bh = *reinterpret_cast<const f16x8*>(ldv + off);
+                    const f16x8 bl = *reinterpret_cast<const f16x8*>(ldv + VT_PLANE + off);
+                    tacc[bt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, bh, tacc[bt], 0, 0, 0);
+                    tacc[bt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, bl, tacc[bt], 0, 0, 0);
+                    tacc[bt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, bh, tacc[bt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- store: lane holds column b = 32 bt + l31 of rows i0 + mfma32_row(r, h); the row scale comes from lane (row)
+    const float oscale = (3.0517578125e-05f / V_PRESCALE) / rst.y;      // 2^-15 2^-6 / rowsum of this lane's row (= l31)
+#pragma unroll
+    for (int bt = 0; bt < 3; ++bt) {
+        const int b = 32 * bt + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rr = mfma32_row(r, h);
+            const float sc = __shfl(oscale, rr, 64);
+            const int i = i0 + rr;
+            if (b < DV && i < N) T[((size_t)z * N + i) * DV + b] = tacc[bt][r] * sc;
+        }
+    }
+}
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+struct EmmWs {
+    _Float16 *qh, *ql, *kh, *kl, *vh, *vl;
+    float2 *rowstat, *colstat;
+    float* cmax;
+    size_t bytes;
+};
+inline EmmWs carve(void* base, int Z, int N) {
+    const int Np = (N + 127) / 128 * 128;
+    unsigned char* p = (unsigned char*)base;
+    size_t o = 0;
+    auto take = [&](size_t n) { unsigned char* r = p ? p + o : nullptr; o += align256(n); return r; };
+    EmmWs w;
+    const size_t qk = (size_t)Z * Np * D * 2, vt = (size_t)Z * (Np / KT) * DVP * KT * 2, st = (size_t)Z * N * 8;
+    w.qh = (_Float16*)take(qk); w.ql = (_Float16*)take(qk); w.kh = (_Float16*)take(qk); w.kl = (_Float16*)take(qk);
+    w.vh = (_Float16*)take(vt); w.vl = (_Float16*)take(vt);
+    w.rowstat = (float2*)take(st); w.colstat = (float2*)take(st);
+    w.cmax = (float*)take((size_t)Z * Np * 4);
+    w.bytes = o;
+    return w;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t far_emm_pv_f16s_workspace_bytes(int Z, int N) {
+    if (Z <= 0 || N <= 0) return 0;
+    return carve(nullptr, Z, N).bytes;
+}
+
+// T[z] = P[z] @ [v[z] | pos], P = softmax over keys * softmax over queries of s = (q k^T) * scale  -- the whole K2
+// operator (statistics included) on split-fp16 operands.  q, k, v [Z][N][64], pos [N][6], T_out [Z][N][70] fp32;
+// ws: far_emm_pv_f16s_workspace_bytes(Z, N) bytes.
+int far_emm_pv_f16s(const float* q, const float* k, const float* v, const float* pos, int Z, int N, int Dh, float scale,
+                    void* ws, float* T_out, hipStream_t stream) {
+    far_clear_errors();
+    if (!q || !k || !v || !pos || !ws || !T_out || Z <= 0 || N <= 0 || Dh != D) return FAR_EINVAL;
+    const int Np = (N + 127) / 128 * 128;
+    const EmmWs w = carve(ws, Z, N);
+    const float c1 = scale * 1.44269504088896341f / (QK_PRESCALE * QK_PRESCALE);      // scores -> log2 domain
+    const unsigned gprep = (unsigned)(((long)Z * Np * 8 + 255) / 256 < 65536L * 4 ? ((long)Z * Np * 8 + 255) / 256 : 65536L * 4);
+    hipLaunchKernelGGL(k_prep_qk, dim3(gprep), dim3(256), 0, stream, q, Z, N, Np, w.qh, w.ql);
+    hipLaunchKernelGGL(k_prep_qk, dim3(gprep), dim3(256), 0, stream, k, Z, N, Np, w.kh, w.kl);
+    const dim3 grid((unsigned)(Np / 128) * Z);
+    // softmax over keys (rows = queries), then over queries (rows = keys): the same kernel with the sides swapped
+    hipLaunchKernelGGL(k_rowstats, grid, dim3(256), 0, stream, w.qh, w.ql, w.kh, w.kl, Z, N, Np, c1, w.rowstat);
+    hipLaunchKernelGGL(k_rowstats, grid, dim3(256), 0, stream, w.kh, w.kl, w.qh, w.ql, Z, N, Np, c1, w.colstat);
+    hipLaunchKernelGGL(k_prep_v, dim3((unsigned)(Np / KT) * Z), dim3(256), 0, stream, v, pos, w.colstat, Z, N, Np, w.vh, w.vl, w.cmax);
+    hipLaunchKernelGGL(k_pv, grid, dim3(256), 0, stream, w.qh, w.ql, w.kh, w.kl, w.vh, w.vl, w.rowstat, w.cmax, Z, N,
+                       Np, c1, T_out);
+    return far_check_launch();
+}
+
+}  // extern "C"

@@ -84,16 +84,23 @@ def coarse_match(f0, f1, temperature, thr, border, hw0, hw1, cell_scale, mask0=N
     }
 
 
-def emm_bilinear(q, k, v, pos, scale):
+def emm_bilinear(q, k, v, pos, scale, exact_f32=False):
     """K2.  q, k, v: (Z, N, 64) fp32; pos: (N, 6).  Returns F (Z, 70, 70) = v~^T (P v~), v~ = [v | pos],
-    P = softmax(s, -1) * softmax(s, -2), s = (q k^T) * scale   (transformer.py:275-292)."""
+    P = softmax(s, -1) * softmax(s, -2), s = (q k^T) * scale   (transformer.py:275-292).
+    Default: split-fp16 operands on the f16 matrix cores (fp32-grade); exact_f32: the exact-f32 MFMA kernels."""
     lib = _lib.load()
     Z, N, D = q.shape
-    rowstat, colstat = dual_softmax_stats(q, k, 1.0, 1.0, scale)
     T = torch.empty(Z, N, 70, dtype=torch.float32, device=q.device)
-    rc = lib.far_emm_pv_f32(_p(q, torch.float32), _p(k, torch.float32), _p(v, torch.float32), _p(pos, torch.float32),
-                            Z, N, D, float(scale), _p(rowstat), _p(colstat), _p(T), _stream())
-    _lib.check(rc, 'far_emm_pv_f32')
+    if exact_f32:
+        rowstat, colstat = dual_softmax_stats(q, k, 1.0, 1.0, scale)
+        rc = lib.far_emm_pv_f32(_p(q, torch.float32), _p(k, torch.float32), _p(v, torch.float32), _p(pos, torch.float32),
+                                Z, N, D, float(scale), _p(rowstat), _p(colstat), _p(T), _stream())
+        _lib.check(rc, 'far_emm_pv_f32')
+    else:
+        ws = _ws(lib.far_emm_pv_f16s_workspace_bytes(Z, N), q.device)
+        rc = lib.far_emm_pv_f16s(_p(q, torch.float32), _p(k, torch.float32), _p(v, torch.float32), _p(pos, torch.float32),
+                                 Z, N, D, float(scale), _p(ws), _p(T), _stream())
+        _lib.check(rc, 'far_emm_pv_f16s')
     vt = torch.cat([v, pos.unsqueeze(0).expand(Z, -1, -1)], dim=2)  # (Z, N, 70)
     return torch.bmm(vt.transpose(1, 2), T), T
 

@@ -90,6 +90,13 @@ int far_coarse_match_bf16(const float* f0, const float* f1, int Z, int L, int S,
 int far_emm_pv_f32(const float* q, const float* k, const float* v, const float* pos, int Z, int N, int D,
                    float scale, const float* rowstat, const float* colstat, float* T_out, far_stream_t stream);
 
+/* The whole K2 operator (softmax statistics included) on the f16 matrix cores with split-precision operands
+ * (fp32 tensors, hi + lo fp16 pairs, three MFMAs per product, fp32 accumulation: fp32-grade).  Same inputs / output
+ * as far_emm_pv_f32; ws: far_emm_pv_f16s_workspace_bytes(Z, N) bytes of scratch. */
+size_t far_emm_pv_f16s_workspace_bytes(int Z, int N);
+int far_emm_pv_f16s(const float* q, const float* k, const float* v, const float* pos, int Z, int N, int D, float scale,
+                    void* ws, float* T_out, far_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * K3  fine level: window gather + sub-pixel expectation
  * replaces src/loftr/loftr_module/fine_preprocess.py:40-47 (F.unfold + [b_ids, i_ids] gather)

@@ -1,4 +1,5 @@
-"""K2 parity on the GPU: far_emm_pv_f32 (+ stats) through the C ABI vs oracle/head.py."""
+"""K2 parity on the GPU: far_emm_pv_f16s (split-fp16 operands, the default) and far_emm_pv_f32 (+ stats, exact-f32
+MFMA) through the C ABI vs oracle/head.py."""
 import numpy as np
 import pytest
 import torch
@@ -16,12 +17,13 @@ def _inputs(Z, N, seed, qk_amp=2.0):
     return q, k, v, pos
 
 
-@pytest.mark.parametrize('Z,N', [(3, 192), (2, 221), (1, 4800)])
-def test_emm_bilinear(Z, N):
+@pytest.mark.parametrize('exact_f32', [False, True])
+@pytest.mark.parametrize('Z,N', [(3, 192), (2, 221), (8, 64), (1, 4800)])
+def test_emm_bilinear(Z, N, exact_f32):
     from far_amd import ops
     from oracle import head as oh
     q, k, v, pos = _inputs(Z, N, seed=N)
-    F, T = ops.emm_bilinear(*(torch.from_numpy(a).cuda() for a in (q, k, v, pos)), 0.125)
+    F, T = ops.emm_bilinear(*(torch.from_numpy(a).cuda() for a in (q, k, v, pos)), 0.125, exact_f32=exact_f32)
     torch.cuda.synchronize()
     vt = np.concatenate([v, np.broadcast_to(pos, (Z, N, 6))], axis=2)
     Fref, A = oh.bilinear_attention(q, k, vt, 0.125, dtype=np.float64)
@@ -32,3 +34,15 @@ def test_emm_bilinear(Z, N):
     F32, _ = oh.bilinear_attention(q, k, vt, 0.125, dtype=np.float32)
     print('max|F - f64| / max|F| =', np.abs(F.cpu().numpy() - Fref).max() / np.abs(Fref).max(),
           ' fp32-restatement vs f64:', np.abs(F32 - Fref).max() / np.abs(Fref).max())
+
+
+def test_emm_variants_agree_on_peaked_scores():
+    """Large score range (|s| up to ~60): the one-exp formulation of the split variant must not under/overflow."""
+    from far_amd import ops
+    q, k, v, pos = _inputs(2, 320, seed=5, qk_amp=6.0)
+    t = [torch.from_numpy(a).cuda() for a in (q, k, v, pos)]
+    Fa, Ta = ops.emm_bilinear(*t, 0.125)
+    Fb, Tb = ops.emm_bilinear(*t, 0.125, exact_f32=True)
+    assert torch.isfinite(Ta).all()
+    torch.testing.assert_close(Ta, Tb, atol=2e-5 * float(Tb.abs().max()), rtol=1e-4)
+    torch.testing.assert_close(Fa, Fb, atol=1e-4 * float(Fb.abs().max()), rtol=1e-3)
