@@ -89,21 +89,30 @@ def kernel_rooflines(n_pairs):
     k = torch.randn(Z, L, 64, device=dev, generator=g)
     v = torch.randn(Z, L, 64, device=dev, generator=g)
     pos = torch.rand(L, 6, device=dev, generator=g)
-    t3 = event_time_ms(lambda: ops.dual_softmax_stats(q, k, 1.0, 1.0, 0.125), iters=3, warm=1)
-    fl3 = 2.0 * L * L * 64 * Z
-    out['k_stats_f32[K2]'] = dict(ms=t3, tflops=fl3 / t3 / 1e9, frac=fl3 / t3 / 1e9 / F32_MFMA_PEAK_TFLOPS)
-    rs, cs = ops.dual_softmax_stats(q, k, 1.0, 1.0, 0.125)
     T = torch.empty(Z, L, 70, device=dev)
     from far_amd import _lib
     lib = _lib.load()
     import ctypes
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    fl4 = (2.0 * L * L * 64 + 2.0 * L * L * 70) * Z
+    ws = torch.empty(lib.far_emm_pv_f16s_workspace_bytes(Z, L), dtype=torch.uint8, device=dev)
+
+    def pv16():
+        lib.far_emm_pv_f16s(q.data_ptr(), k.data_ptr(), v.data_ptr(), pos.data_ptr(), Z, L, 64, ctypes.c_float(0.125),
+                            ws.data_ptr(), T.data_ptr(), st)
+    t5 = event_time_ms(pv16, iters=3, warm=1)
+    out['far_emm_pv_f16s[K2 all passes, split-fp16]'] = dict(ms=t5, tflops=fl4 / t5 / 1e9, frac=fl4 / t5 / 1e9 / F16_MFMA_PEAK_TFLOPS)
+    del ws
+    t3 = event_time_ms(lambda: ops.dual_softmax_stats(q, k, 1.0, 1.0, 0.125), iters=3, warm=1)
+    fl3 = 2.0 * L * L * 64 * Z
+    out['k_stats_f32[K2, exact-f32 variant]'] = dict(ms=t3, tflops=fl3 / t3 / 1e9, frac=fl3 / t3 / 1e9 / F32_MFMA_PEAK_TFLOPS)
+    rs, cs = ops.dual_softmax_stats(q, k, 1.0, 1.0, 0.125)
 
     def pv():
         lib.far_emm_pv_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), pos.data_ptr(), Z, L, 64, ctypes.c_float(0.125),
-                           rs.data_ptr(), cs.data_ptr(), T.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+                           rs.data_ptr(), cs.data_ptr(), T.data_ptr(), st)
     t4 = event_time_ms(pv, iters=3, warm=1)
-    fl4 = (2.0 * L * L * 64 + 2.0 * L * L * 70) * Z
-    out['k_emm_pv_f32[K2]'] = dict(ms=t4, tflops=fl4 / t4 / 1e9, frac=fl4 / t4 / 1e9 / F32_MFMA_PEAK_TFLOPS)
+    out['k_emm_pv_f32[K2, exact-f32 variant]'] = dict(ms=t4, tflops=fl4 / t4 / 1e9, frac=fl4 / t4 / 1e9 / F32_MFMA_PEAK_TFLOPS)
     del q, k, v, T
     # K9: split-fp16 implicit GEMM.  tflops = ALGORITHMIC convolution flops (2 N H W Cin Cout 9) / time, priced
     # against the dense f16 MFMA peak; the kernel issues three MFMAs per fp32-grade product, so its matrix-pipe

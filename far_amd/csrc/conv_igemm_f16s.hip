@@ -154,37 +154,50 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const f32x16 (&
                                               int cout_w, int wm, int l31, int h) {
     const float* __restrict__ resp = p.res;
     float* __restrict__ yp = p.y;
+    // Accumulator register r of a lane covers tile pixel  row (r >> 3), column (r & 3) + 8 ((r >> 2) & 1) + 4 h  of
+    // its 2 x 16 pixel MFMA tile (32 consecutive pixels in GEMM mode): 32-bit offsets from one 64-bit base per tile.
+    const int rowstep = (KS == 1 ? 16 : p.Wo) * p.Csub;
 #pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) {
-        const int co = cout_w + 32 * nt + l31;
-        if (co >= p.Cout) continue;
-        const float sc = p.scale[co], sh = p.shift ? p.shift[co] : 0.f;
-        const int plane = co / p.Csub;
-        const long cbase = (long)plane * p.npix * p.Csub + (co - plane * p.Csub);
+    for (int mt = 0; mt < 2; ++mt) {
+        const int mtile = 2 * wm + mt;
+        long pix0;                       // first pixel of the tile
+        int nrow, ncol;                  // valid tile rows / columns
+        if (KS == 1) {
+            pix0 = tp.pix0 + 32 * mtile;
+            const long left = p.npix - pix0;
+            nrow = left >= 32 ? 2 : (left > 16 ? 2 : (left > 0 ? 1 : 0));
+            ncol = left >= 32 ? 16 : -1;                               // -1: ragged, test the linear index instead
+        } else {
+            const int oy = tp.oy0 + 2 * mtile;
+            pix0 = ((long)tp.img * p.Ho + oy) * p.Wo + tp.ox0;
+            nrow = p.Ho - oy;
+            ncol = p.Wo - tp.ox0;
+        }
+        const long left = KS == 1 ? p.npix - pix0 : 0;
+        int delta[16];
+        bool ok[16];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const int mtile = 2 * wm + mt;
-            long off[16];
+        for (int r = 0; r < 16; ++r) {
+            const int trow = r >> 3, tcol = (r & 3) + 8 * ((r >> 2) & 1) + 4 * h;
+            delta[r] = trow * rowstep + tcol * p.Csub;
+            ok[r] = (KS == 1 && ncol < 0) ? (16 * trow + tcol < left) : (trow < nrow && tcol < ncol);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const int co = cout_w + 32 * nt + l31;
+            if (co >= p.Cout) continue;
+            const float sc = p.scale[co], sh = p.shift ? p.shift[co] : 0.f;
+            const int plane = co / p.Csub;
+            const long base = (long)plane * p.npix * p.Csub + pix0 * p.Csub + (co - plane * p.Csub);
             float rv[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int prow = mfma32_row(r, h);
-                off[r] = -1;
-                if (KS == 1) {
-                    const long pix = tp.pix0 + 32 * mtile + prow;
-                    if (pix < p.npix) off[r] = pix * p.Csub + cbase;
-                } else {
-                    const int oy = tp.oy0 + 2 * mtile + (prow >> 4), ox = tp.ox0 + (prow & 15);
-                    if (oy < p.Ho && ox < p.Wo) off[r] = (((long)tp.img * p.Ho + oy) * p.Wo + ox) * p.Csub + cbase;
-                }
-                rv[r] = (resp && off[r] >= 0) ? resp[off[r]] : 0.f;
-            }
+            for (int r = 0; r < 16; ++r) rv[r] = (resp && ok[r]) ? resp[base + delta[r]] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float v = acc[mt][nt][r] * sc + sh + rv[r];
                 if (p.act == 1) v = fmaxf(v, 0.f);
                 else if (p.act == 2) v = v > 0.f ? v : v * p.slope;
-                if (off[r] >= 0) yp[off[r]] = v;
+                if (ok[r]) yp[base + delta[r]] = v;
             }
         }
     }
