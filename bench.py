@@ -261,7 +261,7 @@ def main():
             'value': round(world * a.pairs * a.steps / dt, 3), 'unit': 'image-pairs/sec',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(1000 * dt / a.steps, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32' if a.precision == 'fp32' else f'f32 kernels + {a.precision} convolutions', 'data': 'synthetic',
+            'dtype': 'f32' if a.precision == 'fp32' else f'f32 tensors/accumulation, {a.precision} matrix operands', 'data': 'synthetic',
             'config': {'workload': 'Matterport3D-shaped eval (BASELINE configs[1]): batch 32 pairs @ 640x480 per GPU, '
                                    'LoFTR match + 8-pt prior-RANSAC solve (x2 rounds) + EMM head (x2), seeded random weights',
                        'pairs_per_gpu': a.pairs, 'hypotheses': a.hyp, 'fine_pred_steps': 2,

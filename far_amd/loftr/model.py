@@ -79,13 +79,18 @@ class LoFTR(nn.Module):
           'fp32'      K9 with split-fp16 operand pairs: fp32-grade -- the parity configuration (default);
           'fp16-fine' split trunk + plain-fp16 operands in the FPN branch: coarse features and match decisions stay
                       bit-identical, only the sub-pixel refinement input changes;
-          'fp16'      plain fp16 operands everywhere in K9 (fp32 accumulation, fp32 activations);
+          'fp16'      plain fp16 operands everywhere in K9 -- backbone and the encoder layers' Linear layers (fp32
+                      accumulation, fp32 activations): the 16-bit-operand configuration of BASELINE configs[1];
           'bf16'      the vendor convolutions under bf16 autocast (reference-style modules), channels_last."""
         if mode not in self.PRECISIONS:
             raise ValueError(f'precision must be one of {self.PRECISIONS}')
         self.backbone_dtype = torch.bfloat16 if mode == 'bf16' else torch.float32
         self.backbone.trunk_split = mode in ('fp32', 'fp16-fine')
         self.backbone.fpn_split = mode == 'fp32'
+        from .transformer import LoFTREncoderLayer
+        for m in self.modules():
+            if isinstance(m, LoFTREncoderLayer):
+                m.split_operands = mode != 'fp16'
         return self
 
     # -------------------------------------------------------------------------------------------------

@@ -44,6 +44,8 @@ class LinearAttention(nn.Module):
 
 
 class LoFTREncoderLayer(nn.Module):
+    split_operands = True        # K9 operand precision of the Linear layers (False: plain fp16, LoFTR.set_precision)
+
     def __init__(self, d_model, nhead, attention='linear', use_num_corres=False):
         super().__init__()
         if attention != 'linear':
@@ -76,8 +78,9 @@ class LoFTREncoderLayer(nn.Module):
         # inference: the five Linear layers on K9 (split-fp16 operands: fp32-grade, and -- unlike a vendor GEMM whose
         # kernel is chosen by the row count -- every output row depends on its input row only)
         pk = self.__dict__.setdefault('_packs', ops.PackCache())
-        lin = lambda name, *mods: pk.get(name, [m.weight for m in mods],
-                                         lambda: ops.PackedConv(torch.cat([m.weight for m in mods], 0)))
+        sp = self.split_operands
+        lin = lambda name, *mods: pk.get((name, sp), [m.weight for m in mods],
+                                         lambda: ops.PackedConv(torch.cat([m.weight for m in mods], 0), split=sp))
         x = x.contiguous()
         heads = lambda t: t.view(bs, -1, self.nhead, self.dim)
         fuse = self.nhead * self.dim >= 256     # measured: fusing pays at d_model 256 (wide tiles), not at 128

@@ -202,3 +202,33 @@ def test_linear_output_planes():
         assert y.shape == (P, 2, 301, Csub) and y.is_contiguous()
         ref = (x.double() @ w.double().t()).view(2, 301, P, Csub).permute(2, 0, 1, 3)
         assert _rel(y, ref)[0] < 4e-6
+
+
+def test_pack_cache_follows_weight_updates():
+    """The packed K9 images are rebuilt when a parameter or BatchNorm buffer changes in place (optimizer step,
+    load_state_dict): the fused backbone must track its reference-style modules after every kind of update."""
+    from far_amd.config import far_eval_config
+    from far_amd.loftr.backbone import build_backbone
+    torch.manual_seed(1)
+    bb = build_backbone(far_eval_config()).cuda().eval()
+    ref = build_backbone(far_eval_config()).cuda().eval().double()
+    x = torch.rand(1, 1, 64, 96, device='cuda')
+
+    def check():
+        ref.load_state_dict({k: v.double() for k, v in bb.state_dict().items()})
+        with torch.no_grad():
+            c, f = bb(x)
+            cr, fr = ref(x.double())
+        assert _rel(c, cr)[0] < 2e-5 and _rel(f, fr)[0] < 2e-5
+
+    check()
+    with torch.no_grad():
+        c0 = bb(x)[0].clone()
+        bb.layer1[0].conv1.weight.mul_(1.5)                     # in-place parameter update
+        bb.layer2[1].bn2.running_var.add_(0.3)                   # buffer update (folded into the epilogue vectors)
+    check()
+    with torch.no_grad():
+        assert not torch.equal(bb(x)[0], c0)
+        sd = {k: v * (1.1 if k.endswith('layer3_outconv.weight') else 1.0) for k, v in bb.state_dict().items()}
+    bb.load_state_dict(sd)                                       # copy_ into the same storage: version bump
+    check()
