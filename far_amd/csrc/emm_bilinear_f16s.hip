@@ -33,13 +33,27 @@ constexpr float QK_PRESCALE = 16.0f;     // q, k scaled by 2^4 before the split 
 constexpr float V_PRESCALE = 64.0f;      // v~ / colsum scaled by 2^6; p by 2^15 (it is <= 1)
 constexpr float NEG_HUGE = -1.0e30f;
 
+// Where problem z = p * heads + hh of a [Z][N][64] operand lives: base + hh * head_stride + ((p + rot) % P) * prob_stride
+// (floats; P = Z / heads).  Contiguous [Z][N][64]: heads = 1, prob_stride = N * 64.  The head's fused q | k | v
+// projection writes per-(tensor, head) planes [2B][N][64]: heads = 4, head_stride = 2B N 64, prob_stride = N 64, and
+// the query side of direction d is image 1 - d: rot = B.
+struct ZLayout {
+    int heads, P, rot;
+    long head_stride, prob_stride;
+    __device__ __forceinline__ size_t base(long z) const {
+        const long pz = z / heads;
+        const int hh = (int)(z - pz * heads);
+        return (size_t)hh * head_stride + (size_t)((pz + rot) % P) * prob_stride;
+    }
+};
+
 __device__ __forceinline__ void split1(float x, _Float16& hi, _Float16& lo) {
     hi = (_Float16)x;
     lo = (_Float16)(x - (float)hi);
 }
 
 // ---- k_prep_qk: x [Z][N][64] fp32 -> hi / lo [Z][Np][64] fp16 (rows >= N zero), 16-byte slot ^= (row >> 1) & 7
-__global__ void k_prep_qk(const float* __restrict__ x, int Z, int N, int Np, _Float16* __restrict__ hi, _Float16* __restrict__ lo) {
+__global__ void k_prep_qk(const float* __restrict__ x, ZLayout lay, int Z, int N, int Np, _Float16* __restrict__ hi, _Float16* __restrict__ lo) {
     const long total = (long)Z * Np * 8;
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
         const int slot = (int)(t & 7);
@@ -48,8 +62,9 @@ __global__ void k_prep_qk(const float* __restrict__ x, int Z, int N, int Np, _Fl
         const long z = row / Np;
         f16x8 vh, vl;
         if (i < N) {
-            const float4 a = *reinterpret_cast<const float4*>(x + ((size_t)z * N + i) * D + slot * 8);
-            const float4 b = *reinterpret_cast<const float4*>(x + ((size_t)z * N + i) * D + slot * 8 + 4);
+            const float* src = x + lay.base(z) + (size_t)i * D + slot * 8;
+            const float4 a = *reinterpret_cast<const float4*>(src);
+            const float4 b = *reinterpret_cast<const float4*>(src + 4);
             const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
             for (int e = 0; e < 8; ++e) { _Float16 h, l; split1(v[e] * QK_PRESCALE, h, l); vh[e] = h; vl[e] = l; }
@@ -163,7 +178,7 @@ __global__ __launch_bounds__(256, 3) void k_rowstats(const _Float16* __restrict_
 
 // ---- k_prep_v: v~^T / colsum in LDS-image tiles: out[plane][z][jt][96 b][8 slots ^ ((b >> 1) & 7)][8 keys (permuted)]
 // position p = 8 g + e of a 32-key group holds key  16 (g >> 1) + 4 (g & 1) + (e < 4 ? e : e + 4)
-__global__ __launch_bounds__(256) void k_prep_v(const float* __restrict__ v, const float* __restrict__ pos,
+__global__ __launch_bounds__(256) void k_prep_v(const float* __restrict__ v, ZLayout lay, const float* __restrict__ pos,
                                                const float2* __restrict__ colstat, int Z, int N, int Np,
                                                _Float16* __restrict__ oh, _Float16* __restrict__ ol,
                                                float* __restrict__ cmax) {
@@ -176,7 +191,7 @@ __global__ __launch_bounds__(256) void k_prep_v(const float* __restrict__ v, con
         const int j = jt * KT + r;
         float x = 0.f;
         if (j < N) {
-            x = c < D ? v[((size_t)z * N + j) * D + c] : pos[(size_t)j * 6 + (c - D)];
+            x = c < D ? v[lay.base(z) + (size_t)j * D + c] : pos[(size_t)j * 6 + (c - D)];
             x = x / colstat[(size_t)z * N + j].y * V_PRESCALE;
         }
         tile[r][c] = x;
@@ -331,23 +346,30 @@ size_t far_emm_pv_f16s_workspace_bytes(int Z, int N) {
 }
 
 // T[z] = P[z] @ [v[z] | pos], P = softmax over keys * softmax over queries of s = (q k^T) * scale  -- the whole K2
-// operator (statistics included) on split-fp16 operands.  q, k, v [Z][N][64], pos [N][6], T_out [Z][N][70] fp32;
+// operator (statistics included) on split-fp16 operands.  pos [N][6], T_out [Z][N][70] fp32; q, k, v: problem
+// z = p * heads + hh starts at  ptr + hh * head_stride + p' * prob_stride  floats and is [N][64] contiguous, with
+// p' = p for k, v and (p + q_rot) mod (Z / heads) for q  (contiguous [Z][N][64]: heads = 1, prob_stride = 64 N, q_rot = 0);
 // ws: far_emm_pv_f16s_workspace_bytes(Z, N) bytes.
 int far_emm_pv_f16s(const float* q, const float* k, const float* v, const float* pos, int Z, int N, int Dh, float scale,
-                    void* ws, float* T_out, hipStream_t stream) {
+                    int heads, long head_stride, long prob_stride, int q_rot, void* ws, float* T_out,
+                    hipStream_t stream) {
     far_clear_errors();
-    if (!q || !k || !v || !pos || !ws || !T_out || Z <= 0 || N <= 0 || Dh != D) return FAR_EINVAL;
+    if (!q || !k || !v || !pos || !ws || !T_out || Z <= 0 || N <= 0 || Dh != D || heads < 1 || Z % heads || q_rot < 0 ||
+        q_rot >= Z / heads)
+        return FAR_EINVAL;
+    const ZLayout lay{heads, Z / heads, 0, head_stride, prob_stride};
+    const ZLayout layq{heads, Z / heads, q_rot, head_stride, prob_stride};
     const int Np = (N + 127) / 128 * 128;
     const EmmWs w = carve(ws, Z, N);
     const float c1 = scale * 1.44269504088896341f / (QK_PRESCALE * QK_PRESCALE);      // scores -> log2 domain
     const unsigned gprep = (unsigned)(((long)Z * Np * 8 + 255) / 256 < 65536L * 4 ? ((long)Z * Np * 8 + 255) / 256 : 65536L * 4);
-    hipLaunchKernelGGL(k_prep_qk, dim3(gprep), dim3(256), 0, stream, q, Z, N, Np, w.qh, w.ql);
-    hipLaunchKernelGGL(k_prep_qk, dim3(gprep), dim3(256), 0, stream, k, Z, N, Np, w.kh, w.kl);
+    hipLaunchKernelGGL(k_prep_qk, dim3(gprep), dim3(256), 0, stream, q, layq, Z, N, Np, w.qh, w.ql);
+    hipLaunchKernelGGL(k_prep_qk, dim3(gprep), dim3(256), 0, stream, k, lay, Z, N, Np, w.kh, w.kl);
     const dim3 grid((unsigned)(Np / 128) * Z);
     // softmax over keys (rows = queries), then over queries (rows = keys): the same kernel with the sides swapped
     hipLaunchKernelGGL(k_rowstats, grid, dim3(256), 0, stream, w.qh, w.ql, w.kh, w.kl, Z, N, Np, c1, w.rowstat);
     hipLaunchKernelGGL(k_rowstats, grid, dim3(256), 0, stream, w.kh, w.kl, w.qh, w.ql, Z, N, Np, c1, w.colstat);
-    hipLaunchKernelGGL(k_prep_v, dim3((unsigned)(Np / KT) * Z), dim3(256), 0, stream, v, pos, w.colstat, Z, N, Np, w.vh, w.vl, w.cmax);
+    hipLaunchKernelGGL(k_prep_v, dim3((unsigned)(Np / KT) * Z), dim3(256), 0, stream, v, lay, pos, w.colstat, Z, N, Np, w.vh, w.vl, w.cmax);
     hipLaunchKernelGGL(k_pv, grid, dim3(256), 0, stream, w.qh, w.ql, w.kh, w.kl, w.vh, w.vl, w.rowstat, w.cmax, Z, N,
                        Np, c1, T_out);
     return far_check_launch();

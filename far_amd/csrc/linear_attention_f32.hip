@@ -170,10 +170,12 @@ int launch_la(const float* q, const float* k, const float* v, int N, int L, int 
     float* part = ws;
     float* kv = ws + (size_t)N * nchunk * per_n;
     long units = (long)N * nchunk * H;
+    // a single chunk (short sequences, e.g. the 25-token fine windows) IS the reduced result: write it in place
     hipLaunchKernelGGL(k_la_kv_partial<D>, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, stream, k, v, kv_mask, N, S, H,
-                       tok_per_chunk, nchunk, part);
-    hipLaunchKernelGGL(k_la_kv_reduce, dim3((int)((per_n + 255) / 256) * N), dim3(256), 0, stream, part, nchunk,
-                       (int)per_n, kv);
+                       tok_per_chunk, nchunk, nchunk == 1 ? kv : part);
+    if (nchunk > 1)
+        hipLaunchKernelGGL(k_la_kv_reduce, dim3((int)((per_n + 255) / 256) * N), dim3(256), 0, stream, part, nchunk,
+                           (int)per_n, kv);
     const int ntile = (L + D - 1) / D;
     int tiles_per_unit = ntile >= 64 ? 8 : ntile;
     int nblk = (ntile + tiles_per_unit - 1) / tiles_per_unit;

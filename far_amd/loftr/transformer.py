@@ -182,19 +182,26 @@ class CrossAttention(nn.Module):
     def forward(self, x1, x2, intrinsics=None, loftr_preds=None, inv_loftr_preds=None):
         B, N, C = x1.shape
         h, d = self.num_heads, C // self.num_heads
-        # (2, B, N, 3, h, d) -> (3, 2, B, h, N, d): one packed copy feeds both directions of K2
-        qkv = self.qkv(torch.stack([x1, x2], 0)).reshape(2, B, N, 3, h, d).permute(3, 0, 1, 4, 2, 5).contiguous()
-        q, k, v = qkv[0], qkv[1], qkv[2]                           # each (2, B, h, N, d); index 0 = image 1
-        # direction 1: attn_1 = q2 k1^T, contracted with v1 (:275,:291); direction 2: q1 k2^T with v2 (:276,:292)
-        qq = torch.stack([q[1], q[0]], 0).reshape(2 * B * h, N, d)
-        kk = k.reshape(2 * B * h, N, d)
-        vv = v.reshape(2 * B * h, N, d)
         if self.pos6.shape[0] != N:
             raise ValueError(f'the head is tied to a 60x80 coarse grid (N=4800), got N={N} (transformer.py:194)')
-        if ag.needs_grad(qq, kk, vv):
-            F = ag.bilinear_attention(qq, kk, vv, self.pos6, self.scale)
+        if ag.needs_grad(x1, x2, self.qkv.weight) or not x1.is_cuda:
+            # (2, B, N, 3, h, d) -> (3, 2, B, h, N, d): one packed copy feeds both directions
+            qkv = self.qkv(torch.stack([x1, x2], 0)).reshape(2, B, N, 3, h, d).permute(3, 0, 1, 4, 2, 5).contiguous()
+            q, k, v = qkv[0], qkv[1], qkv[2]                           # each (2, B, h, N, d); index 0 = image 1
+            # direction 1: attn_1 = q2 k1^T, contracted with v1 (:275,:291); direction 2: q1 k2^T with v2 (:276,:292)
+            qq = torch.stack([q[1], q[0]], 0).reshape(2 * B * h, N, d)
+            F = ag.bilinear_attention(qq, k.reshape(2 * B * h, N, d), v.reshape(2 * B * h, N, d), self.pos6, self.scale)
         else:
-            F, _ = ops.emm_bilinear(qq, kk, vv, self.pos6, self.scale)  # (2Bh, 70, 70)
+            # inference: the qkv Linear on K9 with one output plane per (tensor, head) -- the layout K2 reads in place
+            pk = self.__dict__.setdefault('_packs', ops.PackCache())
+            ts = [self.qkv.weight] + ([self.qkv.bias] if self.qkv.bias is not None else [])
+            pc = pk.get('qkv', ts, lambda: ops.PackedConv(self.qkv.weight, None, self.qkv.bias))
+            # the two images are the two halves of one (2B, N, C) buffer when they come from CrossBlock: no copy
+            adjacent = (x1.is_contiguous() and x2.is_contiguous() and
+                        x2.data_ptr() == x1.data_ptr() + x1.numel() * x1.element_size())
+            x12 = torch.as_strided(x1, (2, B, N, C), (B * N * C, N * C, C, 1)) if adjacent else torch.stack([x1, x2], 0)
+            planes = ops.linear_f16s(x12.reshape(2 * B, N, C), pc, out_planes=3 * h)     # (3h, 2B, N, d)
+            F, _ = ops.emm_bilinear_planes(planes, self.pos6, self.scale, B)             # (2Bh, 70, 70)
         F = F.view(2, B, h, d + 6, d + 6)
         # raw reshape of (B, h, 70, 70) to (B, 280, 70), then transpose (:294-295)
         f1 = F[0].reshape(B, C + 6 * h, (C + 6 * h) // h).transpose(-2, -1)
@@ -237,10 +244,11 @@ class CrossBlock(nn.Module):
         x = x + self.pos_embed
         x1_in, x2_in = x[:B], x[B:]           # == x.reshape(-1, 2, h_w, nf)[:, 0/1] for the reference's B = 1
         if ag.needs_grad(x, self.norm1.weight):
-            n1 = self.norm1
-        else:
-            n1 = lambda t: ops.layernorm(t.contiguous(), self.norm1.weight, self.norm1.bias, self.norm1.eps)
-        f1, f2 = self.cross_attn(n1(x1_in), n1(x2_in), intrinsics=intrinsics,
+            n1_1, n1_2 = self.norm1(x1_in), self.norm1(x2_in)
+        else:                                 # one LayerNorm launch over both images; the halves stay adjacent
+            n = ops.layernorm(x.contiguous(), self.norm1.weight, self.norm1.bias, self.norm1.eps)
+            n1_1, n1_2 = n[:B], n[B:]
+        f1, f2 = self.cross_attn(n1_1, n1_2, intrinsics=intrinsics,
                                  loftr_preds=loftr_preds, inv_loftr_preds=inv_loftr_preds)
         f = torch.cat([f1.unsqueeze(1), f2.unsqueeze(1)], dim=1).reshape(b_s, -1, nf)
         return f + self.mlp(self.norm2(f))

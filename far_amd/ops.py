@@ -99,9 +99,30 @@ def emm_bilinear(q, k, v, pos, scale, exact_f32=False):
     else:
         ws = _ws(lib.far_emm_pv_f16s_workspace_bytes(Z, N), q.device)
         rc = lib.far_emm_pv_f16s(_p(q, torch.float32), _p(k, torch.float32), _p(v, torch.float32), _p(pos, torch.float32),
-                                 Z, N, D, float(scale), _p(ws), _p(T), _stream())
+                                 Z, N, D, float(scale), 1, 0, N * D, 0, _p(ws), _p(T), _stream())
         _lib.check(rc, 'far_emm_pv_f16s')
     vt = torch.cat([v, pos.unsqueeze(0).expand(Z, -1, -1)], dim=2)  # (Z, N, 70)
+    return torch.bmm(vt.transpose(1, 2), T), T
+
+
+def emm_bilinear_planes(qkv, pos, scale, B):
+    """K2 on the output of the head's fused q | k | v projection: qkv (12, 2B, N, 64) = (tensor t, head) planes of
+    [image, pair][N][64] (ops.linear_f16s(..., out_planes=12)).  Problem z = (direction, pair, head); direction d pairs
+    the queries of image 1 - d with the keys / values of image d (transformer.py:275-276, 291-292).
+    Returns F (2 B h, 70, 70), T."""
+    lib = _lib.load()
+    P12, P, N, D = qkv.shape
+    h = P12 // 3
+    Z = P * h
+    T = torch.empty(Z, N, 70, dtype=torch.float32, device=qkv.device)
+    ws = _ws(lib.far_emm_pv_f16s_workspace_bytes(Z, N), qkv.device)
+    base = qkv.data_ptr()
+    plane = P * N * D * 4
+    rc = lib.far_emm_pv_f16s(ctypes.c_void_p(base), ctypes.c_void_p(base + h * plane), ctypes.c_void_p(base + 2 * h * plane),
+                             _p(pos, torch.float32), Z, N, D, float(scale), h, P * N * D, N * D, B, _p(ws), _p(T), _stream())
+    _lib.check(rc, 'far_emm_pv_f16s')
+    v = qkv[2 * h:].permute(1, 0, 2, 3).reshape(Z, N, D)                       # (P, h, N, D) -> z = p * h + hh
+    vt = torch.cat([v, pos.unsqueeze(0).expand(Z, -1, -1)], dim=2)
     return torch.bmm(vt.transpose(1, 2), T), T
 
 

@@ -92,10 +92,15 @@ int far_emm_pv_f32(const float* q, const float* k, const float* v, const float* 
 
 /* The whole K2 operator (softmax statistics included) on the f16 matrix cores with split-precision operands
  * (fp32 tensors, hi + lo fp16 pairs, three MFMAs per product, fp32 accumulation: fp32-grade).  Same inputs / output
- * as far_emm_pv_f32; ws: far_emm_pv_f16s_workspace_bytes(Z, N) bytes of scratch. */
+ * as far_emm_pv_f32, except that q, k, v may be strided per problem: z = p * heads + hh starts at
+ * ptr + hh * head_stride + p' * prob_stride (floats), p' = p for k, v and (p + q_rot) mod (Z / heads) for q -- the
+ * layout in which the head's fused q | k | v projection (far_conv_nhwc_f32 with out_planes = 12) leaves them, so
+ * the reference's reshape/permute (transformer.py:270-274) needs no copy.  Contiguous [Z][N][64]: heads = 1,
+ * prob_stride = 64 N, q_rot = 0.  ws: far_emm_pv_f16s_workspace_bytes(Z, N) bytes of scratch. */
 size_t far_emm_pv_f16s_workspace_bytes(int Z, int N);
 int far_emm_pv_f16s(const float* q, const float* k, const float* v, const float* pos, int Z, int N, int D, float scale,
-                    void* ws, float* T_out, far_stream_t stream);
+                    int heads, long head_stride, long prob_stride, int q_rot, void* ws, float* T_out,
+                    far_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * K3  fine level: window gather + sub-pixel expectation

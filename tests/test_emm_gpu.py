@@ -46,3 +46,17 @@ def test_emm_variants_agree_on_peaked_scores():
     assert torch.isfinite(Ta).all()
     torch.testing.assert_close(Ta, Tb, atol=2e-5 * float(Tb.abs().max()), rtol=1e-4)
     torch.testing.assert_close(Fa, Fb, atol=1e-4 * float(Fb.abs().max()), rtol=1e-3)
+
+
+def test_emm_planes_layout_matches_contiguous():
+    """K2 reading q | k | v from the per-(tensor, head) planes of the fused projection == K2 on the permuted copies."""
+    from far_amd import ops
+    B, h, N = 2, 4, 256
+    g = torch.Generator(device='cuda').manual_seed(9)
+    planes = torch.randn(3 * h, 2 * B, N, 64, device='cuda', generator=g)
+    pos = torch.rand(N, 6, device='cuda', generator=g)
+    F, T = ops.emm_bilinear_planes(planes, pos, 0.125, B)
+    q, k, v = (planes[t * h:(t + 1) * h].permute(1, 0, 2, 3) for t in range(3))       # (2B, h, N, 64): [image, pair]
+    q = torch.cat([q[B:], q[:B]], 0)                                                   # direction d uses image 1 - d
+    Fr, Tr = ops.emm_bilinear(*(t.reshape(2 * B * h, N, 64).contiguous() for t in (q, k, v)), pos, 0.125)
+    assert torch.equal(T, Tr) and torch.equal(F, Fr)
