@@ -31,8 +31,8 @@ F16_MFMA_PEAK_TFLOPS = 2500.0    # dense f16/bf16 MFMA peak (same guide; AMD hea
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--pairs', type=int, default=PAIRS_PER_GPU, help='pairs per GPU per step')
     ap.add_argument('--hyp', type=int, default=2048, help='RANSAC hypotheses per pair (metrics.py:120)')
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'fp16-fine', 'fp16', 'bf16'],
@@ -208,8 +208,8 @@ def main():
         test_step(model, batch, H=a.hyp, seed=0)
         return batch
 
-    # at least two untimed steps: the caching allocator still grows (a multi-GB hipMalloc) during the second step
-    a.warmup = max(a.warmup, 2)
+    # at least three untimed steps: the caching allocator still grows (multi-GB hipMallocs) during the first ones
+    a.warmup = max(a.warmup, 3)
     for _ in range(a.warmup):
         last = step()
 

@@ -1,0 +1,367 @@
+// K1 on the f16 matrix cores with split-precision operands: all-pairs correlation + dual softmax + mutual-NN.
+//
+// Same operator and outputs as far_coarse_match_f32 (dual_softmax_f32.hip; reference
+// mp3d_loftr/src/loftr/utils/coarse_matching.py:86-265), built like K2's split variant (emm_bilinear_f16s.hip):
+//   k1_prep      feat -> fp16 hi / lo planes, scaled by 2^4, stored in the LDS image ([rows][256] fp16, 16-byte
+//                slot ^= row & 15) so that a 64-row tile is one linear LDS-DMA
+//   k1_rowstats  x2: log2-domain softmax statistics of every row of the similarity matrix -- (f0, f1) for the softmax
+//                over columns j, (f1, f0) for the softmax over rows i (a lane owns one row of the transposed score
+//                tile: no cross-lane reductions); the second call also leaves dense, padded column arrays
+//   k1_match     conf = 2^(2 x - rowmax - colmax) / (rowsum colsum): ONE exp per score; per row the best (conf, j)
+//                (ties -> smaller j, as mask.max(dim=2) on CPU), per 128-row block the column maxima (32-lane max of
+//                each accumulator register); optional conf_matrix with 16-byte stores
+// then k_finalize / k_compact of dual_softmax_common.h (threshold, border, mutual-NN, ordered compaction).
+// The contraction is three v_mfma_f32_32x32x16_f16 per 16 channels (hi.hi + hi.lo + lo.hi, fp32 accumulate): an
+// fp32-grade similarity at 16/3 of the exact-f32 MFMA rate of dual_softmax_f32.hip.
+#include "dual_softmax_common.h"
+
+namespace {
+
+using namespace far_ds;
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int C = 256;               // channels (the FAR coarse level)
+constexpr int NS = C / 16;           // MFMA k-steps
+constexpr int KT = 64;               // columns per tile
+constexpr int ROWB = C * 2;          // bytes per fp16 row
+constexpr float PRESCALE = 16.0f;
+constexpr float HUGE_F = 1.0e30f;
+constexpr int TILE_PLANE = KT * ROWB;   // 32 KiB
+
+__device__ __forceinline__ void split1(float x, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)x;
+    lo = (_Float16)(x - (float)hi);
+}
+
+// max over the 32 lanes of each half-wave; the result is valid in lanes 16..31 (and 48..63) of the wave.
+#define FAR_DPP(old, v, ctrl, rowmask) \
+    __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), ctrl, rowmask, 0xF, false))
+__device__ __forceinline__ float max32_to_upper_row(float v) {
+    v = fmaxf(v, FAR_DPP(v, v, 0xB1, 0xF));      // quad_perm [1,0,3,2]
+    v = fmaxf(v, FAR_DPP(v, v, 0x4E, 0xF));      // quad_perm [2,3,0,1]
+    v = fmaxf(v, FAR_DPP(v, v, 0x141, 0xF));     // row_half_mirror
+    v = fmaxf(v, FAR_DPP(v, v, 0x140, 0xF));     // row_mirror: every lane of a 16-lane row holds the row maximum
+    v = fmaxf(v, FAR_DPP(v, v, 0x142, 0xA));     // row_bcast:15 into rows 1 and 3: lanes 16-31 / 48-63 hold the 32-lane maximum
+    return v;
+}
+
+// x [Z][N][256] fp32 -> hi / lo [Z][Np][256] fp16 (rows >= N zero), slot ^= row & 15
+__global__ void k1_prep(const float* __restrict__ x, int Z, int N, int Np, _Float16* __restrict__ hi, _Float16* __restrict__ lo) {
+    const long total = (long)Z * Np * 32;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int slot = (int)(t & 31);
+        const long row = t >> 5;
+        const int i = (int)(row % Np);
+        const long z = row / Np;
+        f16x8 vh, vl;
+        if (i < N) {
+            const float* src = x + ((size_t)z * N + i) * C + slot * 8;
+            const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+            const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { _Float16 h, l; split1(v[e] * PRESCALE, h, l); vh[e] = h; vl[e] = l; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { vh[e] = (_Float16)0.f; vl[e] = (_Float16)0.f; }
+        }
+        const int s2 = slot ^ (i & 15);
+        *reinterpret_cast<f16x8*>(hi + (size_t)row * C + s2 * 8) = vh;
+        *reinterpret_cast<f16x8*>(lo + (size_t)row * C + s2 * 8) = vl;
+    }
+}
+
+// Row-side fragments: row i, channels 16 s + 8 h .. + 7, both planes (128 registers)
+struct RowFrags {
+    f16x8 hi[NS], lo[NS];
+    __device__ __forceinline__ void load(const _Float16* ph, const _Float16* pl, size_t row, int irow, int h) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int slot = (2 * s + h) ^ (irow & 15);
+            hi[s] = *reinterpret_cast<const f16x8*>(ph + row * C + 8 * slot);
+            lo[s] = *reinterpret_cast<const f16x8*>(pl + row * C + 8 * slot);
+        }
+    }
+};
+
+__device__ __forceinline__ void dma_tile(unsigned char* lds, const _Float16* gh, const _Float16* gl, size_t row0, int tid, int wave) {
+    const unsigned char* sh = reinterpret_cast<const unsigned char*>(gh + row0 * C) + tid * 16;
+    const unsigned char* sl = reinterpret_cast<const unsigned char*>(gl + row0 * C) + tid * 16;
+#pragma unroll
+    for (int j = 0; j < TILE_PLANE / 4096; ++j) {
+        __builtin_amdgcn_global_load_lds((gptr_t)(sh + j * 4096), (lptr_t)(lds + j * 4096 + wave * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(sl + j * 4096), (lptr_t)(lds + TILE_PLANE + j * 4096 + wave * 1024), 16, 0, 0);
+    }
+}
+
+// acc[ct]: D[m = tile row 32 ct + ..][n = this lane's row]
+__device__ __forceinline__ void score_tile(f32x16 (&acc)[2], const unsigned char* lds, const RowFrags& rf, int l31, int h) {
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        f16x8 ch[2], cl[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const int row = 32 * ct + l31;
+            const int off = row * ROWB + (((2 * s + h) ^ (row & 15)) * 16);
+            ch[ct] = *reinterpret_cast<const f16x8*>(lds + off);
+            cl[ct] = *reinterpret_cast<const f16x8*>(lds + TILE_PLANE + off);
+        }
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[ct], rf.hi[s], acc[ct], 0, 0, 0);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[ct], rf.lo[s], acc[ct], 0, 0, 0);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cl[ct], rf.hi[s], acc[ct], 0, 0, 0);
+    }
+}
+
+// stat[z][i] = (max_j x_ij, sum_j 2^(x_ij - max)) over the Nc real columns; masked pairs count with x = fill2
+// (masked_fill_(-INF), coarse_matching.py:108-111).  Optional dense padded copies dmax / dinv [Z][Nrp] (+huge / 0 past Nr).
+__global__ __launch_bounds__(256, 2) void k1_rowstats(const _Float16* __restrict__ ah, const _Float16* __restrict__ al,
+                                                      const _Float16* __restrict__ bh, const _Float16* __restrict__ bl,
+                                                      int Z, int Nr, int Nc, int Nrp, int Ncp, float c1, float fill2,
+                                                      const uint8_t* __restrict__ rmask, const uint8_t* __restrict__ cmask,
+                                                      float2* __restrict__ stat, float* __restrict__ dmax, float* __restrict__ dinv) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    int z, Ib;
+    tile_coords(Nrp / 128, Z, z, Ib);
+    const int irow = Ib * 128 + 32 * wave + l31;
+    RowFrags rf;
+    rf.load(ah, al, (size_t)z * Nrp + irow, irow, h);
+    const bool rmasked = rmask && irow < Nr && !rmask[(size_t)z * Nr + irow];
+    float m = -HUGE_F, sum = 0.f, comp = 0.f;
+    const int ntile = (Nc + KT - 1) / KT;
+    for (int jt = 0; jt < ntile; ++jt) {
+        __syncthreads();
+        dma_tile(lds, bh, bl, (size_t)z * Ncp + jt * KT, tid, wave);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        f32x16 acc[2];
+        score_tile(acc, lds, rf, l31, h);
+        const bool special = (jt + 1) * KT > Nc || cmask != nullptr || rmask != nullptr;      // wave-uniform
+        float tm = -HUGE_F;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float x = acc[ct][r] * c1;
+                if (special) {
+                    const int j = jt * KT + 32 * ct + mfma32_row(r, h);
+                    if (j >= Nc) x = -HUGE_F;
+                    else if (rmasked || (cmask && !cmask[(size_t)z * Nc + j])) x = fill2;
+                }
+                acc[ct][r] = x;
+                tm = fmaxf(tm, x);
+            }
+        // The tile's 32 terms are summed on their own and then added to the running sum with Kahan compensation:
+        // once the row maximum (a term equal to 1) is in the accumulator, the other terms (~1e-8 each for a
+        // confident match) are below half an ulp of it and a plain fp32 running sum would drop them one by one
+        // (the "swamping" that costs the fp32 reference ~7e-5 on conf, oracle/coarse.py).
+        const float mn = fmaxf(m, tm);
+        const float resc = __builtin_amdgcn_exp2f(m - mn);
+        float t = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t += __builtin_amdgcn_exp2f(acc[ct][r] - mn);
+        sum *= resc;
+        comp *= resc;
+        const float y = t - comp;
+        const float ns = sum + y;
+        comp = (ns - sum) - y;
+        sum = ns;
+        m = mn;
+    }
+    sum -= comp;
+    const float mo = shfl_xor_f(m, 32), so = shfl_xor_f(sum, 32);
+    const float mn = fmaxf(m, mo);
+    const float st = sum * __builtin_amdgcn_exp2f(m - mn) + so * __builtin_amdgcn_exp2f(mo - mn);
+    if (h == 0) {
+        if (irow < Nr) stat[(size_t)z * Nr + irow] = make_float2(mn, st);
+        if (dmax) {
+            dmax[(size_t)z * Nrp + irow] = irow < Nr ? mn : HUGE_F;
+            dinv[(size_t)z * Nrp + irow] = irow < Nr ? 1.0f / st : 0.f;
+        }
+    }
+}
+
+template <bool CONF>
+__global__ __launch_bounds__(256, 2) void k1_match(const _Float16* __restrict__ ah, const _Float16* __restrict__ al,
+                                                   const _Float16* __restrict__ bh, const _Float16* __restrict__ bl,
+                                                   int Z, int L, int S, int Lp, int Sp, float c1, float fill2,
+                                                   const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1,
+                                                   const float2* __restrict__ rowstat, const float* __restrict__ cmax,
+                                                   const float* __restrict__ cinv, float* __restrict__ conf,
+                                                   float* __restrict__ rowbest_v, int* __restrict__ rowbest_j,
+                                                   float* __restrict__ colbest_part) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    float* colh = reinterpret_cast<float*>(lds + 2 * TILE_PLANE);          // [4 waves][64]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int nI = Lp / 128;
+    int z, Ib;
+    tile_coords(nI, Z, z, Ib);
+    const int irow = Ib * 128 + 32 * wave + l31;
+    const bool ivalid = irow < L;
+    RowFrags rf;
+    rf.load(ah, al, (size_t)z * Lp + irow, irow, h);
+    const float2 rst = ivalid ? rowstat[(size_t)z * L + irow] : make_float2(0.f, 1.f);
+    const float rinv = 1.0f / rst.y;
+    const float c2 = 2.0f * c1;
+    const bool rmasked = mask0 && ivalid && !mask0[(size_t)z * L + irow];
+    const bool aligned4 = (S & 3) == 0;
+    float bestv = -1.f;
+    int bestj = 0x7fffffff;
+    const int ntile = (S + KT - 1) / KT;
+    for (int jt = 0; jt < ntile; ++jt) {
+        __syncthreads();                       // previous tile's fragments and column exchange consumed
+        dma_tile(lds, bh, bl, (size_t)z * Sp + jt * KT, tid, wave);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        f32x16 acc[2];
+        score_tile(acc, lds, rf, l31, h);
+        const bool masks = mask0 != nullptr || mask1 != nullptr;                 // wave-uniform
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            // column statistics of this lane's columns  j = jt*64 + 32 ct + 8 q + 4 h + (0..3)  (padded: +huge / 0 -> p = 0)
+            float cm[16], ci[16];
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const size_t o = (size_t)z * Sp + jt * KT + 32 * ct + 8 * q4 + 4 * h;
+                const float4 a = *reinterpret_cast<const float4*>(cmax + o), b = *reinterpret_cast<const float4*>(cinv + o);
+                cm[4 * q4 + 0] = a.x; cm[4 * q4 + 1] = a.y; cm[4 * q4 + 2] = a.z; cm[4 * q4 + 3] = a.w;
+                ci[4 * q4 + 0] = b.x; ci[4 * q4 + 1] = b.y; ci[4 * q4 + 2] = b.z; ci[4 * q4 + 3] = b.w;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = jt * KT + 32 * ct + mfma32_row(r, h);
+                float x2 = acc[ct][r] * c2;                                       // 2 x in the log2 domain
+                if (masks && j < S && (rmasked || (mask1 && !mask1[(size_t)z * S + j]))) x2 = 2.0f * fill2;
+                const float p = __builtin_amdgcn_exp2f((x2 - rst.x) - cm[r]) * rinv * ci[r];
+                const bool valid = ivalid && j < S;
+                acc[ct][r] = valid ? p : -1.f;
+                if (valid && p > bestv) { bestv = p; bestj = j; }
+            }
+            if (CONF && ivalid) {
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int j = jt * KT + 32 * ct + 8 * q4 + 4 * h;
+                    float* dst = conf + ((size_t)z * L + irow) * S + j;
+                    if (aligned4 && j + 3 < S) {
+                        *reinterpret_cast<float4*>(dst) = make_float4(acc[ct][4 * q4], acc[ct][4 * q4 + 1], acc[ct][4 * q4 + 2], acc[ct][4 * q4 + 3]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (j + e < S) dst[e] = acc[ct][4 * q4 + e];
+                    }
+                }
+            }
+            // column maxima over this wave's 32 rows (the 32 lanes of a half-wave hold the same column per register):
+            // DPP butterflies inside each row of 16 lanes, then lane 15 of the even rows is broadcast to the odd rows
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = max32_to_upper_row(acc[ct][r]);
+                if (l31 == 31) colh[wave * 64 + 32 * ct + mfma32_row(r, h)] = v;
+            }
+        }
+        __syncthreads();
+        if (tid < 64 && jt * KT + tid < S)
+            colbest_part[((size_t)z * nI + Ib) * S + jt * KT + tid] =
+                fmaxf(fmaxf(colh[tid], colh[64 + tid]), fmaxf(colh[128 + tid], colh[192 + tid]));
+    }
+    // merge the two half-waves (same rows, interleaved columns): larger value, ties -> smaller j
+    const float vo = shfl_xor_f(bestv, 32);
+    const int jo = shfl_xor_i(bestj, 32);
+    if (vo > bestv || (vo == bestv && jo < bestj)) { bestv = vo; bestj = jo; }
+    if (h == 0 && ivalid) {
+        rowbest_v[(size_t)z * L + irow] = bestv;
+        rowbest_j[(size_t)z * L + irow] = bestj;
+    }
+}
+
+struct Ws16 {
+    K1Workspace k;
+    _Float16 *ah, *al, *bh, *bl;
+    float2* colstat2;
+    float *cmax, *cinv;
+    size_t bytes;
+};
+inline Ws16 carve16(void* ws, int Z, int L, int S) {
+    Ws16 w;
+    w.k = carve(ws, Z, L, S);
+    const int Lp = (L + 127) / 128 * 128, Sp = (S + 127) / 128 * 128;
+    unsigned char* p = (unsigned char*)ws;
+    size_t o = w.k.bytes;
+    auto take = [&](size_t n) { unsigned char* r = p ? p + o : nullptr; o += align256(n); return r; };
+    w.ah = (_Float16*)take((size_t)Z * Lp * C * 2); w.al = (_Float16*)take((size_t)Z * Lp * C * 2);
+    w.bh = (_Float16*)take((size_t)Z * Sp * C * 2); w.bl = (_Float16*)take((size_t)Z * Sp * C * 2);
+    w.colstat2 = (float2*)take((size_t)Z * S * 8);
+    w.cmax = (float*)take((size_t)Z * Sp * 4); w.cinv = (float*)take((size_t)Z * Sp * 4);
+    w.bytes = o;
+    return w;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t far_coarse_match_f16s_workspace_bytes(int Z, int L, int S, int Cc) {
+    if (Z <= 0 || L <= 0 || S <= 0 || Cc != C) return 0;
+    return carve16(nullptr, Z, L, S).bytes;
+}
+
+// Split-fp16 variant of far_coarse_match_f32: same arguments, same outputs (C must be 256).
+int far_coarse_match_f16s(const float* f0, const float* f1, int Z, int L, int S, int Cc,
+                          float temperature, float thr, int border, int h0, int w0, int h1, int w1,
+                          float cell_scale, const uint8_t* mask0, const uint8_t* mask1,
+                          const int* valid_hw, const float* scale0, const float* scale1,
+                          float* conf_out, int64_t* b_ids, int64_t* i_ids, int64_t* j_ids, float* mconf,
+                          float* mkpts0_c, float* mkpts1_c, int* counts_out, int* total_out,
+                          void* ws, hipStream_t stream) {
+    far_clear_errors();
+    if (!f0 || !f1 || !ws || !b_ids || !i_ids || !j_ids || !mconf || !mkpts0_c || !mkpts1_c || !total_out)
+        return FAR_EINVAL;
+    if (Z <= 0 || L <= 0 || S <= 0 || Cc != C || h0 * w0 != L || h1 * w1 != S) return FAR_EINVAL;
+    const Ws16 w = carve16(ws, Z, L, S);
+    const int Lp = (L + 127) / 128 * 128, Sp = (S + 127) / 128 * 128;
+    // sim = <f0 / sqrt(C), f1 / sqrt(C)> / temperature  ->  log2 domain, operands pre-scaled by 2^4 each
+    const float c1 = (float)(1.4426950408889634 / ((double)C * (double)temperature * PRESCALE * PRESCALE));
+    const float fill2 = -1e9f * 1.44269504088896341f;
+    auto gridp = [](long n) { long b = (n + 255) / 256; return (unsigned)(b < 65536L * 4 ? b : 65536L * 4); };
+    hipLaunchKernelGGL(k1_prep, dim3(gridp((long)Z * Lp * 32)), dim3(256), 0, stream, f0, Z, L, Lp, w.ah, w.al);
+    hipLaunchKernelGGL(k1_prep, dim3(gridp((long)Z * Sp * 32)), dim3(256), 0, stream, f1, Z, S, Sp, w.bh, w.bl);
+    int* counts = counts_out ? counts_out : w.k.counts;
+    hipMemsetAsync(counts, 0, sizeof(int) * Z, stream);
+    const size_t smem_s = 2 * TILE_PLANE, smem_m = 2 * TILE_PLANE + 4 * 64 * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)k1_rowstats, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_s);
+        hipFuncSetAttribute((const void*)k1_match<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_m);
+        hipFuncSetAttribute((const void*)k1_match<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_m);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k1_rowstats, dim3((Lp / 128) * Z), dim3(256), smem_s, stream, w.ah, w.al, w.bh, w.bl, Z, L, S, Lp, Sp,
+                       c1, fill2, mask0, mask1, w.k.rowstat, (float*)nullptr, (float*)nullptr);
+    hipLaunchKernelGGL(k1_rowstats, dim3((Sp / 128) * Z), dim3(256), smem_s, stream, w.bh, w.bl, w.ah, w.al, Z, S, L, Sp, Lp,
+                       c1, fill2, mask1, mask0, w.colstat2, w.cmax, w.cinv);
+    const int nI = Lp / 128;
+    if (conf_out)
+        hipLaunchKernelGGL(k1_match<true>, dim3(nI * Z), dim3(256), smem_m, stream, w.ah, w.al, w.bh, w.bl, Z, L, S, Lp, Sp, c1,
+                           fill2, mask0, mask1, w.k.rowstat, w.cmax, w.cinv, conf_out, w.k.rowbest_v, w.k.rowbest_j, w.k.colbest_part);
+    else
+        hipLaunchKernelGGL(k1_match<false>, dim3(nI * Z), dim3(256), smem_m, stream, w.ah, w.al, w.bh, w.bl, Z, L, S, Lp, Sp, c1,
+                           fill2, mask0, mask1, w.k.rowstat, w.cmax, w.cinv, conf_out, w.k.rowbest_v, w.k.rowbest_j, w.k.colbest_part);
+    hipLaunchKernelGGL(k_finalize, dim3((L + 255) / 256, Z), dim3(256), 0, stream, w.k.rowbest_v, w.k.rowbest_j,
+                       w.k.colbest_part, nI, L, S, thr, border, h0, w0, h1, w1, valid_hw, w.k.match_j, counts);
+    hipLaunchKernelGGL(k_compact, dim3(Z), dim3(256), 0, stream, w.k.match_j, w.k.rowbest_v, counts, L, w0, w1,
+                       cell_scale, scale0, scale1, b_ids, i_ids, j_ids, mconf, mkpts0_c, mkpts1_c, total_out);
+    return far_check_launch();
+}
+
+}  // extern "C"

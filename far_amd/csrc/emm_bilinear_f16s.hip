@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256, 3) void k_rowstats(const _Float16* __restrict_
     const int irow = Ib * 128 + 32 * wave + l31;
     RowFrags rf;
     rf.load(ah, al, (size_t)z * Np + irow, irow, h);
-    float m = NEG_HUGE, sum = 0.f;
+    float m = NEG_HUGE, sum = 0.f, comp = 0.f;
     const int ntile = Np / KT;
     for (int jt = 0; jt < ntile; ++jt) {
         __syncthreads();
@@ -160,15 +160,26 @@ __global__ __launch_bounds__(256, 3) void k_rowstats(const _Float16* __restrict_
                 acc[ct][r] = x;
                 tm = fmaxf(tm, x);
             }
+        // The tile's 32 terms are summed on their own and then added to the running sum with Kahan compensation:
+        // once the row maximum (a term equal to 1) is in the accumulator, the other terms (~1e-8 each for a
+        // confident match) are below half an ulp of it and a plain fp32 running sum would drop them one by one
+        // (the "swamping" that costs the fp32 reference ~7e-5 on conf, oracle/coarse.py).
         const float mn = fmaxf(m, tm);
-        float s = sum * __builtin_amdgcn_exp2f(m - mn);
+        const float resc = __builtin_amdgcn_exp2f(m - mn);
+        float t = 0.f;
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s += __builtin_amdgcn_exp2f(acc[ct][r] - mn);
+            for (int r = 0; r < 16; ++r) t += __builtin_amdgcn_exp2f(acc[ct][r] - mn);
+        sum *= resc;
+        comp *= resc;
+        const float y = t - comp;
+        const float ns = sum + y;
+        comp = (ns - sum) - y;
+        sum = ns;
         m = mn;
-        sum = s;
     }
+    sum -= comp;
     // the two half-waves hold the two key halves of the same rows
     const float mo = shfl_xor_f(m, 32), so = shfl_xor_f(sum, 32);
     const float mn = fmaxf(m, mo);

@@ -38,8 +38,11 @@ class CoarseMatching(nn.Module):
         # data['conf_matrix'] (92 MB / pair) is consumed only by the coarse loss and by plotting
         # (loftr_loss.py:307-311); it is materialised when training or when asked for explicitly.
         self.materialize_conf = False
-        # contraction on the bf16 matrix core (far_coarse_match_bf16): 4x faster, exact on bf16-rounded features,
-        # match-set IoU vs the fp32 path reported by tests/test_coarse_gpu.py; off = the fp32 parity configuration
+        # K1 arithmetic: 'f16s' (default) split-fp16 operand pairs on the f16 matrix cores -- an fp32-grade similarity,
+        # held to the same parity tests as 'f32' (the exact-f32 MFMA kernels); C must be 256 (other widths use 'f32').
+        # bf16 = True: bf16 operands (far_coarse_match_bf16), exact on bf16-rounded features, deviation reported as
+        # match-set IoU by tests/test_coarse_gpu.py
+        self.variant = 'f16s'
         self.bf16 = False
 
     def forward(self, feat_c0, feat_c1, data, mask_c0=None, mask_c1=None):
@@ -60,7 +63,8 @@ class CoarseMatching(nn.Module):
         s1 = data['scale1'].float().contiguous() if 'scale1' in data else None
         out = ops.coarse_match(feat_c0.float().contiguous(), feat_c1.float().contiguous(), self.temperature,
                                self.thr, self.border_rm, hw0, hw1, scale, as_u8(mask_c0), as_u8(mask_c1),
-                               valid_hw, s0, s1, want_conf=self.materialize_conf, bf16=self.bf16)
+                               valid_hw, s0, s1, want_conf=self.materialize_conf,
+                               variant='bf16' if self.bf16 else (self.variant if feat_c0.shape[-1] == 256 else 'f32'))
         mconf = out['mconf']
         data.update({
             'conf_matrix': out['conf_matrix'],

@@ -47,8 +47,9 @@ def dual_softmax_stats(f0, f1, feat_div=1.0, sim_div=1.0, sim_mul=1.0, mask0=Non
 
 
 def coarse_match(f0, f1, temperature, thr, border, hw0, hw1, cell_scale, mask0=None, mask1=None,
-                 valid_hw=None, scale0=None, scale1=None, want_conf=False, bf16=False):
+                 valid_hw=None, scale0=None, scale1=None, want_conf=False, bf16=False, variant=None):
     """K1.  Returns dict(b_ids, i_ids, j_ids, mconf, mkpts0_c, mkpts1_c, counts, conf_matrix|None).
+    variant: 'f32' exact-f32 MFMA (default), 'f16s' split-fp16 operands (fp32-grade), 'bf16' bf16 operands.
 
     One host synchronisation (reading M) is inherent: the reference's outputs have data-dependent shape
     (torch.where, coarse_matching.py:193).
@@ -57,8 +58,11 @@ def coarse_match(f0, f1, temperature, thr, border, hw0, hw1, cell_scale, mask0=N
     Z, L, C = f0.shape
     S = f1.shape[1]
     dev = f0.device
-    fn = lib.far_coarse_match_bf16 if bf16 else lib.far_coarse_match_f32
-    ws = _ws(lib.far_coarse_match_bf16_workspace_bytes(Z, L, S, C) if bf16 else lib.far_dual_softmax_workspace_bytes(Z, L, S), dev)
+    variant = variant or ('bf16' if bf16 else 'f32')
+    fn = {'f32': lib.far_coarse_match_f32, 'bf16': lib.far_coarse_match_bf16, 'f16s': lib.far_coarse_match_f16s}[variant]
+    ws = _ws({'f32': lambda: lib.far_dual_softmax_workspace_bytes(Z, L, S),
+              'bf16': lambda: lib.far_coarse_match_bf16_workspace_bytes(Z, L, S, C),
+              'f16s': lambda: lib.far_coarse_match_f16s_workspace_bytes(Z, L, S, C)}[variant](), dev)
     cap = Z * L
     b_ids = torch.empty(cap, dtype=torch.int64, device=dev)
     i_ids = torch.empty(cap, dtype=torch.int64, device=dev)
@@ -75,7 +79,7 @@ def coarse_match(f0, f1, temperature, thr, border, hw0, hw1, cell_scale, mask0=N
         _p(scale0, torch.float32), _p(scale1, torch.float32), _p(conf),
         _p(b_ids), _p(i_ids), _p(j_ids), _p(mconf), _p(mk0), _p(mk1),
         _p(counts), ctypes.c_void_p(counts.data_ptr() + 4 * Z), _p(ws), _stream())
-    _lib.check(rc, 'far_coarse_match_bf16' if bf16 else 'far_coarse_match_f32')
+    _lib.check(rc, 'far_coarse_match_' + variant)
     counts_h = counts.cpu()
     M = int(counts_h[Z])
     return {

@@ -78,6 +78,18 @@ int far_coarse_match_bf16(const float* f0, const float* f1, int Z, int L, int S,
                           float* mkpts0_c, float* mkpts1_c, int* counts_out, int* total_out,
                           void* ws, far_stream_t stream);
 
+/* Split-fp16 variant of far_coarse_match_f32 (fp32 features, hi + lo fp16 operand pairs on the f16 matrix cores,
+ * fp32 accumulation: an fp32-grade similarity at 16/3 of the exact-f32 MFMA rate; one exp per score; conf_matrix, if
+ * requested, written with 16-byte stores).  Same arguments and outputs; C must be 256. */
+size_t far_coarse_match_f16s_workspace_bytes(int Z, int L, int S, int C);
+int far_coarse_match_f16s(const float* f0, const float* f1, int Z, int L, int S, int C,
+                          float temperature, float thr, int border, int h0, int w0, int h1, int w1,
+                          float cell_scale, const uint8_t* mask0, const uint8_t* mask1,
+                          const int* valid_hw, const float* scale0, const float* scale1,
+                          float* conf_out, int64_t* b_ids, int64_t* i_ids, int64_t* j_ids, float* mconf,
+                          float* mkpts0_c, float* mkpts1_c, int* counts_out, int* total_out,
+                          void* ws, far_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * K2  EMM head: bilinear dual-softmax attention  F = v~^T (softmax_row(s) * softmax_col(s)) v~
  * replaces src/loftr/loftr_module/transformer.py:275-292 (CrossAttention.forward), one call per direction

@@ -11,19 +11,19 @@ ATOL64 = 1e-5
 CFG = dict(thr=0.2, border_rm=2, dsmax_temperature=0.1)
 
 
-def _run(f0, f1, hw, want_conf, border=2, thr=0.2):
+def _run(f0, f1, hw, want_conf, border=2, thr=0.2, variant='f32'):
     from far_amd import ops
     d = ops.coarse_match(torch.from_numpy(f0).cuda(), torch.from_numpy(f1).cuda(), 0.1, thr, border,
-                         hw, hw, 8.0, want_conf=want_conf)
+                         hw, hw, 8.0, want_conf=want_conf, variant=variant)
     torch.cuda.synchronize()
     return d
 
 
-def _check(f0, f1, hw, full_conf):
+def _check(f0, f1, hw, full_conf, variant='f32'):
     from oracle import coarse as oc
     ref = oc.coarse_matching(f0, f1, CFG, hw, hw, (hw[0] * 8, hw[1] * 8))
     ref64 = oc.coarse_matching(f0, f1, CFG, hw, hw, (hw[0] * 8, hw[1] * 8), dtype=np.float64)
-    got = _run(f0, f1, hw, want_conf=full_conf)
+    got = _run(f0, f1, hw, want_conf=full_conf, variant=variant)
     # indices are only well defined away from the discontinuities: require the margin on the oracle side
     rg, cg, tg = oc.margins(ref['conf_matrix'], CFG['thr'])
     sel = ref['conf_matrix'].max(axis=2) > 0.05
@@ -188,3 +188,49 @@ def test_bf16_variant_vs_fp32_path_iou():
     iou = len(sa & sb) / len(sa | sb)
     print('bf16 vs fp32 match-set IoU', iou, len(sa), len(sb))
     assert iou > 0.98
+
+
+# ---- split-fp16 variant (far_coarse_match_f16s, C = 256): the same parity bar as the exact-f32 kernels -------------
+
+@pytest.mark.parametrize('N,hw,seed,amp', [(2, (12, 16), 21, 1.6), (3, (13, 17), 22, 1.6), (1, (60, 80), 3, 1.2)])
+def test_f16s_variant_parity(N, hw, seed, amp):
+    f0, f1, _ = correlated_features(N, hw, 256, seed=seed, amp=amp, frac=0.8)
+    M = _check(f0, f1, hw, True, variant='f16s')
+    assert M > 30
+
+
+def test_f16s_variant_mapfree_grid_and_agreement_with_f32():
+    f0, f1, _ = correlated_features(2, (68, 90), 256, seed=11, amp=1.3, frac=0.9)
+    M = _check(f0, f1, (68, 90), False, variant='f16s')
+    assert M > 6000
+    a, b = _run(f0, f1, (68, 90), False, variant='f16s'), _run(f0, f1, (68, 90), False)
+    for k in ('b_ids', 'i_ids', 'j_ids'):
+        assert torch.equal(a[k], b[k])
+    assert float((a["mconf"] - b["mconf"]).abs().max()) < 1e-5          # both are within 1e-5 of the float64 oracle
+
+
+def test_f16s_variant_no_matches_and_masks():
+    from far_amd import ops
+    rng = np.random.default_rng(5)
+    f0 = rng.standard_normal((1, 192, 256)).astype(np.float32) * 0.1
+    f1 = rng.standard_normal((1, 192, 256)).astype(np.float32) * 0.1
+    got = _run(f0, f1, (12, 16), False, variant='f16s')
+    assert got['b_ids'].numel() == 0 and got['mkpts0_c'].shape == (0, 2)
+    # padded masks + valid extents + scales: must equal the exact-f32 kernels decision for decision
+    N, hw = 2, (12, 16)
+    f0, f1, _ = correlated_features(N, hw, 256, seed=4, amp=1.6)
+    L = hw[0] * hw[1]
+    m0 = np.zeros((N, hw[0], hw[1]), np.uint8); m1 = np.zeros((N, hw[0], hw[1]), np.uint8)
+    ext = [(10, 13, 12, 16), (12, 16, 9, 14)]
+    for n, (h0, w0, h1, w1) in enumerate(ext):
+        m0[n, :h0, :w0] = 1; m1[n, :h1, :w1] = 1
+    kw = dict(mask0=torch.from_numpy(m0.reshape(N, L)).cuda(), mask1=torch.from_numpy(m1.reshape(N, L)).cuda(),
+              valid_hw=torch.tensor(ext, dtype=torch.int32).cuda(),
+              scale0=torch.tensor([[1.1, 0.9], [1.0, 1.2]]).cuda(), scale1=torch.tensor([[0.8, 1.0], [1.3, 1.1]]).cuda())
+    t0, t1 = torch.from_numpy(f0).cuda(), torch.from_numpy(f1).cuda()
+    a = ops.coarse_match(t0, t1, 0.1, 0.2, 2, hw, hw, 8.0, variant='f16s', want_conf=True, **kw)
+    b = ops.coarse_match(t0, t1, 0.1, 0.2, 2, hw, hw, 8.0, variant='f32', want_conf=True, **kw)
+    assert a['b_ids'].numel() > 20
+    for k in ('b_ids', 'i_ids', 'j_ids', 'mkpts0_c', 'mkpts1_c'):
+        assert torch.equal(a[k], b[k]), k
+    assert float((a['conf_matrix'] - b['conf_matrix']).abs().max()) < 1e-5
