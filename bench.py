@@ -72,17 +72,21 @@ def kernel_rooflines(n_pairs):
     out = {}
     t = event_time_ms(lambda: ops.dual_softmax_stats(f0, f1, 16.0, 0.1, 1.0))
     fl = 2.0 * L * S * C * n_pairs
-    out['k_stats_f32[K1]'] = dict(ms=t, tflops=fl / t / 1e9, frac=fl / t / 1e9 / F32_MFMA_PEAK_TFLOPS)
+    out['k_stats_f32[K1, exact-f32 variant]'] = dict(ms=t, tflops=fl / t / 1e9, frac=fl / t / 1e9 / F32_MFMA_PEAK_TFLOPS)
     t2 = event_time_ms(lambda: ops.coarse_match(f0, f1, 0.1, 0.2, 2, (60, 80), (60, 80), 8.0))
-    out['far_coarse_match_f32[K1 all passes]'] = dict(ms=t2, tflops=fl / t2 / 1e9, frac=fl / t2 / 1e9 / F32_MFMA_PEAK_TFLOPS)
+    out['far_coarse_match_f32[K1 all passes, exact-f32 variant]'] = dict(ms=t2, tflops=fl / t2 / 1e9, frac=fl / t2 / 1e9 / F32_MFMA_PEAK_TFLOPS)
     tm = event_time_ms(lambda: ops.coarse_match(f0[:8], f1[:8], 0.1, 0.2, 2, (60, 80), (60, 80), 8.0, want_conf=True))
     by = (4.0 * L * S + 4.0 * (L + S) * C) * min(8, n_pairs)
-    out['far_coarse_match_f32[K1 materialising conf_matrix, 8 pairs]'] = dict(ms=tm, gbs=by / tm / 1e6, frac=by / tm / 1e6 / HBM_PEAK_GBS)
+    out['far_coarse_match_f32[K1 materialising conf_matrix, 8 pairs, exact-f32 variant]'] = dict(ms=tm, gbs=by / tm / 1e6, frac=by / tm / 1e6 / HBM_PEAK_GBS)
     tb = event_time_ms(lambda: ops.coarse_match(f0, f1, 0.1, 0.2, 2, (60, 80), (60, 80), 8.0, bf16=True))
     out['far_coarse_match_bf16[K1 all passes, bf16 MFMA variant]'] = dict(ms=tb, tflops=fl / tb / 1e9, frac=fl / tb / 1e9 / 2500.0)
     tbm = event_time_ms(lambda: ops.coarse_match(f0, f1, 0.1, 0.2, 2, (60, 80), (60, 80), 8.0, want_conf=True, bf16=True), iters=3, warm=1)
     byb = (4.0 * L * S + 4.0 * (L + S) * C) * n_pairs
     out['far_coarse_match_bf16[K1 materialising conf_matrix, bf16 MFMA variant]'] = dict(ms=tbm, gbs=byb / tbm / 1e6, frac=byb / tbm / 1e6 / HBM_PEAK_GBS)
+    ts = event_time_ms(lambda: ops.coarse_match(f0, f1, 0.1, 0.2, 2, (60, 80), (60, 80), 8.0, variant='f16s'))
+    out['far_coarse_match_f16s[K1 all passes, split-fp16 (default)]'] = dict(ms=ts, tflops=fl / ts / 1e9, frac=fl / ts / 1e9 / F16_MFMA_PEAK_TFLOPS)
+    tsm = event_time_ms(lambda: ops.coarse_match(f0, f1, 0.1, 0.2, 2, (60, 80), (60, 80), 8.0, want_conf=True, variant='f16s'), iters=3, warm=1)
+    out['far_coarse_match_f16s[K1 materialising conf_matrix, split-fp16]'] = dict(ms=tsm, gbs=byb / tsm / 1e6, frac=byb / tsm / 1e6 / HBM_PEAK_GBS)
     del f0, f1
     Z = n_pairs * 8
     q = torch.randn(Z, L, 64, device=dev, generator=g)

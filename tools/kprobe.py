@@ -15,6 +15,7 @@ if which in ('k1', 'all'):
     f1 = f0[:, torch.randperm(L, device=dev, generator=g)] + 0.1 * torch.randn(n, L, 256, device=dev, generator=g)
     for _ in range(it):
         ops.coarse_match(f0, f1, 0.1, 0.2, 2, (60, 80), (60, 80), 8.0)
+        ops.coarse_match(f0, f1, 0.1, 0.2, 2, (60, 80), (60, 80), 8.0, variant='f16s')
 if which in ('k1conf', 'all'):
     f0 = 1.2 * torch.randn(n, L, 256, device=dev, generator=g)
     f1 = f0[:, torch.randperm(L, device=dev, generator=g)] + 0.1 * torch.randn(n, L, 256, device=dev, generator=g)

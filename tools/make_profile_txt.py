@@ -1,0 +1,19 @@
+import json
+plain=open('/root/repo/gpurun_out/bench_plain.log').read().strip().splitlines()[-1]
+prof=open('/root/repo/gpurun_out/bench_prof.log').read().strip().splitlines()[-1]
+tr=open('/root/repo/gpurun_out/r01c_trace.txt').read()
+whole,win=tr.split('\n\n',1)
+out=f"""# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 3 --no-cpu-baseline    (round 1, 1x MI355X, default fp32-grade path)
+# bench line of the same profiled run:
+{prof}
+
+# un-profiled bench line (python bench.py, i.e. 5 steps after 3 warm-up steps) on the same box:
+{plain}
+
+## one steady-state step (32 pairs): per kernel
+{win.strip()}
+
+## whole process (includes the warm-up steps and the isolated kernel timings of bench.kernel_rooflines)
+{whole.strip()}
+"""
+open('/root/repo/profiles/r01_bench_fp32_kernel_trace.txt','w').write(out)

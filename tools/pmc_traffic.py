@@ -17,7 +17,7 @@ def load(path, counter):
 
 def short(name):
     for key in ['k_stats_f32', 'k_match_f32', 'k_emm_pv_f32', 'k_la_kv_partial<32>', 'k_la_apply<32>', 'k_layernorm',
-                'k_conv<3, 2, 2, 4, true, 1>', 'k_conv<1, 2, 2, 4, true, 1>', 'k_pv', 'k_rowstats']:
+                'k_conv<3, 2, 2, 4, true, 1>', 'k_conv<1, 2, 2, 4, true, 1>', 'k_pv', 'k_rowstats', 'k1_rowstats', 'k1_matchILb0', 'k1_matchILb1']:
         if key in name:
             return key
     return None
