@@ -58,6 +58,52 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, 
     }
 }
 
+// C <= 256 (one float4 per lane): four rows per wave, their loads issued back to back -- a single 16-byte load per
+// lane in flight does not cover the HBM latency.
+__global__ __launch_bounds__(256) void k_layernorm_r4(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, const float* __restrict__ res,
+                                                      long rows, int C, float eps, float* __restrict__ y) {
+    const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+    const int lane = threadIdx.x & 63;
+    const int nvec = C >> 2;
+    const bool act = lane < nvec;
+    float4 v[4], r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long row = row0 + k;
+        const bool ok = act && row < rows;
+        v[k] = ok ? reinterpret_cast<const float4*>(x + row * C)[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+        r[k] = (ok && res) ? reinterpret_cast<const float4*>(res + row * C)[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float4 g = act ? reinterpret_cast<const float4*>(gamma)[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 b = act ? reinterpret_cast<const float4*>(beta)[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long row = row0 + k;
+        float s = (v[k].x + v[k].y) + (v[k].z + v[k].w);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) s += shfl_xor_f(s, d);
+        const float mean = s / (float)C;
+        float q = 0.f;
+        if (act) {
+            const float a0 = v[k].x - mean, a1 = v[k].y - mean, a2 = v[k].z - mean, a3 = v[k].w - mean;
+            q = (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) q += shfl_xor_f(q, d);
+        const float rstd = 1.0f / sqrtf(q / (float)C + eps);
+        if (act && row < rows) {
+            float4 o;
+            o.x = (v[k].x - mean) * rstd * g.x + b.x;
+            o.y = (v[k].y - mean) * rstd * g.y + b.y;
+            o.z = (v[k].z - mean) * rstd * g.z + b.z;
+            o.w = (v[k].w - mean) * rstd * g.w + b.w;
+            if (res) { o.x += r[k].x; o.y += r[k].y; o.z += r[k].z; o.w += r[k].w; }
+            reinterpret_cast<float4*>(y + row * C)[lane] = o;
+        }
+    }
+}
+
 // generic fallback for other channel counts (C % 4 == 0, C <= 4096): row cached in registers by strided float4
 __global__ __launch_bounds__(256) void k_layernorm_any(const float* __restrict__ x, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const float* __restrict__ res,
@@ -94,7 +140,8 @@ int far_layernorm_f32(const float* x, const float* gamma, const float* beta, con
     if (rows == 0) return FAR_OK;
     if (!x || !gamma || !beta || !y || rows < 0 || C <= 0) return FAR_EINVAL;
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-    if ((C & 3) == 0 && C <= 256) hipLaunchKernelGGL(k_layernorm<1>, grid, block, 0, stream, x, gamma, beta, res, rows, C, eps, y);
+    if ((C & 3) == 0 && C <= 256)
+        hipLaunchKernelGGL(k_layernorm_r4, dim3((unsigned)((rows + 15) / 16)), block, 0, stream, x, gamma, beta, res, rows, C, eps, y);
     else if ((C & 3) == 0 && C <= 512) hipLaunchKernelGGL(k_layernorm<2>, grid, block, 0, stream, x, gamma, beta, res, rows, C, eps, y);
     else hipLaunchKernelGGL(k_layernorm_any, grid, block, 0, stream, x, gamma, beta, res, rows, C, eps, y);
     return far_check_launch();

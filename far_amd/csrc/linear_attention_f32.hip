@@ -125,21 +125,32 @@ __global__ __launch_bounds__(256) void k_la_apply(const float* __restrict__ q, c
         bks[t] = kvn[(size_t)(NK * kk + t) * (D + 1) + D];
     }
     const float fS = (float)S;
-    for (int ti = tb * tiles_per_unit; ti < min(ntile, (tb + 1) * tiles_per_unit); ++ti) {
+    const int t_end = min(ntile, (tb + 1) * tiles_per_unit);
+    // the token rows of tile ti + 1 are requested before tile ti is computed (raw values; elu + mask applied at use)
+    float4 raw[NK / 4], nxt[NK / 4];
+    float mk = 0.f, mk_n = 0.f;
+    auto fetch = [&](int ti, float4 (&dst)[NK / 4], float& m) {
         const int l = ti * TT + col;          // the token this lane feeds into the A operand
-        float qa[NK];
+        m = 0.f;
 #pragma unroll
-        for (int t = 0; t < NK; ++t) qa[t] = 0.f;
-        if (l < L) {
+        for (int t4 = 0; t4 < NK / 4; ++t4) dst[t4] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ti < t_end && l < L) {
             const float* qp = q + ((size_t)n * L + l) * HD + h * D + NK * kk;
-            float m = 1.f;
+            m = 1.f;
             if (q_mask) m = q_mask[(size_t)n * L + l] ? 1.f : 0.f;
 #pragma unroll
-            for (int t4 = 0; t4 < NK / 4; ++t4) {
-                const float4 x = *reinterpret_cast<const float4*>(qp + 4 * t4);
-                qa[4 * t4 + 0] = elu1(x.x) * m; qa[4 * t4 + 1] = elu1(x.y) * m;
-                qa[4 * t4 + 2] = elu1(x.z) * m; qa[4 * t4 + 3] = elu1(x.w) * m;
-            }
+            for (int t4 = 0; t4 < NK / 4; ++t4) dst[t4] = *reinterpret_cast<const float4*>(qp + 4 * t4);
+        }
+    };
+    fetch(tb * tiles_per_unit, raw, mk);
+    for (int ti = tb * tiles_per_unit; ti < t_end; ++ti) {
+        fetch(ti + 1, nxt, mk_n);
+        float qa[NK];
+#pragma unroll
+        for (int t4 = 0; t4 < NK / 4; ++t4) {
+            // a lane outside the sequence contributes zeros (elu(0) + 1 = 1 would not): mk = 0 there
+            qa[4 * t4 + 0] = elu1(raw[t4].x) * mk; qa[4 * t4 + 1] = elu1(raw[t4].y) * mk;
+            qa[4 * t4 + 2] = elu1(raw[t4].z) * mk; qa[4 * t4 + 3] = elu1(raw[t4].w) * mk;
         }
         typename M::acc_t num, den;
 #pragma unroll
@@ -157,6 +168,9 @@ __global__ __launch_bounds__(256) void k_la_apply(const float* __restrict__ q, c
                 out[((size_t)n * L + lo) * HD + h * D + col] = (num[r] * zz) * fS;   // :50
             }
         }
+#pragma unroll
+        for (int t4 = 0; t4 < NK / 4; ++t4) raw[t4] = nxt[t4];
+        mk = mk_n;
     }
 }
 
