@@ -224,10 +224,18 @@ __global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / NW, wn = wave % NW, l31 = lane & 31, h = lane >> 5;
 
-    // ---- which output tile.  Hardware places block b on XCD b % 8: give each XCD a contiguous range of tiles so
-    // that the halos shared by neighbouring tiles are re-read from that XCD's L2.
-    long t = blockIdx.x;
-    if ((p.ntiles & 7) == 0) t = (t & 7) * (p.ntiles >> 3) + (t >> 3);
+    // ---- which output tile / output-channel block.  1-D grid of ntiles * nblkY blocks.  Hardware places block b on
+    // XCD b % 8: each XCD gets a contiguous range of tiles (the halos shared by neighbouring tiles are re-read from
+    // that XCD's L2) and runs the nblkY channel blocks of a tile back to back (they re-read the same pixels).
+    long t;
+    int by;
+    {
+        const long b = blockIdx.x;
+        long seq = b, tile0 = 0;
+        if ((p.ntiles & 7) == 0) { seq = b >> 3; tile0 = (b & 7) * (p.ntiles >> 3); }
+        t = tile0 + seq / p.nblkY;
+        by = (int)(seq % p.nblkY);
+    }
     TilePos tp{0, 0, 0, 0};
     if (KS == 1) {
         tp.pix0 = t * (64 * MW);
@@ -239,7 +247,6 @@ __global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const 
         tp.oy0 = ty * G::TH;
         tp.ox0 = tx * TW;
     }
-    const int by = blockIdx.y;
     const int cout_w = by * NT + 32 * NTW * wn;                       // first output channel of this wave
 
     // ---- weight slabs, stored in execution order [chunk][tap][k-step][cout block]: the LDS-DMA source pointer of
@@ -491,8 +498,8 @@ int far_conv_nhwc_f32(const float* x, const float* x2, int Cin1, const void* pac
     a.act = act; a.slope = slope;
     const long nbx = ksize == 1 ? (a.npix + 64 * c.mw - 1) / (64 * c.mw) : N * a.tilesX * a.tilesY;
     a.ntiles = nbx;
-    if (nbx > 0x7fffffffL) return FAR_EINVAL;
-    dim3 grid((unsigned)nbx, (unsigned)a.nblkY);
+    if (nbx * a.nblkY > 0x7fffffffL) return FAR_EINVAL;
+    dim3 grid((unsigned)(nbx * a.nblkY));
     if (stride == 2) return split ? launch_stride2<true>(a, grid, stream) : launch_stride2<false>(a, grid, stream);
     if (ksize == 3) return split ? launch_cfg<3, true>(c, a, grid, stream) : launch_cfg<3, false>(c, a, grid, stream);
     return split ? launch_cfg<1, true>(c, a, grid, stream) : launch_cfg<1, false>(c, a, grid, stream);
