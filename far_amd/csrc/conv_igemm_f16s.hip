@@ -203,6 +203,76 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const f32x16 (&
     }
 }
 
+// Wide epilogue (Cout, Csub multiples of 4): every 32-pixel x 128-channel accumulator tile of a wave goes through a
+// 16 KiB LDS transpose so that a lane ends up with 4 consecutive channels of one pixel: 16-byte residual loads and
+// 16-byte stores, each store instruction writing two whole 512-byte pixel rows (4x fewer memory instructions than
+// the per-register path above).  `lw` = this wave's private 32 x 128 float region; the caller has synchronised the
+// workgroup (the main loop's LDS buffers are dead).
+template <int KS>
+__device__ __forceinline__ void conv_epilogue_wide(const ConvArgs& p, const f32x16 (&acc)[2][4], const TilePos& tp,
+                                                   int cout_w, int wm, int lane, float* lw) {
+    const int l31 = lane & 31, h = lane >> 5;
+    const float* __restrict__ resp = p.res;
+    float* __restrict__ yp = p.y;
+    float sc[4], sh[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int co = cout_w + 32 * nt + l31;
+        sc[nt] = co < p.Cout ? p.scale[co] : 0.f;
+        sh[nt] = (co < p.Cout && p.shift) ? p.shift[co] : 0.f;
+    }
+    const int co4 = cout_w + 4 * l31;                      // this lane's 4 channels in the store phase
+    const bool cok = co4 < p.Cout;
+    const int plane = cok ? co4 / p.Csub : 0;
+    const long cbase = (long)plane * p.npix * p.Csub + (co4 - plane * p.Csub);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int mtile = 2 * wm + mt;
+        long pix0;
+        int nrow, ncol;
+        long left = 0;
+        if (KS == 1) {
+            pix0 = tp.pix0 + 32 * mtile;
+            left = p.npix - pix0;
+            nrow = 2; ncol = 16;
+        } else {
+            const int oy = tp.oy0 + 2 * mtile;
+            pix0 = ((long)tp.img * p.Ho + oy) * p.Wo + tp.ox0;
+            nrow = p.Ho - oy;
+            ncol = p.Wo - tp.ox0;
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = 16 * (r >> 3) + (r & 3) + 8 * ((r >> 2) & 1) + 4 * h;       // pixel of the tile
+                lw[q * 128 + 32 * nt + l31] = acc[mt][nt][r] * sc[nt] + sh[nt];
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // same wave: LDS executes its requests in order
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int q = 2 * it + h;
+            const int trow = q >> 4, tcol = q & 15;
+            const bool ok = cok && (KS == 1 ? (q < left) : (trow < nrow && tcol < ncol));
+            const long off = (pix0 + (KS == 1 ? q : trow * p.Wo + tcol)) * p.Csub + cbase;
+            float4 v = *reinterpret_cast<const float4*>(lw + q * 128 + 4 * l31);
+            if (ok) {
+                if (resp) {
+                    const float4 rr = *reinterpret_cast<const float4*>(resp + off);
+                    v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+                }
+                if (p.act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                else if (p.act == 2) {
+                    v.x = v.x > 0.f ? v.x : v.x * p.slope; v.y = v.y > 0.f ? v.y : v.y * p.slope;
+                    v.z = v.z > 0.f ? v.z : v.z * p.slope; v.w = v.w > 0.f ? v.w : v.w * p.slope;
+                }
+                *reinterpret_cast<float4*>(yp + off) = v;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // tile read back before the next one overwrites it
+    }
+}
+
 // Workgroup = MW x NW waves: wave (wm, wn) owns 64 pixels (4 tile rows x 16) x 32 NTW output channels.
 template <int KS, int MW, int NW, int NTW, bool SPLIT, int ST>
 __global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const ConvArgs p) {
@@ -380,7 +450,12 @@ __global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const 
         }
     }
 
-    conv_epilogue<KS, NTW>(p, acc, tp, cout_w, wm, l31, h);
+    if (NTW == 4 && ((p.Cout | p.Csub) & 3) == 0) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave is past its last LDS fragment read
+        conv_epilogue_wide<KS>(p, acc, tp, cout_w, wm, lane, reinterpret_cast<float*>(smem) + wave * (32 * 128));
+    } else {
+        conv_epilogue<KS, NTW>(p, acc, tp, cout_w, wm, l31, h);
+    }
 }
 
 // Packs torch-layout weights [Cout][Cin][KS][KS] (or [Cout][Cin] for linear) into the LDS image the kernel DMAs, in
@@ -421,7 +496,9 @@ template <int KS, int MW, int NW, int NTW, bool SPLIT, int ST = 1>
 int launch_conv(const ConvArgs& a, dim3 grid, hipStream_t stream) {
     using G = Geo<KS, MW, ST>;
     constexpr int PLANES = SPLIT ? 2 : 1;
-    constexpr int smem = PLANES * G::A_PLANE + 3 * PLANES * 32 * NTW * NW * 32;
+    constexpr int smem_loop = PLANES * G::A_PLANE + 3 * PLANES * 32 * NTW * NW * 32;
+    constexpr int smem_epi = MW * NW * 32 * 128 * 4;             // conv_epilogue_wide: 16 KiB per wave
+    constexpr int smem = smem_loop > smem_epi ? smem_loop : smem_epi;
     static bool configured = false;
     if (!configured) {
         if (hipFuncSetAttribute((const void*)k_conv<KS, MW, NW, NTW, SPLIT, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
