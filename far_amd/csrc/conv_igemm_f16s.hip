@@ -66,6 +66,7 @@ struct ConvArgs {
     const float* scale;          // [Cout] multiplies the accumulator (BN scale / 1, with the operand scaling folded in)
     const float* shift;          // [Cout] or null
     const float* res;            // residual, same layout as y, or null
+    int res_group;               // > 1: res is [npix / res_group][Cout], row pix / res_group is added to pixel pix
     float* y;
     long npix;                   // N * Ho * Wo output pixels (= input pixels for 1x1)
     long ntiles;                 // blocks along x
@@ -191,7 +192,17 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const f32x16 (&
             const long base = (long)plane * p.npix * p.Csub + pix0 * p.Csub + (co - plane * p.Csub);
             float rv[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) rv[r] = (resp && ok[r]) ? resp[base + delta[r]] : 0.f;
+            for (int r = 0; r < 16; ++r) {
+                rv[r] = 0.f;
+                if (resp && ok[r]) {
+                    if (p.res_group > 1) {        // one residual row per group of consecutive pixels (GEMM mode only)
+                        const long pix = pix0 + 16 * (r >> 3) + ((r & 3) + 8 * ((r >> 2) & 1) + 4 * h);
+                        rv[r] = resp[(pix / p.res_group) * p.Cout + co];
+                    } else {
+                        rv[r] = resp[base + delta[r]];
+                    }
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float v = acc[mt][nt][r] * sc + sh + rv[r];
@@ -258,7 +269,8 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvArgs& p, const f32x
             float4 v = *reinterpret_cast<const float4*>(lw + q * 128 + 4 * l31);
             if (ok) {
                 if (resp) {
-                    const float4 rr = *reinterpret_cast<const float4*>(resp + off);
+                    const long roff = p.res_group > 1 ? ((pix0 + q) / p.res_group) * (long)p.Cout + co4 : off;
+                    const float4 rr = *reinterpret_cast<const float4*>(resp + roff);
                     v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
                 }
                 if (p.act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
@@ -551,20 +563,24 @@ int far_conv_pack_f32(const float* w, int Cin, int Cout, int ksize, int stride, 
 // p = ksize / 2), all fp32 NHWC contiguous; stride s = 1, or 2 for ksize 3; Cin % 4 == 0, Cin1 % 8 == 0.
 // `scale` must include 2^-(w_exp + 4).  act: 0 none, 1 ReLU, 2 LeakyReLU(slope).  A linear layer is ksize = 1 with
 // N = H = 1, W = rows.  out_planes > 1: output channel co goes to plane co / (Cout / out_planes) of y, laid out
-// [out_planes][N][Ho][Wo][Cout / out_planes] (fused projections, e.g. q | k | v); res, if given, has y's layout.
+// [out_planes][N][Ho][Wo][Cout / out_planes] (fused projections, e.g. q | k | v); res, if given, has y's layout, or
+// with res_group = G > 1 (linear layers) is [rows / G][Cout]: every group of G consecutive rows shares one residual
+// row (fine_preprocess.py:52-57: the coarse feature of a match, repeated over its 25 window tokens).
 // y must alias none of the inputs.
 int far_conv_nhwc_f32(const float* x, const float* x2, int Cin1, const void* packed, const float* scale,
                       const float* shift, const float* res, long N, int H, int W, int Cin, int Cout, int ksize,
-                      int stride, int act, float slope, int split, int out_planes, float* y, hipStream_t stream) {
+                      int stride, int act, float slope, int split, int out_planes, int res_group, float* y,
+                      hipStream_t stream) {
     far_clear_errors();
     if (N == 0) return FAR_OK;
     if (!x || !packed || !scale || !y || N < 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) || Cout <= 0 ||
         (ksize != 1 && ksize != 3) || stride < 1 || stride > 2 || (stride == 2 && ksize != 3) || act < 0 || act > 2 ||
         x == y || x2 == y || out_planes < 1 || Cout % out_planes)
         return FAR_EINVAL;
+    if (res_group < 1 || (res_group > 1 && (!res || ksize != 1 || out_planes != 1 || (N * H * W) % res_group))) return FAR_EINVAL;
     if (x2 ? (Cin1 <= 0 || Cin1 >= Cin || (Cin1 & 7)) : (Cin1 != Cin)) return FAR_EINVAL;
     ConvArgs a;
-    a.x = x; a.x2 = x2; a.Cin1 = Cin1; a.w = (const unsigned char*)packed; a.scale = scale; a.shift = shift; a.res = res; a.y = y;
+    a.x = x; a.x2 = x2; a.Cin1 = Cin1; a.w = (const unsigned char*)packed; a.scale = scale; a.shift = shift; a.res = res; a.res_group = res_group; a.y = y;
     a.H = H; a.W = W; a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1; a.Cin = Cin; a.Cout = Cout; a.Csub = Cout / out_planes;
     a.npix = N * a.Ho * a.Wo;
     const TileCfg c = cfg_for(Cout, stride);

@@ -166,8 +166,22 @@ class FinePreprocess(nn.Module):
             w1 = ops.fine_gather(feat_f1.float(), b, j, data['hw1_c'][1], W, stride)
         if self.cat_c_feat:
             c_win = self.down_proj(torch.cat([feat_c0[b, i], feat_c1[b, j]], 0))     # [2M, C]
-            both = torch.cat([torch.cat([w0, w1], 0), c_win.unsqueeze(1).expand(-1, W ** 2, -1)], -1)
-            w0, w1 = torch.chunk(self.merge_feat(both), 2, dim=0)
+            if ag.needs_grad(w0, w1, c_win, self.merge_feat.weight) or not w0.is_cuda:
+                both = torch.cat([torch.cat([w0, w1], 0), c_win.unsqueeze(1).expand(-1, W ** 2, -1)], -1)
+                w0, w1 = torch.chunk(self.merge_feat(both), 2, dim=0)
+            else:
+                # merge_feat(cat[window, repeat(c_win)]) = window W_f^T + (c_win W_c^T + b) repeated over the WW tokens
+                # (:52-57): neither the repeat nor the (2M, 25, 256) concatenation is materialised -- K9 adds one
+                # residual row per group of WW consecutive rows.
+                d = self.d_model_f
+                pk = self.__dict__.setdefault('_packs', ops.PackCache())
+                wt = self.merge_feat.weight
+                pf = pk.get('merge_f', [wt], lambda: ops.PackedConv(wt[:, :d].contiguous()))
+                pc = pk.get('merge_c', [wt, self.merge_feat.bias],
+                            lambda: ops.PackedConv(wt[:, d:].contiguous(), None, self.merge_feat.bias))
+                cw = ops.linear_f16s(c_win.contiguous(), pc)                          # (2M, d)
+                both = ops.linear_f16s(torch.cat([w0, w1], 0), pf, residual=cw, res_group=W ** 2)
+                w0, w1 = torch.chunk(both, 2, dim=0)
         return w0, w1
 
 

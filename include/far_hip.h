@@ -194,10 +194,14 @@ int far_conv_pack_f32(const float* w, int Cin, int Cout, int ksize, int stride, 
  * act: 0 none, 1 ReLU, 2 LeakyReLU(slope).  A linear layer y = x W^T + b is ksize = 1, N = H = 1, W = rows, shift = b.
  * out_planes > 1 splits the output channels into that many separate contiguous tensors, y = [out_planes][N][Ho][Wo]
  * [Cout / out_planes] (fused projections: transformer.py:45-47 q_proj / k_proj / v_proj in one launch).
+ * res_group = G > 1 (ksize 1): res is [N H W / G][Cout] and row pix / G is added to pixel pix -- one residual row
+ * per group of G consecutive rows (fine_preprocess.py:52-57: repeat(feat_c_win, 'n c -> n ww c') + Linear, without
+ * materialising the repeat or the concatenation); G = 1: res has y's layout.
  * y must alias none of the inputs. */
 int far_conv_nhwc_f32(const float* x, const float* x2, int Cin1, const void* packed, const float* scale,
                       const float* shift, const float* res, long N, int H, int W, int Cin, int Cout, int ksize,
-                      int stride, int act, float slope, int split, int out_planes, float* y, far_stream_t stream);
+                      int stride, int act, float slope, int split, int out_planes, int res_group, float* y,
+                      far_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * K10  backbone stem: 7x7 stride-2 convolution of a 1-channel image + folded BatchNorm + ReLU (exact-f32 MFMA)

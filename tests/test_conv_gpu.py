@@ -233,3 +233,20 @@ def test_pack_cache_follows_weight_updates():
         sd = {k: v * (1.1 if k.endswith('layer3_outconv.weight') else 1.0) for k, v in bb.state_dict().items()}
     bb.load_state_dict(sd)                                       # copy_ into the same storage: version bump
     check()
+
+
+def test_linear_grouped_residual():
+    """res_group: one residual row per group of consecutive rows (the repeated coarse feature of FinePreprocess)."""
+    ops = _ops()
+    g = torch.Generator(device='cuda').manual_seed(14)
+    M, G, K, Co = 333, 25, 128, 128
+    x = torch.randn(M, G, K, device='cuda', generator=g)
+    r = torch.randn(M, Co, device='cuda', generator=g)
+    w = torch.randn(Co, K, device='cuda', generator=g) * 0.08
+    y = ops.linear_f16s(x, ops.PackedConv(w), residual=r, res_group=G)
+    ref = x.double() @ w.double().t() + r.double()[:, None, :]
+    assert y.shape == (M, G, Co) and _rel(y, ref)[0] < 4e-6
+    w2 = torch.randn(196, K, device='cuda', generator=g) * 0.08          # narrow (per-register) epilogue path: Cout 196 -> planes
+    r2 = torch.randn(M, 196, device='cuda', generator=g)
+    y2 = ops.linear_f16s(x, ops.PackedConv(w2), residual=r2, res_group=G)
+    assert _rel(y2, x.double() @ w2.double().t() + r2.double()[:, None, :])[0] < 4e-6
