@@ -161,9 +161,11 @@ class FinePreprocess(nn.Module):
         if ag.needs_grad(feat_f0, feat_f1):
             w0 = ag.fine_windows(feat_f0, b, i, W, stride)
             w1 = ag.fine_windows(feat_f1, b, j, W, stride)
-        else:
-            w0 = ops.fine_gather(feat_f0.float(), b, i, data['hw0_c'][1], W, stride)
-            w1 = ops.fine_gather(feat_f1.float(), b, j, data['hw1_c'][1], W, stride)
+        else:       # both images' windows into the halves of one buffer: the later cat([w0, w1]) is then free
+            M = b.shape[0]
+            w01 = torch.empty(2 * M, W ** 2, feat_f0.shape[1], dtype=torch.float32, device=feat_f0.device)
+            w0 = ops.fine_gather(feat_f0.float(), b, i, data['hw0_c'][1], W, stride, out=w01[:M])
+            w1 = ops.fine_gather(feat_f1.float(), b, j, data['hw1_c'][1], W, stride, out=w01[M:])
         if self.cat_c_feat:
             c_win = self.down_proj(torch.cat([feat_c0[b, i], feat_c1[b, j]], 0))     # [2M, C]
             if ag.needs_grad(w0, w1, c_win, self.merge_feat.weight) or not w0.is_cuda:
@@ -180,7 +182,7 @@ class FinePreprocess(nn.Module):
                 pc = pk.get('merge_c', [wt, self.merge_feat.bias],
                             lambda: ops.PackedConv(wt[:, d:].contiguous(), None, self.merge_feat.bias))
                 cw = ops.linear_f16s(c_win.contiguous(), pc)                          # (2M, d)
-                both = ops.linear_f16s(torch.cat([w0, w1], 0), pf, residual=cw, res_group=W ** 2)
+                both = ops.linear_f16s(w01, pf, residual=cw, res_group=W ** 2)
                 w0, w1 = torch.chunk(both, 2, dim=0)
         return w0, w1
 

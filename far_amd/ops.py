@@ -130,13 +130,16 @@ def emm_bilinear_planes(qkv, pos, scale, B):
     return torch.bmm(vt.transpose(1, 2), T), T
 
 
-def fine_gather(feat_f, b_ids, cell_ids, wc, W, stride):
+def fine_gather(feat_f, b_ids, cell_ids, wc, W, stride, out=None):
     """K3a.  feat_f: (N, C, Hf, Wf) fp32 in any strided layout (channels_last is the fast one).
-    Returns (M, W*W, C): the windows F.unfold would have produced at the matched cells."""
+    Returns (M, W*W, C): the windows F.unfold would have produced at the matched cells (written into `out` if given)."""
     lib = _lib.load()
     M = int(b_ids.shape[0])
     N, C, Hf, Wf = feat_f.shape
-    out = torch.empty(M, W * W, C, dtype=torch.float32, device=feat_f.device)
+    if out is None:
+        out = torch.empty(M, W * W, C, dtype=torch.float32, device=feat_f.device)
+    elif tuple(out.shape) != (M, W * W, C) or not out.is_contiguous() or out.dtype != torch.float32:
+        raise _lib.FarHipError('fine_gather: `out` must be a contiguous fp32 (M, W*W, C) tensor')
     if M == 0:
         return out
     if not feat_f.is_cuda or feat_f.dtype != torch.float32:
