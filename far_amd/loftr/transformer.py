@@ -65,7 +65,7 @@ class LoFTREncoderLayer(nn.Module):
         self.norm1 = nn.LayerNorm(d_model)
         self.norm2 = nn.LayerNorm(d_model)
 
-    def forward(self, x, source, x_mask=None, source_mask=None, loftr_preds=None):
+    def forward(self, x, source, x_mask=None, source_mask=None, loftr_preds=None, out=None):
         bs = x.size(0)
         if ag.needs_grad(x, source, self.norm1.weight) or not x.is_cuda:     # training: reference-style modules
             q = self.q_proj(x).view(bs, -1, self.nhead, self.dim)
@@ -102,7 +102,7 @@ class LoFTREncoderLayer(nn.Module):
         h = ops.linear_f16s(x, lin('mlp0', self.mlp[0]), act='relu', x2=msg)
         h = ops.linear_f16s(h, lin('mlp2', self.mlp[2]))
         # norm2 and the residual `x + message` in one pass (:65-67)
-        return ops.layernorm(h, self.norm2.weight, self.norm2.bias, self.norm2.eps, residual=x)
+        return ops.layernorm(h, self.norm2.weight, self.norm2.bias, self.norm2.eps, residual=x, out=out)
 
 
 class LocalFeatureTransformer(nn.Module):
@@ -121,15 +121,26 @@ class LocalFeatureTransformer(nn.Module):
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
 
-    def forward(self, feat0, feat1, mask0=None, mask1=None, loftr_preds=None, inv_loftr_preds=None):
+    def forward(self, feat0, feat1, mask0=None, mask1=None, loftr_preds=None, inv_loftr_preds=None, joint_out=False):
+        """joint_out (inference): the last layer writes feat0 / feat1 into the two halves of one (2N, L, C) buffer,
+        so that a consumer of cat([feat0, feat1], 0) (the EMM head, transformer.py:488) gets it without a copy."""
         assert self.d_model == feat0.size(2), "the feature number of src and transformer must be equal"
-        for layer, name in zip(self.layers, self.layer_names):
+        joint_out = joint_out and feat0.is_cuda and feat0.shape == feat1.shape and not ag.needs_grad(feat0, feat1)
+        n = feat0.size(0)
+        last = len(self.layers) - 1
+        for li, (layer, name) in enumerate(zip(self.layers, self.layer_names)):
+            o0 = o1 = None
+            if joint_out and li == last:
+                buf = torch.empty(2 * n, *feat0.shape[1:], dtype=torch.float32, device=feat0.device)
+                o0, o1 = buf[:n], buf[n:]
+            kw0 = {} if o0 is None else {'out': o0}
+            kw1 = {} if o1 is None else {'out': o1}
             if name == 'self':
-                feat0 = layer(feat0, feat0, mask0, mask0, inv_loftr_preds)
-                feat1 = layer(feat1, feat1, mask1, mask1, loftr_preds)
+                feat0 = layer(feat0, feat0, mask0, mask0, inv_loftr_preds, **kw0)
+                feat1 = layer(feat1, feat1, mask1, mask1, loftr_preds, **kw1)
             elif name == 'cross':
-                feat0 = layer(feat0, feat1, mask0, mask1, inv_loftr_preds)
-                feat1 = layer(feat1, feat0, mask1, mask0, loftr_preds)  # uses the UPDATED feat0 (:107-108)
+                feat0 = layer(feat0, feat1, mask0, mask1, inv_loftr_preds, **kw0)
+                feat1 = layer(feat1, feat0, mask1, mask0, loftr_preds, **kw1)  # uses the UPDATED feat0 (:107-108)
             else:
                 raise KeyError(name)
         return feat0, feat1
@@ -304,9 +315,12 @@ class LocalFeatureTransformerRegressor(nn.Module):
                 return self._feat_cache[1]
         f0, f1 = feat0, feat1
         if self.config['regress_loftr_layers'] > 0:
-            f0, f1 = self.loftr(f0, f1, loftr_preds=loftr_preds, inv_loftr_preds=inv_loftr_preds)
+            f0, f1 = self.loftr(f0, f1, loftr_preds=loftr_preds, inv_loftr_preds=inv_loftr_preds, joint_out=True)
         B = f0.shape[0]
-        x = self.emm(torch.cat([f0, f1], dim=0), loftr_preds=loftr_preds, inv_loftr_preds=inv_loftr_preds)
+        adjacent = (f0.is_cuda and f0.is_contiguous() and f1.is_contiguous() and
+                    f1.data_ptr() == f0.data_ptr() + f0.numel() * f0.element_size())
+        x01 = torch.as_strided(f0, (2 * B,) + tuple(f0.shape[1:]), f0.stride()) if adjacent else torch.cat([f0, f1], dim=0)
+        x = self.emm(x01, loftr_preds=loftr_preds, inv_loftr_preds=inv_loftr_preds)
         features = self.norm(x).reshape([B, -1])
         # hold references to the inputs so that their storage (hence data_ptr) cannot be recycled while cached
         self._feat_cache = (key, features, feat0, feat1) if key is not None else None

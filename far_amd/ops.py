@@ -225,12 +225,15 @@ def solve_pose_batch(kpts0, kpts1, offsets_host, K0, K1, inl_th, many_thr, prior
     return out
 
 
-def layernorm(x, weight, bias, eps=1e-5, residual=None):
-    """K6.  LayerNorm over the last dim (+ residual).  x: (..., C) fp32 contiguous GPU tensor."""
+def layernorm(x, weight, bias, eps=1e-5, residual=None, out=None):
+    """K6.  LayerNorm over the last dim (+ residual).  x: (..., C) fp32 contiguous GPU tensor; `out`: optional
+    contiguous destination of the same shape (e.g. one half of a buffer that a later stage wants concatenated)."""
     lib = _lib.load()
     C = x.shape[-1]
     rows = x.numel() // C
-    y = torch.empty_like(x)
+    y = torch.empty_like(x) if out is None else out
+    if y.shape != x.shape:
+        raise _lib.FarHipError('layernorm: `out` must have the shape of x')
     rc = lib.far_layernorm_f32(_p(x, torch.float32), _p(weight, torch.float32), _p(bias, torch.float32),
                                _p(residual, torch.float32), rows, C, float(eps), _p(y), _stream())
     _lib.check(rc, 'far_layernorm_f32')

@@ -1,7 +1,11 @@
-import json
-plain=open('/root/repo/gpurun_out/bench_plain.log').read().strip().splitlines()[-1]
-prof=open('/root/repo/gpurun_out/bench_prof.log').read().strip().splitlines()[-1]
-tr=open('/root/repo/gpurun_out/r01c_trace.txt').read()
+"""Assembles profiles/r01_bench_fp32_kernel_trace.txt from the files a profiling gpurun call leaves in gpurun_out/:
+  bench_prof.log (bench.py under rocprofv3), r01c_trace.txt (tools/profile_report.py on the rocpd database),
+  bench_plain.log (the un-profiled python bench.py)."""
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+plain=open(ROOT + '/gpurun_out/bench_plain.log').read().strip().splitlines()[-1]
+prof=open(ROOT + '/gpurun_out/bench_prof.log').read().strip().splitlines()[-1]
+tr=open(ROOT + '/gpurun_out/r01c_trace.txt').read()
 whole,win=tr.split('\n\n',1)
 out=f"""# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 3 --no-cpu-baseline    (round 1, 1x MI355X, default fp32-grade path)
 # bench line of the same profiled run:
@@ -16,4 +20,4 @@ out=f"""# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmu
 ## whole process (includes the warm-up steps and the isolated kernel timings of bench.kernel_rooflines)
 {whole.strip()}
 """
-open('/root/repo/profiles/r01_bench_fp32_kernel_trace.txt','w').write(out)
+open(ROOT + '/profiles/r01_bench_fp32_kernel_trace.txt','w').write(out)
