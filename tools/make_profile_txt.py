@@ -3,8 +3,9 @@
   bench_plain.log (the un-profiled python bench.py)."""
 import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-plain=open(ROOT + '/gpurun_out/bench_plain.log').read().strip().splitlines()[-1]
-prof=open(ROOT + '/gpurun_out/bench_prof.log').read().strip().splitlines()[-1]
+last_json = lambda path: [l for l in open(path).read().splitlines() if l.startswith('{')][-1]
+plain=last_json(ROOT + '/gpurun_out/bench_plain.log')
+prof=last_json(ROOT + '/gpurun_out/bench_prof.log')
 tr=open(ROOT + '/gpurun_out/r01c_trace.txt').read()
 whole,win=tr.split('\n\n',1)
 out=f"""# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 3 --no-cpu-baseline    (round 1, 1x MI355X, default fp32-grade path)
