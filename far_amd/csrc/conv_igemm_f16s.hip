@@ -28,7 +28,10 @@
 //    (global_load_lds_dwordx4) into a ring of three slabs, two phases ahead (counted vmcnt + raw s_barrier: the
 //    barrier never drains the DMA queue).  One barrier per phase.
 //  * per phase and wave: 12 ds_read_b128 fragment reads (the pixel fragments one phase ahead, the weight fragments in
-//    two halves, the second behind the first half's MFMAs) and 24 MFMAs (split) / 8 (plain).
+//    two halves, the second behind the first half's MFMAs) and 24 MFMAs (split) / 8 (plain).  The phase body is one
+//    basic block (unconditional slab request, taps and k-steps unrolled) whose issue order is pinned with
+//    sched_group_barrier: one MFMA, then the LDS reads / DMA requests / address arithmetic that fit in the issue
+//    slots its 32-cycle pass leaves free (+5-7 % over letting them queue up in front of the MFMA block).
 // Measured on MI355X (64 images, tools/conv_probe.py): 3x3 layers 270-380 TFLOP/s fp32-equivalent (0.8-1.2 PFLOP/s of
 // f16 MFMA issue, ~47 % of the matrix peak) including the fused epilogue, against 100-125 TFLOP/s for the vendor
 // fp32 Winograd convolution alone.
@@ -337,23 +340,22 @@ __global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const 
     const int last_nks = (p.Cin - 32 * (nchunks - 1)) > 16 ? 2 : 1;
     const size_t slab_stride = (size_t)p.nblkY * B_BUF;
     const unsigned char* wsrc = p.w + (size_t)by * B_BUF + tid * 16;
-    int pc = 0, pt = 0, pk = 0, pslot = 0;          // (chunk, tap, k-step) of the next slab to request, ring slot
+    // The request is unconditional (no branch in the phase body): past the last slab it re-reads that slab into the
+    // ring slot nobody reads any more.  Slabs are stored in execution order; when the all-padding second k-step of
+    // the last chunk is skipped, the pointer advances by two slabs there.
+    const int nslab = ((nchunks - 1) * 2 + last_nks) * TAPS;
+    const int first_last = (nchunks - 1) * 2 * TAPS;           // first slab of the last chunk
+    int pidx = 0, pslot = 0;
     auto prefetch = [&]() {
-        if (pc < nchunks) {
-            unsigned char* dst = Bs + pslot * B_BUF + wave * 1024;
+        unsigned char* dst = Bs + pslot * B_BUF + wave * 1024;
 #pragma unroll
-            for (int j = 0; j < B_ITERS; ++j)
-                if ((j + 1) * NTHR * 16 <= B_BUF || j * NTHR * 16 + wave * 1024 < B_BUF)       // wave-uniform
-                    __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + j * (NTHR * 16)), (lptr_t)(dst + j * (NTHR * 16)), 16, 0, 0);
-            pslot = pslot == 2 ? 0 : pslot + 1;
-            const int nks = pc == nchunks - 1 ? last_nks : 2;
-            wsrc += slab_stride;
-            if (++pk == nks) {
-                if (nks == 1) wsrc += slab_stride;
-                pk = 0;
-                if (++pt == TAPS) { pt = 0; ++pc; }
-            }
-        }
+        for (int j = 0; j < B_ITERS; ++j)
+            if ((j + 1) * NTHR * 16 <= B_BUF || j * NTHR * 16 + wave * 1024 < B_BUF)       // wave-uniform, static
+                __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + j * (NTHR * 16)), (lptr_t)(dst + j * (NTHR * 16)), 16, 0, 0);
+        pslot = pslot == 2 ? 0 : pslot + 1;
+        const size_t adv = (pidx >= first_last && last_nks == 1) ? 2 * slab_stride : slab_stride;
+        ++pidx;
+        wsrc += pidx < nslab ? adv : 0;
     };
 
     // ---- per-lane fragment offsets
@@ -426,13 +428,15 @@ __global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const 
     int slot = 0;
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const int nks = chunk == nchunks - 1 ? last_nks : 2;
+#pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
-            for (int ks = 0; ks < nks; ++ks) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                if (ks >= nks) continue;                                      // between phases; the body is branch free
                 const bool first = tap == 0 && ks == 0;                       // first phase of a chunk
                 const bool last = tap == TAPS - 1 && ks == nks - 1;           // last phase of a chunk
-                // this phase's slab has landed once at most the younger slab's DMAs are outstanding
-                if (pc < nchunks || pslot != (slot == 2 ? 0 : slot + 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B_ITERS) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // this phase's slab has landed once only the younger slab's DMAs are outstanding
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B_ITERS) : "memory");
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 const unsigned char* B = Bs + slot * B_BUF + b_off;
                 read_b(0, B);
@@ -441,16 +445,23 @@ __global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const 
                 prefetch();
                 if (tap == LOAD_TAP && ks == 0 && chunk + 1 < nchunks) stage_load<KS, MW, ST, NTHR, ITERS>(st, p, tp, chunk + 1, tid);
                 read_b(1, B);
-                __builtin_amdgcn_sched_barrier(0);
                 mma_half(0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (APRE && !last) {
-                    const int ntap = ks + 1 == nks ? tap + 1 : tap, nk = ks + 1 == nks ? 0 : ks + 1;
-                    read_a(ahn, aln, ntap, nk);
+                if (APRE && !(tap == TAPS - 1 && ks == 1)) {       // pixel fragments of the next phase of this chunk
+                    const bool wrap = ks + 1 >= nks;               // (a skipped second k-step makes the next phase (tap + 1, 0))
+                    read_a(ahn, aln, wrap ? tap + 1 : tap, wrap ? 0 : 1);
+                }
+                mma_half(1);
+                // issue order: one MFMA, then the other instructions of the phase (LDS reads, the DMA requests and
+                // their address arithmetic) in the issue slots its 32-cycle pass leaves free
+#pragma unroll
+                for (int i = 0; i < (SPLIT ? 6 : 2) * NTW; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // DS read
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // VMEM read (LDS-DMA, pixel loads)
+                    __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);      // VALU / SALU
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                mma_half(1);
-                __builtin_amdgcn_sched_barrier(0);
+                (void)last;
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) if (APRE) { ah[mt] = ahn[mt]; al[mt] = aln[mt]; }
                 slot = slot == 2 ? 0 : slot + 1;
@@ -461,6 +472,7 @@ __global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const 
             stage_store<KS, MW, ST, NTHR, ITERS, SPLIT>(st, As, tid);
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the trailing (unused) slab requests must land before LDS is reused
 
     if (NTW == 4 && ((p.Cout | p.Csub) & 3) == 0) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave is past its last LDS fragment read
