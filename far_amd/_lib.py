@@ -42,7 +42,7 @@ SIGNATURES = {
     'far_upsample2x_add_f32': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     'far_conv_packed_bytes': (c_sz, [c_i, c_i, c_i, c_i, c_i]),
     'far_conv_pack_f32': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
-    'far_conv_nhwc_f32': (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_p, c_p]),
+    'far_conv_nhwc_f32': (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_p, c_p, c_f, c_p, c_p, c_p]),
     'far_emm_pv_f16s_workspace_bytes': (c_sz, [c_i, c_i]),
     'far_emm_pv_f16s': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_i, c_l, c_l, c_i, c_p, c_p, c_p]),
     'far_stem7x7_nhwc_f32': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),

@@ -70,6 +70,10 @@ struct ConvArgs {
     const float* shift;          // [Cout] or null
     const float* res;            // residual, same layout as y, or null
     int res_group;               // > 1: res is [npix / res_group][Cout], row pix / res_group is added to pixel pix
+    const float* ln_gamma;       // fused LayerNorm over the Cout channels of every pixel (after res / act), or null
+    const float* ln_beta;
+    float ln_eps;
+    const float* post_res;       // added after the LayerNorm (y's layout), or null
     float* y;
     long npix;                   // N * Ho * Wo output pixels (= input pixels for 1x1)
     long ntiles;                 // blocks along x
@@ -217,14 +221,25 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const f32x16 (&
     }
 }
 
+// Sum over the 32 lanes of each half-wave, result in every lane: DPP butterflies inside the 16-lane rows, one
+// cross-row exchange.
+#define FAR_DPP_F(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true))
+__device__ __forceinline__ float sum32(float v) {
+    v += FAR_DPP_F(v, 0xB1);       // quad_perm [1,0,3,2]
+    v += FAR_DPP_F(v, 0x4E);       // quad_perm [2,3,0,1]
+    v += FAR_DPP_F(v, 0x141);      // row_half_mirror
+    v += FAR_DPP_F(v, 0x140);      // row_mirror
+    return v + shfl_xor_f(v, 16);
+}
+
 // Wide epilogue (Cout, Csub multiples of 4): every 32-pixel x 128-channel accumulator tile of a wave goes through a
 // 16 KiB LDS transpose so that a lane ends up with 4 consecutive channels of one pixel: 16-byte residual loads and
 // 16-byte stores, each store instruction writing two whole 512-byte pixel rows (4x fewer memory instructions than
 // the per-register path above).  `lw` = this wave's private 32 x 128 float region; the caller has synchronised the
 // workgroup (the main loop's LDS buffers are dead).
-template <int KS>
+template <int KS, int NW>
 __device__ __forceinline__ void conv_epilogue_wide(const ConvArgs& p, const f32x16 (&acc)[2][4], const TilePos& tp,
-                                                   int cout_w, int wm, int lane, float* lw) {
+                                                   int cout_w, int wm, int wave, int lane, float* lw, float* xch) {
     const int l31 = lane & 31, h = lane >> 5;
     const float* __restrict__ resp = p.res;
     float* __restrict__ yp = p.y;
@@ -263,6 +278,63 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvArgs& p, const f32x
                 lw[q * 128 + 32 * nt + l31] = acc[mt][nt][r] * sc[nt] + sh[nt];
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // same wave: LDS executes its requests in order
+        if (p.ln_gamma) {
+            // ---- fused LayerNorm (transformer.py:61, 65-67): the whole channel row of a pixel is in this wave's tile
+            // (Cout = 128) or in the tiles of the two waves that share its pixels (Cout = 256, partial sums exchanged
+            // through `xch`): two-pass mean / variance like K6, then gamma, beta and the post-norm residual.
+            float4 vv[16];
+            float part[16];
+            const float4 g4 = *reinterpret_cast<const float4*>(p.ln_gamma + co4), b4 = *reinterpret_cast<const float4*>(p.ln_beta + co4);
+            const float inv_c = 1.0f / (float)p.Cout;
+            auto all_rows = [&](float (&x)[16]) {               // sum over the channel row of every pixel
+#pragma unroll
+                for (int it = 0; it < 16; ++it) x[it] = sum32(x[it]);
+                if (NW == 2) {
+                    __syncthreads();                             // previous exchange consumed
+                    if (l31 == 0) {
+#pragma unroll
+                        for (int it = 0; it < 16; ++it) xch[wave * 32 + 2 * it + h] = x[it];
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int it = 0; it < 16; ++it) x[it] += xch[(wave ^ 1) * 32 + 2 * it + h];
+                }
+            };
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int q = 2 * it + h;
+                vv[it] = *reinterpret_cast<const float4*>(lw + q * 128 + 4 * l31);
+                part[it] = (vv[it].x + vv[it].y) + (vv[it].z + vv[it].w);
+            }
+            all_rows(part);
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const float mean = part[it] * inv_c;
+                vv[it].x -= mean; vv[it].y -= mean; vv[it].z -= mean; vv[it].w -= mean;
+                part[it] = (vv[it].x * vv[it].x + vv[it].y * vv[it].y) + (vv[it].z * vv[it].z + vv[it].w * vv[it].w);
+            }
+            all_rows(part);
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int q = 2 * it + h;
+                const int trow = q >> 4, tcol = q & 15;
+                const bool ok = cok && (KS == 1 ? (q < left) : (trow < nrow && tcol < ncol));
+                const long off = (pix0 + (KS == 1 ? q : trow * p.Wo + tcol)) * p.Csub + cbase;
+                const float rstd = 1.0f / sqrtf(part[it] * inv_c + p.ln_eps);
+                float4 o;
+                o.x = vv[it].x * rstd * g4.x + b4.x; o.y = vv[it].y * rstd * g4.y + b4.y;
+                o.z = vv[it].z * rstd * g4.z + b4.z; o.w = vv[it].w * rstd * g4.w + b4.w;
+                if (ok) {
+                    if (p.post_res) {
+                        const float4 rr = *reinterpret_cast<const float4*>(p.post_res + off);
+                        o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+                    }
+                    *reinterpret_cast<float4*>(yp + off) = o;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            continue;
+        }
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
             const int q = 2 * it + h;
@@ -476,7 +548,8 @@ __global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const 
 
     if (NTW == 4 && ((p.Cout | p.Csub) & 3) == 0) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave is past its last LDS fragment read
-        conv_epilogue_wide<KS>(p, acc, tp, cout_w, wm, lane, reinterpret_cast<float*>(smem) + wave * (32 * 128));
+        conv_epilogue_wide<KS, NW>(p, acc, tp, cout_w, wm, wave, lane, reinterpret_cast<float*>(smem) + wave * (32 * 128),
+                                   reinterpret_cast<float*>(smem) + MW * NW * (32 * 128));
     } else {
         conv_epilogue<KS, NTW>(p, acc, tp, cout_w, wm, l31, h);
     }
@@ -521,7 +594,7 @@ int launch_conv(const ConvArgs& a, dim3 grid, hipStream_t stream) {
     using G = Geo<KS, MW, ST>;
     constexpr int PLANES = SPLIT ? 2 : 1;
     constexpr int smem_loop = PLANES * G::A_PLANE + 3 * PLANES * 32 * NTW * NW * 32;
-    constexpr int smem_epi = MW * NW * 32 * 128 * 4;             // conv_epilogue_wide: 16 KiB per wave
+    constexpr int smem_epi = MW * NW * (32 * 128 * 4 + 32 * 4);  // conv_epilogue_wide: 16 KiB per wave + LayerNorm exchange
     constexpr int smem = smem_loop > smem_epi ? smem_loop : smem_epi;
     static bool configured = false;
     if (!configured) {
@@ -581,7 +654,8 @@ int far_conv_pack_f32(const float* w, int Cin, int Cout, int ksize, int stride, 
 // y must alias none of the inputs.
 int far_conv_nhwc_f32(const float* x, const float* x2, int Cin1, const void* packed, const float* scale,
                       const float* shift, const float* res, long N, int H, int W, int Cin, int Cout, int ksize,
-                      int stride, int act, float slope, int split, int out_planes, int res_group, float* y,
+                      int stride, int act, float slope, int split, int out_planes, int res_group,
+                      const float* ln_gamma, const float* ln_beta, float ln_eps, const float* post_res, float* y,
                       hipStream_t stream) {
     far_clear_errors();
     if (N == 0) return FAR_OK;
@@ -593,9 +667,12 @@ int far_conv_nhwc_f32(const float* x, const float* x2, int Cin1, const void* pac
     if (x2 ? (Cin1 <= 0 || Cin1 >= Cin || (Cin1 & 7)) : (Cin1 != Cin)) return FAR_EINVAL;
     ConvArgs a;
     a.x = x; a.x2 = x2; a.Cin1 = Cin1; a.w = (const unsigned char*)packed; a.scale = scale; a.shift = shift; a.res = res; a.res_group = res_group; a.y = y;
+    a.ln_gamma = ln_gamma; a.ln_beta = ln_beta; a.ln_eps = ln_eps; a.post_res = post_res;
     a.H = H; a.W = W; a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1; a.Cin = Cin; a.Cout = Cout; a.Csub = Cout / out_planes;
     a.npix = N * a.Ho * a.Wo;
     const TileCfg c = cfg_for(Cout, stride);
+    if ((ln_gamma || post_res) && (!ln_gamma || !ln_beta || Cout != c.nt || out_planes != 1 || (Cout & 3) || post_res == y))
+        return FAR_EINVAL;                    // the fused LayerNorm needs the whole channel row in one block (Cout 128 or 256)
     const int th = 4 * c.mw;
     a.tilesX = (a.Wo + TW - 1) / TW; a.tilesY = (a.Ho + th - 1) / th;
     a.nchunks = (Cin + 31) / 32;

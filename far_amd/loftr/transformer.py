@@ -96,13 +96,14 @@ class LoFTREncoderLayer(nn.Module):
             v = ops.linear_f16s(source, lin('v', self.v_proj))
         q, k, v = heads(q), heads(k), heads(v)
         msg = self.attention(q, k, v, q_mask=x_mask, kv_mask=source_mask, loftr_preds=loftr_preds)
-        msg = ops.linear_f16s(msg.view(bs, -1, self.nhead * self.dim), lin('merge', self.merge))
-        msg = ops.layernorm(msg, self.norm1.weight, self.norm1.bias, self.norm1.eps)                       # :61
+        # merge + norm1 (:60-61) in one launch: the LayerNorm runs in the Linear layer's epilogue
+        msg = ops.linear_f16s(msg.view(bs, -1, self.nhead * self.dim), lin('merge', self.merge),
+                              ln=(self.norm1.weight, self.norm1.bias, self.norm1.eps))
         # mlp[0](cat[x, msg]) reads both inputs in place (:64), ReLU in the epilogue
         h = ops.linear_f16s(x, lin('mlp0', self.mlp[0]), act='relu', x2=msg)
-        h = ops.linear_f16s(h, lin('mlp2', self.mlp[2]))
-        # norm2 and the residual `x + message` in one pass (:65-67)
-        return ops.layernorm(h, self.norm2.weight, self.norm2.bias, self.norm2.eps, residual=x, out=out)
+        # mlp[2] + norm2 + the residual `x + message` (:65-67) in one launch
+        return ops.linear_f16s(h, lin('mlp2', self.mlp[2]), ln=(self.norm2.weight, self.norm2.bias, self.norm2.eps),
+                               post_residual=x, out=out)
 
 
 class LocalFeatureTransformer(nn.Module):

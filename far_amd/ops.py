@@ -341,7 +341,8 @@ class PackCache:
         return hit[1]
 
 
-def conv_nhwc(x, pc, residual=None, act='none', slope=0.01, x2=None, out_planes=1, res_group=1):
+def conv_nhwc(x, pc, residual=None, act='none', slope=0.01, x2=None, out_planes=1, res_group=1, ln=None,
+              post_residual=None, out=None):
     """K9.  x (N, H, W, Cin) fp32 contiguous -> act(conv(x) * scale + shift (+ residual)) as (N, H, W, Cout).
     With x2 (N, H, W, C2) the convolution input is cat([x, x2], -1), read in place.  out_planes = P > 1 returns
     (P, N, H, W, Cout / P): the output channels split into P separate contiguous tensors."""
@@ -354,26 +355,42 @@ def conv_nhwc(x, pc, residual=None, act='none', slope=0.01, x2=None, out_planes=
     if pc.Cout % out_planes:
         raise _lib.FarHipError('conv_nhwc: out_planes must divide the output channel count')
     shape = (N, (H - 1) // st + 1, (W - 1) // st + 1, pc.Cout // out_planes)
-    y = torch.empty((out_planes,) + shape if out_planes > 1 else shape, dtype=torch.float32, device=x.device)
+    full = (out_planes,) + shape if out_planes > 1 else shape
+    if out is None:
+        y = torch.empty(full, dtype=torch.float32, device=x.device)
+    else:
+        y = out
+        n_out = 1
+        for d in full:
+            n_out *= d
+        if y.numel() != n_out or not y.is_contiguous() or y.dtype != torch.float32:
+            raise _lib.FarHipError('conv_nhwc: `out` must be a contiguous fp32 tensor of the output size')
+    g, b, eps = ln if ln is not None else (None, None, 0.0)
     rc = lib.far_conv_nhwc_f32(_p(x, torch.float32), _p(x2, torch.float32), Cin1, _p(pc.packed), _p(pc.scale),
                                _p(pc.shift), _p(residual, torch.float32), N, H, W, Cin, pc.Cout, pc.ksize, st, _ACT[act],
-                               float(slope), int(pc.split), int(out_planes), int(res_group), _p(y), _stream())
+                               float(slope), int(pc.split), int(out_planes), int(res_group),
+                               _p(g, torch.float32), _p(b, torch.float32), float(eps), _p(post_residual, torch.float32),
+                               _p(y), _stream())
     _lib.check(rc, 'far_conv_nhwc_f32')
     return y
 
 
-def linear_f16s(x, pc, residual=None, act='none', x2=None, out_planes=1, res_group=1):
+def linear_f16s(x, pc, residual=None, act='none', x2=None, out_planes=1, res_group=1, ln=None, post_residual=None,
+                out=None):
     """K9 as a linear layer: x (..., K) fp32 -> act(cat([x, x2], -1) W^T * scale + shift (+ residual)) (..., Cout);
     out_planes = P > 1: (P, ..., Cout / P), e.g. the q / k / v projections of one input in one launch.
-    res_group = G > 1: residual is (rows / G, Cout), one row shared by each group of G consecutive rows."""
+    res_group = G > 1: residual is (rows / G, Cout), one row shared by each group of G consecutive rows.
+    ln = (gamma, beta, eps): LayerNorm over the output channels fused into the epilogue (Cout 128 or 256), then
+    + post_residual; out: optional destination."""
     lead = x.shape[:-1]
     rows = 1
     for d in lead:
         rows *= d
     r = None if residual is None else residual.reshape(1, 1, rows // res_group, pc.Cout)
     x2 = None if x2 is None else x2.reshape(1, 1, rows, x2.shape[-1])
+    pr = None if post_residual is None else post_residual.reshape(1, 1, rows, pc.Cout)
     y = conv_nhwc(x.reshape(1, 1, rows, x.shape[-1]), pc, residual=r, act=act, x2=x2, out_planes=out_planes,
-                  res_group=res_group)
+                  res_group=res_group, ln=ln, post_residual=pr, out=out)
     return y.reshape(*lead, pc.Cout) if out_planes == 1 else y.reshape(out_planes, *lead, pc.Cout // out_planes)
 
 

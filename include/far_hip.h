@@ -197,10 +197,14 @@ int far_conv_pack_f32(const float* w, int Cin, int Cout, int ksize, int stride, 
  * res_group = G > 1 (ksize 1): res is [N H W / G][Cout] and row pix / G is added to pixel pix -- one residual row
  * per group of G consecutive rows (fine_preprocess.py:52-57: repeat(feat_c_win, 'n c -> n ww c') + Linear, without
  * materialising the repeat or the concatenation); G = 1: res has y's layout.
+ * ln_gamma, ln_beta != NULL (Cout = 128 or 256): y = LayerNorm over the Cout channels (eps ln_eps, biased variance)
+ * of the value above, times gamma plus beta, plus post_res if given -- transformer.py:61 (norm1 after merge) and
+ * :65-67 (x + norm2(mlp(...))) fused into the Linear layer's epilogue.
  * y must alias none of the inputs. */
 int far_conv_nhwc_f32(const float* x, const float* x2, int Cin1, const void* packed, const float* scale,
                       const float* shift, const float* res, long N, int H, int W, int Cin, int Cout, int ksize,
-                      int stride, int act, float slope, int split, int out_planes, int res_group, float* y,
+                      int stride, int act, float slope, int split, int out_planes, int res_group,
+                      const float* ln_gamma, const float* ln_beta, float ln_eps, const float* post_res, float* y,
                       far_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------

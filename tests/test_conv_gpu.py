@@ -250,3 +250,23 @@ def test_linear_grouped_residual():
     r2 = torch.randn(M, 196, device='cuda', generator=g)
     y2 = ops.linear_f16s(x, ops.PackedConv(w2), residual=r2, res_group=G)
     assert _rel(y2, x.double() @ w2.double().t() + r2.double()[:, None, :])[0] < 4e-6
+
+
+@pytest.mark.parametrize('rows,K,Co', [(700, 256, 256), (1000, 128, 128), (333, 512, 256), (77, 256, 128)])
+def test_linear_fused_layernorm(rows, K, Co):
+    """ln / post_residual: LayerNorm over the output channels (+ residual) in the epilogue == Linear then nn.LayerNorm."""
+    ops = _ops()
+    g = torch.Generator(device='cuda').manual_seed(rows)
+    x = torch.randn(3, rows, K, device='cuda', generator=g)
+    w = torch.randn(Co, K, device='cuda', generator=g) * 0.06
+    gamma = torch.rand(Co, device='cuda', generator=g) + 0.5
+    beta = torch.randn(Co, device='cuda', generator=g) * 0.2
+    r = torch.randn(3, rows, Co, device='cuda', generator=g)
+    out = torch.empty(3, rows, Co, device='cuda')
+    y = ops.linear_f16s(x, ops.PackedConv(w), ln=(gamma, beta, 1e-5), post_residual=r, out=out)
+    assert y.data_ptr() == out.data_ptr()
+    lin = x.double() @ w.double().t()
+    ref = F.layer_norm(lin, (Co,), gamma.double(), beta.double(), 1e-5) + r.double()
+    assert float((y.double() - ref).abs().max()) < 2e-5
+    y2 = ops.linear_f16s(x, ops.PackedConv(w), ln=(gamma, beta, 1e-5))
+    assert float((y2.double() - (ref - r.double())).abs().max()) < 2e-5
