@@ -42,7 +42,7 @@ SIGNATURES = {
     'far_upsample2x_add_f32': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     'far_conv_packed_bytes': (c_sz, [c_i, c_i, c_i, c_i, c_i]),
     'far_conv_pack_f32': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
-    'far_conv_nhwc_f32': (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_p, c_p, c_f, c_p, c_p, c_p]),
+    'far_conv_nhwc_f32': (c_i, [c_p, c_p]),                  # (const far_conv_desc*, stream): see ConvDesc
     'far_emm_pv_f16s_workspace_bytes': (c_sz, [c_i, c_i]),
     'far_emm_pv_f16s': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_i, c_l, c_l, c_i, c_p, c_p, c_p]),
     'far_stem7x7_nhwc_f32': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
@@ -50,6 +50,18 @@ SIGNATURES = {
     'far_solver_f64': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_d, c_i, c_u32, c_p]
                        + [c_p] * 14 + [c_p, c_p]),
 }
+
+
+
+class ConvDesc(ctypes.Structure):
+    """far_conv_desc of include/far_hip.h (field order and types must match)."""
+    _fields_ = [(n, ctypes.c_void_p) for n in ('x', 'x2', 'packed', 'scale', 'shift', 'res', 'ln_gamma', 'ln_beta',
+                                               'post_res', 'y')] + \
+               [('N', ctypes.c_long)] + \
+               [(n, ctypes.c_int) for n in ('H', 'W', 'Cin', 'Cin1', 'Cout', 'ksize', 'stride', 'act', 'split',
+                                            'out_planes', 'res_group')] + \
+               [('slope', ctypes.c_float), ('ln_eps', ctypes.c_float)]
+
 
 _lib = None
 

@@ -652,11 +652,34 @@ int far_conv_pack_f32(const float* w, int Cin, int Cout, int ksize, int stride, 
 // with res_group = G > 1 (linear layers) is [rows / G][Cout]: every group of G consecutive rows shares one residual
 // row (fine_preprocess.py:52-57: the coarse feature of a match, repeated over its 25 window tokens).
 // y must alias none of the inputs.
-int far_conv_nhwc_f32(const float* x, const float* x2, int Cin1, const void* packed, const float* scale,
-                      const float* shift, const float* res, long N, int H, int W, int Cin, int Cout, int ksize,
-                      int stride, int act, float slope, int split, int out_planes, int res_group,
-                      const float* ln_gamma, const float* ln_beta, float ln_eps, const float* post_res, float* y,
-                      hipStream_t stream) {
+struct far_conv_desc {          // mirrors include/far_hip.h
+    const float* x;
+    const float* x2;
+    const void* packed;
+    const float* scale;
+    const float* shift;
+    const float* res;
+    const float* ln_gamma;
+    const float* ln_beta;
+    const float* post_res;
+    float* y;
+    long N;
+    int H, W, Cin, Cin1, Cout, ksize, stride;
+    int act, split, out_planes, res_group;
+    float slope, ln_eps;
+};
+
+int far_conv_nhwc_f32(const far_conv_desc* desc, hipStream_t stream) {
+    if (!desc) return FAR_EINVAL;
+    const far_conv_desc& d = *desc;
+    const float *x = d.x, *x2 = d.x2, *scale = d.scale, *shift = d.shift, *res = d.res;
+    const float *ln_gamma = d.ln_gamma, *ln_beta = d.ln_beta, *post_res = d.post_res;
+    const void* packed = d.packed;
+    float* y = d.y;
+    const long N = d.N;
+    const int H = d.H, W = d.W, Cin = d.Cin, Cin1 = d.Cin1, Cout = d.Cout, ksize = d.ksize, stride = d.stride;
+    const int act = d.act, split = d.split, out_planes = d.out_planes, res_group = d.res_group;
+    const float slope = d.slope, ln_eps = d.ln_eps;
     far_clear_errors();
     if (N == 0) return FAR_OK;
     if (!x || !packed || !scale || !y || N < 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) || Cout <= 0 ||

@@ -366,11 +366,13 @@ def conv_nhwc(x, pc, residual=None, act='none', slope=0.01, x2=None, out_planes=
         if y.numel() != n_out or not y.is_contiguous() or y.dtype != torch.float32:
             raise _lib.FarHipError('conv_nhwc: `out` must be a contiguous fp32 tensor of the output size')
     g, b, eps = ln if ln is not None else (None, None, 0.0)
-    rc = lib.far_conv_nhwc_f32(_p(x, torch.float32), _p(x2, torch.float32), Cin1, _p(pc.packed), _p(pc.scale),
-                               _p(pc.shift), _p(residual, torch.float32), N, H, W, Cin, pc.Cout, pc.ksize, st, _ACT[act],
-                               float(slope), int(pc.split), int(out_planes), int(res_group),
-                               _p(g, torch.float32), _p(b, torch.float32), float(eps), _p(post_residual, torch.float32),
-                               _p(y), _stream())
+    ptr = lambda t: _p(t, torch.float32).value
+    d = _lib.ConvDesc(x=ptr(x), x2=ptr(x2), packed=_p(pc.packed).value, scale=ptr(pc.scale), shift=ptr(pc.shift),
+                      res=ptr(residual), ln_gamma=ptr(g), ln_beta=ptr(b), post_res=ptr(post_residual), y=ptr(y),
+                      N=N, H=H, W=W, Cin=Cin, Cin1=Cin1, Cout=pc.Cout, ksize=pc.ksize, stride=st, act=_ACT[act],
+                      split=int(pc.split), out_planes=int(out_planes), res_group=int(res_group), slope=float(slope),
+                      ln_eps=float(eps))
+    rc = lib.far_conv_nhwc_f32(ctypes.byref(d), _stream())
     _lib.check(rc, 'far_conv_nhwc_f32')
     return y
 

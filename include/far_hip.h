@@ -187,25 +187,41 @@ size_t far_conv_packed_bytes(int Cin, int Cout, int ksize, int stride, int split
 int far_conv_pack_f32(const float* w, int Cin, int Cout, int ksize, int stride, int w_exp, int split, void* packed,
                       far_stream_t stream);
 
-/* y = act(scale[co] * conv(X, W)[.., co] + shift[co] (+ res)); X = x [N][H][W][Cin1] or, with x2 != NULL, the channel
- * concatenation [x | x2] (x2 [N][H][W][Cin - Cin1], Cin1 % 8 == 0; never materialised: transformer.py:64 torch.cat);
- * res / y [N][Ho][Wo][Cout], Ho = (H - 1) / stride + 1; fp32 NHWC, zero padding ksize / 2, Cin % 4 == 0; stride 1, or
- * 2 with ksize 3 (resnet_fpn.py:19 conv3x3(in_planes, planes, stride)).  shift, res may be NULL.
- * act: 0 none, 1 ReLU, 2 LeakyReLU(slope).  A linear layer y = x W^T + b is ksize = 1, N = H = 1, W = rows, shift = b.
- * out_planes > 1 splits the output channels into that many separate contiguous tensors, y = [out_planes][N][Ho][Wo]
- * [Cout / out_planes] (fused projections: transformer.py:45-47 q_proj / k_proj / v_proj in one launch).
- * res_group = G > 1 (ksize 1): res is [N H W / G][Cout] and row pix / G is added to pixel pix -- one residual row
- * per group of G consecutive rows (fine_preprocess.py:52-57: repeat(feat_c_win, 'n c -> n ww c') + Linear, without
- * materialising the repeat or the concatenation); G = 1: res has y's layout.
- * ln_gamma, ln_beta != NULL (Cout = 128 or 256): y = LayerNorm over the Cout channels (eps ln_eps, biased variance)
- * of the value above, times gamma plus beta, plus post_res if given -- transformer.py:61 (norm1 after merge) and
- * :65-67 (x + norm2(mlp(...))) fused into the Linear layer's epilogue.
- * y must alias none of the inputs. */
-int far_conv_nhwc_f32(const float* x, const float* x2, int Cin1, const void* packed, const float* scale,
-                      const float* shift, const float* res, long N, int H, int W, int Cin, int Cout, int ksize,
-                      int stride, int act, float slope, int split, int out_planes, int res_group,
-                      const float* ln_gamma, const float* ln_beta, float ln_eps, const float* post_res, float* y,
-                      far_stream_t stream);
+/* One K9 launch.  y = LN?( act(scale[co] * conv(X, W)[.., co] + shift[co] (+ res)) ) (+ post_res):
+ *   X = x [N][H][W][Cin1] or, with x2 != NULL, the channel concatenation [x | x2] (x2 [N][H][W][Cin - Cin1],
+ *   Cin1 % 8 == 0; never materialised: transformer.py:64 torch.cat); Cin1 = Cin when x2 == NULL.
+ *   y [N][Ho][Wo][Cout], Ho = (H - 1) / stride + 1; fp32 NHWC, zero padding ksize / 2, Cin % 4 == 0; stride 1, or 2
+ *   with ksize 3 (resnet_fpn.py:19 conv3x3(in_planes, planes, stride)).  A linear layer y = x W^T + b is ksize = 1,
+ *   N = H = 1, W = rows, shift = b.
+ *   packed / scale: from far_conv_pack_f32 (scale includes 2^-(w_exp + 4)); shift, res may be NULL.
+ *   act: 0 none, 1 ReLU, 2 LeakyReLU(slope).  split: 1 = hi + lo operand pairs, 0 = plain fp16 operands.
+ *   out_planes > 1 splits the output channels into that many separate contiguous tensors, y = [out_planes][N][Ho][Wo]
+ *   [Cout / out_planes] (fused projections: transformer.py:45-47 q_proj / k_proj / v_proj in one launch).
+ *   res: y's layout; or, with res_group = G > 1 (ksize 1), [N H W / G][Cout] with row pix / G added to pixel pix -- one
+ *   residual row per group of G consecutive rows (fine_preprocess.py:52-57: repeat(feat_c_win, 'n c -> n ww c') +
+ *   Linear, without materialising the repeat or the concatenation).
+ *   ln_gamma, ln_beta != NULL (Cout = 128 or 256): LayerNorm over the Cout channels (eps ln_eps, biased variance)
+ *   times gamma plus beta, then + post_res if given -- transformer.py:61 (norm1 after merge) and :65-67
+ *   (x + norm2(mlp(...))) fused into the Linear layer's epilogue.
+ *   y must alias none of the inputs. */
+typedef struct far_conv_desc {
+    const float* x;
+    const float* x2;
+    const void* packed;
+    const float* scale;
+    const float* shift;
+    const float* res;
+    const float* ln_gamma;
+    const float* ln_beta;
+    const float* post_res;
+    float* y;
+    long N;
+    int H, W, Cin, Cin1, Cout, ksize, stride;
+    int act, split, out_planes, res_group;
+    float slope, ln_eps;
+} far_conv_desc;
+
+int far_conv_nhwc_f32(const far_conv_desc* desc, far_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * K10  backbone stem: 7x7 stride-2 convolution of a 1-channel image + folded BatchNorm + ReLU (exact-f32 MFMA)
