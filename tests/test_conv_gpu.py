@@ -270,3 +270,28 @@ def test_linear_fused_layernorm(rows, K, Co):
     assert float((y.double() - ref).abs().max()) < 2e-5
     y2 = ops.linear_f16s(x, ops.PackedConv(w), ln=(gamma, beta, 1e-5))
     assert float((y2.double() - (ref - r.double())).abs().max()) < 2e-5
+
+
+def test_conv_random_shapes_sweep():
+    """Seeded sweep over odd geometries (ragged tiles, channel counts that are not multiples of 16 / 32, both kernel
+    sizes, both strides, both operand modes): every case against the float64 convolution."""
+    ops = _ops()
+    rng = __import__('random').Random(2024)
+    g = torch.Generator(device='cuda').manual_seed(99)
+    for case in range(40):
+        ks = rng.choice([1, 3, 3])
+        stride = rng.choice([1, 1, 2]) if ks == 3 else 1
+        N = rng.randint(1, 3)
+        H, W = rng.randint(1, 37), rng.randint(1, 45)
+        Cin = 4 * rng.randint(1, 80)
+        Cout = rng.choice([1, 7, 32, 33, 64, 100, 128, 129, 196, 256, 300])
+        split = rng.random() < 0.75
+        x = torch.randn(N, H, W, Cin, device='cuda', generator=g)
+        w = torch.randn(Cout, Cin, ks, ks, device='cuda', generator=g) * (1.5 / (Cin * ks * ks)) ** 0.5
+        b = torch.randn(Cout, device='cuda', generator=g) * 0.1
+        y = ops.conv_nhwc(x, ops.PackedConv(w, None, b, split=split, stride=stride), act='leaky', slope=0.2)
+        ref = F.leaky_relu(F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), stride=stride, padding=ks // 2),
+                           0.2).permute(0, 2, 3, 1)
+        assert y.shape == ref.shape, (case, y.shape, ref.shape)
+        emax = float((y.double() - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+        assert emax < (5e-6 if split else 5e-3), (case, ks, stride, N, H, W, Cin, Cout, split, emax)
