@@ -36,6 +36,7 @@
 // f16 MFMA issue, ~47 % of the matrix peak) including the fused epilogue, against 100-125 TFLOP/s for the vendor
 // fp32 Winograd convolution alone.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -66,6 +67,7 @@ struct ConvArgs {
     const float* x2;             // input channels [Cin1, Cin) (fused concatenation), or null when Cin1 == Cin
     int Cin1;
     const unsigned char* w;      // packed weights (far_conv_pack_f32)
+    const float* zeros;          // the 32 zero bytes that end the packed image
     const float* scale;          // [Cout] multiplies the accumulator (BN scale / 1, with the operand scaling folded in)
     const float* shift;          // [Cout] or null
     const float* res;            // residual, same layout as y, or null
@@ -80,6 +82,8 @@ struct ConvArgs {
     int Csub;                    // output channels per output plane (Cout: one NHWC tensor)
     int H, W, Ho, Wo, Cin, Cout, tilesX, tilesY, nchunks, nblkY, act;   // input H x W, output Ho x Wo
     float slope;
+    int stagger;                 // start delay spread of the first round of workgroups, in 1024-cycle units (0 = none)
+    int stagger_blocks;          // workgroups resident at once (the first round)
 };
 
 __device__ __forceinline__ void split8(const float4& u, const float4& v, f16x8& hi, f16x8& lo) {
@@ -105,14 +109,14 @@ struct TilePos {
 };
 
 template <int KS, int MW, int ST, int NTHR, int ITERS>
-__device__ __forceinline__ void stage_load(Stage<ITERS>& st, const ConvArgs& p, const TilePos& tp, int chunk, int tid) {
+__device__ __forceinline__ void stage_load(Stage<ITERS>& st, const ConvArgs& p, const TilePos& tp, int chunk, int tid, bool live = true) {
     using G = Geo<KS, MW, ST>;
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int i = tid + NTHR * it;
         const int hp = i >> 2, g = i & 3;
         const int c0 = 32 * chunk + 8 * g;
-        bool ok = i < G::ITEMS;
+        bool ok = live && i < G::ITEMS;          // !live: the request is still issued (no branch), to the zero row
         long pix;
         if (KS == 1) {
             pix = tp.pix0 + hp;
@@ -123,15 +127,28 @@ __device__ __forceinline__ void stage_load(Stage<ITERS>& st, const ConvArgs& p, 
             ok = ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
             pix = ((long)tp.img * p.H + iy) * p.W + ix;
         }
-        // unconditional 16-byte loads from a clamped (always valid) address, zeroed by select: no exec-mask branches
+        // unconditional 16-byte loads: padding (outside the image / past Cin) reads the 32 zero bytes that end the
+        // packed weight image (a kernel-argument pointer like x: plain global loads) instead of being masked afterwards -- a select on the loaded value would make the wave wait for HBM right here instead of
+        // at stage_store, one chunk later
         const bool ok0 = ok && c0 < p.Cin, ok1 = ok && c0 + 4 < p.Cin;
         const bool second = c0 >= p.Cin1;                       // Cin1 % 8 == 0: a group never straddles the inputs
         const float* base = second ? p.x2 + pix * (p.Cin - p.Cin1) + (c0 - p.Cin1) : p.x + pix * p.Cin1 + c0;
-        const float* src0 = ok0 ? base : p.x;
-        const float* src1 = ok1 ? base + 4 : p.x;
-        const float4 u = *reinterpret_cast<const float4*>(src0), w = *reinterpret_cast<const float4*>(src1);
-        st.v[it][0] = make_float4(ok0 ? u.x : 0.f, ok0 ? u.y : 0.f, ok0 ? u.z : 0.f, ok0 ? u.w : 0.f);
-        st.v[it][1] = make_float4(ok1 ? w.x : 0.f, ok1 ? w.y : 0.f, ok1 ? w.z : 0.f, ok1 ? w.w : 0.f);
+        const float* src0 = ok0 ? base : p.zeros;
+        const float* src1 = ok1 ? base + 4 : p.zeros;
+        st.v[it][0] = *reinterpret_cast<const float4*>(src0);
+        st.v[it][1] = *reinterpret_cast<const float4*>(src1);
+    }
+}
+
+// "Uses" the staged values (no instruction): the compiler's wait for the loads sits here, on every path, so that no
+// load is pending -- as far as its bookkeeping goes -- when the next chunk writes the staging registers again
+// (otherwise it drains all memory requests there, the weight-slab DMAs included).
+template <int ITERS>
+__device__ __forceinline__ void stage_arrived(Stage<ITERS>& st) {
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        float4 &u = st.v[it][0], &w = st.v[it][1];
+        asm volatile("" : "+v"(u.x), "+v"(u.y), "+v"(u.z), "+v"(u.w), "+v"(w.x), "+v"(w.y), "+v"(w.z), "+v"(w.w));
     }
 }
 
@@ -141,13 +158,14 @@ __device__ __forceinline__ void stage_store(const Stage<ITERS>& st, unsigned cha
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int i = tid + NTHR * it;
-        if (i < G::ITEMS) {
+        const float4 u = st.v[it][0], w = st.v[it][1];
+        if (ITERS * NTHR == G::ITEMS || i < G::ITEMS) {
             const int hp = i >> 2, g = i & 3;
             int off;
             if (KS == 1) off = hp * A_PXB;
             else { const int hy = hp / G::HW; off = G::px_off(hy, hp - hy * G::HW); }
             f16x8 hi, lo;
-            split8(st.v[it][0], st.v[it][1], hi, lo);
+            split8(u, w, hi, lo);
             *reinterpret_cast<f16x8*>(As + off + g * 16) = hi;
             if (SPLIT) *reinterpret_cast<f16x8*>(As + G::A_PLANE + off + g * 16) = lo;
         }
@@ -221,6 +239,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const f32x16 (&
     }
 }
 
+#ifdef FAR_K9_TIMING
+// Development instrumentation (tools/k9_timing.py; never defined in the product build): per-workgroup s_memtime
+// stamps at kernel entry, after the prologue, after the K loop and at exit, plus the hardware id of wave 0.
+__device__ unsigned long long g_k9_stamps[8 * 65536];
+#define FAR_K9_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 65536) g_k9_stamps[8 * blockIdx.x + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FAR_K9_STAMP(i) do {} while (0)
+#endif
+
 // Sum over the 32 lanes of each half-wave, result in every lane: DPP butterflies inside the 16-lane rows, one
 // cross-row exchange.
 #define FAR_DPP_F(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true))
@@ -231,6 +258,11 @@ __device__ __forceinline__ float sum32(float v) {
     v += FAR_DPP_F(v, 0x140);      // row_mirror
     return v + shfl_xor_f(v, 16);
 }
+
+// "Uses" a loaded value (no instruction) so that the compiler's wait for it sits here, on every path: consumption
+// inside an exec-masked block otherwise leaves the load pending on the skip path, and every later merge point gets a
+// conservative s_waitcnt vmcnt(0) -- which on gfx9 also waits for all stores issued so far.
+__device__ __forceinline__ void arrived(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
 
 // Wide epilogue (Cout, Csub multiples of 4): every 32-pixel x 128-channel accumulator tile of a wave goes through a
 // 16 KiB LDS transpose so that a lane ends up with 4 consecutive channels of one pixel: 16-byte residual loads and
@@ -278,13 +310,30 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvArgs& p, const f32x
                 lw[q * 128 + 32 * nt + l31] = acc[mt][nt][r] * sc[nt] + sh[nt];
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // same wave: LDS executes its requests in order
+        if (mt == 0) FAR_K9_STAMP(6);
         if (p.ln_gamma) {
             // ---- fused LayerNorm (transformer.py:61, 65-67): the whole channel row of a pixel is in this wave's tile
             // (Cout = 128) or in the tiles of the two waves that share its pixels (Cout = 256, partial sums exchanged
             // through `xch`): two-pass mean / variance like K6, then gamma, beta and the post-norm residual.
-            float4 vv[16];
-            float part[16];
-            const float4 g4 = *reinterpret_cast<const float4*>(p.ln_gamma + co4), b4 = *reinterpret_cast<const float4*>(p.ln_beta + co4);
+            // The tile stays in LDS and is re-read for each of the three passes (sum, centred squares, output): only
+            // the per-pixel statistics and the residual rows are live across the reductions.
+            float part[16], mean[16];
+            // the post-norm residual rows are requested first: they arrive behind the reductions below
+            float4 pr[16];
+            if (p.post_res) {
+#pragma unroll
+                for (int it = 0; it < 16; ++it) {
+                    const int q = 2 * it + h;
+                    const int trow = q >> 4, tcol = q & 15;
+                    const bool ok = cok && (KS == 1 ? (q < left) : (trow < nrow && tcol < ncol));
+                    const long off = (pix0 + (KS == 1 ? q : trow * p.Wo + tcol)) * p.Csub + cbase;
+                    pr[it] = *reinterpret_cast<const float4*>(p.post_res + (ok ? off : 0));
+                }
+            } else {
+#pragma unroll
+                for (int it = 0; it < 16; ++it) pr[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            float4 g4 = *reinterpret_cast<const float4*>(p.ln_gamma + co4), b4 = *reinterpret_cast<const float4*>(p.ln_beta + co4);
             const float inv_c = 1.0f / (float)p.Cout;
             auto all_rows = [&](float (&x)[16]) {               // sum over the channel row of every pixel
 #pragma unroll
@@ -302,18 +351,21 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvArgs& p, const f32x
             };
 #pragma unroll
             for (int it = 0; it < 16; ++it) {
-                const int q = 2 * it + h;
-                vv[it] = *reinterpret_cast<const float4*>(lw + q * 128 + 4 * l31);
-                part[it] = (vv[it].x + vv[it].y) + (vv[it].z + vv[it].w);
+                const float4 v = *reinterpret_cast<const float4*>(lw + (2 * it + h) * 128 + 4 * l31);
+                part[it] = (v.x + v.y) + (v.z + v.w);
             }
             all_rows(part);
 #pragma unroll
             for (int it = 0; it < 16; ++it) {
-                const float mean = part[it] * inv_c;
-                vv[it].x -= mean; vv[it].y -= mean; vv[it].z -= mean; vv[it].w -= mean;
-                part[it] = (vv[it].x * vv[it].x + vv[it].y * vv[it].y) + (vv[it].z * vv[it].z + vv[it].w * vv[it].w);
+                float4 v = *reinterpret_cast<const float4*>(lw + (2 * it + h) * 128 + 4 * l31);
+                mean[it] = part[it] * inv_c;
+                v.x -= mean[it]; v.y -= mean[it]; v.z -= mean[it]; v.w -= mean[it];
+                part[it] = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
             }
             all_rows(part);
+            arrived(g4); arrived(b4);
+#pragma unroll
+            for (int it = 0; it < 16; ++it) arrived(pr[it]);
 #pragma unroll
             for (int it = 0; it < 16; ++it) {
                 const int q = 2 * it + h;
@@ -321,42 +373,64 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvArgs& p, const f32x
                 const bool ok = cok && (KS == 1 ? (q < left) : (trow < nrow && tcol < ncol));
                 const long off = (pix0 + (KS == 1 ? q : trow * p.Wo + tcol)) * p.Csub + cbase;
                 const float rstd = 1.0f / sqrtf(part[it] * inv_c + p.ln_eps);
+                float4 v = *reinterpret_cast<const float4*>(lw + q * 128 + 4 * l31);
+                v.x -= mean[it]; v.y -= mean[it]; v.z -= mean[it]; v.w -= mean[it];
                 float4 o;
-                o.x = vv[it].x * rstd * g4.x + b4.x; o.y = vv[it].y * rstd * g4.y + b4.y;
-                o.z = vv[it].z * rstd * g4.z + b4.z; o.w = vv[it].w * rstd * g4.w + b4.w;
-                if (ok) {
-                    if (p.post_res) {
-                        const float4 rr = *reinterpret_cast<const float4*>(p.post_res + off);
-                        o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
-                    }
-                    *reinterpret_cast<float4*>(yp + off) = o;
-                }
+                o.x = v.x * rstd * g4.x + b4.x + pr[it].x; o.y = v.y * rstd * g4.y + b4.y + pr[it].y;
+                o.z = v.z * rstd * g4.z + b4.z + pr[it].z; o.w = v.w * rstd * g4.w + b4.w + pr[it].w;
+                if (ok) *reinterpret_cast<float4*>(yp + off) = o;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             continue;
         }
+        // Plain path.  All residual rows of the tile are requested first, then two batches of 8 rows: LDS reads,
+        // activation, stores.  Straight-line code (no branch: the compiler then counts the outstanding requests
+        // exactly) and no wait that has to see a store acknowledged: on gfx9 stores count in vmcnt too, and a residual
+        // load issued after a store cannot be waited for without waiting for that store (~600 cycles each when loads
+        // and stores alternate, which is what made the epilogue 9-34 % of a workgroup's lifetime).  Per-lane 64-bit
+        // base pointers once per tile, 32-bit row offsets after that.
+        // Activation as max(v, v * as + ab): ReLU (0, 0), LeakyReLU (slope in [0, 1], 0), none (0, -inf).
+        const float as = p.act == 2 ? p.slope : 0.f, ab = p.act == 0 ? -__builtin_inff() : 0.f;
+        float* const ybase = yp + (pix0 * (long)p.Csub + cbase);
+        const int leftc = left > 64 ? 64 : (int)left;
+        auto row_ok = [&](int it) { return cok && (KS == 1 ? (2 * it + h < leftc) : ((it >> 3) < nrow && 2 * (it & 7) + h < ncol)); };
+        auto row_off = [&](int it) { return (unsigned)((KS == 1 ? 2 * it + h : (it >> 3) * p.Wo + 2 * (it & 7) + h) * p.Csub); };
+        auto tile_out = [&](auto has_res) {
+            constexpr bool HR = decltype(has_res)::value;
+            float4 rr[16];
+            if (HR) {
+                const bool grouped = p.res_group > 1;               // fine_preprocess: one residual row per res_group rows
+                const unsigned G = grouped ? (unsigned)p.res_group : 1u;
+                const long g0 = pix0 / (long)G;
+                const unsigned rem0 = (unsigned)(pix0 - g0 * (long)G);
+                const float* rbase = grouped ? resp + (g0 * (long)p.Cout + co4) : resp + (pix0 * (long)p.Csub + cbase);
 #pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int q = 2 * it + h;
-            const int trow = q >> 4, tcol = q & 15;
-            const bool ok = cok && (KS == 1 ? (q < left) : (trow < nrow && tcol < ncol));
-            const long off = (pix0 + (KS == 1 ? q : trow * p.Wo + tcol)) * p.Csub + cbase;
-            float4 v = *reinterpret_cast<const float4*>(lw + q * 128 + 4 * l31);
-            if (ok) {
-                if (resp) {
-                    const long roff = p.res_group > 1 ? ((pix0 + q) / p.res_group) * (long)p.Cout + co4 : off;
-                    const float4 rr = *reinterpret_cast<const float4*>(resp + roff);
-                    v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+                for (int it = 0; it < 16; ++it) {
+                    const unsigned ro = grouped ? ((rem0 + (unsigned)(2 * it + h)) / G) * (unsigned)p.Cout : row_off(it);
+                    rr[it] = *reinterpret_cast<const float4*>(row_ok(it) ? rbase + ro : resp);     // always a valid address
                 }
-                if (p.act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                else if (p.act == 2) {
-                    v.x = v.x > 0.f ? v.x : v.x * p.slope; v.y = v.y > 0.f ? v.y : v.y * p.slope;
-                    v.z = v.z > 0.f ? v.z : v.z * p.slope; v.w = v.w > 0.f ? v.w : v.w * p.slope;
-                }
-                *reinterpret_cast<float4*>(yp + off) = v;
+#pragma unroll
+                for (int it = 0; it < 16; ++it) arrived(rr[it]);
             }
-        }
+#pragma unroll
+            for (int b0 = 0; b0 < 16; b0 += 8) {
+                float4 vv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) vv[j] = *reinterpret_cast<const float4*>(lw + (2 * (b0 + j) + h) * 128 + 4 * l31);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float4 v = vv[j];
+                    if (HR) { v.x += rr[b0 + j].x; v.y += rr[b0 + j].y; v.z += rr[b0 + j].z; v.w += rr[b0 + j].w; }
+                    v.x = fmaxf(v.x, __builtin_fmaf(v.x, as, ab)); v.y = fmaxf(v.y, __builtin_fmaf(v.y, as, ab));
+                    v.z = fmaxf(v.z, __builtin_fmaf(v.z, as, ab)); v.w = fmaxf(v.w, __builtin_fmaf(v.w, as, ab));
+                    float* dst = ybase + row_off(b0 + j);
+                    if (row_ok(b0 + j)) *reinterpret_cast<float4*>(dst) = v;
+                }
+            }
+        };
+        if (resp) tile_out(std::true_type{}); else tile_out(std::false_type{});
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // tile read back before the next one overwrites it
+        if (mt == 0) FAR_K9_STAMP(5);
     }
 }
 
@@ -380,6 +454,10 @@ __global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / NW, wn = wave % NW, l31 = lane & 31, h = lane >> 5;
+    FAR_K9_STAMP(0);
+#ifdef FAR_K9_TIMING
+    if (threadIdx.x == 0 && blockIdx.x < 65536) g_k9_stamps[8 * blockIdx.x + 7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+#endif
 
     // ---- which output tile / output-channel block.  1-D grid of ntiles * nblkY blocks.  Hardware places block b on
     // XCD b % 8: each XCD gets a contiguous range of tiles (the halos shared by neighbouring tiles are re-read from
@@ -405,6 +483,16 @@ __global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const 
         tp.ox0 = tx * TW;
     }
     const int cout_w = by * NT + 32 * NTW * wn;                       // first output channel of this wave
+
+    // ---- de-synchronise the chip.  All workgroups take the same time, so without this every round starts, loads and
+    // -- worst -- stores in lockstep: the epilogue's stores of all 512 resident workgroups hit HBM as one burst while
+    // the K loops write nothing (measured: the epilogue took 22-26 k cycles of a workgroup's life, all of it store
+    // back-pressure).  The first round starts spread over a fraction of a workgroup's lifetime (bit-reversed block
+    // index: neighbours get distant delays); later rounds inherit the phase of the slot they replace.
+    if (p.stagger > 0 && (int)blockIdx.x < p.stagger_blocks) {
+        const int n = (int)(((long)p.stagger * (__builtin_bitreverse32(blockIdx.x) >> 23)) >> 9);
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);    // 16 x 64 cycles
+    }
 
     // ---- weight slabs, stored in execution order [chunk][tap][k-step][cout block]: the LDS-DMA source pointer of
     // the prefetch just advances by one slab per phase (two when the all-padding last k-step is skipped).
@@ -455,6 +543,7 @@ __global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const 
     prefetch();
     prefetch();
     stage_store<KS, MW, ST, NTHR, ITERS, SPLIT>(st, As, tid);
+    FAR_K9_STAMP(1);
 
     // Fragment registers.  The pixel (A) fragments of a phase are read during the previous phase; the weight (B)
     // fragments in two halves of NTW / 2 column tiles, the second half behind the first half's MFMAs.
@@ -515,7 +604,8 @@ __global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const 
                 if (first || !APRE) read_a(ah, al, tap, ks);
                 __builtin_amdgcn_sched_barrier(0);
                 prefetch();
-                if (tap == LOAD_TAP && ks == 0 && chunk + 1 < nchunks) stage_load<KS, MW, ST, NTHR, ITERS>(st, p, tp, chunk + 1, tid);
+                if (tap == LOAD_TAP && ks == 0)            // unconditional (no branch in the body): the last chunk requests zeros
+                    stage_load<KS, MW, ST, NTHR, ITERS>(st, p, tp, chunk + 1, tid, chunk + 1 < nchunks);
                 read_b(1, B);
                 mma_half(0);
                 if (APRE && !(tap == TAPS - 1 && ks == 1)) {       // pixel fragments of the next phase of this chunk
@@ -539,12 +629,14 @@ __global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const 
                 slot = slot == 2 ? 0 : slot + 1;
             }
         }
+        stage_arrived(st);
         if (chunk + 1 < nchunks) {
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done with this chunk's pixels
             stage_store<KS, MW, ST, NTHR, ITERS, SPLIT>(st, As, tid);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the trailing (unused) slab requests must land before LDS is reused
+    FAR_K9_STAMP(2);
 
     if (NTW == 4 && ((p.Cout | p.Csub) & 3) == 0) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave is past its last LDS fragment read
@@ -553,6 +645,11 @@ __global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const 
     } else {
         conv_epilogue<KS, NTW>(p, acc, tp, cout_w, wm, l31, h);
     }
+#ifdef FAR_K9_TIMING
+    FAR_K9_STAMP(3);                                   // epilogue instructions issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    FAR_K9_STAMP(4);                                   // stores acknowledged
+#endif
 }
 
 // Packs torch-layout weights [Cout][Cin][KS][KS] (or [Cout][Cin] for linear) into the LDS image the kernel DMAs, in
@@ -561,6 +658,7 @@ __global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const 
 __global__ void k_conv_pack(const float* __restrict__ w, int Cin, int Cout, int taps, int nchunks, int nblkY, int NT,
                             int planes, float wmul, _Float16* __restrict__ out) {
     const long total = (long)taps * nchunks * 2 * nblkY * NT * 2;
+    if (blockIdx.x == 0 && threadIdx.x < 16) out[(size_t)total * 8 * planes + threadIdx.x] = (_Float16)0.f;   // the zero row
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         long t = i;
         const int s = (int)(t & 1); t >>= 1;
@@ -625,7 +723,7 @@ size_t far_conv_packed_bytes(int Cin, int Cout, int ksize, int stride, int split
     if (Cin <= 0 || Cout <= 0 || (ksize != 1 && ksize != 3) || stride < 1 || stride > 2 || (stride == 2 && ksize != 3)) return 0;
     const int NT = cfg_for(Cout, stride).nt;
     const size_t nchunks = (Cin + 31) / 32, nblkY = (Cout + NT - 1) / NT;
-    return (size_t)ksize * ksize * nchunks * nblkY * (split ? 2 : 1) * NT * 64;
+    return (size_t)ksize * ksize * nchunks * nblkY * (split ? 2 : 1) * NT * 64 + 32;   // + the zero row padding lanes read
 }
 
 // w: torch layout [Cout][Cin][ksize][ksize] fp32.  Every weight is multiplied by 2^w_exp before the fp16 split
@@ -684,12 +782,13 @@ int far_conv_nhwc_f32(const far_conv_desc* desc, hipStream_t stream) {
     if (N == 0) return FAR_OK;
     if (!x || !packed || !scale || !y || N < 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) || Cout <= 0 ||
         (ksize != 1 && ksize != 3) || stride < 1 || stride > 2 || (stride == 2 && ksize != 3) || act < 0 || act > 2 ||
-        x == y || x2 == y || out_planes < 1 || Cout % out_planes)
+        (act == 2 && !(slope >= 0.f && slope <= 1.f)) || x == y || x2 == y || out_planes < 1 || Cout % out_planes)
         return FAR_EINVAL;
     if (res_group < 1 || (res_group > 1 && (!res || ksize != 1 || out_planes != 1 || (N * H * W) % res_group))) return FAR_EINVAL;
     if (x2 ? (Cin1 <= 0 || Cin1 >= Cin || (Cin1 & 7)) : (Cin1 != Cin)) return FAR_EINVAL;
     ConvArgs a;
-    a.x = x; a.x2 = x2; a.Cin1 = Cin1; a.w = (const unsigned char*)packed; a.scale = scale; a.shift = shift; a.res = res; a.res_group = res_group; a.y = y;
+    a.x = x; a.x2 = x2; a.Cin1 = Cin1; a.w = (const unsigned char*)packed; a.scale = scale;
+    a.zeros = reinterpret_cast<const float*>((const unsigned char*)packed + far_conv_packed_bytes(Cin, Cout, ksize, stride, split) - 32); a.shift = shift; a.res = res; a.res_group = res_group; a.y = y;
     a.ln_gamma = ln_gamma; a.ln_beta = ln_beta; a.ln_eps = ln_eps; a.post_res = post_res;
     a.H = H; a.W = W; a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1; a.Cin = Cin; a.Cout = Cout; a.Csub = Cout / out_planes;
     a.npix = N * a.Ho * a.Wo;
@@ -704,10 +803,23 @@ int far_conv_nhwc_f32(const far_conv_desc* desc, hipStream_t stream) {
     const long nbx = ksize == 1 ? (a.npix + 64 * c.mw - 1) / (64 * c.mw) : N * a.tilesX * a.tilesY;
     a.ntiles = nbx;
     if (nbx * a.nblkY > 0x7fffffffL) return FAR_EINVAL;
+    {   // start stagger (see k_conv): tuning key 2 = spread in percent of the estimated workgroup lifetime
+        const int pct = far_get_tuning(2);
+        const long slots = 256L * (stride == 2 ? 1 : 2);
+        const long life = (long)a.nchunks * ksize * ksize * 2 * 1900 + 28000;       // cycles, from the s_memtime profile
+        a.stagger_blocks = (int)slots;
+        a.stagger = (pct > 0 && nbx * a.nblkY > slots) ? (int)(life * pct / 100 / 1024) : 0;
+    }
     dim3 grid((unsigned)(nbx * a.nblkY));
     if (stride == 2) return split ? launch_stride2<true>(a, grid, stream) : launch_stride2<false>(a, grid, stream);
     if (ksize == 3) return split ? launch_cfg<3, true>(c, a, grid, stream) : launch_cfg<3, false>(c, a, grid, stream);
     return split ? launch_cfg<1, true>(c, a, grid, stream) : launch_cfg<1, false>(c, a, grid, stream);
 }
+
+#ifdef FAR_K9_TIMING
+int far_k9_timing_dump(void* host, int nblocks) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_k9_stamps), (size_t)nblocks * 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : -5;
+}
+#endif
 
 }  // extern "C"
