@@ -363,6 +363,7 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvArgs& p, const f32x
                 part[it] = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
             }
             all_rows(part);
+            if (mt == 0) FAR_K9_STAMP(7);
             arrived(g4); arrived(b4);
 #pragma unroll
             for (int it = 0; it < 16; ++it) arrived(pr[it]);
@@ -381,6 +382,7 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvArgs& p, const f32x
                 if (ok) *reinterpret_cast<float4*>(yp + off) = o;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (mt == 0) FAR_K9_STAMP(5);
             continue;
         }
         // Plain path.  All residual rows of the tile are requested first, then two batches of 8 rows: LDS reads,
@@ -456,7 +458,6 @@ __global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const 
     const int wm = wave / NW, wn = wave % NW, l31 = lane & 31, h = lane >> 5;
     FAR_K9_STAMP(0);
 #ifdef FAR_K9_TIMING
-    if (threadIdx.x == 0 && blockIdx.x < 65536) g_k9_stamps[8 * blockIdx.x + 7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
 #endif
 
     // ---- which output tile / output-channel block.  1-D grid of ntiles * nblkY blocks.  Hardware places block b on
@@ -596,14 +597,19 @@ __global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const 
                 if (ks >= nks) continue;                                      // between phases; the body is branch free
                 const bool first = tap == 0 && ks == 0;                       // first phase of a chunk
                 const bool last = tap == TAPS - 1 && ks == nks - 1;           // last phase of a chunk
-                // this phase's slab has landed once only the younger slab's DMAs are outstanding
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B_ITERS) : "memory");
+                // This phase's slab has landed once only the requests issued after it are outstanding (vmcnt retires
+                // in order): the younger slab's DMAs, and -- in the two phases after the pixel-load phase -- the next
+                // chunk's pixel loads, which were issued behind this slab's DMAs and need not have arrived yet.
+                const bool after_load = (tap == LOAD_TAP && ks == 1) || (TAPS > 1 && tap == LOAD_TAP + 1 && ks == 0);
+                if (after_load) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B_ITERS + 2 * ITERS) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B_ITERS) : "memory");
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 const unsigned char* B = Bs + slot * B_BUF + b_off;
                 read_b(0, B);
                 if (first || !APRE) read_a(ah, al, tap, ks);
                 __builtin_amdgcn_sched_barrier(0);
                 prefetch();
+                if (tap == LOAD_TAP && ks == 0) __builtin_amdgcn_sched_barrier(0);   // the slab's DMAs stay ahead of the pixel loads (the waits count on it)
                 if (tap == LOAD_TAP && ks == 0)            // unconditional (no branch in the body): the last chunk requests zeros
                     stage_load<KS, MW, ST, NTHR, ITERS>(st, p, tp, chunk + 1, tid, chunk + 1 < nchunks);
                 read_b(1, B);

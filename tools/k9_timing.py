@@ -37,14 +37,14 @@ def report(name, nblocks, wg_per_cu):
     nb = min(nblocks, 65536)
     buf = np.zeros((nb, 8), dtype=np.uint64)
     assert lib.far_k9_timing_dump(buf.ctypes.data, nb) == 0
-    t = buf[:, :7].astype(np.int64)
+    t = buf[:, :8].astype(np.int64)
     t0 = t[:, 0].min()
     pro, loop, epi, life = t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2], t[:, 4] - t[:, 0]
     epi0, drain = t[:, 5] - t[:, 2], t[:, 4] - t[:, 3]
     epiw = t[:, 6] - t[:, 2]
     span = t[:, 4].max() - t0
     print(f'## {name}: {nblocks} workgroups ({nb} sampled), kernel span {span} ticks')
-    for nm, v in (('prologue', pro), ('K loop', loop), ('epilogue issue', epi), (' (first tile)', epi0), (' (its LDS write)', epiw), ('store drain', drain), ('lifetime', life)):
+    for nm, v in (('prologue', pro), ('K loop', loop), ('epilogue issue', epi), (' (first tile)', epi0), (' (its LDS write)', epiw), (' (LN: to stats done)', t[:, 7] - t[:, 2]), ('store drain', drain), ('lifetime', life)):
         print(f'  {nm:15s} mean {v.mean():9.0f}  p10 {np.percentile(v, 10):9.0f}  p50 {np.percentile(v, 50):9.0f}  p90 {np.percentile(v, 90):9.0f}   {100 * v.mean() / life.mean():5.1f} %')
     # resident workgroups over time
     ev = np.concatenate([np.stack([t[:, 0], np.ones(nb, np.int64)], 1), np.stack([t[:, 4], -np.ones(nb, np.int64)], 1)])
