@@ -242,8 +242,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const f32x16 (&
 #ifdef FAR_K9_TIMING
 // Development instrumentation (tools/k9_timing.py; never defined in the product build): per-workgroup s_memtime
 // stamps at kernel entry, after the prologue, after the K loop and at exit, plus the hardware id of wave 0.
-__device__ unsigned long long g_k9_stamps[8 * 65536];
-#define FAR_K9_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 65536) g_k9_stamps[8 * blockIdx.x + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ unsigned long long g_k9_stamps[12 * 65536];
+#define FAR_K9_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 65536) g_k9_stamps[12 * blockIdx.x + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define FAR_K9_STAMP(i) do {} while (0)
 #endif
@@ -458,6 +458,7 @@ __global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const 
     const int wm = wave / NW, wn = wave % NW, l31 = lane & 31, h = lane >> 5;
     FAR_K9_STAMP(0);
 #ifdef FAR_K9_TIMING
+    if (threadIdx.x == 0 && blockIdx.x < 65536) g_k9_stamps[12 * blockIdx.x + 8] = __builtin_amdgcn_s_memrealtime();
 #endif
 
     // ---- which output tile / output-channel block.  1-D grid of ntiles * nblkY blocks.  Hardware places block b on
@@ -655,6 +656,7 @@ __global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const 
     FAR_K9_STAMP(3);                                   // epilogue instructions issued
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     FAR_K9_STAMP(4);                                   // stores acknowledged
+    if (threadIdx.x == 0 && blockIdx.x < 65536) g_k9_stamps[12 * blockIdx.x + 9] = __builtin_amdgcn_s_memrealtime();
 #endif
 }
 
@@ -691,7 +693,11 @@ __global__ void k_conv_pack(const float* __restrict__ w, int Cin, int Cout, int 
 // 128 pixels x 256 channels per block (2 x 2 waves); every wave owns 64 pixels x 128 channels.  (Measured on
 // MI355X: 8-wave workgroups of the same wave tile and 64-channel wave tiles were equal or slower.)
 struct TileCfg { int mw, nw, nt; };
-inline TileCfg cfg_for(int Cout, int stride) { return (Cout <= 128 && stride == 1) ? TileCfg{4, 1, 128} : TileCfg{2, 2, 256}; }
+inline TileCfg cfg_for(int Cout, int stride) {
+    // the narrower tile when it pads less (Cout <= 128, and e.g. 384 = 3 x 128: the fused q | k | v of d_model 128)
+    const int pad128 = (Cout + 127) / 128 * 128, pad256 = (Cout + 255) / 256 * 256;
+    return (stride == 1 && pad128 < pad256) ? TileCfg{4, 1, 128} : TileCfg{2, 2, 256};
+}
 
 template <int KS, int MW, int NW, int NTW, bool SPLIT, int ST = 1>
 int launch_conv(const ConvArgs& a, dim3 grid, hipStream_t stream) {
@@ -823,8 +829,23 @@ int far_conv_nhwc_f32(const far_conv_desc* desc, hipStream_t stream) {
 }
 
 #ifdef FAR_K9_TIMING
+// s_memtime ticks vs the 100 MHz s_memrealtime clock (is a tick a shader cycle?)
+__global__ void k_tick_probe(unsigned long long ticks, unsigned long long* out) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long t1;
+    do { t1 = __builtin_amdgcn_s_memtime(); } while (t1 - t0 < ticks);
+    out[0] = t1 - t0; out[1] = __builtin_amdgcn_s_memrealtime() - r0;
+}
+int far_k9_tick_probe(unsigned long long ticks, unsigned long long* host2) {
+    unsigned long long* d;
+    if (hipMalloc(&d, 16) != hipSuccess) return -5;
+    hipLaunchKernelGGL(k_tick_probe, dim3(1), dim3(64), 0, 0, ticks, d);
+    hipMemcpy(host2, d, 16, hipMemcpyDeviceToHost);
+    hipFree(d);
+    return 0;
+}
 int far_k9_timing_dump(void* host, int nblocks) {
-    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_k9_stamps), (size_t)nblocks * 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : -5;
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_k9_stamps), (size_t)nblocks * 12 * sizeof(unsigned long long)) == hipSuccess ? 0 : -5;
 }
 #endif
 

@@ -48,6 +48,13 @@ rows.append(('merge 256->256 + LN', timed(lambda: ops.conv_nhwc(x, p256, ln=(gm,
 rows.append(('mlp0 cat[x,msg] 512->512 relu', timed(lambda: ops.conv_nhwc(x, pm0, x2=m, act='relu'))))
 rows.append(('mlp2 512->256 + LN + res', timed(lambda: ops.conv_nhwc(h512, pm2, ln=(gm, bt, 1e-5), post_residual=x, out=out))))
 del h512, m
+Rf = 60000 * 25
+xf = torch.randn(1, 1, Rf, 128, device=dev, generator=g)
+p128, p384, p256f = lin(128, 128), lin(128, 384), lin(128, 256)
+rows.append(('fine 128->128 (x3 = q, k, v)', 3 * timed(lambda: ops.conv_nhwc(xf, p128))))
+rows.append(('fine 128->384 planes (fused qkv)', timed(lambda: ops.conv_nhwc(xf, p384, out_planes=3))))
+rows.append(('fine 128->256 planes (fused kv)', timed(lambda: ops.conv_nhwc(xf, p256f, out_planes=2))))
+del xf
 for C, H, W in ((128, 240, 320), (196, 120, 160), (256, 60, 80)):
     xi = torch.randn(64, H, W, C, device=dev, generator=g).relu_()
     pc = ops.PackedConv(torch.randn(C, C, 3, 3, device=dev, generator=g) * 0.03, torch.ones(C, device=dev), torch.zeros(C, device=dev))
