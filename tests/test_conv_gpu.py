@@ -130,6 +130,9 @@ def test_conv_rejects_bad_arguments():
         ops.PackedConv(torch.randn(8, 8, 5, 5, device='cuda'))
     with pytest.raises(FarHipError):
         ops.conv_nhwc(torch.randn(1, 8, 8, 32, device='cuda'), ops.PackedConv(torch.randn(8, 64, 3, 3, device='cuda')))
+    with pytest.raises(FarHipError):                          # LeakyReLU slope outside [0, 1] (the epilogue takes max(v, v * slope))
+        ops.conv_nhwc(torch.randn(1, 8, 8, 32, device='cuda'), ops.PackedConv(torch.randn(8, 32, 3, 3, device='cuda')),
+                      act='leaky', slope=1.5)
 
 
 @pytest.mark.parametrize('N,H,W,Cout', [(2, 48, 64, 128), (1, 37, 51, 128), (1, 480, 640, 128), (2, 20, 24, 64)])
@@ -295,3 +298,26 @@ def test_conv_random_shapes_sweep():
         assert y.shape == ref.shape, (case, y.shape, ref.shape)
         emax = float((y.double() - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
         assert emax < (5e-6 if split else 5e-3), (case, ks, stride, N, H, W, Cin, Cout, split, emax)
+
+
+def test_linear_three_planes_of_128_and_residual_activations():
+    """Cout = 384 runs as three 128-channel blocks (the fused q | k | v of the d_model-128 layers); and the three
+    activation modes of the wide epilogue with a residual, on ragged row counts, against float64."""
+    ops = _ops()
+    g = torch.Generator(device='cuda').manual_seed(5)
+    rows = 3 * 25 * 37 + 11
+    x = torch.randn(rows, 128, device='cuda', generator=g)
+    w = torch.randn(384, 128, device='cuda', generator=g) * 0.09
+    q, k, v = ops.linear_f16s(x, ops.PackedConv(w), out_planes=3)
+    ref = x.double() @ w.double().t()
+    for i, t in enumerate((q, k, v)):
+        emax, _ = _rel(t, ref[:, 128 * i:128 * (i + 1)])
+        assert emax < 5e-6, (i, emax)
+    xi = torch.randn(2, 19, 23, 64, device='cuda', generator=g)
+    wc = torch.randn(128, 64, 3, 3, device='cuda', generator=g) * 0.05
+    res = torch.randn(2, 19, 23, 128, device='cuda', generator=g)
+    base = F.conv2d(xi.permute(0, 3, 1, 2).double(), wc.double(), padding=1).permute(0, 2, 3, 1) + res.double()
+    for act, fn in (('none', lambda t: t), ('relu', torch.relu), ('leaky', lambda t: F.leaky_relu(t, 0.01))):
+        y = ops.conv_nhwc(xi, ops.PackedConv(wc), residual=res, act=act, slope=0.01)
+        emax, _ = _rel(y, fn(base))
+        assert emax < 5e-6, (act, emax)

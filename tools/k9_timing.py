@@ -37,30 +37,26 @@ dev = 'cuda'
 g = torch.Generator(device=dev).manual_seed(1)
 
 
-def report(name, nblocks, wg_per_cu):
+def report(name, nblocks, wg_per_cu, ln=False):
+    """Stamps (s_memtime = shader cycles) of wave 0 of every workgroup: 0 entry, 1 prologue done, 2 K loop done,
+    3 epilogue issued, 4 stores acknowledged, 5 first epilogue tile done, 6 its LDS transpose written,
+    7 (LayerNorm) its statistics done; 8 / 9 = s_memrealtime (100 MHz) at entry / exit."""
     nb = min(nblocks, 65536)
     buf = np.zeros((nb, 12), dtype=np.uint64)
     assert lib.far_k9_timing_dump(buf.ctypes.data, nb) == 0
     t = buf[:, :8].astype(np.int64)
-    t0 = t[:, 0].min()
+    life = t[:, 4] - t[:, 0]
     rt = (buf[:, 9] - buf[:, 8]).astype(np.int64)
-    print(f'  lifetime on the 100 MHz clock: mean {rt.mean() * 10:.0f} ns -> shader clock {(t[:, 4] - t[:, 0]).mean() / (rt.mean() * 10) * 1e3:.0f} MHz during the kernel')
-    pro, loop, epi, life = t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2], t[:, 4] - t[:, 0]
-    epi0, drain = t[:, 5] - t[:, 2], t[:, 4] - t[:, 3]
-    epiw = t[:, 6] - t[:, 2]
-    spans = [int(t[x::8, 4].max() - t[x::8, 0].min()) for x in range(8)]     # every XCD has its own counter
-    span = max(spans)
-    print(f'  per-XCD span (ticks): {spans}')
-    print(f'## {name}: {nblocks} workgroups ({nb} sampled), kernel span {span} ticks')
-    for nm, v in (('prologue', pro), ('K loop', loop), ('epilogue issue', epi), (' (first tile)', epi0), (' (its LDS write)', epiw), (' (LN: to stats done)', t[:, 7] - t[:, 2]), ('store drain', drain), ('lifetime', life)):
-        print(f'  {nm:15s} mean {v.mean():9.0f}  p10 {np.percentile(v, 10):9.0f}  p50 {np.percentile(v, 50):9.0f}  p90 {np.percentile(v, 90):9.0f}   {100 * v.mean() / life.mean():5.1f} %')
-    # resident workgroups over time
-    ev = np.concatenate([np.stack([t[:, 0], np.ones(nb, np.int64)], 1), np.stack([t[:, 4], -np.ones(nb, np.int64)], 1)])
-    ev = ev[np.argsort(ev[:, 0], kind='stable')]
-    occ = np.cumsum(ev[:, 1])
-    dt = np.diff(ev[:, 0])
-    print(f'  mean resident workgroups {float((occ[:-1] * dt).sum()) / max(1, int(dt.sum())):.1f} of {256 * wg_per_cu} slots'
-          f' (sampled blocks only)')
+    print(f'## {name}: {nblocks} workgroups, {wg_per_cu} per CU')
+    print(f'  shader clock during the kernel: {life.mean() / (rt.mean() * 10) * 1e3:.0f} MHz '
+          f'(workgroup lifetime {life.mean():.0f} cycles = {rt.mean() * 10:.0f} ns on the 100 MHz clock)')
+    rows = [('prologue', t[:, 1] - t[:, 0]), ('K loop', t[:, 2] - t[:, 1]), ('epilogue', t[:, 3] - t[:, 2]),
+            ('  first tile', t[:, 5] - t[:, 2]), ('    its LDS transpose', t[:, 6] - t[:, 2])]
+    if ln:
+        rows.append(('    its LayerNorm statistics', t[:, 7] - t[:, 6]))
+    rows += [('store acknowledgement', t[:, 4] - t[:, 3]), ('lifetime', life)]
+    for nm, v in rows:
+        print(f'  {nm:30s} mean {v.mean():9.0f}  p10 {np.percentile(v, 10):9.0f}  p90 {np.percentile(v, 90):9.0f} cycles  {100 * v.mean() / life.mean():5.1f} %')
 
 
 for w in which:
@@ -81,7 +77,7 @@ for w in which:
         for _ in range(3):
             ops.conv_nhwc(r, pl, ln=(gm, bt, 1e-5), post_residual=r)
         torch.cuda.synchronize()
-        report('linear 256->256 + LayerNorm + residual', 64 * 4800 // 128, 2)
+        report('linear 256->256 + LayerNorm + residual', 64 * 4800 // 128, 2, ln=True)
     elif w in ('conv196', 'conv256', 'conv128', 'conv128res'):
         C, H, W = {'conv196': (196, 240, 320), 'conv256': (256, 120, 160), 'conv128': (128, 240, 320), 'conv128res': (128, 240, 320)}[w]
         x = torch.randn(64, H, W, C, device=dev, generator=g).relu_()
