@@ -9,8 +9,7 @@ extern "C" int far_abi_version(void) { return 1; }
 extern "C" int far_last_hip_error(void) { return g_last_hip_error; }
 
 // Tuning knobs for A/B experiments (speed only; never change results).  key 0: bit mask of kernels that use
-// wave-slot priority staggering (1 = k_stats, 2 = k_match, 4 = k_emm_pv).  key 2: K9 start spread of the first round of
-// workgroups, percent of the estimated workgroup lifetime (0 = all start together).
+// wave-slot priority staggering (1 = k_stats, 2 = k_match, 4 = k_emm_pv).
 static int g_tuning[8] = {3, 0, 0, 0, 0, 0, 0, 0};
 extern "C" int far_set_tuning(int key, int value) {
     if (key < 0 || key >= 8) return FAR_EINVAL;

@@ -28,7 +28,8 @@
 //    (global_load_lds_dwordx4) into a ring of three slabs, two phases ahead (counted vmcnt + raw s_barrier: the
 //    barrier never drains the DMA queue).  One barrier per phase.
 //  * per phase and wave: 12 ds_read_b128 fragment reads (the pixel fragments one phase ahead, the weight fragments in
-//    two halves, the second behind the first half's MFMAs) and 24 MFMAs (split) / 8 (plain).  The phase body is one
+//    two halves, the second behind the first half's MFMAs) and 24 MFMAs (split: hi.hi + hi.lo + lo.hi of one 16-channel
+//    k-step) / 16 (plain operands: one phase per tap, both k-steps of the chunk, the slab's two planes = the two k-steps).  The phase body is one
 //    basic block (unconditional slab request, taps and k-steps unrolled) whose issue order is pinned with
 //    sched_group_barrier: one MFMA, then the LDS reads / DMA requests / address arithmetic that fit in the issue
 //    slots its 32-cycle pass leaves free (+5-7 % over letting them queue up in front of the MFMA block).
@@ -82,8 +83,6 @@ struct ConvArgs {
     int Csub;                    // output channels per output plane (Cout: one NHWC tensor)
     int H, W, Ho, Wo, Cin, Cout, tilesX, tilesY, nchunks, nblkY, act;   // input H x W, output Ho x Wo
     float slope;
-    int stagger;                 // start delay spread of the first round of workgroups, in 1024-cycle units (0 = none)
-    int stagger_blocks;          // workgroups resident at once (the first round)
 };
 
 __device__ __forceinline__ void split8(const float4& u, const float4& v, f16x8& hi, f16x8& lo) {
@@ -445,8 +444,11 @@ __global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const 
     constexpr int TAPS = KS * KS;
     constexpr int NT = 32 * NTW * NW;                // output channels per workgroup
     constexpr int A_BUF = PLANES * G::A_PLANE;
+    // Plain operands (SPLIT = false): one phase per tap covers the whole 32-channel chunk (two MFMA k-steps), the slab
+    // holds the two k-steps where the split slab holds the hi and lo planes: same LDS image size, same DMA pattern,
+    // 16 instead of 8 MFMAs per barrier.
     constexpr int B_PLANE = NT * 32;                 // one 16-channel k-step of the weight slab
-    constexpr int B_BUF = PLANES * B_PLANE;
+    constexpr int B_BUF = 2 * B_PLANE;               // split: hi | lo of one k-step; plain: k-step 0 | k-step 1
     constexpr int B_ITERS = (B_BUF + NTHR * 16 - 1) / (NTHR * 16);   // DMA rounds per slab (the last may be partial)
     constexpr int ITERS = (G::ITEMS + NTHR - 1) / NTHR;
     constexpr int LOAD_TAP = TAPS >= 3 ? TAPS - 3 : 0;   // the next chunk's pixels are requested this early
@@ -486,27 +488,17 @@ __global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const 
     }
     const int cout_w = by * NT + 32 * NTW * wn;                       // first output channel of this wave
 
-    // ---- de-synchronise the chip.  All workgroups take the same time, so without this every round starts, loads and
-    // -- worst -- stores in lockstep: the epilogue's stores of all 512 resident workgroups hit HBM as one burst while
-    // the K loops write nothing (measured: the epilogue took 22-26 k cycles of a workgroup's life, all of it store
-    // back-pressure).  The first round starts spread over a fraction of a workgroup's lifetime (bit-reversed block
-    // index: neighbours get distant delays); later rounds inherit the phase of the slot they replace.
-    if (p.stagger > 0 && (int)blockIdx.x < p.stagger_blocks) {
-        const int n = (int)(((long)p.stagger * (__builtin_bitreverse32(blockIdx.x) >> 23)) >> 9);
-        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);    // 16 x 64 cycles
-    }
-
     // ---- weight slabs, stored in execution order [chunk][tap][k-step][cout block]: the LDS-DMA source pointer of
     // the prefetch just advances by one slab per phase (two when the all-padding last k-step is skipped).
     const int nchunks = p.nchunks;
-    const int last_nks = (p.Cin - 32 * (nchunks - 1)) > 16 ? 2 : 1;
+    const int last_nks = !SPLIT ? 1 : (p.Cin - 32 * (nchunks - 1)) > 16 ? 2 : 1;   // phases per tap of the last chunk
     const size_t slab_stride = (size_t)p.nblkY * B_BUF;
     const unsigned char* wsrc = p.w + (size_t)by * B_BUF + tid * 16;
     // The request is unconditional (no branch in the phase body): past the last slab it re-reads that slab into the
     // ring slot nobody reads any more.  Slabs are stored in execution order; when the all-padding second k-step of
     // the last chunk is skipped, the pointer advances by two slabs there.
-    const int nslab = ((nchunks - 1) * 2 + last_nks) * TAPS;
-    const int first_last = (nchunks - 1) * 2 * TAPS;           // first slab of the last chunk
+    const int nslab = SPLIT ? ((nchunks - 1) * 2 + last_nks) * TAPS : nchunks * TAPS;
+    const int first_last = (nchunks - 1) * 2 * TAPS;           // first slab of the last chunk (split)
     int pidx = 0, pslot = 0;
     auto prefetch = [&]() {
         unsigned char* dst = Bs + pslot * B_BUF + wave * 1024;
@@ -515,7 +507,7 @@ __global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const 
             if ((j + 1) * NTHR * 16 <= B_BUF || j * NTHR * 16 + wave * 1024 < B_BUF)       // wave-uniform, static
                 __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + j * (NTHR * 16)), (lptr_t)(dst + j * (NTHR * 16)), 16, 0, 0);
         pslot = pslot == 2 ? 0 : pslot + 1;
-        const size_t adv = (pidx >= first_last && last_nks == 1) ? 2 * slab_stride : slab_stride;
+        const size_t adv = (SPLIT && pidx >= first_last && last_nks == 1) ? 2 * slab_stride : slab_stride;
         ++pidx;
         wsrc += pidx < nslab ? adv : 0;
     };
@@ -558,14 +550,14 @@ __global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const 
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             xh[mt] = *reinterpret_cast<const f16x8*>(A + a_off[mt]);
-            if (SPLIT) xl[mt] = *reinterpret_cast<const f16x8*>(A + G::A_PLANE + a_off[mt]);
+            xl[mt] = *reinterpret_cast<const f16x8*>(A + (SPLIT ? G::A_PLANE : 32) + a_off[mt]);   // lo plane / second k-step
         }
     };
     auto read_b = [&](int half, const unsigned char* B) {
 #pragma unroll
         for (int q = 0; q < NH; ++q) {
             bh[half][q] = *reinterpret_cast<const f16x8*>(B + (half * NH + q) * 32 * 32);
-            if (SPLIT) bl[half][q] = *reinterpret_cast<const f16x8*>(B + B_PLANE + (half * NH + q) * 32 * 32);
+            bl[half][q] = *reinterpret_cast<const f16x8*>(B + B_PLANE + (half * NH + q) * 32 * 32);
         }
     };
     auto mma_half = [&](int half) {
@@ -585,12 +577,18 @@ __global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const 
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
                     acc[mt][half * NH + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[half][q], acc[mt][half * NH + q], 0, 0, 0);
+        } else {                                   // second k-step of the chunk: its own pixel and weight fragments
+#pragma unroll
+            for (int q = 0; q < NH; ++q)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    acc[mt][half * NH + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bl[half][q], acc[mt][half * NH + q], 0, 0, 0);
         }
     };
 
     int slot = 0;
     for (int chunk = 0; chunk < nchunks; ++chunk) {
-        const int nks = chunk == nchunks - 1 ? last_nks : 2;
+        const int nks = !SPLIT ? 1 : chunk == nchunks - 1 ? last_nks : 2;            // phases per tap
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
 #pragma unroll
@@ -601,7 +599,8 @@ __global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const 
                 // This phase's slab has landed once only the requests issued after it are outstanding (vmcnt retires
                 // in order): the younger slab's DMAs, and -- in the two phases after the pixel-load phase -- the next
                 // chunk's pixel loads, which were issued behind this slab's DMAs and need not have arrived yet.
-                const bool after_load = (tap == LOAD_TAP && ks == 1) || (TAPS > 1 && tap == LOAD_TAP + 1 && ks == 0);
+                const bool after_load = SPLIT ? (tap == LOAD_TAP && ks == 1) || (TAPS > 1 && tap == LOAD_TAP + 1 && ks == 0)
+                                              : TAPS > 1 && (tap == LOAD_TAP + 1 || tap == LOAD_TAP + 2);
                 if (after_load) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B_ITERS + 2 * ITERS) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B_ITERS) : "memory");
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -615,7 +614,7 @@ __global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const 
                     stage_load<KS, MW, ST, NTHR, ITERS>(st, p, tp, chunk + 1, tid, chunk + 1 < nchunks);
                 read_b(1, B);
                 mma_half(0);
-                if (APRE && !(tap == TAPS - 1 && ks == 1)) {       // pixel fragments of the next phase of this chunk
+                if (APRE && !(tap == TAPS - 1 && (ks == 1 || !SPLIT))) {       // pixel fragments of the next phase of this chunk
                     const bool wrap = ks + 1 >= nks;               // (a skipped second k-step makes the next phase (tap + 1, 0))
                     read_a(ahn, aln, wrap ? tap + 1 : tap, wrap ? 0 : 1);
                 }
@@ -623,7 +622,7 @@ __global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const 
                 // issue order: one MFMA, then the other instructions of the phase (LDS reads, the DMA requests and
                 // their address arithmetic) in the issue slots its 32-cycle pass leaves free
 #pragma unroll
-                for (int i = 0; i < (SPLIT ? 6 : 2) * NTW; ++i) {
+                for (int i = 0; i < (SPLIT ? 6 : 4) * NTW; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // DS read
                     __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // VMEM read (LDS-DMA, pixel loads)
@@ -662,7 +661,7 @@ __global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const 
 
 // Packs torch-layout weights [Cout][Cin][KS][KS] (or [Cout][Cin] for linear) into the LDS image the kernel DMAs, in
 // execution order: [chunk][tap][k-step][cout block][plane][NT rows][2 slots of 8 channels, slot ^= (row >> 3) & 1]
-// fp16, scaled by 2^w_exp.
+// fp16, scaled by 2^w_exp (plain operands: [chunk][tap][cout block][k-step][NT rows][...], one slab per tap).
 __global__ void k_conv_pack(const float* __restrict__ w, int Cin, int Cout, int taps, int nchunks, int nblkY, int NT,
                             int planes, float wmul, _Float16* __restrict__ out) {
     const long total = (long)taps * nchunks * 2 * nblkY * NT * 2;
@@ -676,8 +675,10 @@ __global__ void k_conv_pack(const float* __restrict__ w, int Cin, int Cout, int 
         const int tap = (int)(t % taps);
         const int chunk = (int)(t / taps);
         const int n = by * NT + nn;
-        _Float16* dst = out + (((((size_t)(chunk * taps + tap) * 2 + ks) * nblkY + by) * planes) * NT + nn) * 16 +
-                        ((s ^ ((nn >> 3) & 1)) * 8);
+        // split: slab = (chunk, tap, k-step), [hi | lo] planes of NT rows; plain: slab = (chunk, tap), [k-step 0 | k-step 1]
+        const size_t row = planes == 2 ? ((((size_t)(chunk * taps + tap) * 2 + ks) * nblkY + by) * 2) * NT + nn
+                                       : ((((size_t)(chunk * taps + tap) * nblkY + by) * 2 + ks)) * NT + nn;
+        _Float16* dst = out + row * 16 + ((s ^ ((nn >> 3) & 1)) * 8);
         for (int e = 0; e < 8; ++e) {
             const int ch = 32 * chunk + 16 * ks + 8 * s + e;
             float v = 0.f;
@@ -703,7 +704,7 @@ template <int KS, int MW, int NW, int NTW, bool SPLIT, int ST = 1>
 int launch_conv(const ConvArgs& a, dim3 grid, hipStream_t stream) {
     using G = Geo<KS, MW, ST>;
     constexpr int PLANES = SPLIT ? 2 : 1;
-    constexpr int smem_loop = PLANES * G::A_PLANE + 3 * PLANES * 32 * NTW * NW * 32;
+    constexpr int smem_loop = PLANES * G::A_PLANE + 3 * 2 * 32 * NTW * NW * 32;
     constexpr int smem_epi = MW * NW * (32 * 128 * 4 + 32 * 4);  // conv_epilogue_wide: 16 KiB per wave + LayerNorm exchange
     constexpr int smem = smem_loop > smem_epi ? smem_loop : smem_epi;
     static bool configured = false;
@@ -815,13 +816,6 @@ int far_conv_nhwc_f32(const far_conv_desc* desc, hipStream_t stream) {
     const long nbx = ksize == 1 ? (a.npix + 64 * c.mw - 1) / (64 * c.mw) : N * a.tilesX * a.tilesY;
     a.ntiles = nbx;
     if (nbx * a.nblkY > 0x7fffffffL) return FAR_EINVAL;
-    {   // start stagger (see k_conv): tuning key 2 = spread in percent of the estimated workgroup lifetime
-        const int pct = far_get_tuning(2);
-        const long slots = 256L * (stride == 2 ? 1 : 2);
-        const long life = (long)a.nchunks * ksize * ksize * 2 * 1900 + 28000;       // cycles, from the s_memtime profile
-        a.stagger_blocks = (int)slots;
-        a.stagger = (pct > 0 && nbx * a.nblkY > slots) ? (int)(life * pct / 100 / 1024) : 0;
-    }
     dim3 grid((unsigned)(nbx * a.nblkY));
     if (stride == 2) return split ? launch_stride2<true>(a, grid, stream) : launch_stride2<false>(a, grid, stream);
     if (ksize == 3) return split ? launch_cfg<3, true>(c, a, grid, stream) : launch_cfg<3, false>(c, a, grid, stream);

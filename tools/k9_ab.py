@@ -9,9 +9,6 @@ from far_amd import _lib
 if len(sys.argv) > 1:
     _lib.LIB_PATH = sys.argv[1]
 from far_amd import ops
-import os
-if os.environ.get('K9_STAGGER'):
-    _lib.load().far_set_tuning(2, int(os.environ['K9_STAGGER']))
 
 dev = 'cuda'
 g = torch.Generator(device=dev).manual_seed(1)

@@ -26,8 +26,6 @@ from far_amd import ops
 lib = _lib.load()
 lib.far_k9_timing_dump.restype = ctypes.c_int
 lib.far_k9_timing_dump.argtypes = [ctypes.c_void_p, ctypes.c_int]
-if os.environ.get('K9_STAGGER'):
-    lib.far_set_tuning(2, int(os.environ['K9_STAGGER']))
 tk = (ctypes.c_ulonglong * 2)()
 lib.far_k9_tick_probe.argtypes = [ctypes.c_ulonglong, ctypes.c_void_p]
 lib.far_k9_tick_probe(200_000_000, tk)
