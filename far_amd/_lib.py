@@ -56,7 +56,7 @@ SIGNATURES = {
 class ConvDesc(ctypes.Structure):
     """far_conv_desc of include/far_hip.h (field order and types must match)."""
     _fields_ = [(n, ctypes.c_void_p) for n in ('x', 'x2', 'packed', 'scale', 'shift', 'res', 'ln_gamma', 'ln_beta',
-                                               'post_res', 'y')] + \
+                                               'post_res', 'up', 'y')] + \
                [('N', ctypes.c_long)] + \
                [(n, ctypes.c_int) for n in ('H', 'W', 'Cin', 'Cin1', 'Cout', 'ksize', 'stride', 'act', 'split',
                                             'out_planes', 'res_group')] + \

@@ -77,6 +77,7 @@ struct ConvArgs {
     const float* ln_beta;
     float ln_eps;
     const float* post_res;       // added after the LayerNorm (y's layout), or null
+    const float* up;             // [N][Ho/2][Wo/2][Cout]: its bilinear 2x upsampling (align_corners) is added (1x1 mode), or null
     float* y;
     long npix;                   // N * Ho * Wo output pixels (= input pixels for 1x1)
     long ntiles;                 // blocks along x
@@ -268,7 +269,7 @@ __device__ __forceinline__ void arrived(float4& v) { asm volatile("" : "+v"(v.x)
 // 16-byte stores, each store instruction writing two whole 512-byte pixel rows (4x fewer memory instructions than
 // the per-register path above).  `lw` = this wave's private 32 x 128 float region; the caller has synchronised the
 // workgroup (the main loop's LDS buffers are dead).
-template <int KS, int NW>
+template <int KS, int NW, bool UP>
 __device__ __forceinline__ void conv_epilogue_wide(const ConvArgs& p, const f32x16 (&acc)[2][4], const TilePos& tp,
                                                    int cout_w, int wm, int wave, int lane, float* lw, float* xch) {
     const int l31 = lane & 31, h = lane >> 5;
@@ -429,14 +430,70 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvArgs& p, const f32x
                 }
             }
         };
-        if (resp) tile_out(std::true_type{}); else tile_out(std::false_type{});
+        // Fused FPN merge (resnet_fpn.py:108-109, :113-114): y = conv1x1(x) + bilinear_2x(up), align_corners = True; the
+        // arithmetic of K8 (k_upsample2x_add: torch's source index and hy * (hx a + lx b) + ly * (hx c + lx d)), so the
+        // result is bit-identical to the two-kernel sequence without writing and re-reading the lateral tensor.
+        auto tile_up = [&]() {
+            constexpr int UB = 2;                                      // rows per batch and lane half (register budget)
+            const int hc = p.Ho >> 1, wc = p.Wo >> 1;
+            const float ry = p.Ho > 1 ? (float)(hc - 1) / (float)(p.Ho - 1) : 0.f;
+            const float rx = p.Wo > 1 ? (float)(wc - 1) / (float)(p.Wo - 1) : 0.f;
+            const long per = (long)p.Ho * p.Wo;
+            const long n0 = pix0 / per;                                // tile start -> (image, row, column); Wo >= 32:
+            const int rem = (int)(pix0 - n0 * per);                    // a tile row wraps at most once
+            const int Y0 = rem / p.Wo, X0 = rem - Y0 * p.Wo;
+#pragma unroll
+            for (int b0 = 0; b0 < 16; b0 += UB) {
+                float4 ta[UB], tb[UB], tc[UB], td[UB], vv[UB];
+                float wy[UB], wx[UB];
+#pragma unroll
+                for (int j = 0; j < UB; ++j) {
+                    const int q = 2 * (b0 + j) + h;
+                    int X = X0 + q, Y = Y0;
+                    long n = n0;
+                    if (X >= p.Wo) { X -= p.Wo; ++Y; }
+                    if (Y >= p.Ho) { Y = 0; ++n; }
+                    const float sy = ry * (float)Y, sx = rx * (float)X;
+                    const int y0 = (int)sy, x0 = (int)sx;
+                    const int y1 = y0 + (y0 < hc - 1 ? 1 : 0), x1 = x0 + (x0 < wc - 1 ? 1 : 0);
+                    wy[j] = sy - (float)y0; wx[j] = sx - (float)x0;
+                    const bool ok = row_ok(b0 + j);
+                    const float* base = p.up + (ok ? (n * hc * (long)wc) * p.Cout + co4 : 0);
+                    const int o00 = ok ? (y0 * wc + x0) * p.Cout : 0, o01 = ok ? (y0 * wc + x1) * p.Cout : 0;
+                    const int o10 = ok ? (y1 * wc + x0) * p.Cout : 0, o11 = ok ? (y1 * wc + x1) * p.Cout : 0;
+                    ta[j] = *reinterpret_cast<const float4*>(base + o00); tb[j] = *reinterpret_cast<const float4*>(base + o01);
+                    tc[j] = *reinterpret_cast<const float4*>(base + o10); td[j] = *reinterpret_cast<const float4*>(base + o11);
+                }
+#pragma unroll
+                for (int j = 0; j < UB; ++j) vv[j] = *reinterpret_cast<const float4*>(lw + (2 * (b0 + j) + h) * 128 + 4 * l31);
+#pragma unroll
+                for (int j = 0; j < UB; ++j) { arrived(ta[j]); arrived(tb[j]); arrived(tc[j]); arrived(td[j]); }
+#pragma unroll
+                for (int j = 0; j < UB; ++j) {
+                    const float ly = wy[j], lx = wx[j], hy = 1.f - ly, hx = 1.f - lx;
+                    float4 v = vv[j];
+                    v.x += hy * (hx * ta[j].x + lx * tb[j].x) + ly * (hx * tc[j].x + lx * td[j].x);
+                    v.y += hy * (hx * ta[j].y + lx * tb[j].y) + ly * (hx * tc[j].y + lx * td[j].y);
+                    v.z += hy * (hx * ta[j].z + lx * tb[j].z) + ly * (hx * tc[j].z + lx * td[j].z);
+                    v.w += hy * (hx * ta[j].w + lx * tb[j].w) + ly * (hx * tc[j].w + lx * td[j].w);
+                    v.x = fmaxf(v.x, __builtin_fmaf(v.x, as, ab)); v.y = fmaxf(v.y, __builtin_fmaf(v.y, as, ab));
+                    v.z = fmaxf(v.z, __builtin_fmaf(v.z, as, ab)); v.w = fmaxf(v.w, __builtin_fmaf(v.w, as, ab));
+                    float* dst = ybase + row_off(b0 + j);
+                    if (row_ok(b0 + j)) *reinterpret_cast<float4*>(dst) = v;
+                }
+                __builtin_amdgcn_sched_barrier(0);      // keep the batches apart (hoisting all 16 rows' addresses spills)
+            }
+        };
+        if (UP) tile_up();                        // a separate instantiation: its registers must not weigh on the others
+        else if (resp) tile_out(std::true_type{});
+        else tile_out(std::false_type{});
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // tile read back before the next one overwrites it
         if (mt == 0) FAR_K9_STAMP(5);
     }
 }
 
 // Workgroup = MW x NW waves: wave (wm, wn) owns 64 pixels (4 tile rows x 16) x 32 NTW output channels.
-template <int KS, int MW, int NW, int NTW, bool SPLIT, int ST>
+template <int KS, int MW, int NW, int NTW, bool SPLIT, int ST, bool UP = false>
 __global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const ConvArgs p) {
     using G = Geo<KS, MW, ST>;
     constexpr int NTHR = 64 * MW * NW;
@@ -646,7 +703,7 @@ __global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const 
 
     if (NTW == 4 && ((p.Cout | p.Csub) & 3) == 0) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave is past its last LDS fragment read
-        conv_epilogue_wide<KS, NW>(p, acc, tp, cout_w, wm, wave, lane, reinterpret_cast<float*>(smem) + wave * (32 * 128),
+        conv_epilogue_wide<KS, NW, UP>(p, acc, tp, cout_w, wm, wave, lane, reinterpret_cast<float*>(smem) + wave * (32 * 128),
                                    reinterpret_cast<float*>(smem) + MW * NW * (32 * 128));
     } else {
         conv_epilogue<KS, NTW>(p, acc, tp, cout_w, wm, l31, h);
@@ -700,7 +757,7 @@ inline TileCfg cfg_for(int Cout, int stride) {
     return (stride == 1 && pad128 < pad256) ? TileCfg{4, 1, 128} : TileCfg{2, 2, 256};
 }
 
-template <int KS, int MW, int NW, int NTW, bool SPLIT, int ST = 1>
+template <int KS, int MW, int NW, int NTW, bool SPLIT, int ST = 1, bool UP = false>
 int launch_conv(const ConvArgs& a, dim3 grid, hipStream_t stream) {
     using G = Geo<KS, MW, ST>;
     constexpr int PLANES = SPLIT ? 2 : 1;
@@ -709,16 +766,20 @@ int launch_conv(const ConvArgs& a, dim3 grid, hipStream_t stream) {
     constexpr int smem = smem_loop > smem_epi ? smem_loop : smem_epi;
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute((const void*)k_conv<KS, MW, NW, NTW, SPLIT, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)k_conv<KS, MW, NW, NTW, SPLIT, ST, UP>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
             return far_check_launch();
         configured = true;
     }
-    hipLaunchKernelGGL((k_conv<KS, MW, NW, NTW, SPLIT, ST>), grid, dim3(64 * MW * NW), smem, stream, a);
+    hipLaunchKernelGGL((k_conv<KS, MW, NW, NTW, SPLIT, ST, UP>), grid, dim3(64 * MW * NW), smem, stream, a);
     return far_check_launch();
 }
 
 template <int KS, bool SPLIT>
 int launch_cfg(const TileCfg& c, const ConvArgs& a, dim3 grid, hipStream_t stream) {
+    if (KS == 1 && a.up) {                          // the FPN merge variant (fused 2x-upsample residual)
+        if (c.mw == 4) return launch_conv<1, 4, 1, 4, SPLIT, 1, true>(a, grid, stream);
+        return launch_conv<1, 2, 2, 4, SPLIT, 1, true>(a, grid, stream);
+    }
     if (c.mw == 4) return launch_conv<KS, 4, 1, 4, SPLIT>(a, grid, stream);
     return launch_conv<KS, 2, 2, 4, SPLIT>(a, grid, stream);
 }
@@ -773,6 +834,7 @@ struct far_conv_desc {          // mirrors include/far_hip.h
     const float* ln_gamma;
     const float* ln_beta;
     const float* post_res;
+    const float* up;
     float* y;
     long N;
     int H, W, Cin, Cin1, Cout, ksize, stride;
@@ -784,7 +846,7 @@ int far_conv_nhwc_f32(const far_conv_desc* desc, hipStream_t stream) {
     if (!desc) return FAR_EINVAL;
     const far_conv_desc& d = *desc;
     const float *x = d.x, *x2 = d.x2, *scale = d.scale, *shift = d.shift, *res = d.res;
-    const float *ln_gamma = d.ln_gamma, *ln_beta = d.ln_beta, *post_res = d.post_res;
+    const float *ln_gamma = d.ln_gamma, *ln_beta = d.ln_beta, *post_res = d.post_res, *up = d.up;
     const void* packed = d.packed;
     float* y = d.y;
     const long N = d.N;
@@ -799,10 +861,15 @@ int far_conv_nhwc_f32(const far_conv_desc* desc, hipStream_t stream) {
         return FAR_EINVAL;
     if (res_group < 1 || (res_group > 1 && (!res || ksize != 1 || out_planes != 1 || (N * H * W) % res_group))) return FAR_EINVAL;
     if (x2 ? (Cin1 <= 0 || Cin1 >= Cin || (Cin1 & 7)) : (Cin1 != Cin)) return FAR_EINVAL;
+    // fused 2x-upsample residual: 1x1 convolutions only, even H x W >= 2 x 32 (a 32-pixel tile row wraps at most once),
+    // one output tensor, no other residual / LayerNorm, 16-byte channel groups, a tensor the 32-bit row offsets can span
+    if (up && (ksize != 1 || (H & 1) || (W & 1) || W < 32 || out_planes != 1 || res || ln_gamma || post_res || (Cout & 3) ||
+               up == y || (long)(H / 2) * (W / 2) * Cout > 0x7fffffffL))
+        return FAR_EINVAL;
     ConvArgs a;
     a.x = x; a.x2 = x2; a.Cin1 = Cin1; a.w = (const unsigned char*)packed; a.scale = scale;
     a.zeros = reinterpret_cast<const float*>((const unsigned char*)packed + far_conv_packed_bytes(Cin, Cout, ksize, stride, split) - 32); a.shift = shift; a.res = res; a.res_group = res_group; a.y = y;
-    a.ln_gamma = ln_gamma; a.ln_beta = ln_beta; a.ln_eps = ln_eps; a.post_res = post_res;
+    a.ln_gamma = ln_gamma; a.ln_beta = ln_beta; a.ln_eps = ln_eps; a.post_res = post_res; a.up = up;
     a.H = H; a.W = W; a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1; a.Cin = Cin; a.Cout = Cout; a.Csub = Cout / out_planes;
     a.npix = N * a.Ho * a.Wo;
     const TileCfg c = cfg_for(Cout, stride);

@@ -120,13 +120,19 @@ class ResNetFPN_8_2(nn.Module):
         x3_out = ops.conv_nhwc(x3, pk.get('layer3_outconv', self.layer3_outconv, None, sp))
         sp = self.fpn_split
         o2, o1 = self.layer2_outconv2, self.layer1_outconv2
-        y = ops.upsample2x_add(x3_out.permute(0, 3, 1, 2),
-                               ops.conv_nhwc(x2, pk.get('layer2_outconv', self.layer2_outconv, None, sp)).permute(0, 3, 1, 2))
-        y = ops.conv_nhwc(y.permute(0, 2, 3, 1), pk.get('o2.0', o2[0], o2[1], sp), act='leaky', slope=o2[2].negative_slope)
+        # FPN merge (:108-109, :113-114): lateral 1x1 convolution + 2x bilinear upsampling of the coarser level, in the
+        # convolution's epilogue when the level is even-sized and at least 32 wide, else conv + K8
+        def merge(name, conv, fine, coarse):
+            pc = pk.get(name, conv, None, sp)
+            N, H, W, _ = fine.shape
+            if H % 2 == 0 and W % 2 == 0 and W >= 32 and tuple(coarse.shape[1:3]) == (H // 2, W // 2):
+                return ops.conv_nhwc(fine, pc, up=coarse)
+            return ops.upsample2x_add(coarse.permute(0, 3, 1, 2), ops.conv_nhwc(fine, pc).permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+        y = merge('layer2_outconv', self.layer2_outconv, x2, x3_out)
+        y = ops.conv_nhwc(y, pk.get('o2.0', o2[0], o2[1], sp), act='leaky', slope=o2[2].negative_slope)
         x2_out = ops.conv_nhwc(y, pk.get('o2.3', o2[3], None, sp))
-        y = ops.upsample2x_add(x2_out.permute(0, 3, 1, 2),
-                               ops.conv_nhwc(x1, pk.get('layer1_outconv', self.layer1_outconv, None, sp)).permute(0, 3, 1, 2))
-        y = ops.conv_nhwc(y.permute(0, 2, 3, 1), pk.get('o1.0', o1[0], o1[1], sp), act='leaky', slope=o1[2].negative_slope)
+        y = merge('layer1_outconv', self.layer1_outconv, x1, x2_out)
+        y = ops.conv_nhwc(y, pk.get('o1.0', o1[0], o1[1], sp), act='leaky', slope=o1[2].negative_slope)
         x1_out = ops.conv_nhwc(y, pk.get('o1.3', o1[3], None, sp))
         # (N, C, H, W)-shaped views of the NHWC buffers: downstream 'n c h w -> n (h w) c' is then a free view
         return [x3_out.permute(0, 3, 1, 2), x1_out.permute(0, 3, 1, 2)]

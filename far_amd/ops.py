@@ -342,12 +342,16 @@ class PackCache:
 
 
 def conv_nhwc(x, pc, residual=None, act='none', slope=0.01, x2=None, out_planes=1, res_group=1, ln=None,
-              post_residual=None, out=None):
+              post_residual=None, out=None, up=None):
     """K9.  x (N, H, W, Cin) fp32 contiguous -> act(conv(x) * scale + shift (+ residual)) as (N, H, W, Cout).
     With x2 (N, H, W, C2) the convolution input is cat([x, x2], -1), read in place.  out_planes = P > 1 returns
-    (P, N, H, W, Cout / P): the output channels split into P separate contiguous tensors."""
+    (P, N, H, W, Cout / P): the output channels split into P separate contiguous tensors.
+    up (N, H/2, W/2, Cout), 1x1 convolutions: + F.interpolate(up, scale_factor=2, bilinear, align_corners=True)
+    in the epilogue (the FPN merge)."""
     lib = _lib.load()
     N, H, W, Cin1 = x.shape
+    if up is not None and (tuple(up.shape) != (N, H // 2, W // 2, pc.Cout) or not up.is_contiguous()):
+        raise _lib.FarHipError(f'conv_nhwc: `up` must be a contiguous ({N}, {H // 2}, {W // 2}, {pc.Cout}) tensor')
     Cin = Cin1 + (x2.shape[-1] if x2 is not None else 0)
     if Cin != pc.Cin or (x2 is not None and tuple(x2.shape[:3]) != (N, H, W)):
         raise _lib.FarHipError(f'conv_nhwc: input has {Cin} channels, weights expect {pc.Cin}')
@@ -368,7 +372,7 @@ def conv_nhwc(x, pc, residual=None, act='none', slope=0.01, x2=None, out_planes=
     g, b, eps = ln if ln is not None else (None, None, 0.0)
     ptr = lambda t: _p(t, torch.float32).value
     d = _lib.ConvDesc(x=ptr(x), x2=ptr(x2), packed=_p(pc.packed).value, scale=ptr(pc.scale), shift=ptr(pc.shift),
-                      res=ptr(residual), ln_gamma=ptr(g), ln_beta=ptr(b), post_res=ptr(post_residual), y=ptr(y),
+                      res=ptr(residual), ln_gamma=ptr(g), ln_beta=ptr(b), post_res=ptr(post_residual), up=ptr(up), y=ptr(y),
                       N=N, H=H, W=W, Cin=Cin, Cin1=Cin1, Cout=pc.Cout, ksize=pc.ksize, stride=st, act=_ACT[act],
                       split=int(pc.split), out_planes=int(out_planes), res_group=int(res_group), slope=float(slope),
                       ln_eps=float(eps))

@@ -203,6 +203,9 @@ int far_conv_pack_f32(const float* w, int Cin, int Cout, int ksize, int stride, 
  *   ln_gamma, ln_beta != NULL (Cout = 128 or 256): LayerNorm over the Cout channels (eps ln_eps, biased variance)
  *   times gamma plus beta, then + post_res if given -- transformer.py:61 (norm1 after merge) and :65-67
  *   (x + norm2(mlp(...))) fused into the Linear layer's epilogue.
+ *   up [N][H/2][W/2][Cout] (ksize 1, even H, W >= 32, no other residual): its 2x bilinear upsampling
+ *   (align_corners = True) is added before the activation -- the FPN merge of resnet_fpn.py:108-109, :113-114
+ *   (F.interpolate(scale_factor=2, mode='bilinear', align_corners=True) + lateral 1x1 convolution) in one launch.
  *   y must alias none of the inputs. */
 typedef struct far_conv_desc {
     const float* x;
@@ -214,6 +217,7 @@ typedef struct far_conv_desc {
     const float* ln_gamma;
     const float* ln_beta;
     const float* post_res;
+    const float* up;
     float* y;
     long N;
     int H, W, Cin, Cin1, Cout, ksize, stride;

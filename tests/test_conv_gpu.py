@@ -321,3 +321,24 @@ def test_linear_three_planes_of_128_and_residual_activations():
         y = ops.conv_nhwc(xi, ops.PackedConv(wc), residual=res, act=act, slope=0.01)
         emax, _ = _rel(y, fn(base))
         assert emax < 5e-6, (act, emax)
+
+
+@pytest.mark.parametrize('N,H,W,Cin,Cout', [(2, 24, 32, 128, 196), (1, 30, 44, 196, 256), (3, 16, 64, 64, 128)])
+def test_conv_fused_upsample_merge_is_bit_identical_to_conv_plus_k8(N, H, W, Cin, Cout):
+    """The FPN merge in the 1x1 convolution's epilogue (up=) against the two-kernel sequence conv -> K8, and K8's own
+    parity target F.interpolate(scale_factor=2, bilinear, align_corners=True)."""
+    ops = _ops()
+    g = torch.Generator(device='cuda').manual_seed(N * H + W)
+    x = torch.randn(N, H, W, Cin, device='cuda', generator=g)
+    coarse = torch.randn(N, H // 2, W // 2, Cout, device='cuda', generator=g)
+    pc = ops.PackedConv(torch.randn(Cout, Cin, 1, 1, device='cuda', generator=g) * 0.08)
+    fused = ops.conv_nhwc(x, pc, up=coarse)
+    lateral = ops.conv_nhwc(x, pc)
+    two = ops.upsample2x_add(coarse.permute(0, 3, 1, 2), lateral.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+    assert torch.equal(fused, two.contiguous())
+    ref = lateral.double() + F.interpolate(coarse.permute(0, 3, 1, 2).double(), scale_factor=2., mode='bilinear',
+                                           align_corners=True).permute(0, 2, 3, 1)
+    assert float((fused.double() - ref).abs().max()) < 1e-5
+    from far_amd._lib import FarHipError
+    with pytest.raises(FarHipError):                      # 3x3 convolutions have no fused merge
+        ops.conv_nhwc(x, ops.PackedConv(torch.randn(Cout, Cin, 3, 3, device='cuda', generator=g)), up=coarse)

@@ -58,6 +58,13 @@ for C, H, W in ((128, 240, 320), (196, 120, 160), (256, 60, 80)):
     rows.append((f'3x3 {C}->{C} @{H}x{W}', timed(lambda: ops.conv_nhwc(xi, pc, act='relu'), 10)))
     rows.append((f'3x3 {C}->{C} @{H}x{W} + res', timed(lambda: ops.conv_nhwc(xi, pc, act='relu', residual=xi), 10)))
     del xi
+for Ci, Co, H, W in ((128, 196, 240, 320), (196, 256, 120, 160)):
+    xi = torch.randn(64, H, W, Ci, device=dev, generator=g)
+    up = torch.randn(64, H // 2, W // 2, Co, device=dev, generator=g)
+    pc = ops.PackedConv(torch.randn(Co, Ci, 1, 1, device=dev, generator=g) * 0.05)
+    rows.append((f'FPN merge {Ci}->{Co} @{H}x{W}: conv, then K8', timed(lambda: ops.upsample2x_add(up.permute(0, 3, 1, 2), ops.conv_nhwc(xi, pc).permute(0, 3, 1, 2)), 10)))
+    rows.append((f'FPN merge {Ci}->{Co} @{H}x{W}: fused', timed(lambda: ops.conv_nhwc(xi, pc, up=up), 10)))
+    del xi, up
 print(f'# {_lib.LIB_PATH}')
 for nm, us in rows:
-    print(f'{nm:36s} {us:9.1f} us')
+    print(f'{nm:48s} {us:9.1f} us')
