@@ -14,6 +14,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from .. import ops
 from ..pose6d import compute_normalized_6d, pose_mean_6d, pose_std_6d, rotation_6d_to_matrix
 from .backbone import build_backbone
 from .stages import CoarseMatching, FineMatching, FinePreprocess
@@ -148,15 +149,22 @@ class LoFTR(nn.Module):
             rt = data['loftr_rt'].detach().to(dev)
             rt = rt.unsqueeze(0) if rt.dim() == 2 else rt
             B = rt.shape[0]
-            last_row = torch.tensor([[[0, 0, 0, 1.]]], device=dev, dtype=rt.dtype).expand(B, -1, -1)
-            rt_inv = torch.linalg.inv(torch.cat([rt, last_row], dim=1))[:, :3, :4]
-            preds = compute_normalized_6d(rt.float())
-            inv_preds = compute_normalized_6d(rt_inv).float()
             extra = []
             if self.config['regress']['regress_use_num_corres']:
                 extra.append('num_correspondences')
             if self.config['use_many_ransac_thr']:
                 extra += ['num_correspondences_before_ransac', 'inliers_best_tight', 'inliers_best_ultra_tight']
+            if rt.is_cuda:                                                     # K11: the lines below in one launch
+                cnts = []
+                for k in extra:
+                    c = data[k].detach().to(dev).reshape(B)
+                    cnts.append(c if c.dtype in (torch.int32, torch.int64) else c.to(torch.int64))
+                preds, inv_preds = ops.pose_features(rt.to(torch.float64), cnts)
+                return f0, f1, data.get('mask_c0'), data.get('mask_c1'), preds, inv_preds
+            last_row = torch.tensor([[[0, 0, 0, 1.]]], device=dev, dtype=rt.dtype).expand(B, -1, -1)
+            rt_inv = torch.linalg.inv(torch.cat([rt, last_row], dim=1))[:, :3, :4]
+            preds = compute_normalized_6d(rt.float())
+            inv_preds = compute_normalized_6d(rt_inv).float()
             if extra:                                                          # counts / 500 (:158, :164-166)
                 cnt = torch.cat([data[k].detach().float().to(dev).reshape(B, 1) / 500 for k in extra], -1)
                 preds, inv_preds = torch.cat([preds, cnt], -1), torch.cat([inv_preds, cnt], -1)

@@ -222,7 +222,49 @@ def solve_pose_batch(kpts0, kpts1, offsets_host, K0, K1, inl_th, many_thr, prior
         _p(ws), _stream())
     _lib.check(rc, 'far_solver_f64')
     out.update(dbg)
+    out['offsets'] = offs_d
     return out
+
+
+def pose_pack(sol, offsets_dev):
+    """K11a.  The solver's result dict -> the data-dict tensors of spvs_RT (supervision.py:218-233) in one launch:
+    rt (B, 3, 4) and E (B, 3, 3) float64 with the identity fallback, before (B,) int64, after / tight / ultra (B,) int32
+    (zero for pairs with fewer than 5 correspondences).  offsets_dev: the solver's (B + 1,) int32 offsets on the GPU."""
+    lib = _lib.load()
+    B = sol['R'].shape[0]
+    dev = sol['R'].device
+    i32 = torch.int32
+    rt = torch.empty(B, 3, 4, dtype=torch.float64, device=dev)
+    E = torch.empty(B, 3, 3, dtype=torch.float64, device=dev)
+    before = torch.empty(B, dtype=torch.int64, device=dev)
+    after, tight, ultra = (torch.empty(B, dtype=i32, device=dev) for _ in range(3))
+    rc = lib.far_pose_pack_f64(_p(sol['R'], torch.float64), _p(sol['t'], torch.float64), _p(sol['E'], torch.float64),
+                               _p(sol['status'], i32), _p(sol['num_after'], i32), _p(sol['tight'], i32), _p(sol['ultra'], i32),
+                               _p(offsets_dev, i32), B, _p(rt), _p(E), _p(before), _p(after), _p(tight), _p(ultra), _stream())
+    _lib.check(rc, 'far_pose_pack_f64')
+    return rt, E, before, after, tight, ultra
+
+
+def pose_features(rt, counts=()):
+    """K11b.  preprocess_helper's arithmetic (loftr.py:137-171): rt (B, 3, 4) float64 GPU -> (preds, inv_preds), each
+    (B, 9 + len(counts)) fp32: the pose / its inverse as normalised [t, R rows 0-1], then count / 500 per count vector
+    (each (B,) int32 or int64 on the GPU, at most four)."""
+    lib = _lib.load()
+    B = rt.shape[0]
+    if len(counts) > 4:
+        raise _lib.FarHipError('pose_features: at most four count vectors')
+    args = []
+    for c in counts:
+        if c.dtype not in (torch.int32, torch.int64) or c.numel() != B:
+            raise _lib.FarHipError('pose_features: counts must be (B,) int32 / int64 tensors')
+        args += [_p(c.contiguous()), c.element_size()]
+    args += [ctypes.c_void_p(0), 0] * (4 - len(counts))
+    width = 9 + len(counts)
+    preds = torch.empty(B, width, dtype=torch.float32, device=rt.device)
+    inv = torch.empty(B, width, dtype=torch.float32, device=rt.device)
+    rc = lib.far_pose_features_f32(_p(rt.contiguous(), torch.float64), B, *args, _p(preds), _p(inv), _stream())
+    _lib.check(rc, 'far_pose_features_f32')
+    return preds, inv
 
 
 def layernorm(x, weight, bias, eps=1e-5, residual=None, out=None):

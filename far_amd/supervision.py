@@ -7,6 +7,7 @@ loftr_rt / expec_rt (3, 4) float64, expec_e (3, 3), count tensors (1,).
 """
 import torch
 
+from . import ops
 from .solver import estimate_pose_batch
 
 
@@ -23,23 +24,18 @@ def spvs_RT(data, config, H=2048, seed=0):
         counts = torch.bincount(data['m_bids'], minlength=B).cpu().tolist()
     out = estimate_pose_batch(data['mkpts0_f'], data['mkpts1_f'], counts, K0, K1, pixel_thr, solver, prior,
                               H=H, seed=seed)
-    ok = out['status'].bool()
-    eye34 = torch.cat([torch.eye(3), torch.zeros(3, 1)], 1).to(device=dev, dtype=torch.float64)
-    rt = torch.cat([out['R'], out['t'].unsqueeze(-1)], dim=-1)                                 # :218-219
-    rt = torch.where(ok[:, None, None], rt, eye34)                                             # :221-224
-    E = torch.where(ok[:, None, None], out['E'], torch.eye(3, device=dev, dtype=torch.float64))
-    few = torch.tensor(counts, device=dev) < 5                                                 # metrics.py:83-85
-    z = lambda v: torch.where(few, torch.zeros_like(v), v)
-    before = torch.tensor(counts, device=dev)
+    # K11: [R | t] with the identity fallback (:218-224), E, and the count tensors (zero below 5 correspondences,
+    # metrics.py:83-85) in one launch
+    rt, E, before, after, tight, ultra = ops.pose_pack(out, out['offsets'])
     data.update({
         'loftr_rt': rt[0] if B == 1 else rt,
         'expec_rt': rt[0] if B == 1 else rt,
         'expec_e': E[0] if B == 1 else E,
         'num_correspondences_before_ransac': before,
-        'num_correspondences_after_ransac': z(out['num_after']),
-        'num_correspondences': z(out['num_after']),
-        'inliers_best_tight': z(out['tight']),
-        'inliers_best_ultra_tight': z(out['ultra']),
+        'num_correspondences_after_ransac': after,
+        'num_correspondences': after,
+        'inliers_best_tight': tight,
+        'inliers_best_ultra_tight': ultra,
         'solver_inlier_mask': out['mask'],
         'solver_status': out['status'],
     })

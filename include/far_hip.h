@@ -236,6 +236,25 @@ int far_stem7x7_nhwc_f32(const float* img, const float* w, const float* scale, c
                          int Cout, float* y, far_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * K11  per-pair arithmetic between the solver and the regression head (one launch each)
+ * far_pose_pack_f64 replaces src/loftr/utils/supervision.py:218-233 (spvs_RT: [R | t] with the identity fallback of
+ *   :221-224, E with its identity fallback, the count tensors) and src/utils/metrics.py:83-85 (< 5 matches: counts 0).
+ *   R, E [B][9], t [B][3] float64, status / num_after / tight / ultra [B] int32 as far_solver_f64 leaves them;
+ *   offsets [B+1] int32.  rt_out [B][12] (3x4 row-major), E_out [B][9] float64; before_out [B] int64;
+ *   after_out / tight_out / ultra_out [B] int32.
+ * far_pose_features_f32 replaces src/loftr/loftr.py:137-171 (preprocess_helper) with src/losses/loftr_loss.py:7-8,
+ *   31-39 (pose_mean_6d / pose_std_6d, compute_normalized_6d): rt [B][12] float64 -> preds (pose, cast to fp32 then
+ *   normalised) and inv_preds (4x4 inverse and normalisation in float64, then cast), each [B][9 + n] fp32 where the n
+ *   present count vectors cnt_k [B] (elem_bytes_k = 4: int32, 8: int64, 0: absent) are appended as count / 500.
+ * --------------------------------------------------------------------------------------------------- */
+int far_pose_pack_f64(const double* R, const double* t, const double* E, const int* status, const int* num_after,
+                      const int* tight, const int* ultra, const int* offsets, int B, double* rt_out, double* E_out,
+                      long* before_out, int* after_out, int* tight_out, int* ultra_out, far_stream_t stream);
+int far_pose_features_f32(const double* rt, int B, const void* cnt0, int elem_bytes0, const void* cnt1, int elem_bytes1,
+                          const void* cnt2, int elem_bytes2, const void* cnt3, int elem_bytes3, float* preds,
+                          float* inv_preds, far_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * K4  batched essential-matrix solver (hypothesise / verify / decompose / cheirality), float64
  * replaces src/utils/metrics.py:80-174 (estimate_pose), third_party/prior_ransac/ransac.py:340-442
  *      (RANSAC.forward + verify + get_prior_estimate), cv_geometry.py:713-833 (run_8point),
