@@ -14,7 +14,7 @@ if gcols:
     g = gcols[0] if 'grid_size' not in cols else 'grid_size'
     sel = ', '.join(gcols[:3])
     for row in cur.execute(f"select {sel}, count(*), avg(end-start)/1e3, min(end-start)/1e3, max(end-start)/1e3 from kernels "
-                           f"where name like '%k_conv<3, 2, 2, 4, true, 1>%' group by {sel} order by 5 desc"):
+                           f"where name like '%k_conv<3, 2, 2, 4, true, 1, false>%' group by {sel} order by 5 desc"):
         print('grid', row[:len(gcols[:3])], f'calls {row[-4]}  avg {row[-3]:.1f} us  min {row[-2]:.1f}  max {row[-1]:.1f}')
 else:
     print('no grid columns in', cols)
