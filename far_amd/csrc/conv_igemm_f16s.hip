@@ -597,9 +597,12 @@ __global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const 
     FAR_K9_STAMP(1);
 
     // Fragment registers.  The pixel (A) fragments of a phase are read during the previous phase; the weight (B)
-    // fragments in two halves of NTW / 2 column tiles, the second half behind the first half's MFMAs.
-    constexpr int NH = NTW / 2;
+    // fragments in groups of NH column tiles, double buffered: group g + 1 is read behind group g's MFMAs.  Two groups
+    // of NTW / 2 tiles normally; single tiles (16 fewer registers) where the staging registers of a large halo
+    // (ITERS > 3: the 4 x 1 wave layout of the 3x3 mode) would otherwise spill inside the K loop.
     constexpr bool APRE = ITERS <= 3;      // pixel fragments one phase ahead (needs 16 more registers)
+    constexpr int NH = APRE ? NTW / 2 : 1;
+    constexpr int NGRP = NTW / NH;
     f16x8 ah[2], al[2], ahn[2], aln[2], bh[2][NH], bl[2][NH];
     auto read_a = [&](f16x8 (&xh)[2], f16x8 (&xl)[2], int tap, int ks) {
         const int tapoff = KS == 1 ? 0 : G::px_off(tap / KS, tap % KS);
@@ -610,36 +613,38 @@ __global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const 
             xl[mt] = *reinterpret_cast<const f16x8*>(A + (SPLIT ? G::A_PLANE : 32) + a_off[mt]);   // lo plane / second k-step
         }
     };
-    auto read_b = [&](int half, const unsigned char* B) {
+    auto read_b = [&](int grp, const unsigned char* B) {
+        const int half = grp & 1;
 #pragma unroll
         for (int q = 0; q < NH; ++q) {
-            bh[half][q] = *reinterpret_cast<const f16x8*>(B + (half * NH + q) * 32 * 32);
-            bl[half][q] = *reinterpret_cast<const f16x8*>(B + B_PLANE + (half * NH + q) * 32 * 32);
+            bh[half][q] = *reinterpret_cast<const f16x8*>(B + (grp * NH + q) * 32 * 32);
+            bl[half][q] = *reinterpret_cast<const f16x8*>(B + B_PLANE + (grp * NH + q) * 32 * 32);
         }
     };
-    auto mma_half = [&](int half) {
+    auto mma_half = [&](int grp) {
+        const int half = grp & 1;
 #pragma unroll
         for (int q = 0; q < NH; ++q)
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
-                acc[mt][half * NH + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[half][q], acc[mt][half * NH + q], 0, 0, 0);
+                acc[mt][grp * NH + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[half][q], acc[mt][grp * NH + q], 0, 0, 0);
         if (SPLIT) {
 #pragma unroll
             for (int q = 0; q < NH; ++q)
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
-                    acc[mt][half * NH + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[half][q], acc[mt][half * NH + q], 0, 0, 0);
+                    acc[mt][grp * NH + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[half][q], acc[mt][grp * NH + q], 0, 0, 0);
 #pragma unroll
             for (int q = 0; q < NH; ++q)
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
-                    acc[mt][half * NH + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[half][q], acc[mt][half * NH + q], 0, 0, 0);
+                    acc[mt][grp * NH + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[half][q], acc[mt][grp * NH + q], 0, 0, 0);
         } else {                                   // second k-step of the chunk: its own pixel and weight fragments
 #pragma unroll
             for (int q = 0; q < NH; ++q)
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
-                    acc[mt][half * NH + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bl[half][q], acc[mt][half * NH + q], 0, 0, 0);
+                    acc[mt][grp * NH + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bl[half][q], acc[mt][grp * NH + q], 0, 0, 0);
         }
     };
 
@@ -669,13 +674,15 @@ __global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const 
                 if (tap == LOAD_TAP && ks == 0) __builtin_amdgcn_sched_barrier(0);   // the slab's DMAs stay ahead of the pixel loads (the waits count on it)
                 if (tap == LOAD_TAP && ks == 0)            // unconditional (no branch in the body): the last chunk requests zeros
                     stage_load<KS, MW, ST, NTHR, ITERS>(st, p, tp, chunk + 1, tid, chunk + 1 < nchunks);
-                read_b(1, B);
-                mma_half(0);
-                if (APRE && !(tap == TAPS - 1 && (ks == 1 || !SPLIT))) {       // pixel fragments of the next phase of this chunk
-                    const bool wrap = ks + 1 >= nks;               // (a skipped second k-step makes the next phase (tap + 1, 0))
-                    read_a(ahn, aln, wrap ? tap + 1 : tap, wrap ? 0 : 1);
+#pragma unroll
+                for (int grp = 0; grp < NGRP; ++grp) {
+                    if (grp + 1 < NGRP) read_b(grp + 1, B);
+                    if (grp == NGRP - 1 && APRE && !(tap == TAPS - 1 && (ks == 1 || !SPLIT))) {   // pixel fragments of the next phase of this chunk
+                        const bool wrap = ks + 1 >= nks;           // (a skipped second k-step makes the next phase (tap + 1, 0))
+                        read_a(ahn, aln, wrap ? tap + 1 : tap, wrap ? 0 : 1);
+                    }
+                    mma_half(grp);
                 }
-                mma_half(1);
                 // issue order: one MFMA, then the other instructions of the phase (LDS reads, the DMA requests and
                 // their address arithmetic) in the issue slots its 32-cycle pass leaves free
 #pragma unroll
