@@ -29,13 +29,22 @@
 //    barrier never drains the DMA queue).  One barrier per phase.
 //  * per phase and wave: 12 ds_read_b128 fragment reads (the pixel fragments one phase ahead, the weight fragments in
 //    two halves, the second behind the first half's MFMAs) and 24 MFMAs (split: hi.hi + hi.lo + lo.hi of one 16-channel
-//    k-step) / 16 (plain operands: one phase per tap, both k-steps of the chunk, the slab's two planes = the two k-steps).  The phase body is one
-//    basic block (unconditional slab request, taps and k-steps unrolled) whose issue order is pinned with
+//    k-step) / 16 (plain operands: one phase per tap, both k-steps of the chunk, the slab's two planes = the two
+//    k-steps).  The phase body is one basic block (unconditional slab request, taps and k-steps unrolled) whose issue order is pinned with
 //    sched_group_barrier: one MFMA, then the LDS reads / DMA requests / address arithmetic that fit in the issue
 //    slots its 32-cycle pass leaves free (+5-7 % over letting them queue up in front of the MFMA block).
-// Measured on MI355X (64 images, tools/conv_probe.py): 3x3 layers 270-380 TFLOP/s fp32-equivalent (0.8-1.2 PFLOP/s of
-// f16 MFMA issue, ~47 % of the matrix peak) including the fused epilogue, against 100-125 TFLOP/s for the vendor
-// fp32 Winograd convolution alone.
+//  * memory waits: loads, LDS-DMA requests and stores share ONE in-order vmcnt on gfx9, and with LDS-DMA requests
+//    pending the compiler turns every wait on a load into vmcnt(0).  So nothing touches a staged pixel value before
+//    stage_store (padding lanes load a zero row appended to the packed weights instead of being masked), the slab
+//    waits are explicit and count the pixel loads in flight, and the epilogue's store loops are straight-line with all
+//    their loads (residual rows, LayerNorm parameters) marked arrived up front: stores stream back to back.
+//  * epilogue: acc * scale + shift through a 16 KiB-per-wave LDS transpose to 16-byte row accesses; optional residual
+//    (one row per pixel or per group of rows), fused LayerNorm (+ post-norm residual), or the FPN merge (2x bilinear
+//    upsampling of the coarser level added, `up`, its own template instantiation); activation max(v, v a + b).
+// Measured on MI355X (64 images, bench.py / tools/k9_ab.py): 3x3 layers 331-438 TFLOP/s fp32-equivalent (1.0-1.3 PFLOP/s
+// of f16 MFMA issue: 40-53 % of the matrix peak at the nominal 2.4 GHz, ~75 % of the pipe's cycles at the 1.5-1.8 GHz
+// the part sustains under this load, tools/k9_timing.py) including the fused epilogue, against 100-125 TFLOP/s for
+// the vendor fp32 Winograd convolution alone.
 #include "common.h"
 #include <type_traits>
 
