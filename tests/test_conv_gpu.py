@@ -342,3 +342,24 @@ def test_conv_fused_upsample_merge_is_bit_identical_to_conv_plus_k8(N, H, W, Cin
     from far_amd._lib import FarHipError
     with pytest.raises(FarHipError):                      # 3x3 convolutions have no fused merge
         ops.conv_nhwc(x, ops.PackedConv(torch.randn(Cout, Cin, 3, 3, device='cuda', generator=g)), up=coarse)
+
+
+def test_conv_is_run_to_run_deterministic_under_load():
+    """K9's slab / pixel waits count memory requests; an under-wait would be a race.  Same launch repeated with other
+    work in flight on a second stream: every output bit-identical to the first (tools/k9_stress.py is the long form)."""
+    ops = _ops()
+    g = torch.Generator(device='cuda').manual_seed(8)
+    side = torch.cuda.Stream()
+    junk = torch.randn(2048, 2048, device='cuda')
+    for (N, H, W, Cin, Cout, ks, st) in [(4, 60, 80, 196, 196, 3, 1), (4, 60, 80, 128, 128, 3, 1), (1, 1, 40000, 256, 256, 1, 1),
+                                         (4, 60, 80, 128, 196, 3, 2)]:
+        for split in (True, False):
+            x = torch.randn(N, H, W, Cin, device='cuda', generator=g)
+            pc = ops.PackedConv(torch.randn(Cout, Cin, ks, ks, device='cuda', generator=g) * 0.03, split=split, stride=st)
+            first = ops.conv_nhwc(x, pc, act='relu')
+            for r in range(8):
+                with torch.cuda.stream(side):
+                    for _ in range(r % 3):
+                        junk = junk @ junk * 1e-3
+                assert torch.equal(ops.conv_nhwc(x, pc, act='relu'), first), (N, H, W, Cin, Cout, ks, st, split, r)
+    torch.cuda.synchronize()
