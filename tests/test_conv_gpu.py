@@ -151,7 +151,7 @@ def test_stem_matches_float64(N, H, W, Cout):
     assert emax < 2e-6 and erms < 5e-7, (emax, erms)
 
 
-@pytest.mark.parametrize('H,W', [(96, 128), (136, 184)])      # whole tiles; ragged tiles at every level (BASELINE C5 is 544x720)
+@pytest.mark.parametrize('H,W', [(96, 128), (136, 184), (64, 96)])      # whole tiles; ragged tiles at every level (BASELINE C5 is 544x720); a level narrower than 32 (merge through K8)
 def test_fused_backbone_matches_reference_modules(H, W):
     """The NHWC kernel path of the backbone against its own reference-style torch modules in float64."""
     from far_amd.config import far_eval_config
