@@ -40,7 +40,17 @@ class PositionEncodingSine(nn.Module):
         self.register_buffer('pe', pe.unsqueeze(0), persistent=False)
 
     def forward(self, x):
-        return x + self.pe[:, :, :x.size(2), :x.size(3)]
+        pe = self.pe[:, :, :x.size(2), :x.size(3)]
+        if x.is_cuda and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous():
+            # the fused backbone hands over NHWC memory: add an NHWC copy of the table (cached per shape), so that the
+            # sum is one contiguous pass (the NCHW table against NHWC features was a strided 250 us kernel) and the
+            # 'n c h w -> n (h w) c' that follows stays a free view
+            key = (x.size(2), x.size(3), x.device)
+            cache = self.__dict__.setdefault('_pe_nhwc', {})
+            if key not in cache:
+                cache[key] = pe.contiguous(memory_format=torch.channels_last)
+            pe = cache[key]
+        return x + pe
 
 
 def _tokens(fmap, pos_enc):
