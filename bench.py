@@ -254,8 +254,11 @@ def main():
         kr = kernel_rooflines(a.pairs)
         # dominant kernel of the step: K9 (60 % of the kernel-busy time, profiles/); its costliest launch is reported
         dom = 'k_conv[K9 3x3 196->196 @240x320]'
+        tr = pmc_traffic(dom, a.pairs)
         roof = {'kernel': dom, 'bound': 'mfma', 'achieved': round(kr[dom]['tflops'], 2), 'peak': F16_MFMA_PEAK_TFLOPS,
-                'unit': 'TFLOP/s', 'frac': round(kr[dom]['frac'], 4), 'traffic': pmc_traffic(dom, a.pairs),
+                'unit': 'TFLOP/s', 'frac': round(kr[dom]['frac'], 4),
+                # HBM/fabric bytes per launch from the committed PMC passes (null when they do not match this geometry)
+                'traffic': (tr or {}).get('bytes'), 'traffic_detail': tr,
                 'launch_ms': round(kr[dom]['ms'], 3), 'mfma_issue_frac': round(kr[dom]['mfma_issue_frac'], 4),
                 'note': 'algorithmic convolution flops per launch / event-timed launch duration against the dense f16 '
                         'MFMA peak; the kernel executes 3 f16 MFMAs per fp32-grade product (split operands), so the '
