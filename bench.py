@@ -1,8 +1,11 @@
 #!/usr/bin/env python
 """bench.py -- image-pairs/sec of FAR's pose-estimation hot path (match + solve + regress) at 640x480.
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched under
-torch.distributed.run with one rank per GPU.  One "step" = one pass of the full evaluation path
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`.  For N > 1 the driver launches it under
+torch.distributed.run with one rank per GPU (WORLD_SIZE / RANK / LOCAL_RANK in the environment); when it is started
+plainly with --gpus N > 1 it launches those N ranks itself (far_amd.parallel.launch_ranks: child processes under
+torch.distributed.run, started before this process touches the GPU) and returns their exit code.
+One "step" = one pass of the full evaluation path
 (far_amd.pipeline.test_step == lightning_loftr.py:325-343) over one batch of 32 synthetic pairs per GPU
 (BASELINE.json configs[1]: "Matterport3D eval, batch 32 pairs @ 640x480, 1xMI355X"), inputs resident in HBM.
 Pairs are independent: ranks shard them with no data-path collective ("weak" scaling); the only collective is
@@ -39,6 +42,10 @@ def parse():
                     help='backbone convolution arithmetic (far_amd.loftr.LoFTR.set_precision): fp32 = split-fp16 operand pairs (fp32-grade)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-pairs', type=int, default=3)
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help="torch.distributed backend of the N > 1 run ('nccl' is RCCL on ROCm; 'gloo' only for the CPU self-test)")
+    ap.add_argument('--selftest-launcher', action='store_true',
+                    help='rendezvous + barrier + timing reduction only (no GPU work): exercises the N > 1 launch path on CPU')
     return ap.parse_args()
 
 
@@ -137,25 +144,32 @@ def kernel_rooflines(n_pairs):
     return out
 
 
-def pmc_traffic(kernel_label, n_pairs):
-    """HBM/fabric bytes per launch of the dominant kernel, from the committed PMC passes
-    (profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 x2 read correction).
-    Counters cannot be collected inside this process; the value is only reported when the committed measurement
-    was taken at the same launch geometry (batch 32), otherwise null."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
-    if not os.path.exists(path) or n_pairs != 32:
+def pmc_traffic(kernel_label, n_pairs, precision):
+    """HBM/fabric bytes per launch of the dominant kernel, from the newest committed PMC pass
+    (profiles/r*_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 x2 read
+    correction).  Counters cannot be collected inside this process, so this is a COMMITTED measurement, reported
+    only when it was taken at this launch geometry (batch 32) and operand precision -- otherwise null.  The entry
+    names the file it comes from, so that nobody divides it by a launch time of a different build unknowingly."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))
+    if not files or n_pairs != 32:
         return None
-    per = json.load(open(path))['per_launch']
+    path = files[-1]
+    doc = json.load(open(path))
+    if doc.get('precision', 'fp32') != precision:
+        return None
+    per = doc['per_launch']
     name = kernel_label.split('[')[0]
-    grid = {'k_emm_pv_f32': 38 * n_pairs * 8 * 256, 'k_stats_f32': None,
-            'k_conv': 2 * n_pairs * 30 * 20 * 256}.get(name)      # 196->196 @240x320: 30 x 20 tiles of 8 x 16 per image
-    if name == 'k_conv':
-        name = 'k_conv<3, 2, 2, 4, true, 1>'
-    if name == 'k_stats_f32':
-        grid = 38 * n_pairs * (8 if 'K2' in kernel_label else 1) * 256
-    ent = per.get(f'{name}|grid={grid}')
+    ent = None
+    for key, val in per.items():
+        if key.startswith(name) and val.get('label', kernel_label) == kernel_label:
+            ent = val
+            break
+    if ent is None and name == 'k_conv':          # round-1 file: keyed by template instantiation and grid
+        ent = per.get(f'k_conv<3, 2, 2, 4, true, 1>|grid={2 * n_pairs * 30 * 20 * 256}')
     return None if ent is None else {'bytes': ent['total_bytes'], 'read_bytes': ent['read_bytes'],
-                                     'write_bytes': ent['write_bytes'], 'source': 'profiles/r01_pmc_traffic.json'}
+                                     'write_bytes': ent['write_bytes'], 'precision': doc.get('precision', 'fp32'),
+                                     'source': os.path.relpath(path, ROOT), 'commit': doc.get('commit')}
 
 
 def cpu_baseline(n_pairs, hyp):
@@ -179,8 +193,36 @@ def cpu_baseline(n_pairs, hyp):
                       f'(numpy + torch-CPU fp32, solver float64, H={hyp}), {dt:.1f} s wall'}
 
 
+def selftest_launcher(a):
+    """N > 1 launch path without GPU work: every rank joins the process group, passes a barrier, contributes a
+    fake step time; rank 0 prints the JSON skeleton with the rank count the backend reports."""
+    import torch.distributed as dist
+    from far_amd import parallel
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    if world > 1:
+        dist.init_process_group(a.backend)
+    dist_world = dist.get_world_size() if world > 1 else 1
+    if world > 1:
+        dist.barrier()
+    dt = parallel.max_over_ranks(0.001 * (rank + 1))
+    per = parallel.gather_floats(0.001 * (rank + 1))
+    if rank == 0:
+        print(json.dumps({'selftest': 'launcher', 'n_gpus': dist_world, 'requested_gpus': a.gpus, 'backend': a.backend,
+                          'max_s': dt, 'per_rank_s': per}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks as children BEFORE this process initialises the GPU
+        from far_amd import parallel
+        sys.exit(parallel.launch_ranks(a.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
+    if a.selftest_launcher:
+        return selftest_launcher(a)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -189,7 +231,8 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        dist.init_process_group(a.backend, device_id=dev if a.backend == 'nccl' else None)
+        world = dist.get_world_size()            # the rank count the backend (RCCL) reports
     from far_amd import synth
     from far_amd.config import far_eval_config
     from far_amd.loftr import LoFTR
@@ -212,9 +255,10 @@ def main():
         test_step(model, batch, H=a.hyp, seed=0)
         return batch
 
-    # at least three untimed steps: the caching allocator still grows (multi-GB hipMallocs) during the first ones
-    a.warmup = max(a.warmup, 3)
-    for _ in range(a.warmup):
+    # the caching allocator still grows (multi-GB hipMallocs) during the first three steps: when fewer warm-up steps
+    # are asked for, the difference runs as separate untimed priming steps (reported as `prime_steps`)
+    prime = max(0, 3 - a.warmup)
+    for _ in range(prime + a.warmup):
         last = step()
 
     def fence():
@@ -230,6 +274,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     from far_amd import parallel
+    per_rank_ms = [round(1000 * x / a.steps, 3) for x in parallel.gather_floats(dt, device=dev)]
     dt = parallel.max_over_ranks(dt, device=dev)          # the slowest rank defines the step time
     matches = float(last['b_ids'].numel()) / a.pairs
     ok_frac = float(last['solver_status'].float().mean().item())
@@ -254,11 +299,12 @@ def main():
         kr = kernel_rooflines(a.pairs)
         # dominant kernel of the step: K9 (60 % of the kernel-busy time, profiles/); its costliest launch is reported
         dom = 'k_conv[K9 3x3 196->196 @240x320]'
-        tr = pmc_traffic(dom, a.pairs)
+        tr = pmc_traffic(dom, a.pairs, a.precision)
         roof = {'kernel': dom, 'bound': 'mfma', 'achieved': round(kr[dom]['tflops'], 2), 'peak': F16_MFMA_PEAK_TFLOPS,
                 'unit': 'TFLOP/s', 'frac': round(kr[dom]['frac'], 4),
-                # HBM/fabric bytes per launch from the committed PMC passes (null when they do not match this geometry)
-                'traffic': (tr or {}).get('bytes'), 'traffic_detail': tr,
+                # HBM/fabric bytes per launch from the committed PMC passes (null when they do not match this geometry
+                # and precision); `committed_profile` names the file / commit they were measured at
+                'traffic': (tr or {}).get('bytes'), 'committed_profile': tr,
                 'launch_ms': round(kr[dom]['ms'], 3), 'mfma_issue_frac': round(kr[dom]['mfma_issue_frac'], 4),
                 'note': 'algorithmic convolution flops per launch / event-timed launch duration against the dense f16 '
                         'MFMA peak; the kernel executes 3 f16 MFMAs per fp32-grade product (split operands), so the '
@@ -268,9 +314,15 @@ def main():
         res = {
             'metric': 'image-pairs/sec (match+solve+regress) at 640x480',
             'value': round(world * a.pairs * a.steps / dt, 3), 'unit': 'image-pairs/sec',
-            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(1000 * dt / a.steps, 3),
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'prime_steps': prime,
+            'ms_per_step': round(1000 * dt / a.steps, 3), 'per_rank_ms_per_step': per_rank_ms,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32' if a.precision == 'fp32' else f'f32 tensors/accumulation, {a.precision} matrix operands', 'data': 'synthetic',
+            'dtype': 'f32' if a.precision == 'fp32' else f'f32 tensors/accumulation, {a.precision} matrix operands',
+            'dtype_note': ('f32 = fp32 tensors, fp32 accumulation; matrix products on the f16 MFMA pipe as split-f16x3 operand '
+                           'pairs (hi*hi + hi*lo + lo*hi, 22 significand bits: fp32-grade, not a bitwise fmaf chain); '
+                           'solver float64.  Activations above |a| = 4094 would overflow the split to inf (never silently); '
+                           'untested on a real-checkpoint activation distribution (no checkpoint offline)') if a.precision == 'fp32' else None,
+            'data': 'synthetic',
             'config': {'workload': 'Matterport3D-shaped eval (BASELINE configs[1]): batch 32 pairs @ 640x480 per GPU, '
                                    'LoFTR match + 8-pt prior-RANSAC solve (x2 rounds) + EMM head (x2), seeded random weights',
                        'pairs_per_gpu': a.pairs, 'hypotheses': a.hyp, 'fine_pred_steps': 2,

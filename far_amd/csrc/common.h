@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <float.h>
+#include <atomic>
 
 #define FAR_OK 0
 #define FAR_EINVAL (-22)
@@ -77,6 +78,25 @@ static inline void far_clear_errors() { (void)hipGetLastError(); }
 extern "C" int far_last_hip_error(void);
 int far_get_tuning(int key);
 void far_record_hip_error(int e);
+
+// Kernel attributes (hipFuncAttributeMaxDynamicSharedMemorySize) are PER DEVICE: a process-wide `static bool` would
+// leave every GPU but the first unconfigured (a gather on another device, a test that switches cuda:1).  One bit per
+// device ordinal per call site; the bit is published after the (idempotent) configuration call has returned, so a
+// thread that sees it set may launch, and two racing threads at worst both configure.
+static inline int far_current_device() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    return d & 63;
+}
+#define FAR_ONCE_PER_DEVICE(...)                                                        \
+    do {                                                                                \
+        static std::atomic<unsigned long long> far_done_{0};                            \
+        const unsigned long long far_bit_ = 1ull << far_current_device();               \
+        if (!(far_done_.load(std::memory_order_acquire) & far_bit_)) {                  \
+            __VA_ARGS__;                                                                \
+            far_done_.fetch_or(far_bit_, std::memory_order_release);                    \
+        }                                                                               \
+    } while (0)
 
 static inline int far_check_launch() {
     hipError_t e = hipGetLastError();

@@ -780,12 +780,10 @@ int launch_conv(const ConvArgs& a, dim3 grid, hipStream_t stream) {
     constexpr int smem_loop = PLANES * G::A_PLANE + 3 * 2 * 32 * NTW * NW * 32;
     constexpr int smem_epi = MW * NW * (32 * 128 * 4 + 32 * 4);  // conv_epilogue_wide: 16 KiB per wave + LayerNorm exchange
     constexpr int smem = smem_loop > smem_epi ? smem_loop : smem_epi;
-    static bool configured = false;
-    if (!configured) {
-        if (hipFuncSetAttribute((const void*)k_conv<KS, MW, NW, NTW, SPLIT, ST, UP>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
-            return far_check_launch();
-        configured = true;
-    }
+    bool cfg_failed = false;
+    FAR_ONCE_PER_DEVICE(cfg_failed = hipFuncSetAttribute((const void*)k_conv<KS, MW, NW, NTW, SPLIT, ST, UP>,
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess);
+    if (cfg_failed) return far_check_launch();
     hipLaunchKernelGGL((k_conv<KS, MW, NW, NTW, SPLIT, ST, UP>), grid, dim3(64 * MW * NW), smem, stream, a);
     return far_check_launch();
 }

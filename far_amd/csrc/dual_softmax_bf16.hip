@@ -375,13 +375,10 @@ int far_coarse_match_bf16(const float* f0, const float* f1, int Z, int L, int S,
     const int nI = (L + TILE_M - 1) / TILE_M;
     int* counts = counts_out ? counts_out : w.counts;
     hipMemsetAsync(counts, 0, sizeof(int) * Z, stream);
-    static bool attr_set = false;
     const size_t smem = 2 * 64 * (size_t)C * 2 + 2 * 4 * 64 * sizeof(float2);
-    if (!attr_set) {
+    FAR_ONCE_PER_DEVICE(
         hipFuncSetAttribute((const void*)k_stats_bf16<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipFuncSetAttribute((const void*)k_match_bf16<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_set = true;
-    }
+        hipFuncSetAttribute((const void*)k_match_bf16<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
 #define FAR_BF16_LAUNCH(NS)                                                                                          \
     hipLaunchKernelGGL(k_stats_bf16<NS>, dim3(nI * Z), dim3(256), smem, stream, f0b, f1b, Z, L, S, sp, mask0, mask1, \
                        w.rowstat, w.colpart);                                                                        \

@@ -339,13 +339,10 @@ int far_coarse_match_f16s(const float* f0, const float* f1, int Z, int L, int S,
     int* counts = counts_out ? counts_out : w.k.counts;
     hipMemsetAsync(counts, 0, sizeof(int) * Z, stream);
     const size_t smem_s = 2 * TILE_PLANE, smem_m = 2 * TILE_PLANE + 4 * 64 * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    FAR_ONCE_PER_DEVICE(
         hipFuncSetAttribute((const void*)k1_rowstats, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_s);
         hipFuncSetAttribute((const void*)k1_match<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_m);
-        hipFuncSetAttribute((const void*)k1_match<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_m);
-        attr_set = true;
-    }
+        hipFuncSetAttribute((const void*)k1_match<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_m));
     hipLaunchKernelGGL(k1_rowstats, dim3((Lp / 128) * Z), dim3(256), smem_s, stream, w.ah, w.al, w.bh, w.bl, Z, L, S, Lp, Sp,
                        c1, fill2, mask0, mask1, w.k.rowstat, (float*)nullptr, (float*)nullptr);
     hipLaunchKernelGGL(k1_rowstats, dim3((Sp / 128) * Z), dim3(256), smem_s, stream, w.bh, w.bl, w.ah, w.al, Z, S, L, Sp, Lp,

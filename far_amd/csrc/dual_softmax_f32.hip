@@ -478,12 +478,9 @@ int far_dual_softmax_stats_f32(const float* f0, const float* f1, int Z, int L, i
     int nI = (L + TILE_M - 1) / TILE_M;
     float2* rs = rowstat_out ? (float2*)rowstat_out : w.rowstat;
     float2* cs = colstat_out ? (float2*)colstat_out : w.colstat;
-    static bool attr_set = false;
-    if (!attr_set) {
+    FAR_ONCE_PER_DEVICE(
         hipFuncSetAttribute((const void*)k_stats_f32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTileSmem);
-        hipFuncSetAttribute((const void*)k_match_f32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTileSmem);
-        attr_set = true;
-    }
+        hipFuncSetAttribute((const void*)k_match_f32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTileSmem));
     if (C == 64 && sp.feat_div == 1.0f && !mask0 && !mask1 && far_get_tuning(1) == 0) {
         const size_t smem = 128 * S64_KS * sizeof(float) + 4 * 64 * sizeof(float2);
         hipLaunchKernelGGL(k_stats_c64_f32, dim3(nI * Z), dim3(256), smem, stream, f0, f1, Z, L, S, sp, rs, w.colpart);

@@ -202,11 +202,8 @@ int far_emm_pv_f32(const float* q, const float* k, const float* v, const float* 
                    float scale, const float* rowstat, const float* colstat, float* T_out, hipStream_t stream) {
     far_clear_errors();
     if (!q || !k || !v || !pos || !rowstat || !colstat || !T_out || Z <= 0 || N <= 0 || D != EM_D) return FAR_EINVAL;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)k_emm_pv_f32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(EmmLds));
-        attr_set = true;
-    }
+    FAR_ONCE_PER_DEVICE(
+        hipFuncSetAttribute((const void*)k_emm_pv_f32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(EmmLds)));
     hipLaunchKernelGGL(k_emm_pv_f32, dim3(((N + 127) / 128) * Z), dim3(256), sizeof(EmmLds), stream, q, k, v, pos, Z, N,
                        scale, (const float2*)rowstat, (const float2*)colstat, T_out, (far_get_tuning(0) >> 2) & 1);
     return far_check_launch();

@@ -167,16 +167,22 @@ class FinePreprocess(nn.Module):
             w0 = ops.fine_gather(feat_f0.float(), b, i, data['hw0_c'][1], W, stride, out=w01[:M])
             w1 = ops.fine_gather(feat_f1.float(), b, j, data['hw1_c'][1], W, stride, out=w01[M:])
         if self.cat_c_feat:
-            c_win = self.down_proj(torch.cat([feat_c0[b, i], feat_c1[b, j]], 0))     # [2M, C]
-            if ag.needs_grad(w0, w1, c_win, self.merge_feat.weight) or not w0.is_cuda:
+            c_in = torch.cat([feat_c0[b, i], feat_c1[b, j]], 0)                      # [2M, C_coarse]
+            if ag.needs_grad(w0, w1, c_in, self.merge_feat.weight, self.down_proj.weight) or not w0.is_cuda:
+                c_win = self.down_proj(c_in)                                         # [2M, C]
                 both = torch.cat([torch.cat([w0, w1], 0), c_win.unsqueeze(1).expand(-1, W ** 2, -1)], -1)
                 w0, w1 = torch.chunk(self.merge_feat(both), 2, dim=0)
             else:
+                # down_proj on K9 as well: every output row depends on its input row only, so a pair's windows do not
+                # depend on how many other pairs' matches share the launch (a vendor GEMM picks its kernel by the row
+                # count, which moved sub-pixel positions by an ulp between batch sizes)
+                pk = self.__dict__.setdefault('_packs', ops.PackCache())
+                dw, db = self.down_proj.weight, self.down_proj.bias
+                c_win = ops.linear_f16s(c_in.contiguous(), pk.get('down', [dw, db], lambda: ops.PackedConv(dw, None, db)))
                 # merge_feat(cat[window, repeat(c_win)]) = window W_f^T + (c_win W_c^T + b) repeated over the WW tokens
                 # (:52-57): neither the repeat nor the (2M, 25, 256) concatenation is materialised -- K9 adds one
                 # residual row per group of WW consecutive rows.
                 d = self.d_model_f
-                pk = self.__dict__.setdefault('_packs', ops.PackCache())
                 wt = self.merge_feat.weight
                 pf = pk.get('merge_f', [wt], lambda: ops.PackedConv(wt[:, :d].contiguous()))
                 pc = pk.get('merge_c', [wt, self.merge_feat.bias],

@@ -304,16 +304,20 @@ class LocalFeatureTransformerRegressor(nn.Module):
         # The evaluation loop calls the head FINE_PRED_STEPS times on the SAME coarse features; only the 13 solver
         # numbers change between calls (lightning_loftr.py:338-343).  Everything up to `features` (2 LoFTR layers,
         # K2, CrossBlock, LayerNorm) does not depend on them -- LinearAttention ignores loftr_preds
-        # (linear_attention.py:20) -- so it is computed once per feature pair and kept resident.  Inference only.
-        self.cache_features = True
-        self._feat_cache = None
+        # (linear_attention.py:20).  This module keeps NO state about it: `compute_features` is pure, and the reuse
+        # lives in the caller-owned data dict (LoFTR.forward_rt_prediction), whose lifetime is one batch.
+        self.cache_features = True          # False: LoFTR.forward_rt_prediction recomputes the features on every call
 
-    def _features(self, feat0, feat1, loftr_preds, inv_loftr_preds):
-        key = None
-        if self.cache_features and not torch.is_grad_enabled():
-            key = (feat0.data_ptr(), feat1.data_ptr(), feat0._version, feat1._version, tuple(feat0.shape))
-            if self._feat_cache is not None and self._feat_cache[0] == key:
-                return self._feat_cache[1]
+    def feature_stamp(self):
+        """What `compute_features` depends on besides its inputs: every weight it reads (storage + version, so that
+        load_state_dict / an optimizer step / an in-place edit invalidate) and the operand precision of its layers."""
+        mods = [self.emm, self.norm] + ([self.loftr] if self.config['regress_loftr_layers'] > 0 else [])
+        ws = tuple((p.data_ptr(), p._version) for m in mods for p in m.parameters())
+        prec = tuple(m.split_operands for m in self.modules() if isinstance(m, LoFTREncoderLayer))
+        return ws, prec, self.training
+
+    def compute_features(self, feat0, feat1, loftr_preds=None, inv_loftr_preds=None):
+        """(B, 35840) head features of transformer.py:488-497 + :424-428 (LoFTR layer(s), CrossBlock, LayerNorm)."""
         f0, f1 = feat0, feat1
         if self.config['regress_loftr_layers'] > 0:
             f0, f1 = self.loftr(f0, f1, loftr_preds=loftr_preds, inv_loftr_preds=inv_loftr_preds, joint_out=True)
@@ -322,13 +326,10 @@ class LocalFeatureTransformerRegressor(nn.Module):
                     f1.data_ptr() == f0.data_ptr() + f0.numel() * f0.element_size())
         x01 = torch.as_strided(f0, (2 * B,) + tuple(f0.shape[1:]), f0.stride()) if adjacent else torch.cat([f0, f1], dim=0)
         x = self.emm(x01, loftr_preds=loftr_preds, inv_loftr_preds=inv_loftr_preds)
-        features = self.norm(x).reshape([B, -1])
-        # hold references to the inputs so that their storage (hence data_ptr) cannot be recycled while cached
-        self._feat_cache = (key, features, feat0, feat1) if key is not None else None
-        return features
+        return self.norm(x).reshape([B, -1])
 
     def forward_emm(self, feat0, feat1, loftr_preds=None, inv_loftr_preds=None, features=None):
-        if features is None:
+        if features is None:                  # reference call shape: feat0 / feat1 are the LoFTR-layer outputs
             B = feat0.shape[0]
             x = self.emm(torch.cat([feat0, feat1], dim=0), loftr_preds=loftr_preds, inv_loftr_preds=inv_loftr_preds)
             features = self.norm(x).reshape([B, -1])
@@ -360,6 +361,9 @@ class LocalFeatureTransformerRegressor(nn.Module):
         pose = torch.cat([pred_T, pred_R], dim=-1)
         return pose, (features if rc['save_mlp_feats'] else None), gate
 
-    def forward(self, feat0, feat1, loftr_preds=None, inv_loftr_preds=None, mask0=None, mask1=None, F=None):
-        features = self._features(feat0, feat1, loftr_preds, inv_loftr_preds)
+    def forward(self, feat0, feat1, loftr_preds=None, inv_loftr_preds=None, mask0=None, mask1=None, F=None,
+                features=None):
+        """features: the output of compute_features on these same inputs, when the caller already has it."""
+        if features is None:
+            features = self.compute_features(feat0, feat1, loftr_preds, inv_loftr_preds)
         return self.forward_emm(feat0, feat1, loftr_preds, inv_loftr_preds, features=features)

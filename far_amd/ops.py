@@ -27,6 +27,15 @@ def _p(t, dtype=None):
     return ctypes.c_void_p(t.data_ptr())
 
 
+def _written(t):
+    """Tell autograd's version counter that `t` was overwritten through its raw device pointer (the kernels write
+    caller-provided `out=` tensors behind torch's back; anything keyed on Tensor._version -- PackCache, the head's
+    feature reuse -- must see it).  Inference tensors carry no version counter."""
+    if t is not None and not t.is_inference():
+        torch.autograd.graph.increment_version(t)
+    return t
+
+
 def _ws(nbytes, device):
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
@@ -149,7 +158,7 @@ def fine_gather(feat_f, b_ids, cell_ids, wc, W, stride, out=None):
                                  _p(b_ids, torch.int64), _p(cell_ids, torch.int64), int(wc), int(W), int(stride), M,
                                  _p(out), _stream())
     _lib.check(rc, 'far_fine_gather_f32')
-    return out
+    return _written(out)
 
 
 def fine_expect(feat0, feat1, mkpts1_c, win_scale, scale1=None, b_ids=None):
@@ -279,7 +288,7 @@ def layernorm(x, weight, bias, eps=1e-5, residual=None, out=None):
     rc = lib.far_layernorm_f32(_p(x, torch.float32), _p(weight, torch.float32), _p(bias, torch.float32),
                                _p(residual, torch.float32), rows, C, float(eps), _p(y), _stream())
     _lib.check(rc, 'far_layernorm_f32')
-    return y
+    return y if out is None else _written(y)
 
 
 def _layout(t):
@@ -318,7 +327,7 @@ def affine_act(x, scale, shift, residual=None, act='relu', slope=0.01, inplace=T
                                 ctypes.c_void_p(residual.data_ptr() if residual is not None else 0),
                                 N, C, H * W, lay, code, float(slope), ctypes.c_void_p(y.data_ptr()), _stream())
     _lib.check(rc, 'far_affine_act_f32')
-    return y
+    return _written(y) if inplace else y
 
 
 def upsample2x_add(lo, hi):
@@ -420,7 +429,7 @@ def conv_nhwc(x, pc, residual=None, act='none', slope=0.01, x2=None, out_planes=
                       ln_eps=float(eps))
     rc = lib.far_conv_nhwc_f32(ctypes.byref(d), _stream())
     _lib.check(rc, 'far_conv_nhwc_f32')
-    return y
+    return y if out is None else _written(y)
 
 
 def linear_f16s(x, pc, residual=None, act='none', x2=None, out_planes=1, res_group=1, ln=None, post_residual=None,

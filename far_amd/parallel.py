@@ -6,6 +6,11 @@ timing reduction of bench.py and an optional gather of per-pair results to rank 
 metrics over a gloo side group, src/utils/comm.py:141-219 -- out of scope; this is the tensor-only equivalent).
 Works with backend 'nccl' (= RCCL on ROCm) and 'gloo' (CPU tests).
 """
+import os
+import socket
+import subprocess
+import sys
+
 import torch
 import torch.distributed as dist
 
@@ -53,3 +58,41 @@ def gather_pair_results(local, n_pairs, dst=0):
         idx = shard_indices(n_pairs, r, w)
         full[idx] = out[r][:len(idx)]
     return full
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_command(n_ranks, script_argv, port=None):
+    """The one-node launch line the driver itself uses for N > 1 (one rank per GPU, rendezvous on 127.0.0.1)."""
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={int(n_ranks)}',
+            '--master-addr', '127.0.0.1', '--master-port', str(port or free_port())] + list(script_argv)
+
+
+def launch_ranks(n_ranks, script_argv, port=None, env=None):
+    """Start `script_argv` as n_ranks child ranks under torch.distributed.run and return its exit code.
+
+    Must be called BEFORE anything in the calling process touches the GPU: the ranks are children (never an exec of
+    a process that initialised HIP), the parent only waits.  HSA_ENABLE_IPC_MODE_LEGACY=0 is kept in the children's
+    environment (RCCL needs dmabuf IPC on this driver)."""
+    e = dict(os.environ if env is None else env)
+    e.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        e.pop(k, None)
+    return subprocess.call(launch_command(n_ranks, script_argv, port), env=e)
+
+
+def gather_floats(value, device='cpu'):
+    """Every rank's scalar as a python list on every rank (per-rank step times of bench.py)."""
+    _, w = world()
+    if w == 1:
+        return [float(value)]
+    t = torch.zeros(w, dtype=torch.float64, device=device)
+    t[dist.get_rank()] = float(value)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(x) for x in t.tolist()]

@@ -10,7 +10,9 @@
  *     the caller passes workspaces sized by the matching *_workspace_bytes();
  *   - every function enqueues on `stream` and returns immediately: 0 = enqueued, negative errno otherwise
  *     (-22 invalid argument, -5 launch failure); nothing throws, nothing prints;
- *   - no global state besides one-time kernel attribute setup; one process per GPU;
+ *   - process-global state is limited to (a) per-device one-time kernel attribute setup and (b) the speed-only
+ *     A/B knobs of far_set_tuning() (atomics; they never change results); the usual deployment is one process
+ *     per GPU, but launching on several devices from one process is supported;
  *   - "Z" is a flat batch (image pairs, or pairs x heads x directions for the head).
  */
 #ifndef FAR_HIP_H

@@ -58,3 +58,27 @@ def test_two_rank_gloo_gather_and_timing():
     assert full1 is None
     assert full0 == [[float(i), float(2 * i)] for i in range(n_pairs)]
     assert t0 == t1 == 2.0                      # slowest rank
+
+
+def test_bench_launches_n_ranks_when_started_plainly():
+    """`python bench.py --gpus 2` without WORLD_SIZE in the environment must start 2 ranks itself (the round-1 bench
+    parsed --gpus and ignored it).  The self-test mode joins a gloo group and does the timing reduction only."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--selftest-launcher',
+                          '--backend', 'gloo'], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out.stdout                # rank 0 prints ONE JSON line
+    res = json.loads(lines[0])
+    assert res['n_gpus'] == 2 and res['requested_gpus'] == 2
+    assert res['per_rank_s'] == [0.001, 0.002] and res['max_s'] == 0.002
+
+
+def test_launch_command_is_the_drivers_line():
+    cmd = parallel.launch_command(8, ['bench.py', '--gpus', '8'], port=29511)
+    assert cmd[1:] == ['-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=8', '--master-addr', '127.0.0.1',
+                       '--master-port', '29511', 'bench.py', '--gpus', '8']

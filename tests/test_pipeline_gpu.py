@@ -9,6 +9,7 @@ import torch
 
 from far_amd import synth
 from far_amd.config import far_eval_config
+from tests.util import deviation
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
@@ -30,27 +31,32 @@ def _batch(N, seed):
 
 
 def test_matcher_vs_reference_golden(model):
+    """LoFTR.forward on one 640x480 pair against the reference's own run (G7).  Bars = ~3x the deviation measured on
+    MI355X between the fp32-grade kernels and the fp32 reference (deviation() prints the measured values)."""
     g = np.load(os.path.join(G, 'g7_full.npz'))
     data, _, _ = _batch(1, 0)
     with torch.no_grad():
         model(data)
-    np.testing.assert_allclose(data['feats_c'][:, ::16, ::7, ::9].cpu().numpy(), g['feats_c_sample'], atol=2e-3, rtol=1e-3)
-    np.testing.assert_allclose(data['featmap0'][0, ::97].cpu().numpy(), g['featmap0_sample'], atol=3e-3, rtol=1e-3)
+    deviation('g7 feats_c', data['feats_c'][:, ::16, ::7, ::9], g['feats_c_sample'], atol=6e-5, rtol=1e-4)
+    deviation('g7 featmap_f0', data['featmap_f0'][:, ::16, ::31, ::37], g['featmap_f0_sample'], atol=6e-5, rtol=1e-4)
+    deviation('g7 featmap0 (tokens)', data['featmap0'][0, ::97], g['featmap0_sample'], atol=3e-4, rtol=1e-4)
+    deviation('g7 featmap1 (tokens)', data['featmap1'][0, ::97], g['featmap1_sample'], atol=3e-4, rtol=1e-4)
     gi, gj = data['i_ids'].cpu().numpy(), data['j_ids'].cpu().numpy()
     got = dict(zip(gi.tolist(), gj.tolist()))
     ref = dict(zip(g['i_ids'].tolist(), g['j_ids'].tolist()))
-    safe = (np.abs(g['rowmax'] - 0.2) > 2e-3) & (g['rowgap'] > 2e-3)
+    safe = (np.abs(g['rowmax'] - 0.2) > 1e-4) & (g['rowgap'] > 1e-4)            # SURVEY 8c protocol: margin 1e-4
+    print('[g7] rows with margin:', int(safe.sum()), 'of', safe.size)
     for i in np.nonzero(safe)[0]:
         assert (i in got) == (i in ref), i
         if i in got:
             assert got[i] == ref[i]
     common = [i for i in ref if i in got]
-    assert len(common) > 0.98 * len(ref) > 1000
+    assert len(common) > 0.99 * len(ref) > 1000
     a = np.array([{i: n for n, i in enumerate(gi.tolist())}[i] for i in common])
     b = np.array([{i: n for n, i in enumerate(g['i_ids'].tolist())}[i] for i in common])
-    np.testing.assert_allclose(data['mconf'].cpu().numpy()[a], g['mconf'][b], atol=5e-3, rtol=0)
-    np.testing.assert_allclose(data['mkpts1_f'].cpu().numpy()[a], g['mkpts1_f'][b], atol=2e-2, rtol=0)
-    np.testing.assert_allclose(data['expec_f'].cpu().numpy()[a], g['expec_f'][b], atol=5e-3, rtol=0)
+    deviation('g7 mconf', data['mconf'][a], g['mconf'][b], atol=3e-4, rtol=0)
+    deviation('g7 mkpts1_f', data['mkpts1_f'][a], g['mkpts1_f'][b], atol=2e-3, rtol=0)
+    deviation('g7 expec_f', data['expec_f'][a], g['expec_f'][b], atol=5e-4, rtol=0)
 
 
 def test_head_vs_reference_golden(model):
@@ -191,27 +197,150 @@ def test_cached_prediction_mode_head_only():
         np.testing.assert_allclose(reg[b:b + 1], g['regressed_rt'], atol=1e-3 * np.abs(g['regressed_rt']).max(), rtol=1e-3)
 
 
-def test_head_feature_cache_is_exact(model):
-    """The second head call of a step reuses the pair features; results must be bit-identical to recomputing."""
+def _head_inputs(rng, B=2):
+    f0 = torch.from_numpy(rng.standard_normal((B, 4800, 256)).astype(np.float32)).cuda()
+    f1 = torch.from_numpy(rng.standard_normal((B, 4800, 256)).astype(np.float32)).cuda()
+    rt = torch.eye(3, 4, dtype=torch.float64).repeat(B, 1, 1).cuda()
+    rt[:, :, 3] = torch.tensor([0.6, 0.0, 0.8], dtype=torch.float64)
+    cnt = lambda v: torch.full((B,), v, dtype=torch.int64).cuda()
+    return {'featmap0': f0, 'featmap1': f1, 'loftr_rt': rt, 'num_correspondences': cnt(700),
+            'num_correspondences_before_ransac': cnt(1500), 'inliers_best_tight': cnt(400), 'inliers_best_ultra_tight': cnt(50)}
+
+
+def test_head_feature_reuse_is_exact_and_never_stale(model):
+    """The second head call of a step reuses the pair features (kept in the caller's data dict).  Reuse must be
+    bit-identical to recomputing, and must NOT survive: a torch in-place edit, a raw-pointer overwrite through
+    far_amd.ops(out=...) (round-1 hazard: kernels write behind torch's version counter), the same buffers handed
+    over in a new dict, a weight change, a precision change.  It must also work under torch.inference_mode()."""
+    import copy
+    from far_amd import ops
+    m = copy.deepcopy(model)
+    head = m.loftr_regress
     rng = np.random.default_rng(3)
-    f0 = torch.from_numpy(rng.standard_normal((2, 4800, 256)).astype(np.float32)).cuda()
-    f1 = torch.from_numpy(rng.standard_normal((2, 4800, 256)).astype(np.float32)).cuda()
-    lp = torch.from_numpy(rng.standard_normal((2, 13)).astype(np.float32)).cuda()
-    lp2 = torch.from_numpy(rng.standard_normal((2, 13)).astype(np.float32)).cuda()
-    reg = model.loftr_regress
+    data = _head_inputs(rng)
+    key = m._HEAD_KEY
     with torch.no_grad():
-        reg.cache_features = False
-        a1 = reg(f0, f1, loftr_preds=lp, inv_loftr_preds=lp)[0].clone()
-        a2 = reg(f0, f1, loftr_preds=lp2, inv_loftr_preds=lp2)[0].clone()
-        reg.cache_features = True
-        reg._feat_cache = None
-        b1 = reg(f0, f1, loftr_preds=lp, inv_loftr_preds=lp)[0].clone()
-        b2 = reg(f0, f1, loftr_preds=lp2, inv_loftr_preds=lp2)[0].clone()      # served from the cache
-        assert reg._feat_cache is not None
-        f0.add_(1.0)                                                           # in-place change must invalidate
-        b3 = reg(f0, f1, loftr_preds=lp, inv_loftr_preds=lp)[0]
-    assert torch.equal(a1, b1) and torch.equal(a2, b2)
-    assert not torch.equal(b3, b1)
+        head.cache_features = False
+        m.forward_rt_prediction(data)
+        a1 = data['regressed_rt'].clone()
+        assert key not in data
+        data['loftr_rt'][:, 0, 3] = 0.3
+        m.forward_rt_prediction(data)
+        a2 = data['regressed_rt'].clone()
+        head.cache_features = True
+        data['loftr_rt'][:, 0, 3] = 0.6
+        m.forward_rt_prediction(data)
+        b1 = data['regressed_rt'].clone()
+        feats = data[key][1]
+        data['loftr_rt'][:, 0, 3] = 0.3
+        m.forward_rt_prediction(data)                       # served from the dict
+        b2 = data['regressed_rt'].clone()
+        assert data[key][1] is feats
+        assert torch.equal(a1, b1) and torch.equal(a2, b2) and not torch.equal(a1, a2)
+        # (1) torch in-place edit
+        data['featmap0'].add_(1.0)
+        m.forward_rt_prediction(data)
+        assert data[key][1] is not feats and not torch.equal(data['regressed_rt'], b2)
+        # (2) overwrite through a kernel's out= (raw device pointer): the next call must see the new contents
+        feats = data[key][1]
+        fresh = torch.from_numpy(rng.standard_normal((2, 4800, 256)).astype(np.float32)).cuda()
+        ops.layernorm(fresh, head.norm.weight, head.norm.bias, 1e-6, out=data['featmap0'])
+        m.forward_rt_prediction(data)
+        got = data['regressed_rt'].clone()
+        assert data[key][1] is not feats
+        ref = dict(data)
+        ref.pop(key)
+        ref['featmap0'] = data['featmap0'].clone()
+        head.cache_features = False
+        m.forward_rt_prediction(ref)
+        head.cache_features = True
+        assert torch.equal(got, ref['regressed_rt'])
+        # (3) the same (preallocated, overwritten) buffers in a NEW dict: nothing carries over
+        nxt = {k: v for k, v in data.items() if k != key}
+        m.forward_rt_prediction(nxt)
+        assert nxt[key][1] is not data[key][1] and torch.equal(nxt['regressed_rt'], got)
+        # (4) weights change between two calls on one dict (scoring several checkpoints on cached predictions)
+        feats = data[key][1]
+        sd = {k: v.clone() for k, v in m.state_dict().items()}
+        sd['loftr_regress.emm.norm1.weight'] = sd['loftr_regress.emm.norm1.weight'] * 1.5
+        m.load_state_dict(sd)
+        m.forward_rt_prediction(data)
+        assert data[key][1] is not feats and not torch.equal(data['regressed_rt'], got)
+        # (5) operand precision change
+        feats = data[key][1]
+        head_only_layers = [x for x in head.modules() if hasattr(x, 'split_operands')]
+        for x in head_only_layers:
+            x.split_operands = False
+        m.forward_rt_prediction(data)
+        assert data[key][1] is not feats
+        for x in head_only_layers:
+            x.split_operands = True
+    # (6) Lightning >= 1.8 runs test/validate/predict under inference_mode: tensors have no version counter
+    with torch.inference_mode():
+        d2 = _head_inputs(np.random.default_rng(3))
+        m2 = copy.deepcopy(model)
+        m2.forward_rt_prediction(d2)
+        c1 = d2['regressed_rt'].clone()
+        d2['loftr_rt'] = d2['loftr_rt'].clone()
+        d2['loftr_rt'][:, 0, 3] = 0.3
+        m2.forward_rt_prediction(d2)
+        c2 = d2['regressed_rt'].clone()
+    assert torch.equal(c1, a1) and torch.equal(c2, a2)
+
+
+def test_full_step_under_inference_mode(model):
+    """pipeline.test_step inside torch.inference_mode() (what Lightning's trainer.test does) == under no_grad."""
+    from far_amd.pipeline import test_step
+    d1, _, _ = _batch(2, 5)
+    test_step(model, d1, H=256)
+    with torch.inference_mode():
+        d2, _, _ = _batch(2, 5)
+        test_step(model, d2, H=256)
+    for k in ('i_ids', 'j_ids', 'mconf', 'mkpts1_f', 'regressed_rt', 'loftr_rt'):
+        assert torch.equal(d1[k], d2[k]), k
+
+
+def test_batch32_is_32_independent_single_pair_runs(model):
+    """BASELINE configs[1] runs 32 pairs per step; the reference's solver + head are batch-size-1 code (SURVEY.md
+    section 0 fact 4), so "batch 32" MEANS 32 independent B = 1 runs stacked.  Every kernel of this library is
+    row / pixel / problem independent, so pair b of the batch must equal the B = 1 run of pair b BIT FOR BIT through
+    matcher and solver (ids, confidences, sub-pixel positions, [R | t], inlier mask, counts); the head's vendor GEMMs
+    (MLPs, gate: chosen by row count) are held to 1e-4 of the output scale."""
+    from far_amd.config import RunCfg
+    from far_amd.supervision import compute_supervision_RT
+    B, Hn, seed = 32, 512, 2
+    data, _, _ = _batch(B, 77)
+    run = RunCfg('prior_ransac', 2)
+    with torch.no_grad():
+        model(data)
+        compute_supervision_RT(data, run, H=Hn, seed=seed)
+        model.forward_rt_prediction(data)
+    counts = [int(c) for c in data['match_counts']]
+    offs = np.concatenate([[0], np.cumsum(counts)])
+    assert min(counts) > 1000
+    reg = data['regressed_rt']
+    scale = float(reg.abs().max())
+    worst = 0.0
+    for b in range(B):
+        d1 = {'image0': data['image0'][b:b + 1], 'image1': data['image1'][b:b + 1], 'K0': data['K0'][b:b + 1],
+              'K1': data['K1'][b:b + 1], 'dataset_name': ['mp3d']}
+        with torch.no_grad():
+            model(d1)
+            # the sampling hash is keyed by (seed XOR pair index, hypothesis, slot) (oracle/solver.py:hash_u32):
+            # pair 0 of a run seeded with seed ^ b draws the samples of pair b of the batch
+            compute_supervision_RT(d1, run, H=Hn, seed=seed ^ b)
+            model.forward_rt_prediction(d1)
+        sl = slice(int(offs[b]), int(offs[b + 1]))
+        assert int(d1['match_counts'][0]) == counts[b], b
+        for k in ('i_ids', 'j_ids', 'mconf', 'mkpts0_f', 'mkpts1_f', 'expec_f', 'solver_inlier_mask'):
+            assert torch.equal(data[k][sl], d1[k]), (b, k)
+        assert torch.equal(data['loftr_rt'][b], d1['loftr_rt']), b
+        for k in ('num_correspondences', 'num_correspondences_before_ransac', 'inliers_best_tight', 'inliers_best_ultra_tight'):
+            assert int(data[k][b]) == int(d1[k][0]), (b, k)
+        assert torch.equal(data['featmap0'][b], d1['featmap0'][0]) and torch.equal(data['featmap1'][b], d1['featmap1'][0])
+        worst = max(worst, float((reg[b] - d1['regressed_rt'][0]).abs().max()))
+    print(f'[batch32] max |regressed_rt(batch) - regressed_rt(single)| = {worst:.3e} (scale {scale:.3e})')
+    assert worst <= 1e-4 * scale
 
 
 def test_training_step_on_gpu(model):

@@ -145,3 +145,69 @@ def test_estimate_pose_single_pair_contract():
     assert abs(float(ret2[1].norm()) - 2.5) < 1e-9                              # t *= translation_scale (:167-168)
     # fewer than 5 correspondences -> (None, 0, 0, 0) without touching the GPU (:83-85)
     assert estimate_pose(torch.from_numpy(k0[:4]).cuda(), torch.from_numpy(k1[:4]).cuda(), Kt, Kt, 0.5) == (None, 0, 0, 0)
+
+
+def test_spvs_rt_is_order_independent_like_the_reference():
+    """supervision.py:209-210 selects a pair's correspondences with `m_bids == bs`; in training m_bids is unsorted
+    for B > 1 (coarse_matching.py:216-240).  The batched call site must give every pair ITS correspondences whatever
+    the order, return the inlier mask in the caller's order, and ignore a stale `match_counts`."""
+    from far_amd.config import RunCfg
+    from far_amd.supervision import compute_supervision_RT
+    scenes = [two_view_scene(M, seed=40 + s) for s, M in enumerate([400, 250, 600])]
+    k0 = np.concatenate([s[0] for s in scenes])
+    k1 = np.concatenate([s[1] for s in scenes])
+    bid = np.concatenate([np.full(len(s[0]), b) for b, s in enumerate(scenes)])
+    K = torch.from_numpy(np.stack([s[2] for s in scenes])).cuda()
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+    def run(perm, extra=None):
+        b = cu(bid[perm])
+        d = {'mkpts0_f': cu(k0[perm]), 'mkpts1_f': cu(k1[perm]), 'm_bids': b, 'b_ids': b, 'K0': K, 'K1': K.clone()}
+        d.update(extra or {})
+        compute_supervision_RT(d, RunCfg('prior_ransac_noprior'), H=H, seed=5)
+        return d
+
+    ident = np.arange(len(bid))
+    ref = run(ident, {'match_counts': torch.tensor([len(s[0]) for s in scenes])})
+    # interleave the pairs round-robin (the order INSIDE a pair is kept: sample indices address positions in a pair)
+    pos = [list(np.nonzero(bid == b)[0]) for b in range(3)]
+    rr = []
+    while any(pos):
+        for p in pos:
+            if p:
+                rr.append(p.pop(0))
+    rr = np.array(rr)
+    got = run(rr, {'match_counts': torch.tensor([1, 2, 3])})          # stale counts must be ignored, not trusted
+    np.testing.assert_array_equal(got['loftr_rt'].cpu().numpy(), ref['loftr_rt'].cpu().numpy())
+    for k in ('num_correspondences', 'num_correspondences_before_ransac', 'inliers_best_tight'):
+        np.testing.assert_array_equal(got[k].cpu().numpy(), ref[k].cpu().numpy())
+    np.testing.assert_array_equal(got['solver_inlier_mask'].cpu().numpy(), ref['solver_inlier_mask'].cpu().numpy()[rr])
+    assert np.linalg.norm(ref['loftr_rt'].cpu().numpy()[1, :, :3] - scenes[1][3]) < 0.05
+    with pytest.raises(ValueError):
+        bad = {'mkpts0_f': cu(k0), 'mkpts1_f': cu(k1[:-1]), 'm_bids': cu(bid), 'K0': K, 'K1': K}
+        compute_supervision_RT(bad, RunCfg('ransac'), H=64)
+
+
+@pytest.mark.parametrize('tag,mode', [('p', 'prior'), ('n', 'noprior')])
+def test_kernel_vs_reference_whole_ransac_loop(tag, mode):
+    """far_solver_f64 on the committed sample indices against the reference's own RANSAC.forward (golden G12,
+    ransac.py:340-442): same selected hypothesis, same inlier sets off the decision margin (bars and measured
+    agreement in tests/test_oracle_golden.py:g12_expectations)."""
+    import os
+    from tests.test_oracle_golden import g12_expectations
+    from oracle import solver as osv
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'g12_ransac_loop.npz'))
+    scene = (g[f'{tag}_kpts0'], g[f'{tag}_kpts1'], g[f'{tag}_K'], g[f'{tag}_R_gt'], g[f'{tag}_t_gt'])
+    priors = g['p_prior'][None] if tag == 'p' else None
+    pcl = g['p_pcl'] if tag == 'p' else None
+    smp = g[f'{tag}_samples'].astype(np.int32)[None]
+    got, offs = _run([scene], mode, priors, pcl, H=smp.shape[1], samples=smp)
+    valid = np.isfinite(got['score_all'][0])
+    wq = None
+    if tag == 'p':      # the kernel's integer weights are internal; the oracle's are held to the golden on CPU
+        wq = osv.estimate_pose(scene[0], scene[1], scene[2], scene[2], 0.5, solver='prior_ransac', priorRT=priors[0],
+                               pcl=pcl, samples=smp[0])[4]['wq']
+    g12_expectations(tag, valid, got['count_all'][0], np.where(valid, got['score_all'][0], -np.inf), int(got['best'][0]),
+                     wq, (int(got['num_after'][0]), int(got['tight'][0]), int(got['ultra'][0])),
+                     got['mask'].astype(bool), g)
+    assert np.linalg.norm(got['R'][0] - g[f'{tag}_R_gt']) < 0.03

@@ -52,3 +52,18 @@ def two_view_scene(M, seed=0, outlier_frac=0.3, noise_px=0.3, K=None):
         p1[idx] = np.stack([rng.uniform(0, 640, nout), rng.uniform(0, 480, nout)], 1)
     return p0.astype(np.float32), p1.astype(np.float32), K, R, t / np.linalg.norm(t)
 
+
+
+def deviation(name, got, ref, atol, rtol=0.0):
+    """assert_allclose that also PRINTS the measured deviation (max |got - ref|, and relative to max |ref|), so that
+    the bars in the tests can be kept at ~3x what the hardware run measures (`pytest -s` shows the lines)."""
+    import torch
+    g = got.detach().cpu().numpy() if torch.is_tensor(got) else np.asarray(got)
+    r = ref.detach().cpu().numpy() if torch.is_tensor(ref) else np.asarray(ref)
+    d = float(np.abs(g.astype(np.float64) - r.astype(np.float64)).max()) if g.size else 0.0
+    scale = float(np.abs(r).max()) if r.size else 1.0
+    print(f'[deviation] {name}: max|d| = {d:.3e}  (max|ref| = {scale:.3e}, rel = {d / max(scale, 1e-30):.3e}; bar atol {atol:g} rtol {rtol:g})')
+    import os
+    if os.environ.get('FAR_MEASURE_ONLY') != '1':          # measurement runs print every deviation without stopping
+        np.testing.assert_allclose(g, r, atol=atol, rtol=rtol, err_msg=name)
+    return d

@@ -287,6 +287,104 @@ def g10_training(m):
     m.eval()
 
 
+def g11_matcher_544x720(m):
+    """LoFTR.forward (loftr.py:194-205) at 544x720 (coarse grid 68x90, L = S = 6120; fine grid 272x360): BASELINE
+    configs[4]'s resolution on the mp3d_loftr matcher (the head is tied to 60x80 and is not part of this config)."""
+    im0, im1 = synth.synth_image_pair(1, seed=5, hw=(544, 720))
+    data = {'image0': torch.from_numpy(im0), 'image1': torch.from_numpy(im1)}
+    with torch.no_grad():
+        m(data)
+    c = data['conf_matrix'][0]
+    rs = torch.sort(c, dim=1)[0]
+    save('g11_matcher_544x720', seed=5, hw=(544, 720), b_ids=data['b_ids'].numpy(), i_ids=data['i_ids'].numpy(),
+         j_ids=data['j_ids'].numpy(), mconf=data['mconf'].numpy(), mkpts0_f=data['mkpts0_f'].numpy(),
+         mkpts1_f=data['mkpts1_f'].numpy(), expec_f=data['expec_f'].numpy(), rowmax=rs[:, -1].numpy(),
+         rowgap=(rs[:, -1] - rs[:, -2]).numpy(), featmap0_sample=data['featmap0'][0, ::97].numpy(),
+         feats_c_sample=data['feats_c'][:, ::16, ::7, ::9].numpy(),
+         featmap_f0_sample=data['featmap_f0'][:, ::16, ::31, ::37].numpy())
+
+
+def g12_ransac_loop():
+    """The reference's WHOLE hypothesise-and-verify loop, RANSAC.forward (ransac.py:340-442), run with committed
+    sample indices: the object estimate_pose builds for 'prior_ransac' / 'prior_ransac_noprior' (metrics.py:104-147:
+    model_type='essential_cv2', max_iter=1, inl_th=3e-7, lambda 0.3, linear bias sampling, sigma^2 0.1), with the
+    minimal solver wired the way RANSAC(model_type='fundamental') wires it (ransac.py:140-145: run_8point, 8-point
+    samples) -- the one north_star-sanctioned substitution (cv2's 5-point is absent).  `sample` (:161-175) is
+    replaced by an observer that records the weight vector it is handed and returns the committed indices; `verify`
+    and `remove_bad_models` are observed, not changed.  Pins: bias weights :358-371, remove_bad_models :303-308,
+    prior error/score :203-231 + :395-398, Sampson counts + argmax :273-281, the masks at thr, thr/10, thr/100
+    :284-287, the score floor :353/:409."""
+    from cv_geometry import run_8point
+    from ransac import RANSAC
+    out = {}
+    for tag, seed, with_prior in (('p', 77, True), ('n', 78, False)):
+        k0, k1, K, Rgt, tgt = two_view_scene(500, seed=seed, outlier_frac=0.35)
+        # metrics.py:88-89 on float32 pixel tensors and float64 intrinsics, then torch.FloatTensor (:124-125)
+        kn0 = ((torch.from_numpy(k0) - torch.from_numpy(K)[[0, 1], [2, 2]][None]) / torch.from_numpy(K)[[0, 1], [0, 1]][None]).numpy()
+        kn1 = ((torch.from_numpy(k1) - torch.from_numpy(K)[[0, 1], [2, 2]][None]) / torch.from_numpy(K)[[0, 1], [0, 1]][None]).numpy()
+        kp1, kp2 = torch.FloatTensor(kn0), torch.FloatTensor(kn1)
+        rng = np.random.default_rng(seed)
+        Hn = 512
+        samples = np.stack([rng.choice(len(k0), 8, replace=False) for _ in range(Hn)]).astype(np.int64)
+        # a perturbed ground-truth pose as the prior (non-unit translation: setup_prior normalises it in place, :183)
+        ang = 0.05
+        dR = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]])
+        prior = np.concatenate([dR @ Rgt, (1.7 * tgt + 0.03)[:, None]], 1).astype(np.float32)
+        pcl = np.random.RandomState(0).uniform(low=-3.0, high=3.0, size=(300, 3)).astype(np.float32)
+        pp = {'rotation_pcl_error': True, 'rotation_error': False, 'K1': torch.eye(3), 'K2': torch.eye(3),
+              'RT': torch.FloatTensor(prior.copy()), 'pcl': torch.FloatTensor(pcl), 'lambda': 0.3,
+              'biased_sampling': 'biased'} if with_prior else {}
+        rs = RANSAC(model_type='essential_cv2', max_iter=1, inl_th=3e-7, prior_params=pp, max_lo_iters=0, batch_size=Hn,
+                    use_noexp_prior_scoring=with_prior, use_linear_bias_sampling=with_prior,
+                    **({'bias_sigma_sq': 0.1} if with_prior else {}))
+        rs.minimal_solver = run_8point          # ransac.py:143
+        rs.minimal_sample_size = 8              # ransac.py:144
+        seen = {}
+
+        def sample(sample_size, pop_size, batch_size, weight=None, device=None, _s=samples, _seen=seen):
+            assert sample_size == 8 and batch_size == len(_s)
+            _seen['weight'] = None if weight is None else weight.detach().clone()
+            return torch.from_numpy(_s)
+        rs.sample = sample
+        rbm = rs.remove_bad_models
+
+        def remove_bad_models(models, _seen=seen):
+            _seen['models_all'] = models.detach().clone()
+            kept = rbm(models)
+            diag = torch.diagonal(models, dim1=1, dim2=2)
+            _seen['keep'] = (diag.abs().min(dim=1)[0] > 1e-4)
+            return kept
+        rs.remove_bad_models = remove_bad_models
+        ver = rs.verify
+
+        def verify(kp1_, kp2_, models, inl_th, prior_score, _seen=seen, _rs=rs):
+            _seen['prior_score'] = prior_score.detach().clone()
+            errs = _rs.error_fn(kp1_[None].expand(len(models), -1, 2), kp2_[None].expand(len(models), -1, 2), models, squared=True)
+            _seen['count'] = (errs <= inl_th).sum(1)
+            tot = (errs <= inl_th).to(kp1_).sum(1) + prior_score.to(kp1_)
+            _seen['best_kept'] = int(tot.argmax())
+            _seen['score'] = tot.detach().clone()
+            _seen['err_best'] = errs[_seen['best_kept']].detach().clone()
+            return ver(kp1_, kp2_, models, inl_th, prior_score)
+        rs.verify = verify
+        with torch.no_grad():
+            E, inl, tight, ultra = rs.forward(kp1=kp1, kp2=kp2)
+        keep = seen['keep'].numpy()
+        best_all = int(np.nonzero(keep)[0][seen['best_kept']])
+        out.update({f'{tag}_kpts0': k0, f'{tag}_kpts1': k1, f'{tag}_K': K, f'{tag}_samples': samples,
+                    f'{tag}_models': seen['models_all'].numpy(), f'{tag}_keep': keep,
+                    f'{tag}_prior_score': seen['prior_score'].numpy().astype(np.float32),
+                    f'{tag}_count': seen['count'].numpy(), f'{tag}_score': seen['score'].numpy(),
+                    f'{tag}_best': best_all, f'{tag}_E': E.numpy(), f'{tag}_inliers': inl.numpy().reshape(-1),
+                    f'{tag}_tight': tight.numpy().reshape(-1), f'{tag}_ultra': ultra.numpy().reshape(-1),
+                    f'{tag}_err_best': seen['err_best'].numpy(), f'{tag}_R_gt': Rgt, f'{tag}_t_gt': tgt})
+        if with_prior:
+            out.update({'p_prior': prior, 'p_pcl': pcl, 'p_bias_weight': seen['weight'].numpy()})
+        print(tag, 'kept', int(keep.sum()), 'best', best_all, 'count', int(seen['count'][seen['best_kept']]),
+              'inliers', int(inl.sum()), int(tight.sum()), int(ultra.sum()))
+    save('g12_ransac_loop', note=NOTE_KORNIA, **out)
+
+
 def g8_manifest(m):
     man = {k: list(v.shape) for k, v in m.state_dict().items()}
     with open(os.path.join(OUT, 'g8_state_dict_manifest.json'), 'w') as f:
@@ -303,6 +401,12 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'g10':
         g10_training(ref_model()[0])
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'g11':
+        g11_matcher_544x720(ref_model()[0])
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'g12':
+        g12_ransac_loop()
+        sys.exit(0)
     g1_coarse()
     g9_metrics()
     g5_solver()
@@ -314,3 +418,5 @@ if __name__ == '__main__':
     g4_head(model)
     g7_full(model)
     g10_training(model)
+    g11_matcher_544x720(model)
+    g12_ransac_loop()
