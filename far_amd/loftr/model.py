@@ -216,7 +216,7 @@ class LoFTR(nn.Module):
 
     @staticmethod
     def _tensor_stamp(t):
-        return (id(t), t.data_ptr(), tuple(t.shape), None if t.is_inference() else t._version)
+        return (id(t), t.data_ptr(), tuple(t.shape), ops.tensor_version(t))
 
     def _head_features(self, data, f0, f1, preds, inv_preds):
         head = self.loftr_regress

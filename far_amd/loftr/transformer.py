@@ -312,7 +312,7 @@ class LocalFeatureTransformerRegressor(nn.Module):
         """What `compute_features` depends on besides its inputs: every weight it reads (storage + version, so that
         load_state_dict / an optimizer step / an in-place edit invalidate) and the operand precision of its layers."""
         mods = [self.emm, self.norm] + ([self.loftr] if self.config['regress_loftr_layers'] > 0 else [])
-        ws = tuple((p.data_ptr(), p._version) for m in mods for p in m.parameters())
+        ws = tuple((p.data_ptr(), ops.tensor_version(p)) for m in mods for p in m.parameters())
         prec = tuple(m.split_operands for m in self.modules() if isinstance(m, LoFTREncoderLayer))
         return ws, prec, self.training
 

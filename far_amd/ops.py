@@ -36,6 +36,12 @@ def _written(t):
     return t
 
 
+def tensor_version(t):
+    """Tensor._version, or None for inference tensors (created under torch.inference_mode(): immutable outside it,
+    no counter to read)."""
+    return None if t.is_inference() else t._version
+
+
 def _ws(nbytes, device):
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
@@ -384,7 +390,7 @@ class PackCache:
         self._store = {}
 
     def get(self, key, tensors, build):
-        stamp = tuple((t.data_ptr(), t._version) for t in tensors)
+        stamp = tuple((t.data_ptr(), tensor_version(t)) for t in tensors)
         hit = self._store.get(key)
         if hit is None or hit[0] != stamp:
             hit = (stamp, build())

@@ -42,8 +42,8 @@ def test_matcher_544x720_vs_reference_golden(model):
     assert tuple(data['hw0_c']) == (68, 90) and tuple(data['hw0_f']) == (272, 360) and data['featmap0'].shape == (1, 6120, 256)
     # bars = ~3x the deviations measured on MI355X (printed by deviation(); fp32-grade kernels vs the fp32 reference)
     deviation('c5 feats_c', data['feats_c'][:, ::16, ::7, ::9], g['feats_c_sample'], atol=6e-5, rtol=1e-4)
-    deviation('c5 featmap_f0', data['featmap_f0'][:, ::16, ::31, ::37], g['featmap_f0_sample'], atol=6e-5, rtol=1e-4)
-    deviation('c5 featmap0 (tokens)', data['featmap0'][0, ::97], g['featmap0_sample'], atol=3e-4, rtol=1e-4)
+    deviation('c5 featmap_f0', data['featmap_f0'][:, ::16, ::31, ::37], g['featmap_f0_sample'], atol=1.2e-4, rtol=1e-4)
+    deviation('c5 featmap0 (tokens)', data['featmap0'][0, ::97], g['featmap0_sample'], atol=7e-5, rtol=1e-4)
     gi, gj = data['i_ids'].cpu().numpy(), data['j_ids'].cpu().numpy()
     got = dict(zip(gi.tolist(), gj.tolist()))
     ref = dict(zip(g['i_ids'].tolist(), g['j_ids'].tolist()))
@@ -57,9 +57,9 @@ def test_matcher_544x720_vs_reference_golden(model):
     assert len(common) > 0.99 * len(ref) > 2000
     a = np.array([{i: n for n, i in enumerate(gi.tolist())}[i] for i in common])
     b = np.array([{i: n for n, i in enumerate(g['i_ids'].tolist())}[i] for i in common])
-    deviation('c5 mconf', data['mconf'][a], g['mconf'][b], atol=3e-4, rtol=0)
-    deviation('c5 mkpts1_f', data['mkpts1_f'][a], g['mkpts1_f'][b], atol=2e-3, rtol=0)
-    deviation('c5 expec_f', data['expec_f'][a], g['expec_f'][b], atol=5e-4, rtol=0)
+    deviation('c5 mconf', data['mconf'][a], g['mconf'][b], atol=1.5e-4, rtol=0)
+    deviation('c5 mkpts1_f', data['mkpts1_f'][a], g['mkpts1_f'][b], atol=4e-3, rtol=0)
+    deviation('c5 expec_f', data['expec_f'][a], g['expec_f'][b], atol=1.5e-3, rtol=0)
 
 
 def test_c5_two_pairs_matcher_and_solver_vs_oracle(model):
@@ -79,7 +79,7 @@ def test_c5_two_pairs_matcher_and_solver_vs_oracle(model):
     gm = set(zip(data['b_ids'].tolist(), data['i_ids'].tolist(), data['j_ids'].tolist()))
     rm = set(zip(odata['b_ids'].tolist(), odata['i_ids'].tolist(), odata['j_ids'].tolist()))
     assert len(gm & rm) > 0.99 * len(rm) > 3000, (len(gm & rm), len(rm))
-    deviation('c5 featmap0 vs oracle', data['featmap0'], odata['featmap0'], atol=5e-4, rtol=1e-4)
+    deviation('c5 featmap0 vs oracle', data['featmap0'], odata['featmap0'], atol=1e-4, rtol=1e-4)
     mk0, mk1 = data['mkpts0_f'].cpu().numpy(), data['mkpts1_f'].cpu().numpy()
     bids = data['m_bids'].cpu().numpy()
     pcl = np.random.RandomState(0).uniform(low=-3.0, high=3.0, size=(300, 3)).astype(np.float32)

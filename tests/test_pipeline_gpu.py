@@ -38,9 +38,9 @@ def test_matcher_vs_reference_golden(model):
     with torch.no_grad():
         model(data)
     deviation('g7 feats_c', data['feats_c'][:, ::16, ::7, ::9], g['feats_c_sample'], atol=6e-5, rtol=1e-4)
-    deviation('g7 featmap_f0', data['featmap_f0'][:, ::16, ::31, ::37], g['featmap_f0_sample'], atol=6e-5, rtol=1e-4)
-    deviation('g7 featmap0 (tokens)', data['featmap0'][0, ::97], g['featmap0_sample'], atol=3e-4, rtol=1e-4)
-    deviation('g7 featmap1 (tokens)', data['featmap1'][0, ::97], g['featmap1_sample'], atol=3e-4, rtol=1e-4)
+    deviation('g7 featmap_f0', data['featmap_f0'][:, ::16, ::31, ::37], g['featmap_f0_sample'], atol=1.2e-4, rtol=1e-4)
+    deviation('g7 featmap0 (tokens)', data['featmap0'][0, ::97], g['featmap0_sample'], atol=7e-5, rtol=1e-4)
+    deviation('g7 featmap1 (tokens)', data['featmap1'][0, ::97], g['featmap1_sample'], atol=7e-5, rtol=1e-4)
     gi, gj = data['i_ids'].cpu().numpy(), data['j_ids'].cpu().numpy()
     got = dict(zip(gi.tolist(), gj.tolist()))
     ref = dict(zip(g['i_ids'].tolist(), g['j_ids'].tolist()))
@@ -54,9 +54,9 @@ def test_matcher_vs_reference_golden(model):
     assert len(common) > 0.99 * len(ref) > 1000
     a = np.array([{i: n for n, i in enumerate(gi.tolist())}[i] for i in common])
     b = np.array([{i: n for n, i in enumerate(g['i_ids'].tolist())}[i] for i in common])
-    deviation('g7 mconf', data['mconf'][a], g['mconf'][b], atol=3e-4, rtol=0)
-    deviation('g7 mkpts1_f', data['mkpts1_f'][a], g['mkpts1_f'][b], atol=2e-3, rtol=0)
-    deviation('g7 expec_f', data['expec_f'][a], g['expec_f'][b], atol=5e-4, rtol=0)
+    deviation('g7 mconf', data['mconf'][a], g['mconf'][b], atol=1.5e-4, rtol=0)
+    deviation('g7 mkpts1_f', data['mkpts1_f'][a], g['mkpts1_f'][b], atol=4e-3, rtol=0)
+    deviation('g7 expec_f', data['expec_f'][a], g['expec_f'][b], atol=1.5e-3, rtol=0)
 
 
 def test_head_vs_reference_golden(model):
