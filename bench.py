@@ -94,6 +94,30 @@ def kernel_rooflines(n_pairs):
     out['far_coarse_match_f16s[K1 all passes, split-fp16 (default)]'] = dict(ms=ts, tflops=fl / ts / 1e9, frac=fl / ts / 1e9 / F16_MFMA_PEAK_TFLOPS)
     tsm = event_time_ms(lambda: ops.coarse_match(f0, f1, 0.1, 0.2, 2, (60, 80), (60, 80), 8.0, want_conf=True, variant='f16s'), iters=3, warm=1)
     out['far_coarse_match_f16s[K1 materialising conf_matrix, split-fp16]'] = dict(ms=tsm, gbs=byb / tsm / 1e6, frac=byb / tsm / 1e6 / HBM_PEAK_GBS)
+    # the HBM-bound conf_matrix writer (dual_softmax_conf_f16.hip): stage 2 of far_conf_matrix_f16s timed on its own
+    # (k1_conf + k1_conf_fix; operand planes and statistics prepared once by stage 1), then the whole call
+    from far_amd import _lib as _l
+    import ctypes as _ct
+    lib_ = _l.load()
+    ws_ = torch.empty(lib_.far_coarse_match_f16s_workspace_bytes(n_pairs, L, S, C), dtype=torch.uint8, device=dev)
+    conf_ = torch.empty(n_pairs, L, S, device=dev)
+    info_ = torch.zeros(2, dtype=torch.int32, device=dev)
+    st_ = _ct.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def writer(stages):
+        rc = lib_.far_conf_matrix_f16s(f0.data_ptr(), f1.data_ptr(), n_pairs, L, S, C, _ct.c_float(0.1), None, None, stages,
+                                       conf_.data_ptr(), info_.data_ptr(), ws_.data_ptr(), st_)
+        assert rc == 0, rc
+    writer(1)
+    tw = event_time_ms(lambda: writer(2), iters=5, warm=2)
+    listed = int(info_[0].item())
+    byw = 4.0 * L * S * n_pairs + 2.0 * (L + S) * C * n_pairs          # matrix written + fp16 operand planes read once
+    out['k1_conf+k1_conf_fix[K1 conf_matrix writer alone, plain-fp16 scores + exact fix-up]'] = dict(
+        ms=tw, gbs=byw / tw / 1e6, frac=byw / tw / 1e6 / HBM_PEAK_GBS, exact_entries_per_row=listed / (n_pairs * L))
+    ta = event_time_ms(lambda: writer(3), iters=3, warm=1)
+    out['far_conf_matrix_f16s[K1 materialising conf_matrix, all passes: planes + statistics + writer]'] = dict(
+        ms=ta, gbs=byb / ta / 1e6, frac=byb / ta / 1e6 / HBM_PEAK_GBS)
+    del ws_, conf_
     del f0, f1
     Z = n_pairs * 8
     q = torch.randn(Z, L, 64, device=dev, generator=g)

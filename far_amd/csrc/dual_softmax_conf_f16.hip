@@ -1,0 +1,243 @@
+// K1, materialising mode: data['conf_matrix'] (Z, L, S) fp32 at HBM write speed.
+//
+// Replaces coarse_matching.py:108-118 when the dense matrix itself is wanted (the reference's dense loss / plotting,
+// loftr_loss.py:307-311).  The fused matcher (dual_softmax_f16s.hip) is MFMA-bound at three f16 MFMAs per product and
+// wrote the matrix at 0.7 TB/s; here the 3.26 GB of a 32-pair batch are the bound, so the arithmetic is arranged
+// around the stores:
+//   * statistics (row / column max and sum) come from the split-precision passes of dual_softmax_f16s.hip: fp32-grade;
+//   * k1_conf       one v_mfma_f32_32x32x16_f16 per 16 channels on the fp16 `hi` planes only (x' = fp16-operand
+//                   score), p' = 2^(2 x' - rowmax - colmax) / (rowsum colsum): one exp per score.  The tile is NOT
+//                   transposed: a lane owns one COLUMN, so that each store instruction of a wave writes two whole
+//                   128-byte lines of two rows (dword stores, fully coalesced), with no LDS staging;
+//                   column tiles arrive by LDS-DMA into a double buffer, one barrier per tile, the stores of tile t
+//                   drain under the MFMAs of tile t + 1;  work item = (pair, 128-row block, column chunk), so that
+//                   the grid is ~12 rounds of the chip (no tail) and all items of a pair run on one XCD (L2-resident
+//                   operand planes);
+//   * exactness     |p' - p| <= 2 ln2 |x' - x| p: the fp16 operand error (|x' - x| ~ 5e-4 in log2 units, rigorous
+//                   bound 2^-10 sum|a_c b_c| log2e / (C temperature)) only matters where p is not tiny.  Every entry
+//                   with p' > FIX_TAU = 2^-12 (a handful per row) is appended to a list and k1_conf_fix recomputes it
+//                   from the fp32 features with a float64 dot product: conf_matrix is within 1e-5 of the float64
+//                   oracle everywhere (tests/test_coarse_gpu.py), although 99.99 % of it never saw an fp32 product.
+#include "dual_softmax_common.h"
+
+namespace far_conf {
+
+using namespace far_ds;
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int C = 256;
+constexpr int NS = C / 16;
+constexpr int KT = 64;                 // columns per tile
+constexpr int ROWB = C * 2;            // bytes per fp16 row
+constexpr int TILE = KT * ROWB;        // 32 KiB
+constexpr float FIX_TAU = 1.0f / 4096.0f;
+constexpr int CHUNK_MAX = 16;          // column tiles per work item (upper bound: sizes the LDS copy of the column statistics)
+
+// one 64-column tile of the `hi` plane (LDS image: 16-byte slot ^= row & 15, written by k1_prep) -> LDS, 8 KiB per wave
+__device__ __forceinline__ void dma_tile(unsigned char* lds, const _Float16* g, size_t row0, int tid, int wave) {
+    const unsigned char* s = reinterpret_cast<const unsigned char*>(g + row0 * C) + tid * 16;
+#pragma unroll
+    for (int j = 0; j < TILE / 4096; ++j)
+        __builtin_amdgcn_global_load_lds((gptr_t)(s + j * 4096), (lptr_t)(lds + j * 4096 + wave * 1024), 16, 0, 0);
+}
+
+// grid: Z * nI * NCH work items; item -> (z, row block Ib, column chunk ch); all items of one z on one XCD
+template <bool MASKS>
+__global__ __launch_bounds__(256, 2) void k1_conf(const _Float16* __restrict__ ah, const _Float16* __restrict__ bh,
+                                                  int Z, int L, int S, int Lp, int Sp, int nI, int nch, int tiles_per_chunk,
+                                                  float c2, float fill2x2, const uint8_t* __restrict__ mask0,
+                                                  const uint8_t* __restrict__ mask1, const float2* __restrict__ rowstat,
+                                                  const float* __restrict__ cmax, const float* __restrict__ cinv,
+                                                  float* __restrict__ conf, int* __restrict__ fix_count,
+                                                  uint2* __restrict__ fix_list, int fix_cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    int z, item;
+    tile_coords(nI * nch, Z, z, item);
+    const int Ib = item / nch, ch = item - Ib * nch;
+    const int ntile = (S + KT - 1) / KT;
+    const int t0 = ch * tiles_per_chunk, t1 = min(ntile, t0 + tiles_per_chunk);
+    if (t0 >= t1) return;                                        // whole workgroup (uniform)
+    const int row0 = Ib * 128 + 32 * wave;                       // first row of this wave
+    // A operand: this wave's 32 rows, all 256 channels, in registers (64 VGPRs); lane = (row l31, k-half h)
+    f16x8 af[NS];
+    {
+        const int irow = row0 + l31;
+        const _Float16* p = ah + ((size_t)z * Lp + irow) * C;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) af[s] = *reinterpret_cast<const f16x8*>(p + 8 * ((2 * s + h) ^ (irow & 15)));
+    }
+    // row statistics of the 16 rows whose results this lane holds: i = row0 + (r & 3) + 8 (r >> 2) + 4 h
+    float rm[16], ri[16];
+    unsigned rmask_bits = 0;                                     // bit r: row masked out (mask0 == 0)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = row0 + mfma32_row(r, h);
+        const float2 st = i < L ? rowstat[(size_t)z * L + i] : make_float2(0.f, 1.f);
+        rm[r] = st.x;
+        ri[r] = i < L ? 1.0f / st.y : 0.f;
+        if (MASKS && mask0 && i < L && !mask0[(size_t)z * L + i]) rmask_bits |= 1u << r;
+    }
+    unsigned offr[16];                                           // byte offset of (row mfma32_row(r, h), column l31)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) offr[r] = (unsigned)(mfma32_row(r, h) * S + l31) * 4u;
+    const bool rows_live = row0 < L;                             // wave-uniform: any valid row in this wave
+    const bool rows_full = row0 + 32 <= L;                       // wave-uniform: all 32 rows valid
+    float* const crow = conf + ((size_t)z * L + row0) * S;       // wave-uniform base of this wave's first row
+    // this chunk's column statistics -> LDS (read back with LDS latency in every tile's epilogue)
+    float* const cstat = reinterpret_cast<float*>(lds + 2 * TILE);           // [2][CHUNK_MAX * KT]: max | 1 / sum
+    for (int o = tid; o < (t1 - t0) * KT; o += 256) {
+        cstat[o] = cmax[(size_t)z * Sp + t0 * KT + o];
+        cstat[CHUNK_MAX * KT + o] = cinv[(size_t)z * Sp + t0 * KT + o];
+    }
+    dma_tile(lds, bh, (size_t)z * Sp + (size_t)t0 * KT, tid, wave);
+    for (int jt = t0; jt < t1; ++jt) {
+        unsigned char* cur = lds + ((jt - t0) & 1) * TILE;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's pieces of tile jt (and older stores) done
+        __syncthreads();                                         // everyone's pieces landed; the other buffer is free
+        if (jt + 1 < t1) dma_tile(lds + ((jt + 1 - t0) & 1) * TILE, bh, (size_t)z * Sp + (size_t)(jt + 1) * KT, tid, wave);
+        f32x16 acc[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+        // B fragments one k-step ahead of the MFMAs that consume them (LDS latency under the matrix pipe)
+        f16x8 bf[2][2];
+        const unsigned char* brow[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) brow[ct] = cur + (32 * ct + l31) * ROWB;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) bf[0][ct] = *reinterpret_cast<const f16x8*>(brow[ct] + ((h ^ (l31 & 15)) * 16));
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (s + 1 < NS) {
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+                    bf[(s + 1) & 1][ct] = *reinterpret_cast<const f16x8*>(brow[ct] + (((2 * (s + 1) + h) ^ (l31 & 15)) * 16));
+            }
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s], bf[s & 1][ct], acc[ct], 0, 0, 0);
+        }
+        // column statistics of this lane's two columns, staged in LDS at item start (padded columns: +huge / 0 -> p = 0)
+        float cm[2], ci[2];
+        bool cmasked[2] = {false, false};
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const int o = (jt - t0) * KT + 32 * ct + l31;
+            cm[ct] = cstat[o];
+            ci[ct] = cstat[CHUNK_MAX * KT + o];
+            if (MASKS && mask1) {
+                const int j = jt * KT + 32 * ct + l31;
+                cmasked[ct] = j < S && !mask1[(size_t)z * S + j];
+            }
+        }
+        float tmax = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float e = fmaf(acc[ct][r], c2, -(rm[r] + cm[ct]));
+                if (MASKS && (((rmask_bits >> r) & 1u) || cmasked[ct])) e = fill2x2 - (rm[r] + cm[ct]);
+                const float p = __builtin_amdgcn_exp2f(e) * (ri[r] * ci[ct]);
+                acc[ct][r] = p;
+                tmax = fmaxf(tmax, p);
+            }
+        if (rows_live) {
+            // lane (l31, h) holds, for column j = jt*64 + 32 ct + l31, the rows row0 + (r & 3) + 8 (r >> 2) + 4 h: one store
+            // instruction = register r of all lanes = 32 consecutive floats of two rows (two whole 128-byte lines).
+            // Address = wave-uniform tile base (SGPR pair) + per-lane 32-bit byte offset of (row, l31) + immediate.
+            unsigned char* const tbase = reinterpret_cast<unsigned char*>(crow + jt * KT);   // wave-uniform
+            if (rows_full && (jt + 1) * KT <= S) {                          // wave-uniform: no per-store predicate
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) *reinterpret_cast<float*>(tbase + offr[r] + 128 * ct) = acc[ct][r];
+            } else {
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    const int j = jt * KT + 32 * ct + l31;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (j < S && row0 + mfma32_row(r, h) < L) *reinterpret_cast<float*>(tbase + offr[r] + 128 * ct) = acc[ct][r];
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(tmax > FIX_TAU) != 0ull) {      // rare: some entry needs the exact value
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int i = row0 + mfma32_row(r, h), j = jt * KT + 32 * ct + l31;
+                        if (acc[ct][r] > FIX_TAU && i < L && j < S) {
+                            const int idx = atomicAdd(fix_count, 1);
+                            if (idx < fix_cap) fix_list[idx] = make_uint2((unsigned)(z * L + i), (unsigned)j);
+                        }
+                    }
+            }
+        }
+    }
+}
+
+// one wave per listed entry: x = <f0_i, f1_j> in float64 from the fp32 features, p as in the exact kernels
+__global__ __launch_bounds__(256) void k1_conf_fix(const float* __restrict__ f0, const float* __restrict__ f1, int L, int S,
+                                                   int Sp, double k2, const uint8_t* __restrict__ mask0,
+                                                   const uint8_t* __restrict__ mask1, const float2* __restrict__ rowstat,
+                                                   const float* __restrict__ cmax, const float* __restrict__ cinv,
+                                                   float* __restrict__ conf, const int* __restrict__ fix_count,
+                                                   const uint2* __restrict__ fix_list, int fix_cap) {
+    const int lane = threadIdx.x & 63;
+    const int n = min(*fix_count, fix_cap);
+    const int nw = gridDim.x * (blockDim.x >> 6);
+    for (int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); e < n; e += nw) {
+        const uint2 ent = fix_list[e];
+        const size_t zi = ent.x;                 // z * L + i
+        const int j = (int)ent.y;
+        const size_t z = zi / (size_t)L;
+        if ((mask0 && !mask0[zi]) || (mask1 && !mask1[z * S + j])) continue;        // masked pairs keep the fill value
+        const float4 a = *reinterpret_cast<const float4*>(f0 + zi * C + 4 * lane);
+        const float4 b = *reinterpret_cast<const float4*>(f1 + (z * S + j) * C + 4 * lane);
+        double d = (double)a.x * (double)b.x + (double)a.y * (double)b.y + (double)a.z * (double)b.z + (double)a.w * (double)b.w;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) d += __shfl_xor(d, m, 64);
+        if (lane == 0) {
+            const float2 st = rowstat[zi];
+            const float x2 = (float)(2.0 * d * k2);
+            conf[zi * S + j] = __builtin_amdgcn_exp2f((x2 - st.x) - cmax[z * Sp + j]) * (1.0f / st.y) * cinv[z * Sp + j];
+        }
+    }
+}
+
+}  // namespace far_conf
+
+// Called by far_coarse_match_f16s / far_conf_matrix_f16s (dual_softmax_f16s.hip) after the statistics passes.
+// ah / bh: fp16 `hi` planes of k1_prep; c1: log2-domain score per unit of the pre-scaled dot product;
+// fix_count (1 int) / fix_list (fix_cap uint2) live in the caller's workspace.
+int far_k1_conf_launch(const float* f0, const float* f1, const _Float16* ah, const _Float16* bh, int Z, int L, int S, int Lp,
+                       int Sp, float c1, float fill2, double k2_exact, const uint8_t* mask0, const uint8_t* mask1,
+                       const float2* rowstat, const float* cmax, const float* cinv, float* conf, int* fix_count,
+                       uint2* fix_list, int fix_cap, hipStream_t stream) {
+    using namespace far_conf;
+    const int nI = Lp / 128;
+    const int ntile = (S + KT - 1) / KT;
+    // ~12 rounds of the chip's 512 resident workgroups: chunks of ~15 column tiles
+    int nch = (ntile + 14) / 15;
+    const int tpc = (ntile + nch - 1) / nch;                     // <= 15 <= CHUNK_MAX
+    nch = (ntile + tpc - 1) / tpc;
+    hipMemsetAsync(fix_count, 0, sizeof(int), stream);
+    const size_t smem = 2 * TILE + 2 * CHUNK_MAX * KT * sizeof(float);
+    FAR_ONCE_PER_DEVICE(
+        hipFuncSetAttribute((const void*)k1_conf<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipFuncSetAttribute((const void*)k1_conf<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    const dim3 grid((unsigned)(Z * nI * nch));
+    if (mask0 || mask1)
+        hipLaunchKernelGGL(k1_conf<true>, grid, dim3(256), smem, stream, ah, bh, Z, L, S, Lp, Sp, nI, nch, tpc, 2.0f * c1,
+                           2.0f * fill2, mask0, mask1, rowstat, cmax, cinv, conf, fix_count, fix_list, fix_cap);
+    else
+        hipLaunchKernelGGL(k1_conf<false>, grid, dim3(256), smem, stream, ah, bh, Z, L, S, Lp, Sp, nI, nch, tpc, 2.0f * c1,
+                           2.0f * fill2, mask0, mask1, rowstat, cmax, cinv, conf, fix_count, fix_list, fix_cap);
+    hipLaunchKernelGGL(k1_conf_fix, dim3(2048), dim3(256), 0, stream, f0, f1, L, S, Sp, k2_exact, mask0, mask1, rowstat, cmax,
+                       cinv, conf, fix_count, fix_list, fix_cap);
+    return far_check_launch();
+}

@@ -14,6 +14,13 @@
 // The contraction is three v_mfma_f32_32x32x16_f16 per 16 channels (hi.hi + hi.lo + lo.hi, fp32 accumulate): an
 // fp32-grade similarity at 16/3 of the exact-f32 MFMA rate of dual_softmax_f32.hip.
 #include "dual_softmax_common.h"
+#include <algorithm>
+
+// dual_softmax_conf_f16.hip: the HBM-bound conf_matrix writer (plain-fp16 scores + exact fix-up of the non-tiny entries)
+int far_k1_conf_launch(const float* f0, const float* f1, const _Float16* ah, const _Float16* bh, int Z, int L, int S, int Lp,
+                       int Sp, float c1, float fill2, double k2_exact, const uint8_t* mask0, const uint8_t* mask1,
+                       const float2* rowstat, const float* cmax, const float* cinv, float* conf, int* fix_count,
+                       uint2* fix_list, int fix_cap, hipStream_t stream);
 
 namespace {
 
@@ -290,6 +297,9 @@ struct Ws16 {
     _Float16 *ah, *al, *bh, *bl;
     float2* colstat2;
     float *cmax, *cinv;
+    int* fix_count;          // [2]: entries listed by k1_conf, capacity
+    uint2* fix_list;
+    int fix_cap;
     size_t bytes;
 };
 inline Ws16 carve16(void* ws, int Z, int L, int S) {
@@ -303,6 +313,9 @@ inline Ws16 carve16(void* ws, int Z, int L, int S) {
     w.bh = (_Float16*)take((size_t)Z * Sp * C * 2); w.bl = (_Float16*)take((size_t)Z * Sp * C * 2);
     w.colstat2 = (float2*)take((size_t)Z * S * 8);
     w.cmax = (float*)take((size_t)Z * Sp * 4); w.cinv = (float*)take((size_t)Z * Sp * 4);
+    w.fix_count = (int*)take(256);
+    w.fix_cap = (int)std::min<size_t>((size_t)Z * L * 8, (size_t)1 << 28);      // 8 exact entries per row on average
+    w.fix_list = (uint2*)take((size_t)w.fix_cap * sizeof(uint2));
     w.bytes = o;
     return w;
 }
@@ -358,6 +371,45 @@ int far_coarse_match_f16s(const float* f0, const float* f1, int Z, int L, int S,
                        w.k.colbest_part, nI, L, S, thr, border, h0, w0, h1, w1, valid_hw, w.k.match_j, counts);
     hipLaunchKernelGGL(k_compact, dim3(Z), dim3(256), 0, stream, w.k.match_j, w.k.rowbest_v, counts, L, w0, w1,
                        cell_scale, scale0, scale1, b_ids, i_ids, j_ids, mconf, mkpts0_c, mkpts1_c, total_out);
+    return far_check_launch();
+}
+
+// data['conf_matrix'] alone (coarse_matching.py:108-118), at HBM write speed: statistics on the split-precision passes
+// (fp32-grade), the matrix itself from plain-fp16 scores with every entry above 2^-12 recomputed exactly
+// (dual_softmax_conf_f16.hip).  stages: bit 0 = operand planes + statistics, bit 1 = write the matrix (a caller that
+// keeps the workspace may run the two separately, e.g. to time the writer alone).  fix_info_out: optional 2 device
+// ints = (entries listed for the exact recomputation, list capacity): listed > capacity means the surplus entries kept
+// their fp16-operand value (relative error <= ~1e-3); the Python front end then falls back to far_coarse_match_f16s.
+int far_conf_matrix_f16s(const float* f0, const float* f1, int Z, int L, int S, int Cc, float temperature,
+                         const uint8_t* mask0, const uint8_t* mask1, int stages, float* conf_out, int* fix_info_out,
+                         void* ws, hipStream_t stream) {
+    far_clear_errors();
+    if (!f0 || !f1 || !ws || !conf_out || Z <= 0 || L <= 0 || S <= 0 || Cc != C || !(stages & 3)) return FAR_EINVAL;
+    const Ws16 w = carve16(ws, Z, L, S);
+    const int Lp = (L + 127) / 128 * 128, Sp = (S + 127) / 128 * 128;
+    const float c1 = (float)(1.4426950408889634 / ((double)C * (double)temperature * PRESCALE * PRESCALE));
+    const float fill2 = -1e9f * 1.44269504088896341f;
+    if (stages & 1) {
+        auto gridp = [](long n) { long b = (n + 255) / 256; return (unsigned)(b < 65536L * 4 ? b : 65536L * 4); };
+        hipLaunchKernelGGL(k1_prep, dim3(gridp((long)Z * Lp * 32)), dim3(256), 0, stream, f0, Z, L, Lp, w.ah, w.al);
+        hipLaunchKernelGGL(k1_prep, dim3(gridp((long)Z * Sp * 32)), dim3(256), 0, stream, f1, Z, S, Sp, w.bh, w.bl);
+        const size_t smem_s = 2 * TILE_PLANE;
+        FAR_ONCE_PER_DEVICE(hipFuncSetAttribute((const void*)k1_rowstats, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_s));
+        hipLaunchKernelGGL(k1_rowstats, dim3((Lp / 128) * Z), dim3(256), smem_s, stream, w.ah, w.al, w.bh, w.bl, Z, L, S, Lp, Sp,
+                           c1, fill2, mask0, mask1, w.k.rowstat, (float*)nullptr, (float*)nullptr);
+        hipLaunchKernelGGL(k1_rowstats, dim3((Sp / 128) * Z), dim3(256), smem_s, stream, w.bh, w.bl, w.ah, w.al, Z, S, L, Sp, Lp,
+                           c1, fill2, mask1, mask0, w.colstat2, w.cmax, w.cinv);
+    }
+    if (stages & 2) {
+        const double k2 = 1.4426950408889634 / ((double)C * (double)temperature);
+        const int rc = far_k1_conf_launch(f0, f1, w.ah, w.bh, Z, L, S, Lp, Sp, c1, fill2, k2, mask0, mask1, w.k.rowstat, w.cmax,
+                                          w.cinv, conf_out, w.fix_count, w.fix_list, w.fix_cap, stream);
+        if (rc != FAR_OK) return rc;
+        if (fix_info_out) {
+            hipMemcpyAsync(fix_info_out, w.fix_count, sizeof(int), hipMemcpyDeviceToDevice, stream);
+            hipMemcpyAsync(fix_info_out + 1, &w.fix_cap, sizeof(int), hipMemcpyHostToDevice, stream);
+        }
+    }
     return far_check_launch();
 }
 

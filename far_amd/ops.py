@@ -103,6 +103,30 @@ def coarse_match(f0, f1, temperature, thr, border, hw0, hw1, cell_scale, mask0=N
     }
 
 
+def conf_matrix(f0, f1, temperature, mask0=None, mask1=None, out=None):
+    """K1, materialising mode: data['conf_matrix'] (Z, L, S) alone (coarse_matching.py:108-118) at HBM write speed
+    (far_conf_matrix_f16s: fp32-grade statistics, plain-fp16 scores, exact recomputation of every entry above 2^-12).
+    Falls back to the fused split-precision matcher's writer if the exact-entry list overflowed (needs one host read).
+    Returns (conf, listed) with listed = number of entries that were recomputed exactly."""
+    lib = _lib.load()
+    Z, L, C = f0.shape
+    S = f1.shape[1]
+    dev = f0.device
+    ws = _ws(lib.far_coarse_match_f16s_workspace_bytes(Z, L, S, C), dev)
+    conf = torch.empty(Z, L, S, dtype=torch.float32, device=dev) if out is None else out
+    info = torch.zeros(2, dtype=torch.int32, device=dev)
+    rc = lib.far_conf_matrix_f16s(_p(f0, torch.float32), _p(f1, torch.float32), Z, L, S, C, float(temperature),
+                                  _p(mask0, torch.uint8), _p(mask1, torch.uint8), 3, _p(conf, torch.float32), _p(info), _p(ws),
+                                  _stream())
+    _lib.check(rc, 'far_conf_matrix_f16s')
+    listed, cap = (int(v) for v in info.cpu())
+    if listed > cap:          # pathological input (more than 8 non-tiny entries per row on average): exact writer
+        hw = (1, L), (1, S)
+        return coarse_match(f0, f1, temperature, 2.0, 0, hw[0], hw[1], 1.0, mask0, mask1, want_conf=True,
+                            variant='f16s')['conf_matrix'], listed
+    return (conf if out is None else _written(conf)), listed
+
+
 def emm_bilinear(q, k, v, pos, scale, exact_f32=False):
     """K2.  q, k, v: (Z, N, 64) fp32; pos: (N, 6).  Returns F (Z, 70, 70) = v~^T (P v~), v~ = [v | pos],
     P = softmax(s, -1) * softmax(s, -2), s = (q k^T) * scale   (transformer.py:275-292).

@@ -234,3 +234,48 @@ def test_f16s_variant_no_matches_and_masks():
     for k in ('b_ids', 'i_ids', 'j_ids', 'mkpts0_c', 'mkpts1_c'):
         assert torch.equal(a[k], b[k]), k
     assert float((a['conf_matrix'] - b['conf_matrix']).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize('N,hw,seed,amp,frac', [(1, (60, 80), 3, 1.2, 0.8), (2, (68, 90), 11, 1.3, 0.9), (8, (60, 80), 23, 1.2, 0.8)])
+def test_conf_matrix_writer_is_fp32_grade(N, hw, seed, amp, frac):
+    """far_conf_matrix_f16s (the HBM-bound writer: plain-fp16 scores + exact recomputation of every entry above 2^-12)
+    against the float64 oracle: <= 1e-5 everywhere, like the split-precision matcher's writer; ragged sizes included
+    (68x90: L = S = 6120 is not a multiple of the 64-column tile)."""
+    from far_amd import ops
+    from oracle import coarse as oc
+    f0, f1, _ = correlated_features(N, hw, 256, seed=seed, amp=amp, frac=frac)
+    t0, t1 = torch.from_numpy(f0).cuda(), torch.from_numpy(f1).cuda()
+    conf, listed = ops.conf_matrix(t0, t1, 0.1)
+    ref_fused = ops.coarse_match(t0, t1, 0.1, 0.2, 2, hw, hw, 8.0, want_conf=True, variant='f16s')['conf_matrix']
+    L = hw[0] * hw[1]
+    assert conf.shape == (N, L, L) and 0 < listed < N * L * 8
+    worst = 0.0
+    for n in range(min(N, 2)):          # the float64 oracle of one 4800 x 4800 matrix takes a few seconds
+        ref64 = oc.conf_matrix(f0[n:n + 1], f1[n:n + 1], 0.1, dtype=np.float64)[0]
+        worst = max(worst, float(np.abs(conf[n].cpu().numpy() - ref64).max()))
+    dev_fused = float((conf - ref_fused).abs().max())
+    big = ref_fused > 2.0 ** -11
+    print(f'[conf writer] N={N} hw={hw}: listed {listed} entries ({listed / (N * L):.2f} per row), '
+          f'max|conf - float64| = {worst:.2e}, max|conf - fused split writer| = {dev_fused:.2e}, '
+          f'on entries > 2^-11: {float((conf - ref_fused).abs()[big].max()):.2e}')
+    assert worst <= ATOL64 and dev_fused <= 2e-5
+
+
+def test_conf_matrix_writer_with_masks():
+    """Padded masks (coarse_matching.py:110-113: masked pairs get -1e9 before the softmaxes)."""
+    from far_amd import ops
+    from oracle import coarse as oc
+    N, hw = 2, (24, 32)
+    f0, f1, _ = correlated_features(N, hw, 256, seed=31, amp=1.4)
+    L = hw[0] * hw[1]
+    m0 = np.ones((N, L), np.uint8)
+    m1 = np.ones((N, L), np.uint8)
+    m0[0, 500:] = 0
+    m1[1, 600:] = 0
+    conf, _ = ops.conf_matrix(torch.from_numpy(f0).cuda(), torch.from_numpy(f1).cuda(), 0.1,
+                              torch.from_numpy(m0).cuda(), torch.from_numpy(m1).cuda())
+    ref64 = oc.conf_matrix(f0, f1, 0.1, m0.astype(bool), m1.astype(bool), dtype=np.float64)
+    valid = m0[..., None].astype(bool) & m1[:, None].astype(bool)
+    got = conf.cpu().numpy()
+    assert np.abs(got - ref64)[valid].max() <= ATOL64
+    assert got[~valid].max() <= 1e-30 or np.abs(got - ref64)[~valid].max() <= ATOL64

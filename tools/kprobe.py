@@ -21,6 +21,14 @@ if which in ('k1conf', 'all'):
     f1 = f0[:, torch.randperm(L, device=dev, generator=g)] + 0.1 * torch.randn(n, L, 256, device=dev, generator=g)
     for _ in range(it):
         ops.coarse_match(f0, f1, 0.1, 0.2, 2, (60, 80), (60, 80), 8.0, want_conf=True)
+if which in ('k1w', 'all'):
+    f0 = 1.2 * torch.randn(n, L, 256, device=dev, generator=g)
+    f1 = f0[:, torch.randperm(L, device=dev, generator=g)] + 0.1 * torch.randn(n, L, 256, device=dev, generator=g)
+    conf = torch.empty(n, L, L, device=dev)
+    for _ in range(it):
+        c, listed = ops.conf_matrix(f0, f1, 0.1, out=conf)
+    print('k1w: listed', listed, 'entries =', listed / (n * L), 'per row')
+    del conf
 if which in ('k1b',):
     f0 = 1.2 * torch.randn(n, L, 256, device=dev, generator=g)
     f1 = f0[:, torch.randperm(L, device=dev, generator=g)] + 0.1 * torch.randn(n, L, 256, device=dev, generator=g)
