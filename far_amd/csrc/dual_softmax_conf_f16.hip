@@ -14,10 +14,15 @@
 //                   the grid is ~12 rounds of the chip (no tail) and all items of a pair run on one XCD (L2-resident
 //                   operand planes);
 //   * exactness     |p' - p| <= 2 ln2 |x' - x| p: the fp16 operand error (|x' - x| ~ 5e-4 in log2 units, rigorous
-//                   bound 2^-10 sum|a_c b_c| log2e / (C temperature)) only matters where p is not tiny.  Every entry
-//                   with p' > FIX_TAU = 2^-12 (a handful per row) is appended to a list and k1_conf_fix recomputes it
-//                   from the fp32 features with a float64 dot product: conf_matrix is within 1e-5 of the float64
-//                   oracle everywhere (tests/test_coarse_gpu.py), although 99.99 % of it never saw an fp32 product.
+//                   bound 2^-10 sum|a_c b_c| log2e / (C temperature)) only matters where p is not tiny.  The second
+//                   statistics pass (k1_rowstats<CAND>, dual_softmax_f16s.hip) lists every entry whose row softmax is
+//                   >= 2^-12 -- a superset of p >= 2^-12, about one entry per row -- WITH its split-precision score x;
+//                   k1_conf_fix rewrites those with the fused matcher's formula on that x.  It has to be that x: the
+//                   statistics were accumulated from it, and an independently computed score, however exact, would not
+//                   cancel against them (a float64 dot product here measured 1.6e-5 on confident entries; the fp32
+//                   accumulation error of a 256-term dot is ~1e-5 in the log2 domain).  Every unlisted entry is below
+//                   2^-12, where the fp16-operand error is < 3e-6 absolute: conf_matrix is within 1e-5 of the float64
+//                   oracle everywhere (tests/test_coarse_gpu.py), although 99.99 % of it never saw an fp32-grade product.
 #include "dual_softmax_common.h"
 
 namespace far_conf {
@@ -33,7 +38,6 @@ constexpr int NS = C / 16;
 constexpr int KT = 64;                 // columns per tile
 constexpr int ROWB = C * 2;            // bytes per fp16 row
 constexpr int TILE = KT * ROWB;        // 32 KiB
-constexpr float FIX_TAU = 1.0f / 4096.0f;
 constexpr int CHUNK_MAX = 16;          // column tiles per work item (upper bound: sizes the LDS copy of the column statistics)
 
 // one 64-column tile of the `hi` plane (LDS image: 16-byte slot ^= row & 15, written by k1_prep) -> LDS, 8 KiB per wave
@@ -51,8 +55,7 @@ __global__ __launch_bounds__(256, 2) void k1_conf(const _Float16* __restrict__ a
                                                   float c2, float fill2x2, const uint8_t* __restrict__ mask0,
                                                   const uint8_t* __restrict__ mask1, const float2* __restrict__ rowstat,
                                                   const float* __restrict__ cmax, const float* __restrict__ cinv,
-                                                  float* __restrict__ conf, int* __restrict__ fix_count,
-                                                  uint2* __restrict__ fix_list, int fix_cap) {
+                                                  float* __restrict__ conf) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     int z, item;
@@ -134,7 +137,6 @@ __global__ __launch_bounds__(256, 2) void k1_conf(const _Float16* __restrict__ a
                 cmasked[ct] = j < S && !mask1[(size_t)z * S + j];
             }
         }
-        float tmax = 0.f;
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -143,7 +145,6 @@ __global__ __launch_bounds__(256, 2) void k1_conf(const _Float16* __restrict__ a
                 if (MASKS && (((rmask_bits >> r) & 1u) || cmasked[ct])) e = fill2x2 - (rm[r] + cm[ct]);
                 const float p = __builtin_amdgcn_exp2f(e) * (ri[r] * ci[ct]);
                 acc[ct][r] = p;
-                tmax = fmaxf(tmax, p);
             }
         if (rows_live) {
             // lane (l31, h) holds, for column j = jt*64 + 32 ct + l31, the rows row0 + (r & 3) + 8 (r >> 2) + 4 h: one store
@@ -164,60 +165,39 @@ __global__ __launch_bounds__(256, 2) void k1_conf(const _Float16* __restrict__ a
                         if (j < S && row0 + mfma32_row(r, h) < L) *reinterpret_cast<float*>(tbase + offr[r] + 128 * ct) = acc[ct][r];
                 }
             }
-            if (__builtin_amdgcn_ballot_w64(tmax > FIX_TAU) != 0ull) {      // rare: some entry needs the exact value
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int i = row0 + mfma32_row(r, h), j = jt * KT + 32 * ct + l31;
-                        if (acc[ct][r] > FIX_TAU && i < L && j < S) {
-                            const int idx = atomicAdd(fix_count, 1);
-                            if (idx < fix_cap) fix_list[idx] = make_uint2((unsigned)(z * L + i), (unsigned)j);
-                        }
-                    }
-            }
         }
     }
 }
 
-// one wave per listed entry: x = <f0_i, f1_j> in float64 from the fp32 features, p as in the exact kernels
-__global__ __launch_bounds__(256) void k1_conf_fix(const float* __restrict__ f0, const float* __restrict__ f1, int L, int S,
-                                                   int Sp, double k2, const uint8_t* __restrict__ mask0,
-                                                   const uint8_t* __restrict__ mask1, const float2* __restrict__ rowstat,
+// one thread per listed entry (z * L + i, j, bits of the split-precision log2-domain score x): the fused matcher's
+// formula (dual_softmax_f16s.hip:k1_match), bit for bit
+__global__ __launch_bounds__(256) void k1_conf_fix(int L, int S, int Sp, const float2* __restrict__ rowstat,
                                                    const float* __restrict__ cmax, const float* __restrict__ cinv,
                                                    float* __restrict__ conf, const int* __restrict__ fix_count,
-                                                   const uint2* __restrict__ fix_list, int fix_cap) {
-    const int lane = threadIdx.x & 63;
-    const int n = min(*fix_count, fix_cap);
-    const int nw = gridDim.x * (blockDim.x >> 6);
-    for (int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); e < n; e += nw) {
-        const uint2 ent = fix_list[e];
-        const size_t zi = ent.x;                 // z * L + i
+                                                   const uint4* __restrict__ fix_list, int fix_cap,
+                                                   int* __restrict__ fix_info_out) {
+    const int listed = *fix_count;
+    const int n = min(listed, fix_cap);
+    if (fix_info_out && blockIdx.x == 0 && threadIdx.x == 0) { fix_info_out[0] = listed; fix_info_out[1] = fix_cap; }
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+        const uint4 ent = fix_list[e];
+        const size_t zi = ent.x, z = zi / (size_t)L;
         const int j = (int)ent.y;
-        const size_t z = zi / (size_t)L;
-        if ((mask0 && !mask0[zi]) || (mask1 && !mask1[z * S + j])) continue;        // masked pairs keep the fill value
-        const float4 a = *reinterpret_cast<const float4*>(f0 + zi * C + 4 * lane);
-        const float4 b = *reinterpret_cast<const float4*>(f1 + (z * S + j) * C + 4 * lane);
-        double d = (double)a.x * (double)b.x + (double)a.y * (double)b.y + (double)a.z * (double)b.z + (double)a.w * (double)b.w;
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) d += __shfl_xor(d, m, 64);
-        if (lane == 0) {
-            const float2 st = rowstat[zi];
-            const float x2 = (float)(2.0 * d * k2);
-            conf[zi * S + j] = __builtin_amdgcn_exp2f((x2 - st.x) - cmax[z * Sp + j]) * (1.0f / st.y) * cinv[z * Sp + j];
-        }
+        const float2 st = rowstat[zi];
+        const float x2 = 2.0f * __uint_as_float(ent.z);
+        conf[zi * S + j] = __builtin_amdgcn_exp2f((x2 - st.x) - cmax[z * Sp + j]) * (1.0f / st.y) * cinv[z * Sp + j];
     }
 }
 
 }  // namespace far_conf
 
-// Called by far_coarse_match_f16s / far_conf_matrix_f16s (dual_softmax_f16s.hip) after the statistics passes.
-// ah / bh: fp16 `hi` planes of k1_prep; c1: log2-domain score per unit of the pre-scaled dot product;
-// fix_count (1 int) / fix_list (fix_cap uint2) live in the caller's workspace.
-int far_k1_conf_launch(const float* f0, const float* f1, const _Float16* ah, const _Float16* bh, int Z, int L, int S, int Lp,
-                       int Sp, float c1, float fill2, double k2_exact, const uint8_t* mask0, const uint8_t* mask1,
-                       const float2* rowstat, const float* cmax, const float* cinv, float* conf, int* fix_count,
-                       uint2* fix_list, int fix_cap, hipStream_t stream) {
+// Called by far_conf_matrix_f16s (dual_softmax_f16s.hip) after the statistics passes.  ah / bh: fp16 `hi` planes of
+// k1_prep; c1: log2-domain score per unit of the pre-scaled dot product; fix_count / fix_list: the entries listed by
+// k1_rowstats<CAND>.
+int far_k1_conf_launch(const _Float16* ah, const _Float16* bh, int Z, int L, int S, int Lp, int Sp, float c1, float fill2,
+                       const uint8_t* mask0, const uint8_t* mask1, const float2* rowstat, const float* cmax,
+                       const float* cinv, float* conf, const int* fix_count, const uint4* fix_list, int fix_cap,
+                       int* fix_info_out, hipStream_t stream) {
     using namespace far_conf;
     const int nI = Lp / 128;
     const int ntile = (S + KT - 1) / KT;
@@ -225,7 +205,6 @@ int far_k1_conf_launch(const float* f0, const float* f1, const _Float16* ah, con
     int nch = (ntile + 14) / 15;
     const int tpc = (ntile + nch - 1) / nch;                     // <= 15 <= CHUNK_MAX
     nch = (ntile + tpc - 1) / tpc;
-    hipMemsetAsync(fix_count, 0, sizeof(int), stream);
     const size_t smem = 2 * TILE + 2 * CHUNK_MAX * KT * sizeof(float);
     FAR_ONCE_PER_DEVICE(
         hipFuncSetAttribute((const void*)k1_conf<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -233,11 +212,11 @@ int far_k1_conf_launch(const float* f0, const float* f1, const _Float16* ah, con
     const dim3 grid((unsigned)(Z * nI * nch));
     if (mask0 || mask1)
         hipLaunchKernelGGL(k1_conf<true>, grid, dim3(256), smem, stream, ah, bh, Z, L, S, Lp, Sp, nI, nch, tpc, 2.0f * c1,
-                           2.0f * fill2, mask0, mask1, rowstat, cmax, cinv, conf, fix_count, fix_list, fix_cap);
+                           2.0f * fill2, mask0, mask1, rowstat, cmax, cinv, conf);
     else
         hipLaunchKernelGGL(k1_conf<false>, grid, dim3(256), smem, stream, ah, bh, Z, L, S, Lp, Sp, nI, nch, tpc, 2.0f * c1,
-                           2.0f * fill2, mask0, mask1, rowstat, cmax, cinv, conf, fix_count, fix_list, fix_cap);
-    hipLaunchKernelGGL(k1_conf_fix, dim3(2048), dim3(256), 0, stream, f0, f1, L, S, Sp, k2_exact, mask0, mask1, rowstat, cmax,
-                       cinv, conf, fix_count, fix_list, fix_cap);
+                           2.0f * fill2, mask0, mask1, rowstat, cmax, cinv, conf);
+    hipLaunchKernelGGL(k1_conf_fix, dim3(512), dim3(256), 0, stream, L, S, Sp, rowstat, cmax, cinv, conf, fix_count, fix_list,
+                       fix_cap, fix_info_out);
     return far_check_launch();
 }

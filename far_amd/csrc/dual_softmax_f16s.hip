@@ -17,10 +17,10 @@
 #include <algorithm>
 
 // dual_softmax_conf_f16.hip: the HBM-bound conf_matrix writer (plain-fp16 scores + exact fix-up of the non-tiny entries)
-int far_k1_conf_launch(const float* f0, const float* f1, const _Float16* ah, const _Float16* bh, int Z, int L, int S, int Lp,
-                       int Sp, float c1, float fill2, double k2_exact, const uint8_t* mask0, const uint8_t* mask1,
-                       const float2* rowstat, const float* cmax, const float* cinv, float* conf, int* fix_count,
-                       uint2* fix_list, int fix_cap, hipStream_t stream);
+int far_k1_conf_launch(const _Float16* ah, const _Float16* bh, int Z, int L, int S, int Lp, int Sp, float c1, float fill2,
+                       const uint8_t* mask0, const uint8_t* mask1, const float2* rowstat, const float* cmax,
+                       const float* cinv, float* conf, const int* fix_count, const uint4* fix_list, int fix_cap,
+                       int* fix_info_out, hipStream_t stream);
 
 namespace {
 
@@ -130,11 +130,19 @@ __device__ __forceinline__ void score_tile(f32x16 (&acc)[2], const unsigned char
 
 // stat[z][i] = (max_j x_ij, sum_j 2^(x_ij - max)) over the Nc real columns; masked pairs count with x = fill2
 // (masked_fill_(-INF), coarse_matching.py:108-111).  Optional dense padded copies dmax / dinv [Z][Nrp] (+huge / 0 past Nr).
+// CAND (second call of the conf_matrix writer, rows = the matrix's COLUMNS j, tile columns = its rows i whose statistics
+// are final): every entry with x >= othr[i] = rowmax_i + log2(rowsum_i) - 12, i.e. softmax_row(i, j) >= 2^-12 (a
+// superset of conf >= 2^-12), is appended to `cand` as (z * Nc + i, j, bits of x): the writer's fix-up evaluates those
+// from THIS x, the very value the statistics were accumulated from (an independently computed "exact" x would not
+// cancel against them: the fp32 accumulation error of a 256-term dot product is ~1e-5 in the log2 domain).
+template <bool CAND>
 __global__ __launch_bounds__(256, 2) void k1_rowstats(const _Float16* __restrict__ ah, const _Float16* __restrict__ al,
                                                       const _Float16* __restrict__ bh, const _Float16* __restrict__ bl,
                                                       int Z, int Nr, int Nc, int Nrp, int Ncp, float c1, float fill2,
                                                       const uint8_t* __restrict__ rmask, const uint8_t* __restrict__ cmask,
-                                                      float2* __restrict__ stat, float* __restrict__ dmax, float* __restrict__ dinv) {
+                                                      float2* __restrict__ stat, float* __restrict__ dmax, float* __restrict__ dinv,
+                                                      float* __restrict__ dthr, const float* __restrict__ othr,
+                                                      int* __restrict__ cand_count, uint4* __restrict__ cand, int cand_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     int z, Ib;
@@ -167,6 +175,35 @@ __global__ __launch_bounds__(256, 2) void k1_rowstats(const _Float16* __restrict
                 acc[ct][r] = x;
                 tm = fmaxf(tm, x);
             }
+        if (CAND) {
+            // thresholds of this lane's tile indices i = jt*64 + 32 ct + 8 q + 4 h + (0..3)  (padded: +huge)
+            float hot = -1.f;
+            float th[2][16];
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const float4 a = *reinterpret_cast<const float4*>(othr + (size_t)z * Ncp + jt * KT + 32 * ct + 8 * q4 + 4 * h);
+                    th[ct][4 * q4 + 0] = a.x; th[ct][4 * q4 + 1] = a.y; th[ct][4 * q4 + 2] = a.z; th[ct][4 * q4 + 3] = a.w;
+                }
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hot = fmaxf(hot, acc[ct][r] - th[ct][r]);
+            if (__builtin_amdgcn_ballot_w64(hot >= 0.f) != 0ull) {            // rare
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int i = jt * KT + 32 * ct + mfma32_row(r, h);
+                        if (acc[ct][r] >= th[ct][r] && acc[ct][r] > -1.0e8f && i < Nc && irow < Nr) {
+                            const int idx = atomicAdd(cand_count, 1);
+                            if (idx < cand_cap)
+                                cand[idx] = make_uint4((unsigned)(z * Nc + i), (unsigned)irow, __float_as_uint(acc[ct][r]), 0u);
+                        }
+                    }
+            }
+        }
         // The tile's 32 terms are summed on their own and then added to the running sum with Kahan compensation:
         // once the row maximum (a term equal to 1) is in the accumulator, the other terms (~1e-8 each for a
         // confident match) are below half an ulp of it and a plain fp32 running sum would drop them one by one
@@ -196,6 +233,7 @@ __global__ __launch_bounds__(256, 2) void k1_rowstats(const _Float16* __restrict
             dmax[(size_t)z * Nrp + irow] = irow < Nr ? mn : HUGE_F;
             dinv[(size_t)z * Nrp + irow] = irow < Nr ? 1.0f / st : 0.f;
         }
+        if (dthr) dthr[(size_t)z * Nrp + irow] = irow < Nr ? mn + __builtin_amdgcn_logf(st) - 12.0f : HUGE_F;
     }
 }
 
@@ -297,8 +335,9 @@ struct Ws16 {
     _Float16 *ah, *al, *bh, *bl;
     float2* colstat2;
     float *cmax, *cinv;
-    int* fix_count;          // [2]: entries listed by k1_conf, capacity
-    uint2* fix_list;
+    float* rthr;             // [Z][Lp]: rowmax + log2(rowsum) - 12 (candidate threshold of the conf_matrix writer)
+    int* fix_count;          // entries listed for the writer's exact pass
+    uint4* fix_list;         // (z * L + i, j, bits of x, -)
     int fix_cap;
     size_t bytes;
 };
@@ -313,9 +352,10 @@ inline Ws16 carve16(void* ws, int Z, int L, int S) {
     w.bh = (_Float16*)take((size_t)Z * Sp * C * 2); w.bl = (_Float16*)take((size_t)Z * Sp * C * 2);
     w.colstat2 = (float2*)take((size_t)Z * S * 8);
     w.cmax = (float*)take((size_t)Z * Sp * 4); w.cinv = (float*)take((size_t)Z * Sp * 4);
+    w.rthr = (float*)take((size_t)Z * Lp * 4);
     w.fix_count = (int*)take(256);
-    w.fix_cap = (int)std::min<size_t>((size_t)Z * L * 8, (size_t)1 << 28);      // 8 exact entries per row on average
-    w.fix_list = (uint2*)take((size_t)w.fix_cap * sizeof(uint2));
+    w.fix_cap = (int)std::min<size_t>((size_t)Z * L * 8, (size_t)1 << 27);      // 8 exact entries per row on average
+    w.fix_list = (uint4*)take((size_t)w.fix_cap * sizeof(uint4));
     w.bytes = o;
     return w;
 }
@@ -353,13 +393,15 @@ int far_coarse_match_f16s(const float* f0, const float* f1, int Z, int L, int S,
     hipMemsetAsync(counts, 0, sizeof(int) * Z, stream);
     const size_t smem_s = 2 * TILE_PLANE, smem_m = 2 * TILE_PLANE + 4 * 64 * sizeof(float);
     FAR_ONCE_PER_DEVICE(
-        hipFuncSetAttribute((const void*)k1_rowstats, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_s);
+        hipFuncSetAttribute((const void*)k1_rowstats<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_s);
         hipFuncSetAttribute((const void*)k1_match<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_m);
         hipFuncSetAttribute((const void*)k1_match<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_m));
-    hipLaunchKernelGGL(k1_rowstats, dim3((Lp / 128) * Z), dim3(256), smem_s, stream, w.ah, w.al, w.bh, w.bl, Z, L, S, Lp, Sp,
-                       c1, fill2, mask0, mask1, w.k.rowstat, (float*)nullptr, (float*)nullptr);
-    hipLaunchKernelGGL(k1_rowstats, dim3((Sp / 128) * Z), dim3(256), smem_s, stream, w.bh, w.bl, w.ah, w.al, Z, S, L, Sp, Lp,
-                       c1, fill2, mask1, mask0, w.colstat2, w.cmax, w.cinv);
+    hipLaunchKernelGGL(k1_rowstats<false>, dim3((Lp / 128) * Z), dim3(256), smem_s, stream, w.ah, w.al, w.bh, w.bl, Z, L, S, Lp, Sp,
+                       c1, fill2, mask0, mask1, w.k.rowstat, (float*)nullptr, (float*)nullptr, (float*)nullptr,
+                       (const float*)nullptr, (int*)nullptr, (uint4*)nullptr, 0);
+    hipLaunchKernelGGL(k1_rowstats<false>, dim3((Sp / 128) * Z), dim3(256), smem_s, stream, w.bh, w.bl, w.ah, w.al, Z, S, L, Sp, Lp,
+                       c1, fill2, mask1, mask0, w.colstat2, w.cmax, w.cinv, (float*)nullptr, (const float*)nullptr,
+                       (int*)nullptr, (uint4*)nullptr, 0);
     const int nI = Lp / 128;
     if (conf_out)
         hipLaunchKernelGGL(k1_match<true>, dim3(nI * Z), dim3(256), smem_m, stream, w.ah, w.al, w.bh, w.bl, Z, L, S, Lp, Sp, c1,
@@ -375,7 +417,8 @@ int far_coarse_match_f16s(const float* f0, const float* f1, int Z, int L, int S,
 }
 
 // data['conf_matrix'] alone (coarse_matching.py:108-118), at HBM write speed: statistics on the split-precision passes
-// (fp32-grade), the matrix itself from plain-fp16 scores with every entry above 2^-12 recomputed exactly
+// (fp32-grade), the matrix itself from plain-fp16 scores, and every entry whose row softmax exceeds 2^-12 (listed by the
+// second statistics pass together with its split-precision score) rewritten with the fused matcher's exact formula
 // (dual_softmax_conf_f16.hip).  stages: bit 0 = operand planes + statistics, bit 1 = write the matrix (a caller that
 // keeps the workspace may run the two separately, e.g. to time the writer alone).  fix_info_out: optional 2 device
 // ints = (entries listed for the exact recomputation, list capacity): listed > capacity means the surplus entries kept
@@ -394,21 +437,22 @@ int far_conf_matrix_f16s(const float* f0, const float* f1, int Z, int L, int S, 
         hipLaunchKernelGGL(k1_prep, dim3(gridp((long)Z * Lp * 32)), dim3(256), 0, stream, f0, Z, L, Lp, w.ah, w.al);
         hipLaunchKernelGGL(k1_prep, dim3(gridp((long)Z * Sp * 32)), dim3(256), 0, stream, f1, Z, S, Sp, w.bh, w.bl);
         const size_t smem_s = 2 * TILE_PLANE;
-        FAR_ONCE_PER_DEVICE(hipFuncSetAttribute((const void*)k1_rowstats, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_s));
-        hipLaunchKernelGGL(k1_rowstats, dim3((Lp / 128) * Z), dim3(256), smem_s, stream, w.ah, w.al, w.bh, w.bl, Z, L, S, Lp, Sp,
-                           c1, fill2, mask0, mask1, w.k.rowstat, (float*)nullptr, (float*)nullptr);
-        hipLaunchKernelGGL(k1_rowstats, dim3((Sp / 128) * Z), dim3(256), smem_s, stream, w.bh, w.bl, w.ah, w.al, Z, S, L, Sp, Lp,
-                           c1, fill2, mask1, mask0, w.colstat2, w.cmax, w.cinv);
+        FAR_ONCE_PER_DEVICE(
+            hipFuncSetAttribute((const void*)k1_rowstats<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_s);
+            hipFuncSetAttribute((const void*)k1_rowstats<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_s));
+        hipMemsetAsync(w.fix_count, 0, sizeof(int), stream);
+        // row statistics (+ the dense candidate thresholds), then column statistics with candidate listing
+        hipLaunchKernelGGL(k1_rowstats<false>, dim3((Lp / 128) * Z), dim3(256), smem_s, stream, w.ah, w.al, w.bh, w.bl, Z, L, S, Lp,
+                           Sp, c1, fill2, mask0, mask1, w.k.rowstat, (float*)nullptr, (float*)nullptr, w.rthr,
+                           (const float*)nullptr, (int*)nullptr, (uint4*)nullptr, 0);
+        hipLaunchKernelGGL(k1_rowstats<true>, dim3((Sp / 128) * Z), dim3(256), smem_s, stream, w.bh, w.bl, w.ah, w.al, Z, S, L, Sp,
+                           Lp, c1, fill2, mask1, mask0, w.colstat2, w.cmax, w.cinv, (float*)nullptr, (const float*)w.rthr,
+                           w.fix_count, w.fix_list, w.fix_cap);
     }
     if (stages & 2) {
-        const double k2 = 1.4426950408889634 / ((double)C * (double)temperature);
-        const int rc = far_k1_conf_launch(f0, f1, w.ah, w.bh, Z, L, S, Lp, Sp, c1, fill2, k2, mask0, mask1, w.k.rowstat, w.cmax,
-                                          w.cinv, conf_out, w.fix_count, w.fix_list, w.fix_cap, stream);
+        const int rc = far_k1_conf_launch(w.ah, w.bh, Z, L, S, Lp, Sp, c1, fill2, mask0, mask1, w.k.rowstat, w.cmax, w.cinv,
+                                          conf_out, w.fix_count, w.fix_list, w.fix_cap, fix_info_out, stream);
         if (rc != FAR_OK) return rc;
-        if (fix_info_out) {
-            hipMemcpyAsync(fix_info_out, w.fix_count, sizeof(int), hipMemcpyDeviceToDevice, stream);
-            hipMemcpyAsync(fix_info_out + 1, &w.fix_cap, sizeof(int), hipMemcpyHostToDevice, stream);
-        }
     }
     return far_check_launch();
 }

@@ -1,6 +1,6 @@
 """Run the hand-written kernels in isolation at bench shapes (for rocprofv3 --pmc / --kernel-trace passes)."""
-import ctypes, sys
-sys.path.insert(0, '.')
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from far_amd import ops, _lib
 
