@@ -73,34 +73,57 @@ __global__ __launch_bounds__(256, 2) void k1_conf(const _Float16* __restrict__ a
 #pragma unroll
         for (int s = 0; s < NS; ++s) af[s] = *reinterpret_cast<const f16x8*>(p + 8 * ((2 * s + h) ^ (irow & 15)));
     }
-    // row statistics of the 16 rows whose results this lane holds: i = row0 + (r & 3) + 8 (r >> 2) + 4 h
-    float rm[16], ri[16];
+    // log2 conf = 2 x - (rowmax + log2 rowsum) - (colmax + log2 colsum): one fma + one exp per entry.
+    // Row terms of the 16 rows whose results this lane holds: i = row0 + (r & 3) + 8 (r >> 2) + 4 h
+    float rl[16];
     unsigned rmask_bits = 0;                                     // bit r: row masked out (mask0 == 0)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int i = row0 + mfma32_row(r, h);
         const float2 st = i < L ? rowstat[(size_t)z * L + i] : make_float2(0.f, 1.f);
-        rm[r] = st.x;
-        ri[r] = i < L ? 1.0f / st.y : 0.f;
+        rl[r] = st.x + __builtin_amdgcn_logf(st.y);
         if (MASKS && mask0 && i < L && !mask0[(size_t)z * L + i]) rmask_bits |= 1u << r;
     }
-    unsigned offr[16];                                           // byte offset of (row mfma32_row(r, h), column l31)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) offr[r] = (unsigned)(mfma32_row(r, h) * S + l31) * 4u;
     const bool rows_live = row0 < L;                             // wave-uniform: any valid row in this wave
     const bool rows_full = row0 + 32 <= L;                       // wave-uniform: all 32 rows valid
-    float* const crow = conf + ((size_t)z * L + row0) * S;       // wave-uniform base of this wave's first row
-    // this chunk's column statistics -> LDS (read back with LDS latency in every tile's epilogue)
-    float* const cstat = reinterpret_cast<float*>(lds + 2 * TILE);           // [2][CHUNK_MAX * KT]: max | 1 / sum
-    for (int o = tid; o < (t1 - t0) * KT; o += 256) {
-        cstat[o] = cmax[(size_t)z * Sp + t0 * KT + o];
-        cstat[CHUNK_MAX * KT + o] = cinv[(size_t)z * Sp + t0 * KT + o];
-    }
+    // stores: lane (l31, h) holds, for column j = jt*64 + 32 ct + l31, the rows row0 + (r & 3) + 8 (r >> 2) + 4 h, so one
+    // store instruction (register r of all lanes) writes 32 consecutive floats of two rows: two whole 128-byte lines.
+    // Address = wave-uniform base of row (r & 3) + 8 (r >> 2) [SGPR pair] + this lane's 32-bit byte offset + immediate.
+    unsigned char* const crow = reinterpret_cast<unsigned char*>(conf + ((size_t)z * L + row0) * S);
+    const unsigned lane_off = (unsigned)(4 * h * S + l31) * 4u;
+    const size_t row_bytes = (size_t)S * 4;
+    // this chunk's column terms -> LDS (read back with LDS latency in every tile's epilogue; padded columns: +inf -> p = 0)
+    float* const cstat = reinterpret_cast<float*>(lds + 2 * TILE);           // [CHUNK_MAX * KT]
+    for (int o = tid; o < (t1 - t0) * KT; o += 256)
+        cstat[o] = cmax[(size_t)z * Sp + t0 * KT + o] - __builtin_amdgcn_logf(cinv[(size_t)z * Sp + t0 * KT + o]);
     dma_tile(lds, bh, (size_t)z * Sp + (size_t)t0 * KT, tid, wave);
+    // The stores of a tile are issued one tile LATE (after the next tile's barrier), so that the vmcnt(0) each barrier needs
+    // for the LDS-DMA never waits for stores younger than a whole tile of MFMA work: `hold` carries the tile across.
+    f32x16 hold[2];
+    auto store_tile = [&](int jt) {
+        unsigned char* const tbase = crow + (size_t)jt * KT * 4;
+        if (rows_full && (jt + 1) * KT <= S) {                              // wave-uniform: no per-store predicate
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    *reinterpret_cast<float*>(tbase + (size_t)((r & 3) + 8 * (r >> 2)) * row_bytes + 128 * ct + lane_off) = hold[ct][r];
+        } else if (rows_live) {
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const int j = jt * KT + 32 * ct + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (j < S && row0 + mfma32_row(r, h) < L)
+                        *reinterpret_cast<float*>(tbase + (size_t)((r & 3) + 8 * (r >> 2)) * row_bytes + 128 * ct + lane_off) = hold[ct][r];
+            }
+        }
+    };
     for (int jt = t0; jt < t1; ++jt) {
         unsigned char* cur = lds + ((jt - t0) & 1) * TILE;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's pieces of tile jt (and older stores) done
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // tile jt landed; stores issued a tile ago acknowledged
         __syncthreads();                                         // everyone's pieces landed; the other buffer is free
+        if (jt > t0) store_tile(jt - 1);
         if (jt + 1 < t1) dma_tile(lds + ((jt + 1 - t0) & 1) * TILE, bh, (size_t)z * Sp + (size_t)(jt + 1) * KT, tid, wave);
         f32x16 acc[2];
 #pragma unroll
@@ -124,49 +147,24 @@ __global__ __launch_bounds__(256, 2) void k1_conf(const _Float16* __restrict__ a
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s], bf[s & 1][ct], acc[ct], 0, 0, 0);
         }
-        // column statistics of this lane's two columns, staged in LDS at item start (padded columns: +huge / 0 -> p = 0)
-        float cm[2], ci[2];
-        bool cmasked[2] = {false, false};
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
-            const int o = (jt - t0) * KT + 32 * ct + l31;
-            cm[ct] = cstat[o];
-            ci[ct] = cstat[CHUNK_MAX * KT + o];
+            const float cl = cstat[(jt - t0) * KT + 32 * ct + l31];
+            bool cmasked = false;
             if (MASKS && mask1) {
                 const int j = jt * KT + 32 * ct + l31;
-                cmasked[ct] = j < S && !mask1[(size_t)z * S + j];
+                cmasked = j < S && !mask1[(size_t)z * S + j];
             }
-        }
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float e = fmaf(acc[ct][r], c2, -(rm[r] + cm[ct]));
-                if (MASKS && (((rmask_bits >> r) & 1u) || cmasked[ct])) e = fill2x2 - (rm[r] + cm[ct]);
-                const float p = __builtin_amdgcn_exp2f(e) * (ri[r] * ci[ct]);
-                acc[ct][r] = p;
-            }
-        if (rows_live) {
-            // lane (l31, h) holds, for column j = jt*64 + 32 ct + l31, the rows row0 + (r & 3) + 8 (r >> 2) + 4 h: one store
-            // instruction = register r of all lanes = 32 consecutive floats of two rows (two whole 128-byte lines).
-            // Address = wave-uniform tile base (SGPR pair) + per-lane 32-bit byte offset of (row, l31) + immediate.
-            unsigned char* const tbase = reinterpret_cast<unsigned char*>(crow + jt * KT);   // wave-uniform
-            if (rows_full && (jt + 1) * KT <= S) {                          // wave-uniform: no per-store predicate
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) *reinterpret_cast<float*>(tbase + offr[r] + 128 * ct) = acc[ct][r];
-            } else {
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct) {
-                    const int j = jt * KT + 32 * ct + l31;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (j < S && row0 + mfma32_row(r, h) < L) *reinterpret_cast<float*>(tbase + offr[r] + 128 * ct) = acc[ct][r];
-                }
+                float e = fmaf(acc[ct][r], c2, -(rl[r] + cl));
+                if (MASKS && (((rmask_bits >> r) & 1u) || cmasked)) e = fill2x2 - (rl[r] + cl);
+                hold[ct][r] = __builtin_amdgcn_exp2f(e);
             }
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    store_tile(t1 - 1);
 }
 
 // one thread per listed entry (z * L + i, j, bits of the split-precision log2-domain score x): the fused matcher's
@@ -205,7 +203,7 @@ int far_k1_conf_launch(const _Float16* ah, const _Float16* bh, int Z, int L, int
     int nch = (ntile + 14) / 15;
     const int tpc = (ntile + nch - 1) / nch;                     // <= 15 <= CHUNK_MAX
     nch = (ntile + tpc - 1) / tpc;
-    const size_t smem = 2 * TILE + 2 * CHUNK_MAX * KT * sizeof(float);
+    const size_t smem = 2 * TILE + CHUNK_MAX * KT * sizeof(float);
     FAR_ONCE_PER_DEVICE(
         hipFuncSetAttribute((const void*)k1_conf<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         hipFuncSetAttribute((const void*)k1_conf<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));

@@ -131,8 +131,8 @@ __device__ __forceinline__ void score_tile(f32x16 (&acc)[2], const unsigned char
 // stat[z][i] = (max_j x_ij, sum_j 2^(x_ij - max)) over the Nc real columns; masked pairs count with x = fill2
 // (masked_fill_(-INF), coarse_matching.py:108-111).  Optional dense padded copies dmax / dinv [Z][Nrp] (+huge / 0 past Nr).
 // CAND (second call of the conf_matrix writer, rows = the matrix's COLUMNS j, tile columns = its rows i whose statistics
-// are final): every entry with x >= othr[i] = rowmax_i + log2(rowsum_i) - 12, i.e. softmax_row(i, j) >= 2^-12 (a
-// superset of conf >= 2^-12), is appended to `cand` as (z * Nc + i, j, bits of x): the writer's fix-up evaluates those
+// are final): every entry that can reach conf >= 2^-12 (row term exact, column term bounded from above by the running
+// column statistics) is appended to `cand` as (z * Nc + i, j, bits of x): the writer's fix-up evaluates those
 // from THIS x, the very value the statistics were accumulated from (an independently computed "exact" x would not
 // cancel against them: the fp32 accumulation error of a 256-term dot product is ~1e-5 in the log2 domain).
 template <bool CAND>
@@ -156,6 +156,8 @@ __global__ __launch_bounds__(256, 2) void k1_rowstats(const _Float16* __restrict
     for (int jt = 0; jt < ntile; ++jt) {
         __syncthreads();
         dma_tile(lds, bh, bl, (size_t)z * Ncp + jt * KT, tid, wave);
+        if (CAND && tid < KT)
+            reinterpret_cast<float*>(lds + 2 * TILE_PLANE)[tid] = othr[(size_t)z * Ncp + jt * KT + tid];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         f32x16 acc[2];
@@ -175,35 +177,6 @@ __global__ __launch_bounds__(256, 2) void k1_rowstats(const _Float16* __restrict
                 acc[ct][r] = x;
                 tm = fmaxf(tm, x);
             }
-        if (CAND) {
-            // thresholds of this lane's tile indices i = jt*64 + 32 ct + 8 q + 4 h + (0..3)  (padded: +huge)
-            float hot = -1.f;
-            float th[2][16];
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    const float4 a = *reinterpret_cast<const float4*>(othr + (size_t)z * Ncp + jt * KT + 32 * ct + 8 * q4 + 4 * h);
-                    th[ct][4 * q4 + 0] = a.x; th[ct][4 * q4 + 1] = a.y; th[ct][4 * q4 + 2] = a.z; th[ct][4 * q4 + 3] = a.w;
-                }
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) hot = fmaxf(hot, acc[ct][r] - th[ct][r]);
-            if (__builtin_amdgcn_ballot_w64(hot >= 0.f) != 0ull) {            // rare
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int i = jt * KT + 32 * ct + mfma32_row(r, h);
-                        if (acc[ct][r] >= th[ct][r] && acc[ct][r] > -1.0e8f && i < Nc && irow < Nr) {
-                            const int idx = atomicAdd(cand_count, 1);
-                            if (idx < cand_cap)
-                                cand[idx] = make_uint4((unsigned)(z * Nc + i), (unsigned)irow, __float_as_uint(acc[ct][r]), 0u);
-                        }
-                    }
-            }
-        }
         // The tile's 32 terms are summed on their own and then added to the running sum with Kahan compensation:
         // once the row maximum (a term equal to 1) is in the accumulator, the other terms (~1e-8 each for a
         // confident match) are below half an ulp of it and a plain fp32 running sum would drop them one by one
@@ -222,6 +195,41 @@ __global__ __launch_bounds__(256, 2) void k1_rowstats(const _Float16* __restrict
         comp = (ns - sum) - y;
         sum = ns;
         m = mn;
+        if (CAND) {
+            // log2 conf(i, j) = (x - rowmax_i - log2 rowsum_i) + (x - colmax_j - log2 colsum_j); this lane's running
+            // (m, sum) -- this tile included -- bound the column term from ABOVE (final 2^M Sigma >= running 2^m sum), so
+            //   2 x - (m + log2 sum) >= othr[i] = rowmax_i + log2 rowsum_i - 12
+            // holds for every entry with conf >= 2^-12 (false positives only while the running sum is still small).
+            const float clog = m + __builtin_amdgcn_logf(sum - comp);
+            float hot = -1.f;
+            float th[2][16];
+            const float* tl = reinterpret_cast<const float*>(lds + 2 * TILE_PLANE);      // this tile's 64 thresholds
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const float4 a = *reinterpret_cast<const float4*>(tl + 32 * ct + 8 * q4 + 4 * h);
+                    th[ct][4 * q4 + 0] = a.x + clog; th[ct][4 * q4 + 1] = a.y + clog;
+                    th[ct][4 * q4 + 2] = a.z + clog; th[ct][4 * q4 + 3] = a.w + clog;
+                }
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hot = fmaxf(hot, 2.0f * acc[ct][r] - th[ct][r]);
+            if (__builtin_amdgcn_ballot_w64(hot >= 0.f) != 0ull) {            // rare
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int i = jt * KT + 32 * ct + mfma32_row(r, h);
+                        if (2.0f * acc[ct][r] >= th[ct][r] && acc[ct][r] > -1.0e8f && i < Nc && irow < Nr) {
+                            const int idx = atomicAdd(cand_count, 1);
+                            if (idx < cand_cap)
+                                cand[idx] = make_uint4((unsigned)(z * Nc + i), (unsigned)irow, __float_as_uint(acc[ct][r]), 0u);
+                        }
+                    }
+            }
+        }
     }
     sum -= comp;
     const float mo = shfl_xor_f(m, 32), so = shfl_xor_f(sum, 32);
@@ -391,7 +399,7 @@ int far_coarse_match_f16s(const float* f0, const float* f1, int Z, int L, int S,
     hipLaunchKernelGGL(k1_prep, dim3(gridp((long)Z * Sp * 32)), dim3(256), 0, stream, f1, Z, S, Sp, w.bh, w.bl);
     int* counts = counts_out ? counts_out : w.k.counts;
     hipMemsetAsync(counts, 0, sizeof(int) * Z, stream);
-    const size_t smem_s = 2 * TILE_PLANE, smem_m = 2 * TILE_PLANE + 4 * 64 * sizeof(float);
+    const size_t smem_s = 2 * TILE_PLANE + KT * sizeof(float), smem_m = 2 * TILE_PLANE + 4 * 64 * sizeof(float);
     FAR_ONCE_PER_DEVICE(
         hipFuncSetAttribute((const void*)k1_rowstats<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_s);
         hipFuncSetAttribute((const void*)k1_match<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_m);
@@ -436,7 +444,7 @@ int far_conf_matrix_f16s(const float* f0, const float* f1, int Z, int L, int S, 
         auto gridp = [](long n) { long b = (n + 255) / 256; return (unsigned)(b < 65536L * 4 ? b : 65536L * 4); };
         hipLaunchKernelGGL(k1_prep, dim3(gridp((long)Z * Lp * 32)), dim3(256), 0, stream, f0, Z, L, Lp, w.ah, w.al);
         hipLaunchKernelGGL(k1_prep, dim3(gridp((long)Z * Sp * 32)), dim3(256), 0, stream, f1, Z, S, Sp, w.bh, w.bl);
-        const size_t smem_s = 2 * TILE_PLANE;
+        const size_t smem_s = 2 * TILE_PLANE + KT * sizeof(float);
         FAR_ONCE_PER_DEVICE(
             hipFuncSetAttribute((const void*)k1_rowstats<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_s);
             hipFuncSetAttribute((const void*)k1_rowstats<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_s));
