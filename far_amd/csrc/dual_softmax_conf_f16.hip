@@ -167,6 +167,142 @@ __global__ __launch_bounds__(256, 2) void k1_conf(const _Float16* __restrict__ a
     store_tile(t1 - 1);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k1_conf_wide: the same arithmetic with the operand roles swapped so that a workgroup's stores of one step cover
+// 32 rows x 1 KiB CONTIGUOUS (k1_conf above: 128 rows x 256 B): each wave keeps the fragments of 64 COLUMNS in registers
+// (128 VGPRs) -- the four waves sit side by side, 256 columns -- and 32-row tiles of the other map stream through LDS.
+// HBM pages (1-2 KiB of one matrix row) are then written within one step instead of over eight.
+// Work item = (pair, 256-column block, chunk of row tiles).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int RT = 32;                  // rows per tile
+constexpr int RTILE = RT * ROWB;        // 16 KiB
+constexpr int RCHUNK_MAX = 16;          // row tiles per work item
+
+__device__ __forceinline__ void dma_rows(unsigned char* lds, const _Float16* g, size_t row0, int tid, int wave) {
+    const unsigned char* s = reinterpret_cast<const unsigned char*>(g + row0 * C) + tid * 16;
+#pragma unroll
+    for (int j = 0; j < RTILE / 4096; ++j)
+        __builtin_amdgcn_global_load_lds((gptr_t)(s + j * 4096), (lptr_t)(lds + j * 4096 + wave * 1024), 16, 0, 0);
+}
+
+template <bool MASKS>
+__global__ __launch_bounds__(256, 2) void k1_conf_wide(const _Float16* __restrict__ ah, const _Float16* __restrict__ bh,
+                                                       int Z, int L, int S, int Lp, int Sp, int nJ, int nch, int tiles_per_chunk,
+                                                       float c2, float fill2x2, const uint8_t* __restrict__ mask0,
+                                                       const uint8_t* __restrict__ mask1, const float2* __restrict__ rowstat,
+                                                       const float* __restrict__ cmax, const float* __restrict__ cinv,
+                                                       float* __restrict__ conf) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    int z, item;
+    tile_coords(nJ * nch, Z, z, item);
+    const int Jb = item / nch, ch = item - Jb * nch;
+    const int ntile = (L + RT - 1) / RT;
+    const int t0 = ch * tiles_per_chunk, t1 = min(ntile, t0 + tiles_per_chunk);
+    if (t0 >= t1) return;
+    const int col0 = Jb * 256 + 64 * wave;                       // first column of this wave (may be >= S: dead wave)
+    // B operand: this wave's 64 columns, all 256 channels, in registers (128 VGPRs); lane = (column l31 of subtile ct, k-half h)
+    f16x8 bfr[2][NS];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        const int j = min(col0 + 32 * ct + l31, Sp - 1);
+        const _Float16* p = bh + ((size_t)z * Sp + j) * C;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) bfr[ct][s] = *reinterpret_cast<const f16x8*>(p + 8 * ((2 * s + h) ^ (j & 15)));
+    }
+    // column terms of this lane's two columns (padded / out-of-range columns: +inf -> p = 0, never stored)
+    float cl[2];
+    bool cmasked[2] = {false, false};
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        const int j = col0 + 32 * ct + l31;
+        cl[ct] = j < S ? cmax[(size_t)z * Sp + j] - __builtin_amdgcn_logf(cinv[(size_t)z * Sp + j]) : 1.0e30f;
+        if (MASKS && mask1) cmasked[ct] = j < S && !mask1[(size_t)z * S + j];
+    }
+    const bool cols_live = col0 < S;                              // wave-uniform
+    const bool cols_full = col0 + 64 <= S;                        // wave-uniform
+    // this chunk's row terms -> LDS  (rows >= L: 0, never stored)
+    float* const rstat = reinterpret_cast<float*>(lds + 2 * RTILE);            // [RCHUNK_MAX * RT]
+    for (int o = tid; o < (t1 - t0) * RT; o += 256) {
+        const int i = t0 * RT + o;
+        float v = 0.f;
+        if (i < L) { const float2 st = rowstat[(size_t)z * L + i]; v = st.x + __builtin_amdgcn_logf(st.y); }
+        rstat[o] = v;
+    }
+    unsigned char* const cbase = reinterpret_cast<unsigned char*>(conf + (size_t)z * L * S + col0);   // wave-uniform
+    const unsigned lane_off = (unsigned)(4 * h * S + l31) * 4u;
+    const size_t row_bytes = (size_t)S * 4;
+    dma_rows(lds, ah, (size_t)z * Lp + (size_t)t0 * RT, tid, wave);
+    f32x16 hold[2];
+    auto store_tile = [&](int it) {
+        unsigned char* const tbase = cbase + (size_t)it * RT * row_bytes;
+        const int i0 = it * RT;
+        if (cols_full && i0 + RT <= L) {
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    *reinterpret_cast<float*>(tbase + (size_t)((r & 3) + 8 * (r >> 2)) * row_bytes + 128 * ct + lane_off) = hold[ct][r];
+        } else if (cols_live) {
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const int j = col0 + 32 * ct + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (j < S && i0 + mfma32_row(r, h) < L)
+                        *reinterpret_cast<float*>(tbase + (size_t)((r & 3) + 8 * (r >> 2)) * row_bytes + 128 * ct + lane_off) = hold[ct][r];
+            }
+        }
+    };
+    for (int it = t0; it < t1; ++it) {
+        const unsigned char* cur = lds + ((it - t0) & 1) * RTILE;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (it > t0) store_tile(it - 1);
+        if (it + 1 < t1) dma_rows(lds + ((it + 1 - t0) & 1) * RTILE, ah, (size_t)z * Lp + (size_t)(it + 1) * RT, tid, wave);
+        f32x16 acc[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+        // A fragments (row l31 of the tile) one k-step ahead of the MFMAs that consume them
+        const unsigned char* arow = cur + l31 * ROWB;
+        f16x8 af[2];
+        af[0] = *reinterpret_cast<const f16x8*>(arow + ((h ^ (l31 & 15)) * 16));
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (s + 1 < NS) af[(s + 1) & 1] = *reinterpret_cast<const f16x8*>(arow + (((2 * (s + 1) + h) ^ (l31 & 15)) * 16));
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s & 1], bfr[ct][s], acc[ct], 0, 0, 0);
+        }
+        // row terms of this lane's 16 rows: i = it*32 + (r & 3) + 8 (r >> 2) + 4 h  ->  four 16-byte LDS reads
+        float rl[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 a = *reinterpret_cast<const float4*>(rstat + (it - t0) * RT + 8 * q + 4 * h);
+            rl[4 * q + 0] = a.x; rl[4 * q + 1] = a.y; rl[4 * q + 2] = a.z; rl[4 * q + 3] = a.w;
+        }
+        unsigned rmask_bits = 0;
+        if (MASKS && mask0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = it * RT + mfma32_row(r, h);
+                if (i < L && !mask0[(size_t)z * L + i]) rmask_bits |= 1u << r;
+            }
+        }
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float e = fmaf(acc[ct][r], c2, -(rl[r] + cl[ct]));
+                if (MASKS && (((rmask_bits >> r) & 1u) || cmasked[ct])) e = fill2x2 - (rl[r] + cl[ct]);
+                hold[ct][r] = __builtin_amdgcn_exp2f(e);
+            }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    store_tile(t1 - 1);
+}
+
 // one thread per listed entry (z * L + i, j, bits of the split-precision log2-domain score x): the fused matcher's
 // formula (dual_softmax_f16s.hip:k1_match), bit for bit
 __global__ __launch_bounds__(256) void k1_conf_fix(int L, int S, int Sp, const float2* __restrict__ rowstat,
@@ -197,23 +333,40 @@ int far_k1_conf_launch(const _Float16* ah, const _Float16* bh, int Z, int L, int
                        const float* cinv, float* conf, const int* fix_count, const uint4* fix_list, int fix_cap,
                        int* fix_info_out, hipStream_t stream) {
     using namespace far_conf;
-    const int nI = Lp / 128;
-    const int ntile = (S + KT - 1) / KT;
-    // ~12 rounds of the chip's 512 resident workgroups: chunks of ~15 column tiles
-    int nch = (ntile + 14) / 15;
-    const int tpc = (ntile + nch - 1) / nch;                     // <= 15 <= CHUNK_MAX
-    nch = (ntile + tpc - 1) / tpc;
-    const size_t smem = 2 * TILE + CHUNK_MAX * KT * sizeof(float);
-    FAR_ONCE_PER_DEVICE(
-        hipFuncSetAttribute((const void*)k1_conf<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipFuncSetAttribute((const void*)k1_conf<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    const dim3 grid((unsigned)(Z * nI * nch));
-    if (mask0 || mask1)
-        hipLaunchKernelGGL(k1_conf<true>, grid, dim3(256), smem, stream, ah, bh, Z, L, S, Lp, Sp, nI, nch, tpc, 2.0f * c1,
-                           2.0f * fill2, mask0, mask1, rowstat, cmax, cinv, conf);
-    else
-        hipLaunchKernelGGL(k1_conf<false>, grid, dim3(256), smem, stream, ah, bh, Z, L, S, Lp, Sp, nI, nch, tpc, 2.0f * c1,
-                           2.0f * fill2, mask0, mask1, rowstat, cmax, cinv, conf);
+    const float c2 = 2.0f * c1, f2 = 2.0f * fill2;
+    if (far_get_tuning(2) == 1) {          // A/B experiment: the tall-tile writer (128 rows x 64 columns per step)
+        const int nI = Lp / 128;
+        const int ntile = (S + KT - 1) / KT;
+        int nch = (ntile + 14) / 15;
+        const int tpc = (ntile + nch - 1) / nch;                     // <= 15 <= CHUNK_MAX
+        nch = (ntile + tpc - 1) / tpc;
+        const size_t smem = 2 * TILE + CHUNK_MAX * KT * sizeof(float);
+        FAR_ONCE_PER_DEVICE(
+            hipFuncSetAttribute((const void*)k1_conf<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            hipFuncSetAttribute((const void*)k1_conf<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        const dim3 grid((unsigned)(Z * nI * nch));
+        if (mask0 || mask1)
+            hipLaunchKernelGGL(k1_conf<true>, grid, dim3(256), smem, stream, ah, bh, Z, L, S, Lp, Sp, nI, nch, tpc, c2, f2, mask0,
+                               mask1, rowstat, cmax, cinv, conf);
+        else
+            hipLaunchKernelGGL(k1_conf<false>, grid, dim3(256), smem, stream, ah, bh, Z, L, S, Lp, Sp, nI, nch, tpc, c2, f2, mask0,
+                               mask1, rowstat, cmax, cinv, conf);
+    } else {
+        // work item = (pair, 256-column block, chunk of <= 15 row tiles): ~12 rounds of the chip's 512 resident workgroups
+        const int nJ = (S + 255) / 256;
+        const int ntile = (L + RT - 1) / RT;
+        int nch = (ntile + 14) / 15;
+        const int tpc = (ntile + nch - 1) / nch;                     // <= 15 <= RCHUNK_MAX
+        nch = (ntile + tpc - 1) / tpc;
+        const size_t smem = 2 * RTILE + RCHUNK_MAX * RT * sizeof(float);
+        const dim3 grid((unsigned)(Z * nJ * nch));
+        if (mask0 || mask1)
+            hipLaunchKernelGGL(k1_conf_wide<true>, grid, dim3(256), smem, stream, ah, bh, Z, L, S, Lp, Sp, nJ, nch, tpc, c2, f2,
+                               mask0, mask1, rowstat, cmax, cinv, conf);
+        else
+            hipLaunchKernelGGL(k1_conf_wide<false>, grid, dim3(256), smem, stream, ah, bh, Z, L, S, Lp, Sp, nJ, nch, tpc, c2, f2,
+                               mask0, mask1, rowstat, cmax, cinv, conf);
+    }
     hipLaunchKernelGGL(k1_conf_fix, dim3(512), dim3(256), 0, stream, L, S, Sp, rowstat, cmax, cinv, conf, fix_count, fix_list,
                        fix_cap, fix_info_out);
     return far_check_launch();

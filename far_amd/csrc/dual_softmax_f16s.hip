@@ -202,30 +202,27 @@ __global__ __launch_bounds__(256, 2) void k1_rowstats(const _Float16* __restrict
             // holds for every entry with conf >= 2^-12 (false positives only while the running sum is still small).
             const float clog = m + __builtin_amdgcn_logf(sum - comp);
             float hot = -1.f;
-            float th[2][16];
             const float* tl = reinterpret_cast<const float*>(lds + 2 * TILE_PLANE);      // this tile's 64 thresholds
+            // streamed (no 32-register threshold array: the kernel sits at the 256-VGPR limit with its row fragments)
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) {
                     const float4 a = *reinterpret_cast<const float4*>(tl + 32 * ct + 8 * q4 + 4 * h);
-                    th[ct][4 * q4 + 0] = a.x + clog; th[ct][4 * q4 + 1] = a.y + clog;
-                    th[ct][4 * q4 + 2] = a.z + clog; th[ct][4 * q4 + 3] = a.w + clog;
+                    hot = fmaxf(hot, fmaxf(fmaxf(2.0f * acc[ct][4 * q4 + 0] - a.x, 2.0f * acc[ct][4 * q4 + 1] - a.y),
+                                           fmaxf(2.0f * acc[ct][4 * q4 + 2] - a.z, 2.0f * acc[ct][4 * q4 + 3] - a.w)));
                 }
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) hot = fmaxf(hot, 2.0f * acc[ct][r] - th[ct][r]);
-            if (__builtin_amdgcn_ballot_w64(hot >= 0.f) != 0ull) {            // rare
-#pragma unroll
+            if (__builtin_amdgcn_ballot_w64(hot >= clog) != 0ull) {           // rare
+#pragma unroll 1
                 for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int i = jt * KT + 32 * ct + mfma32_row(r, h);
-                        if (2.0f * acc[ct][r] >= th[ct][r] && acc[ct][r] > -1.0e8f && i < Nc && irow < Nr) {
+                        const float xv = ct == 0 ? acc[0][r] : acc[1][r];
+                        if (2.0f * xv >= tl[32 * ct + mfma32_row(r, h)] + clog && xv > -1.0e8f && i < Nc && irow < Nr) {
                             const int idx = atomicAdd(cand_count, 1);
                             if (idx < cand_cap)
-                                cand[idx] = make_uint4((unsigned)(z * Nc + i), (unsigned)irow, __float_as_uint(acc[ct][r]), 0u);
+                                cand[idx] = make_uint4((unsigned)(z * Nc + i), (unsigned)irow, __float_as_uint(xv), 0u);
                         }
                     }
             }

@@ -25,9 +25,15 @@ if which in ('k1w', 'all'):
     f0 = 1.2 * torch.randn(n, L, 256, device=dev, generator=g)
     f1 = f0[:, torch.randperm(L, device=dev, generator=g)] + 0.1 * torch.randn(n, L, 256, device=dev, generator=g)
     conf = torch.empty(n, L, L, device=dev)
-    for _ in range(it):
-        c, listed = ops.conf_matrix(f0, f1, 0.1, out=conf)
-    print('k1w: listed', listed, 'entries =', listed / (n * L), 'per row')
+    lib = _lib.load()
+    for variant in (0, 1):                      # 0 = wide-tile writer (default), 1 = tall-tile writer
+        lib.far_set_tuning(2, variant)
+        for _ in range(it):
+            c, listed = ops.conf_matrix(f0, f1, 0.1, out=conf)
+        ref = ops.coarse_match(f0[:2], f1[:2], 0.1, 0.2, 2, (60, 80), (60, 80), 8.0, want_conf=True, variant='f16s')['conf_matrix']
+        print('k1w variant', variant, ': listed', listed, 'entries =', listed / (n * L), 'per row; max dev vs fused writer',
+              float((c[:2] - ref).abs().max()))
+    lib.far_set_tuning(2, 0)
     del conf
 if which in ('k1b',):
     f0 = 1.2 * torch.randn(n, L, 256, device=dev, generator=g)
