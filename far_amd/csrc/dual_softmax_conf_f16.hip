@@ -178,11 +178,31 @@ constexpr int RT = 32;                  // rows per tile
 constexpr int RTILE = RT * ROWB;        // 16 KiB
 constexpr int RCHUNK_MAX = 16;          // row tiles per work item
 
+// LDS-DMA written as inline asm ON PURPOSE: hipcc does not see these requests, so it neither counts them nor guards the
+// ds_reads of the tile with its own wait.  With the builtin it must assume that a ds_read may alias ANY pending LDS-DMA
+// -- including the one just issued for the other buffer -- and emits s_waitcnt vmcnt(0) in front of the first MFMA,
+// draining the stores this pipeline wants in flight.  Completion is counted by hand (vmcnt, see the loop), visibility to
+// the other waves by the barrier.  M0 (the LDS base of the request) is saved and restored inside the statement
+// (cdna_hip_programming.md section 5.7).
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst_uniform) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
+}
+
+// The stores too: hipcc keeps a store's DATA registers reserved until vmcnt says the store has completed, i.e. it puts
+// s_waitcnt vmcnt(31) ... vmcnt(0) in front of the MFMAs / ds_reads that reuse them -- again draining what should stay in
+// flight.  The hardware has read a dword store's data by the time the next instruction issues (only 96/128-bit stores
+// need wait states, cdna_hip_programming.md section 5.7), so the stores are written as asm and counted by hand.
+__device__ __forceinline__ void gstore32(void* addr, float v) {
+    asm volatile("global_store_dword %0, %1, off" : : "v"(addr), "v"(v) : "memory");
+}
+
 __device__ __forceinline__ void dma_rows(unsigned char* lds, const _Float16* g, size_t row0, int tid, int wave) {
     const unsigned char* s = reinterpret_cast<const unsigned char*>(g + row0 * C) + tid * 16;
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t)(lds + wave * 1024));
 #pragma unroll
-    for (int j = 0; j < RTILE / 4096; ++j)
-        __builtin_amdgcn_global_load_lds((gptr_t)(s + j * 4096), (lptr_t)(lds + j * 4096 + wave * 1024), 16, 0, 0);
+    for (int j = 0; j < RTILE / 4096; ++j) glds16(s + j * 4096, dst + j * 4096);
 }
 
 template <bool MASKS>
@@ -232,6 +252,16 @@ __global__ __launch_bounds__(256, 2) void k1_conf_wide(const _Float16* __restric
     unsigned char* const cbase = reinterpret_cast<unsigned char*>(conf + (size_t)z * L * S + col0);   // wave-uniform
     const unsigned lane_off = (unsigned)(4 * h * S + l31) * 4u;
     const size_t row_bytes = (size_t)S * 4;
+    // Everything loaded so far is made "arrived" HERE as far as hipcc's wait bookkeeping goes (an empty asm that uses the
+    // registers): otherwise it carries the 32 fragment loads as pending into the loop and re-executes their lazy waits
+    // (s_waitcnt vmcnt(31), (15), (14) ... (0) in front of the MFMAs that first use each fragment) in EVERY iteration,
+    // where they would drain the stores in flight.
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) asm volatile("" : "+v"(bfr[ct][s]));
+        asm volatile("" : "+v"(cl[ct]));
+    }
     dma_rows(lds, ah, (size_t)z * Lp + (size_t)t0 * RT, tid, wave);
     f32x16 hold[2];
     auto store_tile = [&](int it) {
@@ -242,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void k1_conf_wide(const _Float16* __restric
             for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    *reinterpret_cast<float*>(tbase + (size_t)((r & 3) + 8 * (r >> 2)) * row_bytes + 128 * ct + lane_off) = hold[ct][r];
+                    gstore32(tbase + (size_t)((r & 3) + 8 * (r >> 2)) * row_bytes + 128 * ct + lane_off, hold[ct][r]);
         } else if (cols_live) {
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
@@ -250,16 +280,28 @@ __global__ __launch_bounds__(256, 2) void k1_conf_wide(const _Float16* __restric
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     if (j < S && i0 + mfma32_row(r, h) < L)
-                        *reinterpret_cast<float*>(tbase + (size_t)((r & 3) + 8 * (r >> 2)) * row_bytes + 128 * ct + lane_off) = hold[ct][r];
+                        gstore32(tbase + (size_t)((r & 3) + 8 * (r >> 2)) * row_bytes + 128 * ct + lane_off, hold[ct][r]);
             }
         }
     };
+    // Pipeline per 32-row tile:   wait -> barrier -> request tile it+1 (LDS-DMA) -> STORE tile it-1 -> MFMAs + exp of tile it.
+    // vmcnt retires in issue order, and the stores of tile it-1 are issued AFTER the DMA requests of tile it+1, so the
+    // wait at the top of the next iteration is vmcnt(32): "everything but my 32 youngest operations" = the tile has
+    // landed, while the 32 stores stay in flight for another whole tile (two tiles of stores per wave in flight keep
+    // ~128 KiB per CU outstanding: at the write-acknowledge latency of a saturated HBM that is what ~6 TB/s needs; with
+    // vmcnt(0) here -- every store acknowledged before the next barrier -- the same kernel ran at 4.1 TB/s).
+    bool counted = false;                                          // wave-uniform: the last store_tile issued exactly 32 stores
     for (int it = t0; it < t1; ++it) {
         const unsigned char* cur = lds + ((it - t0) & 1) * RTILE;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (it > t0) store_tile(it - 1);
+        if (counted) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                              // everyone's pieces landed; the other buffer is free
         if (it + 1 < t1) dma_rows(lds + ((it + 1 - t0) & 1) * RTILE, ah, (size_t)z * Lp + (size_t)(it + 1) * RT, tid, wave);
+        counted = false;
+        if (it > t0) {
+            store_tile(it - 1);
+            counted = cols_full && (it - 1) * RT + RT <= L;        // the unpredicated path: 32 store instructions
+        }
         f32x16 acc[2];
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
