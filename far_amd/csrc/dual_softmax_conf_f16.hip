@@ -177,6 +177,7 @@ __global__ __launch_bounds__(256, 2) void k1_conf(const _Float16* __restrict__ a
 constexpr int RT = 32;                  // rows per tile
 constexpr int RTILE = RT * ROWB;        // 16 KiB
 constexpr int RCHUNK_MAX = 16;          // row tiles per work item
+constexpr int RING = 4;                 // LDS slots of 32-row tiles (requests run three tiles ahead)
 
 // LDS-DMA written as inline asm ON PURPOSE: hipcc does not see these requests, so it neither counts them nor guards the
 // ds_reads of the tile with its own wait.  With the builtin it must assume that a ds_read may alias ANY pending LDS-DMA
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(256, 2) void k1_conf_wide(const _Float16* __restric
     const bool cols_live = col0 < S;                              // wave-uniform
     const bool cols_full = col0 + 64 <= S;                        // wave-uniform
     // this chunk's row terms -> LDS  (rows >= L: 0, never stored)
-    float* const rstat = reinterpret_cast<float*>(lds + 2 * RTILE);            // [RCHUNK_MAX * RT]
+    float* const rstat = reinterpret_cast<float*>(lds + RING * RTILE);         // [RCHUNK_MAX * RT]
     for (int o = tid; o < (t1 - t0) * RT; o += 256) {
         const int i = t0 * RT + o;
         float v = 0.f;
@@ -262,7 +263,20 @@ __global__ __launch_bounds__(256, 2) void k1_conf_wide(const _Float16* __restric
         for (int s = 0; s < NS; ++s) asm volatile("" : "+v"(bfr[ct][s]));
         asm volatile("" : "+v"(cl[ct]));
     }
-    dma_rows(lds, ah, (size_t)z * Lp + (size_t)t0 * RT, tid, wave);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // (the rowstat loads feeding rstat: really arrived)
+    // Pipeline per 32-row tile, ring of RING = 4 LDS slots:
+    //     wait -> barrier -> request tile it+3 (4 LDS-DMA ops) -> STORE tile it-1 (32 ops) -> MFMAs + exp of tile it.
+    // vmcnt retires in issue order.  At the top of iteration `it` the operations issued after the requests of tile `it`
+    // are: [stores it-4] req it+1, stores it-3, req it+2, stores it-2  (>= 63 from the fourth iteration on), so
+    // s_waitcnt vmcnt(63) -- "all but my 63 youngest operations" -- guarantees that tile `it` has landed while the stores
+    // of the last two tiles stay in flight, and the tile requests have three iterations (~10 us) to come back through a
+    // fabric saturated with writes (with a one-tile lookahead and vmcnt(0) the same kernel ran at 4.1 TB/s; the store
+    // pattern alone sustains 5.5 TB/s, tools/ubench/store_pattern.hip).  Waves whose store bursts are predicated (edge
+    // columns / the last, partial row tile) issue an unknown number of stores and simply wait for vmcnt(0).
+    const bool exact_counts = cols_full && t1 * RT <= L;            // wave-uniform
+#pragma unroll
+    for (int k = 0; k < RING - 1; ++k)
+        if (t0 + k < t1) dma_rows(lds + k * RTILE, ah, (size_t)z * Lp + (size_t)(t0 + k) * RT, tid, wave);
     f32x16 hold[2];
     auto store_tile = [&](int it) {
         unsigned char* const tbase = cbase + (size_t)it * RT * row_bytes;
@@ -284,24 +298,27 @@ __global__ __launch_bounds__(256, 2) void k1_conf_wide(const _Float16* __restric
             }
         }
     };
-    // Pipeline per 32-row tile:   wait -> barrier -> request tile it+1 (LDS-DMA) -> STORE tile it-1 -> MFMAs + exp of tile it.
-    // vmcnt retires in issue order, and the stores of tile it-1 are issued AFTER the DMA requests of tile it+1, so the
-    // wait at the top of the next iteration is vmcnt(32): "everything but my 32 youngest operations" = the tile has
-    // landed, while the 32 stores stay in flight for another whole tile (two tiles of stores per wave in flight keep
-    // ~128 KiB per CU outstanding: at the write-acknowledge latency of a saturated HBM that is what ~6 TB/s needs; with
-    // vmcnt(0) here -- every store acknowledged before the next barrier -- the same kernel ran at 4.1 TB/s).
-    bool counted = false;                                          // wave-uniform: the last store_tile issued exactly 32 stores
     for (int it = t0; it < t1; ++it) {
-        const unsigned char* cur = lds + ((it - t0) & 1) * RTILE;
-        if (counted) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                              // everyone's pieces landed; the other buffer is free
-        if (it + 1 < t1) dma_rows(lds + ((it + 1 - t0) & 1) * RTILE, ah, (size_t)z * Lp + (size_t)(it + 1) * RT, tid, wave);
-        counted = false;
-        if (it > t0) {
-            store_tile(it - 1);
-            counted = cols_full && (it - 1) * RT + RT <= L;        // the unpredicated path: 32 store instructions
+        const int k = it - t0;
+        const unsigned char* cur = lds + (k & (RING - 1)) * RTILE;
+        // `need` = operations this wave issued after the requests of tile it: 4 per later tile request (tiles k+1 .. k+2 that
+        // exist) + 32 per store burst (issued in the iterations between that request and now); any immediate <= need is safe
+        int need = 0;
+        if (exact_counts) {
+            const int n = t1 - t0;
+            const int later = min(k + RING - 2, n - 1) - k;
+            const int bursts = k >= RING - 1 ? (k - 1) - max(k - (RING - 1), 1) + 1 : max(k - 1, 0);
+            need = 4 * later + 32 * bursts;
         }
+        if (need >= 63) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+        else if (need >= 40) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+        else if (need >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (need >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                              // everyone's pieces landed; slot (k + 3) % 4 is free
+        if (it + RING - 1 < t1)
+            dma_rows(lds + ((k + RING - 1) & (RING - 1)) * RTILE, ah, (size_t)z * Lp + (size_t)(it + RING - 1) * RT, tid, wave);
+        if (it > t0) store_tile(it - 1);
         f32x16 acc[2];
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
@@ -400,7 +417,7 @@ int far_k1_conf_launch(const _Float16* ah, const _Float16* bh, int Z, int L, int
         int nch = (ntile + 14) / 15;
         const int tpc = (ntile + nch - 1) / nch;                     // <= 15 <= RCHUNK_MAX
         nch = (ntile + tpc - 1) / tpc;
-        const size_t smem = 2 * RTILE + RCHUNK_MAX * RT * sizeof(float);
+        const size_t smem = RING * RTILE + RCHUNK_MAX * RT * sizeof(float);
         const dim3 grid((unsigned)(Z * nJ * nch));
         if (mask0 || mask1)
             hipLaunchKernelGGL(k1_conf_wide<true>, grid, dim3(256), smem, stream, ah, bh, Z, L, S, Lp, Sp, nJ, nch, tpc, c2, f2,
