@@ -198,6 +198,12 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst_unifor
 __device__ __forceinline__ void gstore32(void* addr, float v) {
     asm volatile("global_store_dword %0, %1, off" : : "v"(addr), "v"(v) : "memory");
 }
+// saddr form: address = wave-uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset + immediate.  No VALU address
+// arithmetic per store (three 64-bit vector adds per store were the largest non-matrix cost of the writer's loop).
+template <int IMM>
+__device__ __forceinline__ void gstore32_s(const void* sbase_uniform, unsigned voff, float v) {
+    asm volatile("global_store_dword %0, %1, %2 offset:%3" : : "v"(voff), "v"(v), "s"(sbase_uniform), "n"(IMM) : "memory");
+}
 
 __device__ __forceinline__ void dma_rows(unsigned char* lds, const _Float16* g, size_t row0, int tid, int wave) {
     const unsigned char* s = reinterpret_cast<const unsigned char*>(g + row0 * C) + tid * 16;
@@ -250,7 +256,10 @@ __global__ __launch_bounds__(256, 2) void k1_conf_wide(const _Float16* __restric
         if (i < L) { const float2 st = rowstat[(size_t)z * L + i]; v = st.x + __builtin_amdgcn_logf(st.y); }
         rstat[o] = v;
     }
-    unsigned char* const cbase = reinterpret_cast<unsigned char*>(conf + (size_t)z * L * S + col0);   // wave-uniform
+    // wave-uniform base of this wave's first column (readfirstlane: `wave` = tid >> 6 is not provably uniform to hipcc)
+    const unsigned long long cb = reinterpret_cast<unsigned long long>(conf + (size_t)z * L * S + col0);
+    unsigned char* const cbase = reinterpret_cast<unsigned char*>(
+        ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(cb >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)cb));
     const unsigned lane_off = (unsigned)(4 * h * S + l31) * 4u;
     const size_t row_bytes = (size_t)S * 4;
     // Everything loaded so far is made "arrived" HERE as far as hipcc's wait bookkeeping goes (an empty asm that uses the
@@ -283,10 +292,11 @@ __global__ __launch_bounds__(256, 2) void k1_conf_wide(const _Float16* __restric
         const int i0 = it * RT;
         if (cols_full && i0 + RT <= L) {
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    gstore32(tbase + (size_t)((r & 3) + 8 * (r >> 2)) * row_bytes + 128 * ct + lane_off, hold[ct][r]);
+            for (int r = 0; r < 16; ++r) {
+                const unsigned char* rb = tbase + (size_t)((r & 3) + 8 * (r >> 2)) * row_bytes;      // wave-uniform (SALU)
+                gstore32_s<0>(rb, lane_off, hold[0][r]);
+                gstore32_s<128>(rb, lane_off, hold[1][r]);
+            }
         } else if (cols_live) {
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
