@@ -200,9 +200,14 @@ __device__ __forceinline__ void gstore32(void* addr, float v) {
 }
 // saddr form: address = wave-uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset + immediate.  No VALU address
 // arithmetic per store (three 64-bit vector adds per store were the largest non-matrix cost of the writer's loop).
-template <int IMM>
+// NOP5: five wait states in front (an SALU write of the base SGPRs may sit directly before the statement; hipcc pads
+// nothing inside asm, and a VMEM instruction reading a just-written SGPR base is a hazard that hung the GPU here).
+template <int IMM, bool NOP5 = false>
 __device__ __forceinline__ void gstore32_s(const void* sbase_uniform, unsigned voff, float v) {
-    asm volatile("global_store_dword %0, %1, %2 offset:%3" : : "v"(voff), "v"(v), "s"(sbase_uniform), "n"(IMM) : "memory");
+    if (NOP5)
+        asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2 offset:%3" : : "v"(voff), "v"(v), "s"(sbase_uniform), "n"(IMM) : "memory");
+    else
+        asm volatile("global_store_dword %0, %1, %2 offset:%3" : : "v"(voff), "v"(v), "s"(sbase_uniform), "n"(IMM) : "memory");
 }
 
 __device__ __forceinline__ void dma_rows(unsigned char* lds, const _Float16* g, size_t row0, int tid, int wave) {
@@ -262,6 +267,9 @@ __global__ __launch_bounds__(256, 2) void k1_conf_wide(const _Float16* __restric
         ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(cb >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)cb));
     const unsigned lane_off = (unsigned)(4 * h * S + l31) * 4u;
     const size_t row_bytes = (size_t)S * 4;
+    unsigned offr[16];                                            // byte offset of (row mfma32_row(r, h), column l31) in a tile
+#pragma unroll
+    for (int r = 0; r < 16; ++r) offr[r] = (unsigned)(mfma32_row(r, h) * S + l31) * 4u;
     // Everything loaded so far is made "arrived" HERE as far as hipcc's wait bookkeeping goes (an empty asm that uses the
     // registers): otherwise it carries the 32 fragment loads as pending into the loop and re-executes their lazy waits
     // (s_waitcnt vmcnt(31), (15), (14) ... (0) in front of the MFMAs that first use each fragment) in EVERY iteration,
@@ -272,6 +280,8 @@ __global__ __launch_bounds__(256, 2) void k1_conf_wide(const _Float16* __restric
         for (int s = 0; s < NS; ++s) asm volatile("" : "+v"(bfr[ct][s]));
         asm volatile("" : "+v"(cl[ct]));
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(offr[r]));   // keep them in registers (not rematerialised per tile)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // (the rowstat loads feeding rstat: really arrived)
     // Pipeline per 32-row tile, ring of RING = 4 LDS slots:
     //     wait -> barrier -> request tile it+3 (4 LDS-DMA ops) -> STORE tile it-1 (32 ops) -> MFMAs + exp of tile it.
@@ -286,25 +296,30 @@ __global__ __launch_bounds__(256, 2) void k1_conf_wide(const _Float16* __restric
 #pragma unroll
     for (int k = 0; k < RING - 1; ++k)
         if (t0 + k < t1) dma_rows(lds + k * RTILE, ah, (size_t)z * Lp + (size_t)(t0 + k) * RT, tid, wave);
-    f32x16 hold[2];
+    // one register set serves as MFMA accumulator AND as the tile kept for the late stores: the stores of tile it-1 are
+    // issued before the first MFMA of tile it (which starts from C = 0) overwrites it
+    f32x16 acc[2];
     auto store_tile = [&](int it) {
         unsigned char* const tbase = cbase + (size_t)it * RT * row_bytes;
         const int i0 = it * RT;
         if (cols_full && i0 + RT <= L) {
+            // ONE scalar base per tile (written many instructions before its first use: an SALU write directly in front of
+            // a VMEM instruction that reads the SGPR as its base is a hazard hipcc does not pad inside asm -- a per-row
+            // s_add in front of each store hung the GPU), the row in the per-lane offset register offr[r], the column
+            // half in the immediate.
+            gstore32_s<0, true>(tbase, offr[0], acc[0][0]);
+            gstore32_s<128>(tbase, offr[0], acc[1][0]);
+#pragma unroll
+            for (int r = 1; r < 16; ++r) {
+                gstore32_s<0>(tbase, offr[r], acc[0][r]);
+                gstore32_s<128>(tbase, offr[r], acc[1][r]);
+            }
+        } else if (cols_live) {                                     // edge tiles: the same stores, predicated per lane
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const unsigned char* rb = tbase + (size_t)((r & 3) + 8 * (r >> 2)) * row_bytes;      // wave-uniform (SALU)
-                gstore32_s<0>(rb, lane_off, hold[0][r]);
-                gstore32_s<128>(rb, lane_off, hold[1][r]);
-            }
-        } else if (cols_live) {
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) {
-                const int j = col0 + 32 * ct + l31;
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (j < S && i0 + mfma32_row(r, h) < L)
-                        gstore32(tbase + (size_t)((r & 3) + 8 * (r >> 2)) * row_bytes + 128 * ct + lane_off, hold[ct][r]);
+                const bool rok = i0 + mfma32_row(r, h) < L;
+                if (rok && col0 + l31 < S) gstore32_s<0, true>(tbase, offr[r], acc[0][r]);
+                if (rok && col0 + 32 + l31 < S) gstore32_s<128, true>(tbase, offr[r], acc[1][r]);
             }
         }
     };
@@ -329,7 +344,6 @@ __global__ __launch_bounds__(256, 2) void k1_conf_wide(const _Float16* __restric
         if (it + RING - 1 < t1)
             dma_rows(lds + ((k + RING - 1) & (RING - 1)) * RTILE, ah, (size_t)z * Lp + (size_t)(it + RING - 1) * RT, tid, wave);
         if (it > t0) store_tile(it - 1);
-        f32x16 acc[2];
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -365,7 +379,7 @@ __global__ __launch_bounds__(256, 2) void k1_conf_wide(const _Float16* __restric
             for (int r = 0; r < 16; ++r) {
                 float e = fmaf(acc[ct][r], c2, -(rl[r] + cl[ct]));
                 if (MASKS && (((rmask_bits >> r) & 1u) || cmasked[ct])) e = fill2x2 - (rl[r] + cl[ct]);
-                hold[ct][r] = __builtin_amdgcn_exp2f(e);
+                acc[ct][r] = __builtin_amdgcn_exp2f(e);
             }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
