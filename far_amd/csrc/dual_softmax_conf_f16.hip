@@ -212,7 +212,7 @@ __device__ __forceinline__ void gstore32_s(const void* sbase_uniform, unsigned v
 
 __device__ __forceinline__ void dma_rows(unsigned char* lds, const _Float16* g, size_t row0, int tid, int wave) {
     const unsigned char* s = reinterpret_cast<const unsigned char*>(g + row0 * C) + tid * 16;
-    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t)(lds + wave * 1024));
+    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(lptr_t)(lds + wave * 1024));
 #pragma unroll
     for (int j = 0; j < RTILE / 4096; ++j) glds16(s + j * 4096, dst + j * 4096);
 }
@@ -264,7 +264,8 @@ __global__ __launch_bounds__(256, 2) void k1_conf_wide(const _Float16* __restric
     // wave-uniform base of this wave's first column (readfirstlane: `wave` = tid >> 6 is not provably uniform to hipcc)
     const unsigned long long cb = reinterpret_cast<unsigned long long>(conf + (size_t)z * L * S + col0);
     unsigned char* const cbase = reinterpret_cast<unsigned char*>(
-        ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(cb >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)cb));
+        ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(cb >> 32)) << 32) |
+        (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)cb));     // (the builtin returns a signed int)
     const unsigned lane_off = (unsigned)(4 * h * S + l31) * 4u;
     const size_t row_bytes = (size_t)S * 4;
     unsigned offr[16];                                            // byte offset of (row mfma32_row(r, h), column l31) in a tile
