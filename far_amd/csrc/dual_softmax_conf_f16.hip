@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void k1_conf(const _Float16* __restrict__ a
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int RT = 32;                  // rows per tile
 constexpr int RTILE = RT * ROWB;        // 16 KiB
-constexpr int RCHUNK_MAX = 16;          // row tiles per work item
+constexpr int RCHUNK_MAX = 32;          // row tiles per work item
 constexpr int RING = 4;                 // LDS slots of 32-row tiles (requests run three tiles ahead)
 
 // LDS-DMA written as inline asm ON PURPOSE: hipcc does not see these requests, so it neither counts them nor guards the
@@ -205,9 +205,9 @@ __device__ __forceinline__ void gstore32(void* addr, float v) {
 template <int IMM, bool NOP5 = false>
 __device__ __forceinline__ void gstore32_s(const void* sbase_uniform, unsigned voff, float v) {
     if (NOP5)
-        asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2 offset:%3" : : "v"(voff), "v"(v), "s"(sbase_uniform), "n"(IMM) : "memory");
+        asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2 offset:%3 nt" : : "v"(voff), "v"(v), "s"(sbase_uniform), "n"(IMM) : "memory");
     else
-        asm volatile("global_store_dword %0, %1, %2 offset:%3" : : "v"(voff), "v"(v), "s"(sbase_uniform), "n"(IMM) : "memory");
+        asm volatile("global_store_dword %0, %1, %2 offset:%3 nt" : : "v"(voff), "v"(v), "s"(sbase_uniform), "n"(IMM) : "memory");
 }
 
 __device__ __forceinline__ void dma_rows(unsigned char* lds, const _Float16* g, size_t row0, int tid, int wave) {
@@ -387,34 +387,43 @@ __global__ __launch_bounds__(256, 2) void k1_conf_wide(const _Float16* __restric
     store_tile(t1 - 1);
 }
 
-// one thread per listed entry (z * L + i, j, bits of the split-precision log2-domain score x): the fused matcher's
-// formula (dual_softmax_f16s.hip:k1_match), bit for bit
-__global__ __launch_bounds__(256) void k1_conf_fix(int L, int S, int Sp, const float2* __restrict__ rowstat,
+// one thread per slot of the lists written by k1_rowstats<CAND>: entry (i, bits of the split-precision log2-domain score
+// x) of column j -> the fused matcher's formula (dual_softmax_f16s.hip:k1_match), bit for bit
+__global__ __launch_bounds__(256) void k1_conf_fix(int Z, int L, int S, int Sp, int slots, const float2* __restrict__ rowstat,
                                                    const float* __restrict__ cmax, const float* __restrict__ cinv,
                                                    float* __restrict__ conf, const int* __restrict__ fix_count,
-                                                   const uint4* __restrict__ fix_list, int fix_cap,
-                                                   int* __restrict__ fix_info_out) {
-    const int listed = *fix_count;
-    const int n = min(listed, fix_cap);
-    if (fix_info_out && blockIdx.x == 0 && threadIdx.x == 0) { fix_info_out[0] = listed; fix_info_out[1] = fix_cap; }
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
-        const uint4 ent = fix_list[e];
-        const size_t zi = ent.x, z = zi / (size_t)L;
-        const int j = (int)ent.y;
+                                                   const uint2* __restrict__ fix_list, int* __restrict__ fix_info_out) {
+    const size_t total = (size_t)Z * S * 2 * slots;
+    int done = 0, dropped = 0;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const int slot = (int)(t % slots);
+        const size_t lh = t / slots;                      // (z S + j) * 2 + h
+        const int cnt = fix_count[lh];
+        if (slot == 0 && cnt > slots) dropped += cnt - slots;
+        if (slot >= cnt) continue;
+        const size_t zj = lh >> 1, z = zj / (size_t)S;
+        const int j = (int)(zj - z * S);
+        const uint2 ent = fix_list[t];
+        const size_t zi = z * L + ent.x;
         const float2 st = rowstat[zi];
-        const float x2 = 2.0f * __uint_as_float(ent.z);
+        const float x2 = 2.0f * __uint_as_float(ent.y);
         conf[zi * S + j] = __builtin_amdgcn_exp2f((x2 - st.x) - cmax[z * Sp + j]) * (1.0f / st.y) * cinv[z * Sp + j];
+        ++done;
+    }
+    if (fix_info_out) {
+        if (done) atomicAdd(&fix_info_out[0], done);
+        if (dropped) atomicAdd(&fix_info_out[1], dropped);
     }
 }
 
 }  // namespace far_conf
 
 // Called by far_conf_matrix_f16s (dual_softmax_f16s.hip) after the statistics passes.  ah / bh: fp16 `hi` planes of
-// k1_prep; c1: log2-domain score per unit of the pre-scaled dot product; fix_count / fix_list: the entries listed by
-// k1_rowstats<CAND>.
+// k1_prep; c1: log2-domain score per unit of the pre-scaled dot product; fix_count / fix_list: the per-column slot lists
+// written by k1_rowstats<CAND>.
 int far_k1_conf_launch(const _Float16* ah, const _Float16* bh, int Z, int L, int S, int Lp, int Sp, float c1, float fill2,
                        const uint8_t* mask0, const uint8_t* mask1, const float2* rowstat, const float* cmax,
-                       const float* cinv, float* conf, const int* fix_count, const uint4* fix_list, int fix_cap,
+                       const float* cinv, float* conf, const int* fix_count, const uint2* fix_list, int slots,
                        int* fix_info_out, hipStream_t stream) {
     using namespace far_conf;
     const float c2 = 2.0f * c1, f2 = 2.0f * fill2;
@@ -436,13 +445,17 @@ int far_k1_conf_launch(const _Float16* ah, const _Float16* bh, int Z, int L, int
             hipLaunchKernelGGL(k1_conf<false>, grid, dim3(256), smem, stream, ah, bh, Z, L, S, Lp, Sp, nI, nch, tpc, c2, f2, mask0,
                                mask1, rowstat, cmax, cinv, conf);
     } else {
-        // work item = (pair, 256-column block, chunk of <= 15 row tiles): ~12 rounds of the chip's 512 resident workgroups
+        // work item = (pair, 256-column block, chunk of <= 30 row tiles): ~6 rounds of the chip's 512 resident workgroups
         const int nJ = (S + 255) / 256;
         const int ntile = (L + RT - 1) / RT;
-        int nch = (ntile + 14) / 15;
-        const int tpc = (ntile + nch - 1) / nch;                     // <= 15 <= RCHUNK_MAX
+        const int want = far_get_tuning(3) > 0 ? far_get_tuning(3) : 30;     // row tiles per item (A/B knob; default 30)
+        int nch = (ntile + want - 1) / want;
+        const int tpc = (ntile + nch - 1) / nch;                     // <= RCHUNK_MAX
         nch = (ntile + tpc - 1) / tpc;
         const size_t smem = RING * RTILE + RCHUNK_MAX * RT * sizeof(float);
+        FAR_ONCE_PER_DEVICE(
+            hipFuncSetAttribute((const void*)k1_conf_wide<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            hipFuncSetAttribute((const void*)k1_conf_wide<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         const dim3 grid((unsigned)(Z * nJ * nch));
         if (mask0 || mask1)
             hipLaunchKernelGGL(k1_conf_wide<true>, grid, dim3(256), smem, stream, ah, bh, Z, L, S, Lp, Sp, nJ, nch, tpc, c2, f2,
@@ -451,7 +464,8 @@ int far_k1_conf_launch(const _Float16* ah, const _Float16* bh, int Z, int L, int
             hipLaunchKernelGGL(k1_conf_wide<false>, grid, dim3(256), smem, stream, ah, bh, Z, L, S, Lp, Sp, nJ, nch, tpc, c2, f2,
                                mask0, mask1, rowstat, cmax, cinv, conf);
     }
-    hipLaunchKernelGGL(k1_conf_fix, dim3(512), dim3(256), 0, stream, L, S, Sp, rowstat, cmax, cinv, conf, fix_count, fix_list,
-                       fix_cap, fix_info_out);
+    if (fix_info_out) hipMemsetAsync(fix_info_out, 0, 2 * sizeof(int), stream);
+    hipLaunchKernelGGL(k1_conf_fix, dim3(1024), dim3(256), 0, stream, Z, L, S, Sp, slots, rowstat, cmax, cinv, conf, fix_count,
+                       fix_list, fix_info_out);
     return far_check_launch();
 }

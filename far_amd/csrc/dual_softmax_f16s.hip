@@ -19,7 +19,7 @@
 // dual_softmax_conf_f16.hip: the HBM-bound conf_matrix writer (plain-fp16 scores + exact fix-up of the non-tiny entries)
 int far_k1_conf_launch(const _Float16* ah, const _Float16* bh, int Z, int L, int S, int Lp, int Sp, float c1, float fill2,
                        const uint8_t* mask0, const uint8_t* mask1, const float2* rowstat, const float* cmax,
-                       const float* cinv, float* conf, const int* fix_count, const uint4* fix_list, int fix_cap,
+                       const float* cinv, float* conf, const int* fix_count, const uint2* fix_list, int slots,
                        int* fix_info_out, hipStream_t stream);
 
 namespace {
@@ -37,6 +37,7 @@ constexpr int ROWB = C * 2;          // bytes per fp16 row
 constexpr float PRESCALE = 16.0f;
 constexpr float HUGE_F = 1.0e30f;
 constexpr int TILE_PLANE = KT * ROWB;   // 32 KiB
+constexpr int CAND_SLOTS = 4;           // exact-entry slots per (column, half-wave) of the conf_matrix writer
 
 __device__ __forceinline__ void split1(float x, _Float16& hi, _Float16& lo) {
     hi = (_Float16)x;
@@ -132,7 +133,9 @@ __device__ __forceinline__ void score_tile(f32x16 (&acc)[2], const unsigned char
 // (masked_fill_(-INF), coarse_matching.py:108-111).  Optional dense padded copies dmax / dinv [Z][Nrp] (+huge / 0 past Nr).
 // CAND (second call of the conf_matrix writer, rows = the matrix's COLUMNS j, tile columns = its rows i whose statistics
 // are final): every entry that can reach conf >= 2^-12 (row term exact, column term bounded from above by the running
-// column statistics) is appended to `cand` as (z * Nc + i, j, bits of x): the writer's fix-up evaluates those
+// column statistics) is appended to this lane's PRIVATE slot list cand[(z Nr + j) * 2 + h][CAND_SLOTS] as (i, bits of x)
+// -- no atomics, no cross-lane traffic: four slots per half-column, the count (which may exceed the slots: overflow is
+// reported, never silent) in cand_count -- and the writer's fix-up evaluates those
 // from THIS x, the very value the statistics were accumulated from (an independently computed "exact" x would not
 // cancel against them: the fp32 accumulation error of a 256-term dot product is ~1e-5 in the log2 domain).
 template <bool CAND>
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void k1_rowstats(const _Float16* __restrict
                                                       const uint8_t* __restrict__ rmask, const uint8_t* __restrict__ cmask,
                                                       float2* __restrict__ stat, float* __restrict__ dmax, float* __restrict__ dinv,
                                                       float* __restrict__ dthr, const float* __restrict__ othr,
-                                                      int* __restrict__ cand_count, uint4* __restrict__ cand, int cand_cap) {
+                                                      int* __restrict__ cand_count, uint2* __restrict__ cand) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     int z, Ib;
@@ -152,6 +155,7 @@ __global__ __launch_bounds__(256, 2) void k1_rowstats(const _Float16* __restrict
     rf.load(ah, al, (size_t)z * Nrp + irow, irow, h);
     const bool rmasked = rmask && irow < Nr && !rmask[(size_t)z * Nr + irow];
     float m = -HUGE_F, sum = 0.f, comp = 0.f;
+    int ncand = 0;
     const int ntile = (Nc + KT - 1) / KT;
     for (int jt = 0; jt < ntile; ++jt) {
         __syncthreads();
@@ -212,7 +216,8 @@ __global__ __launch_bounds__(256, 2) void k1_rowstats(const _Float16* __restrict
                     hot = fmaxf(hot, fmaxf(fmaxf(2.0f * acc[ct][4 * q4 + 0] - a.x, 2.0f * acc[ct][4 * q4 + 1] - a.y),
                                            fmaxf(2.0f * acc[ct][4 * q4 + 2] - a.z, 2.0f * acc[ct][4 * q4 + 3] - a.w)));
                 }
-            if (__builtin_amdgcn_ballot_w64(hot >= clog) != 0ull) {           // rare
+            if (__builtin_amdgcn_ballot_w64(hot >= clog) != 0ull) {           // a candidate somewhere in this wave's tile
+                uint2* const slots = cand + ((size_t)z * Nr + min(irow, Nr - 1)) * (2 * CAND_SLOTS) + h * CAND_SLOTS;
 #pragma unroll 1
                 for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -220,14 +225,14 @@ __global__ __launch_bounds__(256, 2) void k1_rowstats(const _Float16* __restrict
                         const int i = jt * KT + 32 * ct + mfma32_row(r, h);
                         const float xv = ct == 0 ? acc[0][r] : acc[1][r];
                         if (2.0f * xv >= tl[32 * ct + mfma32_row(r, h)] + clog && xv > -1.0e8f && i < Nc && irow < Nr) {
-                            const int idx = atomicAdd(cand_count, 1);
-                            if (idx < cand_cap)
-                                cand[idx] = make_uint4((unsigned)(z * Nc + i), (unsigned)irow, __float_as_uint(xv), 0u);
+                            if (ncand < CAND_SLOTS) slots[ncand] = make_uint2((unsigned)i, __float_as_uint(xv));
+                            ++ncand;
                         }
                     }
             }
         }
     }
+    if (CAND && irow < Nr) cand_count[((size_t)z * Nr + irow) * 2 + h] = ncand;
     sum -= comp;
     const float mo = shfl_xor_f(m, 32), so = shfl_xor_f(sum, 32);
     const float mn = fmaxf(m, mo);
@@ -341,9 +346,8 @@ struct Ws16 {
     float2* colstat2;
     float *cmax, *cinv;
     float* rthr;             // [Z][Lp]: rowmax + log2(rowsum) - 12 (candidate threshold of the conf_matrix writer)
-    int* fix_count;          // entries listed for the writer's exact pass
-    uint4* fix_list;         // (z * L + i, j, bits of x, -)
-    int fix_cap;
+    int* fix_count;          // [Z][S][2]: entries each (column, half-wave) wanted to list for the writer's exact pass
+    uint2* fix_list;         // [Z][S][2][CAND_SLOTS]: (i, bits of x)
     size_t bytes;
 };
 inline Ws16 carve16(void* ws, int Z, int L, int S) {
@@ -358,9 +362,8 @@ inline Ws16 carve16(void* ws, int Z, int L, int S) {
     w.colstat2 = (float2*)take((size_t)Z * S * 8);
     w.cmax = (float*)take((size_t)Z * Sp * 4); w.cinv = (float*)take((size_t)Z * Sp * 4);
     w.rthr = (float*)take((size_t)Z * Lp * 4);
-    w.fix_count = (int*)take(256);
-    w.fix_cap = (int)std::min<size_t>((size_t)Z * L * 8, (size_t)1 << 27);      // 8 exact entries per row on average
-    w.fix_list = (uint4*)take((size_t)w.fix_cap * sizeof(uint4));
+    w.fix_count = (int*)take((size_t)Z * S * 2 * sizeof(int));
+    w.fix_list = (uint2*)take((size_t)Z * S * 2 * CAND_SLOTS * sizeof(uint2));
     w.bytes = o;
     return w;
 }
@@ -403,10 +406,10 @@ int far_coarse_match_f16s(const float* f0, const float* f1, int Z, int L, int S,
         hipFuncSetAttribute((const void*)k1_match<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_m));
     hipLaunchKernelGGL(k1_rowstats<false>, dim3((Lp / 128) * Z), dim3(256), smem_s, stream, w.ah, w.al, w.bh, w.bl, Z, L, S, Lp, Sp,
                        c1, fill2, mask0, mask1, w.k.rowstat, (float*)nullptr, (float*)nullptr, (float*)nullptr,
-                       (const float*)nullptr, (int*)nullptr, (uint4*)nullptr, 0);
+                       (const float*)nullptr, (int*)nullptr, (uint2*)nullptr);
     hipLaunchKernelGGL(k1_rowstats<false>, dim3((Sp / 128) * Z), dim3(256), smem_s, stream, w.bh, w.bl, w.ah, w.al, Z, S, L, Sp, Lp,
                        c1, fill2, mask1, mask0, w.colstat2, w.cmax, w.cinv, (float*)nullptr, (const float*)nullptr,
-                       (int*)nullptr, (uint4*)nullptr, 0);
+                       (int*)nullptr, (uint2*)nullptr);
     const int nI = Lp / 128;
     if (conf_out)
         hipLaunchKernelGGL(k1_match<true>, dim3(nI * Z), dim3(256), smem_m, stream, w.ah, w.al, w.bh, w.bl, Z, L, S, Lp, Sp, c1,
@@ -445,18 +448,17 @@ int far_conf_matrix_f16s(const float* f0, const float* f1, int Z, int L, int S, 
         FAR_ONCE_PER_DEVICE(
             hipFuncSetAttribute((const void*)k1_rowstats<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_s);
             hipFuncSetAttribute((const void*)k1_rowstats<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_s));
-        hipMemsetAsync(w.fix_count, 0, sizeof(int), stream);
         // row statistics (+ the dense candidate thresholds), then column statistics with candidate listing
         hipLaunchKernelGGL(k1_rowstats<false>, dim3((Lp / 128) * Z), dim3(256), smem_s, stream, w.ah, w.al, w.bh, w.bl, Z, L, S, Lp,
                            Sp, c1, fill2, mask0, mask1, w.k.rowstat, (float*)nullptr, (float*)nullptr, w.rthr,
-                           (const float*)nullptr, (int*)nullptr, (uint4*)nullptr, 0);
+                           (const float*)nullptr, (int*)nullptr, (uint2*)nullptr);
         hipLaunchKernelGGL(k1_rowstats<true>, dim3((Sp / 128) * Z), dim3(256), smem_s, stream, w.bh, w.bl, w.ah, w.al, Z, S, L, Sp,
                            Lp, c1, fill2, mask1, mask0, w.colstat2, w.cmax, w.cinv, (float*)nullptr, (const float*)w.rthr,
-                           w.fix_count, w.fix_list, w.fix_cap);
+                           w.fix_count, w.fix_list);
     }
     if (stages & 2) {
         const int rc = far_k1_conf_launch(w.ah, w.bh, Z, L, S, Lp, Sp, c1, fill2, mask0, mask1, w.k.rowstat, w.cmax, w.cinv,
-                                          conf_out, w.fix_count, w.fix_list, w.fix_cap, fix_info_out, stream);
+                                          conf_out, w.fix_count, w.fix_list, CAND_SLOTS, fix_info_out, stream);
         if (rc != FAR_OK) return rc;
     }
     return far_check_launch();

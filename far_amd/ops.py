@@ -119,8 +119,8 @@ def conf_matrix(f0, f1, temperature, mask0=None, mask1=None, out=None):
                                   _p(mask0, torch.uint8), _p(mask1, torch.uint8), 3, _p(conf, torch.float32), _p(info), _p(ws),
                                   _stream())
     _lib.check(rc, 'far_conf_matrix_f16s')
-    listed, cap = (int(v) for v in info.cpu())
-    if listed > cap:          # pathological input (more than 8 non-tiny entries per row on average): exact writer
+    listed, dropped = (int(v) for v in info.cpu())
+    if dropped > 0:           # pathological input (a column with more than 8 non-tiny entries): the exact writer
         hw = (1, L), (1, S)
         return coarse_match(f0, f1, temperature, 2.0, 0, hw[0], hw[1], 1.0, mask0, mask1, want_conf=True,
                             variant='f16s')['conf_matrix'], listed

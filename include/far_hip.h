@@ -95,11 +95,11 @@ int far_coarse_match_f16s(const float* f0, const float* f1, int Z, int L, int S,
 /* data['conf_matrix'] alone -- CoarseMatching.forward's dual-softmax matrix (coarse_matching.py:108-118), which only the
  * dense coarse loss and plotting consume (loftr_loss.py:307-311) -- written at HBM speed: statistics from the
  * split-precision passes above (fp32-grade), the (Z, L, S) matrix from plain-fp16 scores (one MFMA per 16 channels,
- * one exp per score, full-line stores), and every entry above 2^-12 -- a handful per row, the only ones an fp16
- * operand error can move by more than 1e-5 -- recomputed from the fp32 features with a float64 dot product.
+ * one exp per score, full-line stores), and every entry that can exceed 2^-12 -- about one per row, the only ones an
+ * fp16 operand error can move by more than 1e-5 -- rewritten from the split-precision score the statistics pass saw.
  *   stages        bit 0: operand planes + statistics; bit 1: write the matrix (callers that keep `ws` may split them)
- *   fix_info_out  optional 2 device ints: entries listed for exact recomputation, list capacity (listed > capacity:
- *                 the surplus kept its fp16-operand value, relative error ~1e-3; use far_coarse_match_f16s then)
+ *   fix_info_out  optional 2 device ints: entries rewritten exactly, entries that did not fit their slot list (> 0:
+ *                 those kept their fp16-operand value, relative error ~1e-3; use far_coarse_match_f16s then)
  *   ws            far_coarse_match_f16s_workspace_bytes(Z, L, S, C) bytes; C must be 256. */
 int far_conf_matrix_f16s(const float* f0, const float* f1, int Z, int L, int S, int C, float temperature,
                          const uint8_t* mask0, const uint8_t* mask1, int stages, float* conf_out, int* fix_info_out,

@@ -26,14 +26,16 @@ if which in ('k1w', 'all'):
     f1 = f0[:, torch.randperm(L, device=dev, generator=g)] + 0.1 * torch.randn(n, L, 256, device=dev, generator=g)
     conf = torch.empty(n, L, L, device=dev)
     lib = _lib.load()
-    for variant in (0, 1):                      # 0 = wide-tile writer (default), 1 = tall-tile writer
+    for variant, tiles in ((0, 30), (0, 15), (0, 20)):     # wide-tile writer with 30 / 15 / 20 row tiles per work item
         lib.far_set_tuning(2, variant)
+        lib.far_set_tuning(3, tiles)
         for _ in range(it):
             c, listed = ops.conf_matrix(f0, f1, 0.1, out=conf)
         ref = ops.coarse_match(f0[:2], f1[:2], 0.1, 0.2, 2, (60, 80), (60, 80), 8.0, want_conf=True, variant='f16s')['conf_matrix']
-        print('k1w variant', variant, ': listed', listed, 'entries =', listed / (n * L), 'per row; max dev vs fused writer',
+        print('k1w variant', variant, tiles, ': listed', listed, 'entries =', listed / (n * L), 'per row; max dev vs fused writer',
               float((c[:2] - ref).abs().max()))
     lib.far_set_tuning(2, 0)
+    lib.far_set_tuning(3, 0)
     del conf
 if which in ('k1b',):
     f0 = 1.2 * torch.randn(n, L, 256, device=dev, generator=g)
