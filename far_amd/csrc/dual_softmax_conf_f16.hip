@@ -387,28 +387,29 @@ __global__ __launch_bounds__(256, 2) void k1_conf_wide(const _Float16* __restric
     store_tile(t1 - 1);
 }
 
-// one thread per slot of the lists written by k1_rowstats<CAND>: entry (i, bits of the split-precision log2-domain score
-// x) of column j -> the fused matcher's formula (dual_softmax_f16s.hip:k1_match), bit for bit
+// one thread per slot LIST written by k1_rowstats<CAND> (column j, half-wave h): its entries (i, bits of the
+// split-precision log2-domain score x) -> the fused matcher's formula (dual_softmax_f16s.hip:k1_match), bit for bit
 __global__ __launch_bounds__(256) void k1_conf_fix(int Z, int L, int S, int Sp, int slots, const float2* __restrict__ rowstat,
                                                    const float* __restrict__ cmax, const float* __restrict__ cinv,
                                                    float* __restrict__ conf, const int* __restrict__ fix_count,
                                                    const uint2* __restrict__ fix_list, int* __restrict__ fix_info_out) {
-    const size_t total = (size_t)Z * S * 2 * slots;
+    const size_t total = (size_t)Z * S * 2;
     int done = 0, dropped = 0;
-    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
-        const int slot = (int)(t % slots);
-        const size_t lh = t / slots;                      // (z S + j) * 2 + h
-        const int cnt = fix_count[lh];
-        if (slot == 0 && cnt > slots) dropped += cnt - slots;
-        if (slot >= cnt) continue;
+    for (size_t lh = (size_t)blockIdx.x * blockDim.x + threadIdx.x; lh < total; lh += (size_t)gridDim.x * blockDim.x) {
+        const int cnt = fix_count[lh];                    // (z S + j) * 2 + h
+        if (cnt <= 0) continue;
+        if (cnt > slots) dropped += cnt - slots;
         const size_t zj = lh >> 1, z = zj / (size_t)S;
         const int j = (int)(zj - z * S);
-        const uint2 ent = fix_list[t];
-        const size_t zi = z * L + ent.x;
-        const float2 st = rowstat[zi];
-        const float x2 = 2.0f * __uint_as_float(ent.y);
-        conf[zi * S + j] = __builtin_amdgcn_exp2f((x2 - st.x) - cmax[z * Sp + j]) * (1.0f / st.y) * cinv[z * Sp + j];
-        ++done;
+        const float cm = cmax[z * Sp + j], ci = cinv[z * Sp + j];
+        for (int k = 0; k < min(cnt, slots); ++k) {
+            const uint2 ent = fix_list[lh * slots + k];
+            const size_t zi = z * L + ent.x;
+            const float2 st = rowstat[zi];
+            const float x2 = 2.0f * __uint_as_float(ent.y);
+            conf[zi * S + j] = __builtin_amdgcn_exp2f((x2 - st.x) - cm) * (1.0f / st.y) * ci;
+            ++done;
+        }
     }
     if (fix_info_out) {
         if (done) atomicAdd(&fix_info_out[0], done);
