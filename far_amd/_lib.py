@@ -33,6 +33,9 @@ SIGNATURES = {
     'far_coarse_match_f16s': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f,
                                     c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     'far_conf_matrix_f16s': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_i, c_p, c_p, c_p, c_p]),
+    'far_coarse_train_workspace_bytes': (c_sz, [c_i, c_i, c_i, c_i]),
+    'far_coarse_pos_conf_f16s': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_i, c_p, c_p, c_p]),
+    'far_coarse_pos_conf_bwd_f16': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p]),
     'far_emm_pv_f32': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_p]),
     'far_fine_gather_f32': (c_i, [c_p, c_l, c_l, c_l, c_l, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
     'far_fine_expect_f32': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_f, c_p, c_p, c_p, c_p, c_p]),

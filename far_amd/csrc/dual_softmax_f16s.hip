@@ -370,6 +370,39 @@ inline Ws16 carve16(void* ws, int Z, int L, int S) {
 
 }  // namespace
 
+// ---- glue for the training kernels (dual_softmax_bwd_f16.hip): the forward workspace and its statistics passes ----
+size_t far_k1_fwd_ws_bytes(int Z, int L, int S) { return carve16(nullptr, Z, L, S).bytes; }
+
+static float k1_c1(float temperature) {
+    return (float)(1.4426950408889634 / ((double)C * (double)temperature * PRESCALE * PRESCALE));
+}
+
+// operand planes + row statistics + dense column statistics, exactly as far_coarse_match_f16s prepares them
+int far_k1_stats_launch(const float* f0, const float* f1, int Z, int L, int S, float temperature, void* ws, hipStream_t stream) {
+    const Ws16 w = carve16(ws, Z, L, S);
+    const int Lp = (L + 127) / 128 * 128, Sp = (S + 127) / 128 * 128;
+    const float c1 = k1_c1(temperature), fill2 = -1e9f * 1.44269504088896341f;
+    auto gridp = [](long n) { long b = (n + 255) / 256; return (unsigned)(b < 65536L * 4 ? b : 65536L * 4); };
+    hipLaunchKernelGGL(k1_prep, dim3(gridp((long)Z * Lp * 32)), dim3(256), 0, stream, f0, Z, L, Lp, w.ah, w.al);
+    hipLaunchKernelGGL(k1_prep, dim3(gridp((long)Z * Sp * 32)), dim3(256), 0, stream, f1, Z, S, Sp, w.bh, w.bl);
+    const size_t smem_s = 2 * TILE_PLANE + KT * sizeof(float);
+    FAR_ONCE_PER_DEVICE(hipFuncSetAttribute((const void*)k1_rowstats<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_s));
+    hipLaunchKernelGGL(k1_rowstats<false>, dim3((Lp / 128) * Z), dim3(256), smem_s, stream, w.ah, w.al, w.bh, w.bl, Z, L, S, Lp, Sp,
+                       c1, fill2, (const uint8_t*)nullptr, (const uint8_t*)nullptr, w.k.rowstat, (float*)nullptr, (float*)nullptr,
+                       (float*)nullptr, (const float*)nullptr, (int*)nullptr, (uint2*)nullptr);
+    hipLaunchKernelGGL(k1_rowstats<false>, dim3((Sp / 128) * Z), dim3(256), smem_s, stream, w.bh, w.bl, w.ah, w.al, Z, S, L, Sp, Lp,
+                       c1, fill2, (const uint8_t*)nullptr, (const uint8_t*)nullptr, w.colstat2, w.cmax, w.cinv, (float*)nullptr,
+                       (const float*)nullptr, (int*)nullptr, (uint2*)nullptr);
+    return far_check_launch();
+}
+
+void far_k1_fwd_views(void* ws, int Z, int L, int S, const _Float16** ah, const _Float16** bh, const float2** rowstat,
+                      const float** cmax, const float** cinv, float* c1_out) {
+    const Ws16 w = carve16(ws, Z, L, S);
+    *ah = w.ah; *bh = w.bh; *rowstat = w.k.rowstat; *cmax = w.cmax; *cinv = w.cinv;
+    *c1_out = 0.f;      // set by the caller from the temperature (kept out of the workspace: it is not device data)
+}
+
 extern "C" {
 
 size_t far_coarse_match_f16s_workspace_bytes(int Z, int L, int S, int Cc) {

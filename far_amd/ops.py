@@ -127,6 +127,48 @@ def conf_matrix(f0, f1, temperature, mask0=None, mask1=None, out=None):
     return (conf if out is None else _written(conf)), listed
 
 
+class _CoarsePosConf(torch.autograd.Function):
+    """conf_matrix[b, i, j] at M given positions, differentiable w.r.t. both coarse feature maps, without the dense
+    matrix (far_coarse_pos_conf_f16s / far_coarse_pos_conf_bwd_f16)."""
+
+    @staticmethod
+    def forward(ctx, f0, f1, pb, pi, pj, temperature):
+        lib = _lib.load()
+        Z, L, C = f0.shape
+        S = f1.shape[1]
+        f0c, f1c = f0.detach().float().contiguous(), f1.detach().float().contiguous()
+        pb, pi, pj = (t.to(torch.int64).contiguous() for t in (pb, pi, pj))
+        M = int(pb.numel())
+        ws = _ws(lib.far_coarse_train_workspace_bytes(Z, L, S, C), f0.device)
+        p = torch.empty(M, dtype=torch.float32, device=f0.device)
+        rc = lib.far_coarse_pos_conf_f16s(_p(f0c, torch.float32), _p(f1c, torch.float32), Z, L, S, C, float(temperature),
+                                          _p(pb), _p(pi), _p(pj), M, _p(p), _p(ws), _stream())
+        _lib.check(rc, 'far_coarse_pos_conf_f16s')
+        ctx.save_for_backward(f0c, f1c, pb, pi, pj, p, ws)
+        ctx.temperature = float(temperature)
+        return p
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        f0c, f1c, pb, pi, pj, p, ws = ctx.saved_tensors
+        Z, L, C = f0c.shape
+        S = f1c.shape[1]
+        w = (g.float() * p).contiguous()                    # dL/dp * p: bounded for the focal loss even where p -> 0
+        df0, df1 = torch.empty_like(f0c), torch.empty_like(f1c)
+        rc = lib.far_coarse_pos_conf_bwd_f16(_p(f0c), _p(f1c), Z, L, S, C, ctx.temperature, _p(pb), _p(pi), _p(pj),
+                                             int(pb.numel()), _p(w, torch.float32), _p(df0), _p(df1), _p(ws), _stream())
+        _lib.check(rc, 'far_coarse_pos_conf_bwd_f16')
+        return df0, df1, None, None, None, None
+
+
+def coarse_pos_conf(f0, f1, pb, pi, pj, temperature):
+    """K1, training: conf_matrix[pb, pi, pj] (M,) fp32 with a HIP backward to both feature maps; C must be 256."""
+    if not f0.is_cuda:
+        raise _lib.FarHipError('far_amd ops need tensors on the GPU (no CPU fallback exists)')
+    return _CoarsePosConf.apply(f0, f1, pb, pi, pj, temperature)
+
+
 def emm_bilinear(q, k, v, pos, scale, exact_f32=False):
     """K2.  q, k, v: (Z, N, 64) fp32; pos: (N, 6).  Returns F (Z, 70, 70) = v~^T (P v~), v~ = [v | pos],
     P = softmax(s, -1) * softmax(s, -2), s = (q k^T) * scale   (transformer.py:275-292).

@@ -106,6 +106,27 @@ int far_conf_matrix_f16s(const float* f0, const float* f1, int Z, int L, int S, 
                          void* ws, far_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * K1 on the training path: sparse coarse supervision without conf_matrix / conf_matrix_gt
+ * replaces, for match_type 'dual_softmax' + sparse_spvs + focal loss (the FAR training configuration):
+ *   src/loftr/utils/coarse_matching.py:108-118   conf_matrix = softmax(sim, 1) * softmax(sim, 2)     (92 MB / pair)
+ *   src/loftr/utils/supervision.py:113-137       conf_matrix_gt                                       (92 MB / pair)
+ *   src/losses/loftr_loss.py:86-91               pos_conf = conf[pos_mask]   -- the ONLY read of the dense matrix
+ *   and autograd's backward through the two softmaxes and the correlation
+ * positions (pb, pi, pj)[M] int64 = spv_b_ids / spv_i_ids / spv_j_ids.  C must be 256.
+ * ws: far_coarse_train_workspace_bytes(Z, L, S, C) bytes, kept untouched between the forward and the backward call. */
+size_t far_coarse_train_workspace_bytes(int Z, int L, int S, int C);
+/* forward: p_out[k] = conf_matrix[pb[k], pi[k], pj[k]] (fp32-grade statistics; float64 dot product at the positions). */
+int far_coarse_pos_conf_f16s(const float* f0, const float* f1, int Z, int L, int S, int C, float temperature,
+                             const int64_t* pb, const int64_t* pi, const int64_t* pj, int M, float* p_out, void* ws,
+                             far_stream_t stream);
+/* backward: w[k] = dL/dp_k * p_k.  df0 (Z, L, C), df1 (Z, S, C) are overwritten with dL/dfeat_c0, dL/dfeat_c1.
+ * Dense part on the f16 matrix cores (recomputed score tiles, G = u R + v C fed from registers into the second MFMA),
+ * plain fp16 operands / fp32 accumulation: gradient-grade (~1e-3 relative), not parity-grade. */
+int far_coarse_pos_conf_bwd_f16(const float* f0, const float* f1, int Z, int L, int S, int C, float temperature,
+                                const int64_t* pb, const int64_t* pi, const int64_t* pj, int M, const float* w,
+                                float* df0, float* df1, void* ws, far_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * K2  EMM head: bilinear dual-softmax attention  F = v~^T (softmax_row(s) * softmax_col(s)) v~
  * replaces src/loftr/loftr_module/transformer.py:275-292 (CrossAttention.forward), one call per direction
  * ------------------------------------------------------------------------------------------------- */

@@ -1,0 +1,90 @@
+"""Backward kernels of the training path (BASELINE configs[2]) against float64 autograd of the reference's formulas.
+
+K1: sparse coarse supervision (far_coarse_pos_conf_f16s / far_coarse_pos_conf_bwd_f16): conf at the ground-truth positions
+and the gradient of a loss on them w.r.t. both coarse feature maps, vs
+    conf = softmax(sim, 1) * softmax(sim, 2), sim = <f0 / sqrt(C), f1 / sqrt(C)> / T   (coarse_matching.py:104-118)
+evaluated densely in float64 with torch autograd (the reference's own path, loftr_loss.py:86-112)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import correlated_features
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_pos_conf(f0, f1, pb, pi, pj, T):
+    C = f0.shape[-1]
+    sim = torch.einsum('nlc,nsc->nls', f0 / C ** .5, f1 / C ** .5) / T
+    conf = torch.softmax(sim, 1) * torch.softmax(sim, 2)
+    return conf[pb, pi, pj]
+
+
+def _focal(p, alpha=0.25, gamma=2.0):
+    p = torch.clamp(p, 1e-6, 1 - 1e-6)                          # loftr_loss.py:84, :92
+    return (-alpha * torch.pow(1 - p, gamma) * p.log()).mean()
+
+
+@pytest.mark.parametrize('N,hw,seed', [(2, (20, 32), 1), (1, (60, 80), 2), (3, (17, 23), 3)])
+def test_k1_sparse_conf_forward_and_backward(N, hw, seed):
+    from far_amd import ops
+    L = hw[0] * hw[1]
+    f0n, f1n, perms = correlated_features(N, hw, 256, seed=seed, amp=1.2, noise=0.4, frac=0.7)
+    rng = np.random.default_rng(seed)
+    # ground-truth positions: the true permutation for 60 % of the rows (confident and not), random pairs for some more
+    pb, pi, pj = [], [], []
+    for n in range(N):
+        inv = np.empty(L, np.int64)
+        inv[perms[n]] = np.arange(L)                             # f1[j] = f0[perm[j]]  ->  row i matches column inv[i]
+        rows = rng.choice(L, int(0.6 * L), replace=False)
+        pb += [n] * len(rows); pi += rows.tolist(); pj += inv[rows].tolist()
+        extra = rng.integers(0, L, (L // 10, 2))
+        pb += [n] * len(extra); pi += extra[:, 0].tolist(); pj += extra[:, 1].tolist()
+    pb, pi, pj = (torch.tensor(a, dtype=torch.int64).cuda() for a in (pb, pi, pj))
+    f0 = torch.from_numpy(f0n).cuda().requires_grad_(True)
+    f1 = torch.from_numpy(f1n).cuda().requires_grad_(True)
+    p = ops.coarse_pos_conf(f0, f1, pb, pi, pj, 0.1)
+    loss = _focal(p)
+    loss.backward()
+    r0 = torch.from_numpy(f0n).double().cuda().requires_grad_(True)
+    r1 = torch.from_numpy(f1n).double().cuda().requires_grad_(True)
+    pr = _ref_pos_conf(r0, r1, pb, pi, pj, 0.1)
+    lr = _focal(pr)
+    lr.backward()
+    dp = float((p.double() - pr).abs().max())
+    assert dp < 2e-5, dp                                         # conf at the positions (fp32-grade statistics)
+    assert abs(loss.item() - lr.item()) < 2e-5 * max(1.0, abs(lr.item()))
+    for name, g, gr in (('dF0', f0.grad, r0.grad), ('dF1', f1.grad, r1.grad)):
+        scale = float(gr.abs().max())
+        err = float((g.double() - gr).abs().max())
+        rel_fro = float((g.double() - gr).norm() / gr.norm())
+        print(f'[k1 bwd] N={N} hw={hw} {name}: max|d| = {err:.3e} (max|ref| = {scale:.3e}), relative Frobenius error {rel_fro:.3e}')
+        assert rel_fro < 3e-3 and err < 1e-2 * scale, (name, rel_fro, err / scale)
+
+
+def test_k1_sparse_conf_arbitrary_upstream_gradient_and_empty():
+    """Not only the focal loss: any dL/dp (mixed signs, huge dynamic range) must go through; M = 0 gives zero gradients."""
+    from far_amd import ops
+    N, hw = 1, (24, 32)
+    L = hw[0] * hw[1]
+    f0n, f1n, _ = correlated_features(N, hw, 256, seed=9, amp=1.0, noise=0.5)
+    rng = np.random.default_rng(9)
+    M = 500
+    pb = torch.zeros(M, dtype=torch.int64).cuda()
+    pi = torch.from_numpy(rng.integers(0, L, M)).cuda()
+    pj = torch.from_numpy(rng.integers(0, L, M)).cuda()
+    g = torch.from_numpy((rng.standard_normal(M) * 10.0 ** rng.uniform(-3, 3, M)).astype(np.float32)).cuda()
+    f0 = torch.from_numpy(f0n).cuda().requires_grad_(True)
+    f1 = torch.from_numpy(f1n).cuda().requires_grad_(True)
+    ops.coarse_pos_conf(f0, f1, pb, pi, pj, 0.1).backward(g)
+    r0 = torch.from_numpy(f0n).double().cuda().requires_grad_(True)
+    r1 = torch.from_numpy(f1n).double().cuda().requires_grad_(True)
+    _ref_pos_conf(r0, r1, pb, pi, pj, 0.1).backward(g.double())
+    for g_, gr in ((f0.grad, r0.grad), (f1.grad, r1.grad)):
+        assert float((g_.double() - gr).norm() / gr.norm()) < 3e-3
+    f0.grad = None
+    e = torch.zeros(0, dtype=torch.int64).cuda()
+    p = ops.coarse_pos_conf(f0, f1, e, e, e, 0.1)
+    assert p.shape == (0,)
+    p.sum().backward()
+    assert float(f0.grad.abs().max()) == 0.0
