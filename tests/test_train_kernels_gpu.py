@@ -59,7 +59,7 @@ def test_k1_sparse_conf_forward_and_backward(N, hw, seed):
         err = float((g.double() - gr).abs().max())
         rel_fro = float((g.double() - gr).norm() / gr.norm())
         print(f'[k1 bwd] N={N} hw={hw} {name}: max|d| = {err:.3e} (max|ref| = {scale:.3e}), relative Frobenius error {rel_fro:.3e}')
-        assert rel_fro < 3e-3 and err < 1e-2 * scale, (name, rel_fro, err / scale)
+        assert rel_fro < 3e-4 and err < 1e-3 * scale, (name, rel_fro, err / scale)      # measured 2-5e-5 / 7e-5
 
 
 def test_k1_sparse_conf_arbitrary_upstream_gradient_and_empty():
@@ -81,10 +81,51 @@ def test_k1_sparse_conf_arbitrary_upstream_gradient_and_empty():
     r1 = torch.from_numpy(f1n).double().cuda().requires_grad_(True)
     _ref_pos_conf(r0, r1, pb, pi, pj, 0.1).backward(g.double())
     for g_, gr in ((f0.grad, r0.grad), (f1.grad, r1.grad)):
-        assert float((g_.double() - gr).norm() / gr.norm()) < 3e-3
+        assert float((g_.double() - gr).norm() / gr.norm()) < 1e-3
     f0.grad = None
     e = torch.zeros(0, dtype=torch.int64).cuda()
     p = ops.coarse_pos_conf(f0, f1, e, e, e, 0.1)
     assert p.shape == (0,)
     p.sum().backward()
     assert float(f0.grad.abs().max()) == 0.0
+
+
+def test_k1_training_path_in_model_matches_dense_autograd():
+    """The whole matcher in training mode, coarse loss only: K1's sparse HIP path (no conf_matrix) against the dense
+    differentiable vendor-op form (CoarseMatching.materialize_conf = True -> far_amd/autograd_ops.py) on the same
+    model and pair: same loss, same parameter gradients."""
+    from far_amd import synth
+    from far_amd.config import far_eval_config
+    from far_amd.loftr import LoFTR
+    from far_amd.losses import coarse_focal_loss
+    from tests.test_training_cpu import _train_helpers
+    cfg = far_eval_config()
+    cfg['regress_rt'] = False
+    m = LoFTR(cfg)
+    synth.load_synthetic(m, seed=0)
+    m = m.cuda().train()
+    im0, im1, ii, jj, _ = _train_helpers().train_inputs()
+    keys = ['backbone.layer3_outconv.weight', 'loftr_coarse.layers.0.q_proj.weight', 'loftr_coarse.layers.5.mlp.2.weight',
+            'loftr_coarse.layers.3.norm1.bias', 'backbone.conv1.weight']
+    P = dict(m.named_parameters())
+    res = {}
+    for mode in ('sparse', 'dense'):
+        m.coarse_matching.materialize_conf = mode == 'dense'
+        data = {'image0': torch.from_numpy(im0).cuda(), 'image1': torch.from_numpy(im1).cuda(),
+                'spv_b_ids': torch.zeros(len(ii), dtype=torch.int64).cuda(), 'spv_i_ids': torch.from_numpy(ii).cuda(),
+                'spv_j_ids': torch.from_numpy(jj).cuda()}
+        m.zero_grad()
+        torch.manual_seed(5)
+        m(data, train=True)
+        assert (data['conf_matrix'] is None) == (mode == 'sparse')
+        loss = coarse_focal_loss(data)
+        loss.backward()
+        res[mode] = (loss.item(), {k: P[k].grad.detach().double().clone() for k in keys}, len(data['b_ids']))
+    ls, gs, ns = res['sparse']
+    ld, gd, nd = res['dense']
+    assert ns == nd
+    assert abs(ls - ld) < 1e-4 * abs(ld), (ls, ld)
+    for k in keys:
+        rel = float((gs[k] - gd[k]).norm() / gd[k].norm())
+        print(f'[k1 in model] {k}: |grad| = {float(gd[k].norm()):.3e}, relative Frobenius difference {rel:.3e}')
+        assert rel < 3e-3, (k, rel)
