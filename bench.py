@@ -36,7 +36,10 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--pairs', type=int, default=PAIRS_PER_GPU, help='pairs per GPU per step')
+    ap.add_argument('--pairs', type=int, default=None, help='pairs per GPU per step (default: 32 for c2, 256 for c4)')
+    ap.add_argument('--workload', default='c2', choices=['c2', 'c4'],
+                    help="c2 = BASELINE configs[1] (the headline metric: match + solve + regress, batch 32); "
+                         "c4 = BASELINE configs[3] (cached-LoFTR path: GPU solver on cached correspondences + head, batch 256)")
     ap.add_argument('--hyp', type=int, default=2048, help='RANSAC hypotheses per pair (metrics.py:120)')
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'fp16-fine', 'fp16', 'bf16'],
                     help='backbone convolution arithmetic (far_amd.loftr.LoFTR.set_precision): fp32 = split-fp16 operand pairs (fp32-grade)')
@@ -239,8 +242,101 @@ def selftest_launcher(a):
         dist.destroy_process_group()
 
 
+def bench_c4(a, dev, world, rank, dist):
+    """BASELINE configs[3]: InteriorNet-T cached-LoFTR path -- no matcher; cached transformer features + cached fine
+    correspondences -> GPU solver (two rounds, the second with the head's pose as prior) + EMM head (two calls), batch 256
+    (far_amd.pipeline.cached_step).  A second JSON line shape: same contract keys, metric named for this workload."""
+    from far_amd import parallel
+    from far_amd.config import far_eval_config
+    from far_amd.loftr import LoFTR
+    from far_amd.pipeline import cached_step
+    from far_amd.supervision import compute_supervision_RT
+    from far_amd.config import RunCfg
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from tests.util import two_view_scene
+    B = a.pairs
+    cfg = far_eval_config()
+    cfg['from_saved_preds'] = 'loftr_preds'
+    model = LoFTR(cfg).eval()
+    man = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'g8_state_dict_manifest.json')))
+    from far_amd import synth
+    sd = synth.synthetic_state_dict({k: tuple(v) for k, v in man.items() if k.startswith('loftr_regress.')})
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model = model.to(dev)
+    g = torch.Generator(device=dev).manual_seed(4321 + rank)
+    f0 = torch.randn(B, L, C, device=dev, generator=g)
+    f1 = 0.5 * f0 + torch.randn(B, L, C, device=dev, generator=g)
+    rng = np.random.default_rng(99 + rank)
+    scenes = [two_view_scene(int(rng.integers(800, 2000)), seed=1000 * rank + b, outlier_frac=0.3) for b in range(B)]
+    cnt = [len(s_[0]) for s_ in scenes]
+    mk0 = torch.from_numpy(np.concatenate([s_[0] for s_ in scenes])).to(dev)
+    mk1 = torch.from_numpy(np.concatenate([s_[1] for s_ in scenes])).to(dev)
+    bids = torch.repeat_interleave(torch.arange(B), torch.tensor(cnt)).to(dev)
+    K = torch.from_numpy(np.stack([s_[2] for s_ in scenes])).to(dev)
+    base = {'featmap0': f0, 'featmap1': f1, 'mkpts0_f': mk0, 'mkpts1_f': mk1, 'm_bids': bids, 'b_ids': bids,
+            'match_counts': torch.tensor(cnt), 'K0': K, 'K1': K.clone(), 'dataset_name': ['interiornet_streetlearn']}
+
+    def step():
+        batch = dict(base)
+        cached_step(model, batch, H=a.hyp, seed=0)
+        return batch
+
+    prime = max(0, 3 - a.warmup)
+    for _ in range(prime + a.warmup):
+        last = step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        last = step()
+    fence()
+    dt = time.perf_counter() - t0
+    per_rank_ms = [round(1000 * x / a.steps, 3) for x in parallel.gather_floats(dt, device=dev)]
+    dt = parallel.max_over_ranks(dt, device=dev)
+    if rank == 0:
+        # K4 alone (one round with the head's prior): hypotheses per second
+        run = RunCfg('prior_ransac', 2)
+        t_solver = event_time_ms(lambda: compute_supervision_RT(dict(last), run, H=a.hyp, seed=0), iters=5, warm=2)
+        from far_amd import metrics as fm
+        Rgt = torch.from_numpy(np.stack([s_[3] for s_ in scenes])).to(dev)
+        tgt = torch.from_numpy(np.stack([s_[4] for s_ in scenes])).to(dev)
+        Tgt = torch.cat([Rgt, tgt[:, :, None]], 2)
+        rt = last['loftr_rt'].reshape(-1, 3, 4)
+        te, Re, _ = fm.relative_pose_error_batch(Tgt, rt[:, :, :3], rt[:, :, 3])
+        auc = fm.error_auc_device(torch.maximum(te, Re))
+        res = {
+            'metric': 'image-pairs/sec (solve+regress on cached LoFTR predictions) -- BASELINE configs[3], not the headline metric',
+            'value': round(world * B * a.steps / dt, 3), 'unit': 'image-pairs/sec', 'n_gpus': world, 'steps': a.steps,
+            'warmup': a.warmup, 'prime_steps': prime, 'ms_per_step': round(1000 * dt / a.steps, 3),
+            'per_rank_ms_per_step': per_rank_ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32 (head: split-f16x3 operands, fp32 accumulate) / f64 (solver)', 'data': 'synthetic',
+            'config': {'workload': 'InteriorNet-T-shaped cached-LoFTR path (BASELINE configs[3]): batch 256 pairs per GPU, cached '
+                                   'coarse features + 800-2000 cached correspondences per pair (30 % outliers), GPU 8-pt prior-RANSAC '
+                                   'solve (x2 rounds) + EMM head (x2), seeded random weights',
+                       'pairs_per_gpu': B, 'hypotheses': a.hyp, 'correspondences_per_pair': round(float(np.mean(cnt)), 1),
+                       'solver_success_frac': float(last['solver_status'].float().mean().item()),
+                       'solver_median_R_deg': round(float(Re.median()), 3), 'solver_median_t_deg': round(float(te.median()), 3),
+                       'solver_pose_auc': {k_: round(v_, 4) for k_, v_ in auc.items()},
+                       'parallelism': f'dp{world} (independent pairs, no data-path collective)'},
+            'k4': {'ms_per_round': round(t_solver, 3), 'hypotheses_per_sec': round(B * a.hyp / t_solver * 1e3, 1),
+                   'pairs_per_sec_solver_only': round(B / t_solver * 1e3, 1),
+                   'note': 'far_solver_f64 + far_pose_pack_f64, one prior-RANSAC round of the whole batch (HIP events)'},
+        }
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     a = parse()
+    if a.pairs is None:
+        a.pairs = 256 if a.workload == 'c4' else PAIRS_PER_GPU
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # plain `python bench.py --gpus N`: start the N ranks as children BEFORE this process initialises the GPU
         from far_amd import parallel
@@ -257,6 +353,8 @@ def main():
         import torch.distributed as dist
         dist.init_process_group(a.backend, device_id=dev if a.backend == 'nccl' else None)
         world = dist.get_world_size()            # the rank count the backend (RCCL) reports
+    if a.workload == 'c4':
+        return bench_c4(a, dev, world, rank, dist)
     from far_amd import synth
     from far_amd.config import far_eval_config
     from far_amd.loftr import LoFTR

@@ -40,6 +40,22 @@ def error_auc(errors, thresholds=(5, 10, 20)):
     return out
 
 
+def error_auc_device(errors, thresholds=(5, 10, 20)):
+    """error_auc (metrics.py:307-324) on the device the errors live on: sort + trapezoid rule as torch ops, one small
+    host read of the three numbers at the end (the per-pair errors never leave the GPU)."""
+    e = torch.sort(errors.reshape(-1).to(torch.float64))[0]
+    n = e.numel()
+    x = torch.cat([torch.zeros(1, dtype=torch.float64, device=e.device), e])
+    y = torch.linspace(0, 1, n + 1, dtype=torch.float64, device=e.device)
+    out = {}
+    for thr in (5, 10, 20):
+        last = int(torch.searchsorted(x, torch.tensor(float(thr), dtype=torch.float64, device=e.device)))
+        xs = torch.cat([x[:last], torch.tensor([float(thr)], dtype=torch.float64, device=e.device)])
+        ys = torch.cat([y[:last], y[last - 1:last]])
+        out[f'auc@{thr}'] = float(torch.trapezoid(ys, xs) / thr)
+    return out
+
+
 def aggregate_pose_metrics(t_errs, R_errs, t_errs_abs, successful_fits=None):
     """The pose part of aggregate_metrics (metrics.py:343-376)."""
     t_errs, R_errs, t_abs = (np.asarray(a, np.float64) for a in (t_errs, R_errs, t_errs_abs))

@@ -26,3 +26,24 @@ def test_step(matcher, batch, run_cfg=None, H=2048, seed=0):
         if i < steps - 1 and 'prior_ransac' in cfg.LOFTR.SOLVER:                    # :342
             compute_supervision_RT(batch, cfg, H=H, seed=seed)                      # :343
     return batch
+
+
+@torch.no_grad()
+def cached_step(matcher, batch, run_cfg=None, H=2048, seed=0):
+    """BASELINE configs[3], the cached-prediction path (`--from_saved_preds`): the matcher is not run; the batch carries
+    the cached transformer features (featmap0/1) and fine correspondences (mkpts0_f / mkpts1_f / m_bids, far_amd.cache_io).
+    The reference reads the solver pose from disk and runs the head only (lightning_loftr.py:326, :334); here the GPU
+    solver runs on the cached correspondences, so the same two solver rounds + two head calls as test_step execute:
+
+        compute_supervision_RT -> [forward_rt_prediction -> compute_supervision_RT] x (FINE_PRED_STEPS - 1) -> forward_rt_prediction
+    """
+    cfg = run_cfg or RunCfg(matcher.config['solver'], matcher.config.get('fine_pred_steps', 2))
+    batch['translation_scale'] = None
+    batch.pop('priorRT', None)
+    compute_supervision_RT(batch, cfg, H=H, seed=seed)
+    steps = cfg.LOFTR.FINE_PRED_STEPS
+    for i in range(steps):
+        matcher.forward_rt_prediction(batch)
+        if i < steps - 1 and 'prior_ransac' in cfg.LOFTR.SOLVER:
+            compute_supervision_RT(batch, cfg, H=H, seed=seed)
+    return batch

@@ -128,4 +128,4 @@ def test_k1_training_path_in_model_matches_dense_autograd():
     for k in keys:
         rel = float((gs[k] - gd[k]).norm() / gd[k].norm())
         print(f'[k1 in model] {k}: |grad| = {float(gd[k].norm()):.3e}, relative Frobenius difference {rel:.3e}')
-        assert rel < 3e-3, (k, rel)
+        assert rel < 1e-3, (k, rel)                                     # measured 0.9-2.6e-4
