@@ -8,6 +8,7 @@
 // scalings and the normaliser are fused.  Two streaming kernels (KV / K.sum per token chunk, then apply) plus a
 // tiny fixed-order reduction over chunks (deterministic, no atomics).
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
@@ -85,6 +86,12 @@ __global__ __launch_bounds__(256) void k_la_kv_partial(const float* __restrict__
 #pragma unroll
     for (int r = 0; r < M::NACC; ++r) o[(size_t)M::row(r, kk) * (D + 1) + col] = acc[r];
     if (kk == 0) o[(size_t)col * (D + 1) + D] = ks;
+}
+
+// kv [.][D + 1] rows: multiply the D x D part by f, leave the last (ksum) column (backward: undoes the forward's 1/S)
+__global__ void k_la_scale_kv(float* __restrict__ kv, long total, int D, float f) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < total && (e % (D + 1)) != D) kv[e] *= f;
 }
 
 // kv[n][HD][D+1] = sum over chunks (fixed order).
@@ -220,6 +227,222 @@ int far_linear_attention_f32(const float* q, const float* k, const float* v, int
     if (HD > 1024 || (HD % 64) != 0) return FAR_EINVAL;
     if (D == 32) return launch_la<32>(q, k, v, N, L, S, H, q_mask, kv_mask, eps, out, (float*)ws, stream);
     if (D == 16) return launch_la<16>(q, k, v, N, L, S, H, q_mask, kv_mask, eps, out, (float*)ws, stream);
+    return FAR_EINVAL;
+}
+
+}  // extern "C"
+
+// =====================================================================================================================
+// K5 backward (training path, BASELINE configs[2]): gradients of LinearAttention.forward w.r.t. the raw projections.
+// With Q' = elu(q) + 1, K' = elu(k) + 1 (masked), KV = K'^T V, ksum = sum_s K'_s, den_l = Q'_l . ksum + eps,
+// out_l = Q'_l KV / den_l  (the 1/S and *S of linear_attention.py:43,50 cancel), and g = dL/dout:
+//   dnum_l = g_l / den_l,   dden_l = -(g_l . out_l) / den_l
+//   dQ'_l  = dnum_l KV^T + dden_l ksum                        dq = dQ' * elu'(q)   (elu'(x) = 1 for x > 0, e^x otherwise)
+//   dKV    = sum_l Q'_l^T dnum_l,   dksum = sum_l dden_l Q'_l (the forward's K^T V kernel with a per-token weight)
+//   dK'_s  = dKV V_s + dksum,  dV_s = dKV^T K'_s              dk = dK' * elu'(k)
+// Token-parallel kernels (one thread = one token of one head; the head's D x D matrices in LDS), bandwidth-bound like
+// the forward; the token reductions reuse k_la_kv_partial / k_la_kv_reduce (fixed order: deterministic).
+// =====================================================================================================================
+namespace {
+
+__device__ __forceinline__ float elu1_grad(float x) { return x > 0.f ? 1.f : expf(x); }
+
+// per (n, head, token l): recompute num / den, write dq, dnum (workspace [N][L][HD]) and dden (workspace [N][L][H])
+template <int D>
+__global__ __launch_bounds__(256) void k_la_bwd_q(const float* __restrict__ q, const float* __restrict__ g,
+                                                  const float* __restrict__ kv, const uint8_t* __restrict__ q_mask, int N, int L,
+                                                  int H, float eps, float* __restrict__ dq, float* __restrict__ dnum,
+                                                  float* __restrict__ dden) {
+    __shared__ float s_kv[D][D + 1];
+    __shared__ float s_ks[D];
+    const int h = blockIdx.y, n = blockIdx.z, HD = H * D;
+    const float* kvn = kv + ((size_t)n * HD + h * D) * (D + 1);
+    for (int e = threadIdx.x; e < D * (D + 1); e += blockDim.x) {
+        const int d = e / (D + 1), c = e - d * (D + 1);
+        if (c < D) s_kv[d][c] = kvn[e]; else s_ks[d] = kvn[e];
+    }
+    __syncthreads();
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= L) return;
+    const size_t off = ((size_t)n * L + l) * HD + h * D;
+    const float m = q_mask ? (q_mask[(size_t)n * L + l] ? 1.f : 0.f) : 1.f;
+    float qr[D], Q[D], G[D];
+#pragma unroll
+    for (int d4 = 0; d4 < D / 4; ++d4) {
+        const float4 a = *reinterpret_cast<const float4*>(q + off + 4 * d4), b = *reinterpret_cast<const float4*>(g + off + 4 * d4);
+        qr[4 * d4] = a.x; qr[4 * d4 + 1] = a.y; qr[4 * d4 + 2] = a.z; qr[4 * d4 + 3] = a.w;
+        G[4 * d4] = b.x; G[4 * d4 + 1] = b.y; G[4 * d4 + 2] = b.z; G[4 * d4 + 3] = b.w;
+    }
+    float den = eps;
+#pragma unroll
+    for (int d = 0; d < D; ++d) { Q[d] = elu1(qr[d]) * m; den += Q[d] * s_ks[d]; }
+    const float rden = 1.0f / den;
+    float go = 0.f;                                        // g . num
+    float dn[D];
+#pragma unroll
+    for (int v = 0; v < D; ++v) {
+        float num = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) num += Q[d] * s_kv[d][v];
+        go += G[v] * num;
+        dn[v] = G[v] * rden;
+    }
+    const float dd = -(go * rden) * rden;                  // -(g . out) / den
+    float o4[4];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        float a = dd * s_ks[d];
+#pragma unroll
+        for (int v = 0; v < D; ++v) a += dn[v] * s_kv[d][v];
+        o4[d & 3] = a * m * elu1_grad(qr[d]);
+        if ((d & 3) == 3) *reinterpret_cast<float4*>(dq + off + d - 3) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+    }
+#pragma unroll
+    for (int d4 = 0; d4 < D / 4; ++d4)
+        *reinterpret_cast<float4*>(dnum + off + 4 * d4) = make_float4(dn[4 * d4], dn[4 * d4 + 1], dn[4 * d4 + 2], dn[4 * d4 + 3]);
+    dden[((size_t)n * L + l) * H + h] = dd;
+}
+
+// dKV / dksum partials: the forward's K^T V accumulation with (K -> Q', V -> dnum) and ksum weighted by dden per token
+template <int D>
+__global__ __launch_bounds__(256) void k_la_bwd_dkv_partial(const float* __restrict__ q, const float* __restrict__ dnum,
+                                                            const float* __restrict__ dden, const uint8_t* __restrict__ q_mask,
+                                                            int N, int L, int H, int tok_per_chunk, int nchunk,
+                                                            float* __restrict__ part) {
+    typedef Mf<D> M;
+    const int lane = threadIdx.x & 63, col = lane & (D - 1), kk = lane >> M::SHIFT;
+    const long unit = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (unit >= (long)N * nchunk * H) return;
+    const int h = (int)(unit % H);
+    const int ch = (int)((unit / H) % nchunk);
+    const int n = (int)(unit / ((long)H * nchunk));
+    const int HD = H * D;
+    const int s0 = ch * tok_per_chunk, s1 = min(L, s0 + tok_per_chunk);
+    typename M::acc_t acc;
+#pragma unroll
+    for (int r = 0; r < M::NACC; ++r) acc[r] = 0.f;
+    float ks = 0.f;
+    for (int sb = s0; sb < s1; sb += M::KPER) {
+        const int s = sb + kk;
+        float a = 0.f, b = 0.f, w = 0.f;
+        if (s < s1) {
+            const size_t o = ((size_t)n * L + s) * HD + h * D + col;
+            const float m = q_mask ? (q_mask[(size_t)n * L + s] ? 1.f : 0.f) : 1.f;
+            a = elu1(q[o]) * m;
+            b = dnum[o];
+            w = dden[((size_t)n * L + s) * H + h];
+        }
+        ks += a * w;
+        acc = M::mma(a, b, acc);
+    }
+#pragma unroll
+    for (int d = D; d < 64; d <<= 1) ks += shfl_xor_f(ks, d);
+    float* o = part + (((size_t)n * nchunk + ch) * HD + h * D) * (D + 1);
+#pragma unroll
+    for (int r = 0; r < M::NACC; ++r) o[(size_t)M::row(r, kk) * (D + 1) + col] = acc[r];
+    if (kk == 0) o[(size_t)col * (D + 1) + D] = ks;
+}
+
+// per (n, head, token s): dk = (dKV V_s + dksum) * elu'(k) * mask,  dv = dKV^T K'_s * mask
+template <int D>
+__global__ __launch_bounds__(256) void k_la_bwd_kv(const float* __restrict__ k, const float* __restrict__ v,
+                                                   const float* __restrict__ dkv, const uint8_t* __restrict__ kv_mask, int N, int S,
+                                                   int H, float* __restrict__ dk, float* __restrict__ dv) {
+    __shared__ float s_kv[D][D + 1];
+    __shared__ float s_ks[D];
+    const int h = blockIdx.y, n = blockIdx.z, HD = H * D;
+    const float* kvn = dkv + ((size_t)n * HD + h * D) * (D + 1);
+    for (int e = threadIdx.x; e < D * (D + 1); e += blockDim.x) {
+        const int d = e / (D + 1), c = e - d * (D + 1);
+        if (c < D) s_kv[d][c] = kvn[e]; else s_ks[d] = kvn[e];
+    }
+    __syncthreads();
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const size_t off = ((size_t)n * S + s) * HD + h * D;
+    const float m = kv_mask ? (kv_mask[(size_t)n * S + s] ? 1.f : 0.f) : 1.f;
+    float kr[D], V[D];
+#pragma unroll
+    for (int d4 = 0; d4 < D / 4; ++d4) {
+        const float4 a = *reinterpret_cast<const float4*>(k + off + 4 * d4), b = *reinterpret_cast<const float4*>(v + off + 4 * d4);
+        kr[4 * d4] = a.x; kr[4 * d4 + 1] = a.y; kr[4 * d4 + 2] = a.z; kr[4 * d4 + 3] = a.w;
+        V[4 * d4] = b.x * m; V[4 * d4 + 1] = b.y * m; V[4 * d4 + 2] = b.z * m; V[4 * d4 + 3] = b.w * m;
+    }
+    float o4[4];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        float a = s_ks[d];
+#pragma unroll
+        for (int c = 0; c < D; ++c) a += s_kv[d][c] * V[c];
+        o4[d & 3] = a * m * elu1_grad(kr[d]);
+        if ((d & 3) == 3) *reinterpret_cast<float4*>(dk + off + d - 3) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+    }
+    float Kp[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) Kp[d] = elu1(kr[d]) * m;
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        float a = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) a += Kp[d] * s_kv[d][c];
+        o4[c & 3] = a * m;
+        if ((c & 3) == 3) *reinterpret_cast<float4*>(dv + off + c - 3) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+    }
+}
+
+template <int D>
+int launch_la_bwd(const float* q, const float* k, const float* v, const float* g, int N, int L, int S, int H,
+                  const uint8_t* q_mask, const uint8_t* kv_mask, float eps, float* dq, float* dk, float* dv, float* ws,
+                  hipStream_t stream) {
+    const int HD = H * D;
+    const size_t per_n = (size_t)HD * (D + 1);
+    // 1. KV / ksum of the forward, recomputed WITHOUT the 1/S of values (it cancels against the final *S)
+    int tpc = S >= 1024 ? 320 : S, nch = (S + tpc - 1) / tpc;
+    int tpl = L >= 1024 ? 320 : L, ncl = (L + tpl - 1) / tpl;
+    float* part = ws;                                                     // max(nch, ncl) * N * per_n
+    float* kv = part + (size_t)N * std::max(nch, ncl) * per_n;            // N * per_n
+    float* dkv = kv + (size_t)N * per_n;                                  // N * per_n
+    float* dnum = dkv + (size_t)N * per_n;                                // N * L * HD
+    float* dden = dnum + (size_t)N * L * HD;                              // N * L * H
+    long units = (long)N * nch * H;
+    hipLaunchKernelGGL(k_la_kv_partial<D>, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, stream, k, v, kv_mask, N, S, H, tpc, nch,
+                       nch == 1 ? kv : part);
+    if (nch > 1) hipLaunchKernelGGL(k_la_kv_reduce, dim3((int)((per_n + 255) / 256) * N), dim3(256), 0, stream, part, nch, (int)per_n, kv);
+    // k_la_kv_partial divides the values by S: undo it on the D x D block (ksum column is unscaled)
+    hipLaunchKernelGGL(k_la_scale_kv, dim3((unsigned)((N * per_n + 255) / 256)), dim3(256), 0, stream, kv, (long)N * per_n, D, (float)S);
+    // 2. per query token: dq, dnum, dden
+    hipLaunchKernelGGL(k_la_bwd_q<D>, dim3((L + 255) / 256, H, N), dim3(256), 0, stream, q, g, kv, q_mask, N, L, H, eps, dq, dnum, dden);
+    // 3. dKV, dksum
+    units = (long)N * ncl * H;
+    hipLaunchKernelGGL(k_la_bwd_dkv_partial<D>, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, stream, q, dnum, dden, q_mask, N, L, H,
+                       tpl, ncl, ncl == 1 ? dkv : part);
+    if (ncl > 1) hipLaunchKernelGGL(k_la_kv_reduce, dim3((int)((per_n + 255) / 256) * N), dim3(256), 0, stream, part, ncl, (int)per_n, dkv);
+    // 4. per key token: dk, dv
+    hipLaunchKernelGGL(k_la_bwd_kv<D>, dim3((S + 255) / 256, H, N), dim3(256), 0, stream, k, v, dkv, kv_mask, N, S, H, dk, dv);
+    return far_check_launch();
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t far_linear_attention_bwd_workspace_bytes(int N, int L, int S, int H, int D) {
+    const size_t per_n = (size_t)H * D * (D + 1);
+    const int nch = (S + (S >= 1024 ? 320 : S) - 1) / (S >= 1024 ? 320 : S), ncl = (L + (L >= 1024 ? 320 : L) - 1) / (L >= 1024 ? 320 : L);
+    return ((size_t)N * std::max(nch, ncl) * per_n + 2 * (size_t)N * per_n + (size_t)N * L * H * D + (size_t)N * L * H) * sizeof(float);
+}
+
+// Gradients of far_linear_attention_f32 w.r.t. q, k, v given g = dL/dout (all [N][tokens][H*D] fp32, contiguous).
+int far_linear_attention_bwd_f32(const float* q, const float* k, const float* v, const float* g, int N, int L, int S, int H, int D,
+                                 const uint8_t* q_mask, const uint8_t* kv_mask, float eps, float* dq, float* dk, float* dv,
+                                 void* ws, hipStream_t stream) {
+    far_clear_errors();
+    if (N == 0) return FAR_OK;
+    if (!q || !k || !v || !g || !dq || !dk || !dv || !ws || N < 0 || L <= 0 || S <= 0) return FAR_EINVAL;
+    const int HD = H * D;
+    if (HD > 1024 || (HD % 64) != 0) return FAR_EINVAL;
+    if (D == 32) return launch_la_bwd<32>(q, k, v, g, N, L, S, H, q_mask, kv_mask, eps, dq, dk, dv, (float*)ws, stream);
+    if (D == 16) return launch_la_bwd<16>(q, k, v, g, N, L, S, H, q_mask, kv_mask, eps, dq, dk, dv, (float*)ws, stream);
     return FAR_EINVAL;
 }
 

@@ -34,8 +34,11 @@ class LinearAttention(nn.Module):
     def forward(self, queries, keys, values, q_mask=None, kv_mask=None, loftr_preds=None):
         N, L, H, D = queries.shape
         S = keys.shape[1]
-        if ag.needs_grad(queries, keys, values):      # training: vendor ops + autograd (kernels are forward-only)
-            return ag.linear_attention(queries.reshape(N, L, H * D), keys.reshape(N, S, H * D),
+        if ag.needs_grad(queries, keys, values):
+            if queries.is_cuda and D in (16, 32):     # training on the GPU: K5 forward + K5 backward kernels
+                return ops.linear_attention_train(queries.reshape(N, L, H * D), keys.reshape(N, S, H * D),
+                                                  values.reshape(N, S, H * D), H, q_mask, kv_mask, self.eps).view(N, L, H, D)
+            return ag.linear_attention(queries.reshape(N, L, H * D), keys.reshape(N, S, H * D),       # CPU: vendor ops
                                        values.reshape(N, S, H * D), H, q_mask, kv_mask, self.eps).view(N, L, H, D)
         as_u8 = lambda m: None if m is None else m.to(torch.uint8).contiguous()
         out = ops.linear_attention(queries.reshape(N, L, H * D), keys.reshape(N, S, H * D),
@@ -45,6 +48,7 @@ class LinearAttention(nn.Module):
 
 class LoFTREncoderLayer(nn.Module):
     split_operands = True        # K9 operand precision of the Linear layers (False: plain fp16, LoFTR.set_precision)
+    hip_training = True          # training on the GPU runs K9 / K5 (forward + backward kernels); False: vendor ops + autograd
 
     def __init__(self, d_model, nhead, attention='linear', use_num_corres=False):
         super().__init__()
@@ -67,8 +71,21 @@ class LoFTREncoderLayer(nn.Module):
 
     def forward(self, x, source, x_mask=None, source_mask=None, loftr_preds=None, out=None):
         bs = x.size(0)
-        if ag.needs_grad(x, source, self.norm1.weight) or not x.is_cuda:     # training: reference-style modules
-            q = self.q_proj(x).view(bs, -1, self.nhead, self.dim)
+        if ag.needs_grad(x, source, self.norm1.weight) or not x.is_cuda:
+            if x.is_cuda and self.hip_training:
+                # training on the GPU: the five Linear layers on K9 (forward and dgrad; wgrad = one library GEMM), the
+                # attention core on K5 forward + backward; LayerNorm / ReLU / residual are torch elementwise ops
+                pk = self.__dict__.setdefault('_packs', ops.PackCache())
+                sp = self.split_operands
+                lin = lambda t, mod, name: ops.linear_train(t, mod.weight, mod.bias, pk, ('train', name), split=sp)
+                q = lin(x, self.q_proj, 'q').view(bs, -1, self.nhead, self.dim)
+                k = lin(source, self.k_proj, 'k').view(bs, -1, self.nhead, self.dim)
+                v = lin(source, self.v_proj, 'v').view(bs, -1, self.nhead, self.dim)
+                msg = self.attention(q, k, v, q_mask=x_mask, kv_mask=source_mask, loftr_preds=loftr_preds)
+                msg = self.norm1(lin(msg.view(bs, -1, self.nhead * self.dim), self.merge, 'merge'))
+                msg = lin(torch.relu(lin(torch.cat([x, msg], dim=2), self.mlp[0], 'mlp0')), self.mlp[2], 'mlp2')
+                return x + self.norm2(msg)
+            q = self.q_proj(x).view(bs, -1, self.nhead, self.dim)                  # CPU: reference-style modules
             k = self.k_proj(source).view(bs, -1, self.nhead, self.dim)
             v = self.v_proj(source).view(bs, -1, self.nhead, self.dim)
             msg = self.attention(q, k, v, q_mask=x_mask, kv_mask=source_mask, loftr_preds=loftr_preds)

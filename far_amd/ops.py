@@ -266,6 +266,75 @@ def linear_attention(q, k, v, nhead, q_mask=None, kv_mask=None, eps=1e-6):
     return out
 
 
+class _LinearAttentionFn(torch.autograd.Function):
+    """K5 with its HIP backward (far_linear_attention_f32 / far_linear_attention_bwd_f32)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, nhead, q_mask, kv_mask, eps):
+        qc, kc, vc = (t.detach().float().contiguous() for t in (q, k, v))
+        out = linear_attention(qc, kc, vc, nhead, q_mask, kv_mask, eps)
+        ctx.save_for_backward(qc, kc, vc, q_mask if q_mask is not None else torch.empty(0), kv_mask if kv_mask is not None else torch.empty(0))
+        ctx.nhead, ctx.eps, ctx.has = nhead, eps, (q_mask is not None, kv_mask is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        qc, kc, vc, qm, km = ctx.saved_tensors
+        qm = qm if ctx.has[0] else None
+        km = km if ctx.has[1] else None
+        N, L, C = qc.shape
+        S = kc.shape[1]
+        D = C // ctx.nhead
+        g = g.float().contiguous()
+        dq, dk, dv = torch.empty_like(qc), torch.empty_like(kc), torch.empty_like(vc)
+        if N:
+            ws = _ws(lib.far_linear_attention_bwd_workspace_bytes(N, L, S, ctx.nhead, D), qc.device)
+            rc = lib.far_linear_attention_bwd_f32(_p(qc), _p(kc), _p(vc), _p(g, torch.float32), N, L, S, ctx.nhead, D,
+                                                  _p(qm, torch.uint8), _p(km, torch.uint8), float(ctx.eps), _p(dq), _p(dk), _p(dv),
+                                                  _p(ws), _stream())
+            _lib.check(rc, 'far_linear_attention_bwd_f32')
+        return dq, dk, dv, None, None, None, None
+
+
+def linear_attention_train(q, k, v, nhead, q_mask=None, kv_mask=None, eps=1e-6):
+    """K5 with gradients: q (N, L, C), k, v (N, S, C) raw projections -> (N, L, C)."""
+    as_u8 = lambda m: None if m is None else m.to(torch.uint8).contiguous()
+    return _LinearAttentionFn.apply(q, k, v, nhead, as_u8(q_mask), as_u8(kv_mask), eps)
+
+
+class _LinearF16sFn(torch.autograd.Function):
+    """y = x W^T (+ b) on K9 with gradients: dx = dy W is K9 again (the weight packed transposed: a Linear layer whose
+    weight is W^T), dW = dy^T x is one library GEMM over all rows (a 256 x 256 output reduced over 10^5 rows is a plain
+    split-K vendor GEMM, not an implicit-GEMM shape), db = column sums."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, pack, pack_t):
+        xc = x.detach().float().contiguous()
+        y = linear_f16s(xc, pack())
+        ctx.save_for_backward(xc, weight)
+        ctx.pack_t, ctx.has_bias = pack_t, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        xc, weight = ctx.saved_tensors
+        g = g.float().contiguous()
+        dx = linear_f16s(g, ctx.pack_t()) if ctx.needs_input_grad[0] else None
+        g2, x2 = g.reshape(-1, g.shape[-1]), xc.reshape(-1, xc.shape[-1])
+        dw = g2.t().mm(x2) if ctx.needs_input_grad[1] else None
+        db = g2.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dw, db, None, None
+
+
+def linear_train(x, weight, bias, cache, name, split=True):
+    """K9 Linear with gradients.  cache: a PackCache; name: key prefix of this layer's forward / transposed weight images."""
+    pack = lambda: cache.get((name, split), [weight] + ([bias] if bias is not None else []),
+                             lambda: PackedConv(weight, None, bias, split=split))
+    pack_t = lambda: cache.get((name, 'T', split), [weight], lambda: PackedConv(weight.detach().t().contiguous(), split=split))
+    return _LinearF16sFn.apply(x, weight, bias, pack, pack_t)
+
+
 def solve_pose_batch(kpts0, kpts1, offsets_host, K0, K1, inl_th, many_thr, priorRT=None, pcl=None,
                      prior_lambda=0.3, H=2048, seed=0, samples=None, debug=False):
     """K4.  kpts0/kpts1: (Mtot, 2) fp32 GPU; offsets_host: python list / CPU int tensor of B+1 offsets;

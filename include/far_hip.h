@@ -182,6 +182,14 @@ int far_linear_attention_f32(const float* q, const float* k, const float* v, int
                              const uint8_t* q_mask, const uint8_t* kv_mask, float eps, float* out, void* ws,
                              far_stream_t stream);
 
+/* K5 backward (training path): gradients of far_linear_attention_f32 w.r.t. the raw projections q, k, v given
+ * g = dL/dout -- what autograd derives from linear_attention.py:31-50 in the reference.  Token-parallel kernels with the
+ * head's D x D matrices in LDS; the token reductions (dKV, dksum) in fixed order (deterministic). */
+size_t far_linear_attention_bwd_workspace_bytes(int N, int L, int S, int H, int D);
+int far_linear_attention_bwd_f32(const float* q, const float* k, const float* v, const float* g, int N, int L, int S,
+                                 int H, int D, const uint8_t* q_mask, const uint8_t* kv_mask, float eps,
+                                 float* dq, float* dk, float* dv, void* ws, far_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * K6  LayerNorm (+ fused residual) of the encoder layers and the head
  * replaces src/loftr/loftr_module/transformer.py:61, :65-67 (norm1; norm2 + `x + message`), :342, :346, :426

@@ -129,3 +129,60 @@ def test_k1_training_path_in_model_matches_dense_autograd():
         rel = float((gs[k] - gd[k]).norm() / gd[k].norm())
         print(f'[k1 in model] {k}: |grad| = {float(gd[k].norm()):.3e}, relative Frobenius difference {rel:.3e}')
         assert rel < 1e-3, (k, rel)                                     # measured 0.9-2.6e-4
+
+
+@pytest.mark.parametrize('N,L,S,H,D,masked', [(2, 4800, 4800, 8, 32, False), (3, 25, 25, 8, 16, False), (2, 700, 900, 8, 32, True)])
+def test_k5_linear_attention_backward(N, L, S, H, D, masked):
+    """far_linear_attention_bwd_f32 against float64 autograd of linear_attention.py:31-50 (far_amd/autograd_ops.py)."""
+    from far_amd import autograd_ops as ag
+    from far_amd import ops
+    rng = np.random.default_rng(L + S)
+    mk = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32)).cuda()
+    q, k, v, g = mk(N, L, H * D), mk(N, S, H * D), mk(N, S, H * D), mk(N, L, H * D)
+    qm = km = None
+    if masked:
+        qm = torch.from_numpy(rng.random((N, L)) > 0.2).cuda()
+        km = torch.from_numpy(rng.random((N, S)) > 0.3).cuda()
+    a = [t.clone().requires_grad_(True) for t in (q, k, v)]
+    out = ops.linear_attention_train(a[0], a[1], a[2], H, qm, km)
+    out.backward(g)
+    r = [t.double().clone().requires_grad_(True) for t in (q, k, v)]
+    ref = ag.linear_attention(r[0], r[1], r[2], H, None if qm is None else qm.double(), None if km is None else km.double())
+    ref.backward(g.double())
+    assert float((out.double() - ref).abs().max()) < 1e-4 * float(ref.abs().max())
+    for name, x, y in zip('qkv', a, r):
+        rel = float((x.grad.double() - y.grad).norm() / y.grad.norm())
+        print(f'[k5 bwd] N={N} L={L} S={S} D={D} masked={masked} d{name}: relative Frobenius error {rel:.3e}')
+        assert rel < 2e-5, (name, rel)
+
+
+def test_encoder_layer_training_on_hip_matches_vendor_autograd():
+    """LoFTREncoderLayer in training mode: K9 (forward + dgrad) / K5 (forward + backward) against the reference-style
+    vendor-op modules with autograd (hip_training = False) -- outputs and every gradient."""
+    from far_amd.loftr.transformer import LoFTREncoderLayer
+    torch.manual_seed(0)
+    layer = LoFTREncoderLayer(256, 8).cuda().train()
+    for p in layer.parameters():
+        if p.dim() > 1:
+            torch.nn.init.xavier_uniform_(p)
+    x0 = torch.randn(2, 4800, 256, device='cuda')
+    s0 = torch.randn(2, 4800, 256, device='cuda')
+    g = torch.randn(2, 4800, 256, device='cuda')
+    res = {}
+    for mode in (True, False):
+        layer.hip_training = mode
+        layer.zero_grad()
+        x, s = x0.clone().requires_grad_(True), s0.clone().requires_grad_(True)
+        y = layer(x, s)
+        y.backward(g)
+        res[mode] = (y.detach(), x.grad, s.grad, {k: p.grad.clone() for k, p in layer.named_parameters()})
+    yh, xh, sh, ph = res[True]
+    yv, xv, sv, pv = res[False]
+    assert float((yh - yv).abs().max()) < 1e-4 * float(yv.abs().max())
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    print(f'[encoder train] dx {rel(xh, xv):.3e}  dsource {rel(sh, sv):.3e}')
+    assert rel(xh, xv) < 1e-4 and rel(sh, sv) < 1e-4
+    for k in pv:
+        r = rel(ph[k], pv[k])
+        print(f'[encoder train] d{k}: {r:.3e}')
+        assert r < 1e-4, (k, r)
