@@ -153,7 +153,7 @@ def test_k5_linear_attention_backward(N, L, S, H, D, masked):
     for name, x, y in zip('qkv', a, r):
         rel = float((x.grad.double() - y.grad).norm() / y.grad.norm())
         print(f'[k5 bwd] N={N} L={L} S={S} D={D} masked={masked} d{name}: relative Frobenius error {rel:.3e}')
-        assert rel < 2e-5, (name, rel)
+        assert rel < 5e-6, (name, rel)                                   # measured <= 9e-7
 
 
 def test_encoder_layer_training_on_hip_matches_vendor_autograd():
@@ -181,8 +181,8 @@ def test_encoder_layer_training_on_hip_matches_vendor_autograd():
     assert float((yh - yv).abs().max()) < 1e-4 * float(yv.abs().max())
     rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
     print(f'[encoder train] dx {rel(xh, xv):.3e}  dsource {rel(sh, sv):.3e}')
-    assert rel(xh, xv) < 1e-4 and rel(sh, sv) < 1e-4
+    assert rel(xh, xv) < 1e-5 and rel(sh, sv) < 1e-5                 # measured 3e-7 / 1e-6
     for k in pv:
         r = rel(ph[k], pv[k])
         print(f'[encoder train] d{k}: {r:.3e}')
-        assert r < 1e-4, (k, r)
+        assert r < 1e-5, (k, r)                                          # measured <= 1.7e-6
