@@ -386,4 +386,15 @@ int far_emm_pv_f16s(const float* q, const float* k, const float* v, const float*
     return far_check_launch();
 }
 
+// The softmax statistics far_emm_pv_f16s left in its workspace, for the backward kernels (emm_bilinear_bwd_f16.hip):
+// rowstat[z][i] = (max, sum) over keys of query row i, colstat[z][j] over queries of key column j (log2 domain).
+int far_emm_pv_f16s_copy_stats(const void* ws, int Z, int N, float* rowstat_out, float* colstat_out, hipStream_t stream) {
+    far_clear_errors();
+    if (!ws || !rowstat_out || !colstat_out || Z <= 0 || N <= 0) return FAR_EINVAL;
+    const EmmWs w = carve(const_cast<void*>(ws), Z, N);
+    hipMemcpyAsync(rowstat_out, w.rowstat, (size_t)Z * N * 8, hipMemcpyDeviceToDevice, stream);
+    hipMemcpyAsync(colstat_out, w.colstat, (size_t)Z * N * 8, hipMemcpyDeviceToDevice, stream);
+    return far_check_launch();
+}
+
 }  // extern "C"

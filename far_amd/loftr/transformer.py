@@ -200,6 +200,8 @@ def positional_table(h=60, w=80):
 
 
 class CrossAttention(nn.Module):
+    hip_training = True          # training on the GPU runs K2's forward + backward kernels; False: vendor ops + autograd
+
     def __init__(self, dim, num_heads=8, qkv_bias=False, attn_drop=0., proj_drop=0.):
         super().__init__()
         self.num_heads = num_heads
@@ -219,7 +221,11 @@ class CrossAttention(nn.Module):
             q, k, v = qkv[0], qkv[1], qkv[2]                           # each (2, B, h, N, d); index 0 = image 1
             # direction 1: attn_1 = q2 k1^T, contracted with v1 (:275,:291); direction 2: q1 k2^T with v2 (:276,:292)
             qq = torch.stack([q[1], q[0]], 0).reshape(2 * B * h, N, d)
-            F = ag.bilinear_attention(qq, k.reshape(2 * B * h, N, d), v.reshape(2 * B * h, N, d), self.pos6, self.scale)
+            kk, vv = k.reshape(2 * B * h, N, d), v.reshape(2 * B * h, N, d)
+            if x1.is_cuda and d == 64 and self.hip_training:       # K2 forward + backward kernels
+                F = ops.emm_bilinear_train(qq, kk, vv, self.pos6, self.scale)
+            else:                                                  # CPU: vendor ops + autograd (dense score tensors)
+                F = ag.bilinear_attention(qq, kk, vv, self.pos6, self.scale)
         else:
             # inference: the qkv Linear on K9 with one output plane per (tensor, head) -- the layout K2 reads in place
             pk = self.__dict__.setdefault('_packs', ops.PackCache())

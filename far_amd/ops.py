@@ -190,6 +190,72 @@ def emm_bilinear(q, k, v, pos, scale, exact_f32=False):
     return torch.bmm(vt.transpose(1, 2), T), T
 
 
+def _emm_pv(q, k, v, pos, scale, want_stats=False):
+    """far_emm_pv_f16s on contiguous (Z, N, 64) operands -> T = P [v | pos] (Z, N, 70) (+ the softmax statistics)."""
+    lib = _lib.load()
+    Z, N, D = q.shape
+    T = torch.empty(Z, N, 70, dtype=torch.float32, device=q.device)
+    ws = _ws(lib.far_emm_pv_f16s_workspace_bytes(Z, N), q.device)
+    rc = lib.far_emm_pv_f16s(_p(q, torch.float32), _p(k, torch.float32), _p(v, torch.float32), _p(pos, torch.float32),
+                             Z, N, D, float(scale), 1, 0, N * D, 0, _p(ws), _p(T), _stream())
+    _lib.check(rc, 'far_emm_pv_f16s')
+    if not want_stats:
+        return T
+    rs = torch.empty(Z, N, 2, dtype=torch.float32, device=q.device)
+    cs = torch.empty(Z, N, 2, dtype=torch.float32, device=q.device)
+    rc = lib.far_emm_pv_f16s_copy_stats(_p(ws), Z, N, _p(rs), _p(cs), _stream())
+    _lib.check(rc, 'far_emm_pv_f16s_copy_stats')
+    return T, rs, cs
+
+
+class _EmmBilinearFn(torch.autograd.Function):
+    """F = vt^T P vt of the EMM head (K2) with its HIP backward: dq, dk from far_emm_bwd_f16 (recomputed score / dP
+    tiles on the f16 matrix cores), dv from two (N x 70)(70 x 70) products; no (Z, N, N) tensor in either direction."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, pos, scale):
+        qc, kc, vc = (t.detach().float().contiguous() for t in (q, k, v))
+        posc = pos.detach().float().contiguous()
+        T, rs, cs = _emm_pv(qc, kc, vc, posc, scale, want_stats=True)
+        vt = torch.cat([vc, posc.unsqueeze(0).expand(vc.shape[0], -1, -1)], dim=2)           # (Z, N, 70)
+        ctx.save_for_backward(qc, kc, vc, posc, T, rs, cs)
+        ctx.scale = float(scale)
+        return torch.bmm(vt.transpose(1, 2), T)
+
+    @staticmethod
+    def backward(ctx, dF):
+        lib = _lib.load()
+        qc, kc, vc, posc, T, rs, cs = ctx.saved_tensors
+        Z, N, D = qc.shape
+        dF = dF.float().contiguous()
+        vt = torch.cat([vc, posc.unsqueeze(0).expand(Z, -1, -1)], dim=2).contiguous()
+        # T' = P^T vt: the forward kernel with the roles of q and k exchanged (the dual softmax is symmetric under it)
+        Tp = _emm_pv(kc, qc, vc, posc, ctx.scale)
+        A = torch.bmm(vt, dF)                                                                  # vt dF
+        Bm = torch.bmm(vt, dF.transpose(1, 2))                                                 # vt dF^T
+        dvt = torch.bmm(T, dF.transpose(1, 2)) + torch.bmm(Tp, dF)
+        # common power-of-two scale so that max |A|, |B| ~ 1 (fp16 operands of the dP tiles); undone on dq, dk
+        amax = torch.maximum(A.abs().amax(), Bm.abs().amax()).clamp_min(1e-30)
+        alpha = torch.exp2(-torch.ceil(torch.log2(amax)))
+        u = ((A * T).sum(-1) * alpha).contiguous()
+        vw = ((Bm * Tp).sum(-1) * alpha).contiguous()
+        A = (A * alpha).contiguous()
+        dq, dk = torch.empty_like(qc), torch.empty_like(kc)
+        ws = _ws(lib.far_emm_bwd_workspace_bytes(Z, N), qc.device)
+        rc = lib.far_emm_bwd_f16(_p(qc), _p(kc), _p(vt, torch.float32), _p(A, torch.float32), _p(u, torch.float32),
+                                 _p(vw, torch.float32), _p(rs), _p(cs), Z, N, ctx.scale, _p(dq), _p(dk), _p(ws), _stream())
+        _lib.check(rc, 'far_emm_bwd_f16')
+        inv = 1.0 / alpha
+        return dq * inv, dk * inv, dvt[:, :, :D].contiguous(), None, None
+
+
+def emm_bilinear_train(q, k, v, pos, scale):
+    """K2 with gradients: q, k, v (Z, N, 64), pos (N, 6) -> F (Z, 70, 70)."""
+    if not q.is_cuda:
+        raise _lib.FarHipError('far_amd ops need tensors on the GPU (no CPU fallback exists)')
+    return _EmmBilinearFn.apply(q, k, v, pos, scale)
+
+
 def emm_bilinear_planes(qkv, pos, scale, B):
     """K2 on the output of the head's fused q | k | v projection: qkv (12, 2B, N, 64) = (tensor t, head) planes of
     [image, pair][N][64] (ops.linear_f16s(..., out_planes=12)).  Problem z = (direction, pair, head); direction d pairs

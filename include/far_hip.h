@@ -149,6 +149,18 @@ size_t far_emm_pv_f16s_workspace_bytes(int Z, int N);
 int far_emm_pv_f16s(const float* q, const float* k, const float* v, const float* pos, int Z, int N, int D, float scale,
                     int heads, long head_stride, long prob_stride, int q_rot, void* ws, float* T_out,
                     far_stream_t stream);
+/* the statistics of the last far_emm_pv_f16s call on `ws`: rowstat / colstat [Z][N][2] = (max, sum) in the log2 domain */
+int far_emm_pv_f16s_copy_stats(const void* ws, int Z, int N, float* rowstat_out, float* colstat_out, far_stream_t stream);
+
+/* K2 backward (training path): dq, dk [Z][N][64] of F = vt^T P vt (transformer.py:275-292) -- what the reference's
+ * autograd derives through two (B, 4, 4800, 4800) softmax tensors per direction, here from recomputed 32 x 32 tiles.
+ *   vt = [v | pos] and A = vt dF: [Z][N][70];  u = rowdot(A, P vt), vw = rowdot(vt dF^T, P^T vt): [Z][N]
+ *   rowstat / colstat: far_emm_pv_f16s_copy_stats of the forward.  A, u, vw may share a power-of-two scale.
+ * Plain fp16 operands, fp32 accumulation: gradient-grade (~1e-3).  dv~ = (P vt) dF^T + (P^T vt) dF is the caller's. */
+size_t far_emm_bwd_workspace_bytes(int Z, int N);
+int far_emm_bwd_f16(const float* q, const float* k, const float* vt, const float* A, const float* u, const float* vw,
+                    const float* rowstat, const float* colstat, int Z, int N, float scale, float* dq, float* dk,
+                    void* ws, far_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * K3  fine level: window gather + sub-pixel expectation

@@ -186,3 +186,80 @@ def test_encoder_layer_training_on_hip_matches_vendor_autograd():
         r = rel(ph[k], pv[k])
         print(f'[encoder train] d{k}: {r:.3e}')
         assert r < 1e-5, (k, r)                                          # measured <= 1.7e-6
+
+
+@pytest.mark.parametrize('Z,N', [(2, 221), (4, 640), (8, 4800)])
+def test_k2_bilinear_attention_backward(Z, N):
+    """far_emm_bwd_f16 (+ the torch-side N x 70 pieces) against float64 autograd of transformer.py:275-292
+    (far_amd/autograd_ops.py:bilinear_attention, the dense (Z, N, N) form) -- F, dq, dk, dv."""
+    from far_amd import autograd_ops as ag
+    from far_amd import ops
+    rng = np.random.default_rng(N)
+    mk = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32)).cuda()
+    q, k, v = mk(Z, N, 64), mk(Z, N, 64), mk(Z, N, 64)
+    pos = torch.from_numpy(rng.random((N, 6)).astype(np.float32)).cuda()
+    dF = mk(Z, 70, 70) * 3.0
+    a = [t.clone().requires_grad_(True) for t in (q, k, v)]
+    F = ops.emm_bilinear_train(a[0], a[1], a[2], pos, 0.125)
+    F.backward(dF)
+    # float64 reference in chunks of problems (one 4800 x 4800 double matrix with its autograd copies is ~1 GB)
+    r = [t.double().clone().requires_grad_(True) for t in (q, k, v)]
+    Fr = []
+    for z in range(Z):
+        Fz = ag.bilinear_attention(r[0][z:z + 1], r[1][z:z + 1], r[2][z:z + 1], pos.double(), 0.125)
+        Fz.backward(dF[z:z + 1].double())
+        Fr.append(Fz.detach())
+    Fr = torch.cat(Fr)
+    relF = float((F.detach().double() - Fr).norm() / Fr.norm())
+    print(f'[k2] Z={Z} N={N} F: relative Frobenius error {relF:.3e}')
+    assert relF < 1e-4
+    for name, x, y in zip('qkv', a, r):
+        rel = float((x.grad.double() - y.grad).norm() / y.grad.norm())
+        print(f'[k2 bwd] Z={Z} N={N} d{name}: relative Frobenius error {rel:.3e}')
+        assert rel < 5e-3, (name, rel)
+
+
+def test_head_training_on_hip_matches_vendor_autograd():
+    """The EMM head (LoFTR layer + CrossBlock + MLPs + gate) in training mode on one pair: HIP training path (K9 / K5 / K2
+    forward + backward) against the vendor-op autograd path, outputs and a spread of parameter gradients."""
+    import copy
+    from far_amd import synth
+    from far_amd.config import far_eval_config
+    from far_amd.loftr import LoFTR
+    from far_amd.loftr.transformer import CrossAttention, LoFTREncoderLayer
+    cfg = far_eval_config()
+    cfg['from_saved_preds'] = 'loftr_preds'
+    m = LoFTR(cfg)
+    import json, os
+    man = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'g8_state_dict_manifest.json')))
+    sd = synth.synthetic_state_dict({k: tuple(v) for k, v in man.items() if k.startswith('loftr_regress.')})
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m = m.cuda().train()
+    rng = np.random.default_rng(14)
+    f0 = torch.from_numpy(rng.standard_normal((1, 4800, 256)).astype(np.float32)).cuda()
+    f1 = (0.5 * f0 + torch.from_numpy(rng.standard_normal((1, 4800, 256)).astype(np.float32)).cuda())
+    keys = ['loftr_regress.loftr.layers.0.k_proj.weight', 'loftr_regress.emm.cross_attn.qkv.weight', 'loftr_regress.emm.pos_embed',
+            'loftr_regress.emm.norm1.weight', 'loftr_regress.encoder.0.weight', 'loftr_regress.moe_predictor.4.weight']
+    P = dict(m.named_parameters())
+    res = {}
+    for hip in (True, False):
+        for mod in m.modules():
+            if isinstance(mod, (CrossAttention, LoFTREncoderLayer)):
+                mod.hip_training = hip
+        m.zero_grad()
+        a0, a1 = f0.clone().requires_grad_(True), f1.clone().requires_grad_(True)
+        data = {'featmap0': a0, 'featmap1': a1, 'loftr_rt': torch.eye(3, 4, dtype=torch.float64).cuda(),
+                'num_correspondences': torch.tensor([731]).cuda(), 'num_correspondences_before_ransac': torch.tensor([1500]).cuda(),
+                'inliers_best_tight': torch.tensor([410]).cuda(), 'inliers_best_ultra_tight': torch.tensor([57]).cuda()}
+        m.forward_rt_prediction(data)
+        (data['regressed_rt'] * torch.arange(1, 10, device='cuda')).sum().backward()
+        res[hip] = (data['regressed_rt'].detach().clone(), a0.grad.clone(), {k: P[k].grad.detach().double().clone() for k in keys})
+    rh, gh, ph = res[True]
+    rv, gv, pv = res[False]
+    assert float((rh - rv).abs().max()) < 1e-3 * float(rv.abs().max())
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    print(f'[head train] regressed_rt max dev {float((rh - rv).abs().max()):.2e}; d featmap0 {rel(gh, gv):.3e}')
+    assert rel(gh, gv) < 5e-3
+    for k in keys:
+        print(f'[head train] d{k}: {rel(ph[k], pv[k]):.3e}')
+        assert rel(ph[k], pv[k]) < 5e-3, k
