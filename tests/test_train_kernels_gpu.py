@@ -216,7 +216,7 @@ def test_k2_bilinear_attention_backward(Z, N):
     for name, x, y in zip('qkv', a, r):
         rel = float((x.grad.double() - y.grad).norm() / y.grad.norm())
         print(f'[k2 bwd] Z={Z} N={N} d{name}: relative Frobenius error {rel:.3e}')
-        assert rel < 5e-3, (name, rel)
+        assert rel < 5e-3, (name, rel)               # measured: dq, dk 0.8-1.4e-3 (fp16 q, k in the score tiles), dv 9e-7
 
 
 def test_head_training_on_hip_matches_vendor_autograd():
