@@ -28,7 +28,8 @@ def test_pose_error_metrics_on_device_vs_reference_golden():
     np.testing.assert_allclose([auc["auc@5"], auc["auc@10"], auc["auc@20"]], g["auc"], rtol=1e-6, atol=1e-7)      # (errors agree to 2e-5 deg: acos)
     # float32 poses straight from the solver / head are accepted as well
     te32, Re32, _ = fm.relative_pose_error_batch(T.float(), R.float(), t.float())
-    assert float((te32 - te).abs().max()) < 1e-2 and float((Re32 - Re).abs().max()) < 1e-2
+    # (float32 inputs: acos near 1 amplifies the 6e-8 input rounding to ~0.02 degrees)
+    assert float((te32 - te).abs().max()) < 5e-2 and float((Re32 - Re).abs().max()) < 5e-2
 
 
 def _cached_model():
