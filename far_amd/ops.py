@@ -679,3 +679,27 @@ def stem7x7(img, weight, scale, shift):
                                   _p(scale, torch.float32), _p(shift, torch.float32), N, H, W, Cout, _p(y), _stream())
     _lib.check(rc, 'far_stem7x7_nhwc_f32')
     return y
+
+
+_CVW_GRID = {}
+
+
+def corr_volume_warp(vol0, vol1):
+    """K12.  vol0, vol1 (B, 32, H, W) fp32 -> agg (B, 67, H, W) = cat[vol0, warped vol1, warped (u, v) grid, max score]:
+    CorrelationVolumeWarping.forward of the Map-free 6DReg model (aggregator.py:44-115) without the (B, HW, HW) volume."""
+    lib = _lib.load()
+    B, D, H, W = vol0.shape
+    if vol1.shape != vol0.shape:
+        raise _lib.FarHipError('Feature volumes shape must match')
+    key = (H, W, str(vol0.device))
+    if key not in _CVW_GRID:
+        u = torch.linspace(-1, 1, H, device=vol0.device)
+        v = torch.linspace(-1, 1, W, device=vol0.device)
+        uu, vv = torch.meshgrid(u, v, indexing='ij')
+        _CVW_GRID[key] = torch.stack([uu, vv], 0).reshape(2, H * W).contiguous()
+    agg = torch.empty(B, 2 * D + 3, H, W, dtype=torch.float32, device=vol0.device)
+    ws = _ws(lib.far_corr_volume_warp_workspace_bytes(B, H * W), vol0.device)
+    rc = lib.far_corr_volume_warp_f32(_p(vol0.float().contiguous(), torch.float32), _p(vol1.float().contiguous(), torch.float32),
+                                      _p(_CVW_GRID[key]), B, D, H * W, _p(agg), _p(ws), _stream())
+    _lib.check(rc, 'far_corr_volume_warp_f32')
+    return agg

@@ -341,6 +341,17 @@ int far_solver_f64(const float* kpts0, const float* kpts1, const int* offsets, i
                    double* F_all_out, int* count_all_out, double* score_all_out, int* samples_out,
                    void* ws, far_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * K12  correlation-volume warp of the Map-free 6DReg aggregator
+ * replaces mapfree_6dreg/lib/models/regression/aggregator.py:44-115 (CorrelationVolumeWarping.forward) in the FAR
+ * configuration (POSITION_ENCODER, MAX_SCORE_CHANNEL; config/regression/mapfree/rot6d_trans_with_loftr.yaml):
+ *   agg [B][2 D + 3][HW] = cat[vol0, vol1 P^T, grid P^T, rowmax P],  P = softmax_j(vol0_i . vol1_j)  (never materialised)
+ * vol0, vol1 [B][D][HW] fp32 (the reference's (B, D, H, W) tensors; D must be 32), grid [2][HW] (meshgrid of
+ * linspace(-1, 1, H) x linspace(-1, 1, W), :81-84).  Exact fp32 arithmetic on the f32-input matrix core. */
+size_t far_corr_volume_warp_workspace_bytes(int B, int HW);
+int far_corr_volume_warp_f32(const float* vol0, const float* vol1, const float* grid, int B, int D, int HW, float* agg,
+                             void* ws, far_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

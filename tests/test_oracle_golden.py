@@ -349,3 +349,24 @@ def test_g9_pose_metrics_oracle_and_product():
     np.testing.assert_allclose([auc['auc@5'], auc['auc@10'], auc['auc@20']], g['auc'], rtol=1e-12)
     agg = fm.aggregate_pose_metrics(g['errs'][:, 0], g['errs'][:, 1], g['errs'][:, 2], np.ones(len(g['T'])))
     assert agg['dset size'] == len(g['T']) and agg['rot median err'] == np.round(np.median(g['errs'][:, 1]), 2)
+
+
+# ------------------------------------------------------------------------------------------------ G13
+def test_g13_mapfree_corr_volume_warp_oracle():
+    """oracle.mapfree.corr_volume_warp against the reference's CorrelationVolumeWarping (golden G13)."""
+    from oracle import mapfree as omf
+    g = load('g13_mapfree_cvw')
+    agg = omf.corr_volume_warp(g['s_vol0'], g['s_vol1'])
+    np.testing.assert_allclose(agg, g['s_agg'], rtol=2e-5, atol=2e-6)
+    B, H, W = (int(v) for v in g['f_shape'])
+    rng = np.random.default_rng(33)                      # the generator's draw order: small case first, then the full grid
+    for (b, h, w, amp) in ((2, 12, 9, 0.6),):
+        rng.standard_normal((b, 32, h, w)); rng.standard_normal((b, 32, h, w))
+    amp = float(g['f_amp'])
+    v0 = (amp * rng.standard_normal((B, 32, H, W))).astype(np.float32)
+    v1 = (amp * rng.standard_normal((B, 32, H, W))).astype(np.float32)
+    v1[:, :, : H // 2] = 2.0 * v0[:, :, : H // 2][:, :, ::-1] + 0.3 * v1[:, :, : H // 2]
+    agg = omf.corr_volume_warp(v0, v1)
+    np.testing.assert_allclose(agg[:, :, ::7, ::5], g['f_agg_sample'], rtol=5e-5, atol=5e-6)
+    np.testing.assert_allclose(agg[:, 66], g['f_max_score'], rtol=5e-5, atol=1e-7)
+    np.testing.assert_allclose(agg.sum((2, 3)), g['f_agg_sum'], rtol=1e-5, atol=1e-3)

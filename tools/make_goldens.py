@@ -385,6 +385,36 @@ def g12_ransac_loop():
     save('g12_ransac_loop', note=NOTE_KORNIA, **out)
 
 
+def g13_mapfree_corr_volume_warp():
+    """CorrelationVolumeWarping.forward (mapfree_6dreg/lib/models/regression/aggregator.py:44-115) in the FAR configuration
+    (rot6d_trans_with_loftr.yaml: POSITION_ENCODER, MAX_SCORE_CHANNEL), run from the reference's own module: a small
+    case stored in full and the 92 x 68 grid of the 360 x 270 regression images stored as samples + checksums."""
+    import types
+    sys.path.insert(0, '/root/reference/mapfree_6dreg')
+    from lib.models.regression.aggregator import CorrelationVolumeWarping
+    cfg = types.SimpleNamespace(POSITION_ENCODER=True, POSITION_ENCODER_IM1=None, MAX_SCORE_CHANNEL=True, CV_OUTLAYERS=0,
+                                CV_HALF_CHANNELS=False, UPSAMPLE_POS_ENC=0, DUSTBIN=False, NORMALISE_DOT=False)
+    mod = CorrelationVolumeWarping(cfg, 32).eval()
+    assert mod.num_out_layers == 67
+    rng = np.random.default_rng(33)
+    out = {}
+    for tag, (B, H, W, amp) in {'s': (2, 12, 9, 0.6), 'f': (1, 92, 68, 0.45)}.items():
+        v0 = (amp * rng.standard_normal((B, 32, H, W))).astype(np.float32)
+        v1 = (amp * rng.standard_normal((B, 32, H, W))).astype(np.float32)
+        # correlated halves, so that some rows have a confident peak and others are diffuse
+        v1[:, :, : H // 2] = 2.0 * v0[:, :, : H // 2][:, :, ::-1] + 0.3 * v1[:, :, : H // 2]
+        with torch.no_grad():
+            agg = mod(torch.from_numpy(v0), torch.from_numpy(v1)).numpy()
+        out[tag + '_shape'] = np.array([B, H, W])
+        out[tag + '_amp'] = amp
+        if tag == 's':
+            out.update(s_vol0=v0, s_vol1=v1, s_agg=agg)
+        else:
+            out.update(f_agg_sample=agg[:, :, ::7, ::5], f_agg_sum=agg.astype(np.float64).sum((2, 3)),
+                       f_max_score=agg[:, 66])
+    save('g13_mapfree_cvw', seed=33, **out)
+
+
 def g8_manifest(m):
     man = {k: list(v.shape) for k, v in m.state_dict().items()}
     with open(os.path.join(OUT, 'g8_state_dict_manifest.json'), 'w') as f:
@@ -404,6 +434,9 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'g11':
         g11_matcher_544x720(ref_model()[0])
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'g13':
+        g13_mapfree_corr_volume_warp()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'g12':
         g12_ransac_loop()
         sys.exit(0)
@@ -420,3 +453,4 @@ if __name__ == '__main__':
     g10_training(model)
     g11_matcher_544x720(model)
     g12_ransac_loop()
+    g13_mapfree_corr_volume_warp()
