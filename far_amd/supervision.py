@@ -69,3 +69,85 @@ def compute_supervision_RT(data, config, **kw):
         spvs_RT(data, config, **kw)
     else:
         raise NotImplementedError(src)
+
+
+# =====================================================================================================================
+# Coarse ground-truth supervision from depth (training only): spvs_coarse of src/loftr/utils/supervision.py:34-137 with
+# warp_kpts of src/loftr/utils/geometry.py:5-56.  Same outputs for the sparse training path -- spv_b_ids / spv_i_ids /
+# spv_j_ids, spv_w_pt0_i, spv_pt1_i -- batched (no per-sample Python loops), and WITHOUT conf_matrix_gt: the reference
+# scatters the ids into a zero (N, hw0, hw1) fp32 matrix (92 MB per pair) only for its dense loss to find them again
+# with `conf_gt == 1` (loftr_loss.py:63); far_amd.losses reads the ids.  dense_gt=True builds the matrix for drop-in use
+# of the reference's own loss.  Label generation: a few small torch ops per batch, no kernel of its own.
+# =====================================================================================================================
+@torch.no_grad()
+def warp_kpts(kpts0, depth0, depth1, T_0to1, K0, K1):
+    """geometry.py:5-56.  kpts0 (N, L, 2) <x, y>; depth (N, H, W); T (N, 3|4, 4); K (N, 3, 3) -> valid (N, L), warped (N, L, 2)."""
+    N, L = kpts0.shape[:2]
+    bidx = torch.arange(N, device=kpts0.device)[:, None].expand(N, L)
+    k0 = kpts0.round().long()
+    d0 = depth0[bidx, k0[..., 1], k0[..., 0]]                                                  # :22-25
+    nonzero = d0 != 0
+    kh = torch.cat([kpts0, torch.ones_like(kpts0[:, :, :1])], dim=-1) * d0[..., None]          # :31
+    cam = K0.inverse() @ kh.transpose(2, 1)                                                    # :32
+    wcam = T_0to1[:, :3, :3] @ cam + T_0to1[:, :3, 3:4]                                        # :35
+    wdepth = wcam[:, 2, :]
+    wh = (K1 @ wcam).transpose(2, 1)                                                           # :39
+    wk = wh[:, :, :2] / (wh[:, :, 2:3] + 1e-4)                                                 # :40
+    h, w = depth1.shape[1:3]
+    covis = (wk[..., 0] > 0) & (wk[..., 0] < w - 1) & (wk[..., 1] > 0) & (wk[..., 1] < h - 1)   # :44-45
+    wl = wk.long()
+    wl[~covis] = 0
+    d1 = depth1[bidx, wl[..., 1], wl[..., 0]]                                                  # :49-51
+    consistent = ((d1 - wdepth) / d1).abs() < 0.2                                              # :52
+    return nonzero & covis & consistent, wk
+
+
+@torch.no_grad()
+def spvs_coarse(data, config, dense_gt=False):
+    """supervision.py:34-137.  config: the dict-like with ['LOFTR']['RESOLUTION'] (or an int coarse scale)."""
+    dev = data['image0'].device
+    N, _, H0, W0 = data['image0'].shape
+    _, _, H1, W1 = data['image1'].shape
+    scale = config if isinstance(config, int) else config['LOFTR']['RESOLUTION'][0]
+    scale0 = scale * data['scale0'][:, None] if 'scale0' in data else scale                    # :62-63
+    scale1 = scale * data['scale1'][:, None] if 'scale0' in data else scale
+    h0, w0, h1, w1 = (x // scale for x in (H0, W0, H1, W1))
+
+    def grid(h, w):                       # kornia create_meshgrid(h, w, False): (x, y) pixel coordinates, x fastest
+        ys, xs = torch.meshgrid(torch.arange(h, device=dev, dtype=torch.float32),
+                                torch.arange(w, device=dev, dtype=torch.float32), indexing='ij')
+        return torch.stack([xs, ys], -1).reshape(1, h * w, 2).repeat(N, 1, 1)
+    pt0_i = scale0 * grid(h0, w0)                                                              # :69-72
+    pt1_i = scale1 * grid(h1, w1)
+    if 'mask0' in data:                                                                        # :75-77
+        pt0_i = pt0_i * data['mask0'].reshape(N, -1, 1).bool()
+        pt1_i = pt1_i * data['mask1'].reshape(N, -1, 1).bool()
+    _, w_pt0_i = warp_kpts(pt0_i, data['depth0'], data['depth1'], data['T_0to1'], data['K0'], data['K1'])   # :83
+    _, w_pt1_i = warp_kpts(pt1_i, data['depth1'], data['depth0'], data['T_1to0'], data['K1'], data['K0'])   # :84
+    r0 = (w_pt0_i / scale1).round().long()                                                     # :86-90
+    r1 = (w_pt1_i / scale0).round().long()
+    near1 = r0[..., 0] + r0[..., 1] * w1
+    near0 = r1[..., 0] + r1[..., 1] * w0
+    oob = lambda pt, w, h: (pt[..., 0] < 0) | (pt[..., 0] >= w) | (pt[..., 1] < 0) | (pt[..., 1] >= h)      # :96-99
+    near1[oob(r0, w1, h1)] = 0
+    near0[oob(r1, w0, h0)] = 0
+    loop_back = torch.gather(near0, 1, near1)                                                  # :101
+    correct = loop_back == torch.arange(h0 * w0, device=dev)[None]
+    correct[:, 0] = False                                                                      # :103
+    b_ids, i_ids = torch.where(correct)                                                        # :106
+    j_ids = near1[b_ids, i_ids]
+    if dense_gt:                                                                               # :115-119
+        gt = torch.zeros(N, h0 * w0, h1 * w1, device=dev)
+        gt[b_ids, i_ids, j_ids] = 1
+        data['conf_matrix_gt'] = gt
+    if len(b_ids) == 0:                                                                        # :122-128
+        b_ids = i_ids = j_ids = torch.zeros(1, dtype=torch.long, device=dev)
+    data.update({'spv_b_ids': b_ids, 'spv_i_ids': i_ids, 'spv_j_ids': j_ids, 'spv_w_pt0_i': w_pt0_i, 'spv_pt1_i': pt1_i})
+
+
+def compute_supervision_coarse(data, config, **kw):
+    src = data['dataset_name'][0]
+    if src.lower() in ['scannet', 'megadepth', 'mp3d']:                                        # :139-145
+        spvs_coarse(data, config, **kw)
+    else:
+        raise ValueError(f'Unknown data source: {src}')

@@ -370,3 +370,35 @@ def test_g13_mapfree_corr_volume_warp_oracle():
     np.testing.assert_allclose(agg[:, :, ::7, ::5], g['f_agg_sample'], rtol=5e-5, atol=5e-6)
     np.testing.assert_allclose(agg[:, 66], g['f_max_score'], rtol=5e-5, atol=1e-7)
     np.testing.assert_allclose(agg.sum((2, 3)), g['f_agg_sum'], rtol=1e-5, atol=1e-3)
+
+
+# ------------------------------------------------------------------------------------------------ G14
+def test_g14_spvs_coarse_matches_reference():
+    """far_amd.supervision.spvs_coarse (batched, no conf_matrix_gt) against the reference's spvs_coarse run on the same
+    synthetic planar scenes (golden G14): identical ground-truth match ids, warped points, and -- with dense_gt -- the
+    same 0/1 matrix."""
+    import importlib.util
+    import types
+    from far_amd.supervision import spvs_coarse
+    src = open(os.path.join(os.path.dirname(G), '..', 'tools', 'make_goldens.py')).read()
+    mod = types.ModuleType('spvs_scene_helper')
+    mod.__dict__.update({'np': np})
+    exec(src[src.index('def spvs_scene('):src.index('def g14_spvs_coarse():')], mod.__dict__)
+    d0, d1, T01, T10, K = mod.spvs_scene()
+    g = load('g14_spvs_coarse')
+    N = len(d0)
+    data = {'image0': torch.zeros(N, 1, 480, 640), 'image1': torch.zeros(N, 1, 480, 640), 'depth0': torch.from_numpy(d0),
+            'depth1': torch.from_numpy(d1), 'T_0to1': torch.from_numpy(T01), 'T_1to0': torch.from_numpy(T10),
+            'K0': torch.from_numpy(K), 'K1': torch.from_numpy(K), 'dataset_name': ['mp3d']}
+    spvs_coarse(data, {'LOFTR': {'RESOLUTION': (8, 2)}}, dense_gt=True)
+    for k, gk in (('spv_b_ids', 'b_ids'), ('spv_i_ids', 'i_ids'), ('spv_j_ids', 'j_ids')):
+        np.testing.assert_array_equal(data[k].numpy(), g[gk])
+    assert len(g['b_ids']) > 5000
+    np.testing.assert_allclose(data['spv_w_pt0_i'][:, ::37].numpy(), g['w_pt0_i_sample'], rtol=1e-5, atol=1e-3)
+    np.testing.assert_array_equal(data['spv_pt1_i'][:, ::37].numpy(), g['pt1_i_sample'])
+    assert float(data['conf_matrix_gt'].sum()) == float(g['gt_sum'])
+    np.testing.assert_array_equal(data['conf_matrix_gt'].sum(2).numpy().astype(np.int8), g['gt_rowsum'])
+    d2 = dict(data)
+    d2.pop('conf_matrix_gt')
+    spvs_coarse(d2, 8)
+    assert 'conf_matrix_gt' not in d2 and torch.equal(d2['spv_j_ids'], data['spv_j_ids'])

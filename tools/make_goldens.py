@@ -415,6 +415,51 @@ def g13_mapfree_corr_volume_warp():
     save('g13_mapfree_cvw', seed=33, **out)
 
 
+def spvs_scene(seed=61, N=2, H=480, W=640):
+    """Shared by the generator and tests: two fronto-parallel-ish depth maps per pair related by a known rigid motion
+    (planes at different depths per image band, a few zero-depth holes), Matterport intrinsics."""
+    rng = np.random.default_rng(seed)
+    K = np.array([[517.97, 0, 320.], [0, 517.97, 240.], [0, 0, 1.]], np.float32)
+    depth0 = np.empty((N, H, W), np.float32)
+    depth1 = np.empty((N, H, W), np.float32)
+    T01 = np.zeros((N, 4, 4), np.float32)
+    for n in range(N):
+        ang = 0.05 * (n + 1)
+        R = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]], np.float32)
+        t = np.array([0.15 * (n + 1), 0.02, 0.05], np.float32)
+        T01[n, :3, :3] = R; T01[n, :3, 3] = t; T01[n, 3, 3] = 1
+        # a slanted plane n.X = d in camera 0; render its depth in both cameras analytically
+        nrm = np.array([0.1, -0.05, 1.0], np.float32); nrm /= np.linalg.norm(nrm)
+        d = 3.0 + 0.5 * n
+        ys, xs = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing='ij')
+        rays = np.stack([(xs - K[0, 2]) / K[0, 0], (ys - K[1, 2]) / K[1, 1], np.ones_like(xs)], -1)
+        depth0[n] = d / (rays @ nrm)
+        # plane in camera 1: n1 = R n, d1 = d + n1 . t
+        n1 = R @ nrm; d1 = d + n1 @ t
+        depth1[n] = d1 / (rays @ n1)
+        holes = rng.integers(0, H // 8, (20, 2))
+        for hy, hx in holes:
+            depth0[n, hy * 8:hy * 8 + 8, (hx * 8) % W:(hx * 8) % W + 8] = 0
+    T10 = np.linalg.inv(T01).astype(np.float32)
+    return depth0, depth1, T01, T10, np.stack([K] * N)
+
+
+def g14_spvs_coarse():
+    """spvs_coarse (supervision.py:34-137) + warp_kpts (geometry.py:5-56) of the reference on synthetic planar scenes."""
+    from src.loftr.utils.supervision import spvs_coarse
+    d0, d1, T01, T10, K = spvs_scene()
+    N = len(d0)
+    data = {'image0': torch.zeros(N, 1, 480, 640), 'image1': torch.zeros(N, 1, 480, 640), 'depth0': torch.from_numpy(d0),
+            'depth1': torch.from_numpy(d1), 'T_0to1': torch.from_numpy(T01), 'T_1to0': torch.from_numpy(T10),
+            'K0': torch.from_numpy(K), 'K1': torch.from_numpy(K), 'pair_names': [('a', 'b')] * N}
+    spvs_coarse(data, {'LOFTR': {'RESOLUTION': (8, 2)}})
+    gt = data['conf_matrix_gt']
+    save('g14_spvs_coarse', seed=61, b_ids=data['spv_b_ids'].numpy(), i_ids=data['spv_i_ids'].numpy(), j_ids=data['spv_j_ids'].numpy(),
+         w_pt0_i_sample=data['spv_w_pt0_i'][:, ::37].numpy(), pt1_i_sample=data['spv_pt1_i'][:, ::37].numpy(),
+         gt_sum=np.float64(gt.sum().item()), gt_rowsum=gt.sum(2).numpy().astype(np.int8))
+    print('g14: GT matches', len(data['spv_b_ids']))
+
+
 def g8_manifest(m):
     man = {k: list(v.shape) for k, v in m.state_dict().items()}
     with open(os.path.join(OUT, 'g8_state_dict_manifest.json'), 'w') as f:
@@ -433,6 +478,9 @@ if __name__ == '__main__':
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'g11':
         g11_matcher_544x720(ref_model()[0])
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'g14':
+        g14_spvs_coarse()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'g13':
         g13_mapfree_corr_volume_warp()
@@ -454,3 +502,4 @@ if __name__ == '__main__':
     g11_matcher_544x720(model)
     g12_ransac_loop()
     g13_mapfree_corr_volume_warp()
+    g14_spvs_coarse()
