@@ -189,7 +189,7 @@ def pmc_traffic(kernel_label, n_pairs, precision):
     name = kernel_label.split('[')[0]
     ent = None
     for key, val in per.items():
-        if key.startswith(name) and val.get('label', kernel_label) == kernel_label:
+        if val.get('label') == kernel_label:
             ent = val
             break
     if ent is None and name == 'k_conv':          # round-1 file: keyed by template instantiation and grid

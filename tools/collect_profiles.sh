@@ -1,0 +1,17 @@
+#!/bin/bash
+# Runs on the GPU box (gpurun): kernel trace of bench.py, PMC traffic passes (FETCH_SIZE / WRITE_SIZE, separate passes as
+# MI355X_MICROARCH.md prescribes) on the isolated kernels, the un-profiled bench lines.  Output under gpurun_out/; the
+# summaries that are judged get copied into profiles/ by tools/make_profile_txt.py (run in the build container).
+R=${GRAFT_REPO_ROOT:-/root/repo}
+TAG=${1:-r02}
+mkdir -p $R/gpurun_out
+cd /tmp; export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_bench -o bench -- python3 $R/bench.py --steps 3 --warmup 3 --no-cpu-baseline > $R/gpurun_out/bench_prof.log 2>&1
+timeout 200 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/pmc_fetch -o f -- python3 $R/tools/kprobe.py pmc 32 2 > $R/gpurun_out/pmc_fetch.log 2>&1
+timeout 200 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/pmc_write -o w -- python3 $R/tools/kprobe.py pmc 32 2 > $R/gpurun_out/pmc_write.log 2>&1
+cd $R
+timeout 400 python bench.py > gpurun_out/bench_plain.log 2> gpurun_out/bench_plain.err
+timeout 300 python bench.py --workload c4 > gpurun_out/bench_c4.log 2> gpurun_out/bench_c4.err
+python tools/profile_report.py gpurun_out/prof_bench/bench_results.db > gpurun_out/${TAG}_trace.txt 2>&1
+python tools/pmc_traffic.py gpurun_out/pmc_fetch/f_results.db gpurun_out/pmc_write/w_results.db > gpurun_out/${TAG}_pmc_traffic.json 2> gpurun_out/pmc_err.log
+tail -c 400 gpurun_out/bench_plain.log; echo; head -c 600 gpurun_out/${TAG}_pmc_traffic.json

@@ -37,6 +37,32 @@ if which in ('k1w', 'all'):
     lib.far_set_tuning(2, 0)
     lib.far_set_tuning(3, 0)
     del conf
+if which in ('pmc',):
+    # the kernels whose HBM traffic is reported: K9 196->196 3x3 @240x320 (the dominant kernel of the step), K9 linear,
+    # the conf_matrix writer, K1's training backward
+    x = torch.randn(2 * n, 240, 320, 196, device=dev, generator=g).relu_()
+    w = torch.randn(196, 196, 3, 3, device=dev, generator=g) * 0.03
+    pc = ops.PackedConv(w, torch.ones(196, device=dev), torch.zeros(196, device=dev))
+    for _ in range(it):
+        ops.conv_nhwc(x, pc, act='relu')
+    del x
+    r = torch.randn(1, 1, n * L, 256, device=dev, generator=g)
+    pl = ops.PackedConv(torch.randn(256, 256, device=dev, generator=g) * 0.05)
+    for _ in range(it):
+        ops.conv_nhwc(r, pl)
+    del r
+    f0 = 1.2 * torch.randn(n, L, 256, device=dev, generator=g)
+    f1 = f0[:, torch.randperm(L, device=dev, generator=g)] + 0.1 * torch.randn(n, L, 256, device=dev, generator=g)
+    conf = torch.empty(n, L, L, device=dev)
+    for _ in range(it):
+        ops.conf_matrix(f0, f1, 0.1, out=conf)
+    del conf
+    pb = torch.arange(4, device=dev).repeat_interleave(L)
+    pi = torch.arange(L, device=dev).repeat(4)
+    pj = torch.randint(0, L, (4 * L,), device=dev)
+    a0, a1 = f0[:4].clone().requires_grad_(True), f1[:4].clone().requires_grad_(True)
+    for _ in range(it):
+        ops.coarse_pos_conf(a0, a1, pb, pi, pj, 0.1).sum().backward()
 if which in ('k1b',):
     f0 = 1.2 * torch.randn(n, L, 256, device=dev, generator=g)
     f1 = f0[:, torch.randperm(L, device=dev, generator=g)] + 0.1 * torch.randn(n, L, 256, device=dev, generator=g)

@@ -20,7 +20,7 @@ def short(name):
     for key in ['k_conv<3, 2, 2, 4, true, 1', 'k_conv<1, 2, 2, 4, true, 1']:
         if key + ', false>' in name:
             return key + '>'
-    for key in ['k_stats_f32', 'k_match_f32', 'k_emm_pv_f32', 'k_la_kv_partial<32>', 'k_la_apply<32>', 'k_layernorm',
+    for key in ['k1_conf_wide', 'k1_conf_fix', 'k1_bwd', 'k2_bwd', 'k1_rowstatsILb1', 'k_cvw_apply', 'k_stats_f32', 'k_match_f32', 'k_emm_pv_f32', 'k_la_kv_partial<32>', 'k_la_apply<32>', 'k_layernorm',
                 'k_conv<3, 2, 2, 4, true, 1>', 'k_conv<1, 2, 2, 4, true, 1>', 'k_pv', 'k_rowstats', 'k1_rowstats', 'k1_matchILb0', 'k1_matchILb1']:
         if key in name:
             return key
@@ -36,6 +36,15 @@ if __name__ == '__main__':
             continue
         rd = 2.0 * fv * 1024
         wr = w[(k, g)][0] * 1024
-        out[f'{s}|grid={g}'] = {'read_bytes': round(rd), 'write_bytes': round(wr), 'total_bytes': round(rd + wr), 'launches': n}
-    json.dump({'method': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on tools/kprobe.py all 32 2 (+ k9 32 2); '
+        ent = {'read_bytes': round(rd), 'write_bytes': round(wr), 'total_bytes': round(rd + wr), 'launches': n}
+        # the launch bench.py prices as the dominant kernel: 196 -> 196 3x3 at 240 x 320 on 64 images = 64 * 30 * 20 tiles of 256 threads
+        if s == 'k_conv<3, 2, 2, 4, true, 1>' and g == 64 * 30 * 20 * 256:
+            ent['label'] = 'k_conv[K9 3x3 196->196 @240x320]'
+        out[f'{s}|grid={g}'] = ent
+    import subprocess
+    try:
+        commit = subprocess.check_output(['git', 'rev-parse', '--short', 'HEAD'], text=True).strip()
+    except Exception:
+        commit = None
+    json.dump({'precision': 'fp32', 'commit': commit, 'method': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on tools/kprobe.py all 32 2 (+ k9 32 2); '
                          'read = 2 x FETCH_SIZE KiB, write = WRITE_SIZE KiB', 'per_launch': out}, sys.stdout, indent=1)
