@@ -41,10 +41,13 @@ if __name__ == '__main__':
         if s == 'k_conv<3, 2, 2, 4, true, 1>' and g == 64 * 30 * 20 * 256:
             ent['label'] = 'k_conv[K9 3x3 196->196 @240x320]'
         out[f'{s}|grid={g}'] = ent
+    import os
     import subprocess
-    try:
-        commit = subprocess.check_output(['git', 'rev-parse', '--short', 'HEAD'], text=True).strip()
-    except Exception:
-        commit = None
+    commit = os.environ.get('FAR_COMMIT')
+    if not commit:
+        try:
+            commit = subprocess.check_output(['git', 'rev-parse', '--short', 'HEAD'], text=True, stderr=subprocess.DEVNULL).strip()
+        except Exception:
+            commit = None
     json.dump({'precision': 'fp32', 'commit': commit, 'method': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on tools/kprobe.py all 32 2 (+ k9 32 2); '
                          'read = 2 x FETCH_SIZE KiB, write = WRITE_SIZE KiB', 'per_launch': out}, sys.stdout, indent=1)
