@@ -37,7 +37,10 @@ def parse():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--pairs', type=int, default=None, help='pairs per GPU per step (default: 32 for c2, 256 for c4)')
-    ap.add_argument('--workload', default='c2', choices=['c2', 'c4'],
+    ap.add_argument('--vendor-train', action='store_true',
+                    help='c3 only: run the training step on the differentiable vendor-op forms (far_amd/autograd_ops.py) instead '
+                         'of the HIP forward/backward kernels -- the comparison leg')
+    ap.add_argument('--workload', default='c2', choices=['c2', 'c3', 'c4'],
                     help="c2 = BASELINE configs[1] (the headline metric: match + solve + regress, batch 32); "
                          "c4 = BASELINE configs[3] (cached-LoFTR path: GPU solver on cached correspondences + head, batch 256)")
     ap.add_argument('--hyp', type=int, default=2048, help='RANSAC hypotheses per pair (metrics.py:120)')
@@ -333,10 +336,92 @@ def bench_c4(a, dev, world, rank, dist):
         dist.destroy_process_group()
 
 
+def bench_c3(a, dev, world, rank, dist):
+    """BASELINE configs[2]: the training step of mp3d_loftr/scripts/train_matterport.sh (last stage, "FAR (full)":
+    batch_size 1 per GPU, AdamW lr 1e-5, losses coarse focal + fine l2-with-std + 6D pose L1), in the reference's order
+    (far_amd.pipeline.train_step = PL_LoFTR._trainval_inference) + backward + optimizer step; under N > 1 ranks the model
+    is wrapped in DistributedDataParallel (gradient all-reduce over RCCL = the one exchange step of this path)."""
+    from far_amd import parallel, synth
+    from far_amd.config import far_train_config, RunCfg
+    from far_amd.loftr import LoFTR
+    from far_amd.loftr.transformer import LoFTREncoderLayer, CrossAttention
+    from far_amd.losses import LoFTRLoss
+    from far_amd.pipeline import train_step
+    B = a.pairs
+    cfg = far_train_config()
+    model = LoFTR(cfg['loftr'])
+    synth.load_synthetic(model, seed=0)
+    model = model.to(dev).train()
+    if a.vendor_train:
+        LoFTREncoderLayer.hip_training = False
+        CrossAttention.hip_training = False
+        model.coarse_matching.materialize_conf = True          # dense conf_matrix through the vendor ops + autograd
+    loss_fn = LoFTRLoss(cfg).train()
+    fwd = model
+    if dist is not None:
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        fwd = DDP(model, device_ids=[dev.index] if a.backend == 'nccl' else None)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-5, weight_decay=0.1)      # src/optimizers/__init__.py:5-16, default.py TRAINER.*
+    # synthetic supervision: banded lateral disparities -> ground-truth coarse matches + warped grid (far_amd/synth.py)
+    base = synth.synth_training_batch(B, seed=1234 + rank, device=dev)
+    n_gt = int(base['spv_b_ids'].numel()) // B
+    run = RunCfg('prior_ransac', 2)
+
+    def step():
+        batch = dict(base)
+        train_step(model, batch, loss_fn, run, H=a.hyp, seed=0, forward=fwd)
+        batch['loss'].backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        return batch
+
+    prime = max(0, 3 - a.warmup)
+    for _ in range(prime + a.warmup):
+        last = step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        last = step()
+    fence()
+    dt = time.perf_counter() - t0
+    per_rank_ms = [round(1000 * x / a.steps, 3) for x in parallel.gather_floats(dt, device=dev)]
+    dt = parallel.max_over_ranks(dt, device=dev)
+    if rank == 0:
+        sc = {k_: round(float(v_), 5) for k_, v_ in last['loss_scalars'].items() if k_.startswith('loss')}
+        res = {
+            'metric': 'image-pairs/sec (training step: forward + backward + AdamW) -- BASELINE configs[2], not the headline metric',
+            'value': round(world * B * a.steps / dt, 3), 'unit': 'image-pairs/sec', 'n_gpus': world, 'steps': a.steps,
+            'warmup': a.warmup, 'prime_steps': prime, 'ms_per_step': round(1000 * dt / a.steps, 3),
+            'per_rank_ms_per_step': per_rank_ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'dtype_note': 'fp32 tensors and accumulation; K1 / K9-linear / K2 forward on split-f16x3 operands, their backward kernels '
+                          'on fp16 (K1, K2) or split-f16x3 (K9 dgrad) operands; backbone and fine-window ops: vendor fp32 + autograd',
+            'config': {'workload': 'Matterport3D-shaped training step (BASELINE configs[2]): ' + str(B) + ' pair(s) @ 640x480 per GPU, '
+                                   'matcher in training mode (sampled / padded coarse matches), solver x2, head x2 (last with grad), '
+                                   'coarse focal + fine l2_with_std + 6D pose L1 losses, backward, AdamW; seeded random weights',
+                       'pairs_per_gpu': B, 'hypotheses': a.hyp,
+                       'training_kernels': 'vendor ops + autograd (comparison leg)' if a.vendor_train else
+                                           'HIP forward+backward: K1 sparse-position conf, K5, K9 Linear (dgrad), K2',
+                       'gt_coarse_matches_per_pair': n_gt, 'sampled_matches': int(last['b_ids'].numel()),
+                       'losses': sc,
+                       'parallelism': f'ddp{world} (gradient all-reduce over RCCL)' if world > 1 else 'single GPU (no exchange step)'},
+        }
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     a = parse()
     if a.pairs is None:
-        a.pairs = 256 if a.workload == 'c4' else PAIRS_PER_GPU
+        a.pairs = {'c4': 256, 'c3': 1}.get(a.workload, PAIRS_PER_GPU)
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # plain `python bench.py --gpus N`: start the N ranks as children BEFORE this process initialises the GPU
         from far_amd import parallel
@@ -355,6 +440,8 @@ def main():
         world = dist.get_world_size()            # the rank count the backend (RCCL) reports
     if a.workload == 'c4':
         return bench_c4(a, dev, world, rank, dist)
+    if a.workload == 'c3':
+        return bench_c3(a, dev, world, rank, dist)
     from far_amd import synth
     from far_amd.config import far_eval_config
     from far_amd.loftr import LoFTR

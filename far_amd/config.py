@@ -34,6 +34,19 @@ def far_eval_config():
     return copy.deepcopy(FAR_EVAL_CONFIG)
 
 
+def far_train_config():
+    """The lower-cased config LoFTRLoss receives (lightning_loftr.py:40-53) for the last stage of
+    mp3d_loftr/scripts/train_matterport.sh ("training FAR (full)": --rt_weight_rot/tr 0.01, --fine_weight/--coarse_weight 1,
+    --use_l1_rt_loss, --solver prior_ransac, --fine_pred_steps 2) with the loss defaults of src/config/default.py:58-80."""
+    loftr = far_eval_config()
+    loftr['training'] = True
+    loftr['loss'] = {'coarse_type': 'focal', 'coarse_weight': 1.0, 'focal_alpha': 0.25, 'focal_gamma': 2.0, 'pos_weight': 1.0,
+                     'neg_weight': 1.0, 'fine_type': 'l2_with_std', 'fine_weight': 1.0, 'fine_correct_thr': 1.0,
+                     'rt_weight_rot': 0.01, 'rt_weight_tr': 0.01, 'scale_weight': 0.0, 'use_l1_rt_loss': True,
+                     'max_scale_loss': 100.0}
+    return {'loftr': loftr, 'use_correspondence_transformer': False}
+
+
 class TrainerCfg:
     """The two TRAINER fields spvs_RT reads (src/loftr/utils/supervision.py:192-193)."""
     RANSAC_PIXEL_THR = 0.5
@@ -43,6 +56,11 @@ class TrainerCfg:
 class RunCfg:
     """Minimal stand-in for the yacs node handed to compute_supervision_RT: config.TRAINER.*, config.LOFTR.SOLVER."""
 
-    def __init__(self, solver='prior_ransac', fine_pred_steps=2):
+    def __init__(self, solver='prior_ransac', fine_pred_steps=2, resolution=(8, 2), fine_window_size=5):
         self.TRAINER = TrainerCfg()
-        self.LOFTR = type('L', (), {'SOLVER': solver, 'FINE_PRED_STEPS': fine_pred_steps})()
+        self.LOFTR = type('L', (), {'SOLVER': solver, 'FINE_PRED_STEPS': fine_pred_steps, 'RESOLUTION': resolution,
+                                    'FINE_WINDOW_SIZE': fine_window_size})()
+
+    def __getitem__(self, key):                 # spvs_coarse / spvs_fine read config['LOFTR']['RESOLUTION'] (supervision.py:58, :151)
+        node = getattr(self, key)
+        return node if key != 'LOFTR' else {'RESOLUTION': node.RESOLUTION, 'FINE_WINDOW_SIZE': node.FINE_WINDOW_SIZE}

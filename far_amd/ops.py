@@ -395,7 +395,17 @@ class _LinearF16sFn(torch.autograd.Function):
     def backward(ctx, g):
         xc, weight = ctx.saved_tensors
         g = g.float().contiguous()
-        dx = linear_f16s(g, ctx.pack_t()) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            # K9 splits its input into fp16 (hi, lo) pairs after a fixed 2^4 scale: fp32-grade for values in
+            # ~[8e-3, 4e3], the range of activations -- gradients can sit anywhere (1e-7 is usual).  A power-of-two scale
+            # taken from the tensor's maximum (on the device, no host sync) places them at the top of that window;
+            # entries below max * 2^-17 keep 11 bits, which is 2^-28 of the maximum.
+            amax = g.abs().amax()
+            s = torch.exp2(torch.floor(10.0 - torch.log2(amax.clamp_min(1e-37))))
+            s = torch.where(amax > 0, s, torch.ones_like(s))
+            dx = linear_f16s(g * s, ctx.pack_t())
+            dx.mul_(1.0 / s)
         g2, x2 = g.reshape(-1, g.shape[-1]), xc.reshape(-1, xc.shape[-1])
         dw = g2.t().mm(x2) if ctx.needs_input_grad[1] else None
         db = g2.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None

@@ -11,7 +11,7 @@ out of scope and keeps working against the same modu
 import torch
 
 from .config import RunCfg
-from .supervision import compute_supervision_RT
+from .supervision import compute_supervision_RT, compute_supervision_coarse, compute_supervision_fine
 
 
 @torch.no_grad()
@@ -46,4 +46,41 @@ def cached_step(matcher, batch, run_cfg=None, H=2048, seed=0):
         matcher.forward_rt_prediction(batch)
         if i < steps - 1 and 'prior_ransac' in cfg.LOFTR.SOLVER:
             compute_supervision_RT(batch, cfg, H=H, seed=seed)
+    return batch
+
+
+def train_step(matcher, batch, loss_fn, run_cfg=None, H=2048, seed=0, forward=None):
+    """BASELINE configs[2]: one training forward in the reference's order (PL_LoFTR._trainval_inference,
+    lightning_loftr.py:129-172, with training_step :174-182 left to the caller: batch['loss'].backward(), optimizer):
+
+        compute_supervision_coarse -> matcher(batch, train=True) -> compute_supervision_fine -> compute_supervision_RT
+          -> no_grad[forward_rt_prediction -> compute_supervision_RT] x (FINE_PRED_STEPS - 1) -> forward_rt_prediction -> loss
+
+    On GPU tensors the matcher's training forward runs K1's sparse-position kernels, K5, K9 (Linear) and K2 with their
+    HIP backward kernels; the ground truth never becomes a dense conf_matrix_gt (far_amd/losses.py).  A batch that already
+    carries spv_b_ids / spv_i_ids / spv_j_ids (no depth maps) skips the coarse supervision, as the reference does for
+    its depth-less data source (:131-133).  `forward`: the DistributedDataParallel wrapper of `matcher` when there is one
+    (its forward arms the gradient all-reduce hooks; the head call below runs on the wrapped module as in the reference)."""
+    cfg = run_cfg or RunCfg(matcher.config['solver'], matcher.config.get('fine_pred_steps', 2))
+    if 'depth0' in batch:
+        compute_supervision_coarse(batch, cfg)                                      # :133
+    (forward or matcher)(batch, train=True)                                         # :136
+    if 'spv_w_pt0_i' in batch:
+        compute_supervision_fine(batch, cfg)                                        # :140
+    batch.update(num_correspondences_before_ransac=0, num_correspondences_after_ransac=0)   # :142-145
+    if matcher.config['regress_rt']:
+        batch['translation_scale'] = None                                           # :156
+        with torch.no_grad():
+            compute_supervision_RT(batch, cfg, H=H, seed=seed)                      # :157
+        steps = cfg.LOFTR.FINE_PRED_STEPS
+        for i in range(steps):                                                      # :159
+            if i < steps - 1 and 'prior_ransac' in cfg.LOFTR.SOLVER:
+                with torch.no_grad():                                               # :161-164
+                    matcher.forward_rt_prediction(batch)
+                    compute_supervision_RT(batch, cfg, H=H, seed=seed)
+            else:
+                matcher.forward_rt_prediction(batch)                                # :167
+                loss_fn(batch)                                                      # :169
+    else:
+        loss_fn(batch)                                                              # :172
     return batch

@@ -151,3 +151,21 @@ def compute_supervision_coarse(data, config, **kw):
         spvs_coarse(data, config, **kw)
     else:
         raise ValueError(f'Unknown data source: {src}')
+
+
+@torch.no_grad()
+def spvs_fine(data, config):
+    """supervision.py:142-166: the fine-level target of every (sampled) coarse match, in units of the window radius."""
+    w_pt0_i, pt1_i = data['spv_w_pt0_i'], data['spv_pt1_i']
+    scale = config['LOFTR']['RESOLUTION'][1]
+    radius = config['LOFTR']['FINE_WINDOW_SIZE'] // 2
+    b, i, j = data['b_ids'], data['i_ids'], data['j_ids']
+    scale = scale * data['scale1'][b] if 'scale0' in data else scale                           # :158
+    data['expec_f_gt'] = (w_pt0_i[b, i] - pt1_i[b, j]) / scale / radius                        # :161
+
+
+def compute_supervision_fine(data, config):
+    if data['dataset_name'][0].lower() in ['mp3d']:                                            # :170-174
+        spvs_fine(data, config)
+    else:
+        raise NotImplementedError

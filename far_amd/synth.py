@@ -94,6 +94,32 @@ def synth_image_pair(N, seed=0, hw=(480, 640), disparities=(8, 40, 72), noise=0.
 MP3D_K = np.array([[517.97, 0, 320.], [0, 517.97, 240.], [0, 0, 1.]])   # src/utils/dataset.py:201-211
 
 
+def synth_training_batch(B, seed=0, device='cpu', disparities=(8, 40, 72)):
+    """A training batch for the 640x480 banded pairs of synth_image_pair WITH its supervision, in the form the
+    reference's spvs_coarse leaves in the data dict (supervision.py:122-137): ground-truth coarse matches (spv_*_ids),
+    the warped coarse grid of image 0 and the grid of image 1 (for spvs_fine), the relative pose (lateral translation)."""
+    import torch
+    im0, im1 = synth_image_pair(B, seed=seed, disparities=disparities)
+    ys, xs = np.meshgrid(np.arange(60), np.arange(80), indexing='ij')
+    nb = len(disparities)
+    band = np.array([min(nb - 1, next(k for k in range(nb) if y * 8 < ((480 * (k + 1)) // nb // 8 * 8 if k < nb - 1 else 480)))
+                     for y in range(60)])
+    d_c = (np.array(disparities)[band] // 8)[:, None] + 0 * xs
+    ok = xs - d_c >= 0
+    ii = (ys * 80 + xs)[ok].astype(np.int64)
+    jj = (ys * 80 + xs - d_c)[ok].astype(np.int64)
+    grid = (np.stack([xs, ys], -1).reshape(1, 4800, 2) * 8).astype(np.float32)
+    w_pt0 = grid - np.stack([8 * d_c, 0 * d_c], -1).reshape(1, 4800, 2).astype(np.float32)
+    T = np.eye(4, dtype=np.float32)
+    T[0, 3] = -1.0
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    K = t(np.stack([MP3D_K] * B))
+    return {'image0': t(im0), 'image1': t(im1), 'K0': K, 'K1': K.clone(), 'dataset_name': ['mp3d'],
+            'T_0to1': t(T)[None].repeat(B, 1, 1),
+            'spv_b_ids': torch.arange(B, device=device).repeat_interleave(len(ii)), 'spv_i_ids': t(ii).repeat(B),
+            'spv_j_ids': t(jj).repeat(B), 'spv_w_pt0_i': t(w_pt0).repeat(B, 1, 1), 'spv_pt1_i': t(grid).repeat(B, 1, 1)}
+
+
 def calibrate(seed=0):
     """Compute the calibrated layer3_outconv weight with far_amd's own backbone on CPU and store the asset."""
     import torch

@@ -402,3 +402,51 @@ def test_g14_spvs_coarse_matches_reference():
     d2.pop('conf_matrix_gt')
     spvs_coarse(d2, 8)
     assert 'conf_matrix_gt' not in d2 and torch.equal(d2['spv_j_ids'], data['spv_j_ids'])
+
+
+# ------------------------------------------------------------------------------------------------ G15
+def test_g15_losses_and_fine_supervision_match_reference():
+    """far_amd.losses.LoFTRLoss (coarse focal on the ground-truth positions + fine l2-with-std + 6D pose L1/L2) and
+    far_amd.supervision.spvs_fine against the reference's LoFTRLoss.forward / spvs_fine on the same tensors (golden G15).
+    The coarse term is evaluated three ways: gathered from conf_matrix_gt, from spv ids, and from data['conf_pos'] (the form
+    the GPU training path provides) -- all must give the reference's number."""
+    import types
+    from far_amd.config import far_train_config, RunCfg
+    from far_amd.losses import LoFTRLoss
+    from far_amd.supervision import spvs_fine, compute_supervision_fine
+    src = open(os.path.join(os.path.dirname(G), '..', 'tools', 'make_goldens.py')).read()
+    mod = types.ModuleType('loss_inputs_helper')
+    mod.__dict__.update({'np': np})
+    exec(src[src.index('def loss_inputs('):src.index('def g15_losses():')], mod.__dict__)
+    x = mod.loss_inputs()
+    g = load('g15_losses')
+    b, i, j = np.nonzero(x['gt'])
+    for tag, l1, shift in (('l1', True, 0.0), ('l2', False, 0.0), ('nocorrect', True, 5.0)):
+        cfg = far_train_config()
+        cfg['loftr']['loss']['use_l1_rt_loss'] = l1
+        lf = LoFTRLoss(cfg).train()
+        common = {'expec_f': torch.from_numpy(x['expec_f']), 'expec_f_gt': torch.from_numpy(x['expec_f_gt'] + np.float32(shift)),
+                  'expec_rt': torch.from_numpy(x['expec_rt']), 'T_0to1': torch.from_numpy(x['T']),
+                  'num_correspondences_after_ransac': 0, 'num_correspondences_before_ransac': 0}
+        conf = torch.from_numpy(x['conf'])
+        ids = {'spv_b_ids': torch.from_numpy(b), 'spv_i_ids': torch.from_numpy(i), 'spv_j_ids': torch.from_numpy(j)}
+        variants = [dict(common, conf_matrix=conf, conf_matrix_gt=torch.from_numpy(x['gt'])),
+                    dict(common, conf_matrix=conf, **ids),
+                    dict(common, conf_matrix=None, conf_pos=conf[ids['spv_b_ids'], ids['spv_i_ids'], ids['spv_j_ids']], **ids)]
+        for data in variants:
+            lf(data)
+            np.testing.assert_allclose(data['loss'].numpy(), g[f'loss_{tag}'], rtol=2e-6)
+            for k in ('loss_c', 'loss_f', 'loss_rot', 'loss_tr'):
+                np.testing.assert_allclose(data['loss_scalars'][k].item(), g[f'{k}_{tag}'], rtol=2e-6, atol=1e-9, err_msg=f'{k} {tag}')
+    # eval mode without a correct coarse match: no fine term, scalar 1 (loftr_loss.py:171-172, :322-324)
+    lf = LoFTRLoss(far_train_config()).eval()
+    data = dict(variants[1], expec_f_gt=torch.from_numpy(x['expec_f_gt'] + np.float32(5.0)))
+    lf(data)
+    assert float(data['loss_scalars']['loss_f']) == 1.0
+    data = {'spv_w_pt0_i': torch.from_numpy(x['w_pt0']), 'spv_pt1_i': torch.from_numpy(x['pt1']), 'b_ids': torch.from_numpy(x['b_ids']),
+            'i_ids': torch.from_numpy(x['i_ids']), 'j_ids': torch.from_numpy(x['j_ids']), 'dataset_name': ['mp3d']}
+    spvs_fine(data, {'LOFTR': {'RESOLUTION': (8, 2), 'FINE_WINDOW_SIZE': 5}})
+    np.testing.assert_array_equal(data['expec_f_gt'].numpy(), g['expec_f_gt'])
+    d2 = dict(data)
+    compute_supervision_fine(d2, RunCfg())               # the config object the pipeline hands over
+    np.testing.assert_array_equal(d2['expec_f_gt'].numpy(), g['expec_f_gt'])

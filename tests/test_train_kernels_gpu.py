@@ -263,3 +263,48 @@ def test_head_training_on_hip_matches_vendor_autograd():
     for k in keys:
         print(f'[head train] d{k}: {rel(ph[k], pv[k]):.3e}')
         assert rel(ph[k], pv[k]) < 5e-3, k
+
+
+@pytest.mark.parametrize('log2_scale', [-30, -12, 14])
+def test_backward_kernels_keep_their_precision_at_any_gradient_scale(log2_scale):
+    """Upstream gradients of a real loss sit anywhere between 1e-9 and 1e4; the backward kernels feed fp16 (pairs) to the
+    matrix cores, so each normalises by a power of two of its own first.  Scaling dL/dy by 2^k must reproduce the float64
+    gradients to the same relative error as at scale 1 (K9 dgrad: 1e-6; K1: 1e-3; K2: 5e-3) -- found by the fine-level
+    gradients of the training step, which are ~1e-7 and came out 4e-2 off before K9's dgrad normalised its input."""
+    from far_amd import autograd_ops as ag
+    from far_amd import ops
+    sc = 2.0 ** log2_scale
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    rng = np.random.default_rng(5)
+    mk = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32)).cuda()
+    # K9 Linear (dgrad on K9, wgrad vendor GEMM)
+    x, w, g = mk(40, 25, 256).requires_grad_(True), (mk(128, 256) / 16).requires_grad_(True), mk(40, 25, 128)
+    ops.linear_train(x, w, None, ops.PackCache(), ('t', 0)).backward(g * sc)
+    xr, wr = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
+    torch.nn.functional.linear(xr, wr).backward(g.double() * sc)
+    print(f'[scale 2^{log2_scale}] K9 dgrad {rel(x.grad, xr.grad):.2e} wgrad {rel(w.grad, wr.grad):.2e}')
+    assert rel(x.grad, xr.grad) < 1e-6 and rel(w.grad, wr.grad) < 1e-5
+    # K1 sparse-position confidences
+    hw = (24, 32)
+    f0n, f1n, _ = correlated_features(1, hw, 256, seed=3, amp=1.0, noise=0.5)
+    M = 400
+    pb = torch.zeros(M, dtype=torch.int64).cuda()
+    pi = torch.from_numpy(rng.integers(0, hw[0] * hw[1], M)).cuda()
+    pj = torch.from_numpy(rng.integers(0, hw[0] * hw[1], M)).cuda()
+    gp = mk(M)
+    f0, f1 = torch.from_numpy(f0n).cuda().requires_grad_(True), torch.from_numpy(f1n).cuda().requires_grad_(True)
+    ops.coarse_pos_conf(f0, f1, pb, pi, pj, 0.1).backward(gp * sc)
+    r0, r1 = torch.from_numpy(f0n).double().cuda().requires_grad_(True), torch.from_numpy(f1n).double().cuda().requires_grad_(True)
+    _ref_pos_conf(r0, r1, pb, pi, pj, 0.1).backward(gp.double() * sc)
+    print(f'[scale 2^{log2_scale}] K1 df0 {rel(f0.grad, r0.grad):.2e} df1 {rel(f1.grad, r1.grad):.2e}')
+    assert rel(f0.grad, r0.grad) < 2e-3 and rel(f1.grad, r1.grad) < 2e-3
+    # K2 bilinear attention
+    q, k, v = (mk(2, 221, 64).requires_grad_(True) for _ in range(3))
+    pos = torch.from_numpy(rng.random((221, 6)).astype(np.float32)).cuda()
+    dF = mk(2, 70, 70)
+    ops.emm_bilinear_train(q, k, v, pos, 0.125).backward(dF * sc)
+    r = [t.detach().double().requires_grad_(True) for t in (q, k, v)]
+    ag.bilinear_attention(r[0], r[1], r[2], pos.double(), 0.125).backward(dF.double() * sc)
+    errs = [rel(a.grad, b.grad) for a, b in zip((q, k, v), r)]
+    print(f'[scale 2^{log2_scale}] K2 dq {errs[0]:.2e} dk {errs[1]:.2e} dv {errs[2]:.2e}')
+    assert errs[0] < 5e-3 and errs[1] < 5e-3 and errs[2] < 1e-5

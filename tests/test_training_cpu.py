@@ -1,7 +1,8 @@
 """Training path (BASELINE configs[2]) on CPU: the differentiable vendor-op path of far_amd vs golden G10, which
 tools/make_goldens.py produced by running the REFERENCE's training-mode forward + backward.  Also a 2-rank gloo DDP
-step (gradient all-reduce = the one exchange step of the path).  The HIP kernels are forward-only this round; this
-is the path train.py would execute (far_amd/autograd_ops.py)."""
+step (gradient all-reduce = the one exchange step of the path).  On CPU tensors the modules run the differentiable
+vendor-op forms (far_amd/autograd_ops.py); on the GPU the same step runs K1 / K5 / K9-linear / K2 forward and backward
+kernels and is held to the same golden (tests/test_pipeline_gpu.py::test_training_step_on_gpu)."""
 import os
 import socket
 import sys

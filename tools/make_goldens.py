@@ -12,6 +12,7 @@ import sys
 import numpy as np
 import torch
 
+sys.dont_write_bytecode = True          # never leave __pycache__ files inside /root/reference
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tools'))
@@ -460,6 +461,61 @@ def g14_spvs_coarse():
     print('g14: GT matches', len(data['spv_b_ids']))
 
 
+def loss_inputs(seed=71, N=2, L=48, M=40):
+    """Shared by the generator and the tests: random coarse confidences / ground truth / fine predictions / poses."""
+    rng = np.random.default_rng(seed)
+    conf = rng.uniform(0, 1, (N, L, L)).astype(np.float32) ** 3
+    conf[0, 3, 5] = 0.0                                   # clamp paths (:84)
+    conf[1, 7, 7] = 1.0
+    gt = np.zeros((N, L, L), np.float32)
+    pos = [(0, 3, 5), (1, 7, 7)] + [(int(rng.integers(N)), int(rng.integers(L)), int(rng.integers(L))) for _ in range(30)]
+    for b, i, j in pos:
+        gt[b, i, j] = 1
+    expec_f = np.concatenate([rng.normal(0, 0.5, (M, 2)), rng.uniform(0.05, 2.0, (M, 1))], 1).astype(np.float32)
+    expec_f_gt = rng.normal(0, 0.7, (M, 2)).astype(np.float32)
+    expec_rt = rng.normal(0, 1, 9).astype(np.float32)
+    ang = 0.4
+    T = np.eye(4, dtype=np.float32)
+    T[:3, :3] = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]], np.float32)
+    T[:3, 3] = [0.3, -0.2, 1.1]
+    T = np.stack([T, np.eye(4, dtype=np.float32)])
+    # spvs_fine inputs
+    w_pt0 = rng.uniform(0, 640, (N, L, 2)).astype(np.float32)
+    pt1 = rng.uniform(0, 640, (N, L, 2)).astype(np.float32)
+    b_ids = rng.integers(0, N, M)
+    i_ids = rng.integers(0, L, M)
+    j_ids = rng.integers(0, L, M)
+    return dict(conf=conf, gt=gt, expec_f=expec_f, expec_f_gt=expec_f_gt, expec_rt=expec_rt, T=T, w_pt0=w_pt0, pt1=pt1,
+                b_ids=b_ids, i_ids=i_ids, j_ids=j_ids)
+
+
+def g15_losses():
+    """LoFTRLoss.forward (loftr_loss.py:294-356) and spvs_fine (supervision.py:142-166) of the reference."""
+    from src.losses.loftr_loss import LoFTRLoss
+    from src.loftr.utils.supervision import spvs_fine
+    from far_amd.config import far_train_config
+    x = loss_inputs()
+    out = {}
+    for tag, l1, none_correct in (('l1', True, False), ('l2', False, False), ('nocorrect', True, True)):
+        cfg = far_train_config()
+        cfg['loftr']['loss']['use_l1_rt_loss'] = l1
+        lf = LoFTRLoss(cfg).train()
+        gtf = x['expec_f_gt'] + (5.0 if none_correct else 0.0)
+        data = {'conf_matrix': torch.from_numpy(x['conf']), 'conf_matrix_gt': torch.from_numpy(x['gt']),
+                'expec_f': torch.from_numpy(x['expec_f']), 'expec_f_gt': torch.from_numpy(gtf),
+                'expec_rt': torch.from_numpy(x['expec_rt']), 'T_0to1': torch.from_numpy(x['T']),
+                'num_correspondences_after_ransac': 0, 'num_correspondences_before_ransac': 0}
+        lf(data)
+        out[f'loss_{tag}'] = data['loss'].numpy()
+        for k in ('loss_c', 'loss_f', 'loss_rot', 'loss_tr'):
+            out[f'{k}_{tag}'] = np.float64(data['loss_scalars'][k].item())
+    data = {'spv_w_pt0_i': torch.from_numpy(x['w_pt0']), 'spv_pt1_i': torch.from_numpy(x['pt1']), 'b_ids': torch.from_numpy(x['b_ids']),
+            'i_ids': torch.from_numpy(x['i_ids']), 'j_ids': torch.from_numpy(x['j_ids'])}
+    spvs_fine(data, {'LOFTR': {'RESOLUTION': (8, 2), 'FINE_WINDOW_SIZE': 5}})
+    save('g15_losses', seed=71, expec_f_gt=data['expec_f_gt'].numpy(), **out)
+    print('g15:', {k: float(np.ravel(v)[0]) for k, v in out.items()})
+
+
 def g8_manifest(m):
     man = {k: list(v.shape) for k, v in m.state_dict().items()}
     with open(os.path.join(OUT, 'g8_state_dict_manifest.json'), 'w') as f:
@@ -478,6 +534,9 @@ if __name__ == '__main__':
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'g11':
         g11_matcher_544x720(ref_model()[0])
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'g15':
+        g15_losses()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'g14':
         g14_spvs_coarse()
@@ -503,3 +562,4 @@ if __name__ == '__main__':
     g12_ransac_loop()
     g13_mapfree_corr_volume_warp()
     g14_spvs_coarse()
+    g15_losses()
