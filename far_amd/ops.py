@@ -401,11 +401,10 @@ class _LinearF16sFn(torch.autograd.Function):
             # ~[8e-3, 4e3], the range of activations -- gradients can sit anywhere (1e-7 is usual).  A power-of-two scale
             # taken from the tensor's maximum (on the device, no host sync) places them at the top of that window;
             # entries below max * 2^-17 keep 11 bits, which is 2^-28 of the maximum.
-            amax = g.abs().amax()
-            s = torch.exp2(torch.floor(10.0 - torch.log2(amax.clamp_min(1e-37))))
-            s = torch.where(amax > 0, s, torch.ones_like(s))
-            dx = linear_f16s(g * s, ctx.pack_t())
-            dx.mul_(1.0 / s)
+            e = torch.frexp(torch.linalg.vector_norm(g, ord=float('inf')))[1].clamp(min=-100)   # max |g| = m 2^e, m in [0.5, 1)
+            one = torch.ones((), dtype=torch.float32, device=g.device)
+            dx = linear_f16s(g * torch.ldexp(one, 10 - e), ctx.pack_t())
+            dx.mul_(torch.ldexp(one, e - 10))
         g2, x2 = g.reshape(-1, g.shape[-1]), xc.reshape(-1, xc.shape[-1])
         dw = g2.t().mm(x2) if ctx.needs_input_grad[1] else None
         db = g2.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
