@@ -50,6 +50,9 @@ def parse():
     ap.add_argument('--cpu-pairs', type=int, default=3)
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help="torch.distributed backend of the N > 1 run ('nccl' is RCCL on ROCm; 'gloo' only for the CPU self-test)")
+    ap.add_argument('--share-gpu', action='store_true',
+                    help="functional check of the N > 1 path on a one-GPU box: every rank uses cuda:0 (needs --backend gloo; RCCL "
+                         "refuses two ranks on one device).  The timings of such a run mean nothing.")
     ap.add_argument('--selftest-launcher', action='store_true',
                     help='rendezvous + barrier + timing reduction only (no GPU work): exercises the N > 1 launch path on CPU')
     return ap.parse_args()
@@ -430,7 +433,9 @@ def main():
         return selftest_launcher(a)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
+    local = 0 if a.share_gpu else int(os.environ.get('LOCAL_RANK', '0'))
+    if a.share_gpu and world > 1 and a.backend != 'gloo':
+        sys.exit('--share-gpu needs --backend gloo')
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist = None

@@ -12,6 +12,10 @@
 
 namespace {
 
+// tokens per KV partial sum of the forward (long sequences); knob 6 of far_set_tuning overrides it for A/B runs (the
+// workspace query reads the same knob: set it before sizing the workspace)
+static int fwd_chunk() { const int t = far_get_tuning(6); return t > 0 ? t : 320; }
+
 __device__ __forceinline__ float elu1(float x) { return (x > 0.f ? x : expm1f(x)) + 1.f; }  // F.elu(x) + 1
 
 // ---------------------------------------------------------------------------------------------------------
@@ -159,21 +163,25 @@ __global__ __launch_bounds__(256) void k_la_apply(const float* __restrict__ q, c
             qa[4 * t4 + 0] = elu1(raw[t4].x) * mk; qa[4 * t4 + 1] = elu1(raw[t4].y) * mk;
             qa[4 * t4 + 2] = elu1(raw[t4].z) * mk; qa[4 * t4 + 3] = elu1(raw[t4].w) * mk;
         }
+        // transposed product D[m = v][n = token]: the lane that fed token `col` gets that token's outputs for the channels
+        // v = row(r, kk) -- groups of four consecutive channels -> 16-byte stores (32 contiguous bytes per token and
+        // instruction with the kk twin) instead of 4-byte ones
         typename M::acc_t num, den;
 #pragma unroll
         for (int r = 0; r < M::NACC; ++r) { num[r] = 0.f; den[r] = 0.f; }
 #pragma unroll
         for (int t = 0; t < NK; ++t) {
-            num = M::mma(qa[t], bkv[t], num);
-            den = M::mma(qa[t], bks[t], den);
+            num = M::mma(bkv[t], qa[t], num);
+            den = M::mma(bks[t], qa[t], den);
         }
+        const int lo = ti * TT + col;
+        if (lo < L) {
+            const float zz = 1.0f / (den[0] + eps);                                  // linear_attention.py:46 (every row of den is the token's normaliser)
+            float* op = out + ((size_t)n * L + lo) * HD + h * D;
 #pragma unroll
-        for (int r = 0; r < M::NACC; ++r) {
-            const int lo = ti * TT + M::row(r, kk);
-            if (lo < L) {
-                const float zz = 1.0f / (den[r] + eps);                              // linear_attention.py:46
-                out[((size_t)n * L + lo) * HD + h * D + col] = (num[r] * zz) * fS;   // :50
-            }
+            for (int g = 0; g < M::NACC / 4; ++g)                                    // :50
+                *reinterpret_cast<float4*>(op + M::row(4 * g, kk)) = make_float4((num[4 * g] * zz) * fS, (num[4 * g + 1] * zz) * fS,
+                                                                                 (num[4 * g + 2] * zz) * fS, (num[4 * g + 3] * zz) * fS);
         }
 #pragma unroll
         for (int t4 = 0; t4 < NK / 4; ++t4) raw[t4] = nxt[t4];
@@ -181,11 +189,86 @@ __global__ __launch_bounds__(256) void k_la_apply(const float* __restrict__ q, c
     }
 }
 
+// Short sequences with 16-channel heads (the 25-token windows of the fine-level transformer: 61 k windows per 32 pairs):
+// one wave per (window, head) does both steps.  KV (16 x 16) never leaves the accumulator registers -- the layout the
+// first product leaves it in (lane (v, kk) holds KV[4 kk + r][v]) is the A operand of the second, transposed product
+// with the channel order d = 4 kk + t -- so the 532 MB kv round trip of the two-kernel form (a third of its traffic)
+// disappears.  Same products in the same order as k_la_kv_partial / k_la_apply.  No masks (the generic path has them).
+__global__ __launch_bounds__(256) void k_la_window16(const float* __restrict__ q, const float* __restrict__ k,
+                                                     const float* __restrict__ v, long units, int L, int S, int H, float eps,
+                                                     float* __restrict__ out) {
+    typedef Mf<16> M;
+    const int lane = threadIdx.x & 63, col = lane & 15, kk = lane >> 4;
+    const long unit = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (unit >= units) return;
+    const int h = (int)(unit % H);
+    const long n = unit / H;
+    const int HD = H * 16;
+    const float fS = (float)S;
+    const float* kp = k + ((size_t)n * S) * HD + h * 16 + col;
+    const float* vp = v + ((size_t)n * S) * HD + h * 16 + col;
+    float a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int s = 4 * u + kk;
+        a[u] = 0.f; b[u] = 0.f;
+        if (s < S) { a[u] = kp[(size_t)s * HD]; b[u] = vp[(size_t)s * HD]; }
+    }
+    float4 qv[2];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+        const int l = 16 * ti + col;
+        qv[ti] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (l < L) qv[ti] = *reinterpret_cast<const float4*>(q + ((size_t)n * L + l) * HD + h * 16 + 4 * kk);
+    }
+    f32x4 kv;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) kv[r] = 0.f;
+    float ks = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int s = 4 * u + kk;
+        const float ka = s < S ? elu1(a[u]) : 0.f;
+        ks += ka;
+        kv = M::mma(ka, b[u] / fS, kv);                                   // values / v_length (linear_attention.py:43)
+    }
+    ks += shfl_xor_f(ks, 16);
+    ks += shfl_xor_f(ks, 32);                                             // every lane with col = d holds ksum[d]
+    float bks[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) bks[t] = __shfl(ks, 4 * kk + t, 64);      // the normaliser's A operand: ksum[4 kk + t] in every row
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+        const int l = 16 * ti + col;
+        if (16 * ti >= L) break;
+        const float mk = l < L ? 1.f : 0.f;
+        const float qa[4] = {elu1(qv[ti].x) * mk, elu1(qv[ti].y) * mk, elu1(qv[ti].z) * mk, elu1(qv[ti].w) * mk};
+        f32x4 num, den;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { num[r] = 0.f; den[r] = 0.f; }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            num = M::mma(kv[t], qa[t], num);
+            den = M::mma(bks[t], qa[t], den);
+        }
+        if (l < L) {
+            const float zz = 1.0f / (den[0] + eps);
+            *reinterpret_cast<float4*>(out + ((size_t)n * L + l) * HD + h * 16 + 4 * kk) =
+                make_float4((num[0] * zz) * fS, (num[1] * zz) * fS, (num[2] * zz) * fS, (num[3] * zz) * fS);
+        }
+    }
+}
+
 template <int D>
 int launch_la(const float* q, const float* k, const float* v, int N, int L, int S, int H, const uint8_t* q_mask,
               const uint8_t* kv_mask, float eps, float* out, float* ws, hipStream_t stream) {
     const int HD = H * D;
-    int tok_per_chunk = S >= 1024 ? 320 : S;
+    if (D == 16 && L <= 32 && S <= 32 && !q_mask && !kv_mask && far_get_tuning(4) == 0) {
+        const long units = (long)N * H;
+        hipLaunchKernelGGL(k_la_window16, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, stream, q, k, v, units, L, S, H, eps, out);
+        return far_check_launch();
+    }
+    int tok_per_chunk = S >= 1024 ? fwd_chunk() : S;
     int nchunk = (S + tok_per_chunk - 1) / tok_per_chunk;
     size_t per_n = (size_t)HD * (D + 1);
     float* part = ws;
@@ -198,7 +281,8 @@ int launch_la(const float* q, const float* k, const float* v, int N, int L, int 
         hipLaunchKernelGGL(k_la_kv_reduce, dim3((int)((per_n + 255) / 256) * N), dim3(256), 0, stream, part, nchunk,
                            (int)per_n, kv);
     const int ntile = (L + D - 1) / D;
-    int tiles_per_unit = ntile >= 64 ? 8 : ntile;
+    int tiles_per_unit = ntile >= 64 ? 4 : ntile;     // measured at 32 x 4800 x 256: 2-4 tiles 169-172 us (kv + apply), 8: 179, 16: 186
+    if (far_get_tuning(5) > 0) tiles_per_unit = std::min(ntile, far_get_tuning(5));      // A/B knob
     int nblk = (ntile + tiles_per_unit - 1) / tiles_per_unit;
     long aunits = (long)N * nblk * H;
     hipLaunchKernelGGL(k_la_apply<D>, dim3((unsigned)((aunits + 3) / 4)), dim3(256), 0, stream, q, kv, q_mask, N, L, S, H,
@@ -211,7 +295,7 @@ int launch_la(const float* q, const float* k, const float* v, int N, int L, int 
 extern "C" {
 
 size_t far_linear_attention_workspace_bytes(int N, int S, int H, int D) {
-    int tok_per_chunk = S >= 1024 ? 320 : S;
+    int tok_per_chunk = S >= 1024 ? fwd_chunk() : S;
     int nchunk = (S + tok_per_chunk - 1) / tok_per_chunk;
     return ((size_t)N * nchunk + N) * (size_t)H * D * (D + 1) * sizeof(float);
 }

@@ -66,6 +66,31 @@ def test_linear_attention(N, L, S, C):
     np.testing.assert_allclose(got, ref, atol=1e-5 * np.abs(ref).max(), rtol=1e-4)
 
 
+@pytest.mark.parametrize('N,L,S', [(700, 25, 25), (5, 32, 32), (7, 17, 9), (3, 1, 1), (4, 9, 30)])
+def test_linear_attention_short_windows_fused_kernel(N, L, S):
+    """The one-kernel form used for short sequences with 16-channel heads (the fine-level windows): against the float64
+    oracle, and against the generic two-kernel path (same products in the same order: equal to the last bit or two)."""
+    from far_amd import _lib, ops
+    from oracle import attention as oa
+    rng = np.random.default_rng(L * 100 + S)
+    q = rng.standard_normal((N, L, 128)).astype(np.float32)
+    k = rng.standard_normal((N, S, 128)).astype(np.float32)
+    v = rng.standard_normal((N, S, 128)).astype(np.float32)
+    t = [torch.from_numpy(a).cuda() for a in (q, k, v)]
+    got = ops.linear_attention(*t, 8)
+    ref = oa.linear_attention(q, k, v, 8, dtype=np.float64)
+    np.testing.assert_allclose(got.cpu().numpy(), ref, atol=1e-5 * np.abs(ref).max(), rtol=1e-4)
+    lib = _lib.load()
+    lib.far_set_tuning(4, 1)                     # A/B knob: generic path
+    try:
+        gen = ops.linear_attention(*t, 8)
+    finally:
+        lib.far_set_tuning(4, 0)
+    d = float((got - gen).abs().max()) / float(gen.abs().max())
+    print(f'[k5 window] N={N} L={L} S={S}: fused vs generic max rel diff {d:.2e}')
+    assert d < 1e-6
+
+
 @pytest.mark.parametrize('rows,C,res', [(4800 * 3, 256, True), (1000, 256, False), (777 * 25, 128, True), (33, 512, False), (10, 200, True)])
 def test_layernorm(rows, C, res):
     from far_amd import ops
