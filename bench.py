@@ -40,7 +40,7 @@ def parse():
     ap.add_argument('--vendor-train', action='store_true',
                     help='c3 only: run the training step on the differentiable vendor-op forms (far_amd/autograd_ops.py) instead '
                          'of the HIP forward/backward kernels -- the comparison leg')
-    ap.add_argument('--workload', default='c2', choices=['c2', 'c3', 'c4'],
+    ap.add_argument('--workload', default='c2', choices=['c2', 'c3', 'c4', 'c5'],
                     help="c2 = BASELINE configs[1] (the headline metric: match + solve + regress, batch 32); "
                          "c4 = BASELINE configs[3] (cached-LoFTR path: GPU solver on cached correspondences + head, batch 256)")
     ap.add_argument('--hyp', type=int, default=2048, help='RANSAC hypotheses per pair (metrics.py:120)')
@@ -421,10 +421,84 @@ def bench_c3(a, dev, world, rank, dist):
         dist.destroy_process_group()
 
 
+def bench_c5(a, dev, world, rank, dist):
+    """BASELINE configs[4]: Map-free-shaped matcher + solver at 544 x 720 (coarse grid 68 x 90, L = S = 6120), the batched form
+    of the reference's per-sample loop (mapfree_6dreg/lib/models/regression/model.py:236-273 -> far_amd.mapfree.match_and_solve):
+    LoFTR match + GPU 8-pt RANSAC, a second solver round with a pose prior (the `use_prior` loop).  No EMM head: the
+    reference's head is tied to the 60 x 80 grid."""
+    from far_amd import parallel, synth, ops
+    from far_amd.config import far_eval_config
+    from far_amd.loftr import LoFTR
+    from far_amd.mapfree import EssentialMatrixSolver, match_and_solve
+    B = a.pairs
+    model = LoFTR(far_eval_config()).eval()
+    synth.load_synthetic(model, seed=0)
+    model = model.to(dev)
+    model.set_precision(a.precision)
+    im0, im1 = synth.synth_image_pair(B, seed=1234 + rank, hw=(544, 720))
+    Kc = np.array([[590.0, 0, 360.], [0, 590.0, 272.], [0, 0, 1.]])
+    K = torch.from_numpy(np.stack([Kc] * B)).to(dev)
+    base = {'image0': torch.from_numpy(im0).to(dev), 'image1': torch.from_numpy(im1).to(dev), 'K_color0': K, 'K_color1': K.clone()}
+    solver = EssentialMatrixSolver(None, use_prior_ransac=True, H=a.hyp, seed=0)
+    prior = np.stack([np.concatenate([np.eye(3), np.array([[-1.0], [0.0], [0.0]])], 1)] * B).astype(np.float32)
+
+    def step():
+        batch = dict(base)
+        match_and_solve(model, batch, solver, priorRT=None)
+        # second loop of `use_prior` (model.py:239-241): the solver again, now with a prior pose
+        out = solver.solve_batch(batch['mkpts0_f'], batch['mkpts1_f'], batch['match_counts'].tolist(), K, K, prior)
+        batch['solver_status2'] = out['status']
+        return batch
+
+    prime = max(0, 3 - a.warmup)
+    for _ in range(prime + a.warmup):
+        last = step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        last = step()
+    fence()
+    dt = time.perf_counter() - t0
+    per_rank_ms = [round(1000 * x / a.steps, 3) for x in parallel.gather_floats(dt, device=dev)]
+    dt = parallel.max_over_ranks(dt, device=dev)
+    if rank == 0:
+        Lc = 68 * 90
+        g = torch.Generator(device=dev).manual_seed(1)
+        f0 = 1.2 * torch.randn(B, Lc, C, device=dev, generator=g)
+        f1 = f0[:, torch.randperm(Lc, device=dev, generator=g)] + 0.1 * torch.randn(B, Lc, C, device=dev, generator=g)
+        t_k1 = event_time_ms(lambda: ops.coarse_match(f0, f1, 0.1, 0.2, 2, (68, 90), (68, 90), 8.0, variant='f16s'))
+        res = {
+            'metric': 'image-pairs/sec (match+solve) at 544x720 -- BASELINE configs[4], not the headline metric',
+            'value': round(world * B * a.steps / dt, 3), 'unit': 'image-pairs/sec', 'n_gpus': world, 'steps': a.steps,
+            'warmup': a.warmup, 'prime_steps': prime, 'ms_per_step': round(1000 * dt / a.steps, 3),
+            'per_rank_ms_per_step': per_rank_ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32' if a.precision == 'fp32' else f'f32 tensors/accumulation, {a.precision} matrix operands', 'data': 'synthetic',
+            'config': {'workload': 'Map-free-shaped matcher + solver (BASELINE configs[4]): ' + str(B) + ' pairs @ 544x720 per GPU '
+                                   '(coarse 68x90, L = S = 6120), LoFTR match + GPU 8-pt RANSAC + a prior-RANSAC round, seeded random weights',
+                       'pairs_per_gpu': B, 'hypotheses': a.hyp, 'matches_per_pair': round(float(last['m_bids'].numel()) / B, 1),
+                       'solver_success_frac': float(last['solver_status'].float().mean().item()),
+                       'parallelism': f'dp{world} (independent pairs, no data-path collective)'},
+            'k1': {'ms': round(t_k1, 3), 'pairs': B, 'L': Lc,
+                   'tflops': round(2.0 * Lc * Lc * C * B / t_k1 / 1e9, 2),
+                   'frac_of_f16_mfma_peak': round(2.0 * Lc * Lc * C * B / t_k1 / 1e9 / F16_MFMA_PEAK_TFLOPS, 4),
+                   'note': 'far_coarse_match_f16s, all passes; algorithmic flops = 2 L S C per pair (one correlation; the kernel executes three passes of three f16 MFMAs per product), HIP events'},
+        }
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     a = parse()
     if a.pairs is None:
-        a.pairs = {'c4': 256, 'c3': 1}.get(a.workload, PAIRS_PER_GPU)
+        a.pairs = {'c4': 256, 'c3': 1, 'c5': 16}.get(a.workload, PAIRS_PER_GPU)
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # plain `python bench.py --gpus N`: start the N ranks as children BEFORE this process initialises the GPU
         from far_amd import parallel
@@ -447,6 +521,8 @@ def main():
         return bench_c4(a, dev, world, rank, dist)
     if a.workload == 'c3':
         return bench_c3(a, dev, world, rank, dist)
+    if a.workload == 'c5':
+        return bench_c5(a, dev, world, rank, dist)
     from far_amd import synth
     from far_amd.config import far_eval_config
     from far_amd.loftr import LoFTR
