@@ -715,10 +715,12 @@ int far_solver_f64(const float* kpts0, const float* kpts1, const int* offsets, i
                    void* ws, hipStream_t stream) {
     far_clear_errors();
     if (B <= 0) return FAR_OK;
-    if (!offsets || !K0 || !K1 || !inl_th || !R_out || !t_out || !E_out || !mask_out || !status_out ||
+    if (!offsets || !K0 || !K1 || !inl_th || !R_out || !t_out || !E_out || !status_out ||
         !num_after_out || !n_tight_out || !n_ultra_out || !n_cheir_out || !best_out || !ws || H <= 0 || Mtot < 0)
         return FAR_EINVAL;
-    if (Mtot > 0 && (!kpts0 || !kpts1)) return FAR_EINVAL;
+    // a batch in which no pair has a correspondence (Mtot == 0) is legal: every pair reports status 0 (metrics.py:83-85);
+    // the per-correspondence arrays are then empty and may be null
+    if (Mtot > 0 && (!kpts0 || !kpts1 || !mask_out)) return FAR_EINVAL;
     if (priorRT && (!pcl || P <= 0)) return FAR_EINVAL;
     SolverWs w = carve(ws, B, Mtot > 0 ? Mtot : 1, H, P > 0 ? P : 1);
     const bool prior = priorRT != nullptr;

@@ -31,13 +31,25 @@ def coarse_positive_conf(data):
     return data['conf_matrix'][data['spv_b_ids'], data['spv_i_ids'], data['spv_j_ids']]
 
 
+def has_no_ground_truth(data):
+    """The corner case of loftr_loss.py:65-70: not a single ground-truth coarse match.  spvs_coarse then leaves ONE dummy
+    entry (0, 0, 0) in spv_*_ids (supervision.py:122-128) that only keeps the fine level alive; the coarse loss must
+    weigh it with zero.  far_amd's spvs_coarse records the real count; with the reference's own supervision the dense
+    conf_matrix_gt tells; failing both, a lone entry at cell 0 is the dummy (cell 0 is never a real match, :103)."""
+    if 'spv_gt_count' in data:
+        return int(data['spv_gt_count']) == 0
+    if data.get('conf_matrix_gt') is not None:
+        return not bool((data['conf_matrix_gt'] == 1).any())
+    ids = data['spv_i_ids']
+    return ids.numel() == 0 or (ids.numel() == 1 and int(ids[0]) == 0)
+
+
 def coarse_focal_loss(data, alpha=FOCAL_ALPHA, gamma=FOCAL_GAMMA, pos_weight=POS_WEIGHT, weight=None):
     """loftr_loss.py:56-112 (sparse_spvs, dual_softmax, focal).  weight: optional per-position loss weights
     (compute_c_weight, :276-283: padded-mask datasets only)."""
     p = coarse_positive_conf(data)
-    if p.numel() == 0:                       # corner case :64-68: no ground-truth match -> a dummy positive with weight 0
-        ref = data['conf_pos'] if data.get('conf_pos') is not None else data['conf_matrix']
-        return ref.sum() * 0.0
+    if p.numel() == 0 or has_no_ground_truth(data):   # :65-70: a dummy positive with c_pos_w = 0 -> the term and its gradient vanish
+        return p.sum() * 0.0 if p.numel() else (data['conf_pos'] if data.get('conf_pos') is not None else data['conf_matrix']).sum() * 0.0
     p = torch.clamp(p, 1e-6, 1 - 1e-6)                                         # :84
     loss_pos = -alpha * torch.pow(1 - p, gamma) * p.log()                      # :92
     if weight is not None:
@@ -122,7 +134,7 @@ class LoFTRLoss(torch.nn.Module):
             d = data
             if data.get('conf_pos') is None and 'spv_b_ids' not in data:                       # dense drop-in use: positions from conf_matrix_gt
                 b, i, j = torch.where(data['conf_matrix_gt'] == 1)
-                d = dict(data, spv_b_ids=b, spv_i_ids=i, spv_j_ids=j)
+                d = dict(data, spv_b_ids=b, spv_i_ids=i, spv_j_ids=j, spv_gt_count=int(b.numel()))
             loss_c = coarse_focal_loss(d, lc['focal_alpha'], lc['focal_gamma'], self.c_pos_w, weight=self.compute_c_weight(d))
             loss = loss + loss_c * lc['coarse_weight']                                         # :314
             scalars['loss_c'] = loss_c.detach().cpu()

@@ -140,9 +140,12 @@ def spvs_coarse(data, config, dense_gt=False):
         gt = torch.zeros(N, h0 * w0, h1 * w1, device=dev)
         gt[b_ids, i_ids, j_ids] = 1
         data['conf_matrix_gt'] = gt
-    if len(b_ids) == 0:                                                                        # :122-128
+    n_gt = len(b_ids)
+    if n_gt == 0:                                                                              # :122-128
         b_ids = i_ids = j_ids = torch.zeros(1, dtype=torch.long, device=dev)
-    data.update({'spv_b_ids': b_ids, 'spv_i_ids': i_ids, 'spv_j_ids': j_ids, 'spv_w_pt0_i': w_pt0_i, 'spv_pt1_i': pt1_i})
+    # spv_gt_count: what `conf_matrix_gt.any()` tells the reference's loss (loftr_loss.py:65-70) now that no dense matrix exists
+    data.update({'spv_b_ids': b_ids, 'spv_i_ids': i_ids, 'spv_j_ids': j_ids, 'spv_w_pt0_i': w_pt0_i, 'spv_pt1_i': pt1_i,
+                 'spv_gt_count': n_gt})
 
 
 def compute_supervision_coarse(data, config, **kw):

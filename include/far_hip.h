@@ -331,7 +331,8 @@ size_t far_solver_workspace_bytes(int B, int Mtot, int H, int P);
  *   also pass cheirality, as cv2.recoverPose leaves its in/out mask); status_out [B] (1 = pose valid, 0 = the
  *   reference's `ret is None`); num_after_out, n_tight_out, n_ultra_out, n_cheir_out, best_out [B] int32.
  *   Optional debug outputs (NULL to skip): F_all_out [B][H][9], count_all_out [B][H], score_all_out [B][H],
- *   samples_out [B][H][8]. */
+ *   samples_out [B][H][8].  Mtot == 0 (no pair has a correspondence) is legal: kpts0 / kpts1 / mask_out may then be
+ *   NULL and every pair reports status 0. */
 int far_solver_f64(const float* kpts0, const float* kpts1, const int* offsets, int B, int Mtot, int Mmax,
                    const double* K0, const double* K1, const double* inl_th, int many_thr,
                    const float* priorRT, const float* pcl, int P, double prior_lambda,

@@ -438,6 +438,23 @@ def test_g15_losses_and_fine_supervision_match_reference():
             np.testing.assert_allclose(data['loss'].numpy(), g[f'loss_{tag}'], rtol=2e-6)
             for k in ('loss_c', 'loss_f', 'loss_rot', 'loss_tr'):
                 np.testing.assert_allclose(data['loss_scalars'][k].item(), g[f'{k}_{tag}'], rtol=2e-6, atol=1e-9, err_msg=f'{k} {tag}')
+    # no ground-truth coarse match at all (loftr_loss.py:65-70): the dummy (0, 0, 0) entry that spvs_coarse leaves
+    # (supervision.py:122-128) carries zero weight -- dense form, far_amd's sparse form with spv_gt_count, and the bare
+    # dummy ids (a lone entry at cell 0 can only be the dummy)
+    lf = LoFTRLoss(far_train_config()).train()
+    zero = torch.zeros(1, dtype=torch.int64)
+    dummy = {'spv_b_ids': zero, 'spv_i_ids': zero, 'spv_j_ids': zero}
+    conf_g = conf.clone().requires_grad_(True)
+    forms = [dict(common, conf_matrix=conf, conf_matrix_gt=torch.zeros_like(conf)),
+             dict(common, conf_matrix=None, conf_pos=conf_g[zero, zero, zero], spv_gt_count=0, **dummy),
+             dict(common, conf_matrix=conf, **dummy)]
+    for data in forms:
+        data['expec_f_gt'] = torch.from_numpy(x['expec_f_gt'])
+        lf(data)
+        assert float(data['loss_scalars']['loss_c']) == float(g['loss_c_nogt']) == 0.0
+        np.testing.assert_allclose(data['loss'].detach().numpy(), g['loss_nogt'], rtol=2e-6)
+    forms[1]['loss'].backward()
+    assert float(conf_g.grad.abs().max()) == 0.0              # and no gradient flows into the dummy position
     # eval mode without a correct coarse match: no fine term, scalar 1 (loftr_loss.py:171-172, :322-324)
     lf = LoFTRLoss(far_train_config()).eval()
     data = dict(variants[1], expec_f_gt=torch.from_numpy(x['expec_f_gt'] + np.float32(5.0)))

@@ -445,6 +445,40 @@ def test_train_step_pipeline_two_pairs_and_optimizer(model):
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
 
 
+def test_train_step_on_a_pair_without_predictions_or_ground_truth(model):
+    """Early-training / bad-pair corner cases in one batch of two pairs, both blank images (the matcher predicts nothing):
+    pair-level ground truth present (every sampled match is a padded GT match, coarse_matching.py:225-240; the solver gets
+    M = 0 and falls back to the identity, supervision.py:221-224), and -- second run -- no ground truth at all (the dummy
+    (0, 0, 0) entry with zero coarse weight, loftr_loss.py:65-70).  Loss and all gradients finite."""
+    import copy
+    from far_amd.config import far_train_config, RunCfg
+    from far_amd.losses import LoFTRLoss
+    from far_amd.pipeline import train_step
+    m = copy.deepcopy(model).train()
+    m.coarse_matching.thr = 2.0                   # confidences are <= 1: the matcher predicts nothing (training-mode BatchNorm
+                                                  # still finds a few matches between two blank images otherwise)
+    loss_fn = LoFTRLoss(far_train_config()).train()
+    base = synth.synth_training_batch(2, seed=78, device='cuda')
+    base['image0'] = torch.full_like(base['image0'], 0.5)
+    base['image1'] = torch.full_like(base['image1'], 0.5)
+    zero = torch.zeros(1, dtype=torch.int64, device='cuda')
+    for no_gt in (False, True):
+        batch = dict(base)
+        if no_gt:
+            batch.update(spv_b_ids=zero, spv_i_ids=zero, spv_j_ids=zero, spv_gt_count=0)
+        m.zero_grad()
+        train_step(m, batch, loss_fn, RunCfg('prior_ransac', 2), H=256, seed=0)
+        assert int((batch['mconf'] != 0).sum()) == 0                       # nothing predicted: only padded ground truth
+        assert batch['solver_status'].tolist() == [0, 0]
+        np.testing.assert_array_equal(batch['loftr_rt'].cpu().numpy(), np.stack([np.eye(3, 4)] * 2))
+        assert torch.isfinite(batch['loss']).all()
+        if no_gt:
+            assert float(batch['loss_scalars']['loss_c']) == 0.0
+        batch['loss'].backward()
+        for k, p_ in m.named_parameters():
+            assert p_.grad is None or torch.isfinite(p_.grad).all(), k
+
+
 def test_pair_without_matches_in_a_batch(model):
     """A blank pair inside a batch: no coarse matches for it, the solver reports failure for that pair and the
     reference's identity fallback applies (supervision.py:221-224); the other pair is unaffected."""

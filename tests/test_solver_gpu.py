@@ -86,6 +86,12 @@ def test_degenerate_inputs():
     assert list(got['status']) == [0, 1, 0]
     assert got['num_after'][0] == 0 and got['num_after'][2] == 0
     assert got['mask'][offs[0]:offs[1]].sum() == 0
+    # a whole batch without a single correspondence (two blank pairs early in training): legal, every status 0
+    pri = np.stack([np.eye(3, 4)] * 2)
+    pcl = np.random.RandomState(0).uniform(-3, 3, (300, 3)).astype(np.float32)
+    for mode in ('ransac', 'prior'):
+        got, offs = _run([s_none, s_none], mode, pri if mode == 'prior' else None, pcl if mode == 'prior' else None)
+        assert list(got['status']) == [0, 0] and list(got['num_after']) == [0, 0] and len(got['mask']) == 0
 
 
 def test_explicit_samples_match_reference_style_call():

@@ -509,6 +509,15 @@ def g15_losses():
         out[f'loss_{tag}'] = data['loss'].numpy()
         for k in ('loss_c', 'loss_f', 'loss_rot', 'loss_tr'):
             out[f'{k}_{tag}'] = np.float64(data['loss_scalars'][k].item())
+    # corner case loftr_loss.py:65-70: no ground-truth coarse match at all (conf_matrix_gt all zero)
+    lf = LoFTRLoss(far_train_config()).train()
+    data = {'conf_matrix': torch.from_numpy(x['conf']), 'conf_matrix_gt': torch.zeros_like(torch.from_numpy(x['gt'])),
+            'expec_f': torch.from_numpy(x['expec_f']), 'expec_f_gt': torch.from_numpy(x['expec_f_gt']),
+            'expec_rt': torch.from_numpy(x['expec_rt']), 'T_0to1': torch.from_numpy(x['T']),
+            'num_correspondences_after_ransac': 0, 'num_correspondences_before_ransac': 0}
+    lf(data)
+    out['loss_nogt'] = data['loss'].numpy()
+    out['loss_c_nogt'] = np.float64(data['loss_scalars']['loss_c'].item())
     data = {'spv_w_pt0_i': torch.from_numpy(x['w_pt0']), 'spv_pt1_i': torch.from_numpy(x['pt1']), 'b_ids': torch.from_numpy(x['b_ids']),
             'i_ids': torch.from_numpy(x['i_ids']), 'j_ids': torch.from_numpy(x['j_ids'])}
     spvs_fine(data, {'LOFTR': {'RESOLUTION': (8, 2), 'FINE_WINDOW_SIZE': 5}})
