@@ -479,6 +479,58 @@ def test_train_step_on_a_pair_without_predictions_or_ground_truth(model):
             assert p_.grad is None or torch.isfinite(p_.grad).all(), k
 
 
+def test_step_with_no_match_in_the_whole_batch(model):
+    """Every pair blank (B = 2 and B = 1): M = 0 everywhere -- empty (0, .) tensors from the fine stage
+    (fine_preprocess.py:34-37, fine_matching.py:33-41), a solver batch without a single correspondence, identity poses into
+    the head; nothing raises, the head's output is finite."""
+    from far_amd.pipeline import test_step
+    for B in (2, 1):
+        data, _, _ = _batch(B, 9)
+        data['image0'].zero_()
+        data['image1'].zero_()
+        test_step(model, data, H=256)
+        assert data['b_ids'].numel() == 0 and data['mkpts0_f'].shape == (0, 2) and data['mkpts1_f'].shape == (0, 2)
+        assert data['expec_f'].shape == (0, 3)
+        assert data['solver_status'].tolist() == [0] * B
+        rt = data['loftr_rt'].reshape(B, 3, 4).cpu().numpy()
+        np.testing.assert_array_equal(rt, np.stack([np.eye(3, 4)] * B))
+        assert data['regressed_rt'].shape == (B, 9) and torch.isfinite(data['regressed_rt']).all()
+
+
+def test_step_on_a_side_stream_equals_the_default_stream(model):
+    """Every far_* call is enqueued on torch's CURRENT stream (the stream argument of the C ABI); nothing may silently run
+    on the null stream.  The whole step on a side stream must reproduce the default-stream results exactly."""
+    from far_amd.pipeline import test_step
+    ref, _, _ = _batch(2, 12)
+    test_step(model, ref, H=256)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    data, _, _ = _batch(2, 12)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        test_step(model, data, H=256)
+    side.synchronize()
+    for k in ('b_ids', 'i_ids', 'j_ids', 'mconf', 'mkpts1_f', 'loftr_rt', 'regressed_rt', 'solver_inlier_mask'):
+        assert torch.equal(data[k], ref[k]), k
+
+
+def test_non_contiguous_inputs_are_accepted(model):
+    """Images that are strided views (a pair tensor (N, 2, H, W) sliced per view, as a dataloader may hand them over) and
+    intrinsics that are views of a larger tensor: same results as with packed copies."""
+    from far_amd.pipeline import test_step
+    ref, im0, im1 = _batch(2, 13)
+    test_step(model, ref, H=256)
+    pair = torch.from_numpy(np.concatenate([im0, im1], 1)).cuda()              # (N, 2, H, W)
+    Kbig = torch.zeros(2, 2, 3, 3, dtype=torch.float64, device='cuda')
+    Kbig[:, 0] = ref['K0']
+    Kbig[:, 1] = ref['K1']
+    data = {'image0': pair[:, 0:1], 'image1': pair[:, 1:2], 'K0': Kbig[:, 0], 'K1': Kbig[:, 1], 'dataset_name': ['mp3d']}
+    assert not data['image0'].is_contiguous() and not data['K0'].is_contiguous()
+    test_step(model, data, H=256)
+    for k in ('b_ids', 'i_ids', 'j_ids', 'mconf', 'mkpts1_f', 'loftr_rt', 'regressed_rt'):
+        assert torch.equal(data[k], ref[k]), k
+
+
 def test_pair_without_matches_in_a_batch(model):
     """A blank pair inside a batch: no coarse matches for it, the solver reports failure for that pair and the
     reference's identity fallback applies (supervision.py:221-224); the other pair is unaffected."""
