@@ -105,6 +105,26 @@ def test_conv_small_activations_keep_precision():
     assert float((y.double() - ref).abs().max()) < 5e-8
 
 
+def test_conv_activation_overflow_is_loud():
+    """K9 splits activations after a fixed 2^4 scale: |a| > 4094 leaves fp16's range.  That must never produce a
+    plausible finite number: every output that reads such an activation is inf / NaN, every other output is still right."""
+    ops = _ops()
+    g = torch.Generator(device='cuda').manual_seed(13)
+    x = torch.randn(1, 16, 16, 64, device='cuda', generator=g)
+    w = torch.randn(64, 64, 3, 3, device='cuda', generator=g) * 0.05
+    ok = ops.conv_nhwc(x * 200.0, ops.PackedConv(w))                  # |a| up to ~900: inside the window
+    ref = F.conv2d((x * 200.0).permute(0, 3, 1, 2).double(), w.double(), padding=1).permute(0, 2, 3, 1)
+    assert torch.isfinite(ok).all() and _rel(ok, ref)[0] < 4e-6
+    xb = x.clone()
+    xb[0, 5, 7, 3] = 5000.0
+    y = ops.conv_nhwc(xb, ops.PackedConv(w))
+    hit = torch.zeros(16, 16, dtype=torch.bool, device='cuda')
+    hit[4:7, 6:9] = True                                              # the 3x3 outputs that read pixel (5, 7)
+    assert not torch.isfinite(y[0][hit]).any()                        # all 9 x 64 affected outputs are inf / NaN
+    good = ops.conv_nhwc(x, ops.PackedConv(w))
+    assert torch.equal(y[0][~hit], good[0][~hit])                     # and nothing else moved
+
+
 def test_linear_wrapper_matches_addmm():
     ops = _ops()
     g = torch.Generator(device='cuda').manual_seed(3)
