@@ -19,6 +19,9 @@
 //                  v~) -> fp16 hi / lo straight from the accumulator registers -> T += P v~ (36 MFMAs)
 #include "common.h"
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
 namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -90,6 +93,13 @@ struct RowFrags {
             lo[s] = *reinterpret_cast<const f16x8*>(pl + row * D + 8 * slot);
         }
     }
+    // Waits for the loads above HERE and tells the compiler so (the fragments are operands of the statement): left
+    // "possibly pending", hipcc re-waits for them with a descending vmcnt ladder inside the tile loop, where the counter
+    // belongs to the asm-issued tile requests -- each wait of the ladder would then stall on a tile still in flight.
+    __device__ __forceinline__ void arrived() {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]),
+                                            "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]) : : "memory");
+    }
 };
 
 // One 64-row tile of the swizzled ("column") side in LDS: [plane][64 rows][128 B].  Linear DMA of 2 x 8 KiB.
@@ -101,6 +111,30 @@ __device__ __forceinline__ void dma_col_tile(unsigned char* lds, const _Float16*
     for (int j = 0; j < 2; ++j) {
         __builtin_amdgcn_global_load_lds((gptr_t)(sh + j * 4096), (lptr_t)(lds + j * 4096 + wave * 1024), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((gptr_t)(sl + j * 4096), (lptr_t)(lds + CT_PLANE + j * 4096 + wave * 1024), 16, 0, 0);
+    }
+}
+
+// The same requests as `asm`: once a kernel keeps a tile in flight WHILE it computes on the previous one, hipcc's wait
+// insertion puts s_waitcnt vmcnt(0) in front of the first ds_read that follows an LDS-DMA builtin (it cannot tell the
+// two stages apart), which serialises load and compute again.  Requests issued from asm are invisible to that
+// bookkeeping; completion is waited for by hand at the top of the loop, visibility to the other waves comes from the
+// barrier.  M0 (LDS base of the request) is saved and restored inside the statement.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst_uniform) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr_uniform(const unsigned char* p) {
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(lptr_t)p);
+}
+__device__ __forceinline__ void dma_col_tile_async(unsigned char* lds, const _Float16* gh, const _Float16* gl, size_t row0, int tid, int wave) {
+    const unsigned char* sh = reinterpret_cast<const unsigned char*>(gh + row0 * D) + tid * 16;
+    const unsigned char* sl = reinterpret_cast<const unsigned char*>(gl + row0 * D) + tid * 16;
+    const unsigned dst = lds_addr_uniform(lds + wave * 1024);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        glds16(sh + j * 4096, dst + j * 4096);
+        glds16(sl + j * 4096, dst + CT_PLANE + j * 4096);
     }
 }
 
@@ -130,55 +164,96 @@ __device__ __forceinline__ void score_tile(f32x16 (&acc)[2], const unsigned char
 }
 
 // ---- k_rowstats: stat[z][i] = (max_j x_ij, sum_j 2^(x_ij - max)),  x = (a_i . b_j) * c1   (log2 domain)
-__global__ __launch_bounds__(256, 3) void k_rowstats(const _Float16* __restrict__ ah, const _Float16* __restrict__ al,
+// With 64-channel heads a tile is 24 MFMAs (768 matrix-pipe cycles at the nominal clock) against ~135 softmax VALU
+// instructions (33 of them exps at quarter rate).  Measured on 256 problems of 4800 x 4800 (round 2, rocprofv3): the MFMAs
+// and tile traffic alone take 1.83 ms, the VALU work alone 1.12 ms, the kernel 2.35 ms -- i.e. the matrix pipe under this
+// load (three dense f16 MFMAs per product, clock power-limited to ~1.3-1.5 GHz) is the bound, and what is left to gain is
+// the 0.5 ms of imperfect overlap.  Tried one by one, each within 5 % of 2.4 ms: padding test behind a wave-uniform branch +
+// packed fp32 ops (a third fewer VALU instructions), double-buffered tiles through asm LDS-DMA, two row tiles per wave
+// (half the LDS fragment reads per MFMA), and the in-wave software pipeline kept here: the MFMAs of tile t+1 interleaved
+// (sched_group_barrier) with the softmax update of tile t, whose scores sit in a second accumulator pair.
+template <bool MASKED>
+__device__ __forceinline__ void rowstat_update(f32x16 (&acc)[2], float c1, int j0, int N, int h, float& m, float& sum, float& comp) {
+    float tm = NEG_HUGE;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float x = acc[ct][r] * c1;
+            if (MASKED && j0 + 32 * ct + mfma32_row(r, h) >= N) x = NEG_HUGE;
+            acc[ct][r] = x;
+            tm = fmaxf(tm, x);
+        }
+    // The tile's 32 terms are summed on their own and then added to the running sum with Kahan compensation: once the
+    // row maximum (a term equal to 1) is in the accumulator, the other terms (~1e-8 each for a confident match) are
+    // below half an ulp of it and a plain fp32 running sum would drop them one by one (the "swamping" that costs the
+    // fp32 reference ~7e-5 on conf, oracle/coarse.py).  Pairs of scores go through the packed fp32 pipe.
+    const float mn = fmaxf(m, tm);
+    const float resc = __builtin_amdgcn_exp2f(m - mn);
+    f32x2 t2 = {0.f, 0.f};
+    const f32x2 mn2 = {mn, mn};
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const f32x2 d = f32x2{acc[ct][r], acc[ct][r + 1]} - mn2;
+            t2 += f32x2{__builtin_amdgcn_exp2f(d.x), __builtin_amdgcn_exp2f(d.y)};
+        }
+    const float t = t2.x + t2.y;
+    sum *= resc;
+    comp *= resc;
+    const float y = t - comp;
+    const float ns = sum + y;
+    comp = (ns - sum) - y;
+    sum = ns;
+    m = mn;
+}
+
+__global__ __launch_bounds__(256, 2) void k_rowstats(const _Float16* __restrict__ ah, const _Float16* __restrict__ al,
                                                      const _Float16* __restrict__ bh, const _Float16* __restrict__ bl,
                                                      int Z, int N, int Np, float c1, float2* __restrict__ stat) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * CT_PLANE];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_all[2 * 2 * CT_PLANE];      // two stages
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     int z, Ib;
     tile_coords(Np / 128, Z, z, Ib);
     const int irow = Ib * 128 + 32 * wave + l31;
     RowFrags rf;
     rf.load(ah, al, (size_t)z * Np + irow, irow, h);
+    rf.arrived();
     float m = NEG_HUGE, sum = 0.f, comp = 0.f;
     const int ntile = Np / KT;
-    for (int jt = 0; jt < ntile; ++jt) {
-        __syncthreads();
-        dma_col_tile(lds, bh, bl, (size_t)z * Np + jt * KT, tid, wave);
+    auto request = [&](int jt) { dma_col_tile_async(lds_all + (jt & 1) * (2 * CT_PLANE), bh, bl, (size_t)z * Np + jt * KT, tid, wave); };
+    request(0);
+    if (ntile > 1) request(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x16 cur[2];
+    score_tile(cur, lds_all, rf, l31, h);
+    for (int jt = 0; jt + 1 < ntile; ++jt) {
+        // cur = scores of tile jt.  Tile jt + 1 (requested an iteration ago) has landed; after the barrier nobody reads
+        // tile jt's stage any more (its scores were formed before the previous barrier): tile jt + 2 goes there.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        f32x16 acc[2];
-        score_tile(acc, lds, rf, l31, h);
-        const bool ragged = (jt + 1) * KT > N;                       // wave-uniform
-        float tm = NEG_HUGE;
+        if (jt + 2 < ntile) request(jt + 2);
+        const unsigned char* lds = lds_all + ((jt + 1) & 1) * (2 * CT_PLANE);
+        f32x16 nxt[2];
+        if ((jt + 1) * KT <= N) {                                     // wave-uniform: tile jt entirely inside the sequence
+            score_tile(nxt, lds, rf, l31, h);
+            rowstat_update<false>(cur, c1, jt * KT, N, h, m, sum, comp);
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float x = acc[ct][r] * c1;
-                if (ragged && jt * KT + 32 * ct + mfma32_row(r, h) >= N) x = NEG_HUGE;
-                acc[ct][r] = x;
-                tm = fmaxf(tm, x);
+            for (int i = 0; i < 24; ++i) {
+                if (i < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // a fragment read (16 per tile), ahead of its MFMA
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);               // one MFMA of tile jt + 1
+                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);               // softmax VALU of tile jt (~135 per tile, 33 of them exps)
             }
-        // The tile's 32 terms are summed on their own and then added to the running sum with Kahan compensation:
-        // once the row maximum (a term equal to 1) is in the accumulator, the other terms (~1e-8 each for a
-        // confident match) are below half an ulp of it and a plain fp32 running sum would drop them one by one
-        // (the "swamping" that costs the fp32 reference ~7e-5 on conf, oracle/coarse.py).
-        const float mn = fmaxf(m, tm);
-        const float resc = __builtin_amdgcn_exp2f(m - mn);
-        float t = 0.f;
+        } else {
+            score_tile(nxt, lds, rf, l31, h);
+            rowstat_update<true>(cur, c1, jt * KT, N, h, m, sum, comp);
+        }
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) t += __builtin_amdgcn_exp2f(acc[ct][r] - mn);
-        sum *= resc;
-        comp *= resc;
-        const float y = t - comp;
-        const float ns = sum + y;
-        comp = (ns - sum) - y;
-        sum = ns;
-        m = mn;
+        for (int ct = 0; ct < 2; ++ct) cur[ct] = nxt[ct];
     }
+    rowstat_update<true>(cur, c1, (ntile - 1) * KT, N, h, m, sum, comp);
     sum -= comp;
     // the two half-waves hold the two key halves of the same rows
     const float mo = shfl_xor_f(m, 32), so = shfl_xor_f(sum, 32);
@@ -378,8 +453,9 @@ int far_emm_pv_f16s(const float* q, const float* k, const float* v, const float*
     hipLaunchKernelGGL(k_prep_qk, dim3(gprep), dim3(256), 0, stream, k, lay, Z, N, Np, w.kh, w.kl);
     const dim3 grid((unsigned)(Np / 128) * Z);
     // softmax over keys (rows = queries), then over queries (rows = keys): the same kernel with the sides swapped
-    hipLaunchKernelGGL(k_rowstats, grid, dim3(256), 0, stream, w.qh, w.ql, w.kh, w.kl, Z, N, Np, c1, w.rowstat);
-    hipLaunchKernelGGL(k_rowstats, grid, dim3(256), 0, stream, w.kh, w.kl, w.qh, w.ql, Z, N, Np, c1, w.colstat);
+    const dim3 gstat((unsigned)(Np / 128) * Z);
+    hipLaunchKernelGGL(k_rowstats, gstat, dim3(256), 0, stream, w.qh, w.ql, w.kh, w.kl, Z, N, Np, c1, w.rowstat);
+    hipLaunchKernelGGL(k_rowstats, gstat, dim3(256), 0, stream, w.kh, w.kl, w.qh, w.ql, Z, N, Np, c1, w.colstat);
     hipLaunchKernelGGL(k_prep_v, dim3((unsigned)(Np / KT) * Z), dim3(256), 0, stream, v, lay, pos, w.colstat, Z, N, Np, w.vh, w.vl, w.cmax);
     hipLaunchKernelGGL(k_pv, grid, dim3(256), 0, stream, w.qh, w.ql, w.kh, w.kl, w.vh, w.vl, w.rowstat, w.cmax, Z, N,
                        Np, c1, T_out);
