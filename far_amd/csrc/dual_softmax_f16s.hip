@@ -255,9 +255,8 @@ __global__ __launch_bounds__(256, 2) void k1_match(const _Float16* __restrict__ 
                                                    const float2* __restrict__ rowstat, const float* __restrict__ cmax,
                                                    const float* __restrict__ cinv, float* __restrict__ conf,
                                                    float* __restrict__ rowbest_v, int* __restrict__ rowbest_j,
-                                                   float* __restrict__ colbest_part) {
+                                                   unsigned* __restrict__ colbest, float thr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    float* colh = reinterpret_cast<float*>(lds + 2 * TILE_PLANE);          // [4 waves][64]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     const int nI = Lp / 128;
     int z, Ib;
@@ -317,18 +316,23 @@ __global__ __launch_bounds__(256, 2) void k1_match(const _Float16* __restrict__ 
                     }
                 }
             }
-            // column maxima over this wave's 32 rows (the 32 lanes of a half-wave hold the same column per register):
-            // DPP butterflies inside each row of 16 lanes, then lane 15 of the even rows is broadcast to the odd rows
+            // Column maxima, only where they can matter.  The mutual-nearest-neighbour test of k_finalize compares a row's
+            // best confidence with its column's maximum, and only for rows whose best exceeds `thr`; a competitor in that
+            // column beats it only with a confidence > thr as well.  So instead of the maximum of EVERY column over this
+            // wave's 32 rows (32 cross-lane butterflies + an LDS exchange + a barrier per tile: more VALU work than the
+            // tile's 96 MFMAs take) the entries above thr -- at most four per row and column, one per matched row in
+            // practice -- go to colbest[z][j] by atomic max (confidences are positive floats: their bit patterns order
+            // like unsigned integers; the array is zeroed by the caller); order-independent, hence deterministic.
+            float tmax = fmaxf(fmaxf(acc[ct][0], acc[ct][1]), fmaxf(acc[ct][2], acc[ct][3]));
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = max32_to_upper_row(acc[ct][r]);
-                if (l31 == 31) colh[wave * 64 + 32 * ct + mfma32_row(r, h)] = v;
+            for (int r = 4; r < 16; r += 2) tmax = fmaxf(tmax, fmaxf(acc[ct][r], acc[ct][r + 1]));
+            if (__builtin_amdgcn_ballot_w64(tmax > thr) != 0ull) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (acc[ct][r] > thr)
+                        atomicMax(colbest + (size_t)z * S + jt * KT + 32 * ct + mfma32_row(r, h), __float_as_uint(acc[ct][r]));
             }
         }
-        __syncthreads();
-        if (tid < 64 && jt * KT + tid < S)
-            colbest_part[((size_t)z * nI + Ib) * S + jt * KT + tid] =
-                fmaxf(fmaxf(colh[tid], colh[64 + tid]), fmaxf(colh[128 + tid], colh[192 + tid]));
     }
     // merge the two half-waves (same rows, interleaved columns): larger value, ties -> smaller j
     const float vo = shfl_xor_f(bestv, 32);
@@ -444,14 +448,16 @@ int far_coarse_match_f16s(const float* f0, const float* f1, int Z, int L, int S,
                        c1, fill2, mask1, mask0, w.colstat2, w.cmax, w.cinv, (float*)nullptr, (const float*)nullptr,
                        (int*)nullptr, (uint2*)nullptr);
     const int nI = Lp / 128;
+    hipMemsetAsync(w.k.colbest_part, 0, sizeof(float) * (size_t)Z * S, stream);      // the atomic column maxima start at 0
     if (conf_out)
         hipLaunchKernelGGL(k1_match<true>, dim3(nI * Z), dim3(256), smem_m, stream, w.ah, w.al, w.bh, w.bl, Z, L, S, Lp, Sp, c1,
-                           fill2, mask0, mask1, w.k.rowstat, w.cmax, w.cinv, conf_out, w.k.rowbest_v, w.k.rowbest_j, w.k.colbest_part);
+                           fill2, mask0, mask1, w.k.rowstat, w.cmax, w.cinv, conf_out, w.k.rowbest_v, w.k.rowbest_j, reinterpret_cast<unsigned*>(w.k.colbest_part), thr);
     else
         hipLaunchKernelGGL(k1_match<false>, dim3(nI * Z), dim3(256), smem_m, stream, w.ah, w.al, w.bh, w.bl, Z, L, S, Lp, Sp, c1,
-                           fill2, mask0, mask1, w.k.rowstat, w.cmax, w.cinv, conf_out, w.k.rowbest_v, w.k.rowbest_j, w.k.colbest_part);
+                           fill2, mask0, mask1, w.k.rowstat, w.cmax, w.cinv, conf_out, w.k.rowbest_v, w.k.rowbest_j, reinterpret_cast<unsigned*>(w.k.colbest_part), thr);
+    // colbest_part doubles as the single [Z][S] array of atomic column maxima (nI = 1 for k_finalize)
     hipLaunchKernelGGL(k_finalize, dim3((L + 255) / 256, Z), dim3(256), 0, stream, w.k.rowbest_v, w.k.rowbest_j,
-                       w.k.colbest_part, nI, L, S, thr, border, h0, w0, h1, w1, valid_hw, w.k.match_j, counts);
+                       w.k.colbest_part, 1, L, S, thr, border, h0, w0, h1, w1, valid_hw, w.k.match_j, counts);
     hipLaunchKernelGGL(k_compact, dim3(Z), dim3(256), 0, stream, w.k.match_j, w.k.rowbest_v, counts, L, w0, w1,
                        cell_scale, scale0, scale1, b_ids, i_ids, j_ids, mconf, mkpts0_c, mkpts1_c, total_out);
     return far_check_launch();
