@@ -1,19 +1,30 @@
-"""Assembles profiles/r01_bench_fp32_kernel_trace.txt from the files a profiling gpurun call leaves in gpurun_out/:
-  bench_prof.log (bench.py under rocprofv3), r01c_trace.txt (tools/profile_report.py on the rocpd database),
-  bench_plain.log (the un-profiled python bench.py)."""
+"""Assembles profiles/<tag>_bench_fp32_kernel_trace.txt from the files tools/collect_profiles.sh leaves in gpurun_out/:
+  bench_prof.log (bench.py under rocprofv3), <tag>_trace.txt (tools/profile_report.py on the rocpd database),
+  bench_plain.log / bench_c4.log (the un-profiled python bench.py lines), and copies <tag>_pmc_traffic.json.
+Usage: python tools/make_profile_txt.py r02 <commit>"""
 import os
+import shutil
+import sys
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
+commit = sys.argv[2] if len(sys.argv) > 2 else 'unknown'
+G = ROOT + '/gpurun_out/'
 last_json = lambda path: [l for l in open(path).read().splitlines() if l.startswith('{')][-1]
-plain=last_json(ROOT + '/gpurun_out/bench_plain.log')
-prof=last_json(ROOT + '/gpurun_out/bench_prof.log')
-tr=open(ROOT + '/gpurun_out/r01c_trace.txt').read()
-whole,win=tr.split('\n\n',1)
-out=f"""# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 3 --no-cpu-baseline    (round 1, 1x MI355X, default fp32-grade path)
+plain, prof, c4 = last_json(G + 'bench_plain.log'), last_json(G + 'bench_prof.log'), last_json(G + 'bench_c4.log')
+tr = open(G + f'{tag}_trace.txt').read()
+whole, win = tr.split('\n\n', 1)
+rnd = tag[1:].lstrip('0')
+out = f"""# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 3 --no-cpu-baseline    (round {rnd}, 1x MI355X, default fp32-grade path, commit {commit})
+# collected by tools/collect_profiles.sh; summarised by tools/profile_report.py (rocpd database -> per-kernel tables)
 # bench line of the same profiled run:
 {prof}
 
-# un-profiled bench line (python bench.py, i.e. 5 steps after 3 warm-up steps) on the same box:
+# un-profiled bench line (python bench.py: 5 steps after 3 warm-up steps) on the same box:
 {plain}
+
+# un-profiled line of the second workload (python bench.py --workload c4: BASELINE configs[3], cached-LoFTR path, batch 256):
+{c4}
 
 ## one steady-state step (32 pairs): per kernel
 {win.strip()}
@@ -21,4 +32,7 @@ out=f"""# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmu
 ## whole process (includes the warm-up steps and the isolated kernel timings of bench.kernel_rooflines)
 {whole.strip()}
 """
-open(ROOT + '/profiles/r01_bench_fp32_kernel_trace.txt','w').write(out)
+open(ROOT + f'/profiles/{tag}_bench_fp32_kernel_trace.txt', 'w').write(out)
+if os.path.exists(G + f'{tag}_pmc_traffic.json'):
+    shutil.copy(G + f'{tag}_pmc_traffic.json', ROOT + f'/profiles/{tag}_pmc_traffic.json')
+print('wrote', f'profiles/{tag}_bench_fp32_kernel_trace.txt')
