@@ -47,6 +47,7 @@ def parse():
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'fp16-fine', 'fp16', 'bf16'],
                     help='backbone convolution arithmetic (far_amd.loftr.LoFTR.set_precision): fp32 = split-fp16 operand pairs (fp32-grade)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-other-modes', action='store_true', help='skip the informational fp16-operand leg of the default run')
     ap.add_argument('--cpu-pairs', type=int, default=3)
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help="torch.distributed backend of the N > 1 run ('nccl' is RCCL on ROCm; 'gloo' only for the CPU self-test)")
@@ -621,6 +622,23 @@ def main():
             'roofline': roof,
             'kernels': {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in kr.items()},
         }
+        if world == 1 and a.precision == 'fp32' and not a.no_other_modes:
+            # informational: the same step with plain fp16 matrix operands in every K9 launch (the precision class BASELINE
+            # configs[1] names, 'bf16'); NOT the parity configuration and never `value` (match-set IoU > 0.95 vs parity,
+            # tests/test_pipeline_gpu.py::test_precision_modes_deviation)
+            model.set_precision('fp16')
+            for _ in range(2):
+                step()
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                step()
+            fence()
+            dt16 = (time.perf_counter() - t1) / 3
+            model.set_precision('fp32')
+            res['other_modes'] = {'fp16_operands': {'value': round(a.pairs / dt16, 3), 'ms_per_step': round(1000 * dt16, 3),
+                                                    'note': 'plain fp16 operands in the backbone / encoder matrix products, fp32 tensors and '
+                                                            'accumulation; informational, not the parity line'}}
         if world == 1 and not a.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(a.cpu_pairs, a.hyp)
         print(json.dumps(res), flush=True)

@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-r02}
 mkdir -p $R/gpurun_out
 cd /tmp; export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_bench -o bench -- python3 $R/bench.py --steps 3 --warmup 3 --no-cpu-baseline > $R/gpurun_out/bench_prof.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_bench -o bench -- python3 $R/bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-other-modes > $R/gpurun_out/bench_prof.log 2>&1
 timeout 200 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/pmc_fetch -o f -- python3 $R/tools/kprobe.py pmc 32 2 > $R/gpurun_out/pmc_fetch.log 2>&1
 timeout 200 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/pmc_write -o w -- python3 $R/tools/kprobe.py pmc 32 2 > $R/gpurun_out/pmc_write.log 2>&1
 cd $R

@@ -15,7 +15,7 @@ plain, prof, c4 = last_json(G + 'bench_plain.log'), last_json(G + 'bench_prof.lo
 tr = open(G + f'{tag}_trace.txt').read()
 whole, win = tr.split('\n\n', 1)
 rnd = tag[1:].lstrip('0')
-out = f"""# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 3 --no-cpu-baseline    (round {rnd}, 1x MI355X, default fp32-grade path, commit {commit})
+out = f"""# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-other-modes    (round {rnd}, 1x MI355X, default fp32-grade path, commit {commit})
 # collected by tools/collect_profiles.sh; summarised by tools/profile_report.py (rocpd database -> per-kernel tables)
 # bench line of the same profiled run:
 {prof}
