@@ -63,6 +63,38 @@ if which in ('pmc',):
     a0, a1 = f0[:4].clone().requires_grad_(True), f1[:4].clone().requires_grad_(True)
     for _ in range(it):
         ops.coarse_pos_conf(a0, a1, pb, pi, pj, 0.1).sum().backward()
+if which in ('util',):
+    # matrix-pipe utilisation / clock / LDS passes: the split-precision kernels of the step at bench shapes + two
+    # HBM-bound kernels as the clock reference
+    for (cin, cout, hh, ww) in ((196, 196, 240, 320), (128, 128, 240, 320), (256, 256, 120, 160)):
+        x = torch.randn(2 * n, hh, ww, cin, device=dev, generator=g).relu_()
+        w = torch.randn(cout, cin, 3, 3, device=dev, generator=g) * 0.03
+        pc = ops.PackedConv(w, torch.ones(cout, device=dev), torch.zeros(cout, device=dev))
+        for _ in range(it):
+            ops.conv_nhwc(x, pc, act='relu')
+        del x
+    r = torch.randn(1, 1, n * L, 512, device=dev, generator=g)
+    pl = ops.PackedConv(torch.randn(512, 512, device=dev, generator=g) * 0.05)
+    for _ in range(it):
+        ops.conv_nhwc(r, pl)
+    del r
+    f0 = 1.2 * torch.randn(n, L, 256, device=dev, generator=g)
+    f1 = f0[:, torch.randperm(L, device=dev, generator=g)] + 0.1 * torch.randn(n, L, 256, device=dev, generator=g)
+    for _ in range(it):
+        ops.coarse_match(f0, f1, 0.1, 0.2, 2, (60, 80), (60, 80), 8.0, variant='f16s')
+    Z = n * 8
+    q = torch.randn(Z, L, 64, device=dev, generator=g); k = torch.randn(Z, L, 64, device=dev, generator=g)
+    v = torch.randn(Z, L, 64, device=dev, generator=g); pos = torch.rand(L, 6, device=dev, generator=g)
+    for _ in range(it):
+        ops.emm_bilinear(q, k, v, pos, 0.125)
+    del q, k, v
+    q = torch.randn(2 * n, L, 256, device=dev, generator=g); k = torch.randn(2 * n, L, 256, device=dev, generator=g)
+    v = torch.randn(2 * n, L, 256, device=dev, generator=g)
+    for _ in range(it):
+        ops.linear_attention(q, k, v, 8)
+    big = torch.empty(n, L, L, device=dev)
+    for _ in range(it):
+        big.fill_(1.0)
 if which in ('k1b',):
     f0 = 1.2 * torch.randn(n, L, 256, device=dev, generator=g)
     f1 = f0[:, torch.randperm(L, device=dev, generator=g)] + 0.1 * torch.randn(n, L, 256, device=dev, generator=g)
