@@ -600,8 +600,9 @@ def main():
                 'note': 'algorithmic convolution flops per launch / event-timed launch duration against the dense f16 '
                         'MFMA peak; the kernel executes 3 f16 MFMAs per fp32-grade product (split operands), so the '
                         'matrix pipe is busy mfma_issue_frac of the time AT THE NOMINAL 2.4 GHz; the shader clock '
-                        'measured inside this kernel is 1.5-1.8 GHz (power limit under dense MFMA, '
-                        'profiles/r01_k9_workgroup_timeline.txt), i.e. ~75 % of the pipe cycles of a workgroup lifetime'}
+                        'measured inside this kernel is 1.5-1.8 GHz (power limit under dense MFMA: s_memtime stamps in '
+                        'profiles/r01_k9_workgroup_timeline.txt, GRBM_GUI_ACTIVE in profiles/r02_pmc_util.txt: 1.59 GHz, '
+                        'SQ_VALU_MFMA_BUSY_CYCLES = 72 % of those cycles)'}
         res = {
             'metric': 'image-pairs/sec (match+solve+regress) at 640x480',
             'value': round(world * a.pairs * a.steps / dt, 3), 'unit': 'image-pairs/sec',
