@@ -364,6 +364,8 @@ def bench_c3(a, dev, world, rank, dist):
     fwd = model
     if dist is not None:
         from torch.nn.parallel import DistributedDataParallel as DDP
+        if a.backend == 'nccl':            # the reference trains with sync_batchnorm (train.py:342, :350-352); RCCL only
+            model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
         fwd = DDP(model, device_ids=[dev.index] if a.backend == 'nccl' else None)
     opt = torch.optim.AdamW(model.parameters(), lr=1e-5, weight_decay=0.1)      # src/optimizers/__init__.py:5-16, default.py TRAINER.*
     # synthetic supervision: banded lateral disparities -> ground-truth coarse matches + warped grid (far_amd/synth.py)
