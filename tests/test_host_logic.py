@@ -65,3 +65,64 @@ def test_cached_prediction_format_roundtrip(tmp_path):
     back = cache_io.load_batch(str(tmp_path), 'test', [11, 7])
     assert torch.equal(back['loftr_rt'], data['loftr_rt'][[2, 0]]) and back['num_correspondences'].tolist() == [0, 5]
     assert torch.equal(back['featmap0'], data['featmap0'][[2, 0]]) and back['inliers_best_tight'].tolist() == [0, 0]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# property tests (hypothesis) of the host-side logic that no golden vector exercises exhaustively
+# ---------------------------------------------------------------------------------------------------------------------
+from hypothesis import given, settings, strategies as st   # noqa: E402
+
+
+@settings(max_examples=200, deadline=None)
+@given(n=st.integers(0, 500), world=st.integers(1, 16))
+def test_shard_indices_partition_the_pairs(n, world):
+    """Every pair goes to exactly one rank, in rank::world order (DistributedSampler(shuffle=False), data.py:115-117)."""
+    from far_amd.parallel import shard_indices
+    shards = [list(shard_indices(n, r, world)) for r in range(world)]
+    assert sorted(i for s in shards for i in s) == list(range(n))
+    for r, s in enumerate(shards):
+        assert s == list(range(r, n, world))
+        assert abs(len(s) - n / world) < 1                           # balanced to within one pair
+
+
+@settings(max_examples=60, deadline=None)
+@given(seed=st.integers(0, 10_000), m=st.integers(1, 60), shift=st.floats(0.0, 3.0))
+def test_fine_loss_is_a_function_of_the_match_set(seed, m, shift):
+    """loftr_loss.py:151-183: permuting the matches leaves the loss unchanged; it is never negative; the std column only
+    re-weights (weights sum to the number of matches); eval mode without a correct match returns None."""
+    from far_amd.losses import fine_loss_l2_std
+    g = torch.Generator().manual_seed(seed)
+    ef = torch.cat([torch.randn(m, 2, generator=g), torch.rand(m, 1, generator=g) + 0.05], 1)
+    gt = torch.randn(m, 2, generator=g) * 0.6 + shift
+    perm = torch.randperm(m, generator=g)
+    a = fine_loss_l2_std(ef, gt, 1.0, True)
+    b = fine_loss_l2_std(ef[perm], gt[perm], 1.0, True)
+    assert float(a) >= 0 and abs(float(a) - float(b)) <= 1e-5 * max(1.0, float(a))
+    if not bool((gt.abs().amax(1) < 1.0).any()):
+        assert fine_loss_l2_std(ef, gt, 1.0, False) is None and float(a) == 0.0     # the dummy entry carries weight 0
+
+
+@settings(max_examples=40, deadline=None)
+@given(seed=st.integers(0, 10_000), b=st.integers(1, 5), scramble=st.booleans())
+def test_spvs_rt_segments_are_order_independent_on_the_host(seed, b, scramble):
+    """The host-side half of spvs_RT's batching (the solver itself is a GPU kernel): counts from m_bids and the stable
+    sort that makes per-pair segments contiguous reproduce the reference's `mask = m_bids == bs` selection
+    (supervision.py:209-210) for any order of the matches."""
+    g = torch.Generator().manual_seed(seed)
+    counts = torch.randint(0, 9, (b,), generator=g)
+    bids = torch.repeat_interleave(torch.arange(b), counts)
+    pts = torch.arange(len(bids), dtype=torch.float32)[:, None].repeat(1, 2)
+    if scramble and len(bids):
+        p = torch.randperm(len(bids), generator=g)
+        bids, pts = bids[p], pts[p]
+    got_counts = torch.bincount(bids, minlength=b)
+    assert torch.equal(got_counts, counts)
+    order = torch.sort(bids, stable=True)[1]
+    seg = pts[order]
+    offs = torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(got_counts, 0)])
+    for bs in range(b):
+        ref = pts[bids == bs]                                      # the reference's selection, in the caller's order
+        assert torch.equal(seg[offs[bs]:offs[bs + 1]], ref)
+    back = torch.empty_like(order)
+    back[order] = torch.arange(len(order))
+    assert torch.equal(seg[back], pts)                             # and the mask scatter-back is the inverse permutation
