@@ -49,6 +49,7 @@ class LinearAttention(nn.Module):
 class LoFTREncoderLayer(nn.Module):
     split_operands = True        # K9 operand precision of the Linear layers (False: plain fp16, LoFTR.set_precision)
     hip_training = True          # training on the GPU runs K9 / K5 (forward + backward kernels); False: vendor ops + autograd
+    fused_mlp = True             # d_model 128, split operands: the MLP block as one K13 launch (False: two K9 launches)
 
     def __init__(self, d_model, nhead, attention='linear', use_num_corres=False):
         super().__init__()
@@ -116,6 +117,12 @@ class LoFTREncoderLayer(nn.Module):
         # merge + norm1 (:60-61) in one launch: the LayerNorm runs in the Linear layer's epilogue
         msg = ops.linear_f16s(msg.view(bs, -1, self.nhead * self.dim), lin('merge', self.merge),
                               ln=(self.norm1.weight, self.norm1.bias, self.norm1.eps))
+        if self.fused_mlp and sp and x.shape[-1] == 128:
+            # d_model 128 (the fine-level windows: bandwidth-bound): mlp[0] + ReLU + mlp[2] + norm2 + residual (:64-67) in
+            # ONE launch (K13), the 256-channel hidden tensor stays in the accumulator registers
+            pm = pk.get(('mlp-fused',), [self.mlp[0].weight, self.mlp[2].weight],
+                        lambda: ops.PackedMlp(self.mlp[0].weight, self.mlp[2].weight))
+            return ops.mlp_fused(x, msg.contiguous(), pm, self.norm2.weight, self.norm2.bias, self.norm2.eps, out=out)
         # mlp[0](cat[x, msg]) reads both inputs in place (:64), ReLU in the epilogue
         h = ops.linear_f16s(x, lin('mlp0', self.mlp[0]), act='relu', x2=msg)
         # mlp[2] + norm2 + the residual `x + message` (:65-67) in one launch

@@ -601,6 +601,64 @@ class PackedConv:
         self.shift = None if shift is None else shift.detach().float().contiguous()
 
 
+class PackedMlp:
+    """Weight image of far_mlp_fused_f16s (K13): mlp[0] (2d x 2d) and mlp[2] (d x 2d) of a LoFTR encoder layer at d = 128 as
+    24 slabs of 16 KiB in execution order, fp16 (hi, lo) planes, each tensor scaled by a power of two taken from its maximum
+    (as PackedConv).  Slab s < 16 (k-step s of GEMM 1): [hidden tile t][plane][lane][8]: lane = (hidden channel 32 t + (lane & 31),
+    half h = lane >> 5), element e = input channel 32 (s >> 1) + 16 h + 8 (s & 1) + e.  Slab 16 + t (hidden tile t of GEMM 2):
+    [k-step u][output tile ct][plane][lane][8]: lane = (output channel 32 ct + (lane & 31), h), element e = hidden channel
+    32 t + 16 u + 4 h + (e & 3) + 8 (e >> 2) -- the order in which GEMM 1's accumulator registers hold a row's hidden values."""
+
+    def __init__(self, w0, w2):
+        lib = _lib.load()
+        w0, w2 = w0.detach().float(), w2.detach().float()
+        d = w2.shape[0]
+        if tuple(w0.shape) != (2 * d, 2 * d) or tuple(w2.shape) != (d, 2 * d) or lib.far_mlp_fused_packed_bytes(d) == 0:
+            raise _lib.FarHipError(f'far_mlp_fused_f16s is built for d_model = 128 (got weights {tuple(w0.shape)}, {tuple(w2.shape)})')
+        dev = w0.device
+
+        def exp_of(w):
+            amax = float(w.abs().max())                   # host sync at pack time only
+            return 14 - (torch.frexp(torch.tensor(amax)).exponent.item() if amax > 0 else 0)
+
+        def planes(v):                                    # (...,) fp32 (already scaled) -> (2, ...) fp16 hi / lo
+            hi = v.half()
+            return torch.stack([hi, (v - hi.float()).half()])
+
+        self.e0, self.e2 = exp_of(w0), exp_of(w2)
+        ar = lambda n: torch.arange(n, device=dev)
+        s_, t_, l_, e_ = ar(16).view(16, 1, 1, 1), ar(8).view(1, 8, 1, 1), ar(64).view(1, 1, 64, 1), ar(8).view(1, 1, 1, 8)
+        hc = 32 * t_ + (l_ & 31)
+        k = 32 * (s_ >> 1) + 16 * (l_ >> 5) + 8 * (s_ & 1) + e_
+        g1 = planes(w0[hc.expand(16, 8, 64, 8), k.expand(16, 8, 64, 8)] * 2.0 ** self.e0)         # (2, s, t, l, e)
+        g1 = g1.permute(1, 2, 0, 3, 4).contiguous()                                               # (s, t, plane, l, e)
+        t2, u2, c2, l2, e2 = (ar(8).view(8, 1, 1, 1, 1), ar(2).view(1, 2, 1, 1, 1), ar(4).view(1, 1, 4, 1, 1),
+                              ar(64).view(1, 1, 1, 64, 1), ar(8).view(1, 1, 1, 1, 8))
+        co = 32 * c2 + (l2 & 31)
+        hk = 32 * t2 + 16 * u2 + 4 * (l2 >> 5) + (e2 & 3) + 8 * (e2 >> 2)
+        shp = (8, 2, 4, 64, 8)
+        g2 = planes(w2[co.expand(shp), hk.expand(shp)] * 2.0 ** self.e2)                          # (2, t, u, ct, l, e)
+        g2 = g2.permute(1, 2, 3, 0, 4, 5).contiguous()                                            # (t, u, ct, plane, l, e)
+        self.packed = torch.cat([g1.reshape(-1), g2.reshape(-1)]).view(torch.uint8)
+        assert self.packed.numel() == lib.far_mlp_fused_packed_bytes(d)
+        self.d = d
+        self.hscale = 2.0 ** -self.e0                     # accumulator of GEMM 1 -> 2^4 x hidden
+        self.oscale = 2.0 ** -(self.e2 + _CONV_ACT_EXP)   # accumulator of GEMM 2 -> output
+
+
+def mlp_fused(x, msg, pack, gamma, beta, eps, out=None):
+    """K13: x + LayerNorm(W2 relu(W0 [x | msg])) for (.., 128) fp32 tensors (transformer.py:64-67 at d_model = 128)."""
+    lib = _lib.load()
+    if x.shape != msg.shape or x.shape[-1] != pack.d:
+        raise _lib.FarHipError('mlp_fused: x and msg must both be (..., 128)')
+    R = x.numel() // pack.d
+    y = torch.empty_like(x) if out is None else out
+    rc = lib.far_mlp_fused_f16s(_p(x, torch.float32), _p(msg, torch.float32), _p(pack.packed), R, pack.d, pack.hscale, pack.oscale,
+                                _p(gamma, torch.float32), _p(beta, torch.float32), float(eps), _p(y, torch.float32), _stream())
+    _lib.check(rc, 'far_mlp_fused_f16s')
+    return y if out is None else _written(y)
+
+
 class PackCache:
     """K9 weight images keyed by name, rebuilt when any tensor they were derived from changes (in-place update,
     load_state_dict, optimizer step: data_ptr / _version stamp)."""

@@ -212,6 +212,18 @@ int far_layernorm_f32(const float* x, const float* gamma, const float* beta, con
                       float eps, float* y, far_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * K13  the MLP block of a LoFTR encoder layer at d_model = 128 (the fine-level transformer) in one launch
+ * replaces src/loftr/loftr_module/transformer.py:64-67:  x + norm2(mlp(cat[x, message]))  with
+ *          mlp = Linear(2d, 2d, no bias) -> ReLU -> Linear(2d, d, no bias); the hidden tensor never reaches memory.
+ *   x, msg [R][128] fp32; packed = the image far_amd/ops.py:PackedMlp builds (far_mlp_fused_packed_bytes bytes: W0 scaled by
+ *   2^e0, W2 by 2^e2, fp16 hi / lo planes in execution order); hscale = 2^-e0, oscale = 2^-(e2 + 4); gamma, beta [128], eps:
+ *   norm2.  out [R][128] must not alias x or msg.  Arithmetic as K9 (three f16 MFMAs per fp32-grade product).
+ * --------------------------------------------------------------------------------------------------- */
+size_t far_mlp_fused_packed_bytes(int d_model);
+int far_mlp_fused_f16s(const float* x, const float* msg, const void* packed, long R, int d_model, float hscale, float oscale,
+                       const float* gamma, const float* beta, float eps, float* out, far_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * K7 / K8  backbone epilogues (inference): folded BatchNorm + residual + activation; FPN upsample + add
  * replaces the elementwise passes of src/loftr/backbone/resnet_fpn.py:32-40, :80-91, :103, :110-116
  * ------------------------------------------------------------------------------------------------- */
