@@ -1,0 +1,347 @@
+// K14: the attention block of a LoFTR encoder layer at d_model = 128 on short sequences (the 25-token fine windows) as
+// ONE kernel: q / k / v projections, linear attention, merge, norm1.
+//
+// Replaces mp3d_loftr/src/loftr/loftr_module/transformer.py:51-61 (LoFTREncoderLayer.forward, first half)
+//     query, key, value = q_proj(x), k_proj(source), v_proj(source)            [N, L|S, 8 heads, 16]
+//     message = self.attention(query, key, value)                              linear_attention.py:31-50
+//     message = self.norm1(self.merge(message.view(bs, -1, 128)))
+// with  Q = elu(q) + 1, K = elu(k) + 1, KV = sum_s K_s (x) (v_s / S), Z = 1 / (Q . sum_s K_s + eps),  out = (Q KV) Z S.
+// As separate launches (three K9 Linear layers, K5, K9 merge + LayerNorm) this is 11 passes over 781 MB tensors per
+// layer-side at the fine level (61 k windows x 25 tokens per 32 pairs) and bandwidth-bound; here x and source are read
+// once and the normalised message written once.
+//
+// One wave = one window, padded to a 32-row MFMA tile (rows >= L / S are masked), so the attention never leaves the
+// wave; workgroup = 4 waves sharing the weight slabs (16 KiB each, 3-slot LDS ring, asm LDS-DMA two ahead; the wave's
+// input rows arrive by LDS-DMA as well, so every memory request of the loop is waited for by hand).  The GEMMs alternate
+// between the two accumulator orientations so that each result is already the operand of its consumer:
+//   k, v   D[m = token][n = channel]  (lane = channel): K'^T V per 32-channel tile (two heads; the cross-head quarters of
+//          the 32 x 32 block are zeroed) contracts over tokens = over the REGISTERS of a lane -> both are MFMA operands
+//          as they stand;  sum_s K'_s is an in-lane sum
+//   q^T    D[m = channel][n = token]  (lane = token): B operand of  message^T = KV^T Q'^T  (A = the KV block, lane = e)
+//   message^T (lane = token, registers = channels)  = the A operand of the merge GEMM (weights packed in that k order)
+//   merge  D[m = token][n = channel]: LayerNorm over the channels = DPP sums over the 32 lanes of a half-wave, store.
+// Arithmetic as K9 / K13: every product three f16 MFMAs on (hi, lo) pairs, fp32 accumulation.
+#include "common.h"
+#include <type_traits>
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int DM = 128;                  // d_model
+constexpr int CT = DM / 32;              // 32-channel tiles (two 16-channel heads each)
+constexpr int SLAB = 16384;              // two k-steps x 4 tiles x 2 planes x 1 KiB
+constexpr int NSLAB = 16;                // [k c0][v c0][k c1][v c1][k c2][v c2][k c3][v c3][q c0..c3][merge t0..t3]
+constexpr int RING = 3;
+constexpr int WAVES = 4;
+constexpr int PIECES = 16 / WAVES;
+constexpr float ACT_SCALE = 16.0f;
+
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst_uniform) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
+}
+// Every phase waits for ALL of this wave's outstanding requests (vmcnt(0)) before the barrier.  The requests are issued two
+// slabs / one chunk ahead, so the youngest is a phase old and the wait costs ~2 %.  Counting them instead (vmcnt(4) / (8):
+// "slab p and this phase's chunk have landed once only the younger requests remain") worked in K13 but gave stale LDS
+// reads here -- whole windows wrong in ~3 % of the windows of every launch beyond the first round of workgroups -- whenever
+// six or more requests were allowed to stay in flight across a barrier of the k / v phases; the run-to-run determinism test
+// of tests/test_attn_block_gpu.py is what found it.
+__device__ __forceinline__ float elu1(float x) { return (x > 0.f ? x : expm1f(x)) + 1.f; }   // F.elu(x) + 1
+
+__device__ __forceinline__ void split_regs(const float (&v)[8], f16x8& hi, f16x8& lo) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const _Float16 hh = (_Float16)v[i];
+        hi[i] = hh;
+        lo[i] = (_Float16)(v[i] - (float)hh);
+    }
+}
+__device__ __forceinline__ void split8(const float4& u, const float4& v, float scale, f16x8& hi, f16x8& lo) {
+    const float x[8] = {u.x * scale, u.y * scale, u.z * scale, u.w * scale, v.x * scale, v.y * scale, v.z * scale, v.w * scale};
+    split_regs(x, hi, lo);
+}
+__device__ __forceinline__ f32x16 mma3(const f16x8& ah, const f16x8& al, const f16x8& bh, const f16x8& bl, f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);
+}
+
+#define FAR_DPP_F(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true))
+__device__ __forceinline__ float sum32(float v) {
+    v += FAR_DPP_F(v, 0xB1);
+    v += FAR_DPP_F(v, 0x4E);
+    v += FAR_DPP_F(v, 0x141);
+    v += FAR_DPP_F(v, 0x140);
+    return v + shfl_xor_f(v, 16);
+}
+
+struct Scales { float k, v, q, m; };     // accumulator -> value: 2^-(w_exp + 4) per weight tensor
+
+__global__ __launch_bounds__(256, 2) void k_attn128(const float* __restrict__ x, const float* __restrict__ src,
+                                                    const unsigned char* __restrict__ wimg, long nwin, int L, int S, Scales sc,
+                                                    float attn_eps, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    float ln_eps, float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) unsigned char ring[RING * SLAB];
+    __shared__ __attribute__((aligned(16))) unsigned char xs[WAVES * 4096];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    long win = (long)blockIdx.x * WAVES + wave;
+    const bool live = win < nwin;
+    if (!live) win = nwin - 1;                                 // a spare wave of the last workgroup: works on a valid window, stores nothing
+    const unsigned ring_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(lptr_t)ring);
+    const unsigned xs_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(lptr_t)(xs + wave * 4096));
+    const unsigned char* wsrc = wimg + (size_t)lane * 16;
+    auto request_w = [&](int s) {
+        const unsigned dst = ring_base + (unsigned)((s % RING) * SLAB);
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i)
+            glds16(wsrc + (size_t)s * SLAB + (wave + WAVES * i) * 1024, dst + (wave + WAVES * i) * 1024);
+    };
+    // chunk j: 32 channels of this window's rows -> the wave's 4 KiB, row-major [32 rows][8 pieces of 16 B], source-side
+    // swizzle (piece q of row r holds source piece q ^ ((r ^ (r >> 3)) & 7)).  j < 4: source channels 32 j; j >= 4: x.
+    const int rr = lane >> 3, q8 = lane & 7;
+    const long lastrow_s = nwin * S - 1, lastrow_x = nwin * L - 1;
+    auto request_x = [&](int j) {
+        const bool is_src = j < 4;
+        const float* base = (is_src ? src : x) + 32 * (j & 3);
+        const long r0 = win * (is_src ? S : L), last = is_src ? lastrow_s : lastrow_x;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 8 * i + rr;
+            long gr = r0 + r;
+            gr = gr < last ? gr : last;                        // rows past the window are masked below; keep the address valid
+            glds16(base + gr * DM + 4 * (q8 ^ ((r ^ (r >> 3)) & 7)), xs_base + i * 1024);
+        }
+    };
+    request_x(0);
+    request_w(0);
+    request_w(1);
+    const unsigned char* xrd = xs + wave * 4096 + (l31 >> 3) * 1024 + (l31 & 7) * 128;
+    const int sw = (l31 ^ (l31 >> 3)) & 7;
+    f16x8 xh[2], xl[2];                                       // the current chunk of this lane's row: two k-steps of (hi, lo)
+    auto read_chunk = [&](int next) {                          // read out the landed chunk, then request chunk `next` (< 8) into the same 4 KiB
+        float4 raw[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) raw[i] = *reinterpret_cast<const float4*>(xrd + (((4 * h + i) ^ sw) * 16));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (next < 8) request_x(next);
+        split8(raw[0], raw[1], ACT_SCALE, xh[0], xl[0]);
+        split8(raw[2], raw[3], ACT_SCALE, xh[1], xl[1]);
+    };
+    // one slab of a projection GEMM: two k-steps x four 32-channel tiles.  TRANSPOSED: D[m = channel][n = token] (weights are
+    // the A operand), else D[m = token][n = channel]
+    auto gemm_slab = [&](int s, f32x16 (&acc)[CT], auto transposed) {
+        constexpr bool TR = decltype(transposed)::value;
+        const unsigned char* slab = ring + (s % RING) * SLAB + lane * 16;
+        f16x8 wh[3], wl[3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            wh[i] = *reinterpret_cast<const f16x8*>(slab + i * 2048);
+            wl[i] = *reinterpret_cast<const f16x8*>(slab + i * 2048 + 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * CT; ++i) {                     // i = k-step * CT + tile
+            if (i + 2 < 2 * CT) {
+                wh[(i + 2) % 3] = *reinterpret_cast<const f16x8*>(slab + (i + 2) * 2048);
+                wl[(i + 2) % 3] = *reinterpret_cast<const f16x8*>(slab + (i + 2) * 2048 + 1024);
+            }
+            const int ks = i / CT, t = i % CT;
+            if (TR) acc[t] = mma3(wh[i % 3], wl[i % 3], xh[ks], xl[ks], acc[t]);
+            else acc[t] = mma3(xh[ks], xl[ks], wh[i % 3], wl[i % 3], acc[t]);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        }
+    };
+    auto begin_phase = [&](int) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");                               // slab p complete and visible; slot (p + 2) % 3 free
+    };
+    auto zero = [&](f32x16 (&a)[CT]) {
+#pragma unroll
+        for (int t = 0; t < CT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a[t][r] = 0.f;
+    };
+
+    // ------------------------------------------------------------------ k, v = source W^T   (phases 0..7)
+    f32x16 ka[CT], va[CT];
+    zero(ka);
+    zero(va);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        begin_phase(2 * c);
+        read_chunk(c + 1);                                     // source chunk c; next: source chunk c + 1 (c = 3: x chunk 0)
+        request_w(2 * c + 2);
+        gemm_slab(2 * c, ka, std::false_type{});
+        begin_phase(2 * c + 1);
+        request_w(2 * c + 3);
+        gemm_slab(2 * c + 1, va, std::false_type{});
+    }
+    // K' = elu(k) + 1, V = v / S on the rows of the window (registers: token mfma32_row(r, h); lane: channel 32 t + l31)
+    float ksum[CT];
+    const float fS = (float)S;
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+        float s_ = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool ok = mfma32_row(r, h) < S;
+            const float kk = ok ? elu1(ka[t][r] * sc.k) : 0.f;
+            ka[t][r] = kk * ACT_SCALE;
+            va[t][r] = ok ? (va[t][r] * sc.v) / fS * ACT_SCALE : 0.f;      // values / v_length (linear_attention.py:43)
+            s_ += kk;
+        }
+        ksum[t] = s_ + shfl_xor_f(s_, 32);                      // lane l31 (either half): sum_s K'_s [channel 32 t + l31]
+    }
+    // KV[d][e] = sum_s K'[s][d] V[s][e] per 32-channel tile: D[m = d][n = e], contraction over the registers (tokens)
+    f32x16 kv[CT];
+    zero(kv);
+#pragma unroll
+    for (int t = 0; t < CT; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float a8[8], b8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { a8[e] = ka[t][8 * u + e]; b8[e] = va[t][8 * u + e]; }
+            f16x8 ah, al, bh, bl;
+            split_regs(a8, ah, al);
+            split_regs(b8, bh, bl);
+            kv[t] = mma3(ah, al, bh, bl, kv[t]);
+        }
+    // kv[t][r]: d = mfma32_row(r, h), e = l31; drop the cross-head quarters (head = channel / 16) and the two 2^4 scales
+#pragma unroll
+    for (int t = 0; t < CT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            kv[t][r] = ((r >= 8) == (l31 >= 16)) ? kv[t][r] * (1.0f / ACT_SCALE) : 0.f;      // left scaled by 2^4 for its split
+
+    // ------------------------------------------------------------------ q^T = Wq x^T   (phases 8..11)
+    f32x16 qa[CT];
+    zero(qa);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        begin_phase(8 + c);
+        read_chunk(c + 5);                                     // x chunk c; next: x chunk c + 1 (none after the last)
+        request_w(10 + c);
+        gemm_slab(8 + c, qa, std::true_type{});
+    }
+    // Q' = elu(q) + 1 (lane = token l31; registers: channel 32 t + mfma32_row(r, h));  den = Q' . ksum per head
+    f32x16 ma[CT];                                             // message^T: D[m = e][n = token]
+    zero(ma);
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+        float den0 = 0.f, den1 = 0.f;                          // heads 2 t and 2 t + 1
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float qq = elu1(qa[t][r] * sc.q);
+            const float ks = __shfl(ksum[t], mfma32_row(r, h), 64);          // ksum of this register's channel
+            if (r < 8) den0 += qq * ks; else den1 += qq * ks;
+            qa[t][r] = qq * ACT_SCALE;
+        }
+        den0 += shfl_xor_f(den0, 32);
+        den1 += shfl_xor_f(den1, 32);
+        // message^T[e][token] = sum_d KV[d][e] Q'[token][d]:  A = KV block (lane = e, registers = d), B = Q'^T (lane = token)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float a8[8], b8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { a8[e] = kv[t][8 * u + e]; b8[e] = qa[t][8 * u + e]; }
+            f16x8 ah, al, bh, bl;
+            split_regs(a8, ah, al);
+            split_regs(b8, bh, bl);
+            ma[t] = mma3(ah, al, bh, bl, ma[t]);
+        }
+        // out = (Q KV) Z S, Z = 1 / (Q . ksum + eps)  (:46, :50); registers r < 8 belong to head 2 t, the others to 2 t + 1
+        const float z0 = fS / (den0 + attn_eps), z1 = fS / (den1 + attn_eps);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ma[t][r] = ma[t][r] * (r < 8 ? z0 : z1) * (1.0f / ACT_SCALE);   // 2^-8 of the operands, x 2^4 for the split
+    }
+
+    // ------------------------------------------------------------------ merge: D[m = token][n = channel]   (phases 12..15)
+    f32x16 mg[CT];
+    zero(mg);
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+        begin_phase(12 + t);
+        if (14 + t < NSLAB) request_w(14 + t);
+        const unsigned char* slab = ring + ((12 + t) % RING) * SLAB + lane * 16;
+        f16x8 ah[2], al[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float a8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a8[e] = ma[t][8 * u + e];
+            split_regs(a8, ah[u], al[u]);
+        }
+        f16x8 bh[3], bl[3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            bh[i] = *reinterpret_cast<const f16x8*>(slab + (i * 2) * 1024);
+            bl[i] = *reinterpret_cast<const f16x8*>(slab + (i * 2 + 1) * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * CT; ++i) {                     // i = u * CT + ct
+            if (i + 2 < 2 * CT) {
+                bh[(i + 2) % 3] = *reinterpret_cast<const f16x8*>(slab + ((i + 2) * 2) * 1024);
+                bl[(i + 2) % 3] = *reinterpret_cast<const f16x8*>(slab + ((i + 2) * 2 + 1) * 1024);
+            }
+            const int u = i / CT, ct = i % CT;
+            mg[ct] = mma3(ah[u], al[u], bh[i % 3], bl[i % 3], mg[ct]);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        }
+    }
+
+    // ------------------------------------------------------------------ norm1 over the 128 channels of a token, store
+    const float inv_c = 1.0f / (float)DM;
+    float g[CT], b[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) { g[ct] = gamma[32 * ct + l31]; b[ct] = beta[32 * ct + l31]; }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float v[CT];
+        float sum = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) { v[ct] = mg[ct][r] * sc.m; sum += v[ct]; }
+        const float mean = sum32(sum) * inv_c;
+        float sq = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) { v[ct] -= mean; sq += v[ct] * v[ct]; }
+        const float rstd = 1.0f / sqrtf(sum32(sq) * inv_c + ln_eps);
+        const int tok = mfma32_row(r, h);
+        if (live && tok < L) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) out[(win * L + tok) * DM + 32 * ct + l31] = v[ct] * rstd * g[ct] + b[ct];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t far_attn_block_packed_bytes(int d_model) { return d_model == DM ? (size_t)NSLAB * SLAB : 0; }
+
+// out [nwin][L][128] = norm1(merge(LinearAttention(q_proj(x), k_proj(src), v_proj(src))))   (transformer.py:51-61 at d_model = 128,
+// 8 heads of 16, sequences of at most 32 tokens: the fine-level windows).  x [nwin][L][128], src [nwin][S][128] fp32;
+// packed: the image far_amd/ops.py:PackedAttn builds; scale_* = 2^-(w_exp + 4) of Wk, Wv, Wq, Wm; out must not alias x / src.
+int far_attn_block_f16s(const float* x, const float* src, const void* packed, long nwin, int L, int S, int d_model, int heads,
+                        float scale_k, float scale_v, float scale_q, float scale_m, float attn_eps, const float* gamma,
+                        const float* beta, float ln_eps, float* out, hipStream_t stream) {
+    far_clear_errors();
+    if (nwin == 0) return FAR_OK;
+    if (!x || !src || !packed || !gamma || !beta || !out || nwin < 0 || L <= 0 || S <= 0 || L > 32 || S > 32 ||
+        d_model != DM || heads != 8 || out == x || out == src)
+        return FAR_EINVAL;
+    const long nb = (nwin + WAVES - 1) / WAVES;
+    if (nb > 0x7fffffffL) return FAR_EINVAL;
+    const Scales sc{scale_k, scale_v, scale_q, scale_m};
+    hipLaunchKernelGGL(k_attn128, dim3((unsigned)nb), dim3(64 * WAVES), 0, stream, x, src, (const unsigned char*)packed, nwin, L, S,
+                       sc, attn_eps, gamma, beta, ln_eps, out);
+    return far_check_launch();
+}
+
+}  // extern "C"

@@ -16,7 +16,7 @@
 // Arithmetic as K9: every product as three f16 MFMAs on (hi, lo) operand pairs, fp32 accumulation (fp32-grade).
 // Workgroup = 4 waves = 128 rows; its waves consume the same 24 weight slabs of 16 KiB (16 k-steps of W0, 8 hidden tiles
 // of W2) from a 3-slot LDS ring filled by asm LDS-DMA two slabs ahead (one barrier per slab = per 24 MFMAs of a wave); the
-// input rows arrive by LDS-DMA too (4 KiB per wave), so every memory request of the loop is counted by hand (vmcnt).
+// input rows arrive by LDS-DMA too (4 KiB per wave), so every memory request of the loop is waited for by hand.
 // 64 KiB LDS, <= 256 VGPRs: two independent workgroups per CU (one workgroup of eight waves moved in lock step with its
 // barrier and left the matrix pipe idle during every LDS round trip: 1.18 ms against 1.47 ms for the two K9 launches).
 #include "common.h"
@@ -66,23 +66,9 @@ __device__ __forceinline__ float sum32(float v) {
     return v + shfl_xor_f(v, 16);
 }
 
-// s_waitcnt vmcnt(n), n in {0, 4, 8}
-__device__ __forceinline__ void wait_vm(int n) {
-    switch (n) {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-    }
-}
-// Requests issued in phase p (after its wait, in this order): on even phases the input chunk p / 2 + 1 while there is one
-// (4 requests), then weight slab p + 2 while there is one (PIECES = 4 requests).  vmcnt retires in order, so "slab s (and, on
-// even phases, chunk s / 2) has landed" = "at most the requests issued after them are outstanding":
-__device__ __forceinline__ int x_ops(int p) { return ((p & 1) == 0 && (p >> 1) + 1 < KIN / 32) ? 4 : 0; }
-__device__ __forceinline__ int w_ops(int p) { return p + 2 < NSLAB ? PIECES : 0; }
-__device__ __forceinline__ int allowed_outstanding(int s) {
-    if (s == 0) return PIECES;                                 // prologue order: chunk 0, slab 0, slab 1
-    return ((s & 1) ? x_ops(s - 1) : 0) + w_ops(s - 1);
-}
+// Every phase waits for all of this wave's outstanding requests (vmcnt(0)) before the barrier: they are issued two slabs /
+// one chunk ahead, so the youngest is a phase old (measured: no slower than counted waits; see attn_block_f16s.hip for why
+// the counted form was dropped).
 
 __global__ __launch_bounds__(256, 2) void k_mlp128(const float* __restrict__ x, const float* __restrict__ msg,
                                                    const unsigned char* __restrict__ wimg, long R, float hscale, float oscale,
@@ -132,9 +118,9 @@ __global__ __launch_bounds__(256, 2) void k_mlp128(const float* __restrict__ x, 
 
     // ---------------------------------------------------------------- GEMM 1: 16 k-steps, one slab each
 #pragma unroll
-    for (int s = 0; s < NS1; ++s) {                            // unrolled: the wait counts and ring slots are immediates
-        wait_vm(allowed_outstanding(s));
-        __builtin_amdgcn_s_barrier();                         // all 16 pieces of slab s visible; slot (s + 2) % 3 is free
+    for (int s = 0; s < NS1; ++s) {                            // unrolled: ring slots and chunk parity are immediates
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");                               // all 16 pieces of slab s visible; slot (s + 2) % 3 is free
         if ((s & 1) == 0) {                                   // a new chunk: read this lane's 64 bytes, split
             float4 raw[4];
 #pragma unroll
@@ -178,8 +164,8 @@ __global__ __launch_bounds__(256, 2) void k_mlp128(const float* __restrict__ x, 
 #pragma unroll
     for (int t = 0; t < HT; ++t) {
         const int s = NS1 + t;
-        wait_vm(allowed_outstanding(s));
-        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");      
         if (s + 2 < NSLAB) request_w(s + 2);
         const unsigned char* slab = ring + (s % RING) * SLAB + lane * 16;
         // hidden = relu(acc * 2^-(w_exp + 4)), then x 2^4 for the split: hscale = 2^-w_exp.  Both k-steps' A operands first

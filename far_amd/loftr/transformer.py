@@ -30,6 +30,7 @@ class LinearAttention(nn.Module):
     def __init__(self, eps=1e-6, use_num_corres=False):
         super().__init__()
         self.eps = eps
+        self.use_num_corres = use_num_corres
 
     def forward(self, queries, keys, values, q_mask=None, kv_mask=None, loftr_preds=None):
         N, L, H, D = queries.shape
@@ -50,6 +51,7 @@ class LoFTREncoderLayer(nn.Module):
     split_operands = True        # K9 operand precision of the Linear layers (False: plain fp16, LoFTR.set_precision)
     hip_training = True          # training on the GPU runs K9 / K5 (forward + backward kernels); False: vendor ops + autograd
     fused_mlp = True             # d_model 128, split operands: the MLP block as one K13 launch (False: two K9 launches)
+    fused_attn = True            # d_model 128, sequences <= 32 tokens, no masks: the attention block as one K14 launch
 
     def __init__(self, d_model, nhead, attention='linear', use_num_corres=False):
         super().__init__()
@@ -103,6 +105,20 @@ class LoFTREncoderLayer(nn.Module):
         heads = lambda t: t.view(bs, -1, self.nhead, self.dim)
         fuse = True     # measured: q | k | v (and k | v) in one launch pays at d_model 256 and, with 128-channel blocks, at 128
         source = source.contiguous()
+        if (self.fused_attn and sp and x.shape[-1] == 128 and self.nhead == 8 and x.shape[1] <= 32 and source.shape[1] <= 32
+                and x_mask is None and source_mask is None):
+            # d_model 128 on short sequences (the fine-level windows: bandwidth-bound): the whole layer in two launches --
+            # K14 (q / k / v projections, linear attention, merge, norm1) and K13 (the MLP block, norm2, residual)
+            pa = pk.get(('attn-fused',), [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight, self.merge.weight],
+                        lambda: ops.PackedAttn(self.q_proj.weight, self.k_proj.weight, self.v_proj.weight, self.merge.weight))
+            msg = ops.attn_block(x, source, pa, self.nhead, self.norm1.weight, self.norm1.bias, self.norm1.eps, self.attention.eps)
+            if self.fused_mlp:
+                pm = pk.get(('mlp-fused',), [self.mlp[0].weight, self.mlp[2].weight],
+                            lambda: ops.PackedMlp(self.mlp[0].weight, self.mlp[2].weight))
+                return ops.mlp_fused(x, msg, pm, self.norm2.weight, self.norm2.bias, self.norm2.eps, out=out)
+            h = ops.linear_f16s(x, lin('mlp0', self.mlp[0]), act='relu', x2=msg)
+            return ops.linear_f16s(h, lin('mlp2', self.mlp[2]), ln=(self.norm2.weight, self.norm2.bias, self.norm2.eps),
+                                   post_residual=x, out=out)
         if fuse and source is x:  # self attention: q | k | v of the one input in a single launch, three output tensors
             q, k, v = ops.linear_f16s(x, lin('qkv', self.q_proj, self.k_proj, self.v_proj), out_planes=3)
         elif fuse:

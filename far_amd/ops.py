@@ -659,6 +659,68 @@ def mlp_fused(x, msg, pack, gamma, beta, eps, out=None):
     return y if out is None else _written(y)
 
 
+class PackedAttn:
+    """Weight image of far_attn_block_f16s (K14): q / k / v / merge projections (128 x 128, no bias) of a LoFTR encoder layer
+    as 16 slabs of 16 KiB in execution order [k c0][v c0] .. [k c3][v c3][q c0..c3][merge t0..t3], fp16 (hi, lo) planes, each
+    tensor scaled by a power of two from its maximum.  Projection slab (chunk c of W): [k-step ks][tile t][plane][lane][8]:
+    lane = (output channel 32 t + (lane & 31), h = lane >> 5), element e = input channel 32 c + 16 h + 8 ks + e.  Merge slab t
+    (as PackedMlp's second half): [k-step u][output tile ct][plane][lane][8], element e = input channel
+    32 t + 16 u + 4 h + (e & 3) + 8 (e >> 2)."""
+
+    def __init__(self, wq, wk, wv, wm):
+        lib = _lib.load()
+        ws = [w.detach().float() for w in (wk, wv, wq, wm)]
+        d = ws[0].shape[0]
+        if any(tuple(w.shape) != (d, d) for w in ws) or lib.far_attn_block_packed_bytes(d) == 0:
+            raise _lib.FarHipError('far_attn_block_f16s is built for d_model = 128')
+        dev = ws[0].device
+
+        def exp_of(w):
+            amax = float(w.abs().max())
+            return 14 - (torch.frexp(torch.tensor(amax)).exponent.item() if amax > 0 else 0)
+
+        def planes(v):
+            hi = v.half()
+            return torch.stack([hi, (v - hi.float()).half()])
+
+        self.exps = [exp_of(w) for w in ws]
+        ar = lambda n: torch.arange(n, device=dev)
+        c_, k_, t_, l_, e_ = (ar(4).view(4, 1, 1, 1, 1), ar(2).view(1, 2, 1, 1, 1), ar(4).view(1, 1, 4, 1, 1),
+                              ar(64).view(1, 1, 1, 64, 1), ar(8).view(1, 1, 1, 1, 8))
+        shp = (4, 2, 4, 64, 8)
+        co = (32 * t_ + (l_ & 31)).expand(shp)
+        ci = (32 * c_ + 16 * (l_ >> 5) + 8 * k_ + e_).expand(shp)
+
+        def proj(w, ex):                                   # -> (chunk, ks, tile, plane, lane, e)
+            return planes(w[co, ci] * 2.0 ** ex).permute(1, 2, 3, 0, 4, 5).contiguous()
+
+        pk, pv, pq = proj(ws[0], self.exps[0]), proj(ws[1], self.exps[1]), proj(ws[2], self.exps[2])
+        kvi = torch.stack([pk, pv], 1).reshape(-1)          # [c][k | v][...]: slabs k c0, v c0, k c1, ...
+        mi = (32 * c_ + 16 * k_ + 4 * (l_ >> 5) + (e_ & 3) + 8 * (e_ >> 2)).expand(shp)     # c_ = input tile t, k_ = u, t_ = output tile
+        pm = planes(ws[3][co, mi] * 2.0 ** self.exps[3]).permute(1, 2, 3, 0, 4, 5).contiguous()
+        self.packed = torch.cat([kvi, pq.reshape(-1), pm.reshape(-1)]).view(torch.uint8)
+        assert self.packed.numel() == lib.far_attn_block_packed_bytes(d)
+        self.d = d
+        self.scales = [2.0 ** -(ex + _CONV_ACT_EXP) for ex in self.exps]       # k, v, q, merge
+
+
+def attn_block(x, source, pack, nhead, gamma, beta, ln_eps, attn_eps=1e-6, out=None):
+    """K14: norm1(merge(LinearAttention(q_proj(x), k_proj(source), v_proj(source)))) for (N, L <= 32, 128) windows
+    (transformer.py:51-61 at d_model = 128, 8 heads)."""
+    lib = _lib.load()
+    N, L, d = x.shape
+    S = source.shape[1]
+    if d != pack.d or source.shape[0] != N or source.shape[2] != d:
+        raise _lib.FarHipError('attn_block: x (N, L, 128) and source (N, S, 128) expected')
+    y = torch.empty_like(x) if out is None else out
+    sk, sv, sq, sm = pack.scales
+    rc = lib.far_attn_block_f16s(_p(x, torch.float32), _p(source, torch.float32), _p(pack.packed), N, L, S, d, int(nhead), sk, sv, sq, sm,
+                                 float(attn_eps), _p(gamma, torch.float32), _p(beta, torch.float32), float(ln_eps), _p(y, torch.float32),
+                                 _stream())
+    _lib.check(rc, 'far_attn_block_f16s')
+    return y if out is None else _written(y)
+
+
 class PackCache:
     """K9 weight images keyed by name, rebuilt when any tensor they were derived from changes (in-place update,
     load_state_dict, optimizer step: data_ptr / _version stamp)."""

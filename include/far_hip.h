@@ -219,6 +219,16 @@ int far_layernorm_f32(const float* x, const float* gamma, const float* beta, con
  *   2^e0, W2 by 2^e2, fp16 hi / lo planes in execution order); hscale = 2^-e0, oscale = 2^-(e2 + 4); gamma, beta [128], eps:
  *   norm2.  out [R][128] must not alias x or msg.  Arithmetic as K9 (three f16 MFMAs per fp32-grade product).
  * --------------------------------------------------------------------------------------------------- */
+/* K14  the attention block of a LoFTR encoder layer at d_model = 128 on sequences of <= 32 tokens (the fine-level windows)
+ * replaces src/loftr/loftr_module/transformer.py:51-61 with linear_attention.py:31-50:
+ *          norm1(merge(LinearAttention(q_proj(x), k_proj(src), v_proj(src))))      8 heads of 16 channels
+ *   x [nwin][L][128], src [nwin][S][128] fp32 (L, S <= 32); packed = the image far_amd/ops.py:PackedAttn builds
+ *   (far_attn_block_packed_bytes bytes); scale_k / _v / _q / _m = 2^-(w_exp + 4) of the four weight tensors; attn_eps: the
+ *   1e-6 of LinearAttention; gamma, beta [128], ln_eps: norm1.  out [nwin][L][128] must not alias x or src. */
+size_t far_attn_block_packed_bytes(int d_model);
+int far_attn_block_f16s(const float* x, const float* src, const void* packed, long nwin, int L, int S, int d_model, int heads,
+                        float scale_k, float scale_v, float scale_q, float scale_m, float attn_eps, const float* gamma,
+                        const float* beta, float ln_eps, float* out, far_stream_t stream);
 size_t far_mlp_fused_packed_bytes(int d_model);
 int far_mlp_fused_f16s(const float* x, const float* msg, const void* packed, long R, int d_model, float hscale, float oscale,
                        const float* gamma, const float* beta, float eps, float* out, far_stream_t stream);
