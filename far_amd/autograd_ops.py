@@ -1,8 +1,11 @@
-"""Differentiable vendor-path forms of the fused operators, used ONLY when gradients are required (training,
-BASELINE configs[2]).  The HIP kernels of this round are forward-only; until their backward kernels exist the
-training step runs these torch compositions (same formulas as the reference, autograd supplies the backward) --
-explicitly, never as a silent fallback for inference: every caller checks `needs_grad(...)` first and the
-inference path raises on CPU tensors.  Citations as in the kernels they stand in for.
+"""Differentiable vendor-op forms of the fused operators (torch compositions, autograd supplies the backward).
+
+Who uses them: (1) CPU tensors in training mode (the golden G10 / gloo DDP tests); (2) the explicit comparison legs
+`hip_training = False` / `materialize_conf = True` (bench.py --workload c3 --vendor-train); (3) on the GPU only the
+pieces that have no HIP backward kernel yet (the fine-window gather / expectation; the backbone's training-mode
+convolutions run on the vendor library).  K1 (sparse positions), K2, K5 and K9-Linear have HIP forward + backward
+kernels; the inference path never comes here (it raises on CPU tensors).  Citations as in the kernels they stand
+in for.
 """
 import torch
 import torch.nn.functional as F

@@ -106,7 +106,8 @@ def coarse_match(f0, f1, temperature, thr, border, hw0, hw1, cell_scale, mask0=N
 def conf_matrix(f0, f1, temperature, mask0=None, mask1=None, out=None):
     """K1, materialising mode: data['conf_matrix'] (Z, L, S) alone (coarse_matching.py:108-118) at HBM write speed
     (far_conf_matrix_f16s: fp32-grade statistics, plain-fp16 scores, exact recomputation of every entry above 2^-12).
-    Falls back to the fused split-precision matcher's writer if the exact-entry list overflowed (needs one host read).
+    Falls back to the fused split-precision matcher's writer if the exact-entry list overflowed; reading that flag is one
+    host synchronisation per call.  With `out=` the result is always in `out` (also after the fallback).
     Returns (conf, listed) with listed = number of entries that were recomputed exactly."""
     lib = _lib.load()
     Z, L, C = f0.shape
@@ -119,11 +120,15 @@ def conf_matrix(f0, f1, temperature, mask0=None, mask1=None, out=None):
                                   _p(mask0, torch.uint8), _p(mask1, torch.uint8), 3, _p(conf, torch.float32), _p(info), _p(ws),
                                   _stream())
     _lib.check(rc, 'far_conf_matrix_f16s')
-    listed, dropped = (int(v) for v in info.cpu())
+    listed, dropped = (int(v) for v in info.cpu())            # one blocking host read per call (the overflow flag)
     if dropped > 0:           # pathological input (a column with more than 8 non-tiny entries): the exact writer
         hw = (1, L), (1, S)
-        return coarse_match(f0, f1, temperature, 2.0, 0, hw[0], hw[1], 1.0, mask0, mask1, want_conf=True,
-                            variant='f16s')['conf_matrix'], listed
+        exact = coarse_match(f0, f1, temperature, 2.0, 0, hw[0], hw[1], 1.0, mask0, mask1, want_conf=True,
+                             variant='f16s')['conf_matrix']
+        if out is None:
+            return exact, listed
+        out.copy_(exact)      # the caller's buffer must hold the result it asked for, not the partially exact one
+        return _written(out), listed
     return (conf if out is None else _written(conf)), listed
 
 

@@ -377,13 +377,8 @@ def test_g14_spvs_coarse_matches_reference():
     """far_amd.supervision.spvs_coarse (batched, no conf_matrix_gt) against the reference's spvs_coarse run on the same
     synthetic planar scenes (golden G14): identical ground-truth match ids, warped points, and -- with dense_gt -- the
     same 0/1 matrix."""
-    import importlib.util
-    import types
     from far_amd.supervision import spvs_coarse
-    src = open(os.path.join(os.path.dirname(G), '..', 'tools', 'make_goldens.py')).read()
-    mod = types.ModuleType('spvs_scene_helper')
-    mod.__dict__.update({'np': np})
-    exec(src[src.index('def spvs_scene('):src.index('def g14_spvs_coarse():')], mod.__dict__)
+    from tests import util as mod
     d0, d1, T01, T10, K = mod.spvs_scene()
     g = load('g14_spvs_coarse')
     N = len(d0)
@@ -410,14 +405,10 @@ def test_g15_losses_and_fine_supervision_match_reference():
     far_amd.supervision.spvs_fine against the reference's LoFTRLoss.forward / spvs_fine on the same tensors (golden G15).
     The coarse term is evaluated three ways: gathered from conf_matrix_gt, from spv ids, and from data['conf_pos'] (the form
     the GPU training path provides) -- all must give the reference's number."""
-    import types
     from far_amd.config import far_train_config, RunCfg
     from far_amd.losses import LoFTRLoss
     from far_amd.supervision import spvs_fine, compute_supervision_fine
-    src = open(os.path.join(os.path.dirname(G), '..', 'tools', 'make_goldens.py')).read()
-    mod = types.ModuleType('loss_inputs_helper')
-    mod.__dict__.update({'np': np})
-    exec(src[src.index('def loss_inputs('):src.index('def g15_losses():')], mod.__dict__)
+    from tests import util as mod
     x = mod.loss_inputs()
     g = load('g15_losses')
     b, i, j = np.nonzero(x['gt'])

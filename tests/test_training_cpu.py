@@ -20,17 +20,9 @@ G = os.path.join(ROOT, 'tests', 'golden')
 
 
 def _train_helpers():
-    """train_inputs / train_step / GRAD_KEYS are shared with the golden generator; import them without running it
-    (the reference shim is only needed when the module's __main__ runs)."""
-    import importlib.util
-    import types
-    src = open(os.path.join(ROOT, 'tools', 'make_goldens.py')).read()
-    start = src.index('def train_inputs():')
-    end = src.index('def g10_training(m):')
-    mod = types.ModuleType('train_helpers')
-    mod.__dict__.update({'np': np, 'torch': torch, 'synth': synth})
-    exec(src[start:end], mod.__dict__)
-    return mod
+    """train_inputs / train_step / GRAD_KEYS: the builders the golden generator used (tests/util.py)."""
+    from tests import util
+    return util
 
 
 @pytest.mark.timeout(900)

@@ -1,4 +1,5 @@
-"""Shared synthetic-input builders for the parity tests (seeded, no reference access)."""
+"""Shared synthetic-input builders for the parity tests (seeded, no reference access).  tools/make_goldens.py imports the
+same builders when it runs the reference, so a golden's inputs and the test's inputs are one piece of code."""
 import numpy as np
 
 
@@ -67,3 +68,114 @@ def deviation(name, got, ref, atol, rtol=0.0):
     if os.environ.get('FAR_MEASURE_ONLY') != '1':          # measurement runs print every deviation without stopping
         np.testing.assert_allclose(g, r, atol=atol, rtol=rtol, err_msg=name)
     return d
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# inputs shared with tools/make_goldens.py (G10, G14, G15)
+# ---------------------------------------------------------------------------------------------------------------------
+def train_inputs():
+    """Shared by the generator and tests/test_training_cpu.py: one synthetic pair, GT coarse matches from the known
+    band disparities, fake solver outputs."""
+    from far_amd import synth
+    im0, im1 = synth.synth_image_pair(1, seed=0)
+    disp = (8, 40, 72)
+    ii, jj = [], []
+    for y in range(60):
+        d = disp[min(2, (y * 8) // 160)] // 8
+        for x in range(80):
+            if 0 <= x - d < 80:
+                ii.append(y * 80 + x)
+                jj.append(y * 80 + x - d)
+    ang = 0.3
+    R = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+    rt = np.concatenate([R, np.array([0.6, -0.1, 0.79])[:, None]], 1)
+    return im0, im1, np.array(ii, np.int64), np.array(jj, np.int64), rt
+
+
+GRAD_KEYS = ['backbone.conv1.weight', 'backbone.layer1.0.conv1.weight', 'backbone.layer3.1.bn2.weight',
+             'backbone.layer3_outconv.weight', 'backbone.layer1_outconv2.3.weight',
+             'loftr_coarse.layers.0.q_proj.weight', 'loftr_coarse.layers.5.mlp.2.weight', 'loftr_coarse.layers.3.norm1.bias',
+             'fine_preprocess.merge_feat.weight', 'loftr_fine.layers.1.v_proj.weight',
+             'loftr_regress.loftr.layers.0.k_proj.weight', 'loftr_regress.emm.cross_attn.qkv.weight',
+             'loftr_regress.emm.pos_embed', 'loftr_regress.encoder.0.weight', 'loftr_regress.moe_predictor.4.weight',
+             'loftr_regress.pose_regressor_simple_moe.2.bias']
+
+
+def train_step(m, im0, im1, ii, jj, rt):
+    """One training-mode forward + backward with a synthetic loss touching conf_matrix, expec_f and regressed_rt."""
+    import torch
+    data = {'image0': torch.from_numpy(im0), 'image1': torch.from_numpy(im1),
+            'spv_b_ids': torch.zeros(len(ii), dtype=torch.int64), 'spv_i_ids': torch.from_numpy(ii),
+            'spv_j_ids': torch.from_numpy(jj)}
+    m.train()
+    torch.manual_seed(123)
+    m(data, train=True)
+    data.update({'loftr_rt': torch.from_numpy(rt), 'num_correspondences': torch.tensor([731]),
+                 'num_correspondences_before_ransac': torch.tensor([1500]), 'inliers_best_tight': torch.tensor([410]),
+                 'inliers_best_ultra_tight': torch.tensor([57])})
+    m.forward_rt_prediction(data)
+    conf = data['conf_matrix']
+    loss_c = -torch.log(conf[0, data['spv_i_ids'], data['spv_j_ids']] + 1e-6).mean()
+    loss_f = data['expec_f'].pow(2).mean()
+    loss_rt = data['regressed_rt'].pow(2).sum()
+    loss = loss_c + loss_f + loss_rt
+    m.zero_grad()
+    loss.backward()
+    return data, (loss_c, loss_f, loss_rt)
+
+
+def spvs_scene(seed=61, N=2, H=480, W=640):
+    """Shared by the generator and tests: two fronto-parallel-ish depth maps per pair related by a known rigid motion
+    (planes at different depths per image band, a few zero-depth holes), Matterport intrinsics."""
+    rng = np.random.default_rng(seed)
+    K = np.array([[517.97, 0, 320.], [0, 517.97, 240.], [0, 0, 1.]], np.float32)
+    depth0 = np.empty((N, H, W), np.float32)
+    depth1 = np.empty((N, H, W), np.float32)
+    T01 = np.zeros((N, 4, 4), np.float32)
+    for n in range(N):
+        ang = 0.05 * (n + 1)
+        R = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]], np.float32)
+        t = np.array([0.15 * (n + 1), 0.02, 0.05], np.float32)
+        T01[n, :3, :3] = R; T01[n, :3, 3] = t; T01[n, 3, 3] = 1
+        # a slanted plane n.X = d in camera 0; render its depth in both cameras analytically
+        nrm = np.array([0.1, -0.05, 1.0], np.float32); nrm /= np.linalg.norm(nrm)
+        d = 3.0 + 0.5 * n
+        ys, xs = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing='ij')
+        rays = np.stack([(xs - K[0, 2]) / K[0, 0], (ys - K[1, 2]) / K[1, 1], np.ones_like(xs)], -1)
+        depth0[n] = d / (rays @ nrm)
+        # plane in camera 1: n1 = R n, d1 = d + n1 . t
+        n1 = R @ nrm; d1 = d + n1 @ t
+        depth1[n] = d1 / (rays @ n1)
+        holes = rng.integers(0, H // 8, (20, 2))
+        for hy, hx in holes:
+            depth0[n, hy * 8:hy * 8 + 8, (hx * 8) % W:(hx * 8) % W + 8] = 0
+    T10 = np.linalg.inv(T01).astype(np.float32)
+    return depth0, depth1, T01, T10, np.stack([K] * N)
+
+
+def loss_inputs(seed=71, N=2, L=48, M=40):
+    """Shared by the generator and the tests: random coarse confidences / ground truth / fine predictions / poses."""
+    rng = np.random.default_rng(seed)
+    conf = rng.uniform(0, 1, (N, L, L)).astype(np.float32) ** 3
+    conf[0, 3, 5] = 0.0                                   # clamp paths (:84)
+    conf[1, 7, 7] = 1.0
+    gt = np.zeros((N, L, L), np.float32)
+    pos = [(0, 3, 5), (1, 7, 7)] + [(int(rng.integers(N)), int(rng.integers(L)), int(rng.integers(L))) for _ in range(30)]
+    for b, i, j in pos:
+        gt[b, i, j] = 1
+    expec_f = np.concatenate([rng.normal(0, 0.5, (M, 2)), rng.uniform(0.05, 2.0, (M, 1))], 1).astype(np.float32)
+    expec_f_gt = rng.normal(0, 0.7, (M, 2)).astype(np.float32)
+    expec_rt = rng.normal(0, 1, 9).astype(np.float32)
+    ang = 0.4
+    T = np.eye(4, dtype=np.float32)
+    T[:3, :3] = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]], np.float32)
+    T[:3, 3] = [0.3, -0.2, 1.1]
+    T = np.stack([T, np.eye(4, dtype=np.float32)])
+    # spvs_fine inputs
+    w_pt0 = rng.uniform(0, 640, (N, L, 2)).astype(np.float32)
+    pt1 = rng.uniform(0, 640, (N, L, 2)).astype(np.float32)
+    b_ids = rng.integers(0, N, M)
+    i_ids = rng.integers(0, L, M)
+    j_ids = rng.integers(0, L, M)
+    return dict(conf=conf, gt=gt, expec_f=expec_f, expec_f_gt=expec_f_gt, expec_rt=expec_rt, T=T, w_pt0=w_pt0, pt1=pt1,
+                b_ids=b_ids, i_ids=i_ids, j_ids=j_ids)
