@@ -366,7 +366,10 @@ def bench_c3(a, dev, world, rank, dist):
         from torch.nn.parallel import DistributedDataParallel as DDP
         if a.backend == 'nccl':            # the reference trains with sync_batchnorm (train.py:342, :350-352); RCCL only
             model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
-        fwd = DDP(model, device_ids=[dev.index] if a.backend == 'nccl' else None)
+        # no device_ids: the module already lives on `dev`, and a DDP built WITH device_ids passes dict inputs through
+        # _recursive_to, which rebuilds them -- LoFTR.forward writes its results into the dict it is given
+        # (pipeline._trainval_inference merges a returned copy back, tests/test_multirank_gpu.py covers both forms)
+        fwd = DDP(model)
     opt = torch.optim.AdamW(model.parameters(), lr=1e-5, weight_decay=0.1)      # src/optimizers/__init__.py:5-16, default.py TRAINER.*
     # synthetic supervision: banded lateral disparities -> ground-truth coarse matches + warped grid (far_amd/synth.py)
     base = synth.synth_training_batch(B, seed=1234 + rank, device=dev)
@@ -398,6 +401,38 @@ def bench_c3(a, dev, world, rank, dist):
     dt = time.perf_counter() - t0
     per_rank_ms = [round(1000 * x / a.steps, 3) for x in parallel.gather_floats(dt, device=dev)]
     dt = parallel.max_over_ranks(dt, device=dev)
+    # The path's one exchange step: the gradient all-reduce.  Reported two ways: a stand-alone all-reduce of
+    # one flat fp32 buffer of the gradients' size (what the ring costs when nothing overlaps it), and the part of it that is
+    # EXPOSED in the step = step time with the hooks armed minus step time under no_sync() (same work, no exchange).
+    exchange = None
+    if dist is not None:
+        n_param = sum(p.numel() for p in model.parameters() if p.requires_grad)
+        flat = torch.zeros(n_param, dtype=torch.float32, device=dev)
+        for _ in range(2):
+            dist.all_reduce(flat)
+        fence()
+        t1 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            dist.all_reduce(flat)
+        fence()
+        ar_ms = parallel.max_over_ranks(time.perf_counter() - t1, device=dev) / reps * 1000
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            with fwd.no_sync():
+                step()
+        fence()
+        nosync_ms = parallel.max_over_ranks(time.perf_counter() - t1, device=dev) / a.steps * 1000
+        nbytes = 4 * n_param
+        ring = 2 * (world - 1) / world * nbytes                       # bytes each rank sends (= receives) in a ring all-reduce
+        exchange = {'what': 'gradient all-reduce, fp32, DistributedDataParallel buckets overlapped with backward',
+                    'bytes': nbytes, 'standalone_ms': round(ar_ms, 3), 'bus_GBps': round(ring / ar_ms / 1e6, 1),
+                    'per_link_bound_ms': round(ring / 153e9 * 1000, 3),
+                    'bound_note': 'ring over xGMI: 2(N-1)/N x bytes through one ~153 GB/s link per direction (MI355X_MICROARCH.md)',
+                    'step_ms_without_exchange': round(nosync_ms, 3),
+                    'exposed_ms_in_step': round(1000 * dt / a.steps - nosync_ms, 3),
+                    'backend': dist.get_backend(), 'ranks': world}
     if rank == 0:
         sc = {k_: round(float(v_), 5) for k_, v_ in last['loss_scalars'].items() if k_.startswith('loss')}
         res = {
@@ -417,6 +452,7 @@ def bench_c3(a, dev, world, rank, dist):
                        'gt_coarse_matches_per_pair': n_gt, 'sampled_matches': int(last['b_ids'].numel()),
                        'losses': sc,
                        'parallelism': f'ddp{world} (gradient all-reduce over RCCL)' if world > 1 else 'single GPU (no exchange step)'},
+            'exchange': exchange,
         }
         print(json.dumps(res), flush=True)
     if dist is not None:

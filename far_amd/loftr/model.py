@@ -236,8 +236,12 @@ class LoFTR(nn.Module):
         data.pop(cls._HEAD_KEY, None)
 
     def forward(self, data, train=False):
+        """Results are side effects on `data` (loftr.py:194-205, which returns None).  The dict is also RETURNED: a
+        wrapper that copies dict arguments on the way in (DistributedDataParallel built with device_ids) would otherwise
+        leave the caller with a dict the module never wrote to; far_amd.pipeline merges a returned copy back."""
         self.forward_feature_extraction(data)
         self.forward_correspondence_prediction(data, train=train)
+        return data
 
     def load_state_dict(self, state_dict, *args, **kwargs):
         # Lightning checkpoints carry the 'matcher.' prefix (lightning_loftr.py:58-75, loftr.py:207-211)

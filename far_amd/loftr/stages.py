@@ -74,6 +74,15 @@ class CoarseMatching(nn.Module):
             'mkpts0_c': out['mkpts0_c'], 'mkpts1_c': out['mkpts1_c'], 'mconf': mconf,
             'match_counts': out['counts'],   # per-pair M (host), reused by the batched solver
         })
+        if 'spv_b_ids' in data and not self.materialize_conf and feat_c0.shape[-1] == 256 and 'mask0' not in data:
+            # validation (lightning_loftr.py:266-267: _trainval_inference with the matcher in eval mode, then the loss):
+            # the coarse loss reads conf_matrix at the ground-truth positions only (loftr_loss.py:86-91), so those are
+            # evaluated instead of the dense matrix -- the forward half of the training kernels, no graph
+            with torch.no_grad():
+                data['conf_pos'] = ops.coarse_pos_conf(feat_c0.float().contiguous(), feat_c1.float().contiguous(),
+                                                       data['spv_b_ids'], data['spv_i_ids'], data['spv_j_ids'], self.temperature)
+        else:
+            data.pop('conf_pos', None)
 
     # ------------------------------------------------------------------------------------------------------
     # training (coarse_matching.py:86-147 + :199-240).  The coarse loss of this configuration (dual-softmax, sparse

@@ -126,3 +126,40 @@ def test_spvs_rt_segments_are_order_independent_on_the_host(seed, b, scramble):
     back = torch.empty_like(order)
     back[order] = torch.arange(len(order))
     assert torch.equal(seg[back], pts)                             # and the mask scatter-back is the inverse permutation
+
+
+def test_trainval_inference_merges_a_copied_dict_and_checks_the_supervision_contract():
+    """pipeline._trainval_inference with a stand-in matcher: (1) a forward wrapper that hands the module a COPY of the
+    batch (what DistributedDataParallel(device_ids=[...]) does to dict inputs) -- the returned dict is merged back into the
+    caller's; (2) a depth-supervised source without depth or labels is refused up front; (3) interiornet_streetlearn
+    skips both supervision calls (lightning_loftr.py:131-140)."""
+    import pytest
+    import torch
+    from far_amd.config import RunCfg
+    from far_amd.pipeline import _trainval_inference
+
+    class Matcher:
+        config = {'regress_rt': False}
+
+        def __call__(self, data, train=False):
+            data.update(b_ids=torch.tensor([0, 0]), i_ids=torch.tensor([1, 2]), j_ids=torch.tensor([3, 4]),
+                        mkpts0_f=torch.zeros(2, 2), seen_train=train)
+            return data
+    m = Matcher()
+    seen = {}
+    loss_fn = lambda d: seen.update(keys=set(d))
+    labels = dict(spv_b_ids=torch.zeros(1, dtype=torch.long), spv_i_ids=torch.zeros(1, dtype=torch.long),
+                  spv_j_ids=torch.zeros(1, dtype=torch.long), spv_w_pt0_i=torch.zeros(1, 8, 2), spv_pt1_i=torch.ones(1, 8, 2))
+    batch = dict(labels, dataset_name=['mp3d'])
+    copying = lambda d, train=False: m(dict(d), train=train)
+    _trainval_inference(m, batch, loss_fn, RunCfg(), True, 16, 0, forward=copying)
+    assert batch['seen_train'] is True and 'b_ids' in batch and batch['expec_f_gt'].shape == (2, 2)
+    assert 'expec_f_gt' in seen['keys']
+    with pytest.raises(KeyError, match='depth-supervised'):
+        _trainval_inference(m, {'dataset_name': ['mp3d'], 'spv_b_ids': labels['spv_b_ids']}, loss_fn, RunCfg(), False, 16, 0)
+    b3 = {'dataset_name': ['interiornet_streetlearn']}
+    _trainval_inference(m, b3, loss_fn, RunCfg(), False, 16, 0)
+    assert 'expec_f_gt' not in b3 and b3['seen_train'] is False
+    silent = lambda d, train=False: None if m(dict(d), train=train) else None       # a wrapper that swallows the dict
+    with pytest.raises(AssertionError, match='different dict'):
+        _trainval_inference(m, dict(labels, dataset_name=['mp3d']), loss_fn, RunCfg(), True, 16, 0, forward=silent)

@@ -41,3 +41,44 @@ def test_two_ranks_training_step_under_ddp():
     assert res['n_gpus'] == 2 and len(res['per_rank_ms_per_step']) == 2
     assert res['config']['parallelism'].startswith('ddp2')
     assert all(v == v and abs(v) < 1e4 for v in res['config']['losses'].values())      # finite losses after DDP steps
+
+
+@pytest.mark.timeout(900)
+def test_ddp_built_with_device_ids_still_hands_the_results_back():
+    """DistributedDataParallel(model, device_ids=[0]) rebuilds dict arguments on the way in (_recursive_to), so the module
+    writes b_ids / conf_pos / expec_f / ... into a COPY of the caller's batch.  LoFTR.forward returns its dict and
+    pipeline._trainval_inference merges a returned copy back: the reference-order training step must work for both DDP
+    forms (with device_ids: the copy path; without: the pass-through path bench.py uses).  One process, world size 1."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from far_amd import parallel, synth
+    from far_amd.config import RunCfg, far_train_config
+    from far_amd.loftr import LoFTR
+    from far_amd.losses import LoFTRLoss
+    from far_amd.pipeline import train_step
+    cfg = far_train_config()
+    model = LoFTR(cfg['loftr'])
+    synth.load_synthetic(model, seed=0)
+    model = model.cuda().train()
+    loss_fn = LoFTRLoss(cfg).train()
+    dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{parallel.free_port()}', rank=0, world_size=1)
+    try:
+        base = synth.synth_training_batch(1, seed=9, device='cuda')
+        losses = []
+        for ids in ([0], None):
+            fwd = DDP(model, device_ids=ids)
+            batch = dict(base)
+            torch.manual_seed(3)
+            train_step(model, batch, loss_fn, RunCfg('prior_ransac', 2), H=256, seed=0, forward=fwd)
+            assert 'b_ids' in batch and batch['conf_pos'].requires_grad and batch['loss'].requires_grad
+            model.zero_grad()
+            batch['loss'].backward()
+            g = model.loftr_coarse.layers[0].q_proj.weight.grad
+            assert g is not None and torch.isfinite(g).all() and float(g.abs().sum()) > 0
+            losses.append(float(batch['loss']))
+            del fwd
+        np.testing.assert_allclose(losses[0], losses[1], rtol=1e-6)
+    finally:
+        dist.destroy_process_group()

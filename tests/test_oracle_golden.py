@@ -458,3 +458,92 @@ def test_g15_losses_and_fine_supervision_match_reference():
     d2 = dict(data)
     compute_supervision_fine(d2, RunCfg())               # the config object the pipeline hands over
     np.testing.assert_array_equal(d2['expec_f_gt'].numpy(), g['expec_f_gt'])
+
+
+# ------------------------------------------------------------------------------------------------ G16
+def _g16_stub(x):
+    calls = []
+
+    def stub(k0, k1, K0, K1, thr, conf=None, translation_scale=None, solver=None, priorRT=None):
+        b = len(calls)
+        calls.append(len(k0))
+        if x['fit_ok'][b] == 0:
+            return None, 0, 0, 0
+        mask = x['fit_mask'][x['m_bids'] == b] > 0
+        return (torch.from_numpy(x['fit_R'][b]), torch.from_numpy(x['fit_t'][b]), mask, torch.eye(3)), torch.tensor(int(mask.sum())), 0, 0
+    return stub
+
+
+def test_g16_eval_metrics_match_reference():
+    """The evaluation step after the path (lightning_loftr.py:227-264): far_amd.metrics.compute_symmetrical_epipolar_errors,
+    compute_pose_errors (head branch, solver branch with committed fits incl. a failed one, no-match branch),
+    epidist_prec and aggregate_metrics -- and the float64 oracle -- against the reference's own functions (golden G16)."""
+    from far_amd import metrics as fm
+    from far_amd.config import RunCfg
+    from oracle import metrics as om
+    from tests.util import eval_batch, eval_metrics_table
+    g = load('g16_eval_metrics')
+    x = eval_batch()
+    B = len(x['T'])
+    t = torch.from_numpy
+    # epipolar errors: fp32 in the reference; the oracle is float64
+    ref64 = om.compute_symmetrical_epipolar_errors(x['T'].astype(np.float64), x['m_bids'], x['mk0'].astype(np.float64),
+                                                   x['mk1'].astype(np.float64), x['K0'].astype(np.float64), x['K1'].astype(np.float64))
+    np.testing.assert_allclose(ref64, g['epi_errs'], rtol=2e-4, atol=1e-9)
+    data = {'T_0to1': t(x['T']), 'K0': t(x['K0']), 'K1': t(x['K1']), 'm_bids': t(x['m_bids']), 'mkpts0_f': t(x['mk0']), 'mkpts1_f': t(x['mk1'])}
+    fm.compute_symmetrical_epipolar_errors(data)
+    assert data['epi_errs'].shape == (len(x['m_bids']),)
+    np.testing.assert_allclose(data['epi_errs'].numpy(), g['epi_errs'], rtol=2e-4, atol=1e-9)
+    d64 = {k: (v.double() if v.is_floating_point() else v) for k, v in data.items() if k != 'epi_errs'}
+    fm.compute_symmetrical_epipolar_errors(d64)
+    np.testing.assert_allclose(d64['epi_errs'].numpy(), ref64, rtol=1e-10)
+    # an unsorted m_bids (training order) gives the reference's pair-after-pair concatenation
+    perm = np.random.default_rng(0).permutation(len(x['m_bids']))
+    dp = dict(d64, m_bids=d64['m_bids'][perm], mkpts0_f=d64['mkpts0_f'][perm], mkpts1_f=d64['mkpts1_f'][perm])
+    fm.compute_symmetrical_epipolar_errors(dp)
+    np.testing.assert_allclose(np.sort(dp['epi_errs'].numpy()), np.sort(ref64), rtol=1e-10)
+    for b in range(B):
+        np.testing.assert_allclose(np.sort(dp['epi_errs'].numpy()[np.sort(x['m_bids']) == b]), np.sort(ref64[x['m_bids'] == b]), rtol=1e-10)
+    cfg = RunCfg('prior_ransac')
+    # (1) head branch: per pair (the reference's batch size 1) and all pairs in one call
+    d = {'T_0to1': t(x['T']), 'K0': t(x['K0']), 'K1': t(x['K1']), 'regressed_rt': t(x['regressed_rt'])}
+    fm.compute_pose_errors(d, cfg)
+    got = np.array([d['R_errs'], d['t_errs'], d['t_errs_abs'], d['successful_fits']]).T
+    np.testing.assert_allclose(got, g['head_errs'], rtol=1e-5, atol=2e-3)       # the reference evaluates acos in fp32
+    o = om.compute_pose_errors(x['T'], regressed_rt=x['regressed_rt'])
+    np.testing.assert_allclose(got[:, :3], np.array([o['R_errs'], o['t_errs'], o['t_errs_abs']]).T, rtol=1e-5, atol=2e-4)
+    np.testing.assert_allclose(d['pred_R'], g['head_pred_R'], atol=1e-6)
+    np.testing.assert_allclose(d['pred_t'], g['head_pred_t'], atol=1e-6)
+    assert d['inliers'] == [0] * B and isinstance(d['pred_R'], np.ndarray)
+    # (2) solver branch with the committed fits the generator's stub returned
+    d = dict(data, translation_scale=None, priorRT=x['priorRT'])
+    fm.compute_pose_errors(d, cfg, estimate_pose_fn=_g16_stub(x))
+    got = np.array([d['R_errs'], d['t_errs'], d['t_errs_abs'], d['successful_fits']], np.float64).T
+    # (angles: the reference takes the norm of its float32 ground-truth translation in float32 (metrics.py:20); acos turns
+    # that 6e-8 into up to 0.02 degrees near zero error -- pair 0's fit IS the truth and reads 0.015 there, 9e-7 here)
+    np.testing.assert_allclose(got, g['fit_errs'], rtol=1e-6, atol=2e-2)
+    np.testing.assert_allclose(got[:, 2:], g['fit_errs'][:, 2:], rtol=1e-6, atol=1e-6)
+    np.testing.assert_array_equal([np.asarray(i).sum() for i in d['inliers']], g['fit_inlier_sums'])
+    np.testing.assert_array_equal([len(i) for i in d['inliers']], g['fit_inlier_lens'])
+    np.testing.assert_array_equal(d['num_correspondences_before_ransac'], g['fit_before'])
+    np.testing.assert_array_equal([int(v) for v in d['num_correspondences_after_ransac']], g['fit_after'])
+    np.testing.assert_allclose(d['pred_R'], g['fit_pred_R'], atol=1e-12)
+    np.testing.assert_allclose(d['pred_t'], g['fit_pred_t'], atol=1e-12)
+    assert bool(g['stub_saw_prior'].all())
+    fits = [None if not x['fit_ok'][b] else (x['fit_R'][b], x['fit_t'][b], None) for b in range(B)]
+    o = om.compute_pose_errors(x['T'], fits=fits)
+    np.testing.assert_allclose(np.array([o['R_errs'], o['t_errs'], o['t_errs_abs'], o['successful_fits']]).T, g['fit_errs'], rtol=1e-6, atol=2e-2)
+    np.testing.assert_allclose(np.array([o['R_errs'], o['t_errs'], o['t_errs_abs'], o['successful_fits']]).T, got, rtol=1e-9, atol=1e-5)
+    # (3) nothing to fit on
+    d = {'T_0to1': t(x['T'][:1]), 'K0': t(x['K0'][:1]), 'K1': t(x['K1'][:1])}
+    fm.compute_pose_errors(d, cfg)
+    np.testing.assert_allclose([d['R_errs'][0], d['t_errs'][0], d['t_errs_abs'][0], d['successful_fits'][0]], g['none_errs'], rtol=1e-6, atol=2e-2)
+    # (4) aggregation
+    m = eval_metrics_table()
+    for agg in (fm.aggregate_metrics(dict(m), 5e-4), om.aggregate_metrics(dict(m), 5e-4)):
+        assert list(agg.keys()) == g['agg_keys'].tolist()
+        np.testing.assert_allclose([float(v) for v in agg.values()], g['agg_vals'], rtol=1e-12)
+    pr = fm.epidist_prec(m['epi_errs'], [1e-4, 5e-4, 1e-3], True)
+    assert list(pr.keys()) == g['prec_keys'].tolist()
+    np.testing.assert_allclose(list(pr.values()), g['prec_vals'], rtol=1e-12)
+    np.testing.assert_allclose(list(om.epidist_prec(m['epi_errs'], [1e-4, 5e-4, 1e-3]).values()), g['prec_vals'], rtol=1e-12)

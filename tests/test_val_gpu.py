@@ -1,0 +1,166 @@
+"""The validation step on the GPU: far_amd.pipeline.val_step replays PL_LoFTR.validation_step
+(mp3d_loftr/src/lightning/lightning_loftr.py:266-281 = _trainval_inference(batch) with the matcher in eval mode :129-172,
+then _compute_metrics :227-264) -- depth supervision, matcher, both solver rounds, head, the LOSS, epipolar and pose
+errors -- against the oracle on the same tensors and against goldens G14 / G16 from the reference's own functions."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from far_amd import synth
+from far_amd.config import RunCfg, far_eval_config, far_train_config
+from tests.util import deviation
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+@pytest.fixture(scope='module')
+def model():
+    from far_amd.loftr import LoFTR
+    m = LoFTR(far_eval_config()).eval()
+    synth.load_synthetic(m, seed=0)
+    return m.cuda()
+
+
+def _val_batch(B, seed):
+    """The banded synthetic pairs WITH the scene that explains them: fronto-parallel planes at depth f / d per band seen
+    from two cameras one unit apart along x, so that the reference's depth-based supervision (spvs_coarse) applies."""
+    base = synth.synth_training_batch(B, seed=seed, device='cuda')
+    disp = (8, 40, 72)
+    depth = np.empty((480, 640), np.float32)
+    for k, d in enumerate(disp):
+        r0 = (480 * k) // 3 // 8 * 8
+        r1 = (480 * (k + 1)) // 3 // 8 * 8 if k < 2 else 480
+        depth[r0:r1] = synth.MP3D_K[0, 0] / d
+    dep = torch.from_numpy(depth).cuda()[None].repeat(B, 1, 1)
+    T10 = torch.linalg.inv(base['T_0to1'])
+    batch = {k: base[k] for k in ('image0', 'image1', 'K0', 'K1', 'dataset_name', 'T_0to1')}
+    batch.update(depth0=dep, depth1=dep.clone(), T_1to0=T10, K0=base['K0'].float(), K1=base['K1'].float(),
+                 pair_names=[tuple(f's/a{b}' for b in range(B)), tuple(f's/b{b}' for b in range(B))])
+    return batch, base
+
+
+def test_val_step_matches_oracle_and_reference_contract(model):
+    from far_amd.losses import LoFTRLoss
+    from far_amd.metrics import aggregate_metrics
+    from far_amd.pipeline import val_step
+    from oracle import coarse as oc
+    from oracle import metrics as om
+    B = 2
+    batch, base = _val_batch(B, seed=31)
+    loss_fn = LoFTRLoss(far_train_config()).eval()
+    cfg = RunCfg('prior_ransac', 2)
+    ret = val_step(model, batch, loss_fn, cfg, H=512, seed=0)
+    # the depth supervision reproduces the labels the synthetic scene was built from (cell 0 is never a match, :103)
+    keep = ~((base['spv_i_ids'] == 0))
+    for k in ('spv_b_ids', 'spv_i_ids', 'spv_j_ids'):
+        assert torch.equal(batch[k], base[k][keep]), k
+    # eval-mode matcher: no dense matrix, conf at the ground-truth positions only; predictions unsampled
+    assert batch['conf_matrix'] is None and batch['conf_pos'].shape == batch['spv_b_ids'].shape
+    assert not batch['conf_pos'].requires_grad and len(batch['b_ids']) == len(batch['mconf']) > 1000
+    assert batch['expec_f_gt'].shape == (len(batch['b_ids']), 2)
+    # coarse loss vs the float64 oracle on the same coarse features
+    f0, f1 = batch['featmap0'].cpu().numpy(), batch['featmap1'].cpu().numpy()
+    ref = oc.coarse_matching(f0, f1, far_eval_config()['match_coarse'], (60, 80), (60, 80), (480, 640), dtype=np.float64)
+    sb, si, sj = (batch[k].cpu().numpy() for k in ('spv_b_ids', 'spv_i_ids', 'spv_j_ids'))
+    p = ref['conf_matrix'][sb, si, sj]
+    deviation('val conf_pos', batch['conf_pos'], p, atol=1e-5)
+    pc = np.clip(p, 1e-6, 1 - 1e-6)
+    loss_c = float(np.mean(-0.25 * (1 - pc) ** 2 * np.log(pc)))
+    deviation('val loss_c', ret['loss_scalars']['loss_c'], loss_c, atol=1e-6, rtol=1e-5)
+    assert set(ret['loss_scalars']) >= {'loss', 'loss_c', 'loss_f', 'loss_rot', 'loss_tr', 'num_correspondences_after_ransac'}
+    # fine loss (loftr_loss.py:151-183, eval mode) recomputed from the dict's own tensors in float64
+    e, eg = batch['expec_f'].double().cpu().numpy(), batch['expec_f_gt'].double().cpu().numpy()
+    correct = np.abs(eg).max(1) < 1.0
+    assert correct.sum() > 500                                   # the matcher finds the scene's true matches
+    w = 1.0 / np.clip(e[:, 2], 1e-10, None)
+    w = w / w.mean()
+    loss_f = float((((eg[correct] - e[correct, :2]) ** 2).sum(-1) * w[correct]).mean())
+    deviation('val loss_f', ret['loss_scalars']['loss_f'], loss_f, atol=1e-6, rtol=1e-4)
+    # epipolar errors of every match vs the oracle (float64), per-pair lists as _compute_metrics builds them
+    T = batch['T_0to1'].double().cpu().numpy()
+    K = batch['K0'].double().cpu().numpy()
+    epi = om.compute_symmetrical_epipolar_errors(T, batch['m_bids'].cpu().numpy(), batch['mkpts0_f'].double().cpu().numpy(),
+                                                 batch['mkpts1_f'].double().cpu().numpy(), K, K)
+    deviation('val epi_errs', batch['epi_errs'], epi, atol=1e-9, rtol=2e-4)
+    m = ret['metrics']
+    assert m['identifiers'] == ['s/a0#s/b0', 's/a1#s/b1']
+    assert [len(x) for x in m['epi_errs']] == [int(c) for c in batch['match_counts']]
+    # the scene is a pure translation and the matches are its true matches: most are epipolar-consistent
+    assert np.mean(np.concatenate(m['epi_errs']) < 5e-4) > 0.9
+    # pose errors: 'regressed_rt' is in the dict after the head ran -> the head branch (metrics.py:228-233)
+    o = om.compute_pose_errors(T, regressed_rt=batch['regressed_rt'].cpu().numpy())
+    for k in ('R_errs', 't_errs', 't_errs_abs'):
+        deviation('val ' + k, np.array(m[k]), np.array(o[k]), atol=5e-4, rtol=1e-5)
+    assert m['successful_fits'] == [0, 0] and m['inliers'] == [0, 0]
+    assert m['pred_R'].shape == (1, 3, 3) and m['gt_R'].shape == (B, 3, 3)
+    agg = aggregate_metrics({k: list(v) if isinstance(v, list) else v for k, v in m.items()}, 5e-4)
+    assert agg['dset size'] == B and 0.9 < agg['prec@5e-04'] <= 1.0
+    # without the head's output the same call takes the solver branch: ONE K4 launch for the batch
+    from far_amd.metrics import compute_pose_errors
+    d2 = {k: v for k, v in batch.items() if k != 'regressed_rt'}
+    compute_pose_errors(d2, cfg, H=512, seed=0)
+    assert d2['successful_fits'] == [1, 1] and [len(i) for i in d2['inliers']] == [int(c) for c in batch['match_counts']]
+    assert all(e < 3.0 for e in d2['R_errs']) and all(e < 5.0 for e in d2['t_errs']), (d2['R_errs'], d2['t_errs'])
+    assert d2['num_correspondences_before_ransac'] == [int(c) for c in batch['match_counts']]
+    # drop-in use of a dense-matrix loss: materialize_conf gives data['conf_matrix'] in eval mode, same loss
+    model.coarse_matching.materialize_conf = True
+    try:
+        b2, _ = _val_batch(B, seed=31)
+        r2 = val_step(model, b2, loss_fn, cfg, H=512, seed=0)
+    finally:
+        model.coarse_matching.materialize_conf = False
+    assert b2['conf_matrix'].shape == (B, 4800, 4800) and 'conf_pos' not in b2
+    deviation('val loss_c (dense)', r2['loss_scalars']['loss_c'], float(ret['loss_scalars']['loss_c']), atol=2e-6)
+    deviation('val loss (dense)', r2['loss_scalars']['loss'], ret['loss_scalars']['loss'], atol=1e-5)
+
+
+def test_val_step_refuses_a_depth_supervised_batch_without_labels(model):
+    from far_amd.losses import LoFTRLoss
+    from far_amd.pipeline import val_step
+    batch, _ = _val_batch(1, seed=3)
+    del batch['depth0']
+    with pytest.raises(KeyError, match='depth-supervised'):
+        val_step(model, batch, LoFTRLoss(far_train_config()).eval(), RunCfg('prior_ransac', 2), H=256)
+
+
+def test_spvs_coarse_on_the_device_matches_reference_golden():
+    """Golden G14 (the reference's spvs_coarse / warp_kpts) with every tensor on cuda: identical ids."""
+    from far_amd.supervision import spvs_coarse
+    from tests.util import spvs_scene
+    g = np.load(os.path.join(G, 'g14_spvs_coarse.npz'))
+    d0, d1, T01, T10, K = spvs_scene()
+    N = len(d0)
+    c = lambda a: torch.from_numpy(a).cuda()
+    data = {'image0': torch.zeros(N, 1, 480, 640, device='cuda'), 'image1': torch.zeros(N, 1, 480, 640, device='cuda'),
+            'depth0': c(d0), 'depth1': c(d1), 'T_0to1': c(T01), 'T_1to0': c(T10), 'K0': c(K), 'K1': c(K), 'dataset_name': ['mp3d']}
+    spvs_coarse(data, {'LOFTR': {'RESOLUTION': (8, 2)}})
+    got = np.stack([data[k].cpu().numpy() for k in ('spv_b_ids', 'spv_i_ids', 'spv_j_ids')])
+    ref = np.stack([g['b_ids'], g['i_ids'], g['j_ids']])
+    if got.shape == ref.shape:
+        diff = int((got != ref).any(0).sum())
+    else:
+        diff = len(set(map(tuple, got.T)) ^ set(map(tuple, ref.T)))
+    print(f'[g14 on cuda] {got.shape[1]} matches, {diff} differ from the CPU reference')
+    # GPU and CPU matmul / inverse round differently; a warped point that lands within an ulp of a rounding boundary may flip
+    assert diff <= 2
+    np.testing.assert_allclose(data['spv_w_pt0_i'][:, ::37].cpu().numpy(), g['w_pt0_i_sample'], rtol=1e-5, atol=2e-3)
+
+
+def test_eval_metrics_on_the_device_vs_reference_golden():
+    """Golden G16 (the reference's compute_symmetrical_epipolar_errors / compute_pose_errors) with the tensors on cuda."""
+    from far_amd import metrics as fm
+    from tests.util import eval_batch
+    g = np.load(os.path.join(G, 'g16_eval_metrics.npz'))
+    x = eval_batch()
+    c = lambda a: torch.from_numpy(a).cuda()
+    data = {'T_0to1': c(x['T']), 'K0': c(x['K0']), 'K1': c(x['K1']), 'm_bids': c(x['m_bids']), 'mkpts0_f': c(x['mk0']), 'mkpts1_f': c(x['mk1'])}
+    fm.compute_symmetrical_epipolar_errors(data)
+    assert data['epi_errs'].is_cuda
+    deviation('g16 epi_errs', data['epi_errs'], g['epi_errs'], atol=1e-9, rtol=3e-4)
+    d = {'T_0to1': c(x['T']), 'K0': c(x['K0']), 'K1': c(x['K1']), 'regressed_rt': c(x['regressed_rt'])}
+    fm.compute_pose_errors(d, RunCfg('prior_ransac'))
+    got = np.array([d['R_errs'], d['t_errs'], d['t_errs_abs'], d['successful_fits']]).T
+    deviation('g16 head errs', got, g['head_errs'], atol=2e-3, rtol=1e-5)

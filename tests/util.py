@@ -179,3 +179,47 @@ def loss_inputs(seed=71, N=2, L=48, M=40):
     j_ids = rng.integers(0, L, M)
     return dict(conf=conf, gt=gt, expec_f=expec_f, expec_f_gt=expec_f_gt, expec_rt=expec_rt, T=T, w_pt0=w_pt0, pt1=pt1,
                 b_ids=b_ids, i_ids=i_ids, j_ids=j_ids)
+
+
+def eval_batch(seed=81, B=4, M=60):
+    """Inputs of golden G16 (shared with tools/make_goldens.py): B pairs of synthetic two-view correspondences with ground
+    truth, a head output per pair, committed solver fits (pair 1 fails) and a prior."""
+    rng = np.random.default_rng(seed)
+    T, mk0, mk1, bids, fit_R, fit_t = [], [], [], [], [], []
+    K = None
+    for b in range(B):
+        p0, p1, K, R, t = two_view_scene(M + 7 * b, seed=seed + b, outlier_frac=0.25)
+        Tb = np.eye(4, dtype=np.float32)
+        Tb[:3, :3] = R
+        Tb[:3, 3] = t * rng.uniform(0.5, 2.5)
+        T.append(Tb)
+        mk0.append(p0)
+        mk1.append(p1)
+        bids.append(np.full(len(p0), b, np.int64))
+        _, _, _, Re, te = two_view_scene(8, seed=seed + b + 100 * (b % 2))          # a fit near (even b) / off (odd b) the truth
+        fit_R.append(Re)
+        fit_t.append(te * (1.0 if b % 3 else -1.0))
+    m_bids = np.concatenate(bids)
+    K32 = np.stack([K.astype(np.float32)] * B)
+    regressed = rng.normal(0, 0.6, (B, 9)).astype(np.float32)
+    ang = 0.2
+    prior = np.concatenate([np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]]),
+                            np.array([[0.5], [0.1], [-0.8]])], 1)
+    return dict(T=np.stack(T), K0=K32, K1=K32.copy(), m_bids=m_bids, mk0=np.concatenate(mk0), mk1=np.concatenate(mk1),
+                regressed_rt=regressed, fit_R=np.stack(fit_R), fit_t=np.stack(fit_t), fit_ok=np.array([1, 0, 1, 1]),
+                fit_mask=(rng.uniform(size=len(m_bids)) < 0.6).astype(np.uint8), priorRT=prior)
+
+
+def eval_metrics_table(seed=82, n=23):
+    """A gathered per-pair metrics table as PL_LoFTR.validation_epoch_end hands to aggregate_metrics: two duplicated
+    identifiers (DistributedSampler padding), one pair without matches, failed fits."""
+    rng = np.random.default_rng(seed)
+    ids = [f'scene{i // 5}#im{i}a#im{i}b' for i in range(n)]
+    ids[n - 2], ids[n - 1] = ids[0], ids[3]
+    R = rng.gamma(1.2, 6.0, n)
+    t = rng.gamma(1.5, 9.0, n)
+    R[n - 2] = 0.7          # the duplicate's later entry is the one the de-duplication keeps
+    epi = [rng.gamma(0.6, 6e-4, int(rng.integers(0, 40))) for _ in range(n)]
+    epi[5] = np.zeros(0)
+    return {'identifiers': ids, 'epi_errs': epi, 'R_errs': list(R), 't_errs': list(t), 't_errs_abs': list(rng.gamma(2.0, 0.5, n)),
+            'successful_fits': list((rng.uniform(size=n) < 0.8).astype(np.int64))}

@@ -420,6 +420,64 @@ def g15_losses():
     print('g15:', {k: float(np.ravel(v)[0]) for k, v in out.items()})
 
 
+def g16_eval_metrics():
+    """compute_symmetrical_epipolar_errors (metrics.py:58-77), compute_pose_errors (:198-303; its solver call replaced by
+    a stub that returns committed fits -- cv2 is absent -- so that the reference's BOOKKEEPING runs: successful_fits, the
+    failed-fit convention, the counts, pred_R / pred_t), epidist_prec (:326-337) and aggregate_metrics (:339-377)."""
+    import src.utils.metrics as rm
+    from tests.util import eval_batch, eval_metrics_table
+    x = eval_batch()
+    B = len(x['T'])
+    t = lambda a: torch.from_numpy(a)
+    data = {'T_0to1': t(x['T']), 'K0': t(x['K0']), 'K1': t(x['K1']), 'm_bids': t(x['m_bids']),
+            'mkpts0_f': t(x['mk0']), 'mkpts1_f': t(x['mk1'])}
+    rm.compute_symmetrical_epipolar_errors(data)
+    out = {'epi_errs': data['epi_errs'].numpy()}
+    cfg = ref_shim._AttrDict(TRAINER=ref_shim._AttrDict(RANSAC_PIXEL_THR=0.5, RANSAC_CONF=0.99999),
+                             LOFTR=ref_shim._AttrDict(SOLVER='prior_ransac'), SAVE_PREDS=None)
+    # (1) the head branch, one pair per call as the reference evaluates (batch size 1)
+    errs = []
+    for b in range(B):
+        d = {'T_0to1': t(x['T'][b:b + 1]), 'K0': t(x['K0'][b:b + 1]), 'K1': t(x['K1'][b:b + 1]),
+             'regressed_rt': t(x['regressed_rt'][b:b + 1])}
+        rm.compute_pose_errors(d, cfg)
+        errs.append([d['R_errs'][0], d['t_errs'][0], d['t_errs_abs'][0], d['successful_fits'][0]])
+        last = d
+    out.update(head_errs=np.array(errs, np.float64), head_pred_R=np.asarray(last['pred_R']), head_pred_t=np.asarray(last['pred_t']))
+    # (2) the solver branch with committed fits (pair 1 fails)
+    calls = []
+
+    def stub(k0, k1, K0, K1, thr, conf=None, translation_scale=None, solver=None, priorRT=None):
+        b = len(calls)
+        calls.append((len(k0), solver, None if priorRT is None else np.asarray(priorRT).copy()))
+        if x['fit_ok'][b] == 0:
+            return None, 0, 0, 0
+        mask = x['fit_mask'][x['m_bids'] == b] > 0
+        return (t(x['fit_R'][b]), t(x['fit_t'][b]), mask, t(np.eye(3))), torch.tensor(int(mask.sum())), 0, 0
+    rm.estimate_pose = stub
+    d = dict(data, translation_scale=None, priorRT=x['priorRT'])
+    rm.compute_pose_errors(d, cfg)
+    out.update(fit_errs=np.array([d['R_errs'], d['t_errs'], d['t_errs_abs'], d['successful_fits']], np.float64).T,
+               fit_inlier_sums=np.array([np.asarray(i).sum() for i in d['inliers']], np.float64),
+               fit_inlier_lens=np.array([len(i) for i in d['inliers']]),
+               fit_before=np.array(d['num_correspondences_before_ransac']), fit_after=np.array([int(v) for v in d['num_correspondences_after_ransac']]),
+               fit_pred_R=np.asarray(d['pred_R']), fit_pred_t=np.asarray(d['pred_t']),
+               stub_saw_prior=np.array([c[2] is not None for c in calls]), stub_counts=np.array([c[0] for c in calls]))
+    # (3) no correspondences in the dict at all
+    d = {'T_0to1': t(x['T'][:1]), 'K0': t(x['K0'][:1]), 'K1': t(x['K1'][:1])}
+    np.random.seed(0)
+    rm.compute_pose_errors(d, cfg)
+    out.update(none_errs=np.array([d['R_errs'][0], d['t_errs'][0], d['t_errs_abs'][0], d['successful_fits'][0]], np.float64))
+    # (4) aggregation over a gathered table with DistributedSampler duplicates and a pair without matches
+    m = eval_metrics_table()
+    agg = rm.aggregate_metrics({k: (list(v) if isinstance(v, (list, np.ndarray)) else v) for k, v in m.items()}, 5e-4)
+    out.update(agg_keys=np.array(list(agg.keys())), agg_vals=np.array([float(v) for v in agg.values()], np.float64))
+    pr = rm.epidist_prec(np.array(m['epi_errs'], dtype=object), [1e-4, 5e-4, 1e-3], True)
+    out.update(prec_keys=np.array(list(pr.keys())), prec_vals=np.array([float(v) for v in pr.values()], np.float64))
+    save('g16_eval_metrics', seed=81, **out)
+    print('g16:', dict(zip(out['agg_keys'].tolist(), out['agg_vals'].tolist())))
+
+
 def g8_manifest(m):
     man = {k: list(v.shape) for k, v in m.state_dict().items()}
     with open(os.path.join(OUT, 'g8_state_dict_manifest.json'), 'w') as f:
@@ -438,6 +496,9 @@ if __name__ == '__main__':
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'g11':
         g11_matcher_544x720(ref_model()[0])
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'g16':
+        g16_eval_metrics()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'g15':
         g15_losses()
@@ -467,3 +528,4 @@ if __name__ == '__main__':
     g13_mapfree_corr_volume_warp()
     g14_spvs_coarse()
     g15_losses()
+    g16_eval_metrics()
