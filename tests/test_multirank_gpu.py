@@ -77,7 +77,7 @@ def test_ddp_built_with_device_ids_still_hands_the_results_back():
             batch['loss'].backward()
             g = model.loftr_coarse.layers[0].q_proj.weight.grad
             assert g is not None and torch.isfinite(g).all() and float(g.abs().sum()) > 0
-            losses.append(float(batch['loss']))
+            losses.append(float(batch['loss'].detach()))
             del fwd
         np.testing.assert_allclose(losses[0], losses[1], rtol=1e-6)
     finally:
