@@ -22,6 +22,7 @@ SIGNATURES = {
     'far_abi_version': (c_i, []),
     'far_last_hip_error': (c_i, []),
     'far_set_tuning': (c_i, [c_i, c_i]),
+    'far_mfma_probe_f16': (c_i, [c_i, c_i, c_i, c_p, c_p, c_p]),
     'far_dual_softmax_workspace_bytes': (c_sz, [c_i, c_i, c_i]),
     'far_dual_softmax_stats_f32': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p]),
     'far_coarse_match_f32': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f,

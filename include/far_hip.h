@@ -35,6 +35,14 @@ int far_last_hip_error(void);
  * wave-slot issue-priority staggering (1 k_stats, 2 k_match, 4 k_emm_pv). */
 int far_set_tuning(int key, int value);
 
+/* Measurement aid (no reference counterpart): the f16 matrix-pipe rate this part SUSTAINS under dense
+ * v_mfma_f32_32x32x16_f16 issue with the register / LDS footprint of K9 / K1 / K2 (2 x 4 accumulator tiles per wave,
+ * 4 waves per workgroup, 2 workgroups per CU), pseudo-random operands.  mode 0: operands in registers; mode 1: the six
+ * operand fragments re-read from LDS every step.  Launches rounds x 2 x CU-count workgroups, `iters` steps of 8 MFMAs per
+ * wave; *flops_out (host memory, may be NULL) = flops executed by the launch.  bench.py times it with events and reports
+ * roofline.sustained_peak; `sink` is one device float that is never written. */
+int far_mfma_probe_f16(int mode, int iters, int rounds, float* sink, double* flops_out, far_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * K1  coarse matcher: all-pairs correlation + dual-softmax + mutual-NN selection
  * replaces src/loftr/utils/coarse_matching.py:86-147 (CoarseMatching.forward, dual_softmax branch)
