@@ -9,14 +9,18 @@
 // Launches of one call (all on the caller's stream, workspace from the caller):
 //   k_prep_qk      q, k -> fp16 hi / lo planes, scaled by 2^4 (exact), written in the LDS image (16-byte slots
 //                  XOR-swizzled per row) so that a 64-row tile is one linear LDS-DMA copy
-//   k_rowstats x2  log2-domain softmax statistics (max, sum 2^(x - max)) of every row of s: once with (q, k) for the
-//                  softmax over keys, once with (k, q) for the softmax over queries -- no cross-lane reductions:
-//                  in the transposed score tile D[m = column][n = row] a lane owns one row
+//   k_rowstats     log2-domain softmax statistics (max, sum 2^(x - max)) of every COLUMN of s (the softmax over queries):
+//                  run with (k, q), so that in the transposed score tile D[m = column][n = row] a lane owns one key --
+//                  no cross-lane reductions.  (Round 2 ran it a second time with (q, k) for the softmax over keys;
+//                  those statistics are now formed online inside k_pv: one score pass of three became two.)
 //   k_prep_v       [v | pos] / colsum, transposed to [96 columns][keys] fp16 hi / lo tiles in LDS-image order, keys
-//                  permuted inside each group of 32 into the k-order in which the accumulator registers hold P
-//   k_pv           per 128 queries: for every 64-key tile  scores (24 MFMAs) -> p = 2^(2 x - rowmax - colmax + 15)
-//                  (ONE exp per score; 1 / rowsum, 1 / colsum and the 2^-15 are folded into the output scale and into
-//                  v~) -> fp16 hi / lo straight from the accumulator registers -> T += P v~ (36 MFMAs)
+//                  permuted inside each group of 32 into the k-order in which the accumulator registers hold P; the
+//                  column reference C_j = ceil(colmax_j) as an integer, colsum rescaled to it
+//   k_pv           per 128 queries: for every 64-key tile  scores (24 MFMAs) -> running integer row reference
+//                  R_i = ceil(running row max) (a change rescales the accumulators by an exact power of two) ->
+//                  e = 2^(x - R_i) (ONE exp per score), rowsum += e, p = e * ldexp(e, R_i - C_j + 15)
+//                  = 2^(2 x - R_i - C_j + 15) <= 2^15 -> fp16 hi / lo straight from the accumulator registers ->
+//                  T += P v~ (36 MFMAs); 1 / rowsum, 1 / colsum and the 2^-15 are folded into the output scale and v~
 #include "common.h"
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -35,6 +39,8 @@ constexpr int KT = 64;           // keys per tile
 constexpr float QK_PRESCALE = 16.0f;     // q, k scaled by 2^4 before the split (their fp16 lo parts stay normal)
 constexpr float V_PRESCALE = 64.0f;      // v~ / colsum scaled by 2^6; p by 2^15 (it is <= 1)
 constexpr float NEG_HUGE = -1.0e30f;
+constexpr int PAD_REF = 1 << 24;         // column reference of a padded key: p = ldexp(e, R - PAD_REF + 15) = 0
+constexpr int ROW_REF0 = -(1 << 24);     // row reference before the first tile
 
 // Where problem z = p * heads + hh of a [Z][N][64] operand lives: base + hh * head_stride + ((p + rot) % P) * prob_stride
 // (floats; P = Z / heads).  Contiguous [Z][N][64]: heads = 1, prob_stride = N * 64.  The head's fused q | k | v
@@ -267,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void k_rowstats(const _Float16* __restrict_
 __global__ __launch_bounds__(256) void k_prep_v(const float* __restrict__ v, ZLayout lay, const float* __restrict__ pos,
                                                const float2* __restrict__ colstat, int Z, int N, int Np,
                                                _Float16* __restrict__ oh, _Float16* __restrict__ ol,
-                                               float* __restrict__ cmax) {
+                                               int* __restrict__ cref) {
     __shared__ float tile[KT][DV + 3];
     const int ntile = Np / KT;
     const int z = blockIdx.x / ntile, jt = blockIdx.x - z * ntile;
@@ -278,13 +284,16 @@ __global__ __launch_bounds__(256) void k_prep_v(const float* __restrict__ v, ZLa
         float x = 0.f;
         if (j < N) {
             x = c < D ? v[lay.base(z) + (size_t)j * D + c] : pos[(size_t)j * 6 + (c - D)];
-            x = x / colstat[(size_t)z * N + j].y * V_PRESCALE;
+            // the column's statistics re-based from its maximum m to the integer reference C = ceil(m):
+            // sum 2^(x - C) = colsum 2^(m - C)
+            const float2 cs = colstat[(size_t)z * N + j];
+            x = x / (cs.y * __builtin_amdgcn_exp2f(cs.x - ceilf(cs.x))) * V_PRESCALE;
         }
         tile[r][c] = x;
     }
-    if (tid < KT) {                                      // dense column maxima; keys past N get +huge -> p = 0
+    if (tid < KT) {                                      // integer column references; keys past N get +huge -> p = 0
         const int j = jt * KT + tid;
-        cmax[(size_t)z * Np + j] = j < N ? colstat[(size_t)z * N + j].x : -NEG_HUGE;
+        cref[(size_t)z * Np + j] = j < N ? (int)ceilf(fminf(fmaxf(colstat[(size_t)z * N + j].x, -1.0e6f), 1.0e6f)) : PAD_REF;
     }
     __syncthreads();
     const size_t base = ((size_t)z * ntile + jt) * DVP * KT;
@@ -306,13 +315,32 @@ __global__ __launch_bounds__(256) void k_prep_v(const float* __restrict__ v, ZLa
     }
 }
 
-// ---- k_pv: T[z][i][:] = (2^-15 / rowsum_i) * sum_j 2^(2 x_ij - rowmax_i - colmax_j + 15) * (v~_j / colsum_j)
+// ---- k_pv: T[z][i][:] = (2^-15 / rowsum_i) * sum_j 2^(2 x_ij - R_i - C_j + 15) * (v~_j / colsum_j),  rowsum_i = sum_j 2^(x_ij - R_i)
+// with the row statistics formed ONLINE: R_i = ceil(max_j x_ij) over the keys seen so far, an integer, so that a change of
+// reference rescales the running sum and the T accumulators by an exact power of two (v_ldexp), and so that the one
+// exponential per score e = 2^(x - R_i) serves both softmaxes: the row sum takes e, the product takes
+// p = e * ldexp(e, R_i - C_j + 15) (x <= R_i and x <= C_j: p <= 2^15, e <= 1; padded keys have C_j = 2^24: p = 0).
+// Both half-waves hold keys of the same 32 rows and feed ONE accumulator through the MFMA's k dimension, so they agree on
+// R_i (one cross-half exchange per tile).  Writes rowstat[z][i] = (R_i, rowsum_i) for the backward kernels.
 constexpr int VT_PLANE = DVP * 128;     // one v~^T tile plane: 96 rows x 64 keys fp16
+template <bool MASKED>
+__device__ __forceinline__ float tile_rowmax(const f32x16 (&acc)[2], float c1, int j0, int N, int h) {
+    float tm = NEG_HUGE;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool pad = MASKED && j0 + 32 * ct + mfma32_row(r, h) >= N;
+            tm = fmaxf(tm, pad ? NEG_HUGE : acc[ct][r]);
+        }
+    return tm * c1;                       // c1 > 0
+}
+
 __global__ __launch_bounds__(256, 2) void k_pv(const _Float16* __restrict__ qh, const _Float16* __restrict__ ql,
                                                const _Float16* __restrict__ kh, const _Float16* __restrict__ kl,
                                                const _Float16* __restrict__ vh, const _Float16* __restrict__ vl,
-                                               const float2* __restrict__ rowstat, const float* __restrict__ cmax,
-                                               int Z, int N, int Np, float c1, float* __restrict__ T) {
+                                               const int* __restrict__ cref, int Z, int N, int Np, float c1,
+                                               float2* __restrict__ rowstat, float* __restrict__ T) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * CT_PLANE + 2 * VT_PLANE];
     unsigned char* const ldv = lds + 2 * CT_PLANE;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
@@ -322,15 +350,14 @@ __global__ __launch_bounds__(256, 2) void k_pv(const _Float16* __restrict__ qh, 
     const int irow = i0 + l31;
     RowFrags rf;
     rf.load(qh, ql, (size_t)z * Np + irow, irow, h);
-    const float2 rst = irow < N ? rowstat[(size_t)z * N + irow] : make_float2(0.f, 1.f);
-    const float c2 = 2.0f * c1;
-    const float rterm = 15.0f - rst.x;
 
     f32x16 tacc[3];
 #pragma unroll
     for (int bt = 0; bt < 3; ++bt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) tacc[bt][r] = 0.f;
+    int R = ROW_REF0;                      // integer row reference, equal in lanes l and l + 32
+    float sum = 0.f, comp = 0.f;           // this half-wave's share of rowsum (Kahan-compensated per tile)
 
     const int ntile = Np / KT;
     const unsigned char* vsrc_h = reinterpret_cast<const unsigned char*>(vh + (size_t)z * ntile * DVP * KT) + tid * 16;
@@ -343,13 +370,13 @@ __global__ __launch_bounds__(256, 2) void k_pv(const _Float16* __restrict__ qh, 
             __builtin_amdgcn_global_load_lds((gptr_t)(vsrc_h + (size_t)jt * VT_PLANE + j * 4096), (lptr_t)(ldv + j * 4096 + wave * 1024), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gptr_t)(vsrc_l + (size_t)jt * VT_PLANE + j * 4096), (lptr_t)(ldv + VT_PLANE + j * 4096 + wave * 1024), 16, 0, 0);
         }
-        // column maxima of this lane's keys: j = jt*64 + 32 ct + 8 q + 4 h + (0..3)
-        float cm[2][16];
+        // column references of this lane's keys: j = jt*64 + 32 ct + 8 q + 4 h + (0..3)
+        int cm[2][16];
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
-                const float4 c = *reinterpret_cast<const float4*>(cmax + (size_t)z * Np + jt * KT + 32 * ct + 8 * q4 + 4 * h);
+                const int4 c = *reinterpret_cast<const int4*>(cref + (size_t)z * Np + jt * KT + 32 * ct + 8 * q4 + 4 * h);
                 cm[ct][4 * q4 + 0] = c.x; cm[ct][4 * q4 + 1] = c.y; cm[ct][4 * q4 + 2] = c.z; cm[ct][4 * q4 + 3] = c.w;
             }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -357,6 +384,28 @@ __global__ __launch_bounds__(256, 2) void k_pv(const _Float16* __restrict__ qh, 
 
         f32x16 acc[2];
         score_tile(acc, lds, rf, l31, h);
+        // ---- row reference: ceil of the running maximum, agreed between the two half-waves
+        const bool ragged = (jt + 1) * KT > N;                                   // wave-uniform
+        const float tm = ragged ? tile_rowmax<true>(acc, c1, jt * KT, N, h) : tile_rowmax<false>(acc, c1, jt * KT, N, h);
+        int Rn = (int)ceilf(fminf(fmaxf(tm, -1.0e6f), 1.0e6f));
+        Rn = Rn > R ? Rn : R;
+        const int Ro = __shfl_xor(Rn, 32, 64);
+        Rn = Rn > Ro ? Rn : Ro;
+        if (__any(Rn != R)) {                                                    // rare after the first tiles
+            int d = R - Rn;                                                      // <= 0
+            d = d < -200 ? -200 : d;                                             // 2^-200 flushes every fp32 to zero already
+            sum = ldexpf(sum, d);
+            comp = ldexpf(comp, d);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {                                       // accumulator register r holds row mfma32_row(r, h)
+                const int dr = __shfl(d, mfma32_row(r, h), 64);
+#pragma unroll
+                for (int bt = 0; bt < 3; ++bt) tacc[bt][r] = ldexpf(tacc[bt][r], dr);
+            }
+            R = Rn;
+        }
+        const float nR = -(float)R;
+        f32x2 t2 = {0.f, 0.f};
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
 #pragma unroll
@@ -364,12 +413,22 @@ __global__ __launch_bounds__(256, 2) void k_pv(const _Float16* __restrict__ qh, 
                 // p for this lane's 8 keys of MFMA (ct, u): accumulator registers 8 u .. 8 u + 7
                 f16x8 ph, pl;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
+                for (int e = 0; e < 8; e += 2) {
                     const int r = 8 * u + e;
-                    const float pe = __builtin_amdgcn_exp2f(fmaf(acc[ct][r], c2, rterm) - cm[ct][r]);
+                    float e0 = __builtin_amdgcn_exp2f(fmaf(acc[ct][r], c1, nR));
+                    float e1 = __builtin_amdgcn_exp2f(fmaf(acc[ct][r + 1], c1, nR));
+                    if (ragged) {                                                // zero-padded keys score 0, not -inf
+                        if (jt * KT + 32 * ct + mfma32_row(r, h) >= N) e0 = 0.f;
+                        if (jt * KT + 32 * ct + mfma32_row(r + 1, h) >= N) e1 = 0.f;
+                    }
+                    t2 += f32x2{e0, e1};
+                    const float p0 = e0 * ldexpf(e0, R - cm[ct][r] + 15);
+                    const float p1 = e1 * ldexpf(e1, R - cm[ct][r + 1] + 15);
                     _Float16 hh, ll;
-                    split1(pe, hh, ll);
+                    split1(p0, hh, ll);
                     ph[e] = hh; pl[e] = ll;
+                    split1(p1, hh, ll);
+                    ph[e + 1] = hh; pl[e + 1] = ll;
                 }
                 const int slot = 4 * ct + 2 * u + h;
 #pragma unroll
@@ -384,9 +443,17 @@ __global__ __launch_bounds__(256, 2) void k_pv(const _Float16* __restrict__ qh, 
                 }
             }
         }
+        // the tile's 32 terms summed on their own, then added with Kahan compensation (see rowstat_update)
+        const float y = (t2.x + t2.y) - comp;
+        const float ns = sum + y;
+        comp = (ns - sum) - y;
+        sum = ns;
     }
+    sum -= comp;
+    const float rsum = sum + shfl_xor_f(sum, 32);          // both halves carry the same reference R
+    if (h == 0 && irow < N) rowstat[(size_t)z * N + irow] = make_float2((float)R, rsum);
     // ---- store: lane holds column b = 32 bt + l31 of rows i0 + mfma32_row(r, h); the row scale comes from lane (row)
-    const float oscale = (3.0517578125e-05f / V_PRESCALE) / rst.y;      // 2^-15 2^-6 / rowsum of this lane's row (= l31)
+    const float oscale = (3.0517578125e-05f / V_PRESCALE) / rsum;       // 2^-15 2^-6 / rowsum of this lane's row (= l31)
 #pragma unroll
     for (int bt = 0; bt < 3; ++bt) {
         const int b = 32 * bt + l31;
@@ -404,7 +471,7 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 struct EmmWs {
     _Float16 *qh, *ql, *kh, *kl, *vh, *vl;
     float2 *rowstat, *colstat;
-    float* cmax;
+    int* cref;
     size_t bytes;
 };
 inline EmmWs carve(void* base, int Z, int N) {
@@ -417,7 +484,7 @@ inline EmmWs carve(void* base, int Z, int N) {
     w.qh = (_Float16*)take(qk); w.ql = (_Float16*)take(qk); w.kh = (_Float16*)take(qk); w.kl = (_Float16*)take(qk);
     w.vh = (_Float16*)take(vt); w.vl = (_Float16*)take(vt);
     w.rowstat = (float2*)take(st); w.colstat = (float2*)take(st);
-    w.cmax = (float*)take((size_t)Z * Np * 4);
+    w.cref = (int*)take((size_t)Z * Np * 4);
     w.bytes = o;
     return w;
 }
@@ -452,18 +519,18 @@ int far_emm_pv_f16s(const float* q, const float* k, const float* v, const float*
     hipLaunchKernelGGL(k_prep_qk, dim3(gprep), dim3(256), 0, stream, q, layq, Z, N, Np, w.qh, w.ql);
     hipLaunchKernelGGL(k_prep_qk, dim3(gprep), dim3(256), 0, stream, k, lay, Z, N, Np, w.kh, w.kl);
     const dim3 grid((unsigned)(Np / 128) * Z);
-    // softmax over keys (rows = queries), then over queries (rows = keys): the same kernel with the sides swapped
+    // softmax over queries (rows of the statistics kernel = keys); the softmax over keys is formed online inside k_pv
     const dim3 gstat((unsigned)(Np / 128) * Z);
-    hipLaunchKernelGGL(k_rowstats, gstat, dim3(256), 0, stream, w.qh, w.ql, w.kh, w.kl, Z, N, Np, c1, w.rowstat);
     hipLaunchKernelGGL(k_rowstats, gstat, dim3(256), 0, stream, w.kh, w.kl, w.qh, w.ql, Z, N, Np, c1, w.colstat);
-    hipLaunchKernelGGL(k_prep_v, dim3((unsigned)(Np / KT) * Z), dim3(256), 0, stream, v, lay, pos, w.colstat, Z, N, Np, w.vh, w.vl, w.cmax);
-    hipLaunchKernelGGL(k_pv, grid, dim3(256), 0, stream, w.qh, w.ql, w.kh, w.kl, w.vh, w.vl, w.rowstat, w.cmax, Z, N,
-                       Np, c1, T_out);
+    hipLaunchKernelGGL(k_prep_v, dim3((unsigned)(Np / KT) * Z), dim3(256), 0, stream, v, lay, pos, w.colstat, Z, N, Np, w.vh, w.vl, w.cref);
+    hipLaunchKernelGGL(k_pv, grid, dim3(256), 0, stream, w.qh, w.ql, w.kh, w.kl, w.vh, w.vl, w.cref, Z, N, Np, c1,
+                       w.rowstat, T_out);
     return far_check_launch();
 }
 
 // The softmax statistics far_emm_pv_f16s left in its workspace, for the backward kernels (emm_bilinear_bwd_f16.hip):
-// rowstat[z][i] = (max, sum) over keys of query row i, colstat[z][j] over queries of key column j (log2 domain).
+// rowstat[z][i] = (ref, sum 2^(x - ref)) over keys of query row i with ref = ceil(max) (any reference >= the maximum
+// gives the same softmax), colstat[z][j] = (max, sum) over queries of key column j (log2 domain).
 int far_emm_pv_f16s_copy_stats(const void* ws, int Z, int N, float* rowstat_out, float* colstat_out, hipStream_t stream) {
     far_clear_errors();
     if (!ws || !rowstat_out || !colstat_out || Z <= 0 || N <= 0) return FAR_EINVAL;
