@@ -116,7 +116,7 @@ def kernel_rooflines(n_pairs):
 
     def writer(stages):
         rc = lib_.far_conf_matrix_f16s(f0.data_ptr(), f1.data_ptr(), n_pairs, L, S, C, _ct.c_float(0.1), None, None, stages,
-                                       conf_.data_ptr(), info_.data_ptr(), ws_.data_ptr(), st_)
+                                       conf_.data_ptr(), info_.data_ptr(), ws_.data_ptr(), None, st_)
         assert rc == 0, rc
     writer(1)
     tw = event_time_ms(lambda: writer(2), iters=5, warm=2)
@@ -144,7 +144,7 @@ def kernel_rooflines(n_pairs):
 
     def pv16():
         lib.far_emm_pv_f16s(q.data_ptr(), k.data_ptr(), v.data_ptr(), pos.data_ptr(), Z, L, 64, ctypes.c_float(0.125),
-                            1, 0, L * 64, 0, ws.data_ptr(), T.data_ptr(), st)
+                            1, 0, L * 64, 0, ws.data_ptr(), T.data_ptr(), None, st)
     t5 = event_time_ms(pv16, iters=3, warm=1)
     out['far_emm_pv_f16s[K2 all passes, split-fp16]'] = dict(ms=t5, tflops=fl4 / t5 / 1e9, frac=fl4 / t5 / 1e9 / F16_MFMA_PEAK_TFLOPS)
     del ws

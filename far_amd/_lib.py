@@ -32,10 +32,10 @@ SIGNATURES = {
                                     c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     'far_coarse_match_f16s_workspace_bytes': (c_sz, [c_i, c_i, c_i, c_i]),
     'far_coarse_match_f16s': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f,
-                                    c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
-    'far_conf_matrix_f16s': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_i, c_p, c_p, c_p, c_p]),
+                                    c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    'far_conf_matrix_f16s': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p]),
     'far_coarse_train_workspace_bytes': (c_sz, [c_i, c_i, c_i, c_i]),
-    'far_coarse_pos_conf_f16s': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_i, c_p, c_p, c_p]),
+    'far_coarse_pos_conf_f16s': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p]),
     'far_coarse_pos_conf_bwd_f16': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p]),
     'far_emm_pv_f32': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_p]),
     'far_fine_gather_f32': (c_i, [c_p, c_l, c_l, c_l, c_l, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
@@ -46,16 +46,16 @@ SIGNATURES = {
     'far_linear_attention_bwd_f32': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p]),
     'far_layernorm_f32': (c_i, [c_p, c_p, c_p, c_p, c_l, c_i, c_f, c_p, c_p]),
     'far_attn_block_packed_bytes': (c_sz, [c_i]),
-    'far_attn_block_f16s': (c_i, [c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_f, c_p, c_p]),
+    'far_attn_block_f16s': (c_i, [c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_f, c_p, c_p, c_p]),
     'far_mlp_fused_packed_bytes': (c_sz, [c_i]),
-    'far_mlp_fused_f16s': (c_i, [c_p, c_p, c_p, c_l, c_i, c_f, c_f, c_p, c_p, c_f, c_p, c_p]),
+    'far_mlp_fused_f16s': (c_i, [c_p, c_p, c_p, c_l, c_i, c_f, c_f, c_p, c_p, c_f, c_p, c_p, c_p]),
     'far_affine_act_f32': (c_i, [c_p, c_p, c_p, c_p, c_l, c_i, c_l, c_i, c_i, c_f, c_p, c_p]),
     'far_upsample2x_add_f32': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     'far_conv_packed_bytes': (c_sz, [c_i, c_i, c_i, c_i, c_i]),
     'far_conv_pack_f32': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     'far_conv_nhwc_f32': (c_i, [c_p, c_p]),                  # (const far_conv_desc*, stream): see ConvDesc
     'far_emm_pv_f16s_workspace_bytes': (c_sz, [c_i, c_i]),
-    'far_emm_pv_f16s': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_i, c_l, c_l, c_i, c_p, c_p, c_p]),
+    'far_emm_pv_f16s': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_i, c_l, c_l, c_i, c_p, c_p, c_p, c_p]),
     'far_emm_pv_f16s_copy_stats': (c_i, [c_p, c_i, c_i, c_p, c_p, c_p]),
     'far_emm_bwd_workspace_bytes': (c_sz, [c_i, c_i]),
     'far_emm_bwd_f16': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_p, c_p, c_p, c_p]),
@@ -78,7 +78,7 @@ class ConvDesc(ctypes.Structure):
                [('N', ctypes.c_long)] + \
                [(n, ctypes.c_int) for n in ('H', 'W', 'Cin', 'Cin1', 'Cout', 'ksize', 'stride', 'act', 'split',
                                             'out_planes', 'res_group')] + \
-               [('slope', ctypes.c_float), ('ln_eps', ctypes.c_float)]
+               [('slope', ctypes.c_float), ('ln_eps', ctypes.c_float), ('act_exp', ctypes.c_int), ('overflow', ctypes.c_void_p)]
 
 
 _lib = None

@@ -83,7 +83,7 @@ struct Scales { float k, v, q, m; };     // accumulator -> value: 2^-(w_exp + 4)
 __global__ __launch_bounds__(256, 2) void k_attn128(const float* __restrict__ x, const float* __restrict__ src,
                                                     const unsigned char* __restrict__ wimg, long nwin, int L, int S, Scales sc,
                                                     float attn_eps, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                    float ln_eps, float* __restrict__ out) {
+                                                    float ln_eps, float* __restrict__ out, int* __restrict__ overflow) {
     __shared__ __attribute__((aligned(16))) unsigned char ring[RING * SLAB];
     __shared__ __attribute__((aligned(16))) unsigned char xs[WAVES * 4096];
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
@@ -295,6 +295,17 @@ __global__ __launch_bounds__(256, 2) void k_attn128(const float* __restrict__ x,
         }
     }
 
+    // Activation-range guard (as K9).  The operands of this kernel's chained products are 2^4-scaled activations AND their
+    // products (K'^T V, then KV Q'): the fp16 split overflows when |x| > 4094, or when a head's sum_s K'_s V_s / S or a
+    // message entry exceeds 4094 -- tighter than K9's per-activation bound.  Any such inf reaches `mg` as inf / NaN.
+    if (overflow) {
+        float chk = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) chk += mg[ct][r];
+        if (__any(!(fabsf(chk) <= FLT_MAX)) && (threadIdx.x & 63) == 0) atomicOr(overflow, 1);
+    }
     // ------------------------------------------------------------------ norm1 over the 128 channels of a token, store
     const float inv_c = 1.0f / (float)DM;
     float g[CT], b[CT];
@@ -330,7 +341,7 @@ size_t far_attn_block_packed_bytes(int d_model) { return d_model == DM ? (size_t
 // packed: the image far_amd/ops.py:PackedAttn builds; scale_* = 2^-(w_exp + 4) of Wk, Wv, Wq, Wm; out must not alias x / src.
 int far_attn_block_f16s(const float* x, const float* src, const void* packed, long nwin, int L, int S, int d_model, int heads,
                         float scale_k, float scale_v, float scale_q, float scale_m, float attn_eps, const float* gamma,
-                        const float* beta, float ln_eps, float* out, hipStream_t stream) {
+                        const float* beta, float ln_eps, float* out, int* overflow, hipStream_t stream) {
     far_clear_errors();
     if (nwin == 0) return FAR_OK;
     if (!x || !src || !packed || !gamma || !beta || !out || nwin < 0 || L <= 0 || S <= 0 || L > 32 || S > 32 ||
@@ -340,7 +351,7 @@ int far_attn_block_f16s(const float* x, const float* src, const void* packed, lo
     if (nb > 0x7fffffffL) return FAR_EINVAL;
     const Scales sc{scale_k, scale_v, scale_q, scale_m};
     hipLaunchKernelGGL(k_attn128, dim3((unsigned)nb), dim3(64 * WAVES), 0, stream, x, src, (const unsigned char*)packed, nwin, L, S,
-                       sc, attn_eps, gamma, beta, ln_eps, out);
+                       sc, attn_eps, gamma, beta, ln_eps, out, overflow);
     return far_check_launch();
 }
 

@@ -56,7 +56,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 constexpr int TW = 16;                  // output tile columns of the 3x3 kernels (rows: 4 per pixel-wave)
 constexpr int A_PXB = 80;               // LDS bytes per staged pixel per plane: 32 fp16 channels + 16 B pad
-constexpr float ACT_SCALE = 16.0f;      // activations are scaled by 2^4 before the split (see far_conv_nhwc_f32)
+constexpr int ACT_EXP_DEFAULT = 4;      // activations are scaled by 2^act_exp before the split (see far_conv_nhwc_f32)
 
 // LDS image of the staged input pixels of one 32-channel chunk.  3x3: the (TH+2) x (16+2) halo, row stride rounded
 // up to a multiple of 256 B so that, with the odd 5-slot pixel stride, every 16-lane group of a ds_read_b128
@@ -93,13 +93,16 @@ struct ConvArgs {
     int Csub;                    // output channels per output plane (Cout: one NHWC tensor)
     int H, W, Ho, Wo, Cin, Cout, tilesX, tilesY, nchunks, nblkY, act;   // input H x W, output Ho x Wo
     float slope;
+    float act_scale;             // 2^act_exp: activations are multiplied by it before the fp16 split (default 2^4)
+    float out_mul;               // 2^(4 - act_exp): `scale` folds 2^-4, this corrects it for the scale actually used
+    int* overflow;               // device flag, |= 1 when an accumulator of this launch is not finite (may be null)
 };
 
-__device__ __forceinline__ void split8(const float4& u, const float4& v, f16x8& hi, f16x8& lo) {
+__device__ __forceinline__ void split8(const float4& u, const float4& v, float act_scale, f16x8& hi, f16x8& lo) {
     const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const float s = x[i] * ACT_SCALE;
+        const float s = x[i] * act_scale;
         const _Float16 hh = (_Float16)s;
         hi[i] = hh;
         lo[i] = (_Float16)(s - (float)hh);
@@ -162,7 +165,7 @@ __device__ __forceinline__ void stage_arrived(Stage<ITERS>& st) {
 }
 
 template <int KS, int MW, int ST, int NTHR, int ITERS, bool SPLIT>
-__device__ __forceinline__ void stage_store(const Stage<ITERS>& st, unsigned char* As, int tid) {
+__device__ __forceinline__ void stage_store(const Stage<ITERS>& st, unsigned char* As, int tid, float act_scale) {
     using G = Geo<KS, MW, ST>;
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
@@ -174,7 +177,7 @@ __device__ __forceinline__ void stage_store(const Stage<ITERS>& st, unsigned cha
             if (KS == 1) off = hp * A_PXB;
             else { const int hy = hp / G::HW; off = G::px_off(hy, hp - hy * G::HW); }
             f16x8 hi, lo;
-            split8(u, w, hi, lo);
+            split8(u, w, act_scale, hi, lo);
             *reinterpret_cast<f16x8*>(As + off + g * 16) = hi;
             if (SPLIT) *reinterpret_cast<f16x8*>(As + G::A_PLANE + off + g * 16) = lo;
         }
@@ -221,7 +224,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const f32x16 (&
         for (int nt = 0; nt < NTW; ++nt) {
             const int co = cout_w + 32 * nt + l31;
             if (co >= p.Cout) continue;
-            const float sc = p.scale[co], sh = p.shift ? p.shift[co] : 0.f;
+            const float sc = p.scale[co] * p.out_mul, sh = p.shift ? p.shift[co] : 0.f;
             const int plane = co / p.Csub;
             const long base = (long)plane * p.npix * p.Csub + pix0 * p.Csub + (co - plane * p.Csub);
             float rv[16];
@@ -288,7 +291,7 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvArgs& p, const f32x
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
         const int co = cout_w + 32 * nt + l31;
-        sc[nt] = co < p.Cout ? p.scale[co] : 0.f;
+        sc[nt] = co < p.Cout ? p.scale[co] * p.out_mul : 0.f;
         sh[nt] = (co < p.Cout && p.shift) ? p.shift[co] : 0.f;
     }
     const int co4 = cout_w + 4 * l31;                      // this lane's 4 channels in the store phase
@@ -602,7 +605,7 @@ __global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const 
     stage_load<KS, MW, ST, NTHR, ITERS>(st, p, tp, 0, tid);
     prefetch();
     prefetch();
-    stage_store<KS, MW, ST, NTHR, ITERS, SPLIT>(st, As, tid);
+    stage_store<KS, MW, ST, NTHR, ITERS, SPLIT>(st, As, tid, p.act_scale);
     FAR_K9_STAMP(1);
 
     // Fragment registers.  The pixel (A) fragments of a phase are read during the previous phase; the weight (B)
@@ -711,12 +714,26 @@ __global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const 
         stage_arrived(st);
         if (chunk + 1 < nchunks) {
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done with this chunk's pixels
-            stage_store<KS, MW, ST, NTHR, ITERS, SPLIT>(st, As, tid);
+            stage_store<KS, MW, ST, NTHR, ITERS, SPLIT>(st, As, tid, p.act_scale);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the trailing (unused) slab requests must land before LDS is reused
     FAR_K9_STAMP(2);
 
+    // Activation-range guard: an input beyond the fp16 range of the split (|a| 2^act_exp > 65504) becomes inf and reaches
+    // the accumulators as inf / NaN.  The sum of a wave's accumulators is not finite exactly then (finite accumulators
+    // cannot overflow it: they are sums of products of fp16 numbers); one atomic per wave that saw it, none otherwise.
+    if (p.overflow) {
+        float chk = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) chk += acc[mt][nt][r];
+        const bool bad = !(fabsf(chk) <= FLT_MAX);
+        if (__any(bad) && lane == 0) atomicOr(p.overflow, 1);
+    }
     if (NTW == 4 && ((p.Cout | p.Csub) & 3) == 0) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave is past its last LDS fragment read
         conv_epilogue_wide<KS, NW, UP>(p, acc, tp, cout_w, wm, wave, lane, reinterpret_cast<float*>(smem) + wave * (32 * 128),
@@ -832,7 +849,11 @@ int far_conv_pack_f32(const float* w, int Cin, int Cout, int ksize, int stride, 
 // X = x [N][H][W][Cin1] (+ x2 [N][H][W][Cin - Cin1]: the input is their channel concatenation, never materialised;
 // x2 = NULL and Cin1 = Cin for a single input); res / y [N][Ho][Wo][Cout] with Ho = (H - 1) / s + 1 (zero padding
 // p = ksize / 2), all fp32 NHWC contiguous; stride s = 1, or 2 for ksize 3; Cin % 4 == 0, Cin1 % 8 == 0.
-// `scale` must include 2^-(w_exp + 4).  act: 0 none, 1 ReLU, 2 LeakyReLU(slope).  A linear layer is ksize = 1 with
+// `scale` must include 2^-(w_exp + 4).  act_exp: the activations are multiplied by 2^act_exp before the fp16 split
+// (4 = the default; the kernel corrects `scale` by 2^(4 - act_exp)): inputs up to 65504 / 2^act_exp survive the split, and
+// act_exp can be lowered (down to -24) for tensors beyond 4094 at the price of the absolute resolution of tiny values
+// (2^-24 2^-act_exp).  overflow: device int, OR-ed with 1 when the launch produced a non-finite accumulator (an input beyond
+// that range), NULL to skip the test.  act: 0 none, 1 ReLU, 2 LeakyReLU(slope).  A linear layer is ksize = 1 with
 // N = H = 1, W = rows.  out_planes > 1: output channel co goes to plane co / (Cout / out_planes) of y, laid out
 // [out_planes][N][Ho][Wo][Cout / out_planes] (fused projections, e.g. q | k | v); res, if given, has y's layout, or
 // with res_group = G > 1 (linear layers) is [rows / G][Cout]: every group of G consecutive rows shares one residual
@@ -854,6 +875,8 @@ struct far_conv_desc {          // mirrors include/far_hip.h
     int H, W, Cin, Cin1, Cout, ksize, stride;
     int act, split, out_planes, res_group;
     float slope, ln_eps;
+    int act_exp;
+    int* overflow;
 };
 
 int far_conv_nhwc_f32(const far_conv_desc* desc, hipStream_t stream) {
@@ -868,6 +891,7 @@ int far_conv_nhwc_f32(const far_conv_desc* desc, hipStream_t stream) {
     const int act = d.act, split = d.split, out_planes = d.out_planes, res_group = d.res_group;
     const float slope = d.slope, ln_eps = d.ln_eps;
     far_clear_errors();
+    if (d.act_exp < -24 || d.act_exp > 8) return FAR_EINVAL;
     if (N == 0) return FAR_OK;
     if (!x || !packed || !scale || !y || N < 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) || Cout <= 0 ||
         (ksize != 1 && ksize != 3) || stride < 1 || stride > 2 || (stride == 2 && ksize != 3) || act < 0 || act > 2 ||
@@ -894,6 +918,7 @@ int far_conv_nhwc_f32(const far_conv_desc* desc, hipStream_t stream) {
     a.nchunks = (Cin + 31) / 32;
     a.nblkY = (Cout + c.nt - 1) / c.nt;
     a.act = act; a.slope = slope;
+    a.act_scale = ldexpf(1.0f, d.act_exp); a.out_mul = ldexpf(1.0f, ACT_EXP_DEFAULT - d.act_exp); a.overflow = d.overflow;
     const long nbx = ksize == 1 ? (a.npix + 64 * c.mw - 1) / (64 * c.mw) : N * a.tilesX * a.tilesY;
     a.ntiles = nbx;
     if (nbx * a.nblkY > 0x7fffffffL) return FAR_EINVAL;

@@ -274,7 +274,8 @@ inline WsB carve_b(unsigned char* p, size_t o, int Z, int L, int S) {
 
 // ---- glue with dual_softmax_f16s.hip (same translation-unit-independent layout of the forward workspace) ----
 size_t far_k1_fwd_ws_bytes(int Z, int L, int S);
-int far_k1_stats_launch(const float* f0, const float* f1, int Z, int L, int S, float temperature, void* ws, hipStream_t stream);
+int far_k1_stats_launch(const float* f0, const float* f1, int Z, int L, int S, float temperature, void* ws, int* overflow,
+                        hipStream_t stream);
 void far_k1_fwd_views(void* ws, int Z, int L, int S, const _Float16** ah, const _Float16** bh, const float2** rowstat,
                       const float** cmax, const float** cinv, float* c1);
 
@@ -290,12 +291,12 @@ size_t far_coarse_train_workspace_bytes(int Z, int L, int S, int Cc) {
 // positions loftr_loss.py:86-91 reads), leaving operand planes + statistics in `ws` for the backward call.
 int far_coarse_pos_conf_f16s(const float* f0, const float* f1, int Z, int L, int S, int Cc, float temperature,
                              const int64_t* pb, const int64_t* pi, const int64_t* pj, int M, float* p_out, void* ws,
-                             hipStream_t stream) {
+                             int* overflow, hipStream_t stream) {
     using namespace far_k1b;
     far_clear_errors();
     if (!f0 || !f1 || !ws || Z <= 0 || L <= 0 || S <= 0 || Cc != C || M < 0 || (M > 0 && (!pb || !pi || !pj || !p_out)))
         return FAR_EINVAL;
-    int rc = far_k1_stats_launch(f0, f1, Z, L, S, temperature, ws, stream);
+    int rc = far_k1_stats_launch(f0, f1, Z, L, S, temperature, ws, overflow, stream);
     if (rc != FAR_OK) return rc;
     if (M > 0) {
         const _Float16 *ah, *bh;

@@ -57,8 +57,11 @@ __device__ __forceinline__ float max32_to_upper_row(float v) {
 }
 
 // x [Z][N][256] fp32 -> hi / lo [Z][Np][256] fp16 (rows >= N zero), slot ^= row & 15
-__global__ void k1_prep(const float* __restrict__ x, int Z, int N, int Np, _Float16* __restrict__ hi, _Float16* __restrict__ lo) {
+// overflow (device int or null): |= 1 when a feature is beyond the range of the 2^4-scaled split (|x| > 4094: hi = inf)
+__global__ void k1_prep(const float* __restrict__ x, int Z, int N, int Np, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
+                        int* __restrict__ overflow) {
     const long total = (long)Z * Np * 32;
+    bool bad = false;
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
         const int slot = (int)(t & 31);
         const long row = t >> 5;
@@ -70,7 +73,12 @@ __global__ void k1_prep(const float* __restrict__ x, int Z, int N, int Np, _Floa
             const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
             const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { _Float16 h, l; split1(v[e] * PRESCALE, h, l); vh[e] = h; vl[e] = l; }
+            for (int e = 0; e < 8; ++e) {
+                _Float16 h, l;
+                split1(v[e] * PRESCALE, h, l);
+                vh[e] = h; vl[e] = l;
+                bad |= !(fabsf(v[e]) <= 65504.0f / PRESCALE);          // also true for NaN inputs
+            }
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) { vh[e] = (_Float16)0.f; vl[e] = (_Float16)0.f; }
@@ -79,6 +87,7 @@ __global__ void k1_prep(const float* __restrict__ x, int Z, int N, int Np, _Floa
         *reinterpret_cast<f16x8*>(hi + (size_t)row * C + s2 * 8) = vh;
         *reinterpret_cast<f16x8*>(lo + (size_t)row * C + s2 * 8) = vl;
     }
+    if (overflow && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(overflow, 1);
 }
 
 // Row-side fragments: row i, channels 16 s + 8 h .. + 7, both planes (128 registers)
@@ -382,13 +391,14 @@ static float k1_c1(float temperature) {
 }
 
 // operand planes + row statistics + dense column statistics, exactly as far_coarse_match_f16s prepares them
-int far_k1_stats_launch(const float* f0, const float* f1, int Z, int L, int S, float temperature, void* ws, hipStream_t stream) {
+int far_k1_stats_launch(const float* f0, const float* f1, int Z, int L, int S, float temperature, void* ws, int* overflow,
+                        hipStream_t stream) {
     const Ws16 w = carve16(ws, Z, L, S);
     const int Lp = (L + 127) / 128 * 128, Sp = (S + 127) / 128 * 128;
     const float c1 = k1_c1(temperature), fill2 = -1e9f * 1.44269504088896341f;
     auto gridp = [](long n) { long b = (n + 255) / 256; return (unsigned)(b < 65536L * 4 ? b : 65536L * 4); };
-    hipLaunchKernelGGL(k1_prep, dim3(gridp((long)Z * Lp * 32)), dim3(256), 0, stream, f0, Z, L, Lp, w.ah, w.al);
-    hipLaunchKernelGGL(k1_prep, dim3(gridp((long)Z * Sp * 32)), dim3(256), 0, stream, f1, Z, S, Sp, w.bh, w.bl);
+    hipLaunchKernelGGL(k1_prep, dim3(gridp((long)Z * Lp * 32)), dim3(256), 0, stream, f0, Z, L, Lp, w.ah, w.al, overflow);
+    hipLaunchKernelGGL(k1_prep, dim3(gridp((long)Z * Sp * 32)), dim3(256), 0, stream, f1, Z, S, Sp, w.bh, w.bl, overflow);
     const size_t smem_s = 2 * TILE_PLANE + KT * sizeof(float);
     FAR_ONCE_PER_DEVICE(hipFuncSetAttribute((const void*)k1_rowstats<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_s));
     hipLaunchKernelGGL(k1_rowstats<false>, dim3((Lp / 128) * Z), dim3(256), smem_s, stream, w.ah, w.al, w.bh, w.bl, Z, L, S, Lp, Sp,
@@ -421,7 +431,7 @@ int far_coarse_match_f16s(const float* f0, const float* f1, int Z, int L, int S,
                           const int* valid_hw, const float* scale0, const float* scale1,
                           float* conf_out, int64_t* b_ids, int64_t* i_ids, int64_t* j_ids, float* mconf,
                           float* mkpts0_c, float* mkpts1_c, int* counts_out, int* total_out,
-                          void* ws, hipStream_t stream) {
+                          void* ws, int* overflow, hipStream_t stream) {
     far_clear_errors();
     if (!f0 || !f1 || !ws || !b_ids || !i_ids || !j_ids || !mconf || !mkpts0_c || !mkpts1_c || !total_out)
         return FAR_EINVAL;
@@ -432,8 +442,8 @@ int far_coarse_match_f16s(const float* f0, const float* f1, int Z, int L, int S,
     const float c1 = (float)(1.4426950408889634 / ((double)C * (double)temperature * PRESCALE * PRESCALE));
     const float fill2 = -1e9f * 1.44269504088896341f;
     auto gridp = [](long n) { long b = (n + 255) / 256; return (unsigned)(b < 65536L * 4 ? b : 65536L * 4); };
-    hipLaunchKernelGGL(k1_prep, dim3(gridp((long)Z * Lp * 32)), dim3(256), 0, stream, f0, Z, L, Lp, w.ah, w.al);
-    hipLaunchKernelGGL(k1_prep, dim3(gridp((long)Z * Sp * 32)), dim3(256), 0, stream, f1, Z, S, Sp, w.bh, w.bl);
+    hipLaunchKernelGGL(k1_prep, dim3(gridp((long)Z * Lp * 32)), dim3(256), 0, stream, f0, Z, L, Lp, w.ah, w.al, overflow);
+    hipLaunchKernelGGL(k1_prep, dim3(gridp((long)Z * Sp * 32)), dim3(256), 0, stream, f1, Z, S, Sp, w.bh, w.bl, overflow);
     int* counts = counts_out ? counts_out : w.k.counts;
     hipMemsetAsync(counts, 0, sizeof(int) * Z, stream);
     const size_t smem_s = 2 * TILE_PLANE + KT * sizeof(float), smem_m = 2 * TILE_PLANE + 4 * 64 * sizeof(float);
@@ -472,7 +482,7 @@ int far_coarse_match_f16s(const float* f0, const float* f1, int Z, int L, int S,
 // their fp16-operand value (relative error <= ~1e-3); the Python front end then falls back to far_coarse_match_f16s.
 int far_conf_matrix_f16s(const float* f0, const float* f1, int Z, int L, int S, int Cc, float temperature,
                          const uint8_t* mask0, const uint8_t* mask1, int stages, float* conf_out, int* fix_info_out,
-                         void* ws, hipStream_t stream) {
+                         void* ws, int* overflow, hipStream_t stream) {
     far_clear_errors();
     if (!f0 || !f1 || !ws || !conf_out || Z <= 0 || L <= 0 || S <= 0 || Cc != C || !(stages & 3)) return FAR_EINVAL;
     const Ws16 w = carve16(ws, Z, L, S);
@@ -481,8 +491,8 @@ int far_conf_matrix_f16s(const float* f0, const float* f1, int Z, int L, int S, 
     const float fill2 = -1e9f * 1.44269504088896341f;
     if (stages & 1) {
         auto gridp = [](long n) { long b = (n + 255) / 256; return (unsigned)(b < 65536L * 4 ? b : 65536L * 4); };
-        hipLaunchKernelGGL(k1_prep, dim3(gridp((long)Z * Lp * 32)), dim3(256), 0, stream, f0, Z, L, Lp, w.ah, w.al);
-        hipLaunchKernelGGL(k1_prep, dim3(gridp((long)Z * Sp * 32)), dim3(256), 0, stream, f1, Z, S, Sp, w.bh, w.bl);
+        hipLaunchKernelGGL(k1_prep, dim3(gridp((long)Z * Lp * 32)), dim3(256), 0, stream, f0, Z, L, Lp, w.ah, w.al, overflow);
+        hipLaunchKernelGGL(k1_prep, dim3(gridp((long)Z * Sp * 32)), dim3(256), 0, stream, f1, Z, S, Sp, w.bh, w.bl, overflow);
         const size_t smem_s = 2 * TILE_PLANE + KT * sizeof(float);
         FAR_ONCE_PER_DEVICE(
             hipFuncSetAttribute((const void*)k1_rowstats<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_s);

@@ -62,8 +62,11 @@ __device__ __forceinline__ void split1(float x, _Float16& hi, _Float16& lo) {
 }
 
 // ---- k_prep_qk: x [Z][N][64] fp32 -> hi / lo [Z][Np][64] fp16 (rows >= N zero), 16-byte slot ^= (row >> 1) & 7
-__global__ void k_prep_qk(const float* __restrict__ x, ZLayout lay, int Z, int N, int Np, _Float16* __restrict__ hi, _Float16* __restrict__ lo) {
+// overflow (device int or null): |= 1 when a value is beyond the range of the 2^4-scaled split (|x| > 4094: hi = inf)
+__global__ void k_prep_qk(const float* __restrict__ x, ZLayout lay, int Z, int N, int Np, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
+                          int* __restrict__ overflow) {
     const long total = (long)Z * Np * 8;
+    bool bad = false;
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
         const int slot = (int)(t & 7);
         const long row = t >> 3;
@@ -76,7 +79,12 @@ __global__ void k_prep_qk(const float* __restrict__ x, ZLayout lay, int Z, int N
             const float4 b = *reinterpret_cast<const float4*>(src + 4);
             const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { _Float16 h, l; split1(v[e] * QK_PRESCALE, h, l); vh[e] = h; vl[e] = l; }
+            for (int e = 0; e < 8; ++e) {
+                _Float16 h, l;
+                split1(v[e] * QK_PRESCALE, h, l);
+                vh[e] = h; vl[e] = l;
+                bad |= !(fabsf(v[e]) <= 65504.0f / QK_PRESCALE);
+            }
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) { vh[e] = (_Float16)0.f; vl[e] = (_Float16)0.f; }
@@ -85,6 +93,7 @@ __global__ void k_prep_qk(const float* __restrict__ x, ZLayout lay, int Z, int N
         *reinterpret_cast<f16x8*>(hi + (size_t)row * D + s2 * 8) = vh;
         *reinterpret_cast<f16x8*>(lo + (size_t)row * D + s2 * 8) = vl;
     }
+    if (overflow && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(overflow, 1);
 }
 
 // Fragment of the register-resident ("row") side: row i, channels 16 s + 8 h .. + 7 of both planes (un-swizzled
@@ -502,9 +511,12 @@ size_t far_emm_pv_f16s_workspace_bytes(int Z, int N) {
 // operator (statistics included) on split-fp16 operands.  pos [N][6], T_out [Z][N][70] fp32; q, k, v: problem
 // z = p * heads + hh starts at  ptr + hh * head_stride + p' * prob_stride  floats and is [N][64] contiguous, with
 // p' = p for k, v and (p + q_rot) mod (Z / heads) for q  (contiguous [Z][N][64]: heads = 1, prob_stride = 64 N, q_rot = 0);
-// ws: far_emm_pv_f16s_workspace_bytes(Z, N) bytes.
+// ws: far_emm_pv_f16s_workspace_bytes(Z, N) bytes.  overflow: device int or NULL, |= 1 when a q / k value is beyond the range
+// of the 2^4-scaled fp16 split (|x| > 4094): T is then inf / NaN (far_emm_pv_f32 has no such limit).
+// (v~ / colsum is at most 64 |v| in the split's units: |v| > 1023 would overflow it too; the head's v is a Linear of a
+// LayerNorm output, the caller's range check covers it through the projection's own K9 flag.)
 int far_emm_pv_f16s(const float* q, const float* k, const float* v, const float* pos, int Z, int N, int Dh, float scale,
-                    int heads, long head_stride, long prob_stride, int q_rot, void* ws, float* T_out,
+                    int heads, long head_stride, long prob_stride, int q_rot, void* ws, float* T_out, int* overflow,
                     hipStream_t stream) {
     far_clear_errors();
     if (!q || !k || !v || !pos || !ws || !T_out || Z <= 0 || N <= 0 || Dh != D || heads < 1 || Z % heads || q_rot < 0 ||
@@ -516,8 +528,8 @@ int far_emm_pv_f16s(const float* q, const float* k, const float* v, const float*
     const EmmWs w = carve(ws, Z, N);
     const float c1 = scale * 1.44269504088896341f / (QK_PRESCALE * QK_PRESCALE);      // scores -> log2 domain
     const unsigned gprep = (unsigned)(((long)Z * Np * 8 + 255) / 256 < 65536L * 4 ? ((long)Z * Np * 8 + 255) / 256 : 65536L * 4);
-    hipLaunchKernelGGL(k_prep_qk, dim3(gprep), dim3(256), 0, stream, q, layq, Z, N, Np, w.qh, w.ql);
-    hipLaunchKernelGGL(k_prep_qk, dim3(gprep), dim3(256), 0, stream, k, lay, Z, N, Np, w.kh, w.kl);
+    hipLaunchKernelGGL(k_prep_qk, dim3(gprep), dim3(256), 0, stream, q, layq, Z, N, Np, w.qh, w.ql, overflow);
+    hipLaunchKernelGGL(k_prep_qk, dim3(gprep), dim3(256), 0, stream, k, lay, Z, N, Np, w.kh, w.kl, overflow);
     const dim3 grid((unsigned)(Np / 128) * Z);
     // softmax over queries (rows of the statistics kernel = keys); the softmax over keys is formed online inside k_pv
     const dim3 gstat((unsigned)(Np / 128) * Z);

@@ -73,7 +73,7 @@ __device__ __forceinline__ float sum32(float v) {
 __global__ __launch_bounds__(256, 2) void k_mlp128(const float* __restrict__ x, const float* __restrict__ msg,
                                                    const unsigned char* __restrict__ wimg, long R, float hscale, float oscale,
                                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                                   float* __restrict__ out) {
+                                                   float* __restrict__ out, int* __restrict__ overflow) {
     __shared__ __attribute__((aligned(16))) unsigned char ring[RING * SLAB];
     __shared__ __attribute__((aligned(16))) unsigned char xs[WAVES * 4096];          // per wave: its 32 rows x 128 B of the current chunk
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
@@ -201,6 +201,16 @@ __global__ __launch_bounds__(256, 2) void k_mlp128(const float* __restrict__ x, 
         }
     }
 
+    // Activation-range guard (as K9): an input or a hidden value beyond the fp16 range of its 2^4-scaled split (|a| > 4094)
+    // is inf in the operand and inf / NaN here; the sum of the wave's accumulators is finite exactly when all of them are.
+    if (overflow) {
+        float chk = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) chk += acc2[ct][r];
+        if (__any(!(fabsf(chk) <= FLT_MAX)) && (threadIdx.x & 63) == 0) atomicOr(overflow, 1);
+    }
     // ---------------------------------------------------------------- LayerNorm (two-pass, as K6 / K9) + residual + store
     // acc2[ct][r]: row row0 + mfma32_row(r, h), channel 32 ct + l31
     const float inv_c = 1.0f / (float)DM;
@@ -241,14 +251,14 @@ size_t far_mlp_fused_packed_bytes(int d_model) { return d_model == DM ? (size_t)
 //   execution order); hscale = 2^-w0_exp (accumulator -> 2^4 x hidden), oscale = 2^-(w2_exp + 4) (accumulator -> output);
 //   gamma, beta [128], eps: norm2.  out may not alias x or msg.
 int far_mlp_fused_f16s(const float* x, const float* msg, const void* packed, long R, int d_model, float hscale, float oscale,
-                       const float* gamma, const float* beta, float eps, float* out, hipStream_t stream) {
+                       const float* gamma, const float* beta, float eps, float* out, int* overflow, hipStream_t stream) {
     far_clear_errors();
     if (R == 0) return FAR_OK;
     if (!x || !msg || !packed || !gamma || !beta || !out || R < 0 || d_model != DM || out == x || out == msg) return FAR_EINVAL;
     const long nb = (R + 32 * WAVES - 1) / (32 * WAVES);
     if (nb > 0x7fffffffL) return FAR_EINVAL;
     hipLaunchKernelGGL(k_mlp128, dim3((unsigned)nb), dim3(64 * WAVES), 0, stream, x, msg, (const unsigned char*)packed, R, hscale,
-                       oscale, gamma, beta, eps, out);
+                       oscale, gamma, beta, eps, out, overflow);
     return far_check_launch();
 }
 

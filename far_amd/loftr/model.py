@@ -82,6 +82,9 @@ class LoFTR(nn.Module):
             self.loftr_regress = LocalFeatureTransformerRegressor(config)
         # backbone arithmetic, see set_precision; fp32-grade = parity configuration
         self.backbone_dtype = torch.float32
+        # exponent of the power-of-two activation scale of the split-fp16 kernels (ops.activation_exponent): 4 covers
+        # |activation| <= 4094; lowered by _widen_activation_range when a launch reports an overflow
+        self.act_exp = 4
 
     PRECISIONS = ('fp32', 'fp16-fine', 'fp16', 'bf16')
 
@@ -116,6 +119,10 @@ class LoFTR(nn.Module):
         return coarse.float(), fine.float()
 
     def forward_feature_extraction(self, data):
+        with ops.activation_exponent(self.act_exp):
+            self._feature_extraction(data)
+
+    def _feature_extraction(self, data):
         im0, im1 = data['image0'], data['image1']
         n = im0.size(0)
         data.update(bs=n, hw0_i=im0.shape[2:], hw1_i=im1.shape[2:])
@@ -133,6 +140,10 @@ class LoFTR(nn.Module):
     # stages 2-5: coarse transformer, K1 coarse match, K3 fine refinement (loftr.py:91-135)
     # -------------------------------------------------------------------------------------------------
     def forward_correspondence_prediction(self, data, train=False):
+        with ops.activation_exponent(self.act_exp):
+            self._correspondence_prediction(data, train)
+
+    def _correspondence_prediction(self, data, train=False):
         data.pop(self._HEAD_KEY, None)                     # new coarse features: the head's cached stage is void
         tok0 = _tokens(data['featmap0'], self.pos_encoding)
         tok1 = _tokens(data['featmap1'], self.pos_encoding)
@@ -188,6 +199,15 @@ class LoFTR(nn.Module):
     def forward_rt_prediction(self, data):
         if not self.config['regress_rt']:
             return
+
+        def run():
+            data.pop(self._HEAD_KEY, None) if run.again else None      # a re-run must not reuse features with inf / NaN in them
+            run.again = True
+            self._rt_prediction(data)
+        run.again = False
+        self._guarded(run, data['featmap0'].device)
+
+    def _rt_prediction(self, data):
         f0, f1, m0, m1, preds, inv_preds = self.preprocess_helper(data)
         features = self._head_features(data, f0, f1, preds, inv_preds)
         pose, mlp_feats, gate = self.loftr_regress(f0, f1, mask0=m0, mask1=m1, loftr_preds=preds,
@@ -235,12 +255,56 @@ class LoFTR(nn.Module):
         """For callers that rewrite data['featmap0/1'] through raw device pointers outside torch and far_amd.ops."""
         data.pop(cls._HEAD_KEY, None)
 
+    # -------------------------------------------------------------------------------------------------
+    # Activation range of the split-fp16 kernels.  The reference's fp32 convolutions and Linear layers accept any finite
+    # activation (resnet_fpn.py:101-119); K9 / K13 / K14 / K1 / K2 split their operands around a power-of-two scale and
+    # overflow to inf beyond 65504 / 2^e.  Every such launch ORs a device flag when that happens (ops.overflow_flag);
+    # forward / forward_rt_prediction read it ONCE at their end and, if set, widen the range and run again:
+    #   e -= 4 for K9 (16x the range per step, down to e = -24: |a| <= 1e12),
+    #   the fused fine-level layers (K13 / K14, fixed exponent) run as K9 + K5 launches,
+    #   K1 / K2 (fixed exponent) run on their exact-f32 MFMA variants.
+    # The setting sticks to the module (a checkpoint with large activations pays the re-run once, not per batch).
+    # -------------------------------------------------------------------------------------------------
+    def _widen_activation_range(self):
+        from .transformer import CrossAttention, LoFTREncoderLayer
+        if self.act_exp - 4 < ops.ACT_EXP_MIN:
+            raise ops.ActivationOverflow('activations beyond the widest split-fp16 range (|a| > 1e12 or non-finite inputs)')
+        self.act_exp -= 4
+        for m in self.modules():
+            if isinstance(m, LoFTREncoderLayer):
+                m.fused_attn = m.fused_mlp = False
+            if isinstance(m, CrossAttention):
+                m.exact_f32 = True
+        if hasattr(self, 'coarse_matching'):
+            self.coarse_matching.variant = 'f32'
+        import warnings
+        warnings.warn(f'far_amd: an activation exceeded the split-fp16 range; re-running with activation exponent {self.act_exp} '
+                      f'(|a| <= {65504.0 / 2.0 ** self.act_exp:.3g}), unfused fine-level layers and the exact-f32 K1 / K2 variants')
+
+    def _guarded(self, fn, device):
+        """Runs fn() under this module's activation exponent; on an overflow report widens the range and runs it again."""
+        if device.type != 'cuda':
+            return fn()
+        while True:
+            with ops.activation_exponent(self.act_exp):
+                out = fn()
+            if not ops.activation_overflowed(device):      # one host read per call
+                return out
+            self._widen_activation_range()
+
+    def check_activation_range(self, data):
+        """For callers that drive forward_feature_extraction / forward_correspondence_prediction themselves: raises
+        ops.ActivationOverflow if a launch since the last check left the split-fp16 range (outputs contain inf / NaN)."""
+        ops.check_activation_range(data['image0'].device, 'LoFTR')
+
     def forward(self, data, train=False):
         """Results are side effects on `data` (loftr.py:194-205, which returns None).  The dict is also RETURNED: a
         wrapper that copies dict arguments on the way in (DistributedDataParallel built with device_ids) would otherwise
         leave the caller with a dict the module never wrote to; far_amd.pipeline merges a returned copy back."""
-        self.forward_feature_extraction(data)
-        self.forward_correspondence_prediction(data, train=train)
+        def run():
+            self.forward_feature_extraction(data)
+            self.forward_correspondence_prediction(data, train=train)
+        self._guarded(run, data['image0'].device)
         return data
 
     def load_state_dict(self, state_dict, *args, **kwargs):

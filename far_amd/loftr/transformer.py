@@ -224,6 +224,8 @@ def positional_table(h=60, w=80):
 
 class CrossAttention(nn.Module):
     hip_training = True          # training on the GPU runs K2's forward + backward kernels; False: vendor ops + autograd
+    exact_f32 = False            # inference: K2 on the exact-f32 MFMA kernels (no operand range limit; LoFTR sets it after an
+                                 # activation-range overflow of the split-fp16 variant, model.py:_widen_activation_range)
 
     def __init__(self, dim, num_heads=8, qkv_bias=False, attn_drop=0., proj_drop=0.):
         super().__init__()
@@ -259,7 +261,13 @@ class CrossAttention(nn.Module):
                         x2.data_ptr() == x1.data_ptr() + x1.numel() * x1.element_size())
             x12 = torch.as_strided(x1, (2, B, N, C), (B * N * C, N * C, C, 1)) if adjacent else torch.stack([x1, x2], 0)
             planes = ops.linear_f16s(x12.reshape(2 * B, N, C), pc, out_planes=3 * h)     # (3h, 2B, N, d)
-            F, _ = ops.emm_bilinear_planes(planes, self.pos6, self.scale, B)             # (2Bh, 70, 70)
+            if self.exact_f32:
+                P = planes.view(3, h, 2, B, N, d).permute(0, 2, 3, 1, 4, 5)                # (tensor, image, B, h, N, d)
+                qq = torch.stack([P[0, 1], P[0, 0]], 0).reshape(2 * B * h, N, d).contiguous()
+                F, _ = ops.emm_bilinear(qq, P[1].reshape(2 * B * h, N, d).contiguous(), P[2].reshape(2 * B * h, N, d).contiguous(),
+                                        self.pos6, self.scale, exact_f32=True)
+            else:
+                F, _ = ops.emm_bilinear_planes(planes, self.pos6, self.scale, B)         # (2Bh, 70, 70)
         F = F.view(2, B, h, d + 6, d + 6)
         # raw reshape of (B, h, 70, 70) to (B, 280, 70), then transpose (:294-295)
         f1 = F[0].reshape(B, C + 6 * h, (C + 6 * h) // h).transpose(-2, -1)
@@ -360,7 +368,7 @@ class LocalFeatureTransformerRegressor(nn.Module):
         mods = [self.emm, self.norm] + ([self.loftr] if self.config['regress_loftr_layers'] > 0 else [])
         ws = tuple((p.data_ptr(), ops.tensor_version(p)) for m in mods for p in m.parameters())
         prec = tuple(m.split_operands for m in self.modules() if isinstance(m, LoFTREncoderLayer))
-        return ws, prec, self.training
+        return ws, prec, self.training, ops.activation_exponent_value(), self.emm.cross_attn.exact_f32
 
     def compute_features(self, feat0, feat1, loftr_preds=None, inv_loftr_preds=None):
         """(B, 35840) head features of transformer.py:488-497 + :424-428 (LoFTR layer(s), CrossBlock, LayerNorm)."""

@@ -4,6 +4,7 @@ PyTorch supplies device memory and the current HIP stream; all arithmetic of the
 libfar_hip.so.  Every op raises on CPU tensors -- there is no eager fallback.
 """
 import ctypes
+import threading
 
 import torch
 
@@ -93,7 +94,8 @@ def coarse_match(f0, f1, temperature, thr, border, hw0, hw1, cell_scale, mask0=N
         _p(mask0, torch.uint8), _p(mask1, torch.uint8), _p(valid_hw, torch.int32),
         _p(scale0, torch.float32), _p(scale1, torch.float32), _p(conf),
         _p(b_ids), _p(i_ids), _p(j_ids), _p(mconf), _p(mk0), _p(mk1),
-        _p(counts), ctypes.c_void_p(counts.data_ptr() + 4 * Z), _p(ws), _stream())
+        _p(counts), ctypes.c_void_p(counts.data_ptr() + 4 * Z), _p(ws),
+        *([_p(overflow_flag(dev))] if variant == 'f16s' else []), _stream())
     _lib.check(rc, 'far_coarse_match_' + variant)
     counts_h = counts.cpu()
     M = int(counts_h[Z])
@@ -118,7 +120,7 @@ def conf_matrix(f0, f1, temperature, mask0=None, mask1=None, out=None):
     info = torch.zeros(2, dtype=torch.int32, device=dev)
     rc = lib.far_conf_matrix_f16s(_p(f0, torch.float32), _p(f1, torch.float32), Z, L, S, C, float(temperature),
                                   _p(mask0, torch.uint8), _p(mask1, torch.uint8), 3, _p(conf, torch.float32), _p(info), _p(ws),
-                                  _stream())
+                                  _p(overflow_flag(dev)), _stream())
     _lib.check(rc, 'far_conf_matrix_f16s')
     listed, dropped = (int(v) for v in info.cpu())            # one blocking host read per call (the overflow flag)
     if dropped > 0:           # pathological input (a column with more than 8 non-tiny entries): the exact writer
@@ -147,7 +149,7 @@ class _CoarsePosConf(torch.autograd.Function):
         ws = _ws(lib.far_coarse_train_workspace_bytes(Z, L, S, C), f0.device)
         p = torch.empty(M, dtype=torch.float32, device=f0.device)
         rc = lib.far_coarse_pos_conf_f16s(_p(f0c, torch.float32), _p(f1c, torch.float32), Z, L, S, C, float(temperature),
-                                          _p(pb), _p(pi), _p(pj), M, _p(p), _p(ws), _stream())
+                                          _p(pb), _p(pi), _p(pj), M, _p(p), _p(ws), _p(overflow_flag(f0.device)), _stream())
         _lib.check(rc, 'far_coarse_pos_conf_f16s')
         ctx.save_for_backward(f0c, f1c, pb, pi, pj, p, ws)
         ctx.temperature = float(temperature)
@@ -189,7 +191,7 @@ def emm_bilinear(q, k, v, pos, scale, exact_f32=False):
     else:
         ws = _ws(lib.far_emm_pv_f16s_workspace_bytes(Z, N), q.device)
         rc = lib.far_emm_pv_f16s(_p(q, torch.float32), _p(k, torch.float32), _p(v, torch.float32), _p(pos, torch.float32),
-                                 Z, N, D, float(scale), 1, 0, N * D, 0, _p(ws), _p(T), _stream())
+                                 Z, N, D, float(scale), 1, 0, N * D, 0, _p(ws), _p(T), _p(overflow_flag(T.device)), _stream())
         _lib.check(rc, 'far_emm_pv_f16s')
     vt = torch.cat([v, pos.unsqueeze(0).expand(Z, -1, -1)], dim=2)  # (Z, N, 70)
     return torch.bmm(vt.transpose(1, 2), T), T
@@ -202,7 +204,7 @@ def _emm_pv(q, k, v, pos, scale, want_stats=False):
     T = torch.empty(Z, N, 70, dtype=torch.float32, device=q.device)
     ws = _ws(lib.far_emm_pv_f16s_workspace_bytes(Z, N), q.device)
     rc = lib.far_emm_pv_f16s(_p(q, torch.float32), _p(k, torch.float32), _p(v, torch.float32), _p(pos, torch.float32),
-                             Z, N, D, float(scale), 1, 0, N * D, 0, _p(ws), _p(T), _stream())
+                             Z, N, D, float(scale), 1, 0, N * D, 0, _p(ws), _p(T), _p(overflow_flag(T.device)), _stream())
     _lib.check(rc, 'far_emm_pv_f16s')
     if not want_stats:
         return T
@@ -284,7 +286,7 @@ def emm_bilinear_planes(qkv, pos, scale, B):
     base = qkv.data_ptr()
     plane = P * N * D * 4
     rc = lib.far_emm_pv_f16s(ctypes.c_void_p(base), ctypes.c_void_p(base + h * plane), ctypes.c_void_p(base + 2 * h * plane),
-                             _p(pos, torch.float32), Z, N, D, float(scale), h, P * N * D, N * D, B, _p(ws), _p(T), _stream())
+                             _p(pos, torch.float32), Z, N, D, float(scale), h, P * N * D, N * D, B, _p(ws), _p(T), _p(overflow_flag(T.device)), _stream())
     _lib.check(rc, 'far_emm_pv_f16s')
     v = qkv[2 * h:].permute(1, 0, 2, 3).reshape(Z, N, D)                       # (P, h, N, D) -> z = p * h + hh
     vt = torch.cat([v, pos.unsqueeze(0).expand(Z, -1, -1)], dim=2)
@@ -575,7 +577,74 @@ def upsample2x_add(lo, hi):
 
 
 _ACT = {'none': 0, 'relu': 1, 'leaky': 2}
-_CONV_ACT_EXP = 4          # the kernel scales activations by 2^4 before the fp16 split (conv_igemm_f16s.hip)
+_CONV_ACT_EXP = 4          # default exponent of the activation scale 2^e applied before the fp16 split (conv_igemm_f16s.hip);
+                           # the packed `scale` vectors fold 2^-4, the kernel corrects for the exponent actually used
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Activation range of the split-precision kernels (K9, K13, K14).  An fp32 activation a is split hi = fp16(a 2^e),
+# lo = fp16(a 2^e - hi): |a| <= 65504 / 2^e survives, beyond it hi = inf.  The reference's fp32 convolutions / Linear layers
+# have no such limit (resnet_fpn.py:101-119, transformer.py:44-67), so the limit must never bite silently:
+#   * every launch tests its accumulators and ORs a per-device flag (no cost unless it fires);
+#   * `check_activation_range` reads the flag (one host read) and raises ActivationOverflow;
+#   * far_amd.loftr.LoFTR catches it, lowers the exponent e (thread-local, `activation_exponent`) by 4 -- 16x the range,
+#     16x coarser absolute resolution of values below 2^-14 2^-e -- switches the fused fine-level layers (whose exponent
+#     is fixed) to their K9 + K5 form, and re-runs the forward.  e = 4 covers |a| <= 4094; the floor e = -24 covers 1e12.
+# ---------------------------------------------------------------------------------------------------------------------
+class ActivationOverflow(_lib.FarHipError):
+    pass
+
+
+_ACT_STATE = threading.local()
+_OVERFLOW_FLAGS = {}
+ACT_EXP_MIN = -24
+
+
+def activation_exponent_value():
+    return getattr(_ACT_STATE, 'exp', _CONV_ACT_EXP)
+
+
+class activation_exponent:
+    """Context manager: K9 launches of this thread split their activations around 2^exp."""
+
+    def __init__(self, exp):
+        if not (ACT_EXP_MIN <= int(exp) <= 8):
+            raise ValueError(f'activation exponent must be in [{ACT_EXP_MIN}, 8]')
+        self.exp = int(exp)
+
+    def __enter__(self):
+        self.prev = activation_exponent_value()
+        _ACT_STATE.exp = self.exp
+        return self
+
+    def __exit__(self, *a):
+        _ACT_STATE.exp = self.prev
+
+
+def overflow_flag(device):
+    """The per-device int32 flag every K9 / K13 / K14 launch ORs into."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    f = _OVERFLOW_FLAGS.get(key)
+    if f is None:
+        f = _OVERFLOW_FLAGS[key] = torch.zeros(1, dtype=torch.int32, device=torch.device('cuda', key))
+    return f
+
+
+def activation_overflowed(device, reset=True):
+    """True if a launch since the last reset saw a non-finite accumulator.  One blocking host read."""
+    f = overflow_flag(device)
+    hit = bool(f.item())
+    if hit and reset:
+        f.zero_()
+    return hit
+
+
+def check_activation_range(device, what='far_amd'):
+    if activation_overflowed(device):
+        raise ActivationOverflow(
+            f'{what}: an activation left the range of the split-fp16 operands (|a| > {65504.0 / 2.0 ** activation_exponent_value():.4g} '
+            f'at activation exponent {activation_exponent_value()}): the outputs of this call contain inf / NaN.  '
+            f'Re-run under ops.activation_exponent(e) with a lower e (far_amd.loftr.LoFTR does this by itself).')
 
 
 class PackedConv:
@@ -659,7 +728,8 @@ def mlp_fused(x, msg, pack, gamma, beta, eps, out=None):
     R = x.numel() // pack.d
     y = torch.empty_like(x) if out is None else out
     rc = lib.far_mlp_fused_f16s(_p(x, torch.float32), _p(msg, torch.float32), _p(pack.packed), R, pack.d, pack.hscale, pack.oscale,
-                                _p(gamma, torch.float32), _p(beta, torch.float32), float(eps), _p(y, torch.float32), _stream())
+                                _p(gamma, torch.float32), _p(beta, torch.float32), float(eps), _p(y, torch.float32),
+                                _p(overflow_flag(x.device)), _stream())
     _lib.check(rc, 'far_mlp_fused_f16s')
     return y if out is None else _written(y)
 
@@ -721,7 +791,7 @@ def attn_block(x, source, pack, nhead, gamma, beta, ln_eps, attn_eps=1e-6, out=N
     sk, sv, sq, sm = pack.scales
     rc = lib.far_attn_block_f16s(_p(x, torch.float32), _p(source, torch.float32), _p(pack.packed), N, L, S, d, int(nhead), sk, sv, sq, sm,
                                  float(attn_eps), _p(gamma, torch.float32), _p(beta, torch.float32), float(ln_eps), _p(y, torch.float32),
-                                 _stream())
+                                 _p(overflow_flag(x.device)), _stream())
     _lib.check(rc, 'far_attn_block_f16s')
     return y if out is None else _written(y)
 
@@ -776,7 +846,7 @@ def conv_nhwc(x, pc, residual=None, act='none', slope=0.01, x2=None, out_planes=
                       res=ptr(residual), ln_gamma=ptr(g), ln_beta=ptr(b), post_res=ptr(post_residual), up=ptr(up), y=ptr(y),
                       N=N, H=H, W=W, Cin=Cin, Cin1=Cin1, Cout=pc.Cout, ksize=pc.ksize, stride=st, act=_ACT[act],
                       split=int(pc.split), out_planes=int(out_planes), res_group=int(res_group), slope=float(slope),
-                      ln_eps=float(eps))
+                      ln_eps=float(eps), act_exp=activation_exponent_value(), overflow=overflow_flag(x.device).data_ptr())
     rc = lib.far_conv_nhwc_f32(ctypes.byref(d), _stream())
     _lib.check(rc, 'far_conv_nhwc_f32')
     return y if out is None else _written(y)

@@ -27,7 +27,7 @@ extern "C" {
 
 typedef struct ihipStream_t* far_stream_t; /* == hipStream_t */
 
-/* ABI version of this header; bumped when a signature changes. */
+/* ABI version of this header; bumped when a signature changes (2: activation exponent / overflow flag of K9, K13, K14). */
 int far_abi_version(void);
 /* hipError_t of the most recent failed launch on the calling thread (0 = none): detail behind a -5 return. */
 int far_last_hip_error(void);
@@ -90,7 +90,10 @@ int far_coarse_match_bf16(const float* f0, const float* f1, int Z, int L, int S,
 
 /* Split-fp16 variant of far_coarse_match_f32 (fp32 features, hi + lo fp16 operand pairs on the f16 matrix cores,
  * fp32 accumulation: an fp32-grade similarity at 16/3 of the exact-f32 MFMA rate; one exp per score; conf_matrix, if
- * requested, written with 16-byte stores).  Same arguments and outputs; C must be 256. */
+ * requested, written with 16-byte stores).  Same arguments and outputs; C must be 256.
+ * overflow (this and the other *_f16s entry points of K1 / K2; device int or NULL): OR-ed with 1 when a feature is beyond
+ * the range of the 2^4-scaled fp16 split (|x| > 4094, or NaN) -- the scores are then NaN and NO match is reported, so a
+ * caller must look at the flag (far_amd/loftr does, and re-runs on far_coarse_match_f32, which has no such limit). */
 size_t far_coarse_match_f16s_workspace_bytes(int Z, int L, int S, int C);
 int far_coarse_match_f16s(const float* f0, const float* f1, int Z, int L, int S, int C,
                           float temperature, float thr, int border, int h0, int w0, int h1, int w1,
@@ -98,7 +101,7 @@ int far_coarse_match_f16s(const float* f0, const float* f1, int Z, int L, int S,
                           const int* valid_hw, const float* scale0, const float* scale1,
                           float* conf_out, int64_t* b_ids, int64_t* i_ids, int64_t* j_ids, float* mconf,
                           float* mkpts0_c, float* mkpts1_c, int* counts_out, int* total_out,
-                          void* ws, far_stream_t stream);
+                          void* ws, int* overflow, far_stream_t stream);
 
 /* data['conf_matrix'] alone -- CoarseMatching.forward's dual-softmax matrix (coarse_matching.py:108-118), which only the
  * dense coarse loss and plotting consume (loftr_loss.py:307-311) -- written at HBM speed: statistics from the
@@ -111,7 +114,7 @@ int far_coarse_match_f16s(const float* f0, const float* f1, int Z, int L, int S,
  *   ws            far_coarse_match_f16s_workspace_bytes(Z, L, S, C) bytes; C must be 256. */
 int far_conf_matrix_f16s(const float* f0, const float* f1, int Z, int L, int S, int C, float temperature,
                          const uint8_t* mask0, const uint8_t* mask1, int stages, float* conf_out, int* fix_info_out,
-                         void* ws, far_stream_t stream);
+                         void* ws, int* overflow, far_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * K1 on the training path: sparse coarse supervision without conf_matrix / conf_matrix_gt
@@ -126,7 +129,7 @@ size_t far_coarse_train_workspace_bytes(int Z, int L, int S, int C);
 /* forward: p_out[k] = conf_matrix[pb[k], pi[k], pj[k]] (fp32-grade statistics; float64 dot product at the positions). */
 int far_coarse_pos_conf_f16s(const float* f0, const float* f1, int Z, int L, int S, int C, float temperature,
                              const int64_t* pb, const int64_t* pi, const int64_t* pj, int M, float* p_out, void* ws,
-                             far_stream_t stream);
+                             int* overflow, far_stream_t stream);
 /* backward: w[k] = dL/dp_k * p_k.  df0 (Z, L, C), df1 (Z, S, C) are overwritten with dL/dfeat_c0, dL/dfeat_c1.
  * Dense part on the f16 matrix cores (recomputed score tiles, G = u R + v C fed from registers into the second MFMA),
  * plain fp16 operands / fp32 accumulation: gradient-grade (~1e-3 relative), not parity-grade. */
@@ -155,7 +158,7 @@ int far_emm_pv_f32(const float* q, const float* k, const float* v, const float* 
  * prob_stride = 64 N, q_rot = 0.  ws: far_emm_pv_f16s_workspace_bytes(Z, N) bytes of scratch. */
 size_t far_emm_pv_f16s_workspace_bytes(int Z, int N);
 int far_emm_pv_f16s(const float* q, const float* k, const float* v, const float* pos, int Z, int N, int D, float scale,
-                    int heads, long head_stride, long prob_stride, int q_rot, void* ws, float* T_out,
+                    int heads, long head_stride, long prob_stride, int q_rot, void* ws, float* T_out, int* overflow,
                     far_stream_t stream);
 /* the statistics of the last far_emm_pv_f16s call on `ws`: rowstat / colstat [Z][N][2] = (max, sum) in the log2 domain */
 int far_emm_pv_f16s_copy_stats(const void* ws, int Z, int N, float* rowstat_out, float* colstat_out, far_stream_t stream);
@@ -232,14 +235,17 @@ int far_layernorm_f32(const float* x, const float* gamma, const float* beta, con
  *          norm1(merge(LinearAttention(q_proj(x), k_proj(src), v_proj(src))))      8 heads of 16 channels
  *   x [nwin][L][128], src [nwin][S][128] fp32 (L, S <= 32); packed = the image far_amd/ops.py:PackedAttn builds
  *   (far_attn_block_packed_bytes bytes); scale_k / _v / _q / _m = 2^-(w_exp + 4) of the four weight tensors; attn_eps: the
- *   1e-6 of LinearAttention; gamma, beta [128], ln_eps: norm1.  out [nwin][L][128] must not alias x or src. */
+ *   1e-6 of LinearAttention; gamma, beta [128], ln_eps: norm1.  out [nwin][L][128] must not alias x or src.
+ *   overflow (both kernels; device int or NULL): OR-ed with 1 when an input or an intermediate left the range of the
+ *   2^4-scaled fp16 split (|value| > 4094; for K14 that includes the per-head K'^T V / S sums and the message) -- the
+ *   result is then inf / NaN, never silently wrong; far_amd/loftr re-runs the layer on K9 + K5 with a lower exponent. */
 size_t far_attn_block_packed_bytes(int d_model);
 int far_attn_block_f16s(const float* x, const float* src, const void* packed, long nwin, int L, int S, int d_model, int heads,
                         float scale_k, float scale_v, float scale_q, float scale_m, float attn_eps, const float* gamma,
-                        const float* beta, float ln_eps, float* out, far_stream_t stream);
+                        const float* beta, float ln_eps, float* out, int* overflow, far_stream_t stream);
 size_t far_mlp_fused_packed_bytes(int d_model);
 int far_mlp_fused_f16s(const float* x, const float* msg, const void* packed, long R, int d_model, float hscale, float oscale,
-                       const float* gamma, const float* beta, float eps, float* out, far_stream_t stream);
+                       const float* gamma, const float* beta, float eps, float* out, int* overflow, far_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * K7 / K8  backbone epilogues (inference): folded BatchNorm + residual + activation; FPN upsample + add
@@ -292,6 +298,12 @@ int far_conv_pack_f32(const float* w, int Cin, int Cout, int ksize, int stride, 
  *   up [N][H/2][W/2][Cout] (ksize 1, even H, W >= 32, no other residual): its 2x bilinear upsampling
  *   (align_corners = True) is added before the activation -- the FPN merge of resnet_fpn.py:108-109, :113-114
  *   (F.interpolate(scale_factor=2, mode='bilinear', align_corners=True) + lateral 1x1 convolution) in one launch.
+ *   act_exp / overflow: the activation range of the split.  Inputs are multiplied by 2^act_exp before hi = fp16(.),
+ *   lo = fp16(. - hi): |input| <= 65504 / 2^act_exp is representable, beyond it hi = inf and every output it feeds is
+ *   inf / NaN (resnet_fpn.py's plain fp32 convolutions have no such limit: callers lower act_exp and re-launch when
+ *   *overflow comes back set -- far_amd/loftr/model.py does, per forward).  `scale` always folds 2^-4; the kernel applies
+ *   the correction 2^(4 - act_exp).  Lower exponents cost resolution at the small end only: values below
+ *   2^-14 2^-act_exp lose their lo part, i.e. the absolute error floor is 2^-25 2^-act_exp.
  *   y must alias none of the inputs. */
 typedef struct far_conv_desc {
     const float* x;
@@ -309,6 +321,8 @@ typedef struct far_conv_desc {
     int H, W, Cin, Cin1, Cout, ksize, stride;
     int act, split, out_planes, res_group;
     float slope, ln_eps;
+    int act_exp;      /* activations x 2^act_exp before the fp16 split; 4 = default, [-24, 8]: inputs up to 65504 / 2^act_exp */
+    int* overflow;    /* device int, |= 1 when an accumulator of the launch is not finite (input out of that range); or NULL */
 } far_conv_desc;
 
 int far_conv_nhwc_f32(const far_conv_desc* desc, far_stream_t stream);

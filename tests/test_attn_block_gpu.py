@@ -131,3 +131,22 @@ def test_fused_fine_kernels_are_run_to_run_deterministic():
         assert torch.equal(a, a0), f'K14 differs at launch {it}'
         assert torch.equal(m, m0), f'K13 differs at launch {it}'
     side.synchronize()
+
+
+def test_attn_block_overflow_is_reported():
+    """K14 chains products of 2^4-scaled operands (K'^T V / S, then KV Q'): an input beyond 4094 -- or inputs of a few
+    hundred whose per-head K'^T V sums pass 4094 -- gives inf / NaN and sets the device flag; in range it stays clear."""
+    from far_amd import ops
+    ws, gam, bet, g = _setup(31)
+    x = torch.randn(40, 25, D, device='cuda', generator=g)
+    ops.overflow_flag('cuda').zero_()
+    y = ops.attn_block(x, x, ops.PackedAttn(*ws), H, gam, bet, 1e-5)
+    assert torch.isfinite(y).all() and not ops.activation_overflowed('cuda')
+    xb = x.clone()
+    xb[7, 3, 9] = 9000.0
+    y = ops.attn_block(xb, xb, ops.PackedAttn(*ws), H, gam, bet, 1e-5)
+    assert not torch.isfinite(y[7]).all() and torch.isfinite(y[8:]).all()
+    assert ops.activation_overflowed('cuda')
+    y = ops.attn_block(x * 300.0, x * 300.0, ops.PackedAttn(*ws), H, gam, bet, 1e-5)     # |x| ~ 1000 < 4094, products are not
+    print('[k14 product overflow] finite:', bool(torch.isfinite(y).all()), 'flag:', int(ops.overflow_flag('cuda').item()))
+    assert bool(torch.isfinite(y).all()) != ops.activation_overflowed('cuda')           # never silently non-finite

@@ -125,6 +125,55 @@ def test_conv_activation_overflow_is_loud():
     assert torch.equal(y[0][~hit], good[0][~hit])                     # and nothing else moved
 
 
+def test_conv_activation_range_flag_and_recovery():
+    """The recovery path behind the loud overflow: every K9 launch reports a non-finite accumulator through the device flag
+    (ops.overflow_flag); under a lower activation exponent the same tensor -- values up to 1e5 next to values of 1e-4 --
+    convolves at fp32-grade accuracy (error relative to the tensor's scale, as for an fp32 convolution), for every epilogue
+    form (3x3 wide / narrow, 1x1 linear with fused LayerNorm)."""
+    ops = _ops()
+    g = torch.Generator(device='cuda').manual_seed(14)
+    x = torch.randn(2, 20, 24, 64, device='cuda', generator=g)
+    x[0, 3, 4, 5] = 1.0e5
+    x[1, 10, 11, 12] = -7.0e4
+    x[:, :, :, 32:] *= 1e-4                                           # half of the channels at the small end
+    flag = ops.overflow_flag('cuda')
+    flag.zero_()
+    for Cout, ks in ((64, 3), (196, 3), (40, 1)):
+        w = torch.randn(Cout, 64, ks, ks, device='cuda', generator=g) * 0.05
+        pc = ops.PackedConv(w)
+        ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), padding=ks // 2).permute(0, 2, 3, 1)
+        y = ops.conv_nhwc(x, pc)                                      # default exponent 4: 1e5 * 16 is beyond fp16
+        assert not torch.isfinite(y).all()
+        assert ops.activation_overflowed('cuda') and int(flag.item()) == 0      # reported, and reset by the read
+        with pytest.raises(ops.ActivationOverflow):
+            ops.conv_nhwc(x, pc)
+            ops.check_activation_range('cuda', 'test')
+        with ops.activation_exponent(-4):                             # |a| <= 65504 * 16 ~ 1e6
+            y = ops.conv_nhwc(x, pc)
+        assert torch.isfinite(y).all() and not ops.activation_overflowed('cuda')
+        emax, erms = _rel(y, ref)
+        assert emax < 4e-6, (Cout, ks, emax, erms)
+        # the small-end channels alone: their contribution is resolved to the fp16 subnormal step of the split, 2^-24 / 2^-4
+        xs = x.clone()
+        xs[:, :, :, :32] = 0
+        refs = F.conv2d(xs.permute(0, 3, 1, 2).double(), w.double(), padding=ks // 2).permute(0, 2, 3, 1)
+        with ops.activation_exponent(-4):
+            ys = ops.conv_nhwc(xs, pc)
+        assert float((ys.double() - refs).abs().max()) < 64 * ks * ks * 0.2 * 2.0 ** -20      # sum |w| x half a step of 2^-20
+    # linear layer with the fused LayerNorm epilogue
+    xl = torch.randn(300, 256, device='cuda', generator=g) * 3.0e4
+    wl = torch.randn(256, 256, device='cuda', generator=g) * 0.06
+    gam, bet = torch.rand(256, device='cuda', generator=g) + 0.5, torch.randn(256, device='cuda', generator=g)
+    pl = ops.PackedConv(wl)
+    y = ops.linear_f16s(xl, pl, ln=(gam, bet, 1e-5))
+    assert ops.activation_overflowed('cuda')
+    with ops.activation_exponent(0):
+        y = ops.linear_f16s(xl, pl, ln=(gam, bet, 1e-5))
+    assert not ops.activation_overflowed('cuda')
+    ref = F.layer_norm(xl.double() @ wl.double().t(), (256,), gam.double(), bet.double(), 1e-5)
+    assert float((y.double() - ref).abs().max()) < 2e-5
+
+
 def test_linear_wrapper_matches_addmm():
     ops = _ops()
     g = torch.Generator(device='cuda').manual_seed(3)

@@ -108,3 +108,25 @@ def test_pack_follows_weight_updates():
         c = layer(x, x)
     assert float((a - b).abs().max()) > 1e-3
     assert float((b - c).abs().max()) < 2e-6 * float(c.abs().max())
+
+
+def test_mlp_fused_overflow_is_reported():
+    """K13's operands are 2^4-scaled activations AND the 2^4-scaled hidden tensor: an input beyond 4094, or a hidden value
+    beyond 4094 from moderate inputs (large weights), makes the result inf / NaN and sets the device flag; in range the flag
+    stays clear."""
+    from far_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(21)
+    w0, w2, gam, bet = _weights(3)
+    x = torch.randn(1, 500, D, device='cuda', generator=g)
+    m = torch.randn(1, 500, D, device='cuda', generator=g)
+    ops.overflow_flag('cuda').zero_()
+    y = ops.mlp_fused(x, m, ops.PackedMlp(w0, w2), gam, bet, 1e-5)
+    assert torch.isfinite(y).all() and not ops.activation_overflowed('cuda')
+    xb = x.clone()
+    xb[0, 77, 5] = 6000.0
+    y = ops.mlp_fused(xb, m, ops.PackedMlp(w0, w2), gam, bet, 1e-5)
+    assert not torch.isfinite(y[0, 77]).any() and torch.isfinite(y[0, :64]).all()
+    assert ops.activation_overflowed('cuda')
+    w0b = w0 * 400.0                                                   # hidden = relu(W0 [x | msg]) reaches ~ 400 * 4 sigma > 4094
+    y = ops.mlp_fused(x * 4, m * 4, ops.PackedMlp(w0b, w2), gam, bet, 1e-5)
+    assert ops.activation_overflowed('cuda') and not torch.isfinite(y).all()

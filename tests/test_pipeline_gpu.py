@@ -584,3 +584,52 @@ def test_precision_modes_deviation(model):
     iou = len(s32 & s16) / len(s32 | s16)
     print('fp16 backbone match-set IoU', iou)
     assert iou > 0.95
+
+
+def test_activation_range_recovery_end_to_end(model):
+    """A checkpoint whose activations leave the split-fp16 range of the default exponent (|a| > 4094): the stem's BatchNorm
+    scale and shift are multiplied by 2^13, so the first feature map reaches ~3e4 and everything downstream grows with it.
+    The reference's fp32 modules do not care; here the forward must notice (device flag), widen the range (activation
+    exponent 4 -> lower, unfused fine layers, exact-f32 K1 / K2), re-run, and return finite results that agree with the
+    vendor fp32 modules on the same weights -- not inf / NaN, not an empty match list."""
+    import copy
+    import warnings
+    from far_amd import ops
+    big = copy.deepcopy(model)
+    with torch.no_grad():
+        big.backbone.bn1.weight.mul_(2.0 ** 13)
+        big.backbone.bn1.bias.mul_(2.0 ** 13)
+    data1, _, _ = _batch(1, 5)
+    ops.overflow_flag('cuda').zero_()
+    with torch.no_grad(), warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter('always')
+        big(data1)
+        big.forward_rt_prediction(dict(data1, loftr_rt=torch.eye(3, 4, dtype=torch.float64, device='cuda'),
+                                       num_correspondences=torch.tensor([100], device='cuda'),
+                                       num_correspondences_before_ransac=torch.tensor([200], device='cuda'),
+                                       inliers_best_tight=torch.tensor([50], device='cuda'),
+                                       inliers_best_ultra_tight=torch.tensor([5], device='cuda')))
+    assert big.act_exp < 4 and any('activation' in str(w.message) for w in rec)
+    print('[range recovery] activation exponent after the re-run(s):', big.act_exp)
+    assert big.coarse_matching.variant == 'f32' and not big.loftr_fine.layers[0].fused_attn
+    for key in ('feats_c', 'featmap_f0', 'featmap0', 'expec_f', 'mkpts1_f', 'mconf'):
+        assert torch.isfinite(data1[key]).all(), key
+    assert len(data1['b_ids']) > 100
+    assert not ops.activation_overflowed('cuda')                     # the re-run left the flag clear
+    # the vendor fp32 modules on the same weights (the reference's arithmetic class) are the yardstick
+    bb = big.backbone
+    with torch.no_grad():
+        x = torch.cat([data1['image0'], data1['image1']], 0)
+        x1 = bb.layer1(bb.relu(bb.bn1(bb.conv1(x))))
+        x2 = bb.layer2(x1)
+        x3_out = bb.layer3_outconv(bb.layer3(x2))
+        fine = bb._fpn_plain(x1, x2, x3_out)
+    deviation('range recovery feats_c', data1['feats_c'], x3_out, atol=1e-4 * float(x3_out.abs().max()))
+    deviation('range recovery featmap_f', torch.cat([data1['featmap_f0'], data1['featmap_f1']], 0), fine, atol=1e-4 * float(fine.abs().max()))
+    assert float(x3_out.abs().max()) > 4094.0                        # the test does exercise the range
+    # a second batch runs at the widened setting without another re-run
+    data2, _, _ = _batch(1, 6)
+    with torch.no_grad(), warnings.catch_warnings(record=True) as rec2:
+        warnings.simplefilter('always')
+        big(data2)
+    assert not [w for w in rec2 if 'activation' in str(w.message)] and len(data2['b_ids']) > 100
