@@ -65,7 +65,7 @@ SIGNATURES = {
     'far_pose_pack_f64': (c_i, [c_p] * 8 + [c_i] + [c_p] * 6 + [c_p]),
     'far_pose_features_f32': (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p]),
     'far_solver_workspace_bytes': (c_sz, [c_i, c_i, c_i, c_i]),
-    'far_solver_f64': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_d, c_i, c_u32, c_p]
+    'far_solver_f64': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_d, c_i, c_i, c_u32, c_p]
                        + [c_p] * 14 + [c_p, c_p]),
 }
 

@@ -29,7 +29,7 @@ def _stale(target, deps):
 
 def build(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.h', '.inc'))]
     objs = []
     procs = []
     for src in sources():

@@ -56,10 +56,13 @@ class TrainerCfg:
 class RunCfg:
     """Minimal stand-in for the yacs node handed to compute_supervision_RT: config.TRAINER.*, config.LOFTR.SOLVER."""
 
-    def __init__(self, solver='prior_ransac', fine_pred_steps=2, resolution=(8, 2), fine_window_size=5):
+    def __init__(self, solver='prior_ransac', fine_pred_steps=2, resolution=(8, 2), fine_window_size=5, minimal_solver=8):
         self.TRAINER = TrainerCfg()
+        # MINIMAL_SOLVER (far_amd's own key, absent from the reference's config = 8): 8 = normalized 8-point hypotheses, the
+        # solver north_star names; 5 = Nister's five-point solver for every pair (what the reference EXECUTES is a five-point
+        # solver too -- OpenCV's; ransac.py:146-152).  Pairs with 5..7 correspondences use the five-point solver either way.
         self.LOFTR = type('L', (), {'SOLVER': solver, 'FINE_PRED_STEPS': fine_pred_steps, 'RESOLUTION': resolution,
-                                    'FINE_WINDOW_SIZE': fine_window_size})()
+                                    'FINE_WINDOW_SIZE': fine_window_size, 'MINIMAL_SOLVER': minimal_solver})()
 
     def __getitem__(self, key):                 # spvs_coarse / spvs_fine read config['LOFTR']['RESOLUTION'] (supervision.py:58, :151)
         node = getattr(self, key)

@@ -321,15 +321,36 @@ __device__ __forceinline__ void sample8(uint32_t seed, int b, int h, int M, cons
     }
 }
 
+// ransac.py:203-231: mean |[R|t] x - target| over the point cloud, min over R1 / R2; :397 -err^2 / lambda
+__device__ __forceinline__ double prior_score_of(const double (&Fe)[9], int b, const float* __restrict__ pcl,
+                                                 const double* __restrict__ tgt, int P, double lambda) {
+    double R1[9], R2[9], t[3];
+    decompose_E(Fe, R1, R2, t);
+    double e1 = 0.0, e2 = 0.0;
+    const double* tg = tgt + (size_t)b * P * 3;
+    for (int p = 0; p < P; ++p) {
+        const double x = pcl[p * 3], y = pcl[p * 3 + 1], z = pcl[p * 3 + 2];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const double g = tg[p * 3 + r];
+            e1 += fabs(R1[r * 3] * x + R1[r * 3 + 1] * y + R1[r * 3 + 2] * z + t[r] - g);
+            e2 += fabs(R2[r * 3] * x + R2[r * 3 + 1] * y + R2[r * 3 + 2] * z + t[r] - g);
+        }
+    }
+    const double err = fmin(e1, e2) / (3.0 * P);
+    return -(err * err) / lambda;
+}
+
 __global__ __launch_bounds__(64, 1) void k_hypotheses(
     const double4* __restrict__ kp, const int* __restrict__ offsets, const uint32_t* __restrict__ cdf_all,
-    const int* __restrict__ samples_in, int H, uint32_t seed, const PairPrior* __restrict__ pp,
+    const int* __restrict__ samples_in, int H, int minimal, uint32_t seed, const PairPrior* __restrict__ pp,
     const float* __restrict__ pcl, const double* __restrict__ tgt, int P, double lambda,
     double* __restrict__ F_all, double* __restrict__ pscore, int* __restrict__ samples_out) {
     const int b = blockIdx.y, h = blockIdx.x * blockDim.x + threadIdx.x;
     if (h >= H) return;
     const int o = offsets[b], M = offsets[b + 1] - o;
     const size_t hid = (size_t)b * H + h;
+    if (minimal == 5 || (M >= 5 && M < 8)) return;          // this pair's hypotheses come from k_hypotheses5
     if (M < 8) { pscore[hid] = -INFINITY; for (int e = 0; e < 9; ++e) F_all[hid * 9 + e] = 0.0; return; }
     int idx[8];
     if (samples_in) {
@@ -428,26 +449,11 @@ __global__ __launch_bounds__(64, 1) void k_hypotheses(
 #pragma unroll
     for (int e = 0; e < 9; ++e) F_all[hid * 9 + e] = Fe[e];
     double ps = 0.0;
-    if (valid && pp) {
-        // ransac.py:203-231: mean |[R|t] x - target| over the cloud, min over R1/R2; :397 -err^2 / lambda
-        double R1[9], R2[9], t[3];
-        decompose_E(Fe, R1, R2, t);
-        double e1 = 0.0, e2 = 0.0;
-        const double* tg = tgt + (size_t)b * P * 3;
-        for (int p = 0; p < P; ++p) {
-            const double x = pcl[p * 3], y = pcl[p * 3 + 1], z = pcl[p * 3 + 2];
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const double g = tg[p * 3 + r];
-                e1 += fabs(R1[r * 3] * x + R1[r * 3 + 1] * y + R1[r * 3 + 2] * z + t[r] - g);
-                e2 += fabs(R2[r * 3] * x + R2[r * 3 + 1] * y + R2[r * 3 + 2] * z + t[r] - g);
-            }
-        }
-        const double err = fmin(e1, e2) / (3.0 * P);
-        ps = -(err * err) / lambda;
-    }
+    if (valid && pp) ps = prior_score_of(Fe, b, pcl, tgt, P, lambda);
     pscore[hid] = valid ? ps : -INFINITY;
 }
+
+#include "solver5_f64.inc"
 
 // ---------------------------------------------------------------------------------------------
 // 3. verify: count Sampson inliers of every hypothesis (ransac.py:256-292)
@@ -489,7 +495,7 @@ __global__ void k_score(const double4* __restrict__ kp, const int* __restrict__ 
 // ---------------------------------------------------------------------------------------------
 __global__ void k_select(const double4* __restrict__ kp, const int* __restrict__ offsets,
                          const double* __restrict__ F_all, const double* __restrict__ score_all,
-                         const double* __restrict__ inl_th, int H, int many_thr, double min_score,
+                         const double* __restrict__ inl_th, int H, int many_thr, int minimal,
                          int* __restrict__ best_out, double* __restrict__ E_out, uint8_t* __restrict__ mask,
                          int* __restrict__ n_inl, int* __restrict__ n_tight, int* __restrict__ n_ultra,
                          int* __restrict__ status) {
@@ -514,7 +520,9 @@ __global__ void k_select(const double4* __restrict__ kp, const int* __restrict__
     }
     const double best_score = sv[0];
     const int best = si[0];
-    const bool ok = M >= 8 && best != 0x7fffffff && best_score > min_score;   // ransac.py:409
+    // ransac.py:353, :409: the best score must exceed the minimal sample size of the solver that produced the models
+    const bool five = minimal == 5 || M < 8;
+    const bool ok = M >= (five ? 5 : 8) && best != 0x7fffffff && best_score > (five ? 5.0 : 8.0);
     if (t < 3) cnt[t] = 0;
     __syncthreads();
     double F[9];
@@ -708,7 +716,7 @@ size_t far_solver_workspace_bytes(int B, int Mtot, int H, int P) { return carve(
 int far_solver_f64(const float* kpts0, const float* kpts1, const int* offsets, int B, int Mtot, int Mmax,
                    const double* K0, const double* K1, const double* inl_th, int many_thr,
                    const float* priorRT, const float* pcl, int P, double prior_lambda,
-                   int H, uint32_t seed, const int* samples_in,
+                   int H, int minimal, uint32_t seed, const int* samples_in,
                    double* R_out, double* t_out, double* E_out, uint8_t* mask_out, int* status_out,
                    int* num_after_out, int* n_tight_out, int* n_ultra_out, int* n_cheir_out, int* best_out,
                    double* F_all_out, int* count_all_out, double* score_all_out, int* samples_out,
@@ -716,7 +724,8 @@ int far_solver_f64(const float* kpts0, const float* kpts1, const int* offsets, i
     far_clear_errors();
     if (B <= 0) return FAR_OK;
     if (!offsets || !K0 || !K1 || !inl_th || !R_out || !t_out || !E_out || !status_out ||
-        !num_after_out || !n_tight_out || !n_ultra_out || !n_cheir_out || !best_out || !ws || H <= 0 || Mtot < 0)
+        !num_after_out || !n_tight_out || !n_ultra_out || !n_cheir_out || !best_out || !ws || H <= 0 || Mtot < 0 ||
+        (minimal != 8 && minimal != 5) || (minimal == 5 && H < 10))
         return FAR_EINVAL;
     // a batch in which no pair has a correspondence (Mtot == 0) is legal: every pair reports status 0 (metrics.py:83-85);
     // the per-correspondence arrays are then empty and may be null
@@ -734,13 +743,29 @@ int far_solver_f64(const float* kpts0, const float* kpts1, const int* offsets, i
     double* F_all = F_all_out ? F_all_out : w.F_all;
     int* count_all = count_all_out ? count_all_out : w.count_all;
     double* score_all = score_all_out ? score_all_out : w.score_all;
-    hipLaunchKernelGGL(k_hypotheses, dim3((H + 63) / 64, B), dim3(64), 81 * 64 * sizeof(double), stream, w.kp, offsets,
-                       (prior && !samples_in) ? w.cdf : nullptr, samples_in, H, seed, prior ? w.pp : nullptr, pcl, w.tgt,
-                       P, prior_lambda, F_all, w.pscore, samples_out);
+    // hypotheses: the normalized 8-point for pairs with >= 8 correspondences (minimal = 8), the five-point solver for pairs
+    // with 5..7 -- and for every pair when minimal = 5.  Explicit samples (tests) follow the mode: [B][H][8] or [B][H/10][5].
+    const int* s8 = minimal == 8 ? samples_in : nullptr;
+    const int* s5 = minimal == 5 ? samples_in : nullptr;
+    if (minimal == 8)
+        hipLaunchKernelGGL(k_hypotheses, dim3((H + 63) / 64, B), dim3(64), 81 * 64 * sizeof(double), stream, w.kp, offsets,
+                           (prior && !samples_in) ? w.cdf : nullptr, s8, H, minimal, seed, prior ? w.pp : nullptr, pcl, w.tgt,
+                           P, prior_lambda, F_all, w.pscore, minimal == 8 ? samples_out : nullptr);
+    {
+        const int H5 = H / 10 > 0 ? H / 10 : 1;
+        constexpr int smem5 = 200 * 64 * sizeof(double);
+        bool cfg_failed = false;
+        FAR_ONCE_PER_DEVICE(cfg_failed = hipFuncSetAttribute((const void*)k_hypotheses5, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                             smem5) != hipSuccess);
+        if (cfg_failed) return far_check_launch();
+        hipLaunchKernelGGL(k_hypotheses5, dim3((H5 + 63) / 64, B), dim3(64), smem5, stream, w.kp, offsets,
+                           (prior && !samples_in) ? w.cdf : nullptr, s5, H, minimal, seed, prior ? w.pp : nullptr, pcl, w.tgt,
+                           P, prior_lambda, F_all, w.pscore, minimal == 5 ? samples_out : nullptr);
+    }
     hipLaunchKernelGGL(k_score, dim3((H + 255) / 256, B), dim3(256), 0, stream, w.kp, offsets, F_all, w.pscore, inl_th, H,
                        count_all, score_all);
     hipLaunchKernelGGL(k_select, dim3(B), dim3(256), 0, stream, w.kp, offsets, F_all, score_all, inl_th, H, many_thr,
-                       8.0, best_out, E_out, mask_out, w.n_inl, n_tight_out, n_ultra_out, w.status_sel);
+                       minimal, best_out, E_out, mask_out, w.n_inl, n_tight_out, n_ultra_out, w.status_sel);
     hipLaunchKernelGGL(k_recover, dim3(B), dim3(256), 0, stream, w.kn, offsets, E_out, w.status_sel, 1e9, mask_out,
                        w.bits, R_out, t_out, n_cheir_out, num_after_out, status_out);
     return far_check_launch();

@@ -178,7 +178,8 @@ def compute_pose_errors(data, config, estimate_pose_fn=None, H=2048, seed=0):
                     data['num_correspondences_after_ransac'].append(n_after)
         else:
             pr = None if prior is None else np.array(np.broadcast_to(prior.reshape(-1, 3, 4), (B, 3, 4)))
-            out = estimate_pose_batch(pts0, pts1, counts, K0, K1, pixel_thr, solver, pr, H=H, seed=seed)
+            out = estimate_pose_batch(pts0, pts1, counts, K0, K1, pixel_thr, solver, pr, H=H, seed=seed,
+                                      minimal=getattr(config.LOFTR, 'MINIMAL_SOLVER', 8))
             status = out['status'].cpu().numpy().astype(bool)
             n_after = out['num_after'].cpu()
             mask = out['mask'].cpu().numpy() > 0

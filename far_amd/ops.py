@@ -427,9 +427,11 @@ def linear_train(x, weight, bias, cache, name, split=True):
 
 
 def solve_pose_batch(kpts0, kpts1, offsets_host, K0, K1, inl_th, many_thr, priorRT=None, pcl=None,
-                     prior_lambda=0.3, H=2048, seed=0, samples=None, debug=False):
+                     prior_lambda=0.3, H=2048, seed=0, samples=None, debug=False, minimal=8):
     """K4.  kpts0/kpts1: (Mtot, 2) fp32 GPU; offsets_host: python list / CPU int tensor of B+1 offsets;
     K0/K1: (B, 3, 3) float64 GPU; inl_th: (B,) float64 GPU; priorRT: (B, 3, 4) fp32 GPU or None.
+    minimal: 8 = normalized 8-point hypotheses (pairs with 5..7 correspondences: five-point), 5 = Nister's five-point solver
+    for every pair; H = models verified per pair (a five-point sample yields up to ten: H // 10 samples).
     Returns a dict of GPU tensors (R, t, E float64; mask uint8; status/num_after/tight/ultra/n_cheir/best int32)."""
     lib = _lib.load()
     dev = K0.device
@@ -451,11 +453,12 @@ def solve_pose_batch(kpts0, kpts1, offsets_host, K0, K1, inl_th, many_thr, prior
     dbg = {}
     if debug:
         dbg = {'F_all': torch.empty(B, H, 3, 3, dtype=f64, device=dev), 'count_all': torch.empty(B, H, dtype=i32, device=dev),
-               'score_all': torch.empty(B, H, dtype=f64, device=dev), 'samples': torch.empty(B, H, 8, dtype=i32, device=dev)}
+               'score_all': torch.empty(B, H, dtype=f64, device=dev),
+               'samples': torch.full((B, H, 8) if minimal == 8 else (B, max(H // 10, 1), 5), -1, dtype=i32, device=dev)}
     rc = lib.far_solver_f64(
         _p(kpts0, torch.float32) if Mtot else ctypes.c_void_p(0), _p(kpts1, torch.float32) if Mtot else ctypes.c_void_p(0),
         _p(offs_d), B, Mtot, Mmax, _p(K0.contiguous(), f64), _p(K1.contiguous(), f64), _p(inl_th, f64), int(bool(many_thr)),
-        _p(priorRT, torch.float32), _p(pcl, torch.float32), P, float(prior_lambda), int(H), int(seed) & 0xffffffff,
+        _p(priorRT, torch.float32), _p(pcl, torch.float32), P, float(prior_lambda), int(H), int(minimal), int(seed) & 0xffffffff,
         _p(samples, torch.int32),
         _p(out['R']), _p(out['t']), _p(out['E']), _p(out['mask']), _p(out['status']), _p(out['num_after']),
         _p(out['tight']), _p(out['ultra']), _p(out['n_cheir']), _p(out['best']),

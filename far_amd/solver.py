@@ -5,8 +5,10 @@ Dispatch mirrors the reference:
   solver == 'prior_ransac' and priorRT is not None -> prior RANSAC (inl_th 3e-7, biased sampling, prior score)
   solver == 'prior_ransac_noprior'                 -> same machinery without prior
   otherwise ('ransac', or 'prior_ransac' w/o prior) -> plain RANSAC with the cv2 threshold semantics
-The minimal solver is the normalized 8-point on the GPU in every branch (the reference executes OpenCV's 5-point
-on the host; see DESIGN.md "K4" for what parity means here).
+The minimal solver is the normalized 8-point on the GPU in every branch by default (the reference executes OpenCV's
+5-point on the host; see DESIGN.md "K4" for what parity means here); pairs with 5..7 correspondences -- and every pair
+with minimal=5 -- get hypotheses from Nister's five-point solver (far_amd/csrc/solver5_f64.inc), which is not degenerate
+on planar scenes.
 """
 import numpy as np
 import torch
@@ -35,7 +37,7 @@ def _branch(solver, has_prior):
     return 'ransac'
 
 
-def estimate_pose_batch(kpts0, kpts1, counts, K0, K1, thresh, solver='ransac', priorRT=None, H=2048, seed=0):
+def estimate_pose_batch(kpts0, kpts1, counts, K0, K1, thresh, solver='ransac', priorRT=None, H=2048, seed=0, minimal=8):
     """kpts0/kpts1: (Mtot, 2) fp32 GPU, concatenated per pair in order; counts: per-pair M (host ints);
     K0/K1: (B, 3, 3); priorRT: None or (B, 3, 4) numpy/tensor.  Returns the dict of ops.solve_pose_batch."""
     dev = kpts0.device
@@ -56,18 +58,19 @@ def estimate_pose_batch(kpts0, kpts1, counts, K0, K1, thresh, solver='ransac', p
         prior = torch.as_tensor(np.asarray(priorRT), dtype=torch.float32).reshape(-1, 3, 4).to(dev).contiguous()
         pcl = prior_point_cloud(dev)
     return ops.solve_pose_batch(kpts0.float().contiguous(), kpts1.float().contiguous(), offs, K0d, K1d,
-                                inl_th.contiguous(), many, priorRT=prior, pcl=pcl, prior_lambda=0.3, H=H, seed=seed)
+                                inl_th.contiguous(), many, priorRT=prior, pcl=pcl, prior_lambda=0.3, H=H, seed=seed,
+                                minimal=minimal)
 
 
 def estimate_pose(kpts0, kpts1, K0, K1, thresh, conf=0.99999, translation_scale=None, solver='ransac',
-                  priorRT=None, H=2048, seed=0):
+                  priorRT=None, H=2048, seed=0, minimal=8):
     """Single-pair form with the reference's return contract:
     (ret, num_correspondences_after_ransac, inliers_best_tight, inliers_best_ultra_tight) where
     ret is None or (R: f64 (3,3) on device, t: f64 (3,), mask: np.bool (M,), E: cpu f64 (3,3))."""
     if len(kpts0) < 5:                                                                        # :83-85
         return None, 0, 0, 0
     out = estimate_pose_batch(kpts0, kpts1, [len(kpts0)], K0[None], K1[None], thresh, solver,
-                              None if priorRT is None else np.asarray(priorRT)[None], H=H, seed=seed)
+                              None if priorRT is None else np.asarray(priorRT)[None], H=H, seed=seed, minimal=minimal)
     host = {k: out[k].cpu() for k in ['status', 'num_after', 'tight', 'ultra']}
     num_after = int(host['num_after'][0])
     tight, ultra = int(host['tight'][0]), int(host['ultra'][0])

@@ -362,6 +362,14 @@ int far_pose_features_f32(const double* rt, int B, const void* cnt0, int elem_by
  * ------------------------------------------------------------------------------------------------- */
 size_t far_solver_workspace_bytes(int B, int Mtot, int H, int P);
 
+/* Minimal solvers (`minimal`).  8: the normalized 8-point of cv_geometry.py:772-833 (RANSAC model_type 'fundamental',
+ *   ransac.py:140-145: sample size 8, score floor 8) for pairs with >= 8 correspondences; pairs with 5..7 -- which the
+ *   reference accepts (metrics.py:83-85) and only a five-point solver can fit -- get five-point hypotheses.
+ *   5: Nister's five-point solver for every pair (cv_geometry.py:861-1043 run_5point_our_kornia, RANSAC model_type 'essential',
+ *   ransac.py:146-150: sample size 5, score floor 5): H / 10 samples, up to ten essential matrices each, model 10 s + k =
+ *   real root k of sample s (H >= 10).  Unlike the 8-point it is not degenerate on coplanar correspondences.
+ *   H counts the MODELS verified per pair in both modes. */
+
 /* B pairs; pair b owns correspondences [offsets[b], offsets[b+1]) of the concatenated arrays.
  *   kpts0, kpts1  [Mtot][2] fp32 pixel coordinates (mkpts0_f / mkpts1_f); offsets [B+1] int32; Mmax = max count
  *   K0, K1        [B][9] float64 row-major intrinsics
@@ -375,12 +383,12 @@ size_t far_solver_workspace_bytes(int B, int Mtot, int H, int P);
  *   also pass cheirality, as cv2.recoverPose leaves its in/out mask); status_out [B] (1 = pose valid, 0 = the
  *   reference's `ret is None`); num_after_out, n_tight_out, n_ultra_out, n_cheir_out, best_out [B] int32.
  *   Optional debug outputs (NULL to skip): F_all_out [B][H][9], count_all_out [B][H], score_all_out [B][H],
- *   samples_out [B][H][8].  Mtot == 0 (no pair has a correspondence) is legal: kpts0 / kpts1 / mask_out may then be
+ *   samples_out [B][H][8] (minimal = 5: samples_in / samples_out are [B][H / 10][5]).  Mtot == 0 (no pair has a correspondence) is legal: kpts0 / kpts1 / mask_out may then be
  *   NULL and every pair reports status 0. */
 int far_solver_f64(const float* kpts0, const float* kpts1, const int* offsets, int B, int Mtot, int Mmax,
                    const double* K0, const double* K1, const double* inl_th, int many_thr,
                    const float* priorRT, const float* pcl, int P, double prior_lambda,
-                   int H, uint32_t seed, const int* samples_in,
+                   int H, int minimal, uint32_t seed, const int* samples_in,
                    double* R_out, double* t_out, double* E_out, uint8_t* mask_out, int* status_out,
                    int* num_after_out, int* n_tight_out, int* n_ultra_out, int* n_cheir_out, int* best_out,
                    double* F_all_out, int* count_all_out, double* score_all_out, int* samples_out,

@@ -15,7 +15,9 @@ golden vectors from the reference's run_8point / decompose_essential_matrix / RA
 
 Deliberate, documented differences from what the reference EXECUTES:
   * minimal solver = the reference's own normalized 8-point `run_8point` on 8-point samples, in place of
-    OpenCV's 5-point (`run_5point_cv2`, cv2 absent and not reproducible);
+    OpenCV's 5-point (`run_5point_cv2`, cv2 absent and not reproducible); pairs with 5..7 correspondences, and every pair
+    when minimal = 5 is asked for, use Nister's five-point solver (oracle/fivepoint.py: the algorithm of the reference's torch
+    variant run_5point_our_kornia, restated from the paper because kornia.geometry.solvers is absent);
   * sampling uses a counter-based integer hash (sample_indices below) instead of numpy's MT19937 /
     torch.rand: same distributions (uniform without replacement; biased with replacement), own stream;
   * hypotheses whose sample repeats a correspondence are rejected (see estimate_pose);
@@ -259,9 +261,13 @@ def normalize_keypoints(kpts0, kpts1, K0, K1):
 
 
 def estimate_pose(kpts0, kpts1, K0, K1, thresh, solver='ransac', priorRT=None, seed=0, pair=0, H=2048,
-                  pcl=None, samples=None):
+                  pcl=None, samples=None, minimal=8):
     """Mirror of metrics.py:80-174.  Returns (ret, num_after, inl_tight, inl_ultra, debug) where
-    ret = None | (R (3,3), t (3,), mask (M,) bool, E (3,3))."""
+    ret = None | (R (3,3), t (3,), mask (M,) bool, E (3,3)).
+    minimal: 8 = normalized 8-point hypotheses (the default; pairs with 5..7 correspondences use the five-point solver, the
+    only one that can fit them -- the reference's gate is len(kpts0) >= 5, metrics.py:83-85); 5 = Nister five-point
+    hypotheses for every pair (ransac.py:146-150 model_type 'essential': sample size 5, score floor 5).  H is the number of
+    MODELS verified per pair in both cases: a five-point sample yields up to ten, so H // 10 samples are drawn."""
     M = len(kpts0)
     if M < 5:                                                        # :83-85
         return None, 0, 0, 0, {}
@@ -282,19 +288,33 @@ def estimate_pose(kpts0, kpts1, K0, K1, thresh, solver='ransac', priorRT=None, s
         w = np.exp(-d / 0.1)                                         # :366 (bias_sigma_sq = 0.1)
         w = np.where(np.isfinite(w), w, 0.0)
         wq = quantize_weights(w)
-    if samples is None:
-        if M < 8:
-            return None, 0, 0, 0, {}
-        samples = sample_indices(seed, pair, H, M, 8, wq)
-    F = run_8point(kp1[samples], kp2[samples])                       # (H,3,3)
-    diag = np.abs(np.stack([F[:, 0, 0], F[:, 1, 1], F[:, 2, 2]], 1))
-    valid = np.nan_to_num(diag, nan=0.0).min(1) > 1e-4               # ransac.py:306-307
-    valid &= np.isfinite(F).all((1, 2))
-    # a sample that repeats a correspondence (possible under biased sampling WITH replacement, ransac.py:169-171)
-    # gives a rank-deficient system whose "null vector" is an arbitrary member of a >=2-dim null space (LAPACK
-    # dependent in the reference): rejected here so that the result is well defined.
-    ssort = np.sort(samples, axis=1)
-    valid &= ~(ssort[:, 1:] == ssort[:, :-1]).any(1)
+    five = minimal == 5 or (M < 8 and samples is None) or (samples is not None and np.asarray(samples).shape[1] == 5)
+    min_score = 5.0 if five else 8.0                                 # ransac.py:353: best_score_total = minimal_sample_size
+    if five:
+        from .fivepoint import five_point
+        if samples is None:
+            samples = sample_indices(seed, pair, max(H // 10, 1), M, 5, wq)
+        E5, v5 = five_point(kp1[samples], kp2[samples])              # (H5, 10, 3, 3), (H5, 10)
+        ssort = np.sort(samples, axis=1)
+        v5 = v5 & ~(ssort[:, 1:] == ssort[:, :-1]).any(1)[:, None]
+        F = E5.reshape(-1, 3, 3)                                     # model 10 s + k = root k of sample s
+        valid = v5.reshape(-1)
+        diag = np.abs(np.stack([F[:, 0, 0], F[:, 1, 1], F[:, 2, 2]], 1))
+        valid = valid & (diag.min(1) > 1e-4)                         # ransac.py:306-307
+    else:
+        if samples is None:
+            samples = sample_indices(seed, pair, H, M, 8, wq)
+        F = run_8point(kp1[samples], kp2[samples])                   # (H,3,3)
+        diag = np.abs(np.stack([F[:, 0, 0], F[:, 1, 1], F[:, 2, 2]], 1))
+        valid = np.nan_to_num(diag, nan=0.0).min(1) > 1e-4           # ransac.py:306-307
+        valid &= np.isfinite(F).all((1, 2))
+        # a sample that repeats a correspondence (possible under biased sampling WITH replacement, ransac.py:169-171)
+        # gives a rank-deficient system whose "null vector" is an arbitrary member of a >=2-dim null space (LAPACK
+        # dependent in the reference): rejected here so that the result is well defined.
+        ssort = np.sort(samples, axis=1)
+        valid &= ~(ssort[:, 1:] == ssort[:, :-1]).any(1)
+    if five:
+        F = np.where(valid[:, None, None], F, 0.0)                   # the kernel stores zeros in the slots of rejected models
     err = sampson_distance(kp1, kp2, F)                              # (H,M)  ransac.py:273-276
     count = (err <= inl_th).sum(1)
     score = count.astype(np.float64)
@@ -309,7 +329,7 @@ def estimate_pose(kpts0, kpts1, K0, K1, thresh, solver='ransac', priorRT=None, s
         return None, 0, 0, 0, dbg
     best = int(np.argmax(score))                                     # first max
     dbg['best'] = best
-    if not score[best] > 8.0:                                        # ransac.py:409 (best_score_total init)
+    if not score[best] > min_score:                                  # ransac.py:409 (best_score_total init)
         return None, 0, 0, 0, dbg
     E = F[best]
     mask = err[best] <= inl_th

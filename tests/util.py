@@ -223,3 +223,47 @@ def eval_metrics_table(seed=82, n=23):
     epi[5] = np.zeros(0)
     return {'identifiers': ids, 'epi_errs': epi, 'R_errs': list(R), 't_errs': list(t), 't_errs_abs': list(rng.gamma(2.0, 0.5, n)),
             'successful_fits': list((rng.uniform(size=n) < 0.8).astype(np.int64))}
+
+
+def planar_scene(M, seed, kind, noise=0.3, outl=0.2, K=None):
+    """Two-view correspondences (pixels, float32) of a scene that is 'general' (depths 2..8), 'two_planes' (a wall and a
+    floor) or one slanted 'plane' -- the configuration on which the normalized 8-point is degenerate.  Returns kpts0, kpts1,
+    R_gt, t_gt (unit)."""
+    rng = np.random.default_rng(seed)
+    if K is None:
+        K = np.array([[517.97, 0, 320.], [0, 517.97, 240.], [0, 0, 1.]])
+    ang = rng.uniform(-0.3, 0.3, 3)
+    cx, sx, cy, sy, cz, sz = np.cos(ang[0]), np.sin(ang[0]), np.cos(ang[1]), np.sin(ang[1]), np.cos(ang[2]), np.sin(ang[2])
+    R = (np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]]) @ np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+         @ np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]]))
+    t = rng.uniform(-1, 1, 3)
+    t[2] *= 0.3
+    n = 6 * M + 40
+    xy = np.stack([rng.uniform(-3, 3, n), rng.uniform(-2, 2, n)], 1)
+    if kind == 'general':
+        z = rng.uniform(2, 8, n)
+    elif kind == 'plane':
+        nrm = np.array([0.2, -0.1, 1.0])
+        z = (4.0 - nrm[0] * xy[:, 0] - nrm[1] * xy[:, 1]) / nrm[2]
+    elif kind == 'two_planes':
+        wall = rng.uniform(size=n) < 0.7
+        z = np.where(wall, 5.0 + 0.3 * xy[:, 0], rng.uniform(2, 6, n))
+        xy[~wall, 1] = 1.5
+    else:
+        raise ValueError(kind)
+    X = np.stack([xy[:, 0], xy[:, 1], z], 1)
+    X2 = X @ R.T + t
+    p0 = X @ K.T
+    p0 = p0[:, :2] / p0[:, 2:]
+    p1 = X2 @ K.T
+    p1 = p1[:, :2] / p1[:, 2:]
+    ok = (X2[:, 2] > 0.5) & (X[:, 2] > 0.5) & (p0[:, 0] > 0) & (p0[:, 0] < 640) & (p0[:, 1] > 0) & (p0[:, 1] < 480) \
+        & (p1[:, 0] > 0) & (p1[:, 0] < 640) & (p1[:, 1] > 0) & (p1[:, 1] < 480)
+    p0, p1 = p0[ok][:M], p1[ok][:M]
+    M = len(p0)
+    p1 = p1 + noise * rng.standard_normal(p1.shape)
+    no = int(outl * M)
+    if no:
+        idx = rng.choice(M, no, replace=False)
+        p1[idx] = np.stack([rng.uniform(0, 640, no), rng.uniform(0, 480, no)], 1)
+    return p0.astype(np.float32), p1.astype(np.float32), R, t / np.linalg.norm(t)
