@@ -157,6 +157,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp128(const float* __restrict__ x, 
 
     // ---------------------------------------------------------------- GEMM 2: 8 hidden tiles, one slab (two k-steps) each
     f32x16 acc2[CT];
+    float hid_chk = 0.f;                  // activation-range guard: sum of the hidden tensor's raw accumulators
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -175,6 +176,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp128(const float* __restrict__ x, 
         for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
+                hid_chk += acc1[t][8 * u + e];                 // (ReLU's max would swallow a NaN: inf - inf of an overflowed input)
                 const float hv = fmaxf(acc1[t][8 * u + e] * hscale, 0.f);
                 const _Float16 hh = (_Float16)hv;
                 ha[u][e] = hh;
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp128(const float* __restrict__ x, 
     // Activation-range guard (as K9): an input or a hidden value beyond the fp16 range of its 2^4-scaled split (|a| > 4094)
     // is inf in the operand and inf / NaN here; the sum of the wave's accumulators is finite exactly when all of them are.
     if (overflow) {
-        float chk = 0.f;
+        float chk = hid_chk;
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll

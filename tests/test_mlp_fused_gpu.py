@@ -125,7 +125,9 @@ def test_mlp_fused_overflow_is_reported():
     xb = x.clone()
     xb[0, 77, 5] = 6000.0
     y = ops.mlp_fused(xb, m, ops.PackedMlp(w0, w2), gam, bet, 1e-5)
-    assert not torch.isfinite(y[0, 77]).any() and torch.isfinite(y[0, :64]).all()
+    # (the row's hidden values are NaN = inf - inf, which ReLU's max turns into 0: the OUTPUT row is finite and wrong -- which
+    #  is why the hidden accumulators are part of the test the kernel makes, not only its outputs)
+    assert torch.isfinite(y[0, :64]).all()
     assert ops.activation_overflowed('cuda')
     w0b = w0 * 400.0                                                   # hidden = relu(W0 [x | msg]) reaches ~ 400 * 4 sigma > 4094
     y = ops.mlp_fused(x * 4, m * 4, ops.PackedMlp(w0b, w2), gam, bet, 1e-5)
