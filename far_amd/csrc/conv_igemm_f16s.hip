@@ -283,7 +283,10 @@ __device__ __forceinline__ void arrived(float4& v) { asm volatile("" : "+v"(v.x)
 // workgroup (the main loop's LDS buffers are dead).
 template <int KS, int NW, bool UP>
 __device__ __forceinline__ void conv_epilogue_wide(const ConvArgs& p, const f32x16 (&acc)[2][4], const TilePos& tp,
-                                                   int cout_w, int wm, int wave, int lane, float* lw, float* xch) {
+                                                   int cout_w, int wm, int wave, int lane, float* lw, float* xch,
+                                                   int mask_mt = -1, int mask_lo = 0, int mask_hi = 0) {
+    // mask_mt >= 0 (N7 mode): in pixel tile mask_mt the lanes mask_lo <= l31 < mask_hi (four channels each) hold a tile this
+    // wave did not compute: they neither load nor store
     const int l31 = lane & 31, h = lane >> 5;
     const float* __restrict__ resp = p.res;
     float* __restrict__ yp = p.y;
@@ -295,11 +298,13 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvArgs& p, const f32x
         sh[nt] = (co < p.Cout && p.shift) ? p.shift[co] : 0.f;
     }
     const int co4 = cout_w + 4 * l31;                      // this lane's 4 channels in the store phase
-    const bool cok = co4 < p.Cout;
-    const int plane = cok ? co4 / p.Csub : 0;
+    const bool cok_all = co4 < p.Cout;
+    const bool lane_masked = l31 >= mask_lo && l31 < mask_hi;
+    const int plane = cok_all ? co4 / p.Csub : 0;
     const long cbase = (long)plane * p.npix * p.Csub + (co4 - plane * p.Csub);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
+        const bool cok = cok_all && !(mt == mask_mt && lane_masked);
         const int mtile = 2 * wm + mt;
         long pix0;
         int nrow, ncol;
@@ -505,8 +510,13 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvArgs& p, const f32x
 }
 
 // Workgroup = MW x NW waves: wave (wm, wn) owns 64 pixels (4 tile rows x 16) x 32 NTW output channels.
-template <int KS, int MW, int NW, int NTW, bool SPLIT, int ST, bool UP = false>
-__global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const ConvArgs p) {
+// N7 (2 x 2 wave layout, 192 < Cout <= 224, e.g. the 196-channel layers): the workgroup covers SEVEN 32-channel tiles
+// instead of eight.  Wave column wn = 0 owns tiles 0..3, wn = 1 tiles 3..6; the shared tile 3 is computed by wn = 0 for its
+// first 32-pixel tile (mt = 0) and by wn = 1 for its second (mt = 1), so that every wave issues 7 of the 8 MFMA triples of a
+// k-step: 12.5 % fewer MFMAs, evenly over the four SIMDs (dropping the all-padding eighth tile from the wn = 1 waves alone
+// leaves the SIMDs of the wn = 0 waves as the bottleneck: measured in round 1, -2 %).
+template <int KS, int MW, int NW, int NTW, bool SPLIT, int ST, bool UP, bool N7, int WN>
+__device__ __forceinline__ void conv_body(const ConvArgs& p) {
     using G = Geo<KS, MW, ST>;
     constexpr int NTHR = 64 * MW * NW;
     constexpr int PLANES = SPLIT ? 2 : 1;
@@ -555,7 +565,8 @@ __global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const 
         tp.oy0 = ty * G::TH;
         tp.ox0 = tx * TW;
     }
-    const int cout_w = by * NT + 32 * NTW * wn;                       // first output channel of this wave
+    static_assert(!N7 || (NW == 2 && NTW == 4), "N7 is a mode of the 2 x 2 wave layout");
+    const int cout_w = by * NT + (N7 ? 96 : 32 * NTW) * wn;          // first output channel of this wave
 
     // ---- weight slabs, stored in execution order [chunk][tap][k-step][cout block]: the LDS-DMA source pointer of
     // the prefetch just advances by one slab per phase (two when the all-padding last k-step is skipped).
@@ -590,7 +601,7 @@ __global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const 
         else a_off[mt] = G::px_off(ST * (2 * mtile + (l31 >> 4)), ST * (l31 & 15)) + h * 16;
     }
     // weight row n of the slab: 2 slots of 8 channels, slot ^= (n >> 3) & 1 (conflict-free fragment reads)
-    const int b_off = (32 * NTW * wn + l31) * 32 + ((h ^ ((l31 >> 3) & 1)) * 16);
+    const int b_off = ((N7 ? 96 : 32 * NTW) * wn + l31) * 32 + ((h ^ ((l31 >> 3) & 1)) * 16);
 
     f32x16 acc[2][NTW];
 #pragma unroll
@@ -633,30 +644,37 @@ __global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const 
             bl[half][q] = *reinterpret_cast<const f16x8*>(B + B_PLANE + (grp * NH + q) * 32 * 32);
         }
     };
+    // (WN: the wave column as a compile-time constant in N7 mode -- the skipped tile depends on it -- and 0 otherwise)
     auto mma_half = [&](int grp) {
         const int half = grp & 1;
+        // N7: wn = 0 leaves out (mt 1, tile 3), wn = 1 leaves out (mt 0, tile 0) -- the half of the shared tile the other column computes
+        auto live = [&](int mt, int nt) { return !N7 || (WN == 0 ? !(mt == 1 && nt == 3) : !(mt == 0 && nt == 0)); };
 #pragma unroll
         for (int q = 0; q < NH; ++q)
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
-                acc[mt][grp * NH + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[half][q], acc[mt][grp * NH + q], 0, 0, 0);
+                if (live(mt, grp * NH + q))
+                    acc[mt][grp * NH + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[half][q], acc[mt][grp * NH + q], 0, 0, 0);
         if (SPLIT) {
 #pragma unroll
             for (int q = 0; q < NH; ++q)
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
-                    acc[mt][grp * NH + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[half][q], acc[mt][grp * NH + q], 0, 0, 0);
+                    if (live(mt, grp * NH + q))
+                        acc[mt][grp * NH + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[half][q], acc[mt][grp * NH + q], 0, 0, 0);
 #pragma unroll
             for (int q = 0; q < NH; ++q)
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
-                    acc[mt][grp * NH + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[half][q], acc[mt][grp * NH + q], 0, 0, 0);
+                    if (live(mt, grp * NH + q))
+                        acc[mt][grp * NH + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[half][q], acc[mt][grp * NH + q], 0, 0, 0);
         } else {                                   // second k-step of the chunk: its own pixel and weight fragments
 #pragma unroll
             for (int q = 0; q < NH; ++q)
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
-                    acc[mt][grp * NH + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bl[half][q], acc[mt][grp * NH + q], 0, 0, 0);
+                    if (live(mt, grp * NH + q))
+                        acc[mt][grp * NH + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bl[half][q], acc[mt][grp * NH + q], 0, 0, 0);
         }
     };
 
@@ -698,7 +716,7 @@ __global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const 
                 // issue order: one MFMA, then the other instructions of the phase (LDS reads, the DMA requests and
                 // their address arithmetic) in the issue slots its 32-cycle pass leaves free
 #pragma unroll
-                for (int i = 0; i < (SPLIT ? 6 : 4) * NTW; ++i) {
+                for (int i = 0; i < (N7 ? (SPLIT ? 21 : 14) : (SPLIT ? 6 : 4) * NTW); ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // DS read
                     __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // VMEM read (LDS-DMA, pixel loads)
@@ -736,8 +754,14 @@ __global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const 
     }
     if (NTW == 4 && ((p.Cout | p.Csub) & 3) == 0) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave is past its last LDS fragment read
-        conv_epilogue_wide<KS, NW, UP>(p, acc, tp, cout_w, wm, wave, lane, reinterpret_cast<float*>(smem) + wave * (32 * 128),
-                                   reinterpret_cast<float*>(smem) + MW * NW * (32 * 128));
+        // N7: channels 96..127 of the workgroup (the shared tile) are stored by wn = 0 for mt = 0 and by wn = 1 for mt = 1
+        if constexpr (N7)
+            conv_epilogue_wide<KS, NW, UP>(p, acc, tp, cout_w, wm, wave, lane, reinterpret_cast<float*>(smem) + wave * (32 * 128),
+                                           reinterpret_cast<float*>(smem) + MW * NW * (32 * 128), wn == 0 ? 1 : 0,
+                                           wn == 0 ? 24 : 0, wn == 0 ? 32 : 8);
+        else
+            conv_epilogue_wide<KS, NW, UP>(p, acc, tp, cout_w, wm, wave, lane, reinterpret_cast<float*>(smem) + wave * (32 * 128),
+                                           reinterpret_cast<float*>(smem) + MW * NW * (32 * 128));
     } else {
         conv_epilogue<KS, NTW>(p, acc, tp, cout_w, wm, l31, h);
     }
@@ -747,6 +771,16 @@ __global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const 
     FAR_K9_STAMP(4);                                   // stores acknowledged
     if (threadIdx.x == 0 && blockIdx.x < 65536) g_k9_stamps[12 * blockIdx.x + 9] = __builtin_amdgcn_s_memrealtime();
 #endif
+}
+
+template <int KS, int MW, int NW, int NTW, bool SPLIT, int ST, bool UP = false, bool N7 = false>
+__global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const ConvArgs p) {
+    if constexpr (N7) {                       // two copies of the body, one per wave column: which tile a wave skips is static
+        if (((threadIdx.x >> 6) % NW) == 1) conv_body<KS, MW, NW, NTW, SPLIT, ST, UP, N7, 1>(p);
+        else conv_body<KS, MW, NW, NTW, SPLIT, ST, UP, N7, 0>(p);
+    } else {
+        conv_body<KS, MW, NW, NTW, SPLIT, ST, UP, N7, 0>(p);
+    }
 }
 
 // Packs torch-layout weights [Cout][Cin][KS][KS] (or [Cout][Cin] for linear) into the LDS image the kernel DMAs, in
@@ -790,7 +824,7 @@ inline TileCfg cfg_for(int Cout, int stride) {
     return (stride == 1 && pad128 < pad256) ? TileCfg{4, 1, 128} : TileCfg{2, 2, 256};
 }
 
-template <int KS, int MW, int NW, int NTW, bool SPLIT, int ST = 1, bool UP = false>
+template <int KS, int MW, int NW, int NTW, bool SPLIT, int ST = 1, bool UP = false, bool N7 = false>
 int launch_conv(const ConvArgs& a, dim3 grid, hipStream_t stream) {
     using G = Geo<KS, MW, ST>;
     constexpr int PLANES = SPLIT ? 2 : 1;
@@ -798,10 +832,10 @@ int launch_conv(const ConvArgs& a, dim3 grid, hipStream_t stream) {
     constexpr int smem_epi = MW * NW * (32 * 128 * 4 + 32 * 4);  // conv_epilogue_wide: 16 KiB per wave + LayerNorm exchange
     constexpr int smem = smem_loop > smem_epi ? smem_loop : smem_epi;
     bool cfg_failed = false;
-    FAR_ONCE_PER_DEVICE(cfg_failed = hipFuncSetAttribute((const void*)k_conv<KS, MW, NW, NTW, SPLIT, ST, UP>,
+    FAR_ONCE_PER_DEVICE(cfg_failed = hipFuncSetAttribute((const void*)k_conv<KS, MW, NW, NTW, SPLIT, ST, UP, N7>,
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess);
     if (cfg_failed) return far_check_launch();
-    hipLaunchKernelGGL((k_conv<KS, MW, NW, NTW, SPLIT, ST, UP>), grid, dim3(64 * MW * NW), smem, stream, a);
+    hipLaunchKernelGGL((k_conv<KS, MW, NW, NTW, SPLIT, ST, UP, N7>), grid, dim3(64 * MW * NW), smem, stream, a);
     return far_check_launch();
 }
 
@@ -812,6 +846,11 @@ int launch_cfg(const TileCfg& c, const ConvArgs& a, dim3 grid, hipStream_t strea
         return launch_conv<1, 2, 2, 4, SPLIT, 1, true>(a, grid, stream);
     }
     if (c.mw == 4) return launch_conv<KS, 4, 1, 4, SPLIT>(a, grid, stream);
+    // seven-tile mode: 3x3, one channel block, 193..224 output channels, the 16-byte epilogue (the 196-channel layers)
+    if constexpr (KS == 3) {
+        if (a.nblkY == 1 && a.Cout > 192 && a.Cout <= 224 && ((a.Cout | a.Csub) & 3) == 0 && far_get_tuning(4) == 0)
+            return launch_conv<KS, 2, 2, 4, SPLIT, 1, false, true>(a, grid, stream);
+    }
     return launch_conv<KS, 2, 2, 4, SPLIT>(a, grid, stream);
 }
 
