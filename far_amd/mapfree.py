@@ -24,12 +24,13 @@ class EssentialMatrixSolver:
     """pose_solver.py:20-97.  cfg: an object with EMAT_RANSAC.PIX_THRESHOLD / .CONFIDENCE (or None: the values of
     config/matching/mapfree/loftr_emat_*.yaml: 2.0 px, 0.9999)."""
 
-    def __init__(self, cfg=None, use_prior_ransac=False, H=2048, seed=0):
+    def __init__(self, cfg=None, use_prior_ransac=False, H=2048, seed=0, minimal=8):
         er = getattr(cfg, 'EMAT_RANSAC', None) if cfg is not None else None
         self.ransac_pix_threshold = float(er.PIX_THRESHOLD) if er is not None else 2.0
         self.ransac_confidence = float(er.CONFIDENCE) if er is not None else 0.9999
         self.use_prior_ransac = use_prior_ransac
         self.H, self.seed = H, seed
+        self.minimal = minimal        # 8: normalized 8-point hypotheses; 5: Nister five-point (what Map-free executes through cv2, :81)
         self.mask = None
 
     def solve_batch(self, kpts0, kpts1, counts, K0, K1, priorRT=None):
@@ -50,7 +51,7 @@ class EssentialMatrixSolver:
             prior = pcl = None
         return ops.solve_pose_batch(kpts0.float().contiguous(), kpts1.float().contiguous(), offs, K0d, K1d,
                                     inl_th.contiguous(), mode == 'prior', priorRT=prior, pcl=pcl, prior_lambda=0.3,
-                                    H=self.H, seed=self.seed)
+                                    H=self.H, seed=self.seed, minimal=self.minimal)
 
     def estimate_pose(self, kpts0, kpts1, data, priorRT=None):
         """Single pair, the reference's contract: ((R (3,3), t (3,), n_inliers), inliers_best_tight, inliers_best_ultra_tight)
@@ -97,3 +98,38 @@ def match_and_solve(matcher, data, solver, priorRT=None, use_prior=True):
         data['inliers'] = n[:, None]
     data.update(mkpts0_f=mk0, mkpts1_f=mk1, m_bids=bids[order], match_counts=counts, solver_status=out['status'])
     return data
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The matcher Map-free instantiates: upstream LoFTR (zju3dv/LoFTR, an un-vendored submodule: etc/feature_matching_baselines/LoFTR,
+# .gitmodules) built from its `default_cfg` and loaded from a released checkpoint with strict=False
+# (lib/models/regression/model.py:103-106).  The mp3d_loftr fork this build mirrors keeps upstream's module tree for the
+# matcher (backbone / pos_encoding / loftr_coarse / coarse_matching / fine_preprocess / loftr_fine / fine_matching: same
+# parameter names and shapes per layer), so an upstream state dict loads into far_amd.loftr.LoFTR once the config says what
+# upstream's says: four (self, cross) coarse layer pairs, the pre-fix position encoding, no regression head.
+# ---------------------------------------------------------------------------------------------------------------------
+def upstream_loftr_config():
+    """Upstream LoFTR's `default_cfg` (src/loftr/utils/cvpr_ds_config.py, lower-cased) as the dict far_amd.loftr.LoFTR takes."""
+    from .config import far_eval_config
+    cfg = far_eval_config()
+    cfg['coarse'].update(layer_names=['self', 'cross'] * 4, temp_bug_fix=False)     # released checkpoints predate the fix
+    cfg['match_coarse'].update(train_coarse_percent=0.4, skh_prefilter=True)
+    cfg.update(regress_rt=False, solver='ransac', use_many_ransac_thr=False, regress_loftr_layers=0)
+    return cfg
+
+
+def load_upstream_loftr(state_dict, device='cuda'):
+    """far_amd.loftr.LoFTR with upstream LoFTR's released weights: `state_dict` is the checkpoint's ['state_dict'] (keys
+    'matcher.*', as torch.load(weights_path)['state_dict'] in model.py:105).  Loaded the way the reference does, strict=False:
+    the optimal-transport checkpoints ('outdoor_ot.ckpt', the file Map-free names) carry `coarse_matching.bin_score`, which
+    the dual-softmax matcher of `default_cfg` does not have.  Anything ELSE missing or unexpected is an error here -- a
+    silent partial load would give a matcher that runs and matches nothing."""
+    from .loftr import LoFTR
+    m = LoFTR(upstream_loftr_config()).eval()
+    sd = state_dict.get('state_dict', state_dict)
+    res = m.load_state_dict(dict(sd), strict=False)
+    unexpected = [k for k in res.unexpected_keys if not k.endswith('coarse_matching.bin_score')]
+    if res.missing_keys or unexpected:
+        raise KeyError(f'upstream LoFTR checkpoint does not fit: missing {res.missing_keys[:5]}{"..." if len(res.missing_keys) > 5 else ""}, '
+                       f'unexpected {unexpected[:5]}{"..." if len(unexpected) > 5 else ""}')
+    return m.to(device)

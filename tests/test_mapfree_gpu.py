@@ -140,3 +140,45 @@ def test_mapfree_single_pair_estimate_pose_contract(matcher):
     assert n2 > 300 and tight2 >= ultra2 > 0 and np.linalg.norm(R2 - Rgt) < 0.05
     (R3, t3, n3), a, b = s.estimate_pose(k0[:4], k1[:4], data2)
     assert n3 == 0 and a == 0 and b == 0 and np.array_equal(R3, np.eye(3)) and np.array_equal(t3, np.zeros(3))
+
+
+def _upstream_style_state_dict(seed=0):
+    """A checkpoint shaped like upstream LoFTR's released ones (torch.load(path)['state_dict']): the matcher's parameters
+    under 'matcher.', four (self, cross) coarse layer pairs, no regression head, plus the optimal-transport bin score."""
+    import json
+    import os
+    from far_amd import synth
+    man = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'g8_state_dict_manifest.json')))
+    shapes = {k: tuple(v) for k, v in man.items() if not k.startswith('loftr_regress.')}
+    for li in (6, 7):                                                   # upstream: 8 coarse layers (the FAR config has 6)
+        for k, v in list(shapes.items()):
+            if k.startswith('loftr_coarse.layers.5.'):
+                shapes[k.replace('layers.5.', f'layers.{li}.')] = v
+    sd = {'matcher.' + k: torch.from_numpy(v) for k, v in synth.synthetic_state_dict(shapes, seed=seed).items()}
+    sd['matcher.coarse_matching.bin_score'] = torch.tensor(1.0)
+    return {'state_dict': sd}
+
+
+def test_upstream_loftr_checkpoint_loads_and_drives_the_mapfree_loop():
+    """The matcher of Map-free's RegressionModel (model.py:103-106: LoFTR(config=default_cfg) + load_state_dict(strict=False)
+    of a released upstream checkpoint): far_amd.mapfree.load_upstream_loftr builds it from an upstream-shaped state dict --
+    'matcher.' prefix, 8 coarse layers, optimal-transport bin_score -- and it runs the batched match + solve loop at 544x720.
+    A checkpoint of another architecture is refused instead of being loaded partially."""
+    from far_amd import synth
+    from far_amd.mapfree import EssentialMatrixSolver, load_upstream_loftr, match_and_solve, upstream_loftr_config
+    ck = _upstream_style_state_dict()
+    m = load_upstream_loftr(ck)
+    assert len(m.loftr_coarse.layers) == 8 and not hasattr(m, 'loftr_regress')
+    assert upstream_loftr_config()['coarse']['temp_bug_fix'] is False
+    w = ck['state_dict']['matcher.loftr_coarse.layers.7.merge.weight']
+    assert torch.equal(m.loftr_coarse.layers[7].merge.weight.cpu(), w)
+    im0, im1 = synth.synth_image_pair(2, seed=23, hw=HW_MF)
+    K = torch.from_numpy(np.stack([K_MF] * 2)).cuda()
+    data = {'image0': torch.from_numpy(im0).cuda(), 'image1': torch.from_numpy(im1).cuda(), 'K_color0': K, 'K_color1': K.clone()}
+    for minimal in (8, 5):                                              # Map-free's own solver is a five-point RANSAC (pose_solver.py:81)
+        match_and_solve(m, data, EssentialMatrixSolver(None, use_prior_ransac=False, H=512, seed=1, minimal=minimal), use_prior=False)
+        assert data['loftr_rt'].shape == (2, 3, 4) and data['inliers'].shape == (2, 1) and bool(torch.isfinite(data['loftr_rt']).all())
+        print(f'[upstream loader] minimal={minimal}: matches per pair', data['match_counts'].tolist(), 'inliers', data['inliers'].flatten().tolist())
+    bad = {'state_dict': {k: v for k, v in ck['state_dict'].items() if '.layers.7.' not in k}}
+    with pytest.raises(KeyError, match='does not fit'):
+        load_upstream_loftr(bad)
