@@ -64,6 +64,12 @@ SIGNATURES = {
     'far_stem7x7_nhwc_f32': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
     'far_pose_pack_f64': (c_i, [c_p] * 8 + [c_i] + [c_p] * 6 + [c_p]),
     'far_pose_features_f32': (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p]),
+    'far_rows_linear_packed_bytes': (c_sz, [c_i, c_i]),
+    'far_rows_linear_workspace_bytes': (c_sz, [c_i, c_i, c_i]),
+    'far_rows_linear_pack_f32': (c_i, [c_p, c_i, c_i, c_p, c_p]),
+    'far_rows_linear_f32': (c_i, [c_p, c_l, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_p, c_l, c_p, c_p]),
+    'far_emm_contract_workspace_bytes': (c_sz, [c_i]),
+    'far_emm_contract_f32': (c_i, [c_p, c_i, c_l, c_l, c_p, c_p, c_i, c_i, c_p, c_p, c_p]),
     'far_solver_workspace_bytes': (c_sz, [c_i, c_i, c_i, c_i]),
     'far_solver_f64': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_d, c_i, c_i, c_u32, c_p]
                        + [c_p] * 14 + [c_p, c_p]),

@@ -143,10 +143,19 @@ __device__ __forceinline__ void stage_load(Stage<ITERS>& st, const ConvArgs& p, 
         // packed weight image (a kernel-argument pointer like x: plain global loads) instead of being masked afterwards -- a select on the loaded value would make the wave wait for HBM right here instead of
         // at stage_store, one chunk later
         const bool ok0 = ok && c0 < p.Cin, ok1 = ok && c0 + 4 < p.Cin;
+#if defined(FAR_K9_EXP) && (FAR_K9_EXP & 4)      // experiment: real data, but always the same 1024 pixels (cache-resident)
+        pix &= 1023;
+#endif
         const bool second = c0 >= p.Cin1;                       // Cin1 % 8 == 0: a group never straddles the inputs
         const float* base = second ? p.x2 + pix * (p.Cin - p.Cin1) + (c0 - p.Cin1) : p.x + pix * p.Cin1 + c0;
+#if defined(FAR_K9_EXP) && (FAR_K9_EXP & 1)      // experiment (never in the product build): no activation traffic
+        const float* src0 = p.zeros;
+        const float* src1 = p.zeros;
+        (void)base; (void)ok0; (void)ok1;
+#else
         const float* src0 = ok0 ? base : p.zeros;
         const float* src1 = ok1 ? base + 4 : p.zeros;
+#endif
         st.v[it][0] = *reinterpret_cast<const float4*>(src0);
         st.v[it][1] = *reinterpret_cast<const float4*>(src1);
     }
@@ -752,6 +761,14 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p) {
         const bool bad = !(fabsf(chk) <= FLT_MAX);
         if (__any(bad) && lane == 0) atomicOr(p.overflow, 1);
     }
+#if defined(FAR_K9_EXP) && (FAR_K9_EXP & 2)      // experiment: no epilogue (one store keeps the accumulators alive)
+    {
+        float t = 0.f;
+        for (int mt = 0; mt < 2; ++mt) for (int nt = 0; nt < NTW; ++nt) for (int r = 0; r < 16; ++r) t += acc[mt][nt][r];
+        if (t == 123.456f) p.y[0] = t;
+        return;
+    }
+#endif
     if (NTW == 4 && ((p.Cout | p.Csub) & 3) == 0) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave is past its last LDS fragment read
         // N7: channels 96..127 of the workgroup (the shared tile) are stored by wn = 0 for mt = 0 and by wn = 1 for mt = 1

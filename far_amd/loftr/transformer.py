@@ -194,8 +194,17 @@ class Mlp(nn.Module):
         self.act = act_layer()
         self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
 
-    def forward(self, x):
-        return self.fc2(self.act(self.fc1(x)))
+    def forward(self, x, residual=None):
+        """fc2(act(fc1(x))) (+ residual).  Inference on the GPU: both Linear layers on K9 (every output row depends on its
+        input row only), the activation as an elementwise torch op in between, the residual in fc2's epilogue."""
+        if ag.needs_grad(x, self.fc1.weight) or not x.is_cuda:
+            y = self.fc2(self.act(self.fc1(x)))
+            return y if residual is None else residual + y
+        pk = self.__dict__.setdefault('_packs', ops.PackCache())
+        p1 = pk.get('fc1', [self.fc1.weight, self.fc1.bias], lambda: ops.PackedConv(self.fc1.weight, None, self.fc1.bias))
+        p2 = pk.get('fc2', [self.fc2.weight, self.fc2.bias], lambda: ops.PackedConv(self.fc2.weight, None, self.fc2.bias))
+        hid = self.act(ops.linear_f16s(x.contiguous(), p1))
+        return ops.linear_f16s(hid, p2, residual=None if residual is None else residual.contiguous())
 
 
 def positional_table(h=60, w=80):
@@ -272,8 +281,15 @@ class CrossAttention(nn.Module):
         # raw reshape of (B, h, 70, 70) to (B, 280, 70), then transpose (:294-295)
         f1 = F[0].reshape(B, C + 6 * h, (C + 6 * h) // h).transpose(-2, -1)
         f2 = F[1].reshape(B, C + 6 * h, (C + 6 * h) // h).transpose(-2, -1)
-        f2 = self.proj_fundamental(f2)
-        f1 = self.proj_fundamental(f1)
+        if ag.needs_grad(f1, self.proj_fundamental.weight) or not f1.is_cuda:
+            f2 = self.proj_fundamental(f2)
+            f1 = self.proj_fundamental(f1)
+        else:                                                      # K9 (row-independent), both directions in one launch
+            pk = self.__dict__.setdefault('_packs', ops.PackCache())
+            pw, pb = self.proj_fundamental.weight, self.proj_fundamental.bias
+            pp = pk.get('proj', [pw, pb], lambda: ops.PackedConv(pw, None, pb))
+            f12 = ops.linear_f16s(torch.stack([f1, f2], 0).contiguous(), pp)
+            f1, f2 = f12[0], f12[1]
         return f2, f1                                              # flipped on purpose (:301-303)
 
 
@@ -317,7 +333,21 @@ class CrossBlock(nn.Module):
         f1, f2 = self.cross_attn(n1_1, n1_2, intrinsics=intrinsics,
                                  loftr_preds=loftr_preds, inv_loftr_preds=inv_loftr_preds)
         f = torch.cat([f1.unsqueeze(1), f2.unsqueeze(1)], dim=1).reshape(b_s, -1, nf)
-        return f + self.mlp(self.norm2(f))
+        if ag.needs_grad(f, self.norm2.weight) or not f.is_cuda:
+            return f + self.mlp(self.norm2(f))
+        f = f.contiguous()
+        return self.mlp(ops.layernorm(f, self.norm2.weight, self.norm2.bias, self.norm2.eps), residual=f)   # K6 + K9
+
+
+class HeadFeatures:
+    """What LocalFeatureTransformerRegressor.compute_features hands to forward_emm on the GPU inference path: the (B, 35840)
+    features of transformer.py:497 plus the feature-only part of the two 35840-wide first layers (encoder[0], moe_predictor[0])."""
+
+    def __init__(self, feats, enc0, moe0):
+        self.feats, self.enc0, self.moe0 = feats, enc0, moe0
+
+    def reshape(self, *shape):          # callers that only want the reference's tensor
+        return self.feats.reshape(*shape)
 
 
 class LocalFeatureTransformerRegressor(nn.Module):
@@ -366,6 +396,8 @@ class LocalFeatureTransformerRegressor(nn.Module):
         """What `compute_features` depends on besides its inputs: every weight it reads (storage + version, so that
         load_state_dict / an optimizer step / an in-place edit invalidate) and the operand precision of its layers."""
         mods = [self.emm, self.norm] + ([self.loftr] if self.config['regress_loftr_layers'] > 0 else [])
+        if self.config['regress']['use_simple_moe']:        # their feature-only part travels with the features (HeadFeatures)
+            mods += [self.encoder[0], self.moe_predictor[0]]
         ws = tuple((p.data_ptr(), ops.tensor_version(p)) for m in mods for p in m.parameters())
         prec = tuple(m.split_operands for m in self.modules() if isinstance(m, LoFTREncoderLayer))
         return ws, prec, self.training, ops.activation_exponent_value(), self.emm.cross_attn.exact_f32
@@ -380,7 +412,20 @@ class LocalFeatureTransformerRegressor(nn.Module):
                     f1.data_ptr() == f0.data_ptr() + f0.numel() * f0.element_size())
         x01 = torch.as_strided(f0, (2 * B,) + tuple(f0.shape[1:]), f0.stride()) if adjacent else torch.cat([f0, f1], dim=0)
         x = self.emm(x01, loftr_preds=loftr_preds, inv_loftr_preds=inv_loftr_preds)
-        return self.norm(x).reshape([B, -1])
+        if ag.needs_grad(x, self.norm.weight) or not x.is_cuda:
+            return self.norm(x).reshape([B, -1])
+        feats = ops.layernorm(x.contiguous(), self.norm.weight, self.norm.bias, self.norm.eps).reshape(B, -1)
+        if not self.config['regress']['use_simple_moe']:
+            return feats
+        # The first layers of `encoder` and `moe_predictor` read only these features (:428, :448: cat[features, pose, solver
+        # numbers]): their feature part is computed here, once per batch, and travels with the features -- the second head
+        # call of a step then re-runs only the 22-number-dependent remainder instead of streaming 2 x 73 MB of weights again
+        pk = self.__dict__.setdefault('_packs', ops.PackCache())
+        e0, m0 = self.encoder[0], self.moe_predictor[0]
+        both = pk.get('enc0|moe0', [e0.weight, m0.weight],
+                      lambda: ops.PackedRows(torch.cat([e0.weight, m0.weight[:, :self.H]], 0)))
+        pre = ops.rows_linear(feats, both)                                  # (B, 1024): encoder[0] | moe_predictor[0], no bias yet
+        return HeadFeatures(feats, pre[:, :self.H2], pre[:, self.H2:])
 
     def forward_emm(self, feat0, feat1, loftr_preds=None, inv_loftr_preds=None, features=None):
         if features is None:                  # reference call shape: feat0 / feat1 are the LoFTR-layer outputs
@@ -388,10 +433,24 @@ class LocalFeatureTransformerRegressor(nn.Module):
             x = self.emm(torch.cat([feat0, feat1], dim=0), loftr_preds=loftr_preds, inv_loftr_preds=inv_loftr_preds)
             features = self.norm(x).reshape([B, -1])
         rc = self.config['regress']
+        pre = None
+        if isinstance(features, HeadFeatures):
+            pre, features = features, features.feats
         if not rc['use_simple_moe']:
             return self.pose_regressor(features), (features if rc['save_mlp_feats'] else None), None
         mean_t, std_t = pose_mean_6d[:3].to(features.device), pose_std_6d[:3].to(features.device)
-        pred_reg_6d = self.pose_regressor_simple_moe(self.encoder(features))
+        if pre is not None:
+            # inference on the GPU: every remaining Linear of the head on K15 (exact fp32, one fma chain per output in a fixed
+            # order: pair b's pose does not depend on the batch it is computed in)
+            pk = self.__dict__.setdefault('_packs', ops.PackCache())
+            lin = lambda name, m, **kw: pk.get(name, [m.weight, m.bias], lambda: ops.PackedRows(m.weight, m.bias, **kw))
+            enc, reg, moe = self.encoder, self.pose_regressor_simple_moe, self.moe_predictor
+            h = torch.relu(pre.enc0 + enc[0].bias)
+            h = ops.rows_linear(h, lin('enc2', enc[2]))
+            h = ops.rows_linear(h, lin('reg0', reg[0]), act='relu')
+            pred_reg_6d = ops.rows_linear(h, lin('reg2', reg[2]))
+        else:
+            pred_reg_6d = self.pose_regressor_simple_moe(self.encoder(features))
         pred_reg_t = pred_reg_6d[..., :3]
         loftr_pred_t = loftr_preds[..., :3]
         if rc['scale_8pt']:
@@ -403,7 +462,13 @@ class LocalFeatureTransformerRegressor(nn.Module):
             loftr_pred_t = (solver_t - mean_t) / std_t
         extra = self.pose_size_in - self.pose_size
         loftr_pred_R = loftr_preds[..., 3:-extra] if extra > 0 else loftr_preds[..., 3:]   # :452-455
-        gate = self.moe_predictor(torch.cat([features, pred_reg_6d, loftr_preds], dim=-1))
+        if pre is not None:
+            tail = torch.cat([pred_reg_6d, loftr_preds.to(pred_reg_6d.dtype)], dim=-1).contiguous()      # (B, 9 + 13)
+            g = ops.rows_linear(tail, lin('moe0-tail', moe[0], cols=(self.H, moe[0].weight.shape[1])), act='relu', add=pre.moe0)
+            g = ops.rows_linear(g, lin('moe2', moe[2]), act='relu')
+            gate = ops.rows_linear(g, lin('moe4', moe[4]), act='sigmoid')
+        else:
+            gate = self.moe_predictor(torch.cat([features, pred_reg_6d, loftr_preds], dim=-1))
         if rc['use_2wt']:
             if rc['use_5050_weight']:
                 raise NotImplementedError('use_5050_weight is a debugging branch in the reference (:461-464)')

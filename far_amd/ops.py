@@ -193,8 +193,7 @@ def emm_bilinear(q, k, v, pos, scale, exact_f32=False):
         rc = lib.far_emm_pv_f16s(_p(q, torch.float32), _p(k, torch.float32), _p(v, torch.float32), _p(pos, torch.float32),
                                  Z, N, D, float(scale), 1, 0, N * D, 0, _p(ws), _p(T), _p(overflow_flag(T.device)), _stream())
         _lib.check(rc, 'far_emm_pv_f16s')
-    vt = torch.cat([v, pos.unsqueeze(0).expand(Z, -1, -1)], dim=2)  # (Z, N, 70)
-    return torch.bmm(vt.transpose(1, 2), T), T
+    return emm_contract(_p(v, torch.float32), 1, 0, N * D, pos, T), T
 
 
 def _emm_pv(q, k, v, pos, scale, want_stats=False):
@@ -288,9 +287,8 @@ def emm_bilinear_planes(qkv, pos, scale, B):
     rc = lib.far_emm_pv_f16s(ctypes.c_void_p(base), ctypes.c_void_p(base + h * plane), ctypes.c_void_p(base + 2 * h * plane),
                              _p(pos, torch.float32), Z, N, D, float(scale), h, P * N * D, N * D, B, _p(ws), _p(T), _p(overflow_flag(T.device)), _stream())
     _lib.check(rc, 'far_emm_pv_f16s')
-    v = qkv[2 * h:].permute(1, 0, 2, 3).reshape(Z, N, D)                       # (P, h, N, D) -> z = p * h + hh
-    vt = torch.cat([v, pos.unsqueeze(0).expand(Z, -1, -1)], dim=2)
-    return torch.bmm(vt.transpose(1, 2), T), T
+    # F = [v | pos]^T T (transformer.py:291-295) straight from the v planes: no (Z, N, 70) concatenation, no vendor bmm
+    return emm_contract(ctypes.c_void_p(base + 2 * h * plane), h, P * N * D, N * D, pos, T), T
 
 
 def fine_gather(feat_f, b_ids, cell_ids, wc, W, stride, out=None):
@@ -910,3 +908,59 @@ def corr_volume_warp(vol0, vol1):
                                       _p(_CVW_GRID[key]), B, D, H * W, _p(agg), _p(ws), _stream())
     _lib.check(rc, 'far_corr_volume_warp_f32')
     return agg
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# K15: row-independent exact-fp32 layers of the regression head (head_linear_f32.hip)
+# ---------------------------------------------------------------------------------------------------------------------
+_ROWS_ACT = {'none': 0, 'relu': 1, 'sigmoid': 2, 'gelu': 3}
+
+
+class PackedRows:
+    """An nn.Linear's weight [N][K] (optionally a column range of it) in far_rows_linear_f32's [K / 4][N][4] image."""
+
+    def __init__(self, weight, bias=None, cols=None):
+        lib = _lib.load()
+        w = weight.detach().float()
+        if cols is not None:
+            w = w[:, cols[0]:cols[1]]
+        w = w.contiguous()
+        self.N, self.K = int(w.shape[0]), int(w.shape[1])
+        self.packed = torch.empty(lib.far_rows_linear_packed_bytes(self.N, self.K), dtype=torch.uint8, device=w.device)
+        _lib.check(lib.far_rows_linear_pack_f32(_p(w, torch.float32), self.N, self.K, _p(self.packed), _stream()), 'far_rows_linear_pack_f32')
+        self.bias = None if bias is None else bias.detach().float().contiguous()
+
+
+def rows_linear(x, pr, act='none', add=None):
+    """K15.  x (B, K) fp32 (rows may be strided) -> act(x W^T + bias + add) (B, N): every row one fp32 fma chain in a fixed
+    order -- bit-identical whatever B is."""
+    lib = _lib.load()
+    if not x.is_cuda:
+        raise _lib.FarHipError('far_amd ops need tensors on the GPU (no CPU fallback exists)')
+    if x.dim() != 2 or x.shape[1] != pr.K or x.dtype != torch.float32 or x.stride(1) != 1:
+        raise _lib.FarHipError(f'rows_linear: x must be (B, {pr.K}) fp32 with unit column stride')
+    if add is not None and (tuple(add.shape) != (x.shape[0], pr.N) or add.stride(1) != 1 or add.dtype != torch.float32):
+        raise _lib.FarHipError('rows_linear: add must be (B, N) fp32 with unit column stride')
+    B = int(x.shape[0])
+    y = torch.empty(B, pr.N, dtype=torch.float32, device=x.device)
+    if B == 0:
+        return y
+    ws = _ws(lib.far_rows_linear_workspace_bytes(B, pr.N, pr.K), x.device)
+    rc = lib.far_rows_linear_f32(ctypes.c_void_p(x.data_ptr()), int(x.stride(0)), _p(pr.packed), _p(pr.bias, torch.float32),
+                                 ctypes.c_void_p(add.data_ptr()) if add is not None else ctypes.c_void_p(0),
+                                 int(add.stride(0)) if add is not None else 0, B, pr.K, pr.N, _ROWS_ACT[act], _p(y), pr.N, _p(ws),
+                                 _stream())
+    _lib.check(rc, 'far_rows_linear_f32')
+    return y
+
+
+def emm_contract(v_ptr, heads, head_stride, prob_stride, pos, T):
+    """K15.  F (Z, 70, 70) = [v | pos]^T T per problem; v addressed as far_emm_pv_f16s addresses it."""
+    lib = _lib.load()
+    Z, N, _ = T.shape
+    F = torch.empty(Z, 70, 70, dtype=torch.float32, device=T.device)
+    ws = _ws(lib.far_emm_contract_workspace_bytes(Z), T.device)
+    rc = lib.far_emm_contract_f32(v_ptr, int(heads), int(head_stride), int(prob_stride), _p(pos, torch.float32), _p(T, torch.float32),
+                                  Z, N, _p(F), _p(ws), _stream())
+    _lib.check(rc, 'far_emm_contract_f32')
+    return F

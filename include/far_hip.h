@@ -355,6 +355,27 @@ int far_pose_features_f32(const double* rt, int B, const void* cnt0, int elem_by
                           float* inv_preds, far_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * K15  the small dense layers of the regression head, row-independent and in exact fp32 (fixed summation order)
+ * replaces, for inference, src/loftr/loftr_module/transformer.py:294-295 (F = v~^T (P v~): the 70 x N x 70 torch.bmm after K2),
+ *      :423-431 (encoder 35840 -> 512 -> 512, pose_regressor_simple_moe 512 -> 512 -> 9) and :448-458 (moe_predictor
+ *      35862 -> 512 -> 512 -> 2 + sigmoid).  A vendor GEMM chooses its kernel by the row count, so a pair's regressed pose used
+ *      to depend (1e-7) on how many pairs shared the batch; here row b of any batch is bit-identical to the pair run alone.
+ * far_rows_linear_f32: y[b][:] = act(x[b][:] W^T + bias + add[b][:]); W packed by far_rows_linear_pack_f32 from the torch
+ *   [N][K] layout; x / y / add rows ldx / ldy / ld_add floats apart; add, bias may be NULL; act 0 none, 1 ReLU, 2 sigmoid,
+ *   3 GELU (erf).  ws: far_rows_linear_workspace_bytes(B, N, K).
+ * far_emm_contract_f32: F [Z][70][70] = [v | pos]^T T per problem (v addressed like far_emm_pv_f16s's v: problem
+ *   z = p * heads + hh at v + hh * head_stride + p * prob_stride, [N][64]; pos [N][6]; T [Z][N][70]).
+ * --------------------------------------------------------------------------------------------------- */
+size_t far_rows_linear_packed_bytes(int N, int K);
+size_t far_rows_linear_workspace_bytes(int B, int N, int K);
+int far_rows_linear_pack_f32(const float* w, int N, int K, void* packed, far_stream_t stream);
+int far_rows_linear_f32(const float* x, long ldx, const void* packed, const float* bias, const float* add, long ld_add, int B,
+                        int K, int N, int act, float* y, long ldy, void* ws, far_stream_t stream);
+size_t far_emm_contract_workspace_bytes(int Z);
+int far_emm_contract_f32(const float* v, int heads, long head_stride, long prob_stride, const float* pos, const float* T, int Z,
+                         int N, float* F, void* ws, far_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * K4  batched essential-matrix solver (hypothesise / verify / decompose / cheirality), float64
  * replaces src/utils/metrics.py:80-174 (estimate_pose), third_party/prior_ransac/ransac.py:340-442
  *      (RANSAC.forward + verify + get_prior_estimate), cv_geometry.py:713-833 (run_8point),
