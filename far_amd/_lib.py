@@ -39,6 +39,7 @@ SIGNATURES = {
     'far_coarse_pos_conf_bwd_f16': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p]),
     'far_emm_pv_f32': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_p]),
     'far_fine_gather_f32': (c_i, [c_p, c_l, c_l, c_l, c_l, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
+    'far_fine_scatter_f32': (c_i, [c_p, c_l, c_l, c_l, c_l, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
     'far_fine_expect_f32': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_f, c_p, c_p, c_p, c_p, c_p]),
     'far_linear_attention_workspace_bytes': (c_sz, [c_i, c_i, c_i, c_i]),
     'far_linear_attention_f32': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_p, c_p, c_p]),

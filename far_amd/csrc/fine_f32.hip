@@ -31,6 +31,26 @@ __global__ void k_fine_gather(const float* __restrict__ feat, long sn, long sc, 
     }
 }
 
+// Backward of k_fine_gather: dfeat[b][c][y][x] += dout[m][ww][c] (autograd of the unfold + gather of fine_preprocess.py:40-47).
+// Windows overlap (5 x 5 at stride 4) and training samples cells with replacement (coarse_matching.py:216-229): fp32
+// atomics, i.e. the summation ORDER is not fixed (the values are: every contribution is added exactly once).
+__global__ void k_fine_scatter(const float* __restrict__ dout, long sn, long sc, long sh, long sw, int C, int Hf, int Wf,
+                               const int64_t* __restrict__ b_ids, const int64_t* __restrict__ cell_ids, int wc, int W,
+                               int stride, int M, float* __restrict__ dfeat) {
+    const int m = blockIdx.x;
+    if (m >= M) return;
+    const int WW = W * W, pad = W / 2;
+    const long b = b_ids[m];
+    const int cell = (int)cell_ids[m];
+    const int y0 = (cell / wc) * stride - pad, x0 = (cell % wc) * stride - pad;
+    for (int e = threadIdx.x; e < WW * C; e += blockDim.x) {
+        const int ww = e / C, c = e - ww * C;
+        const int y = y0 + ww / W, x = x0 + ww % W;
+        if (y >= 0 && y < Hf && x >= 0 && x < Wf)
+            atomicAdd(dfeat + (b * sn + (long)c * sc + (long)y * sh + (long)x * sw), dout[((size_t)m * WW + ww) * C + c]);
+    }
+}
+
 // One wave per match.  feat0/feat1 [M][WW][C].  expec [M][3] = (E[x], E[y], std); mkpts1_f [M][2].
 __global__ void k_fine_expect(const float* __restrict__ feat0, const float* __restrict__ feat1, int M, int W,
                               int C, const float* __restrict__ mkpts1_c, float win_scale,
@@ -101,6 +121,19 @@ int far_fine_gather_f32(const float* feat, long sn, long sc, long sh, long sw, i
     if (!feat || !b_ids || !cell_ids || !out || M < 0 || C <= 0 || W <= 0 || (W & 1) == 0 || wc <= 0) return FAR_EINVAL;
     hipLaunchKernelGGL(k_fine_gather, dim3(M), dim3(256), 0, stream, feat, sn, sc, sh, sw, C, Hf, Wf, b_ids, cell_ids,
                        wc, W, stride, M, out);
+    return far_check_launch();
+}
+
+// Backward of far_fine_gather_f32: dfeat (same strides / shape as feat, zero-initialised or holding a gradient to add to)
+// += the window gradients dout [M][W*W][C] at the positions the forward read.
+int far_fine_scatter_f32(const float* dout, long sn, long sc, long sh, long sw, int C, int Hf, int Wf,
+                         const int64_t* b_ids, const int64_t* cell_ids, int wc, int W, int stride, int M,
+                         float* dfeat, hipStream_t stream) {
+    far_clear_errors();
+    if (M == 0) return FAR_OK;
+    if (!dout || !b_ids || !cell_ids || !dfeat || M < 0 || C <= 0 || W <= 0 || (W & 1) == 0 || wc <= 0) return FAR_EINVAL;
+    hipLaunchKernelGGL(k_fine_scatter, dim3(M), dim3(256), 0, stream, dout, sn, sc, sh, sw, C, Hf, Wf, b_ids, cell_ids,
+                       wc, W, stride, M, dfeat);
     return far_check_launch();
 }
 

@@ -171,6 +171,8 @@ class CoarseMatching(nn.Module):
 # fine level
 # =====================================================================================================
 class FinePreprocess(nn.Module):
+    hip_training = True          # training on the GPU: K3 gather + its scatter backward; False: F.unfold + autograd
+
     def __init__(self, config):
         super().__init__()
         self.config = config
@@ -195,8 +197,12 @@ class FinePreprocess(nn.Module):
             return e, e.clone()
         # direct gather of the M x 25 x C window values instead of unfolding both full maps (:40-47)
         if ag.needs_grad(feat_f0, feat_f1):
-            w0 = ag.fine_windows(feat_f0, b, i, W, stride)
-            w1 = ag.fine_windows(feat_f1, b, j, W, stride)
+            if feat_f0.is_cuda and self.hip_training:     # K3 gather forward + scatter backward (no unfold of the full maps)
+                w0 = ops.fine_windows_train(feat_f0, b, i, data['hw0_c'][1], W, stride)
+                w1 = ops.fine_windows_train(feat_f1, b, j, data['hw1_c'][1], W, stride)
+            else:
+                w0 = ag.fine_windows(feat_f0, b, i, W, stride)
+                w1 = ag.fine_windows(feat_f1, b, j, W, stride)
         else:       # both images' windows into the halves of one buffer: the later cat([w0, w1]) is then free
             M = b.shape[0]
             w01 = torch.empty(2 * M, W ** 2, feat_f0.shape[1], dtype=torch.float32, device=feat_f0.device)

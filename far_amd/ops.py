@@ -313,6 +313,45 @@ def fine_gather(feat_f, b_ids, cell_ids, wc, W, stride, out=None):
     return _written(out)
 
 
+class _FineWindowsFn(torch.autograd.Function):
+    """K3a with its HIP backward: the M x 25 x C windows gathered directly (forward) and their gradients scattered back
+    into the fine map (backward) -- the reference unfolds both full fine maps (123 MB per pair, fine_preprocess.py:40-44)
+    and autograd folds them back."""
+
+    @staticmethod
+    def forward(ctx, feat_f, b_ids, cell_ids, wc, W, stride):
+        f = feat_f.detach().float()
+        out = fine_gather(f, b_ids, cell_ids, wc, W, stride)
+        ctx.save_for_backward(b_ids, cell_ids)
+        ctx.meta = (tuple(f.shape), tuple(f.stride()), int(wc), int(W), int(stride), feat_f.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        b_ids, cell_ids = ctx.saved_tensors
+        shape, strides, wc, W, stride, dt = ctx.meta
+        N, C, Hf, Wf = shape
+        d = torch.empty_strided(shape, strides, dtype=torch.float32, device=g.device).zero_()
+        M = int(b_ids.shape[0])
+        if M:
+            g = g.float().contiguous()
+            rc = lib.far_fine_scatter_f32(_p(g, torch.float32), strides[0], strides[1], strides[2], strides[3], C, Hf, Wf,
+                                          _p(b_ids, torch.int64), _p(cell_ids, torch.int64), wc, W, stride, M,
+                                          ctypes.c_void_p(d.data_ptr()), _stream())
+            _lib.check(rc, 'far_fine_scatter_f32')
+        return d.to(dt), None, None, None, None, None
+
+
+def fine_windows_train(feat_f, b_ids, cell_ids, wc, W, stride):
+    """K3a, differentiable w.r.t. feat_f (N, C, Hf, Wf): (M, W*W, C) windows at the matched cells."""
+    if not feat_f.is_cuda:
+        raise _lib.FarHipError('far_amd ops need tensors on the GPU (no CPU fallback exists)')
+    if not (feat_f.is_contiguous() or feat_f.is_contiguous(memory_format=torch.channels_last)):
+        feat_f = feat_f.contiguous()
+    return _FineWindowsFn.apply(feat_f, b_ids.to(torch.int64).contiguous(), cell_ids.to(torch.int64).contiguous(), wc, W, stride)
+
+
 def fine_expect(feat0, feat1, mkpts1_c, win_scale, scale1=None, b_ids=None):
     """K3b.  feat0/feat1: (M, WW, C).  Returns expec_f (M, 3), mkpts1_f (M, 2)."""
     lib = _lib.load()

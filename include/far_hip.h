@@ -189,6 +189,11 @@ int far_fine_gather_f32(const float* feat, long sn, long sc, long sh, long sw, i
 /* feat0/feat1 [M][W*W][C] (after the fine transformer).  expec_f [M][3] = (E[x], E[y], std) in normalised
  * window coordinates; mkpts1_f [M][2] = mkpts1_c + E[xy] * win_scale (* scale1[b_ids[m]] when scale1 != NULL),
  * win_scale = (W // 2) * (hw0_i[0] / hw0_f[0]). */
+/* backward of far_fine_gather_f32 (training): dfeat (feat's strides and shape) += dout [M][W*W][C] at the gathered positions;
+ * fp32 atomics (overlapping windows, cells sampled with replacement: coarse_matching.py:216-229). */
+int far_fine_scatter_f32(const float* dout, long sn, long sc, long sh, long sw, int C, int Hf, int Wf,
+                         const int64_t* b_ids, const int64_t* cell_ids, int wc, int W, int stride, int M,
+                         float* dfeat, far_stream_t stream);
 int far_fine_expect_f32(const float* feat0, const float* feat1, int M, int W, int C, const float* mkpts1_c,
                         float win_scale, const float* scale1, const int64_t* b_ids, float* expec_f,
                         float* mkpts1_f, far_stream_t stream);

@@ -308,3 +308,32 @@ def test_backward_kernels_keep_their_precision_at_any_gradient_scale(log2_scale)
     errs = [rel(a.grad, b.grad) for a, b in zip((q, k, v), r)]
     print(f'[scale 2^{log2_scale}] K2 dq {errs[0]:.2e} dk {errs[1]:.2e} dv {errs[2]:.2e}')
     assert errs[0] < 5e-3 and errs[1] < 5e-3 and errs[2] < 1e-5
+
+
+def test_fine_window_gather_backward_matches_unfold_autograd():
+    """K3a's scatter backward (far_fine_scatter_f32) against autograd through F.unfold + gather (fine_preprocess.py:40-47):
+    same windows, same gradient of the fine map -- with cells sampled more than once and windows at the image border."""
+    from far_amd import autograd_ops as ag
+    from far_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(8)
+    N, C, Hf, Wf, W, stride = 2, 128, 24, 32, 5, 4
+    wc = Wf // stride
+    feat = torch.randn(N, C, Hf, Wf, device='cuda', generator=g).contiguous(memory_format=torch.channels_last)
+    M = 300
+    b = torch.randint(0, N, (M,), device='cuda', generator=g)
+    cell = torch.randint(0, (Hf // stride) * wc, (M,), device='cuda', generator=g)
+    cell[:20] = cell[20:40]                                             # repeated cells (training samples with replacement)
+    b[:20] = b[20:40]
+    cell[40] = 0
+    cell[41] = (Hf // stride) * wc - 1                                  # corner windows (zero padding)
+    up = torch.randn(M, W * W, C, device='cuda', generator=g)
+    f1 = feat.clone().requires_grad_(True)
+    w1 = ops.fine_windows_train(f1, b, cell, wc, W, stride)
+    (w1 * up).sum().backward()
+    f2 = feat.clone().double().requires_grad_(True)
+    w2 = ag.fine_windows(f2, b, cell, W, stride)
+    (w2 * up.double()).sum().backward()
+    assert torch.equal(w1.detach(), w2.detach().float())
+    err = float((f1.grad.double() - f2.grad).abs().max()) / float(f2.grad.abs().max())
+    print(f'[k3 bwd] fine-map gradient: relative max error {err:.2e}')
+    assert err < 1e-6 and f1.grad.shape == feat.shape
