@@ -413,6 +413,10 @@ def bench_c3(a, dev, world, rank, dist):
     if a.vendor_train:
         LoFTREncoderLayer.hip_training = False
         CrossAttention.hip_training = False
+        from far_amd.loftr.backbone import ResNetFPN_8_2
+        from far_amd.loftr.stages import FinePreprocess
+        ResNetFPN_8_2.hip_training = False
+        FinePreprocess.hip_training = False
         model.coarse_matching.materialize_conf = True          # dense conf_matrix through the vendor ops + autograd
     loss_fn = LoFTRLoss(cfg).train()
     fwd = model

@@ -6,7 +6,9 @@ Mirrors the architecture and PARAMETER NAMES of mp3d_loftr/src/loftr/backbone/re
 Inference in fp32 on the GPU runs `_forward_fused`: NHWC activations end to end, the stem on K10, every 3x3 / 1x1
 convolution on K9 (split-fp16 implicit GEMM with BatchNorm, activation and residual add fused into the epilogue), the
 FPN upsample-add on K8: no vendor convolution is left on the inference path.
-Training (gradients) and the optional half-precision modes run the plain torch modules.
+Training (gradients) on the GPU runs the same module graph with every 3x3 / 1x1 convolution on K9 forward and K9 dgrad
+(ops.conv_train; BatchNorm with batch statistics, activations and the FPN interpolation stay torch ops); CPU tensors and
+the optional half-precision modes run the plain torch modules.
 """
 import torch
 import torch.nn as nn
@@ -47,6 +49,16 @@ def _c3(i, o, s=1):
     return nn.Conv2d(i, o, 3, stride=s, padding=1, bias=False)
 
 
+def _conv(conv, x, owner):
+    """conv(x) for the reference-style (training / CPU) forward: on the GPU with gradients enabled the bias-free 3x3 / 1x1
+    convolutions run K9 forward and K9 dgrad (ops.conv_train); otherwise the nn.Conv2d itself."""
+    if (ResNetFPN_8_2.hip_training and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and conv.bias is None
+            and conv.kernel_size[0] in (1, 3) and conv.in_channels % 4 == 0 and (x.requires_grad or conv.weight.requires_grad)):
+        pk = owner.__dict__.setdefault('_train_packs', ops.PackCache())
+        return ops.conv_train(x, conv.weight, conv.stride[0], pk, id(conv))
+    return conv(x)
+
+
 class BasicBlock(nn.Module):
     def __init__(self, in_planes, planes, stride=1):
         super().__init__()
@@ -58,9 +70,9 @@ class BasicBlock(nn.Module):
         self.downsample = None if stride == 1 else nn.Sequential(_c1(in_planes, planes, stride), nn.BatchNorm2d(planes))
 
     def forward(self, x):          # reference-style modules: training, CPU, autocast (inference runs _forward_fused)
-        y = self.bn2(self.conv2(self.relu(self.bn1(self.conv1(x)))))
+        y = self.bn2(_conv(self.conv2, self.relu(self.bn1(_conv(self.conv1, x, self))), self))
         if self.downsample is not None:
-            x = self.downsample(x)
+            x = self.downsample[1](_conv(self.downsample[0], x, self))
         return self.relu(x + y)
 
 
@@ -88,11 +100,16 @@ class ResNetFPN_8_2(nn.Module):
                 nn.init.constant_(m.weight, 1)
                 nn.init.constant_(m.bias, 0)
 
+    hip_training = True          # training on the GPU: convolutions on K9 (forward + dgrad); False: vendor convolutions + autograd
+
+    def _outconv2(self, seq, x):
+        return _conv(seq[3], seq[2](seq[1](_conv(seq[0], x, self))), self)
+
     def _fpn_plain(self, x1, x2, x3_out):
         up3 = F.interpolate(x3_out, scale_factor=2., mode='bilinear', align_corners=True)
-        x2_out = self.layer2_outconv2(self.layer2_outconv(x2) + up3)
+        x2_out = self._outconv2(self.layer2_outconv2, _conv(self.layer2_outconv, x2, self) + up3)
         up2 = F.interpolate(x2_out, scale_factor=2., mode='bilinear', align_corners=True)
-        return self.layer1_outconv2(self.layer1_outconv(x1) + up2)
+        return self._outconv2(self.layer1_outconv2, _conv(self.layer1_outconv, x1, self) + up2)
 
     # ---- inference fast path: NHWC activations, K10 + K9 + K8 (tensors below are (N, H, W, C)) ----------------
     # K9 operand precision: True = split fp16 pairs (fp32-grade, the parity configuration), False = plain fp16.
@@ -144,7 +161,7 @@ class ResNetFPN_8_2(nn.Module):
         x1 = self.layer1(x0)
         x2 = self.layer2(x1)
         x3 = self.layer3(x2)
-        x3_out = self.layer3_outconv(x3)
+        x3_out = _conv(self.layer3_outconv, x3, self)
         return [x3_out, self._fpn_plain(x1, x2, x3_out)]
 
 

@@ -463,6 +463,71 @@ def linear_train(x, weight, bias, cache, name, split=True):
     return _LinearF16sFn.apply(x, weight, bias, pack, pack_t)
 
 
+class _ConvF16sFn(torch.autograd.Function):
+    """A bias-free 3x3 / 1x1 convolution (stride 1 or 2, 'same' padding) of the ResNet-FPN backbone with gradients
+    (resnet_fpn.py:5-12 conv1x1 / conv3x3 under autograd).  Forward: K9.  dgrad: K9 again -- the transposed convolution of a
+    'same' stride-1 convolution is a 'same' stride-1 convolution with the spatially flipped, channel-transposed kernel; for
+    stride 2 the output gradient is first spread onto the input grid (zeros in between).  wgrad: far_conv_wgrad_f32 when the
+    library has it for the shape, else the vendor's backward-weights.  x, y: (N, C, H, W) logical, channels_last memory."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, pack, pack_d):
+        ks = int(weight.shape[-1])
+        xn = x.detach().float().contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)      # NHWC view
+        xin = xn if (ks == 3 or stride == 1) else xn[:, ::stride, ::stride].contiguous()                # 1x1 stride 2
+        y = conv_nhwc(xin, pack())
+        ctx.save_for_backward(xn, weight)
+        ctx.stride, ctx.pack_d = int(stride), pack_d
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        xn, weight = ctx.saved_tensors
+        ks, st = int(weight.shape[-1]), ctx.stride
+        N, H, W, Cin = xn.shape
+        gn = g.float().contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)                # (N, Ho, Wo, Cout)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            # gradients sit anywhere in magnitude: a power-of-two scale from the maximum places them in K9's window (as _LinearF16sFn)
+            e = torch.frexp(torch.linalg.vector_norm(gn, ord=float('inf')))[1].clamp(min=-100)
+            one = torch.ones((), dtype=torch.float32, device=g.device)
+            gs = gn * torch.ldexp(one, 10 - e)
+            if st == 1:
+                dxn = conv_nhwc(gs.contiguous(), ctx.pack_d())
+            elif ks == 3:
+                up = torch.zeros(N, H, W, gs.shape[-1], dtype=torch.float32, device=g.device)
+                up[:, ::st, ::st] = gs
+                dxn = conv_nhwc(up, ctx.pack_d())
+            else:
+                dxn = torch.zeros(N, H, W, Cin, dtype=torch.float32, device=g.device)
+                dxn[:, ::st, ::st] = conv_nhwc(gs.contiguous(), ctx.pack_d())
+            dxn.mul_(torch.ldexp(one, e - 10))
+            dx = dxn.permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[1]:
+            dw = conv_wgrad(xn, gn, ks, st)
+            if dw is None:                                                                              # shape without a kernel: vendor
+                dw = torch.ops.aten.convolution_backward(gn.permute(0, 3, 1, 2), xn.permute(0, 3, 1, 2), weight, None, [st, st],
+                                                         [ks // 2, ks // 2], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+        return dx, dw, None, None, None
+
+
+def conv_wgrad(xn, gn, ks, stride):
+    """dW (Cout, Cin, ks, ks) of a 'same' convolution from its NHWC input xn and NHWC output gradient gn; None where no HIP
+    kernel covers the shape (the caller then uses the vendor's backward-weights)."""
+    return None
+
+
+def conv_train(x, weight, stride, cache, name, split=True):
+    """K9 convolution with gradients.  x (N, Cin, H, W) fp32 GPU; weight (Cout, Cin, k, k), k in {1, 3}; cache: a PackCache."""
+    if not x.is_cuda:
+        raise _lib.FarHipError('far_amd ops need tensors on the GPU (no CPU fallback exists)')
+    ks = int(weight.shape[-1])
+    pack = lambda: cache.get((name, 'fwd', split), [weight], lambda: PackedConv(weight, split=split, stride=stride if ks == 3 else 1))
+    pack_d = lambda: cache.get((name, 'dgrad', split), [weight],
+                               lambda: PackedConv(weight.detach().flip(2, 3).transpose(0, 1).contiguous(), split=split))
+    return _ConvF16sFn.apply(x, weight, int(stride), pack, pack_d)
+
+
 def solve_pose_batch(kpts0, kpts1, offsets_host, K0, K1, inl_th, many_thr, priorRT=None, pcl=None,
                      prior_lambda=0.3, H=2048, seed=0, samples=None, debug=False, minimal=8):
     """K4.  kpts0/kpts1: (Mtot, 2) fp32 GPU; offsets_host: python list / CPU int tensor of B+1 offsets;

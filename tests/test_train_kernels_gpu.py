@@ -337,3 +337,27 @@ def test_fine_window_gather_backward_matches_unfold_autograd():
     err = float((f1.grad.double() - f2.grad).abs().max()) / float(f2.grad.abs().max())
     print(f'[k3 bwd] fine-map gradient: relative max error {err:.2e}')
     assert err < 1e-6 and f1.grad.shape == feat.shape
+
+
+@pytest.mark.parametrize('Cin,Cout,ks,stride,H,W', [(128, 128, 3, 1, 24, 32), (128, 196, 3, 2, 24, 32), (196, 256, 3, 2, 13, 17),
+                                                   (196, 196, 3, 1, 9, 20), (128, 196, 1, 2, 24, 32), (256, 256, 1, 1, 8, 12)])
+def test_conv_train_forward_and_gradients_match_float64(Cin, Cout, ks, stride, H, W):
+    """ops.conv_train (K9 forward, K9 dgrad with the flipped / transposed kernel, zero-spread output gradient for stride 2)
+    against float64 autograd of F.conv2d: output, input gradient, weight gradient -- at a gradient scale of 1e-6."""
+    import torch.nn.functional as F
+    from far_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(Cin + Cout + ks + stride)
+    x = torch.randn(2, Cin, H, W, device='cuda', generator=g).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(Cout, Cin, ks, ks, device='cuda', generator=g) * (2.0 / (Cin * ks * ks)) ** 0.5
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    up = torch.randn(2, Cout, Ho, Wo, device='cuda', generator=g) * 1e-6
+    x1, w1 = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y1 = ops.conv_train(x1, w1, stride, ops.PackCache(), 'c')
+    (y1 * up).sum().backward()
+    x2, w2 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    y2 = F.conv2d(x2, w2, stride=stride, padding=ks // 2)
+    (y2 * up.double()).sum().backward()
+    rel = lambda a, b: float((a.double() - b).abs().max() / b.abs().max())
+    e = (rel(y1.detach(), y2.detach()), rel(x1.grad, x2.grad), rel(w1.grad, w2.grad))
+    print(f'[conv train] {Cin}->{Cout} k{ks} s{stride}: y {e[0]:.1e}  dx {e[1]:.1e}  dw {e[2]:.1e}')
+    assert y1.shape == y2.shape and e[0] < 4e-6 and e[1] < 4e-6 and e[2] < 2e-5
