@@ -54,6 +54,8 @@ SIGNATURES = {
     'far_upsample2x_add_f32': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     'far_conv_packed_bytes': (c_sz, [c_i, c_i, c_i, c_i, c_i]),
     'far_conv_pack_f32': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
+    'far_conv_pack_auto_f32': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),
+    'far_grad_scale_f32': (c_i, [c_p, c_l, c_p, c_p]),
     'far_conv_nhwc_f32': (c_i, [c_p, c_p]),                  # (const far_conv_desc*, stream): see ConvDesc
     'far_emm_pv_f16s_workspace_bytes': (c_sz, [c_i, c_i]),
     'far_emm_pv_f16s': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_i, c_l, c_l, c_i, c_p, c_p, c_p, c_p]),
@@ -85,7 +87,8 @@ class ConvDesc(ctypes.Structure):
                [('N', ctypes.c_long)] + \
                [(n, ctypes.c_int) for n in ('H', 'W', 'Cin', 'Cin1', 'Cout', 'ksize', 'stride', 'act', 'split',
                                             'out_planes', 'res_group')] + \
-               [('slope', ctypes.c_float), ('ln_eps', ctypes.c_float), ('act_exp', ctypes.c_int), ('overflow', ctypes.c_void_p)]
+               [('slope', ctypes.c_float), ('ln_eps', ctypes.c_float), ('act_exp', ctypes.c_int), ('overflow', ctypes.c_void_p),
+                ('act_scale_dev', ctypes.c_void_p)]
 
 
 _lib = None

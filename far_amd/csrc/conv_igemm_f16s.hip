@@ -96,6 +96,7 @@ struct ConvArgs {
     float act_scale;             // 2^act_exp: activations are multiplied by it before the fp16 split (default 2^4)
     float out_mul;               // 2^(4 - act_exp): `scale` folds 2^-4, this corrects it for the scale actually used
     int* overflow;               // device flag, |= 1 when an accumulator of this launch is not finite (may be null)
+    const float* scale_dev;      // device { act_scale, out_mul } overriding the two fields above (may be null)
 };
 
 __device__ __forceinline__ void split8(const float4& u, const float4& v, float act_scale, f16x8& hi, f16x8& lo) {
@@ -546,6 +547,10 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / NW, wn = wave % NW, l31 = lane & 31, h = lane >> 5;
+    // the activation scale: a launch argument, or two device floats written by far_grad_scale_f32 (gradients: the scale follows
+    // the tensor's maximum, chosen on the device without a host round trip)
+    const float act_scale = p.scale_dev ? p.scale_dev[0] : p.act_scale;
+    const float out_mul = p.scale_dev ? p.scale_dev[1] : p.out_mul;
     FAR_K9_STAMP(0);
 #ifdef FAR_K9_TIMING
     if (threadIdx.x == 0 && blockIdx.x < 65536) g_k9_stamps[12 * blockIdx.x + 8] = __builtin_amdgcn_s_memrealtime();
@@ -625,7 +630,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p) {
     stage_load<KS, MW, ST, NTHR, ITERS>(st, p, tp, 0, tid);
     prefetch();
     prefetch();
-    stage_store<KS, MW, ST, NTHR, ITERS, SPLIT>(st, As, tid, p.act_scale);
+    stage_store<KS, MW, ST, NTHR, ITERS, SPLIT>(st, As, tid, act_scale);
     FAR_K9_STAMP(1);
 
     // Fragment registers.  The pixel (A) fragments of a phase are read during the previous phase; the weight (B)
@@ -741,7 +746,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p) {
         stage_arrived(st);
         if (chunk + 1 < nchunks) {
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done with this chunk's pixels
-            stage_store<KS, MW, ST, NTHR, ITERS, SPLIT>(st, As, tid, p.act_scale);
+            stage_store<KS, MW, ST, NTHR, ITERS, SPLIT>(st, As, tid, act_scale);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the trailing (unused) slab requests must land before LDS is reused
@@ -769,18 +774,20 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p) {
         return;
     }
 #endif
+    ConvArgs pe = p;                 // the epilogues read the output multiplier from their argument block
+    pe.out_mul = out_mul;
     if (NTW == 4 && ((p.Cout | p.Csub) & 3) == 0) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave is past its last LDS fragment read
         // N7: channels 96..127 of the workgroup (the shared tile) are stored by wn = 0 for mt = 0 and by wn = 1 for mt = 1
         if constexpr (N7)
-            conv_epilogue_wide<KS, NW, UP>(p, acc, tp, cout_w, wm, wave, lane, reinterpret_cast<float*>(smem) + wave * (32 * 128),
+            conv_epilogue_wide<KS, NW, UP>(pe, acc, tp, cout_w, wm, wave, lane, reinterpret_cast<float*>(smem) + wave * (32 * 128),
                                            reinterpret_cast<float*>(smem) + MW * NW * (32 * 128), wn == 0 ? 1 : 0,
                                            wn == 0 ? 24 : 0, wn == 0 ? 32 : 8);
         else
-            conv_epilogue_wide<KS, NW, UP>(p, acc, tp, cout_w, wm, wave, lane, reinterpret_cast<float*>(smem) + wave * (32 * 128),
+            conv_epilogue_wide<KS, NW, UP>(pe, acc, tp, cout_w, wm, wave, lane, reinterpret_cast<float*>(smem) + wave * (32 * 128),
                                            reinterpret_cast<float*>(smem) + MW * NW * (32 * 128));
     } else {
-        conv_epilogue<KS, NTW>(p, acc, tp, cout_w, wm, l31, h);
+        conv_epilogue<KS, NTW>(pe, acc, tp, cout_w, wm, l31, h);
     }
 #ifdef FAR_K9_TIMING
     FAR_K9_STAMP(3);                                   // epilogue instructions issued
@@ -800,11 +807,39 @@ __global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const 
     }
 }
 
+// max |w| as its bit pattern (non-negative floats order like unsigned integers): one atomicMax per workgroup
+__global__ void k_absmax_bits(const float* __restrict__ w, long n, unsigned* __restrict__ out) {
+    __shared__ unsigned part[256];
+    unsigned m = 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const unsigned b = __float_as_uint(fabsf(w[i]));
+        m = b > m ? b : m;
+    }
+    part[threadIdx.x] = m;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d && part[threadIdx.x + d] > part[threadIdx.x]) part[threadIdx.x] = part[threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicMax(out, part[0]);
+}
+// s[0] (max |w|, as written above) -> s[0] = 2^w_exp, s[1] = 2^-(w_exp + 4) with w_exp = 14 - exponent(max |w|)  (frexp convention)
+__global__ void k_pack_scale(float* __restrict__ s) {
+    const float amax = s[0];
+    int e = 0;
+    if (amax > 0.f && amax <= FLT_MAX) (void)frexpf(amax, &e);
+    int w_exp = 14 - e;
+    w_exp = w_exp < -60 ? -60 : (w_exp > 60 ? 60 : w_exp);
+    s[0] = ldexpf(1.0f, w_exp);
+    s[1] = ldexpf(1.0f, -(w_exp + ACT_EXP_DEFAULT));
+}
+
 // Packs torch-layout weights [Cout][Cin][KS][KS] (or [Cout][Cin] for linear) into the LDS image the kernel DMAs, in
 // execution order: [chunk][tap][k-step][cout block][plane][NT rows][2 slots of 8 channels, slot ^= (row >> 3) & 1]
 // fp16, scaled by 2^w_exp (plain operands: [chunk][tap][cout block][k-step][NT rows][...], one slab per tap).
 __global__ void k_conv_pack(const float* __restrict__ w, int Cin, int Cout, int taps, int nchunks, int nblkY, int NT,
-                            int planes, float wmul, _Float16* __restrict__ out) {
+                            int planes, float wmul, const float* __restrict__ wmul_dev, _Float16* __restrict__ out) {
+    if (wmul_dev) wmul = *wmul_dev;                      // the scale chosen on the device (far_conv_pack_auto_f32)
     const long total = (long)taps * nchunks * 2 * nblkY * NT * 2;
     if (blockIdx.x == 0 && threadIdx.x < 16) out[(size_t)total * 8 * planes + threadIdx.x] = (_Float16)0.f;   // the zero row
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -897,7 +932,46 @@ int far_conv_pack_f32(const float* w, int Cin, int Cout, int ksize, int stride, 
     const int NT = cfg_for(Cout, stride).nt;
     const int nchunks = (Cin + 31) / 32, nblkY = (Cout + NT - 1) / NT;
     hipLaunchKernelGGL(k_conv_pack, dim3(512), dim3(256), 0, stream, w, Cin, Cout, ksize * ksize, nchunks, nblkY, NT,
-                       split ? 2 : 1, ldexpf(1.0f, w_exp), (_Float16*)packed);
+                       split ? 2 : 1, ldexpf(1.0f, w_exp), (const float*)nullptr, (_Float16*)packed);
+    return far_check_launch();
+}
+
+// The same with the exponent chosen ON THE DEVICE from max|w| (no host read of the weights: a training step re-packs every
+// layer after every optimizer update): scale_out[0] = 2^w_exp (the multiplier applied), scale_out[1] = 2^-(w_exp + 4) (the factor
+// the caller folds into far_conv_nhwc_f32's `scale` vector), with 2^13 <= max|w| 2^w_exp < 2^14 (w_exp = 0 for an all-zero weight).
+int far_conv_pack_auto_f32(const float* w, int Cin, int Cout, int ksize, int stride, int split, void* packed, float* scale_out,
+                           hipStream_t stream) {
+    far_clear_errors();
+    if (!w || !packed || !scale_out || far_conv_packed_bytes(Cin, Cout, ksize, stride, split) == 0) return FAR_EINVAL;
+    const int NT = cfg_for(Cout, stride).nt;
+    const int nchunks = (Cin + 31) / 32, nblkY = (Cout + NT - 1) / NT;
+    const long n = (long)Cout * Cin * ksize * ksize;
+    hipMemsetAsync(scale_out, 0, 2 * sizeof(float), stream);
+    hipLaunchKernelGGL(k_absmax_bits, dim3(256), dim3(256), 0, stream, w, n, reinterpret_cast<unsigned*>(scale_out));
+    hipLaunchKernelGGL(k_pack_scale, dim3(1), dim3(1), 0, stream, scale_out);
+    hipLaunchKernelGGL(k_conv_pack, dim3(512), dim3(256), 0, stream, w, Cin, Cout, ksize * ksize, nchunks, nblkY, NT,
+                       split ? 2 : 1, 1.0f, (const float*)scale_out, (_Float16*)packed);
+    return far_check_launch();
+}
+
+// The activation scale of a tensor whose magnitude is not known in advance (gradients: 1e-7 is usual): out = { 2^e, 2^(4 - e) }
+// with max|x| 2^e in [2^9, 2^10) -- the top of the split's window, two device floats for far_conv_desc.act_scale_dev.  The
+// launch that uses them then needs no pre-scaling pass over its input and no un-scaling pass over its output.
+__global__ void k_grad_scale(float* __restrict__ s) {
+    const float amax = s[0];
+    int e = 0;
+    if (amax > 0.f && amax <= FLT_MAX) (void)frexpf(amax, &e);
+    int ex = 10 - e;
+    ex = ex < -100 ? -100 : (ex > 100 ? 100 : ex);
+    s[0] = ldexpf(1.0f, ex);
+    s[1] = ldexpf(1.0f, ACT_EXP_DEFAULT - ex);
+}
+int far_grad_scale_f32(const float* x, long n, float* out2, hipStream_t stream) {
+    far_clear_errors();
+    if (!x || !out2 || n <= 0) return FAR_EINVAL;
+    hipMemsetAsync(out2, 0, 2 * sizeof(float), stream);
+    hipLaunchKernelGGL(k_absmax_bits, dim3(n > 65536 ? 256 : 16), dim3(256), 0, stream, x, n, reinterpret_cast<unsigned*>(out2));
+    hipLaunchKernelGGL(k_grad_scale, dim3(1), dim3(1), 0, stream, out2);
     return far_check_launch();
 }
 
@@ -933,6 +1007,7 @@ struct far_conv_desc {          // mirrors include/far_hip.h
     float slope, ln_eps;
     int act_exp;
     int* overflow;
+    const float* act_scale_dev;
 };
 
 int far_conv_nhwc_f32(const far_conv_desc* desc, hipStream_t stream) {
@@ -975,6 +1050,7 @@ int far_conv_nhwc_f32(const far_conv_desc* desc, hipStream_t stream) {
     a.nblkY = (Cout + c.nt - 1) / c.nt;
     a.act = act; a.slope = slope;
     a.act_scale = ldexpf(1.0f, d.act_exp); a.out_mul = ldexpf(1.0f, ACT_EXP_DEFAULT - d.act_exp); a.overflow = d.overflow;
+    a.scale_dev = d.act_scale_dev;
     const long nbx = ksize == 1 ? (a.npix + 64 * c.mw - 1) / (64 * c.mw) : N * a.tilesX * a.tilesY;
     a.ntiles = nbx;
     if (nbx * a.nblkY > 0x7fffffffL) return FAR_EINVAL;

@@ -445,10 +445,8 @@ class _LinearF16sFn(torch.autograd.Function):
             # ~[8e-3, 4e3], the range of activations -- gradients can sit anywhere (1e-7 is usual).  A power-of-two scale
             # taken from the tensor's maximum (on the device, no host sync) places them at the top of that window;
             # entries below max * 2^-17 keep 11 bits, which is 2^-28 of the maximum.
-            e = torch.frexp(torch.linalg.vector_norm(g, ord=float('inf')))[1].clamp(min=-100)   # max |g| = m 2^e, m in [0.5, 1)
-            one = torch.ones((), dtype=torch.float32, device=g.device)
-            dx = linear_f16s(g * torch.ldexp(one, 10 - e), ctx.pack_t())
-            dx.mul_(torch.ldexp(one, e - 10))
+            # (far_grad_scale_f32 picks it on the device and K9 applies it inside the launch: no scaling passes over g / dx)
+            dx = linear_f16s(g, ctx.pack_t(), act_scale_dev=grad_scale(g))
         g2, x2 = g.reshape(-1, g.shape[-1]), xc.reshape(-1, xc.shape[-1])
         dw = g2.t().mm(x2) if ctx.needs_input_grad[1] else None
         db = g2.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
@@ -489,19 +487,17 @@ class _ConvF16sFn(torch.autograd.Function):
         dx = dw = None
         if ctx.needs_input_grad[0]:
             # gradients sit anywhere in magnitude: a power-of-two scale from the maximum places them in K9's window (as _LinearF16sFn)
-            e = torch.frexp(torch.linalg.vector_norm(gn, ord=float('inf')))[1].clamp(min=-100)
-            one = torch.ones((), dtype=torch.float32, device=g.device)
-            gs = gn * torch.ldexp(one, 10 - e)
+            gs = gn.contiguous()
+            sc = grad_scale(gs)
             if st == 1:
-                dxn = conv_nhwc(gs.contiguous(), ctx.pack_d())
+                dxn = conv_nhwc(gs, ctx.pack_d(), act_scale_dev=sc)
             elif ks == 3:
                 up = torch.zeros(N, H, W, gs.shape[-1], dtype=torch.float32, device=g.device)
                 up[:, ::st, ::st] = gs
-                dxn = conv_nhwc(up, ctx.pack_d())
+                dxn = conv_nhwc(up, ctx.pack_d(), act_scale_dev=sc)
             else:
                 dxn = torch.zeros(N, H, W, Cin, dtype=torch.float32, device=g.device)
-                dxn[:, ::st, ::st] = conv_nhwc(gs.contiguous(), ctx.pack_d())
-            dxn.mul_(torch.ldexp(one, e - 10))
+                dxn[:, ::st, ::st] = conv_nhwc(gs, ctx.pack_d(), act_scale_dev=sc)
             dx = dxn.permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
             dw = conv_wgrad(xn, gn, ks, st)
@@ -764,19 +760,19 @@ class PackedConv:
         if kh != kw or kh not in (1, 3):
             raise _lib.FarHipError(f'K9 supports 1x1 and 3x3 kernels, got {kh}x{kw}')
         w = w.contiguous().float()
-        amax = float(w.abs().max())                       # one host sync, at pack time only
-        self.w_exp = 14 - (torch.frexp(torch.tensor(amax)).exponent.item() if amax > 0 else 0)
         if stride not in (1, 2) or (stride == 2 and kh != 3):
             raise _lib.FarHipError('K9 supports stride 1, and stride 2 for 3x3 kernels')
         self.Cin, self.Cout, self.ksize, self.split, self.stride = Cin, Cout, kh, bool(split), stride
         nbytes = lib.far_conv_packed_bytes(Cin, Cout, kh, stride, int(self.split))
         self.packed = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
-        rc = lib.far_conv_pack_f32(_p(w, torch.float32), Cin, Cout, kh, stride, self.w_exp, int(self.split), _p(self.packed),
-                                   _stream())
-        _lib.check(rc, 'far_conv_pack_f32')
-        unscale = 2.0 ** -(self.w_exp + _CONV_ACT_EXP)
+        # the power-of-two weight scale 2^w_exp (max |w| 2^w_exp in [2^13, 2^14)) is chosen on the device: no host read of the
+        # weights, so re-packing after every optimizer step costs three small launches and no synchronisation
+        self.pack_scale = torch.empty(2, dtype=torch.float32, device=w.device)          # { 2^w_exp, 2^-(w_exp + 4) }
+        rc = lib.far_conv_pack_auto_f32(_p(w, torch.float32), Cin, Cout, kh, stride, int(self.split), _p(self.packed),
+                                        _p(self.pack_scale), _stream())
+        _lib.check(rc, 'far_conv_pack_auto_f32')
         s = torch.ones(Cout, device=w.device) if scale is None else scale.detach().float()
-        self.scale = (s * unscale).contiguous()           # power-of-two factor: exact
+        self.scale = (s * self.pack_scale[1]).contiguous()        # power-of-two factor: exact
         self.shift = None if shift is None else shift.detach().float().contiguous()
 
 
@@ -917,8 +913,17 @@ class PackCache:
         return hit[1]
 
 
+def grad_scale(x):
+    """Two device floats { 2^e, 2^(4 - e) }, max|x| 2^e in [2^9, 2^10): the activation scale of a K9 launch whose input is a
+    gradient (conv_nhwc(..., act_scale_dev=...)); no host synchronisation."""
+    lib = _lib.load()
+    out = torch.empty(2, dtype=torch.float32, device=x.device)
+    _lib.check(lib.far_grad_scale_f32(_p(x, torch.float32), x.numel(), _p(out), _stream()), 'far_grad_scale_f32')
+    return out
+
+
 def conv_nhwc(x, pc, residual=None, act='none', slope=0.01, x2=None, out_planes=1, res_group=1, ln=None,
-              post_residual=None, out=None, up=None):
+              post_residual=None, out=None, up=None, act_scale_dev=None):
     """K9.  x (N, H, W, Cin) fp32 contiguous -> act(conv(x) * scale + shift (+ residual)) as (N, H, W, Cout).
     With x2 (N, H, W, C2) the convolution input is cat([x, x2], -1), read in place.  out_planes = P > 1 returns
     (P, N, H, W, Cout / P): the output channels split into P separate contiguous tensors.
@@ -951,14 +956,15 @@ def conv_nhwc(x, pc, residual=None, act='none', slope=0.01, x2=None, out_planes=
                       res=ptr(residual), ln_gamma=ptr(g), ln_beta=ptr(b), post_res=ptr(post_residual), up=ptr(up), y=ptr(y),
                       N=N, H=H, W=W, Cin=Cin, Cin1=Cin1, Cout=pc.Cout, ksize=pc.ksize, stride=st, act=_ACT[act],
                       split=int(pc.split), out_planes=int(out_planes), res_group=int(res_group), slope=float(slope),
-                      ln_eps=float(eps), act_exp=activation_exponent_value(), overflow=overflow_flag(x.device).data_ptr())
+                      ln_eps=float(eps), act_exp=activation_exponent_value(), overflow=overflow_flag(x.device).data_ptr(),
+                      act_scale_dev=None if act_scale_dev is None else act_scale_dev.data_ptr())
     rc = lib.far_conv_nhwc_f32(ctypes.byref(d), _stream())
     _lib.check(rc, 'far_conv_nhwc_f32')
     return y if out is None else _written(y)
 
 
 def linear_f16s(x, pc, residual=None, act='none', x2=None, out_planes=1, res_group=1, ln=None, post_residual=None,
-                out=None):
+                out=None, act_scale_dev=None):
     """K9 as a linear layer: x (..., K) fp32 -> act(cat([x, x2], -1) W^T * scale + shift (+ residual)) (..., Cout);
     out_planes = P > 1: (P, ..., Cout / P), e.g. the q / k / v projections of one input in one launch.
     res_group = G > 1: residual is (rows / G, Cout), one row shared by each group of G consecutive rows.
@@ -972,7 +978,7 @@ def linear_f16s(x, pc, residual=None, act='none', x2=None, out_planes=1, res_gro
     x2 = None if x2 is None else x2.reshape(1, 1, rows, x2.shape[-1])
     pr = None if post_residual is None else post_residual.reshape(1, 1, rows, pc.Cout)
     y = conv_nhwc(x.reshape(1, 1, rows, x.shape[-1]), pc, residual=r, act=act, x2=x2, out_planes=out_planes,
-                  res_group=res_group, ln=ln, post_residual=pr, out=out)
+                  res_group=res_group, ln=ln, post_residual=pr, out=out, act_scale_dev=act_scale_dev)
     return y.reshape(*lead, pc.Cout) if out_planes == 1 else y.reshape(out_planes, *lead, pc.Cout // out_planes)
 
 

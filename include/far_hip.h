@@ -283,6 +283,10 @@ size_t far_conv_packed_bytes(int Cin, int Cout, int ksize, int stride, int split
  * 2^13 <= max|w| 2^w_exp < 2^15 and fold 2^-(w_exp + 4) into the `scale` vector of far_conv_nhwc_f32. */
 int far_conv_pack_f32(const float* w, int Cin, int Cout, int ksize, int stride, int w_exp, int split, void* packed,
                       far_stream_t stream);
+/* The same with w_exp chosen on the device from max|w| (no host read: training re-packs every layer after every optimizer
+ * step): scale_out (2 device floats) = { 2^w_exp, 2^-(w_exp + 4) }; the caller multiplies its `scale` vector by scale_out[1]. */
+int far_conv_pack_auto_f32(const float* w, int Cin, int Cout, int ksize, int stride, int split, void* packed, float* scale_out,
+                           far_stream_t stream);
 
 /* One K9 launch.  y = LN?( act(scale[co] * conv(X, W)[.., co] + shift[co] (+ res)) ) (+ post_res):
  *   X = x [N][H][W][Cin1] or, with x2 != NULL, the channel concatenation [x | x2] (x2 [N][H][W][Cin - Cin1],
@@ -328,9 +332,13 @@ typedef struct far_conv_desc {
     float slope, ln_eps;
     int act_exp;      /* activations x 2^act_exp before the fp16 split; 4 = default, [-24, 8]: inputs up to 65504 / 2^act_exp */
     int* overflow;    /* device int, |= 1 when an accumulator of the launch is not finite (input out of that range); or NULL */
+    const float* act_scale_dev;   /* NULL, or two device floats { 2^e, 2^(4 - e) } from far_grad_scale_f32 that replace act_exp */
 } far_conv_desc;
 
 int far_conv_nhwc_f32(const far_conv_desc* desc, far_stream_t stream);
+/* Activation scale for an input of unknown magnitude (the output gradient in a dgrad launch): out2 = { 2^e, 2^(4 - e) } with
+ * max|x| 2^e in [2^9, 2^10), computed on the device -- pass out2 as far_conv_desc.act_scale_dev. */
+int far_grad_scale_f32(const float* x, long n, float* out2, far_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * K10  backbone stem: 7x7 stride-2 convolution of a 1-channel image + folded BatchNorm + ReLU (exact-f32 MFMA)
