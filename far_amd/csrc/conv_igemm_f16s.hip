@@ -823,6 +823,49 @@ __global__ void k_absmax_bits(const float* __restrict__ w, long n, unsigned* __r
     }
     if (threadIdx.x == 0) atomicMax(out, part[0]);
 }
+// max |w| of a small tensor by ONE workgroup (no memset, no atomics: one launch), then `finish` turns it into the two scales
+template <int MODE>      // 0: weight pack scales { 2^w_exp, 2^-(w_exp + 4) }; 1: gradient scales { 2^e, 2^(4 - e) }
+__global__ __launch_bounds__(1024) void k_amax_scale_single(const float* __restrict__ w, long n, float* __restrict__ s) {
+    __shared__ unsigned part[1024];
+    unsigned m = 0;
+    const long n4 = n >> 2;
+    const float4* w4 = reinterpret_cast<const float4*>(w);
+    for (long i = threadIdx.x; i < n4; i += 1024) {
+        const float4 v = w4[i];
+        const unsigned a = __float_as_uint(fabsf(v.x)), b = __float_as_uint(fabsf(v.y)), c = __float_as_uint(fabsf(v.z)),
+                       d = __float_as_uint(fabsf(v.w));
+        const unsigned ab = a > b ? a : b, cd = c > d ? c : d, q = ab > cd ? ab : cd;
+        m = q > m ? q : m;
+    }
+    for (long i = (n4 << 2) + threadIdx.x; i < n; i += 1024) {
+        const unsigned b = __float_as_uint(fabsf(w[i]));
+        m = b > m ? b : m;
+    }
+    part[threadIdx.x] = m;
+    __syncthreads();
+    for (int d = 512; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d && part[threadIdx.x + d] > part[threadIdx.x]) part[threadIdx.x] = part[threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float amax = __uint_as_float(part[0]);
+        int e = 0;
+        if (amax > 0.f && amax <= FLT_MAX) (void)frexpf(amax, &e);
+        if (MODE == 0) {
+            int w_exp = 14 - e;
+            w_exp = w_exp < -60 ? -60 : (w_exp > 60 ? 60 : w_exp);
+            s[0] = ldexpf(1.0f, w_exp);
+            s[1] = ldexpf(1.0f, -(w_exp + ACT_EXP_DEFAULT));
+        } else {
+            int ex = 10 - e;
+            ex = ex < -100 ? -100 : (ex > 100 ? 100 : ex);
+            s[0] = ldexpf(1.0f, ex);
+            s[1] = ldexpf(1.0f, ACT_EXP_DEFAULT - ex);
+        }
+    }
+}
+constexpr long AMAX_SINGLE_MAX = 1L << 21;      // elements one workgroup scans (L2-resident weights / small gradients)
+
 // s[0] (max |w|, as written above) -> s[0] = 2^w_exp, s[1] = 2^-(w_exp + 4) with w_exp = 14 - exponent(max |w|)  (frexp convention)
 __global__ void k_pack_scale(float* __restrict__ s) {
     const float amax = s[0];
@@ -837,8 +880,12 @@ __global__ void k_pack_scale(float* __restrict__ s) {
 // Packs torch-layout weights [Cout][Cin][KS][KS] (or [Cout][Cin] for linear) into the LDS image the kernel DMAs, in
 // execution order: [chunk][tap][k-step][cout block][plane][NT rows][2 slots of 8 channels, slot ^= (row >> 3) & 1]
 // fp16, scaled by 2^w_exp (plain operands: [chunk][tap][cout block][k-step][NT rows][...], one slab per tap).
-__global__ void k_conv_pack(const float* __restrict__ w, int Cin, int Cout, int taps, int nchunks, int nblkY, int NT,
-                            int planes, float wmul, const float* __restrict__ wmul_dev, _Float16* __restrict__ out) {
+// (w is read through element strides: s_co, s_ci per channel, s_tap per tap of the execution order -- a contiguous torch weight
+//  has (Cin * taps, taps, 1); the dgrad image of a convolution reads the SAME tensor with the channel strides swapped and the
+//  taps reversed, w_base pointing at the last tap: no flipped / transposed copy is ever made)
+__global__ void k_conv_pack(const float* __restrict__ w, long s_co, long s_ci, long s_tap, int Cin, int Cout, int taps, int nchunks,
+                            int nblkY, int NT, int planes, float wmul, const float* __restrict__ wmul_dev,
+                            _Float16* __restrict__ out) {
     if (wmul_dev) wmul = *wmul_dev;                      // the scale chosen on the device (far_conv_pack_auto_f32)
     const long total = (long)taps * nchunks * 2 * nblkY * NT * 2;
     if (blockIdx.x == 0 && threadIdx.x < 16) out[(size_t)total * 8 * planes + threadIdx.x] = (_Float16)0.f;   // the zero row
@@ -858,7 +905,7 @@ __global__ void k_conv_pack(const float* __restrict__ w, int Cin, int Cout, int 
         for (int e = 0; e < 8; ++e) {
             const int ch = 32 * chunk + 16 * ks + 8 * s + e;
             float v = 0.f;
-            if (n < Cout && ch < Cin) v = w[((size_t)n * Cin + ch) * taps + tap] * wmul;
+            if (n < Cout && ch < Cin) v = w[(long)n * s_co + (long)ch * s_ci + (long)tap * s_tap] * wmul;
             const _Float16 hh = (_Float16)v;
             dst[e] = hh;
             if (planes == 2) dst[(size_t)NT * 16 + e] = (_Float16)(v - (float)hh);
@@ -914,6 +961,10 @@ int launch_stride2(const ConvArgs& a, dim3 grid, hipStream_t stream) { return la
 
 extern "C" {
 
+int far_weight_scale_f32(const float* w, long n, float* scale_out, hipStream_t stream);
+int far_conv_pack_view_f32(const float* w, long s_co, long s_ci, long s_tap, int Cin, int Cout, int ksize, int stride, int split,
+                           const float* scale_in, void* packed, hipStream_t stream);
+
 // Bytes of the packed weight image for a [Cout][Cin][ksize][ksize] weight (split = 1: hi + lo planes).
 size_t far_conv_packed_bytes(int Cin, int Cout, int ksize, int stride, int split) {
     if (Cin <= 0 || Cout <= 0 || (ksize != 1 && ksize != 3) || stride < 1 || stride > 2 || (stride == 2 && ksize != 3)) return 0;
@@ -931,8 +982,37 @@ int far_conv_pack_f32(const float* w, int Cin, int Cout, int ksize, int stride, 
     if (!w || !packed || far_conv_packed_bytes(Cin, Cout, ksize, stride, split) == 0 || w_exp < -60 || w_exp > 60) return FAR_EINVAL;
     const int NT = cfg_for(Cout, stride).nt;
     const int nchunks = (Cin + 31) / 32, nblkY = (Cout + NT - 1) / NT;
-    hipLaunchKernelGGL(k_conv_pack, dim3(512), dim3(256), 0, stream, w, Cin, Cout, ksize * ksize, nchunks, nblkY, NT,
-                       split ? 2 : 1, ldexpf(1.0f, w_exp), (const float*)nullptr, (_Float16*)packed);
+    hipLaunchKernelGGL(k_conv_pack, dim3(512), dim3(256), 0, stream, w, (long)Cin * ksize * ksize, (long)ksize * ksize, 1L, Cin, Cout,
+                       ksize * ksize, nchunks, nblkY, NT, split ? 2 : 1, ldexpf(1.0f, w_exp), (const float*)nullptr, (_Float16*)packed);
+    return far_check_launch();
+}
+
+// scale_out (2 device floats) = { 2^w_exp, 2^-(w_exp + 4) } with 2^13 <= max|w| 2^w_exp < 2^14 over the n weights at w.
+int far_weight_scale_f32(const float* w, long n, float* scale_out, hipStream_t stream) {
+    far_clear_errors();
+    if (!w || !scale_out || n <= 0) return FAR_EINVAL;
+    if (n <= AMAX_SINGLE_MAX && (reinterpret_cast<uintptr_t>(w) & 15) == 0) {
+        hipLaunchKernelGGL(k_amax_scale_single<0>, dim3(1), dim3(1024), 0, stream, w, n, scale_out);
+    } else {
+        hipMemsetAsync(scale_out, 0, 2 * sizeof(float), stream);
+        hipLaunchKernelGGL(k_absmax_bits, dim3(256), dim3(256), 0, stream, w, n, reinterpret_cast<unsigned*>(scale_out));
+        hipLaunchKernelGGL(k_pack_scale, dim3(1), dim3(1), 0, stream, scale_out);
+    }
+    return far_check_launch();
+}
+
+// Packs a [Cout][Cin][k][k] weight read through element strides (s_co, s_ci, s_tap; w points at the element of tap 0 in
+// execution order), multiplied by the device scale scale_in[0] (far_weight_scale_f32).  The dgrad image of a 'same' stride-1
+// convolution is the view (s_co, s_ci, s_tap) = (taps, Cin_fwd taps, -1) at w + taps - 1 of the forward weight -- channels
+// swapped, taps reversed -- with Cin / Cout exchanged; a transposed Linear weight is (1, K, 0).  No copy of w is made.
+int far_conv_pack_view_f32(const float* w, long s_co, long s_ci, long s_tap, int Cin, int Cout, int ksize, int stride, int split,
+                           const float* scale_in, void* packed, hipStream_t stream) {
+    far_clear_errors();
+    if (!w || !packed || !scale_in || far_conv_packed_bytes(Cin, Cout, ksize, stride, split) == 0) return FAR_EINVAL;
+    const int NT = cfg_for(Cout, stride).nt;
+    const int nchunks = (Cin + 31) / 32, nblkY = (Cout + NT - 1) / NT;
+    hipLaunchKernelGGL(k_conv_pack, dim3(512), dim3(256), 0, stream, w, s_co, s_ci, s_tap, Cin, Cout, ksize * ksize, nchunks, nblkY, NT,
+                       split ? 2 : 1, 1.0f, scale_in, (_Float16*)packed);
     return far_check_launch();
 }
 
@@ -943,15 +1023,11 @@ int far_conv_pack_auto_f32(const float* w, int Cin, int Cout, int ksize, int str
                            hipStream_t stream) {
     far_clear_errors();
     if (!w || !packed || !scale_out || far_conv_packed_bytes(Cin, Cout, ksize, stride, split) == 0) return FAR_EINVAL;
-    const int NT = cfg_for(Cout, stride).nt;
-    const int nchunks = (Cin + 31) / 32, nblkY = (Cout + NT - 1) / NT;
     const long n = (long)Cout * Cin * ksize * ksize;
-    hipMemsetAsync(scale_out, 0, 2 * sizeof(float), stream);
-    hipLaunchKernelGGL(k_absmax_bits, dim3(256), dim3(256), 0, stream, w, n, reinterpret_cast<unsigned*>(scale_out));
-    hipLaunchKernelGGL(k_pack_scale, dim3(1), dim3(1), 0, stream, scale_out);
-    hipLaunchKernelGGL(k_conv_pack, dim3(512), dim3(256), 0, stream, w, Cin, Cout, ksize * ksize, nchunks, nblkY, NT,
-                       split ? 2 : 1, 1.0f, (const float*)scale_out, (_Float16*)packed);
-    return far_check_launch();
+    const int rc = far_weight_scale_f32(w, n, scale_out, stream);
+    if (rc != FAR_OK) return rc;
+    return far_conv_pack_view_f32(w, (long)Cin * ksize * ksize, (long)ksize * ksize, 1, Cin, Cout, ksize, stride, split, scale_out,
+                                  packed, stream);
 }
 
 // The activation scale of a tensor whose magnitude is not known in advance (gradients: 1e-7 is usual): out = { 2^e, 2^(4 - e) }
@@ -969,9 +1045,13 @@ __global__ void k_grad_scale(float* __restrict__ s) {
 int far_grad_scale_f32(const float* x, long n, float* out2, hipStream_t stream) {
     far_clear_errors();
     if (!x || !out2 || n <= 0) return FAR_EINVAL;
-    hipMemsetAsync(out2, 0, 2 * sizeof(float), stream);
-    hipLaunchKernelGGL(k_absmax_bits, dim3(n > 65536 ? 256 : 16), dim3(256), 0, stream, x, n, reinterpret_cast<unsigned*>(out2));
-    hipLaunchKernelGGL(k_grad_scale, dim3(1), dim3(1), 0, stream, out2);
+    if (n <= AMAX_SINGLE_MAX && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+        hipLaunchKernelGGL(k_amax_scale_single<1>, dim3(1), dim3(1024), 0, stream, x, n, out2);
+    } else {
+        hipMemsetAsync(out2, 0, 2 * sizeof(float), stream);
+        hipLaunchKernelGGL(k_absmax_bits, dim3(256), dim3(256), 0, stream, x, n, reinterpret_cast<unsigned*>(out2));
+        hipLaunchKernelGGL(k_grad_scale, dim3(1), dim3(1), 0, stream, out2);
+    }
     return far_check_launch();
 }
 

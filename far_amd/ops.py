@@ -457,7 +457,8 @@ def linear_train(x, weight, bias, cache, name, split=True):
     """K9 Linear with gradients.  cache: a PackCache; name: key prefix of this layer's forward / transposed weight images."""
     pack = lambda: cache.get((name, split), [weight] + ([bias] if bias is not None else []),
                              lambda: PackedConv(weight, None, bias, split=split))
-    pack_t = lambda: cache.get((name, 'T', split), [weight], lambda: PackedConv(weight.detach().t().contiguous(), split=split))
+    # the transposed image reads the same tensor through strides and reuses the forward image's scale (same maximum)
+    pack_t = lambda: cache.get((name, 'T', split), [weight], lambda: PackedConv(weight, split=split, dgrad=True, pack_scale=pack().pack_scale))
     return _LinearF16sFn.apply(x, weight, bias, pack, pack_t)
 
 
@@ -520,7 +521,7 @@ def conv_train(x, weight, stride, cache, name, split=True):
     ks = int(weight.shape[-1])
     pack = lambda: cache.get((name, 'fwd', split), [weight], lambda: PackedConv(weight, split=split, stride=stride if ks == 3 else 1))
     pack_d = lambda: cache.get((name, 'dgrad', split), [weight],
-                               lambda: PackedConv(weight.detach().flip(2, 3).transpose(0, 1).contiguous(), split=split))
+                               lambda: PackedConv(weight, split=split, dgrad=True, pack_scale=pack().pack_scale))
     return _ConvF16sFn.apply(x, weight, int(stride), pack, pack_d)
 
 
@@ -751,7 +752,10 @@ def check_activation_range(device, what='far_amd'):
 class PackedConv:
     """Weights of one convolution / linear layer in K9's packed split-fp16 image, plus the folded epilogue vectors."""
 
-    def __init__(self, weight, scale=None, shift=None, split=True, stride=1):
+    def __init__(self, weight, scale=None, shift=None, split=True, stride=1, dgrad=False, pack_scale=None):
+        """weight: (Cout, Cin, k, k) or (Cout, Cin).  dgrad=True packs the image of the layer's input-gradient convolution --
+        channels exchanged, taps reversed (a Linear layer: the transposed weight) -- read from the SAME tensor through strides.
+        pack_scale: the two device floats of another image of the same weight (its maximum is the same): skips the reduction."""
         lib = _lib.load()
         w = weight.detach()
         if w.dim() == 2:
@@ -762,15 +766,25 @@ class PackedConv:
         w = w.contiguous().float()
         if stride not in (1, 2) or (stride == 2 and kh != 3):
             raise _lib.FarHipError('K9 supports stride 1, and stride 2 for 3x3 kernels')
+        T = kh * kh
+        if dgrad:
+            view = (T, Cin * T, -1 if T > 1 else 0, T - 1)          # (s_co, s_ci, s_tap, offset of tap 0) of the dgrad image
+            Cin, Cout = Cout, Cin
+        else:
+            view = (Cin * T, T, 1, 0)
         self.Cin, self.Cout, self.ksize, self.split, self.stride = Cin, Cout, kh, bool(split), stride
         nbytes = lib.far_conv_packed_bytes(Cin, Cout, kh, stride, int(self.split))
         self.packed = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
         # the power-of-two weight scale 2^w_exp (max |w| 2^w_exp in [2^13, 2^14)) is chosen on the device: no host read of the
-        # weights, so re-packing after every optimizer step costs three small launches and no synchronisation
-        self.pack_scale = torch.empty(2, dtype=torch.float32, device=w.device)          # { 2^w_exp, 2^-(w_exp + 4) }
-        rc = lib.far_conv_pack_auto_f32(_p(w, torch.float32), Cin, Cout, kh, stride, int(self.split), _p(self.packed),
-                                        _p(self.pack_scale), _stream())
-        _lib.check(rc, 'far_conv_pack_auto_f32')
+        # weights, so re-packing after every optimizer step costs two small launches and no synchronisation
+        if pack_scale is None:
+            pack_scale = torch.empty(2, dtype=torch.float32, device=w.device)          # { 2^w_exp, 2^-(w_exp + 4) }
+            _lib.check(lib.far_weight_scale_f32(_p(w, torch.float32), w.numel(), _p(pack_scale), _stream()), 'far_weight_scale_f32')
+        self.pack_scale = pack_scale
+        rc = lib.far_conv_pack_view_f32(ctypes.c_void_p(w.data_ptr() + 4 * view[3]), view[0], view[1], view[2], Cin, Cout, kh, stride,
+                                        int(self.split), _p(pack_scale), _p(self.packed), _stream())
+        _lib.check(rc, 'far_conv_pack_view_f32')
+        self._w = w                                               # keeps the (possibly temporary) contiguous weight alive until the pack ran
         s = torch.ones(Cout, device=w.device) if scale is None else scale.detach().float()
         self.scale = (s * self.pack_scale[1]).contiguous()        # power-of-two factor: exact
         self.shift = None if shift is None else shift.detach().float().contiguous()

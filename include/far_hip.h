@@ -283,6 +283,16 @@ size_t far_conv_packed_bytes(int Cin, int Cout, int ksize, int stride, int split
  * 2^13 <= max|w| 2^w_exp < 2^15 and fold 2^-(w_exp + 4) into the `scale` vector of far_conv_nhwc_f32. */
 int far_conv_pack_f32(const float* w, int Cin, int Cout, int ksize, int stride, int w_exp, int split, void* packed,
                       far_stream_t stream);
+/* Device-side pack for training (weights change every step; nothing is read back, nothing is copied):
+ *   far_weight_scale_f32: scale_out = { 2^w_exp, 2^-(w_exp + 4) } from max|w| over n contiguous floats (one launch);
+ *   far_conv_pack_view_f32: packs the weight read through element strides (s_co, s_ci, s_tap; w = the element of tap 0 in
+ *   execution order) times scale_in[0].  Forward image of a contiguous [Cout][Cin][k][k] weight: (Cin k k, k k, 1).  Its dgrad
+ *   image (the 'same' stride-1 convolution of the output gradient that gives the input gradient, resnet_fpn.py:5-12 under
+ *   autograd): Cin / Cout exchanged, strides (k k, Cout_fwd... see far_amd/ops.py:PackedConv.dgrad_view), taps reversed -- the
+ *   same tensor, no flipped / transposed copy.  A Linear layer's transposed weight W^T: (1, K_fwd, 0). */
+int far_weight_scale_f32(const float* w, long n, float* scale_out, far_stream_t stream);
+int far_conv_pack_view_f32(const float* w, long s_co, long s_ci, long s_tap, int Cin, int Cout, int ksize, int stride, int split,
+                           const float* scale_in, void* packed, far_stream_t stream);
 /* The same with w_exp chosen on the device from max|w| (no host read: training re-packs every layer after every optimizer
  * step): scale_out (2 device floats) = { 2^w_exp, 2^-(w_exp + 4) }; the caller multiplies its `scale` vector by scale_out[1]. */
 int far_conv_pack_auto_f32(const float* w, int Cin, int Cout, int ksize, int stride, int split, void* packed, float* scale_out,
