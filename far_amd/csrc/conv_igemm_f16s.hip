@@ -261,6 +261,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const f32x16 (&
     }
 }
 
+// 16-byte output stores of the wide epilogue.  FAR_K9_EXP bit 3 (experiment build only): non-temporal stores.
+#if defined(FAR_K9_EXP) && (FAR_K9_EXP & 8)
+#define FAR_K9_STORE4(ptr, val) __builtin_nontemporal_store(f32x4{(val).x, (val).y, (val).z, (val).w}, reinterpret_cast<f32x4*>(ptr))
+#else
+#define FAR_K9_STORE4(ptr, val) (*reinterpret_cast<float4*>(ptr) = (val))
+#endif
+
 #ifdef FAR_K9_TIMING
 // Development instrumentation (tools/k9_timing.py; never defined in the product build): per-workgroup s_memtime
 // stamps at kernel entry, after the prologue, after the K loop and at exit, plus the hardware id of wave 0.
@@ -406,7 +413,7 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvArgs& p, const f32x
                 float4 o;
                 o.x = v.x * rstd * g4.x + b4.x + pr[it].x; o.y = v.y * rstd * g4.y + b4.y + pr[it].y;
                 o.z = v.z * rstd * g4.z + b4.z + pr[it].z; o.w = v.w * rstd * g4.w + b4.w + pr[it].w;
-                if (ok) *reinterpret_cast<float4*>(yp + off) = o;
+                if (ok) FAR_K9_STORE4(yp + off, o);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (mt == 0) FAR_K9_STAMP(5);
@@ -453,7 +460,7 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvArgs& p, const f32x
                     v.x = fmaxf(v.x, __builtin_fmaf(v.x, as, ab)); v.y = fmaxf(v.y, __builtin_fmaf(v.y, as, ab));
                     v.z = fmaxf(v.z, __builtin_fmaf(v.z, as, ab)); v.w = fmaxf(v.w, __builtin_fmaf(v.w, as, ab));
                     float* dst = ybase + row_off(b0 + j);
-                    if (row_ok(b0 + j)) *reinterpret_cast<float4*>(dst) = v;
+                    if (row_ok(b0 + j)) FAR_K9_STORE4(dst, v);
                 }
             }
         };
@@ -506,7 +513,7 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvArgs& p, const f32x
                     v.x = fmaxf(v.x, __builtin_fmaf(v.x, as, ab)); v.y = fmaxf(v.y, __builtin_fmaf(v.y, as, ab));
                     v.z = fmaxf(v.z, __builtin_fmaf(v.z, as, ab)); v.w = fmaxf(v.w, __builtin_fmaf(v.w, as, ab));
                     float* dst = ybase + row_off(b0 + j);
-                    if (row_ok(b0 + j)) *reinterpret_cast<float4*>(dst) = v;
+                    if (row_ok(b0 + j)) FAR_K9_STORE4(dst, v);
                 }
                 __builtin_amdgcn_sched_barrier(0);      // keep the batches apart (hoisting all 16 rows' addresses spills)
             }
