@@ -13,6 +13,6 @@ cd $R
 timeout 400 python bench.py > gpurun_out/bench_plain.log 2> gpurun_out/bench_plain.err
 timeout 300 python bench.py --workload c4 > gpurun_out/bench_c4.log 2> gpurun_out/bench_c4.err
 python tools/profile_report.py gpurun_out/prof_bench/bench_results.db > gpurun_out/${TAG}_trace.txt 2>&1
-python tools/pmc_traffic.py gpurun_out/pmc_fetch/f_results.db gpurun_out/pmc_write/w_results.db > gpurun_out/${TAG}_pmc_traffic.json 2> gpurun_out/pmc_err.log
+FAR_COMMIT=${FAR_COMMIT:-unknown} python tools/pmc_traffic.py gpurun_out/pmc_fetch/f_results.db gpurun_out/pmc_write/w_results.db > gpurun_out/${TAG}_pmc_traffic.json 2> gpurun_out/pmc_err.log
 rm -rf gpurun_out/prof_bench gpurun_out/pmc_fetch gpurun_out/pmc_write      # the databases exceed gpurun's 64 MiB copy-back limit
 tail -c 300 gpurun_out/bench_plain.log; echo; head -c 300 gpurun_out/${TAG}_pmc_traffic.json
