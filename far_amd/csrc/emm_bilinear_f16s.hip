@@ -22,6 +22,7 @@
 //                  = 2^(2 x - R_i - C_j + 15) <= 2^15 -> fp16 hi / lo straight from the accumulator registers ->
 //                  T += P v~ (36 MFMAs); 1 / rowsum, 1 / colsum and the 2^-15 are folded into the output scale and v~
 #include "common.h"
+#include <type_traits>
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -415,6 +416,10 @@ __global__ __launch_bounds__(256, 2) void k_pv(const _Float16* __restrict__ qh, 
         }
         const float nR = -(float)R;
         f32x2 t2 = {0.f, 0.f};
+        // the ragged-tile test is hoisted out of the loop (two straight-line copies of it): inside, the compiler split the
+        // tile into four branchy blocks of 9 MFMAs that could not overlap each other's exponentials
+        auto pv_tile = [&](auto ragged_c) {
+        constexpr bool RAGGED = decltype(ragged_c)::value;
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
 #pragma unroll
@@ -426,7 +431,7 @@ __global__ __launch_bounds__(256, 2) void k_pv(const _Float16* __restrict__ qh, 
                     const int r = 8 * u + e;
                     float e0 = __builtin_amdgcn_exp2f(fmaf(acc[ct][r], c1, nR));
                     float e1 = __builtin_amdgcn_exp2f(fmaf(acc[ct][r + 1], c1, nR));
-                    if (ragged) {                                                // zero-padded keys score 0, not -inf
+                    if (RAGGED) {                                                // zero-padded keys score 0, not -inf
                         if (jt * KT + 32 * ct + mfma32_row(r, h) >= N) e0 = 0.f;
                         if (jt * KT + 32 * ct + mfma32_row(r + 1, h) >= N) e1 = 0.f;
                     }
@@ -452,6 +457,9 @@ __global__ __launch_bounds__(256, 2) void k_pv(const _Float16* __restrict__ qh, 
                 }
             }
         }
+        };
+        if (ragged) pv_tile(std::true_type{});
+        else pv_tile(std::false_type{});
         // the tile's 32 terms summed on their own, then added with Kahan compensation (see rowstat_update)
         const float y = (t2.x + t2.y) - comp;
         const float ns = sum + y;
