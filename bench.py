@@ -499,14 +499,17 @@ def bench_c3(a, dev, world, rank, dist):
             'warmup': a.warmup, 'prime_steps': prime, 'ms_per_step': round(1000 * dt / a.steps, 3),
             'per_rank_ms_per_step': per_rank_ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
-            'dtype_note': 'fp32 tensors and accumulation; K1 / K9-linear / K2 forward on split-f16x3 operands, their backward kernels '
-                          'on fp16 (K1, K2) or split-f16x3 (K9 dgrad) operands; backbone and fine-window ops: vendor fp32 + autograd',
+            'dtype_note': 'fp32 tensors and accumulation; K1 / K9 (Linear and backbone convolutions) / K2 forward on split-f16x3 operands, their '
+                          'backward kernels on fp16 (K1, K2) or split-f16x3 (K9 dgrad) operands; convolution wgrad, BatchNorm, stem: vendor fp32',
+            'vendor_convolution': 'forward: none but the 1-channel 7x7 stem; backward: weight gradients only (MIOpen backward-weights)'
+                                  if not a.vendor_train else 'all (comparison leg)',
             'config': {'workload': 'Matterport3D-shaped training step (BASELINE configs[2]): ' + str(B) + ' pair(s) @ 640x480 per GPU, '
                                    'matcher in training mode (sampled / padded coarse matches), solver x2, head x2 (last with grad), '
                                    'coarse focal + fine l2_with_std + 6D pose L1 losses, backward, AdamW; seeded random weights',
                        'pairs_per_gpu': B, 'hypotheses': a.hyp,
                        'training_kernels': 'vendor ops + autograd (comparison leg)' if a.vendor_train else
-                                           'HIP forward+backward: K1 sparse-position conf, K5, K9 Linear (dgrad), K2',
+                                           'HIP forward+backward: K1 sparse-position conf, K5, K9 Linear + backbone convolutions (dgrad), K3 window '
+                                           'gather / scatter, K2; weight packing and gradient scaling without host synchronisation',
                        'gt_coarse_matches_per_pair': n_gt, 'sampled_matches': int(last['b_ids'].numel()),
                        'losses': sc,
                        'parallelism': f'ddp{world} (gradient all-reduce over RCCL)' if world > 1 else 'single GPU (no exchange step)'},
@@ -720,8 +723,9 @@ def main():
             'dtype': 'f32' if a.precision == 'fp32' else f'f32 tensors/accumulation, {a.precision} matrix operands',
             'dtype_note': ('f32 = fp32 tensors, fp32 accumulation; matrix products on the f16 MFMA pipe as split-f16x3 operand '
                            'pairs (hi*hi + hi*lo + lo*hi, 22 significand bits: fp32-grade, not a bitwise fmaf chain); '
-                           'solver float64.  Activations above |a| = 4094 would overflow the split to inf (never silently); '
-                           'untested on a real-checkpoint activation distribution (no checkpoint offline)') if a.precision == 'fp32' else None,
+                           'solver float64.  Activation range: every split-fp16 launch reports an operand beyond its range (|a| > 4094 at '
+                           'the default exponent) through a device flag; LoFTR.forward re-runs at a 16x wider range when it fires '
+                           f'(this run: activation exponent {model.act_exp}, 4 = default = no re-run)') if a.precision == 'fp32' else None,
             'data': 'synthetic',
             'config': {'workload': 'Matterport3D-shaped eval (BASELINE configs[1]): batch 32 pairs @ 640x480 per GPU, '
                                    'LoFTR match + 8-pt prior-RANSAC solve (x2 rounds) + EMM head (x2: the head\'s feature stage -- 2 LoFTR '
