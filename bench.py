@@ -417,6 +417,8 @@ def bench_c3(a, dev, world, rank, dist):
         from far_amd.loftr.stages import FinePreprocess
         ResNetFPN_8_2.hip_training = False
         FinePreprocess.hip_training = False
+        from far_amd import ops as _ops
+        _ops.USE_HIP_WGRAD = False
         model.coarse_matching.materialize_conf = True          # dense conf_matrix through the vendor ops + autograd
     loss_fn = LoFTRLoss(cfg).train()
     fwd = model

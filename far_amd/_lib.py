@@ -66,6 +66,8 @@ SIGNATURES = {
     'far_emm_bwd_f16': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_p, c_p, c_p, c_p]),
     'far_corr_volume_warp_workspace_bytes': (c_sz, [c_i, c_i]),
     'far_corr_volume_warp_f32': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p]),
+    'far_conv_wgrad_ws_bytes': (c_l, [c_i, c_i, c_i, c_i, c_i, c_i, c_i]),
+    'far_conv_wgrad_f16s': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_l, c_p, c_p, c_p]),
     'far_stem7x7_nhwc_f32': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
     'far_pose_pack_f64': (c_i, [c_p] * 8 + [c_i] + [c_p] * 6 + [c_p]),
     'far_pose_features_f32': (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p]),

@@ -871,7 +871,7 @@ __global__ __launch_bounds__(1024) void k_amax_scale_single(const float* __restr
         }
     }
 }
-constexpr long AMAX_SINGLE_MAX = 1L << 21;      // elements one workgroup scans (L2-resident weights / small gradients)
+constexpr long AMAX_SINGLE_MAX = 1L << 17;      // elements one workgroup scans (L2-resident weights / small gradients)
 
 // s[0] (max |w|, as written above) -> s[0] = 2^w_exp, s[1] = 2^-(w_exp + 4) with w_exp = 14 - exponent(max |w|)  (frexp convention)
 __global__ void k_pack_scale(float* __restrict__ s) {

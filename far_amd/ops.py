@@ -424,8 +424,7 @@ def linear_attention_train(q, k, v, nhead, q_mask=None, kv_mask=None, eps=1e-6):
 
 class _LinearF16sFn(torch.autograd.Function):
     """y = x W^T (+ b) on K9 with gradients: dx = dy W is K9 again (the weight packed transposed: a Linear layer whose
-    weight is W^T), dW = dy^T x is one library GEMM over all rows (a 256 x 256 output reduced over 10^5 rows is a plain
-    split-K vendor GEMM, not an implicit-GEMM shape), db = column sums."""
+    weight is W^T), dW = dy^T x is K16 (the 1x1 case of the convolution weight gradient), db = column sums."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, pack, pack_t):
@@ -440,15 +439,20 @@ class _LinearF16sFn(torch.autograd.Function):
         xc, weight = ctx.saved_tensors
         g = g.float().contiguous()
         dx = None
+        sc = grad_scale(g)
         if ctx.needs_input_grad[0]:
             # K9 splits its input into fp16 (hi, lo) pairs after a fixed 2^4 scale: fp32-grade for values in
             # ~[8e-3, 4e3], the range of activations -- gradients can sit anywhere (1e-7 is usual).  A power-of-two scale
             # taken from the tensor's maximum (on the device, no host sync) places them at the top of that window;
             # entries below max * 2^-17 keep 11 bits, which is 2^-28 of the maximum.
             # (far_grad_scale_f32 picks it on the device and K9 applies it inside the launch: no scaling passes over g / dx)
-            dx = linear_f16s(g, ctx.pack_t(), act_scale_dev=grad_scale(g))
+            dx = linear_f16s(g, ctx.pack_t(), act_scale_dev=sc)
         g2, x2 = g.reshape(-1, g.shape[-1]), xc.reshape(-1, xc.shape[-1])
-        dw = g2.t().mm(x2) if ctx.needs_input_grad[1] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = linear_wgrad(x2.contiguous(), g2.contiguous(), sc)
+            if dw is None:
+                dw = g2.t().mm(x2)
         db = g2.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return dx, dw, db, None, None
 
@@ -486,10 +490,10 @@ class _ConvF16sFn(torch.autograd.Function):
         N, H, W, Cin = xn.shape
         gn = g.float().contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)                # (N, Ho, Wo, Cout)
         dx = dw = None
+        # gradients sit anywhere in magnitude: a power-of-two scale from the maximum places them in K9's window (as _LinearF16sFn)
+        gs = gn.contiguous()
+        sc = grad_scale(gs)
         if ctx.needs_input_grad[0]:
-            # gradients sit anywhere in magnitude: a power-of-two scale from the maximum places them in K9's window (as _LinearF16sFn)
-            gs = gn.contiguous()
-            sc = grad_scale(gs)
             if st == 1:
                 dxn = conv_nhwc(gs, ctx.pack_d(), act_scale_dev=sc)
             elif ks == 3:
@@ -501,17 +505,44 @@ class _ConvF16sFn(torch.autograd.Function):
                 dxn[:, ::st, ::st] = conv_nhwc(gs, ctx.pack_d(), act_scale_dev=sc)
             dx = dxn.permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
-            dw = conv_wgrad(xn, gn, ks, st)
+            dw = conv_wgrad(xn, gs, ks, st, dy_scale=sc)
             if dw is None:                                                                              # shape without a kernel: vendor
                 dw = torch.ops.aten.convolution_backward(gn.permute(0, 3, 1, 2), xn.permute(0, 3, 1, 2), weight, None, [st, st],
                                                          [ks // 2, ks // 2], [1, 1], False, [0, 0], 1, [False, True, False])[1]
         return dx, dw, None, None, None
 
 
-def conv_wgrad(xn, gn, ks, stride):
-    """dW (Cout, Cin, ks, ks) of a 'same' convolution from its NHWC input xn and NHWC output gradient gn; None where no HIP
-    kernel covers the shape (the caller then uses the vendor's backward-weights)."""
-    return None
+def conv_wgrad(xn, gn, ks, stride, dy_scale=None):
+    """K16.  dW (Cout, Cin, ks, ks) of a 'same' bias-free convolution from its NHWC input xn (N, H, W, Cin) and NHWC output
+    gradient gn (N, Ho, Wo, Cout); split-fp16 operands, deterministic two-stage sum.  dy_scale = grad_scale(gn) if the caller has
+    it already.  None only on the comparison leg (USE_HIP_WGRAD False)."""
+    lib = _lib.load()
+    N, H, W, Cin = xn.shape
+    Cout = gn.shape[-1]
+    if not USE_HIP_WGRAD:
+        return None
+    xn, gn = xn.contiguous(), gn.contiguous()
+    dw = torch.empty(Cout, Cin, ks, ks, dtype=torch.float32, device=xn.device)
+    nb = int(lib.far_conv_wgrad_ws_bytes(N, H, W, Cin, Cout, ks, stride))
+    ws = torch.empty(nb, dtype=torch.uint8, device=xn.device)
+    rc = lib.far_conv_wgrad_f16s(_p(xn, torch.float32), _p(gn, torch.float32), N, H, W, Cin, Cout, ks, stride,
+                                 activation_exponent_value(), _p(dy_scale) if dy_scale is not None else None, _p(ws), nb, _p(dw),
+                                 overflow_flag(xn.device).data_ptr(), _stream())
+    _lib.check(rc, 'far_conv_wgrad_f16s')
+    return dw
+
+
+USE_HIP_WGRAD = True       # False: the vendor's backward-weights / GEMM (comparison leg of bench.py --workload c3 --vendor-train)
+
+
+def linear_wgrad(x2, g2, dy_scale=None):
+    """K16 as a Linear layer's weight gradient: dW (N_out, K) = g2^T x2 for x2 (rows, K), g2 (rows, N_out); None -> caller's GEMM
+    (comparison leg only)."""
+    rows, K = x2.shape
+    if not USE_HIP_WGRAD or rows == 0:
+        return None
+    h = rows // 32 if rows % 32 == 0 else 1                     # 1x1 kernel: any factoring of the rows into H x W is the same sum
+    return conv_wgrad(x2.reshape(1, h, rows // h, K), g2.reshape(1, h, rows // h, g2.shape[1]), 1, 1, dy_scale).reshape(g2.shape[1], K)
 
 
 def conv_train(x, weight, stride, cache, name, split=True):

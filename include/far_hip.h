@@ -351,6 +351,22 @@ int far_conv_nhwc_f32(const far_conv_desc* desc, far_stream_t stream);
 int far_grad_scale_f32(const float* x, long n, float* out2, far_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * K16  weight gradient of the 3x3 / 1x1 convolutions and of the Linear layers (training)
+ * replaces autograd's backward-weights of src/loftr/backbone/resnet_fpn.py:5-12 (conv1x1 / conv3x3: stride 1 or 2, 'same'
+ *      padding, no bias) and of the nn.Linear layers of src/loftr/loftr_module/transformer.py:25-35
+ *   dw [Cout][Cin][k][k] = sum over pixels of dy[n][oy][ox][co] * x[n][s oy + ky - k/2][s ox + kx - k/2][ci];  x [N][H][W][Cin],
+ *   dy [N][Ho][Wo][Cout] NHWC fp32 contiguous, Ho = (H - 1) / s + 1; a Linear layer is k = 1 with its rows factored as any
+ *   H x W.  Split-fp16 operands (hi + lo, three MFMAs per product: fp32-grade), summed deterministically: pixel ranges write
+ *   partial sums to `ws` (far_conv_wgrad_ws_bytes() bytes of device scratch) and a second kernel adds them in a fixed order.
+ *   x is multiplied by 2^act_exp before the split (as in far_conv_nhwc_f32), dy by dy_scale_dev[0] (far_grad_scale_f32's two
+ *   device floats; NULL: computed by this call).  overflow: device int OR-ed with 1 when a sum is non-finite (an operand
+ *   beyond the split's range), or NULL.  dw is overwritten.
+ * --------------------------------------------------------------------------------------------------- */
+long far_conv_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout, int ksize, int stride);
+int far_conv_wgrad_f16s(const float* x, const float* dy, int N, int H, int W, int Cin, int Cout, int ksize, int stride, int act_exp,
+                        const float* dy_scale_dev, void* ws, long ws_bytes, float* dw, int* overflow, far_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * K10  backbone stem: 7x7 stride-2 convolution of a 1-channel image + folded BatchNorm + ReLU (exact-f32 MFMA)
  * replaces src/loftr/backbone/resnet_fpn.py:60-62, :103   x0 = relu(bn1(conv1(x)))
  * img [N][H][W] fp32, w [Cout][7][7] (torch layout), y [N][(H+1)/2][(W+1)/2][Cout] NHWC; Cout = 64 or 128.

@@ -361,3 +361,25 @@ def test_conv_train_forward_and_gradients_match_float64(Cin, Cout, ks, stride, H
     e = (rel(y1.detach(), y2.detach()), rel(x1.grad, x2.grad), rel(w1.grad, w2.grad))
     print(f'[conv train] {Cin}->{Cout} k{ks} s{stride}: y {e[0]:.1e}  dx {e[1]:.1e}  dw {e[2]:.1e}')
     assert y1.shape == y2.shape and e[0] < 4e-6 and e[1] < 4e-6 and e[2] < 2e-5
+
+
+@pytest.mark.parametrize('N,H,W,Cin,Cout,ks,stride', [(2, 24, 40, 128, 128, 3, 1), (1, 13, 37, 196, 196, 3, 1), (2, 24, 32, 128, 196, 3, 2),
+                                                     (1, 13, 17, 196, 256, 3, 2), (2, 24, 32, 128, 196, 1, 2), (1, 9, 12, 256, 256, 1, 1),
+                                                     (1, 1, 4800, 256, 768, 1, 1), (1, 150, 32, 512, 256, 1, 1)])
+def test_conv_wgrad_matches_float64(N, H, W, Cin, Cout, ks, stride):
+    """K16 (far_conv_wgrad_f16s: split-fp16 operands, deterministic two-stage sum) against float64 autograd."""
+    import torch.nn.functional as F
+    from far_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(N + H + W + Cin + Cout + ks + stride)
+    x = torch.randn(N, H, W, Cin, device='cuda', generator=g)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    dy = torch.randn(N, Ho, Wo, Cout, device='cuda', generator=g)
+    dy = dy * 3e-6                                       # gradients are small: the f16s path places them with a device scale
+    dw = ops.conv_wgrad(x, dy, ks, stride)
+    assert torch.equal(dw, ops.conv_wgrad(x, dy, ks, stride))      # deterministic
+    w = torch.zeros(Cout, Cin, ks, ks, device='cuda', dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x.permute(0, 3, 1, 2).double(), w, stride=stride, padding=ks // 2)
+    (y * dy.permute(0, 3, 1, 2).double()).sum().backward()
+    err = float((dw.double() - w.grad).abs().max() / w.grad.abs().max())
+    print(f'[wgrad] {Cin}->{Cout} k{ks} s{stride} on {N}x{H}x{W}: relative max error {err:.1e}')
+    assert dw.shape == w.shape and err < 5e-6
