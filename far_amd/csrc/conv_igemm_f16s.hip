@@ -830,6 +830,24 @@ __global__ void k_absmax_bits(const float* __restrict__ w, long n, unsigned* __r
     }
     if (threadIdx.x == 0) atomicMax(out, part[0]);
 }
+template <int MODE>      // 0: weight pack scales { 2^w_exp, 2^-(w_exp + 4) }; 1: gradient scales { 2^e, 2^(4 - e) }
+__device__ __forceinline__ void write_scales(float amax, float* __restrict__ s) {
+    int e = 0;
+    if (amax > 0.f && amax <= FLT_MAX) (void)frexpf(amax, &e);
+    if (MODE == 0) {
+        int w_exp = 14 - e;
+        w_exp = w_exp < -60 ? -60 : (w_exp > 60 ? 60 : w_exp);
+        s[0] = ldexpf(1.0f, w_exp);
+        s[1] = ldexpf(1.0f, -(w_exp + ACT_EXP_DEFAULT));
+    } else {
+        int ex = 10 - e;
+        ex = ex < -100 ? -100 : (ex > 100 ? 100 : ex);
+        s[0] = ldexpf(1.0f, ex);
+        s[1] = ldexpf(1.0f, ACT_EXP_DEFAULT - ex);
+    }
+}
+constexpr long AMAX_SINGLE_MAX = 1L << 16;      // elements one workgroup scans (no atomics)
+
 // max |w| of a small tensor by ONE workgroup (no memset, no atomics: one launch), then `finish` turns it into the two scales
 template <int MODE>      // 0: weight pack scales { 2^w_exp, 2^-(w_exp + 4) }; 1: gradient scales { 2^e, 2^(4 - e) }
 __global__ __launch_bounds__(1024) void k_amax_scale_single(const float* __restrict__ w, long n, float* __restrict__ s) {
@@ -854,24 +872,67 @@ __global__ __launch_bounds__(1024) void k_amax_scale_single(const float* __restr
         if ((int)threadIdx.x < d && part[threadIdx.x + d] > part[threadIdx.x]) part[threadIdx.x] = part[threadIdx.x + d];
         __syncthreads();
     }
+    if (threadIdx.x == 0) write_scales<MODE>(__uint_as_float(part[0]), s);
+}
+
+// The same for a tensor too large for one workgroup, still ONE launch: every workgroup folds its maximum into a scratch slot
+// and takes a ticket; the last one to arrive turns the slot into the scales and leaves it zeroed for its next user.  Slots are
+// handed out round-robin on the host, so launches in flight on different streams never share one (1024 slots).
+struct AmaxSlot {
+    unsigned max_bits, ticket;
+};
+__device__ AmaxSlot g_amax_slots[1024];
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_amax_scale_multi(const float* __restrict__ w, long n, float* __restrict__ s, int slot) {
+    __shared__ unsigned part[256];
+    unsigned m = 0;
+    const long n4 = n >> 2;
+    const float4* w4 = reinterpret_cast<const float4*>(w);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 v = w4[i];
+        const unsigned a = __float_as_uint(fabsf(v.x)), b = __float_as_uint(fabsf(v.y)), c = __float_as_uint(fabsf(v.z)),
+                       d = __float_as_uint(fabsf(v.w));
+        const unsigned ab = a > b ? a : b, cd = c > d ? c : d, q = ab > cd ? ab : cd;
+        m = q > m ? q : m;
+    }
+    if (blockIdx.x == 0)
+        for (long i = (n4 << 2) + threadIdx.x; i < n; i += 256) {
+            const unsigned b = __float_as_uint(fabsf(w[i]));
+            m = b > m ? b : m;
+        }
+    part[threadIdx.x] = m;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d && part[threadIdx.x + d] > part[threadIdx.x]) part[threadIdx.x] = part[threadIdx.x + d];
+        __syncthreads();
+    }
     if (threadIdx.x == 0) {
-        const float amax = __uint_as_float(part[0]);
-        int e = 0;
-        if (amax > 0.f && amax <= FLT_MAX) (void)frexpf(amax, &e);
-        if (MODE == 0) {
-            int w_exp = 14 - e;
-            w_exp = w_exp < -60 ? -60 : (w_exp > 60 ? 60 : w_exp);
-            s[0] = ldexpf(1.0f, w_exp);
-            s[1] = ldexpf(1.0f, -(w_exp + ACT_EXP_DEFAULT));
-        } else {
-            int ex = 10 - e;
-            ex = ex < -100 ? -100 : (ex > 100 ? 100 : ex);
-            s[0] = ldexpf(1.0f, ex);
-            s[1] = ldexpf(1.0f, ACT_EXP_DEFAULT - ex);
+        AmaxSlot* const sl = g_amax_slots + slot;
+        atomicMax(&sl->max_bits, part[0]);
+        __threadfence();
+        if (atomicAdd(&sl->ticket, 1u) == gridDim.x - 1) {
+            __threadfence();
+            const unsigned bits = atomicExch(&sl->max_bits, 0u);
+            atomicExch(&sl->ticket, 0u);
+            write_scales<MODE>(__uint_as_float(bits), s);
         }
     }
 }
-constexpr long AMAX_SINGLE_MAX = 1L << 17;      // elements one workgroup scans (L2-resident weights / small gradients)
+
+// One launch either way; float4 reads need a 16-byte aligned tensor (anything else takes the three-launch path of the callers).
+template <int MODE>
+void launch_amax_scale(const float* w, long n, float* out2, hipStream_t stream) {
+    if (n <= AMAX_SINGLE_MAX) {
+        hipLaunchKernelGGL(k_amax_scale_single<MODE>, dim3(1), dim3(1024), 0, stream, w, n, out2);
+        return;
+    }
+    static std::atomic<unsigned> next_slot{0};
+    const int slot = (int)(next_slot.fetch_add(1, std::memory_order_relaxed) & 1023u);
+    long blocks = (n / 4 + 255) / 256 / 4;                         // >= 4 float4 per thread
+    blocks = blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks);
+    hipLaunchKernelGGL(k_amax_scale_multi<MODE>, dim3((unsigned)blocks), dim3(256), 0, stream, w, n, out2, slot);
+}
 
 // s[0] (max |w|, as written above) -> s[0] = 2^w_exp, s[1] = 2^-(w_exp + 4) with w_exp = 14 - exponent(max |w|)  (frexp convention)
 __global__ void k_pack_scale(float* __restrict__ s) {
@@ -998,8 +1059,8 @@ int far_conv_pack_f32(const float* w, int Cin, int Cout, int ksize, int stride, 
 int far_weight_scale_f32(const float* w, long n, float* scale_out, hipStream_t stream) {
     far_clear_errors();
     if (!w || !scale_out || n <= 0) return FAR_EINVAL;
-    if (n <= AMAX_SINGLE_MAX && (reinterpret_cast<uintptr_t>(w) & 15) == 0) {
-        hipLaunchKernelGGL(k_amax_scale_single<0>, dim3(1), dim3(1024), 0, stream, w, n, scale_out);
+    if ((reinterpret_cast<uintptr_t>(w) & 15) == 0) {
+        launch_amax_scale<0>(w, n, scale_out, stream);
     } else {
         hipMemsetAsync(scale_out, 0, 2 * sizeof(float), stream);
         hipLaunchKernelGGL(k_absmax_bits, dim3(256), dim3(256), 0, stream, w, n, reinterpret_cast<unsigned*>(scale_out));
@@ -1052,8 +1113,8 @@ __global__ void k_grad_scale(float* __restrict__ s) {
 int far_grad_scale_f32(const float* x, long n, float* out2, hipStream_t stream) {
     far_clear_errors();
     if (!x || !out2 || n <= 0) return FAR_EINVAL;
-    if (n <= AMAX_SINGLE_MAX && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
-        hipLaunchKernelGGL(k_amax_scale_single<1>, dim3(1), dim3(1024), 0, stream, x, n, out2);
+    if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+        launch_amax_scale<1>(x, n, out2, stream);
     } else {
         hipMemsetAsync(out2, 0, 2 * sizeof(float), stream);
         hipLaunchKernelGGL(k_absmax_bits, dim3(256), dim3(256), 0, stream, x, n, reinterpret_cast<unsigned*>(out2));

@@ -222,18 +222,33 @@ __global__ __launch_bounds__(256, (KS == 3 && ST == 2) ? 1 : 2) void k_wgrad_s(c
                 if (m + 1 <= c.y1) step_s2<1>(p, c, m + 1, A, acc);
             }
         } else {
-            float va[8], vx[ST * 7 + 1];
-            issue_dy(p, c, c.y0, va);
-            issue_x<1, ST>(p, c, ST * c.y0, vx);
-            for (int oy = c.y0; oy < c.y1; ++oy) {
-                Operand A, B[1];
-                split_dy(va, sg, A);
-                split_x<1, ST>(vx, p.sx, B);
-                if (oy + 1 < c.y1) {
-                    issue_dy(p, c, oy + 1, va);
-                    issue_x<1, ST>(p, c, ST * (oy + 1), vx);
+            // 1x1: three MFMAs per row are no cover for a load, so rows go four at a time -- the next four are requested
+            // before the current four are multiplied
+            constexpr int CH = 4;
+            float va[CH][8], vx[CH][ST * 7 + 1];
+#pragma unroll
+            for (int r = 0; r < CH; ++r)
+                if (c.y0 + r < c.y1) {
+                    issue_dy(p, c, c.y0 + r, va[r]);
+                    issue_x<1, ST>(p, c, ST * (c.y0 + r), vx[r]);
                 }
-                mac_row<1>(acc, A, B);
+            for (int oy = c.y0; oy < c.y1; oy += CH) {
+                Operand A[CH], B[CH][1];
+#pragma unroll
+                for (int r = 0; r < CH; ++r)
+                    if (oy + r < c.y1) {
+                        split_dy(va[r], sg, A[r]);
+                        split_x<1, ST>(vx[r], p.sx, B[r]);
+                    }
+#pragma unroll
+                for (int r = 0; r < CH; ++r)
+                    if (oy + CH + r < c.y1) {
+                        issue_dy(p, c, oy + CH + r, va[r]);
+                        issue_x<1, ST>(p, c, ST * (oy + CH + r), vx[r]);
+                    }
+#pragma unroll
+                for (int r = 0; r < CH; ++r)
+                    if (oy + r < c.y1) mac_row<1>(acc, A[r], B[r]);
             }
         }
     }
@@ -283,7 +298,7 @@ Plan plan_for(int N, int Ho, int Wo, int Cin, int Cout, int taps, int stride) {
     pl.wgs_per_range = (int)((tiles + 3) / 4);
     pl.units = (long)N * pl.strips * Ho;
     const double slab_us = 2.0 * taps * Cout * (double)Cin * 4.0 / 4.0e6;          // write + read at ~4 TB/s
-    const double step_us = taps == 9 ? 0.45 : 0.12;                                 // one wave's row step with the SIMD to itself
+    const double step_us = taps == 9 ? 0.45 : 0.25;                                 // one wave's row step (1x1: a quarter of a four-row load round trip)
     double best = 1e30;
     long best_r = 1;
     const int resident = taps == 9 && stride == 2 ? 256 : 512;                      // the stride-2 kernel needs a SIMD's whole register file
