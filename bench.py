@@ -502,16 +502,17 @@ def bench_c3(a, dev, world, rank, dist):
             'per_rank_ms_per_step': per_rank_ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
             'dtype_note': 'fp32 tensors and accumulation; K1 / K9 (Linear and backbone convolutions) / K2 forward on split-f16x3 operands, their '
-                          'backward kernels on fp16 (K1, K2) or split-f16x3 (K9 dgrad) operands; convolution wgrad, BatchNorm, stem: vendor fp32',
-            'vendor_convolution': 'forward: none but the 1-channel 7x7 stem; backward: weight gradients only (MIOpen backward-weights)'
-                                  if not a.vendor_train else 'all (comparison leg)',
+                          'backward kernels on fp16 (K1, K2) or split-f16x3 (K9 dgrad, K16 wgrad) operands; stem forward + wgrad exact fp32 '
+                          'MFMA (K10); BatchNorm, LayerNorm backward, interpolation: vendor fp32',
+            'vendor_convolution': 'none' if not a.vendor_train else 'all (comparison leg)',
             'config': {'workload': 'Matterport3D-shaped training step (BASELINE configs[2]): ' + str(B) + ' pair(s) @ 640x480 per GPU, '
                                    'matcher in training mode (sampled / padded coarse matches), solver x2, head x2 (last with grad), '
                                    'coarse focal + fine l2_with_std + 6D pose L1 losses, backward, AdamW; seeded random weights',
                        'pairs_per_gpu': B, 'hypotheses': a.hyp,
                        'training_kernels': 'vendor ops + autograd (comparison leg)' if a.vendor_train else
-                                           'HIP forward+backward: K1 sparse-position conf, K5, K9 Linear + backbone convolutions (dgrad), K3 window '
-                                           'gather / scatter, K2; weight packing and gradient scaling without host synchronisation',
+                                           'HIP forward+backward: K1 sparse-position conf, K5, K9 Linear + backbone convolutions (dgrad), K16 '
+                                           'convolution / Linear / stem weight gradients (deterministic), K3 window gather / scatter, K2; weight '
+                                           'packing and gradient scaling without host synchronisation',
                        'gt_coarse_matches_per_pair': n_gt, 'sampled_matches': int(last['b_ids'].numel()),
                        'losses': sc,
                        'parallelism': f'ddp{world} (gradient all-reduce over RCCL)' if world > 1 else 'single GPU (no exchange step)'},

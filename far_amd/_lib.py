@@ -69,6 +69,8 @@ SIGNATURES = {
     'far_conv_wgrad_ws_bytes': (c_l, [c_i, c_i, c_i, c_i, c_i, c_i, c_i]),
     'far_conv_wgrad_f16s': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_l, c_p, c_p, c_p]),
     'far_stem7x7_nhwc_f32': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
+    'far_stem7x7_wgrad_ws_bytes': (c_l, [c_i, c_i, c_i, c_i]),
+    'far_stem7x7_wgrad_f32': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_l, c_p, c_p]),
     'far_pose_pack_f64': (c_i, [c_p] * 8 + [c_i] + [c_p] * 6 + [c_p]),
     'far_pose_features_f32': (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p]),
     'far_rows_linear_packed_bytes': (c_sz, [c_i, c_i]),

@@ -16,7 +16,7 @@ constexpr int KP = 50;                         // taps padded to an even count
 
 constexpr int YB = 15;                         // tiles (of 4 output rows) per workgroup: the [50][Cout] weight image (25 KiB from L2) is staged once for them (1.32 -> 1.15 ms per 64 images; 6: 1.18)
 
-template <int NTILES>                          // Cout = 32 * NTILES
+template <int NTILES, bool PLAIN>              // Cout = 32 * NTILES; PLAIN: the bare convolution (training: BatchNorm follows with batch statistics)
 __global__ __launch_bounds__(256) void k_stem(const float* __restrict__ img, const float* __restrict__ w,
                                               const float* __restrict__ scale, const float* __restrict__ shift, int N,
                                               int H, int W, int Ho, int Wo, int tilesX, int tilesY, float* __restrict__ y) {
@@ -38,7 +38,10 @@ __global__ __launch_bounds__(256) void k_stem(const float* __restrict__ img, con
     }
     float sc[NTILES], sh[NTILES];
 #pragma unroll
-    for (int nt = 0; nt < NTILES; ++nt) { sc[nt] = scale[32 * nt + l31]; sh[nt] = shift[32 * nt + l31]; }
+    for (int nt = 0; nt < NTILES; ++nt) {
+        sc[nt] = PLAIN ? 1.f : scale[32 * nt + l31];
+        sh[nt] = PLAIN ? 0.f : shift[32 * nt + l31];
+    }
     for (int ty = tyb * YB; ty < min(tilesY, (tyb + 1) * YB); ++ty) {
         const int oy0 = ty * SR;
         __syncthreads();                                       // the previous tile's patch is consumed (and wl is written)
@@ -74,11 +77,98 @@ __global__ __launch_bounds__(256) void k_stem(const float* __restrict__ img, con
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ox = ox0 + mfma32_row(r, h);
-                    if (ox < Wo) y[(((size_t)n * Ho + oy) * Wo + ox) * C + co] = fmaxf(acc[nt][r] * sc[nt] + sh[nt], 0.f);
+                    if (ox < Wo)
+                        y[(((size_t)n * Ho + oy) * Wo + ox) * C + co] = PLAIN ? acc[nt][r] : fmaxf(acc[nt][r] * sc[nt] + sh[nt], 0.f);
                 }
             }
         }
     }
+}
+
+// Weight gradient of the stem (training): dW[co][ky][kx] = sum_{n, oy, ox} dy[n][oy][ox][co] * img[n][2 oy + ky - 3][2 ox + kx - 3],
+// the same exact-f32 MFMA with the roles turned: M = Cout, N = 49 taps (two 32-wide tiles, the tail zero), K = pixels.  A lane
+// feeds A[co][pixel] = dy[pixel][co] straight from memory (NHWC: 32 consecutive channels per half-wave) and B[pixel][tap]
+// from the same LDS patch the forward kernel gathers from.  A wave owns one output row of each tile and walks a run of tiles;
+// its [Cout][64] partial goes to a slab and k_stem_wgrad_reduce adds the slabs in index order (deterministic).
+template <int NTILES>
+__global__ __launch_bounds__(256) void k_stem_wgrad(const float* __restrict__ img, const float* __restrict__ dy, int N, int H, int W,
+                                                    int Ho, int Wo, int tilesX, int tilesY, int tiles_per_wg, long ntiles,
+                                                    float* __restrict__ part) {
+    constexpr int C = 32 * NTILES;
+    __shared__ float patch[PH * PW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+    int toff[2];
+    bool tval[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const int tap = 32 * tt + l31;
+        tval[tt] = tap < 49;
+        toff[tt] = tval[tt] ? (tap / 7) * PW + tap % 7 : 0;
+    }
+    f32x16 acc[NTILES][2];
+#pragma unroll
+    for (int ct = 0; ct < NTILES; ++ct)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][tt][r] = 0.f;
+    const long t0 = (long)blockIdx.x * tiles_per_wg, t1 = t0 + tiles_per_wg < ntiles ? t0 + tiles_per_wg : ntiles;
+    for (long t = t0; t < t1; ++t) {
+        const int tx = (int)(t % tilesX), ty = (int)((t / tilesX) % tilesY), n = (int)(t / ((long)tilesX * tilesY));
+        const int oy0 = ty * SR, ox0 = tx * SC;
+        const float* im = img + (size_t)n * H * W;
+        __syncthreads();
+        for (int i = tid; i < PH * PW; i += 256) {
+            const int py = i / PW, px = i - py * PW;
+            const int iy = 2 * oy0 - 3 + py, ix = 2 * ox0 - 3 + px;
+            patch[i] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? im[(size_t)iy * W + ix] : 0.f;
+        }
+        __syncthreads();
+        const int oy = oy0 + wave;
+        if (oy >= Ho) continue;                                   // wave-uniform; the barriers above are outside
+        const float* drow = dy + ((size_t)n * Ho + oy) * Wo * C;
+#pragma unroll 4
+        for (int c = 0; c < SC; c += 2) {
+            const int ox = ox0 + c + h;
+            const bool live = ox < Wo;
+            float b[2];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) b[tt] = tval[tt] ? patch[(2 * wave) * PW + 2 * (c + h) + toff[tt]] : 0.f;
+#pragma unroll
+            for (int ct = 0; ct < NTILES; ++ct) {
+                const float a = live ? drow[(size_t)ox * C + 32 * ct + l31] : 0.f;
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) acc[ct][tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[tt], acc[ct][tt], 0, 0, 0);
+            }
+        }
+    }
+    // slab of this wave: [Cout][64]; accumulator register r of lane (l31, h) = D[co = 32 ct + row(r, h)][tap = 32 tt + l31]
+    float* const slab = part + ((size_t)blockIdx.x * 4 + wave) * C * 64;
+#pragma unroll
+    for (int ct = 0; ct < NTILES; ++ct)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) slab[(32 * ct + mfma32_row(r, h)) * 64 + 32 * tt + l31] = acc[ct][tt][r];
+}
+
+__global__ void k_stem_wgrad_reduce(const float* __restrict__ part, int slabs, int C, float* __restrict__ dw) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // over [C][64]
+    if (i >= C * 64) return;
+    const int co = i >> 6, tap = i & 63;
+    if (tap >= 49) return;
+    float s = 0.f;
+    for (int k = 0; k < slabs; ++k) s += part[(size_t)k * C * 64 + i];
+    dw[co * 49 + tap] = s;
+}
+
+int stem_wgrad_wgs(int N, int Ho, int Wo, int* tiles_per_wg, long* ntiles) {
+    const int tilesX = (Wo + SC - 1) / SC, tilesY = (Ho + SR - 1) / SR;
+    *ntiles = (long)N * tilesX * tilesY;
+    long per = (*ntiles + 511) / 512;
+    if (per < 1) per = 1;
+    *tiles_per_wg = (int)per;
+    return (int)((*ntiles + per - 1) / per);
 }
 
 }  // namespace
@@ -87,20 +177,52 @@ extern "C" {
 
 // y[n][oy][ox][co] = relu(scale[co] * sum_{ky,kx} img[n][2 oy + ky - 3][2 ox + kx - 3] * w[co][ky][kx] + shift[co])
 // img [N][H][W] fp32 (one channel), w [Cout][7][7], y [N][Ho][Wo][Cout] NHWC with Ho = (H + 1) / 2, Wo = (W + 1) / 2;
-// Cout = 64 or 128.
+// Cout = 64 or 128.  scale = shift = NULL: the bare convolution, no BatchNorm fold and no ReLU (the training forward).
 int far_stem7x7_nhwc_f32(const float* img, const float* w, const float* scale, const float* shift, int N, int H, int W,
                          int Cout, float* y, hipStream_t stream) {
     far_clear_errors();
     if (N == 0) return FAR_OK;
-    if (!img || !w || !scale || !shift || !y || N < 0 || H <= 0 || W <= 0 || (Cout != 64 && Cout != 128)) return FAR_EINVAL;
+    if (!img || !w || (!scale) != (!shift) || !y || N < 0 || H <= 0 || W <= 0 || (Cout != 64 && Cout != 128)) return FAR_EINVAL;
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
     const int tilesX = (Wo + SC - 1) / SC, tilesY = (Ho + SR - 1) / SR;
     const long nb = (long)N * tilesX * ((tilesY + YB - 1) / YB);
     if (nb > 0x7fffffffL) return FAR_EINVAL;
+    const bool plain = !scale && !shift;
+    if (Cout == 128) {
+        if (plain) hipLaunchKernelGGL((k_stem<4, true>), dim3((unsigned)nb), dim3(256), 0, stream, img, w, scale, shift, N, H, W, Ho, Wo, tilesX, tilesY, y);
+        else hipLaunchKernelGGL((k_stem<4, false>), dim3((unsigned)nb), dim3(256), 0, stream, img, w, scale, shift, N, H, W, Ho, Wo, tilesX, tilesY, y);
+    } else {
+        if (plain) hipLaunchKernelGGL((k_stem<2, true>), dim3((unsigned)nb), dim3(256), 0, stream, img, w, scale, shift, N, H, W, Ho, Wo, tilesX, tilesY, y);
+        else hipLaunchKernelGGL((k_stem<2, false>), dim3((unsigned)nb), dim3(256), 0, stream, img, w, scale, shift, N, H, W, Ho, Wo, tilesX, tilesY, y);
+    }
+    return far_check_launch();
+}
+
+// Bytes of device scratch far_stem7x7_wgrad_f32 needs.
+long far_stem7x7_wgrad_ws_bytes(int N, int H, int W, int Cout) {
+    if (N <= 0 || H <= 0 || W <= 0 || (Cout != 64 && Cout != 128)) return 0;
+    int per; long nt;
+    const int wgs = stem_wgrad_wgs(N, (H + 1) / 2, (W + 1) / 2, &per, &nt);
+    return (long)wgs * 4 * Cout * 64 * (long)sizeof(float);
+}
+
+// dw [Cout][7][7] (overwritten) = sum_{n, oy, ox} dy[n][oy][ox][co] * img[n][2 oy + ky - 3][2 ox + kx - 3]: the weight gradient of
+// the stem convolution from the image [N][H][W] and dy [N][Ho][Wo][Cout] (NHWC).  Exact fp32 products, deterministic sum.
+int far_stem7x7_wgrad_f32(const float* img, const float* dy, int N, int H, int W, int Cout, void* ws, long ws_bytes, float* dw,
+                          hipStream_t stream) {
+    far_clear_errors();
+    const long need = far_stem7x7_wgrad_ws_bytes(N, H, W, Cout);
+    if (!img || !dy || !dw || !ws || need == 0 || ws_bytes < need) return FAR_EINVAL;
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const int tilesX = (Wo + SC - 1) / SC, tilesY = (Ho + SR - 1) / SR;
+    int per; long nt;
+    const int wgs = stem_wgrad_wgs(N, Ho, Wo, &per, &nt);
+    float* const part = reinterpret_cast<float*>(ws);
     if (Cout == 128)
-        hipLaunchKernelGGL(k_stem<4>, dim3((unsigned)nb), dim3(256), 0, stream, img, w, scale, shift, N, H, W, Ho, Wo, tilesX, tilesY, y);
+        hipLaunchKernelGGL(k_stem_wgrad<4>, dim3((unsigned)wgs), dim3(256), 0, stream, img, dy, N, H, W, Ho, Wo, tilesX, tilesY, per, nt, part);
     else
-        hipLaunchKernelGGL(k_stem<2>, dim3((unsigned)nb), dim3(256), 0, stream, img, w, scale, shift, N, H, W, Ho, Wo, tilesX, tilesY, y);
+        hipLaunchKernelGGL(k_stem_wgrad<2>, dim3((unsigned)wgs), dim3(256), 0, stream, img, dy, N, H, W, Ho, Wo, tilesX, tilesY, per, nt, part);
+    hipLaunchKernelGGL(k_stem_wgrad_reduce, dim3((unsigned)((Cout * 64 + 255) / 256)), dim3(256), 0, stream, part, wgs * 4, Cout, dw);
     return far_check_launch();
 }
 

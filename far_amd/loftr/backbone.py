@@ -157,7 +157,11 @@ class ResNetFPN_8_2(nn.Module):
     def forward(self, x):
         if _fused_ok(self, x) and x.shape[1] == 1:
             return self._forward_fused(x)
-        x0 = self.relu(self.bn1(self.conv1(x)))
+        if (ResNetFPN_8_2.hip_training and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and x.shape[1] == 1
+                and self.conv1.weight.requires_grad and self.conv1.out_channels in (64, 128)):
+            x0 = self.relu(self.bn1(ops.stem_train(x, self.conv1.weight)))           # K10 + its weight gradient
+        else:
+            x0 = self.relu(self.bn1(self.conv1(x)))
         x1 = self.layer1(x0)
         x2 = self.layer2(x1)
         x3 = self.layer3(x2)

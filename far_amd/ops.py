@@ -1027,8 +1027,9 @@ def linear_f16s(x, pc, residual=None, act='none', x2=None, out_planes=1, res_gro
     return y.reshape(*lead, pc.Cout) if out_planes == 1 else y.reshape(out_planes, *lead, pc.Cout // out_planes)
 
 
-def stem7x7(img, weight, scale, shift):
-    """K10.  img (N, 1, H, W) fp32 -> relu(bn(conv7x7 stride 2)) as NHWC (N, H/2, W/2, Cout)."""
+def stem7x7(img, weight, scale=None, shift=None):
+    """K10.  img (N, 1, H, W) fp32 -> relu(bn(conv7x7 stride 2)) as NHWC (N, H/2, W/2, Cout); without scale / shift the bare
+    convolution (training: BatchNorm follows with batch statistics)."""
     lib = _lib.load()
     N, one, H, W = img.shape
     Cout = weight.shape[0]
@@ -1036,9 +1037,42 @@ def stem7x7(img, weight, scale, shift):
         raise _lib.FarHipError('stem7x7 expects a 1-channel image and a (Cout, 1, 7, 7) weight')
     y = torch.empty(N, (H + 1) // 2, (W + 1) // 2, Cout, dtype=torch.float32, device=img.device)
     rc = lib.far_stem7x7_nhwc_f32(_p(img.contiguous(), torch.float32), _p(weight.detach().contiguous(), torch.float32),
-                                  _p(scale, torch.float32), _p(shift, torch.float32), N, H, W, Cout, _p(y), _stream())
+                                  _p(scale, torch.float32) if scale is not None else None,
+                                  _p(shift, torch.float32) if shift is not None else None, N, H, W, Cout, _p(y), _stream())
     _lib.check(rc, 'far_stem7x7_nhwc_f32')
     return y
+
+
+class _StemFn(torch.autograd.Function):
+    """The stem convolution with its weight gradient (resnet_fpn.py:60 under autograd; the image needs no gradient): K10 forward
+    without the BatchNorm fold, far_stem7x7_wgrad_f32 backward.  Returns (N, Cout, H/2, W/2) logical, channels_last memory."""
+
+    @staticmethod
+    def forward(ctx, img, weight):
+        img = img.detach().float().contiguous()
+        ctx.save_for_backward(img)
+        return stem7x7(img, weight).permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        img, = ctx.saved_tensors
+        lib = _lib.load()
+        N, _, H, W = img.shape
+        gn = g.float().contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).contiguous()
+        Cout = gn.shape[-1]
+        nb = int(lib.far_stem7x7_wgrad_ws_bytes(N, H, W, Cout))
+        ws = torch.empty(nb, dtype=torch.uint8, device=img.device)
+        dw = torch.empty(Cout, 1, 7, 7, dtype=torch.float32, device=img.device)
+        rc = lib.far_stem7x7_wgrad_f32(_p(img, torch.float32), _p(gn, torch.float32), N, H, W, Cout, _p(ws), nb, _p(dw), _stream())
+        _lib.check(rc, 'far_stem7x7_wgrad_f32')
+        return None, dw
+
+
+def stem_train(img, weight):
+    """K10 with the weight gradient: img (N, 1, H, W) fp32 GPU, weight (Cout, 1, 7, 7) -> conv7x7 stride 2 (no BN, no ReLU)."""
+    if not img.is_cuda:
+        raise _lib.FarHipError('far_amd ops need tensors on the GPU (no CPU fallback exists)')
+    return _StemFn.apply(img, weight)
 
 
 _CVW_GRID = {}

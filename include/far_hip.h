@@ -370,9 +370,16 @@ int far_conv_wgrad_f16s(const float* x, const float* dy, int N, int H, int W, in
  * K10  backbone stem: 7x7 stride-2 convolution of a 1-channel image + folded BatchNorm + ReLU (exact-f32 MFMA)
  * replaces src/loftr/backbone/resnet_fpn.py:60-62, :103   x0 = relu(bn1(conv1(x)))
  * img [N][H][W] fp32, w [Cout][7][7] (torch layout), y [N][(H+1)/2][(W+1)/2][Cout] NHWC; Cout = 64 or 128.
+ * scale = shift = NULL: the bare convolution (no BatchNorm fold, no ReLU) -- the training forward, where bn1 follows with
+ * batch statistics.  far_stem7x7_wgrad_f32: its weight gradient dw [Cout][7][7] (overwritten) = sum over pixels of
+ * dy[n][oy][ox][co] * img[n][2 oy + ky - 3][2 ox + kx - 3] (autograd's backward-weights of resnet_fpn.py:60), exact fp32
+ * products, deterministic two-stage sum through `ws` (far_stem7x7_wgrad_ws_bytes() bytes of device scratch).
  * --------------------------------------------------------------------------------------------------- */
 int far_stem7x7_nhwc_f32(const float* img, const float* w, const float* scale, const float* shift, int N, int H, int W,
                          int Cout, float* y, far_stream_t stream);
+long far_stem7x7_wgrad_ws_bytes(int N, int H, int W, int Cout);
+int far_stem7x7_wgrad_f32(const float* img, const float* dy, int N, int H, int W, int Cout, void* ws, long ws_bytes, float* dw,
+                          far_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * K11  per-pair arithmetic between the solver and the regression head (one launch each)

@@ -383,3 +383,28 @@ def test_conv_wgrad_matches_float64(N, H, W, Cin, Cout, ks, stride):
     err = float((dw.double() - w.grad).abs().max() / w.grad.abs().max())
     print(f'[wgrad] {Cin}->{Cout} k{ks} s{stride} on {N}x{H}x{W}: relative max error {err:.1e}')
     assert dw.shape == w.shape and err < 5e-6
+
+
+@pytest.mark.parametrize('N,H,W,Cout', [(2, 96, 128, 128), (1, 61, 75, 128), (1, 40, 56, 64)])
+def test_stem_train_forward_and_weight_gradient_match_float64(N, H, W, Cout):
+    """K10 in training form (bare 7x7 stride-2 convolution, no BN fold / ReLU) and far_stem7x7_wgrad_f32 against float64
+    autograd of F.conv2d (resnet_fpn.py:60); the weight gradient is deterministic."""
+    import torch.nn.functional as F
+    from far_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(N + H + W + Cout)
+    img = torch.rand(N, 1, H, W, device='cuda', generator=g)
+    w = (torch.randn(Cout, 1, 7, 7, device='cuda', generator=g) * 0.1).requires_grad_(True)
+    y = ops.stem_train(img, w)
+    dy = torch.randn(y.shape, device='cuda', generator=g) * 1e-4
+    y.backward(dy)
+    w64 = w.detach().double().requires_grad_(True)
+    y64 = F.conv2d(img.double(), w64, stride=2, padding=3)
+    y64.backward(dy.double())
+    ey = float((y.double() - y64).abs().max() / y64.abs().max())
+    ew = float((w.grad.double() - w64.grad).abs().max() / w64.grad.abs().max())
+    print(f'[stem train] {N}x{H}x{W} -> {Cout}: y {ey:.1e}  dw {ew:.1e}')
+    assert y.shape == y64.shape and ey < 2e-6 and ew < 5e-6
+    g1 = w.grad.clone()
+    w.grad = None
+    ops.stem_train(img, w).backward(dy)
+    assert torch.equal(g1, w.grad)
