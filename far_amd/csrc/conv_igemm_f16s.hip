@@ -1007,10 +1007,14 @@ int launch_conv(const ConvArgs& a, dim3 grid, hipStream_t stream) {
 }
 
 template <int KS, bool SPLIT>
-int launch_cfg(const TileCfg& c, const ConvArgs& a, dim3 grid, hipStream_t stream) {
+int launch_cfg(const TileCfg& c, const ConvArgs& a, dim3 grid, hipStream_t stream, bool small = false) {
     if (KS == 1 && a.up) {                          // the FPN merge variant (fused 2x-upsample residual)
         if (c.mw == 4) return launch_conv<1, 4, 1, 4, SPLIT, 1, true>(a, grid, stream);
         return launch_conv<1, 2, 2, 4, SPLIT, 1, true>(a, grid, stream);
+    }
+    if constexpr (KS == 1) {                        // few rows (a Linear layer of one pair): half-height tiles, twice the workgroups
+        if (c.mw == 2 && small) return launch_conv<1, 1, 2, 4, SPLIT>(a, grid, stream);
+        if (c.mw == 4 && small) return launch_conv<1, 2, 1, 4, SPLIT>(a, grid, stream);
     }
     if (c.mw == 4) return launch_conv<KS, 4, 1, 4, SPLIT>(a, grid, stream);
     // seven-tile mode: 3x3, one channel block, 193..224 output channels, the 16-byte epilogue (the 196-channel layers)
@@ -1199,13 +1203,16 @@ int far_conv_nhwc_f32(const far_conv_desc* desc, hipStream_t stream) {
     a.act = act; a.slope = slope;
     a.act_scale = ldexpf(1.0f, d.act_exp); a.out_mul = ldexpf(1.0f, ACT_EXP_DEFAULT - d.act_exp); a.overflow = d.overflow;
     a.scale_dev = d.act_scale_dev;
-    const long nbx = ksize == 1 ? (a.npix + 64 * c.mw - 1) / (64 * c.mw) : N * a.tilesX * a.tilesY;
+    long nbx = ksize == 1 ? (a.npix + 64 * c.mw - 1) / (64 * c.mw) : N * a.tilesX * a.tilesY;
+    // a Linear layer over the tokens of one pair fills a fraction of the CUs with full-height tiles: halve them
+    const bool small = ksize == 1 && !up && nbx * a.nblkY < 192 && far_get_tuning(5) == 0;
+    if (small) nbx = (a.npix + 32 * c.mw - 1) / (32 * c.mw);
     a.ntiles = nbx;
     if (nbx * a.nblkY > 0x7fffffffL) return FAR_EINVAL;
     dim3 grid((unsigned)(nbx * a.nblkY));
     if (stride == 2) return split ? launch_stride2<true>(a, grid, stream) : launch_stride2<false>(a, grid, stream);
     if (ksize == 3) return split ? launch_cfg<3, true>(c, a, grid, stream) : launch_cfg<3, false>(c, a, grid, stream);
-    return split ? launch_cfg<1, true>(c, a, grid, stream) : launch_cfg<1, false>(c, a, grid, stream);
+    return split ? launch_cfg<1, true>(c, a, grid, stream, small) : launch_cfg<1, false>(c, a, grid, stream, small);
 }
 
 #ifdef FAR_K9_TIMING

@@ -432,3 +432,37 @@ def test_conv_is_run_to_run_deterministic_under_load():
                         junk = junk @ junk * 1e-3
                 assert torch.equal(ops.conv_nhwc(x, pc, act='relu'), first), (N, H, W, Cin, Cout, ks, st, split, r)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize('rows,K,Co', [(4800, 256, 256), (1500, 128, 128), (4800, 256, 768), (333, 512, 256), (9600, 256, 128), (70, 256, 196)])
+def test_linear_half_height_tiles_equal_full_height(rows, K, Co):
+    """Few-row Linear launches (fewer workgroups than CUs) run 32 MW-row tiles instead of 64 MW: the same products in the same
+    order per output, so every epilogue (bias / activation / residual / LayerNorm / output planes) equals the full-height launch
+    bit for bit (tuning knob 5 forces the full-height path)."""
+    from far_amd import _lib
+    ops = _ops()
+    lib = _lib.load()
+    g = torch.Generator(device='cuda').manual_seed(rows + Co)
+    x = torch.randn(rows, K, device='cuda', generator=g)
+    w = torch.randn(Co, K, device='cuda', generator=g) * 0.06
+    b = torch.randn(Co, device='cuda', generator=g)
+    r = torch.randn(rows, Co, device='cuda', generator=g)
+    gamma, beta = torch.rand(Co, device='cuda', generator=g) + 0.5, torch.randn(Co, device='cuda', generator=g) * 0.2
+    pc, pcb = ops.PackedConv(w), ops.PackedConv(w, None, b)
+
+    def variants():
+        out = [ops.linear_f16s(x, pc), ops.linear_f16s(x, pcb, act='relu'), ops.linear_f16s(x, pc, residual=r, act='leaky')]
+        if Co in (128, 256):
+            out.append(ops.linear_f16s(x, pc, ln=(gamma, beta, 1e-5), post_residual=r))
+        if Co % 3 == 0 and (Co // 3) % 4 == 0:
+            out.append(ops.linear_f16s(x, pc, out_planes=3))
+        return out
+    small = variants()
+    lib.far_set_tuning(5, 1)
+    try:
+        full = variants()
+    finally:
+        lib.far_set_tuning(5, 0)
+    for a, bb in zip(small, full):
+        assert torch.equal(a, bb)
+    assert _rel(small[0], x.double() @ w.double().t())[0] < 4e-6
