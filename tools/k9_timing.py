@@ -68,6 +68,16 @@ for w in which:
         e0.record(); ops.conv_nhwc(r, pl); e1.record(); torch.cuda.synchronize()
         print(f'event-timed launch {e0.elapsed_time(e1) * 1e3:.1f} us')
         report('linear 256->256, 307200 rows', 64 * 4800 // 128, 2)
+    elif w == 'linear_small':
+        r = torch.randn(1, 1, 4800, 256, device=dev, generator=g)
+        pl = ops.PackedConv(torch.randn(256, 256, device=dev, generator=g) * 0.05)
+        for _ in range(3):
+            ops.conv_nhwc(r, pl)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); ops.conv_nhwc(r, pl); e1.record(); torch.cuda.synchronize()
+        print(f'event-timed launch {e0.elapsed_time(e1) * 1e3:.1f} us')
+        report('linear 256->256, 4800 rows (half-height tiles)', 4800 // 64, 1)
     elif w == 'linear_ln':
         r = torch.randn(1, 1, 64 * 4800, 256, device=dev, generator=g)
         pl = ops.PackedConv(torch.randn(256, 256, device=dev, generator=g) * 0.05)

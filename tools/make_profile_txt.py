@@ -36,3 +36,33 @@ open(ROOT + f'/profiles/{tag}_bench_fp32_kernel_trace.txt', 'w').write(out)
 if os.path.exists(G + f'{tag}_pmc_traffic.json'):
     shutil.copy(G + f'{tag}_pmc_traffic.json', ROOT + f'/profiles/{tag}_pmc_traffic.json')
 print('wrote', f'profiles/{tag}_bench_fp32_kernel_trace.txt')
+
+# ---- the training step (BASELINE configs[2]): kernel trace of bench.py --workload c3, both legs' bench lines, K16 vs the vendor
+if os.path.exists(G + f'{tag}_c3_trace.txt') and os.path.exists(G + 'bench_c3.log'):
+    c3, c3v, c3p = last_json(G + 'bench_c3.log'), last_json(G + 'bench_c3_vendor.log'), last_json(G + 'bench_c3_prof.log')
+    tr3 = open(G + f'{tag}_c3_trace.txt').read()
+    whole3, win3 = tr3.split('\n\n', 1)
+    win3 = win3.split('\n## launches of')[0]
+    wg = open(G + f'{tag}_wgrad_time.txt').read() if os.path.exists(G + f'{tag}_wgrad_time.txt') else ''
+    vk = open(G + f'{tag}_c3_vendor_kernels.txt').read() if os.path.exists(G + f'{tag}_c3_vendor_kernels.txt') else ''
+    out3 = f"""# rocprofv3 --kernel-trace --stats -- python3 bench.py --workload c3 --steps 10 --warmup 3 --no-cpu-baseline --no-other-modes    (round {rnd}, 1x MI355X, commit {commit})
+# bench line of the profiled run:
+{c3p}
+
+# un-profiled lines on the same box: HIP training kernels / the vendor-op comparison leg (--vendor-train)
+{c3}
+{c3v}
+
+## one steady-state training step (1 pair): per kernel
+{win3.strip()}
+
+## vendor / ATen kernels left in that step (tools/aten_in_step.py)
+{vk.strip()}
+
+## K16 (far_conv_wgrad_f16s + reduction) against the vendor's backward-weights on the backbone's layer shapes (tools/wgrad_time.py, wall per call)
+{wg.strip()}
+"""
+    open(ROOT + f'/profiles/{tag}_c3_training_kernel_trace.txt', 'w').write(out3)
+    print('wrote', f'profiles/{tag}_c3_training_kernel_trace.txt')
+if os.path.exists(G + 'bench_c5.log'):
+    open(ROOT + f'/profiles/{tag}_bench_c5_line.json', 'w').write(last_json(G + 'bench_c5.log') + '\n')
