@@ -7,7 +7,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libfar_hip.so')
+# FAR_HIP_LIB: another build of the same library (tools/ab_build.py writes lib/libfar_hip_base.so from a git revision, for
+# same-box A/B timings); the default is the in-tree build.
+LIB_PATH = os.environ.get('FAR_HIP_LIB') or os.path.join(_HERE, 'lib', 'libfar_hip.so')
 
 c_p = ctypes.c_void_p
 c_i = ctypes.c_int

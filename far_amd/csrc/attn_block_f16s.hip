@@ -53,10 +53,11 @@ __device__ __forceinline__ float elu1(float x) { return (x > 0.f ? x : expm1f(x)
 
 __device__ __forceinline__ void split_regs(const float (&v)[8], f16x8& hi, f16x8& lo) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const _Float16 hh = (_Float16)v[i];
-        hi[i] = hh;
-        lo[i] = (_Float16)(v[i] - (float)hh);
+    for (int i = 0; i < 8; i += 2) {                       // packed conversions (common.h: split2)
+        f16x2 h, l;
+        split2(f32x2{v[i], v[i + 1]}, h, l);
+        hi[i] = h.x; hi[i + 1] = h.y;
+        lo[i] = l.x; lo[i + 1] = l.y;
     }
 }
 __device__ __forceinline__ void split8(const float4& u, const float4& v, float scale, f16x8& hi, f16x8& lo) {

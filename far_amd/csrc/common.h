@@ -11,6 +11,16 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// The fp16 (hi, lo) split of two values at once: hi = fp16(x), lo = fp16(x - hi), round to nearest -- the same arithmetic
+// as the scalar split, on the packed instructions of gfx950 (v_cvt_pk_f16_f32, v_pk_add_f32): 5 instructions per pair
+// instead of 8.
+__device__ __forceinline__ void split2(f32x2 x, f16x2& hi, f16x2& lo) {
+    hi = __builtin_convertvector(x, f16x2);
+    lo = __builtin_convertvector(x - __builtin_convertvector(hi, f32x2), f16x2);
+}
 
 // Row index inside a 32x32 MFMA accumulator tile for accumulator register `r` (0..15) of a lane
 // whose upper-half flag is `h` (lane >> 5).  Column index is lane & 31.

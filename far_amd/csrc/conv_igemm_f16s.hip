@@ -102,11 +102,11 @@ struct ConvArgs {
 __device__ __forceinline__ void split8(const float4& u, const float4& v, float act_scale, f16x8& hi, f16x8& lo) {
     const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const float s = x[i] * act_scale;
-        const _Float16 hh = (_Float16)s;
-        hi[i] = hh;
-        lo[i] = (_Float16)(s - (float)hh);
+    for (int i = 0; i < 8; i += 2) {                       // two channels per packed conversion (common.h: split2)
+        f16x2 h, l;
+        split2(f32x2{x[i], x[i + 1]} * f32x2{act_scale, act_scale}, h, l);
+        hi[i] = h.x; hi[i + 1] = h.y;
+        lo[i] = l.x; lo[i + 1] = l.y;
     }
 }
 
@@ -920,6 +920,8 @@ __global__ __launch_bounds__(256) void k_amax_scale_multi(const float* __restric
     }
 }
 
+std::atomic<unsigned> g_amax_next_slot{0};       // one counter for both modes: a slot has one user at a time
+
 // One launch either way; float4 reads need a 16-byte aligned tensor (anything else takes the three-launch path of the callers).
 template <int MODE>
 void launch_amax_scale(const float* w, long n, float* out2, hipStream_t stream) {
@@ -927,8 +929,7 @@ void launch_amax_scale(const float* w, long n, float* out2, hipStream_t stream) 
         hipLaunchKernelGGL(k_amax_scale_single<MODE>, dim3(1), dim3(1024), 0, stream, w, n, out2);
         return;
     }
-    static std::atomic<unsigned> next_slot{0};
-    const int slot = (int)(next_slot.fetch_add(1, std::memory_order_relaxed) & 1023u);
+    const int slot = (int)(g_amax_next_slot.fetch_add(1, std::memory_order_relaxed) & 1023u);
     long blocks = (n / 4 + 255) / 256 / 4;                         // >= 4 float4 per thread
     blocks = blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks);
     hipLaunchKernelGGL(k_amax_scale_multi<MODE>, dim3((unsigned)blocks), dim3(256), 0, stream, w, n, out2, slot);

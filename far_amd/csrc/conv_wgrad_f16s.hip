@@ -68,11 +68,11 @@ __device__ __forceinline__ void issue_dy(const WsArgs& p, const Seg& c, int oy, 
 
 __device__ __forceinline__ void split_dy(const float (&v)[8], float sg, Operand& A) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const float s = v[i] * sg;
-        const _Float16 h = (_Float16)s;
-        A.hi[i] = h;
-        A.lo[i] = (_Float16)(s - (float)h);
+    for (int i = 0; i < 8; i += 2) {                       // two pixels per packed conversion (common.h: split2)
+        f16x2 h, l;
+        split2(f32x2{v[i], v[i + 1]} * f32x2{sg, sg}, h, l);
+        A.hi[i] = h.x; A.hi[i + 1] = h.y;
+        A.lo[i] = l.x; A.lo[i + 1] = l.y;
     }
 }
 
@@ -92,20 +92,16 @@ __device__ __forceinline__ void issue_x(const WsArgs& p, const Seg& c, int iy, f
 // ... -> the KS kx-shifted split operands: output pixel q of the lane's 8 reads x pixel ST q + kx.
 template <int KS, int ST>
 __device__ __forceinline__ void split_x(const float (&v)[ST * 7 + KS], float sx, Operand (&B)[KS]) {
-    constexpr int L = ST * 7 + KS;
-    _Float16 h[L], l[L];
-#pragma unroll
-    for (int i = 0; i < L; ++i) {
-        const float s = v[i] * sx;
-        h[i] = (_Float16)s;
-        l[i] = (_Float16)(s - (float)h[i]);
-    }
+    // one packed conversion per operand register (two pixels); identical pairs of different windows (kx = 0 / 2 at stride 1)
+    // are the same expression and are computed once
 #pragma unroll
     for (int kx = 0; kx < KS; ++kx)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            B[kx].hi[q] = h[ST * q + kx];
-            B[kx].lo[q] = l[ST * q + kx];
+        for (int q = 0; q < 8; q += 2) {
+            f16x2 h, l;
+            split2(f32x2{v[ST * q + kx], v[ST * (q + 1) + kx]} * f32x2{sx, sx}, h, l);
+            B[kx].hi[q] = h.x; B[kx].hi[q + 1] = h.y;
+            B[kx].lo[q] = l.x; B[kx].lo[q + 1] = l.y;
         }
 }
 

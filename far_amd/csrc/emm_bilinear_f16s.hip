@@ -24,7 +24,6 @@
 #include "common.h"
 #include <type_traits>
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 namespace {
@@ -37,6 +36,9 @@ constexpr int D = 64;            // head dim
 constexpr int DV = 70;           // v~ width (64 + 6 positional)
 constexpr int DVP = 96;          // padded to 3 MFMA column tiles
 constexpr int KT = 64;           // keys per tile
+// The tile's 64 integer column references ride in two padding rows of the v~^T hi plane (rows 70..95 only feed output
+// columns nobody stores): 256 bytes at row CREF_ROW, written by k_prep_v, so they arrive in LDS with the tile's DMA.
+constexpr int CREF_ROW = 80;
 constexpr float QK_PRESCALE = 16.0f;     // q, k scaled by 2^4 before the split (their fp16 lo parts stay normal)
 constexpr float V_PRESCALE = 64.0f;      // v~ / colsum scaled by 2^6; p by 2^15 (it is <= 1)
 constexpr float NEG_HUGE = -1.0e30f;
@@ -323,6 +325,8 @@ __global__ __launch_bounds__(256) void k_prep_v(const float* __restrict__ v, ZLa
         *reinterpret_cast<f16x8*>(oh + o) = vh;
         *reinterpret_cast<f16x8*>(ol + o) = vl;
     }
+    __syncthreads();                                     // the zero rows are written: now the references over two of them
+    if (tid < KT) reinterpret_cast<int*>(oh + base + (size_t)CREF_ROW * KT)[tid] = cref[(size_t)z * Np + jt * KT + tid];
 }
 
 // ---- k_pv: T[z][i][:] = (2^-15 / rowsum_i) * sum_j 2^(2 x_ij - R_i - C_j + 15) * (v~_j / colsum_j),  rowsum_i = sum_j 2^(x_ij - R_i)
@@ -333,6 +337,7 @@ __global__ __launch_bounds__(256) void k_prep_v(const float* __restrict__ v, ZLa
 // Both half-waves hold keys of the same 32 rows and feed ONE accumulator through the MFMA's k dimension, so they agree on
 // R_i (one cross-half exchange per tile).  Writes rowstat[z][i] = (R_i, rowsum_i) for the backward kernels.
 constexpr int VT_PLANE = DVP * 128;     // one v~^T tile plane: 96 rows x 64 keys fp16
+constexpr int PV_STAGE = 2 * CT_PLANE + 2 * VT_PLANE;     // 40 KiB: two stages = half a CU's LDS, two workgroups per CU
 template <bool MASKED>
 __device__ __forceinline__ float tile_rowmax(const f32x16 (&acc)[2], float c1, int j0, int N, int h) {
     float tm = NEG_HUGE;
@@ -351,8 +356,9 @@ __global__ __launch_bounds__(256, 2) void k_pv(const _Float16* __restrict__ qh, 
                                                const _Float16* __restrict__ vh, const _Float16* __restrict__ vl,
                                                const int* __restrict__ cref, int Z, int N, int Np, float c1,
                                                float2* __restrict__ rowstat, float* __restrict__ T) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * CT_PLANE + 2 * VT_PLANE];
-    unsigned char* const ldv = lds + 2 * CT_PLANE;
+    // two stages of { key tile (hi, lo), v~^T tile (hi, lo) with the tile's column references in two of its padding rows }:
+    // tile jt + 1 travels while tile jt is computed (asm LDS-DMA, one barrier per tile)
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     int z, Ib;
     tile_coords(Np / 128, Z, z, Ib);
@@ -360,6 +366,7 @@ __global__ __launch_bounds__(256, 2) void k_pv(const _Float16* __restrict__ qh, 
     const int irow = i0 + l31;
     RowFrags rf;
     rf.load(qh, ql, (size_t)z * Np + irow, irow, h);
+    rf.arrived();
 
     f32x16 tacc[3];
 #pragma unroll
@@ -372,25 +379,25 @@ __global__ __launch_bounds__(256, 2) void k_pv(const _Float16* __restrict__ qh, 
     const int ntile = Np / KT;
     const unsigned char* vsrc_h = reinterpret_cast<const unsigned char*>(vh + (size_t)z * ntile * DVP * KT) + tid * 16;
     const unsigned char* vsrc_l = reinterpret_cast<const unsigned char*>(vl + (size_t)z * ntile * DVP * KT) + tid * 16;
-    for (int jt = 0; jt < ntile; ++jt) {
-        __syncthreads();
-        dma_col_tile(lds, kh, kl, (size_t)z * Np + jt * KT, tid, wave);
+    auto request = [&](int jt) {
+        unsigned char* const st = lds_all + (jt & 1) * PV_STAGE;
+        dma_col_tile_async(st, kh, kl, (size_t)z * Np + jt * KT, tid, wave);
+        const unsigned dv = lds_addr_uniform(st + 2 * CT_PLANE + wave * 1024);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            __builtin_amdgcn_global_load_lds((gptr_t)(vsrc_h + (size_t)jt * VT_PLANE + j * 4096), (lptr_t)(ldv + j * 4096 + wave * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(vsrc_l + (size_t)jt * VT_PLANE + j * 4096), (lptr_t)(ldv + VT_PLANE + j * 4096 + wave * 1024), 16, 0, 0);
+            glds16(vsrc_h + (size_t)jt * VT_PLANE + j * 4096, dv + j * 4096);
+            glds16(vsrc_l + (size_t)jt * VT_PLANE + j * 4096, dv + VT_PLANE + j * 4096);
         }
-        // column references of this lane's keys: j = jt*64 + 32 ct + 8 q + 4 h + (0..3)
-        int cm[2][16];
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const int4 c = *reinterpret_cast<const int4*>(cref + (size_t)z * Np + jt * KT + 32 * ct + 8 * q4 + 4 * h);
-                cm[ct][4 * q4 + 0] = c.x; cm[ct][4 * q4 + 1] = c.y; cm[ct][4 * q4 + 2] = c.z; cm[ct][4 * q4 + 3] = c.w;
-            }
+    };
+    request(0);
+    for (int jt = 0; jt < ntile; ++jt) {
+        // tile jt (requested an iteration ago) has landed; after the barrier nobody reads the other stage any more
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (jt + 1 < ntile) request(jt + 1);
+        const unsigned char* const lds = lds_all + (jt & 1) * PV_STAGE;
+        const unsigned char* const ldv = lds + 2 * CT_PLANE;
+        const int* const lcr = reinterpret_cast<const int*>(ldv + CREF_ROW * 128);
 
         f32x16 acc[2];
         score_tile(acc, lds, rf, l31, h);
@@ -426,23 +433,26 @@ __global__ __launch_bounds__(256, 2) void k_pv(const _Float16* __restrict__ qh, 
             for (int u = 0; u < 2; ++u) {
                 // p for this lane's 8 keys of MFMA (ct, u): accumulator registers 8 u .. 8 u + 7
                 f16x8 ph, pl;
+                // column references of this lane's keys: j = jt*64 + 32 ct + 8 (r >> 2) + 4 h + (r & 3), r = 8 u .. 8 u + 7
+                const int4 cA = *reinterpret_cast<const int4*>(lcr + 32 * ct + 16 * u + 4 * h);
+                const int4 cB = *reinterpret_cast<const int4*>(lcr + 32 * ct + 16 * u + 8 + 4 * h);
+                const int cmv[8] = {cA.x, cA.y, cA.z, cA.w, cB.x, cB.y, cB.z, cB.w};
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) {
                     const int r = 8 * u + e;
-                    float e0 = __builtin_amdgcn_exp2f(fmaf(acc[ct][r], c1, nR));
-                    float e1 = __builtin_amdgcn_exp2f(fmaf(acc[ct][r + 1], c1, nR));
+                    const f32x2 x2 = __builtin_elementwise_fma(f32x2{acc[ct][r], acc[ct][r + 1]}, f32x2{c1, c1}, f32x2{nR, nR});
+                    float e0 = __builtin_amdgcn_exp2f(x2.x);
+                    float e1 = __builtin_amdgcn_exp2f(x2.y);
                     if (RAGGED) {                                                // zero-padded keys score 0, not -inf
                         if (jt * KT + 32 * ct + mfma32_row(r, h) >= N) e0 = 0.f;
                         if (jt * KT + 32 * ct + mfma32_row(r + 1, h) >= N) e1 = 0.f;
                     }
                     t2 += f32x2{e0, e1};
-                    const float p0 = e0 * ldexpf(e0, R - cm[ct][r] + 15);
-                    const float p1 = e1 * ldexpf(e1, R - cm[ct][r + 1] + 15);
-                    _Float16 hh, ll;
-                    split1(p0, hh, ll);
-                    ph[e] = hh; pl[e] = ll;
-                    split1(p1, hh, ll);
-                    ph[e + 1] = hh; pl[e + 1] = ll;
+                    const f32x2 p2 = f32x2{e0, e1} * f32x2{ldexpf(e0, R - cmv[e] + 15), ldexpf(e1, R - cmv[e + 1] + 15)};
+                    f16x2 h2, l2;
+                    split2(p2, h2, l2);
+                    ph[e] = h2.x; ph[e + 1] = h2.y;
+                    pl[e] = l2.x; pl[e + 1] = l2.y;
                 }
                 const int slot = 4 * ct + 2 * u + h;
 #pragma unroll
@@ -543,7 +553,10 @@ int far_emm_pv_f16s(const float* q, const float* k, const float* v, const float*
     const dim3 gstat((unsigned)(Np / 128) * Z);
     hipLaunchKernelGGL(k_rowstats, gstat, dim3(256), 0, stream, w.kh, w.kl, w.qh, w.ql, Z, N, Np, c1, w.colstat);
     hipLaunchKernelGGL(k_prep_v, dim3((unsigned)(Np / KT) * Z), dim3(256), 0, stream, v, lay, pos, w.colstat, Z, N, Np, w.vh, w.vl, w.cref);
-    hipLaunchKernelGGL(k_pv, grid, dim3(256), 0, stream, w.qh, w.ql, w.kh, w.kl, w.vh, w.vl, w.cref, Z, N, Np, c1,
+    bool cfg_failed = false;
+    FAR_ONCE_PER_DEVICE(cfg_failed = hipFuncSetAttribute((const void*)k_pv, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PV_STAGE) != hipSuccess);
+    if (cfg_failed) return far_check_launch();
+    hipLaunchKernelGGL(k_pv, grid, dim3(256), 2 * PV_STAGE, stream, w.qh, w.ql, w.kh, w.kl, w.vh, w.vl, w.cref, Z, N, Np, c1,
                        w.rowstat, T_out);
     return far_check_launch();
 }

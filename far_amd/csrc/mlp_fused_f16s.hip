@@ -48,11 +48,11 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst_unifor
 __device__ __forceinline__ void split8(const float4& u, const float4& v, float scale, f16x8& hi, f16x8& lo) {
     const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const float s = x[i] * scale;
-        const _Float16 hh = (_Float16)s;
-        hi[i] = hh;
-        lo[i] = (_Float16)(s - (float)hh);
+    for (int i = 0; i < 8; i += 2) {                       // packed conversions (common.h: split2)
+        f16x2 h, l;
+        split2(f32x2{x[i], x[i + 1]} * f32x2{scale, scale}, h, l);
+        hi[i] = h.x; hi[i + 1] = h.y;
+        lo[i] = l.x; lo[i + 1] = l.y;
     }
 }
 
@@ -175,12 +175,13 @@ __global__ __launch_bounds__(256, 2) void k_mlp128(const float* __restrict__ x, 
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                hid_chk += acc1[t][8 * u + e];                 // (ReLU's max would swallow a NaN: inf - inf of an overflowed input)
-                const float hv = fmaxf(acc1[t][8 * u + e] * hscale, 0.f);
-                const _Float16 hh = (_Float16)hv;
-                ha[u][e] = hh;
-                hl[u][e] = (_Float16)(hv - (float)hh);
+            for (int e = 0; e < 8; e += 2) {
+                hid_chk += acc1[t][8 * u + e] + acc1[t][8 * u + e + 1];       // (ReLU's max would swallow a NaN: inf - inf of an overflowed input)
+                const f32x2 hv = __builtin_elementwise_max(f32x2{acc1[t][8 * u + e], acc1[t][8 * u + e + 1]} * f32x2{hscale, hscale}, f32x2{0.f, 0.f});
+                f16x2 h2, l2;
+                split2(hv, h2, l2);
+                ha[u][e] = h2.x; ha[u][e + 1] = h2.y;
+                hl[u][e] = l2.x; hl[u][e + 1] = l2.y;
             }
         f16x8 bh[3], bl[3];
 #pragma unroll

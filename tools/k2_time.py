@@ -3,7 +3,7 @@ import ctypes, sys
 sys.path.insert(0, '.')
 import torch
 import bench
-from far_amd import _lib
+from far_amd import _lib          # FAR_HIP_LIB=far_amd/lib/libfar_hip_base.so (tools/ab_build.py) times another build
 lib = _lib.load()
 Z, L = 256, 4800
 g = torch.Generator(device='cuda').manual_seed(1)
