@@ -432,6 +432,7 @@ class _LinearF16sFn(torch.autograd.Function):
         y = linear_f16s(xc, pack())
         ctx.save_for_backward(xc, weight)
         ctx.pack_t, ctx.has_bias = pack_t, bias is not None
+        ctx.act_exp = activation_exponent_value()            # the weight gradient splits xc with the forward's exponent
         return y
 
     @staticmethod
@@ -450,7 +451,7 @@ class _LinearF16sFn(torch.autograd.Function):
         g2, x2 = g.reshape(-1, g.shape[-1]), xc.reshape(-1, xc.shape[-1])
         dw = None
         if ctx.needs_input_grad[1]:
-            dw = linear_wgrad(x2.contiguous(), g2.contiguous(), sc)
+            dw = linear_wgrad(x2.contiguous(), g2.contiguous(), sc, ctx.act_exp)
             if dw is None:
                 dw = g2.t().mm(x2)
         db = g2.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
@@ -481,6 +482,7 @@ class _ConvF16sFn(torch.autograd.Function):
         y = conv_nhwc(xin, pack())
         ctx.save_for_backward(xn, weight)
         ctx.stride, ctx.pack_d = int(stride), pack_d
+        ctx.act_exp = activation_exponent_value()            # the weight gradient splits xn with the forward's exponent
         return y.permute(0, 3, 1, 2)
 
     @staticmethod
@@ -505,17 +507,18 @@ class _ConvF16sFn(torch.autograd.Function):
                 dxn[:, ::st, ::st] = conv_nhwc(gs, ctx.pack_d(), act_scale_dev=sc)
             dx = dxn.permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
-            dw = conv_wgrad(xn, gs, ks, st, dy_scale=sc)
+            dw = conv_wgrad(xn, gs, ks, st, dy_scale=sc, act_exp=ctx.act_exp)
             if dw is None:                                                                              # shape without a kernel: vendor
                 dw = torch.ops.aten.convolution_backward(gn.permute(0, 3, 1, 2), xn.permute(0, 3, 1, 2), weight, None, [st, st],
                                                          [ks // 2, ks // 2], [1, 1], False, [0, 0], 1, [False, True, False])[1]
         return dx, dw, None, None, None
 
 
-def conv_wgrad(xn, gn, ks, stride, dy_scale=None):
+def conv_wgrad(xn, gn, ks, stride, dy_scale=None, act_exp=None):
     """K16.  dW (Cout, Cin, ks, ks) of a 'same' bias-free convolution from its NHWC input xn (N, H, W, Cin) and NHWC output
     gradient gn (N, Ho, Wo, Cout); split-fp16 operands, deterministic two-stage sum.  dy_scale = grad_scale(gn) if the caller has
-    it already.  None only on the comparison leg (USE_HIP_WGRAD False)."""
+    it already; act_exp: the activation exponent xn was consumed with in the forward (default: the current one).  None only on
+    the comparison leg (USE_HIP_WGRAD False)."""
     lib = _lib.load()
     N, H, W, Cin = xn.shape
     Cout = gn.shape[-1]
@@ -526,7 +529,8 @@ def conv_wgrad(xn, gn, ks, stride, dy_scale=None):
     nb = int(lib.far_conv_wgrad_ws_bytes(N, H, W, Cin, Cout, ks, stride))
     ws = torch.empty(nb, dtype=torch.uint8, device=xn.device)
     rc = lib.far_conv_wgrad_f16s(_p(xn, torch.float32), _p(gn, torch.float32), N, H, W, Cin, Cout, ks, stride,
-                                 activation_exponent_value(), _p(dy_scale) if dy_scale is not None else None, _p(ws), nb, _p(dw),
+                                 activation_exponent_value() if act_exp is None else int(act_exp),
+                                 _p(dy_scale) if dy_scale is not None else None, _p(ws), nb, _p(dw),
                                  overflow_flag(xn.device).data_ptr(), _stream())
     _lib.check(rc, 'far_conv_wgrad_f16s')
     return dw
@@ -535,14 +539,14 @@ def conv_wgrad(xn, gn, ks, stride, dy_scale=None):
 USE_HIP_WGRAD = True       # False: the vendor's backward-weights / GEMM (comparison leg of bench.py --workload c3 --vendor-train)
 
 
-def linear_wgrad(x2, g2, dy_scale=None):
+def linear_wgrad(x2, g2, dy_scale=None, act_exp=None):
     """K16 as a Linear layer's weight gradient: dW (N_out, K) = g2^T x2 for x2 (rows, K), g2 (rows, N_out); None -> caller's GEMM
     (comparison leg only)."""
     rows, K = x2.shape
     if not USE_HIP_WGRAD or rows == 0:
         return None
     h = rows // 32 if rows % 32 == 0 else 1                     # 1x1 kernel: any factoring of the rows into H x W is the same sum
-    return conv_wgrad(x2.reshape(1, h, rows // h, K), g2.reshape(1, h, rows // h, g2.shape[1]), 1, 1, dy_scale).reshape(g2.shape[1], K)
+    return conv_wgrad(x2.reshape(1, h, rows // h, K), g2.reshape(1, h, rows // h, g2.shape[1]), 1, 1, dy_scale, act_exp).reshape(g2.shape[1], K)
 
 
 def conv_train(x, weight, stride, cache, name, split=True):

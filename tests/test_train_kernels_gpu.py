@@ -408,3 +408,29 @@ def test_stem_train_forward_and_weight_gradient_match_float64(N, H, W, Cout):
     w.grad = None
     ops.stem_train(img, w).backward(dy)
     assert torch.equal(g1, w.grad)
+
+
+def test_weight_gradient_uses_the_forwards_activation_exponent():
+    """A layer whose forward ran under a widened activation range (ops.activation_exponent(-4): inputs to 1e5) must split the
+    same input with the same exponent in K16 -- the backward runs outside the forward's context."""
+    from far_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(5)
+    x = torch.randn(1, 128, 24, 32, device='cuda', generator=g) * 3e4            # beyond 4094: overflows the default split
+    w = (torch.randn(128, 128, 3, 3, device='cuda', generator=g) * 0.03).requires_grad_(True)
+    lin_x = torch.randn(640, 256, device='cuda', generator=g) * 3e4
+    lw = (torch.randn(256, 256, device='cuda', generator=g) * 0.05).requires_grad_(True)
+    pk = ops.PackCache()
+    with ops.activation_exponent(-4):
+        y = ops.conv_train(x, w, 1, pk, 'c')
+        z = ops.linear_train(lin_x, lw, None, pk, 'l')
+    assert torch.isfinite(y).all() and torch.isfinite(z).all()
+    dy, dz = torch.randn_like(y) * 1e-6, torch.randn_like(z) * 1e-6
+    torch.autograd.backward([y, z], [dy, dz])
+    assert not ops.activation_overflowed('cuda')
+    w64 = w.detach().double().requires_grad_(True)
+    torch.nn.functional.conv2d(x.double(), w64, padding=1).backward(dy.double())
+    ref_l = dz.double().t() @ lin_x.double()
+    ew = float((w.grad.double() - w64.grad).abs().max() / w64.grad.abs().max())
+    el = float((lw.grad.double() - ref_l).abs().max() / ref_l.abs().max())
+    print(f'[wgrad, widened range] conv dW {ew:.1e}  linear dW {el:.1e}')
+    assert ew < 5e-6 and el < 5e-6
