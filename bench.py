@@ -410,6 +410,11 @@ def bench_c3(a, dev, world, rank, dist):
     model = LoFTR(cfg['loftr'])
     synth.load_synthetic(model, seed=0)
     model = model.to(dev).train()
+    if os.environ.get('FAR_C3_PER_OP') == '1':         # A/B aid: one autograd node per operator (round-3 mid state) instead of per layer
+        from far_amd import ops as _ops_ln
+        from far_amd.loftr.transformer import LoFTREncoderLayer as _L
+        _L.layer_node = False
+        _ops_ln.USE_HIP_LAYERNORM_TRAIN = False
     if a.vendor_train:
         LoFTREncoderLayer.hip_training = False
         CrossAttention.hip_training = False
@@ -419,6 +424,7 @@ def bench_c3(a, dev, world, rank, dist):
         FinePreprocess.hip_training = False
         from far_amd import ops as _ops
         _ops.USE_HIP_WGRAD = False
+        _ops.USE_HIP_LAYERNORM_TRAIN = False
         model.coarse_matching.materialize_conf = True          # dense conf_matrix through the vendor ops + autograd
     loss_fn = LoFTRLoss(cfg).train()
     fwd = model

@@ -48,6 +48,8 @@ SIGNATURES = {
     'far_linear_attention_bwd_workspace_bytes': (c_sz, [c_i, c_i, c_i, c_i, c_i]),
     'far_linear_attention_bwd_f32': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p]),
     'far_layernorm_f32': (c_i, [c_p, c_p, c_p, c_p, c_l, c_i, c_f, c_p, c_p]),
+    'far_layernorm_bwd_ws_bytes': (c_l, [c_l, c_i]),
+    'far_layernorm_bwd_f32': (c_i, [c_p, c_p, c_p, c_l, c_i, c_f, c_p, c_p, c_p, c_p, c_l, c_p]),
     'far_attn_block_packed_bytes': (c_sz, [c_i]),
     'far_attn_block_f16s': (c_i, [c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_f, c_p, c_p, c_p]),
     'far_mlp_fused_packed_bytes': (c_sz, [c_i]),

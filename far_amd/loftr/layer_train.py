@@ -1,0 +1,100 @@
+"""One autograd node per LoFTR encoder layer for training on the GPU.
+
+`LoFTREncoderLayer.forward` under autograd (mp3d_loftr/src/loftr/loftr_module/transformer.py:44-67) is five Linear layers, the
+linear-attention core, two LayerNorms, a ReLU, a concatenation and a residual add.  As separate autograd nodes that is ~12
+Python-level nodes per layer call, each with its own engine hop, plus the elementwise kernels autograd inserts between them
+(gradient accumulation adds, the split of the concatenation's gradient, the ReLU mask) -- and the training step at batch 1 is
+bound by that host work, not by the kernels.  Here the layer is ONE node: the forward launches the same
+kernels the per-op path launches (K9, K5, K6), the backward launches their backward kernels in sequence (K6 backward, K9 dgrad,
+K16 wgrad, K5 backward) and folds what was elementwise glue into them:
+  * the residual path and the three input-gradient contributions of q / k / v projections accumulate through K9's `residual`
+    epilogue input (no add kernels);
+  * the gradient of cat([x, message]) leaves the mlp[0] dgrad launch as two output planes (no split copies);
+  * every gradient tensor gets its power-of-two scale once (far_grad_scale_f32) for both its dgrad and its wgrad launch.
+Same arithmetic as the per-op path kernel for kernel; `LoFTREncoderLayer.layer_node = False` selects that path (the tests
+compare the two).
+"""
+import torch
+
+from .. import ops
+
+
+class _EncoderLayerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, source, wq, wk, wv, wm, w0, w2, g1, b1, g2, b2, layer):
+        self_attn = source is None
+        xc = x.detach().float().contiguous()
+        sc = xc if self_attn else source.detach().float().contiguous()
+        pk = layer.__dict__.setdefault('_packs', ops.PackCache())
+        sp = layer.split_operands
+        P = lambda w, name: ops.train_pack(pk, ('train', name), w, None, sp)
+        nh = layer.nhead
+        q = ops.linear_f16s(xc, P(wq, 'q'))
+        k = ops.linear_f16s(sc, P(wk, 'k'))
+        v = ops.linear_f16s(sc, P(wv, 'v'))
+        msg0 = ops.linear_attention(q, k, v, nh, None, None, layer.attention.eps)
+        m1 = ops.linear_f16s(msg0, P(wm, 'merge'))
+        n1 = ops.layernorm(m1, g1.detach(), b1.detach(), layer.norm1.eps)
+        xcat = torch.cat([xc, n1], dim=-1)
+        h = ops.linear_f16s(xcat, P(w0, 'mlp0'), act='relu')
+        m2 = ops.linear_f16s(h, P(w2, 'mlp2'))
+        y = ops.layernorm(m2, g2.detach(), b2.detach(), layer.norm2.eps, residual=xc)
+        ctx.save_for_backward(xc, sc, q, k, v, msg0, m1, xcat, h, m2, wq, wk, wv, wm, w0, w2, g1, g2)
+        ctx.layer, ctx.self_attn, ctx.act_exp = layer, self_attn, ops.activation_exponent_value()
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xc, sc, q, k, v, msg0, m1, xcat, h, m2, wq, wk, wv, wm, w0, w2, g1, g2 = ctx.saved_tensors
+        layer, ae = ctx.layer, ctx.act_exp
+        pk = layer.__dict__.setdefault('_packs', ops.PackCache())
+        sp = layer.split_operands
+        PT = lambda w, name: ops.train_pack_t(pk, ('train', name), w, None, sp)
+        C = xc.shape[-1]
+        flat = lambda t: t.reshape(-1, t.shape[-1])
+        gy = gy.float().contiguous()
+        # norm2 (+ residual: its gradient is gy itself) and mlp[2]
+        dm2, dg2, db2 = ops.layernorm_bwd(m2, g2, gy, layer.norm2.eps)
+        s = ops.grad_scale(dm2)
+        dh = ops.linear_f16s(dm2, PT(w2, 'mlp2'), act_scale_dev=s)
+        dw2 = ops.linear_wgrad(flat(h), flat(dm2), s, ae)
+        # ReLU, mlp[0]: the gradient of cat([x, norm1(..)]) as two planes
+        dh = torch.ops.aten.threshold_backward(dh, h, 0.0)
+        s = ops.grad_scale(dh)
+        dcat = ops.linear_f16s(dh, PT(w0, 'mlp0'), out_planes=2, act_scale_dev=s)
+        dw0 = ops.linear_wgrad(flat(xcat), flat(dh), s, ae)
+        dxa = gy + dcat[0]
+        # norm1, merge
+        dm1, dg1, db1 = ops.layernorm_bwd(m1, g1, dcat[1], layer.norm1.eps)
+        s = ops.grad_scale(dm1)
+        dmsg = ops.linear_f16s(dm1, PT(wm, 'merge'), act_scale_dev=s)
+        dwm = ops.linear_wgrad(flat(msg0), flat(dm1), s, ae)
+        # attention core
+        dq, dk, dv = ops.linear_attention_bwd(q, k, v, dmsg, layer.nhead, None, None, layer.attention.eps)
+        # the three projections: input gradients accumulate through the dgrad launches' residual input
+        s = ops.grad_scale(dq)
+        dx = ops.linear_f16s(dq, PT(wq, 'q'), residual=dxa, act_scale_dev=s)
+        dwq = ops.linear_wgrad(flat(xc), flat(dq), s, ae)
+        s = ops.grad_scale(dk)
+        if ctx.self_attn:
+            dx = ops.linear_f16s(dk, PT(wk, 'k'), residual=dx, act_scale_dev=s)
+        else:
+            ds = ops.linear_f16s(dk, PT(wk, 'k'), act_scale_dev=s)
+        dwk = ops.linear_wgrad(flat(sc), flat(dk), s, ae)
+        s = ops.grad_scale(dv)
+        if ctx.self_attn:
+            dx = ops.linear_f16s(dv, PT(wv, 'v'), residual=dx, act_scale_dev=s)
+            ds = None
+        else:
+            ds = ops.linear_f16s(dv, PT(wv, 'v'), residual=ds, act_scale_dev=s)
+        dwv = ops.linear_wgrad(flat(sc), flat(dv), s, ae)
+        return dx, ds, dwq, dwk, dwv, dwm, dw0, dw2, dg1, db1, dg2, db2, None
+
+
+def encoder_layer_train(layer, x, source):
+    """LoFTREncoderLayer.forward(x, source) (no masks) with gradients as one autograd node; `source is x` = self-attention."""
+    if any(m.bias is not None for m in (layer.q_proj, layer.k_proj, layer.v_proj, layer.merge, layer.mlp[0], layer.mlp[2])):
+        raise ops._lib.FarHipError('encoder_layer_train: the FAR encoder layers have bias-free Linear layers')
+    return _EncoderLayerFn.apply(x, None if source is x else source, layer.q_proj.weight, layer.k_proj.weight, layer.v_proj.weight,
+                                 layer.merge.weight, layer.mlp[0].weight, layer.mlp[2].weight, layer.norm1.weight, layer.norm1.bias,
+                                 layer.norm2.weight, layer.norm2.bias, layer)

@@ -50,6 +50,7 @@ class LinearAttention(nn.Module):
 class LoFTREncoderLayer(nn.Module):
     split_operands = True        # K9 operand precision of the Linear layers (False: plain fp16, LoFTR.set_precision)
     hip_training = True          # training on the GPU runs K9 / K5 (forward + backward kernels); False: vendor ops + autograd
+    layer_node = True            # ... as one autograd node per layer call (layer_train.py); False: one node per operator
     fused_mlp = True             # d_model 128, split operands: the MLP block as one K13 launch (False: two K9 launches)
     fused_attn = True            # d_model 128, sequences <= 32 tokens, no masks: the attention block as one K14 launch
 
@@ -75,9 +76,14 @@ class LoFTREncoderLayer(nn.Module):
     def forward(self, x, source, x_mask=None, source_mask=None, loftr_preds=None, out=None):
         bs = x.size(0)
         if ag.needs_grad(x, source, self.norm1.weight) or not x.is_cuda:
+            if (x.is_cuda and self.hip_training and self.layer_node and x_mask is None and source_mask is None and x.numel()
+                    and source.numel() and self.dim in (16, 32) and x.shape[-1] % 4 == 0 and x.shape[-1] <= 512 and torch.is_grad_enabled()):
+                # the whole layer as ONE autograd node (layer_train.py): same kernels, no elementwise glue between them
+                from .layer_train import encoder_layer_train
+                return encoder_layer_train(self, x, source)
             if x.is_cuda and self.hip_training:
-                # training on the GPU: the five Linear layers on K9 (forward and dgrad; wgrad = one library GEMM), the
-                # attention core on K5 forward + backward; LayerNorm / ReLU / residual are torch elementwise ops
+                # training on the GPU: the five Linear layers on K9 (forward and dgrad) and K16 (wgrad), the attention core on
+                # K5 forward + backward, both LayerNorms (the second with the residual add) on K6 forward + backward
                 pk = self.__dict__.setdefault('_packs', ops.PackCache())
                 sp = self.split_operands
                 lin = lambda t, mod, name: ops.linear_train(t, mod.weight, mod.bias, pk, ('train', name), split=sp)
@@ -85,9 +91,9 @@ class LoFTREncoderLayer(nn.Module):
                 k = lin(source, self.k_proj, 'k').view(bs, -1, self.nhead, self.dim)
                 v = lin(source, self.v_proj, 'v').view(bs, -1, self.nhead, self.dim)
                 msg = self.attention(q, k, v, q_mask=x_mask, kv_mask=source_mask, loftr_preds=loftr_preds)
-                msg = self.norm1(lin(msg.view(bs, -1, self.nhead * self.dim), self.merge, 'merge'))
+                msg = ops.layernorm_train(lin(msg.view(bs, -1, self.nhead * self.dim), self.merge, 'merge'), self.norm1)
                 msg = lin(torch.relu(lin(torch.cat([x, msg], dim=2), self.mlp[0], 'mlp0')), self.mlp[2], 'mlp2')
-                return x + self.norm2(msg)
+                return ops.layernorm_train(msg, self.norm2, residual=x)          # x + norm2(msg): the add in K6's epilogue
             q = self.q_proj(x).view(bs, -1, self.nhead, self.dim)                  # CPU: reference-style modules
             k = self.k_proj(source).view(bs, -1, self.nhead, self.dim)
             v = self.v_proj(source).view(bs, -1, self.nhead, self.dim)

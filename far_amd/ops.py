@@ -398,22 +398,26 @@ class _LinearAttentionFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        lib = _lib.load()
         qc, kc, vc, qm, km = ctx.saved_tensors
-        qm = qm if ctx.has[0] else None
-        km = km if ctx.has[1] else None
-        N, L, C = qc.shape
-        S = kc.shape[1]
-        D = C // ctx.nhead
-        g = g.float().contiguous()
-        dq, dk, dv = torch.empty_like(qc), torch.empty_like(kc), torch.empty_like(vc)
-        if N:
-            ws = _ws(lib.far_linear_attention_bwd_workspace_bytes(N, L, S, ctx.nhead, D), qc.device)
-            rc = lib.far_linear_attention_bwd_f32(_p(qc), _p(kc), _p(vc), _p(g, torch.float32), N, L, S, ctx.nhead, D,
-                                                  _p(qm, torch.uint8), _p(km, torch.uint8), float(ctx.eps), _p(dq), _p(dk), _p(dv),
-                                                  _p(ws), _stream())
-            _lib.check(rc, 'far_linear_attention_bwd_f32')
+        dq, dk, dv = linear_attention_bwd(qc, kc, vc, g, ctx.nhead, qm if ctx.has[0] else None, km if ctx.has[1] else None, ctx.eps)
         return dq, dk, dv, None, None, None, None
+
+
+def linear_attention_bwd(qc, kc, vc, g, nhead, q_mask=None, kv_mask=None, eps=1e-6):
+    """K5 backward: (dq, dk, dv) of linear_attention(qc, kc, vc) for the output gradient g; all (N, L | S, C) fp32 contiguous."""
+    lib = _lib.load()
+    N, L, C = qc.shape
+    S = kc.shape[1]
+    D = C // nhead
+    g = g.float().contiguous()
+    dq, dk, dv = torch.empty_like(qc), torch.empty_like(kc), torch.empty_like(vc)
+    if N:
+        ws = _ws(lib.far_linear_attention_bwd_workspace_bytes(N, L, S, nhead, D), qc.device)
+        rc = lib.far_linear_attention_bwd_f32(_p(qc), _p(kc), _p(vc), _p(g, torch.float32), N, L, S, nhead, D,
+                                              _p(q_mask, torch.uint8), _p(kv_mask, torch.uint8), float(eps), _p(dq), _p(dk), _p(dv),
+                                              _p(ws), _stream())
+        _lib.check(rc, 'far_linear_attention_bwd_f32')
+    return dq, dk, dv
 
 
 def linear_attention_train(q, k, v, nhead, q_mask=None, kv_mask=None, eps=1e-6):
@@ -460,11 +464,20 @@ class _LinearF16sFn(torch.autograd.Function):
 
 def linear_train(x, weight, bias, cache, name, split=True):
     """K9 Linear with gradients.  cache: a PackCache; name: key prefix of this layer's forward / transposed weight images."""
-    pack = lambda: cache.get((name, split), [weight] + ([bias] if bias is not None else []),
-                             lambda: PackedConv(weight, None, bias, split=split))
-    # the transposed image reads the same tensor through strides and reuses the forward image's scale (same maximum)
-    pack_t = lambda: cache.get((name, 'T', split), [weight], lambda: PackedConv(weight, split=split, dgrad=True, pack_scale=pack().pack_scale))
+    pack = lambda: train_pack(cache, name, weight, bias, split)
+    pack_t = lambda: train_pack_t(cache, name, weight, bias, split)
     return _LinearF16sFn.apply(x, weight, bias, pack, pack_t)
+
+
+def train_pack(cache, name, weight, bias=None, split=True):
+    """The K9 image of a Linear layer's weight for the training forward (re-packed when the weight's version changes)."""
+    return cache.get((name, split), [weight] + ([bias] if bias is not None else []), lambda: PackedConv(weight, None, bias, split=split))
+
+
+def train_pack_t(cache, name, weight, bias=None, split=True):
+    """The transposed image (dgrad): the same tensor read through strides, with the forward image's scale (same maximum)."""
+    return cache.get((name, 'T', split), [weight],
+                     lambda: PackedConv(weight, split=split, dgrad=True, pack_scale=train_pack(cache, name, weight, bias, split).pack_scale))
 
 
 class _ConvF16sFn(torch.autograd.Function):
@@ -658,6 +671,60 @@ def layernorm(x, weight, bias, eps=1e-5, residual=None, out=None):
                                _p(residual, torch.float32), rows, C, float(eps), _p(y), _stream())
     _lib.check(rc, 'far_layernorm_f32')
     return y if out is None else _written(y)
+
+
+class _LayerNormFn(torch.autograd.Function):
+    """nn.LayerNorm over the last dimension (+ residual) with gradients (transformer.py:61, 65-67 under autograd): K6 forward,
+    far_layernorm_bwd_f32 backward (dx; dgamma / dbeta summed in a fixed order).  The residual's gradient is dy itself."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, residual):
+        xc = x.detach().float().contiguous()
+        r = None if residual is None else residual.detach().float().contiguous()
+        y = layernorm(xc, weight.detach(), bias.detach(), eps, residual=r)
+        ctx.save_for_backward(xc, weight)
+        ctx.eps, ctx.has_res = float(eps), residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        xc, weight = ctx.saved_tensors
+        g = g.float().contiguous()
+        dx, dg, db = layernorm_bwd(xc, weight, g, ctx.eps)
+        return dx, dg, db, None, (g if ctx.has_res else None)
+
+
+def layernorm_bwd(xc, weight, g, eps):
+    """K6 backward: (dx, dgamma, dbeta) of LayerNorm(xc; eps) * weight + bias over the last dimension for the output gradient g
+    (fp32 contiguous, C % 4 == 0, C <= 1024)."""
+    lib = _lib.load()
+    C = xc.shape[-1]
+    rows = xc.numel() // C
+    nb = int(lib.far_layernorm_bwd_ws_bytes(rows, C))
+    if nb == 0:
+        raise _lib.FarHipError(f'layernorm_bwd: {C} channels not covered (C % 4 == 0, C <= 1024)')
+    ws = torch.empty(nb, dtype=torch.uint8, device=xc.device)
+    dx = torch.empty_like(xc)
+    dgb = torch.empty(2, C, dtype=torch.float32, device=xc.device)
+    rc = lib.far_layernorm_bwd_f32(_p(xc, torch.float32), _p(weight.detach().contiguous(), torch.float32), _p(g, torch.float32), rows, C,
+                                   float(eps), _p(dx), _p(dgb[0]), _p(dgb[1]), _p(ws), nb, _stream())
+    _lib.check(rc, 'far_layernorm_bwd_f32')
+    return dx, dgb[0], dgb[1]
+
+
+USE_HIP_LAYERNORM_TRAIN = True      # False: nn.LayerNorm under autograd (comparison leg of bench.py --workload c3 --vendor-train)
+
+
+def layernorm_train(x, norm, residual=None):
+    """K6 with gradients: norm(x) (+ residual) for an nn.LayerNorm over the last dimension of a GPU tensor; shapes the backward
+    kernel does not cover (C % 4 != 0 or C > 1024) use the module itself."""
+    C = x.shape[-1]
+    if not x.is_cuda:
+        raise _lib.FarHipError('far_amd ops need tensors on the GPU (no CPU fallback exists)')
+    if (C & 3) or C > 1024 or norm.weight is None or norm.bias is None or x.numel() == 0 or not USE_HIP_LAYERNORM_TRAIN:
+        y = norm(x)
+        return y if residual is None else y + residual
+    return _LayerNormFn.apply(x, norm.weight, norm.bias, norm.eps, residual)
 
 
 def _layout(t):

@@ -226,6 +226,13 @@ int far_linear_attention_bwd_f32(const float* q, const float* k, const float* v,
 /* y[r][:] = LayerNorm(x[r][:]; eps) * gamma + beta (+ res[r][:] when res != NULL).  x, res, y [rows][C] fp32. */
 int far_layernorm_f32(const float* x, const float* gamma, const float* beta, const float* res, long rows, int C,
                       float eps, float* y, far_stream_t stream);
+/* Backward of the same normalisation (autograd of nn.LayerNorm at transformer.py:61, 65-67, training): dx [rows][C],
+ * dgamma [C], dbeta [C] from x, gamma, dy; the statistics are recomputed as the forward forms them, dgamma / dbeta are summed
+ * in a fixed order (deterministic).  C % 4 == 0, C <= 1024 (far_layernorm_bwd_ws_bytes() = 0 otherwise); ws: that many bytes of
+ * device scratch.  A fused residual needs nothing here: its gradient is dy itself. */
+long far_layernorm_bwd_ws_bytes(long rows, int C);
+int far_layernorm_bwd_f32(const float* x, const float* gamma, const float* dy, long rows, int C, float eps, float* dx,
+                          float* dgamma, float* dbeta, void* ws, long ws_bytes, far_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * K13  the MLP block of a LoFTR encoder layer at d_model = 128 (the fine-level transformer) in one launch

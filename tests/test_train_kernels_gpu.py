@@ -434,3 +434,79 @@ def test_weight_gradient_uses_the_forwards_activation_exponent():
     el = float((lw.grad.double() - ref_l).abs().max() / ref_l.abs().max())
     print(f'[wgrad, widened range] conv dW {ew:.1e}  linear dW {el:.1e}')
     assert ew < 5e-6 and el < 5e-6
+
+
+@pytest.mark.parametrize('shape,res', [((2, 4800, 256), True), ((3, 25, 128), False), ((1, 777, 512), True), ((5, 1024), False), ((7, 3, 196), True)])
+def test_layernorm_train_matches_float64(shape, res):
+    """K6 forward + far_layernorm_bwd_f32 (dx, dgamma, dbeta; residual gradient = dy) against float64 autograd of
+    F.layer_norm; deterministic parameter gradients."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from far_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(sum(shape))
+    C = shape[-1]
+    x = (torch.randn(shape, device='cuda', generator=g) * 2 + 0.3).requires_grad_(True)
+    r = torch.randn(shape, device='cuda', generator=g).requires_grad_(True) if res else None
+    norm = nn.LayerNorm(C).cuda()
+    with torch.no_grad():
+        norm.weight.copy_(torch.rand(C, device='cuda', generator=g) + 0.5)
+        norm.bias.copy_(torch.randn(C, device='cuda', generator=g) * 0.2)
+    y = ops.layernorm_train(x, norm, residual=r)
+    dy = torch.randn(shape, device='cuda', generator=g) * 1e-3
+    y.backward(dy)
+    x64 = x.detach().double().requires_grad_(True)
+    w64, b64 = norm.weight.detach().double().requires_grad_(True), norm.bias.detach().double().requires_grad_(True)
+    y64 = F.layer_norm(x64, (C,), w64, b64, norm.eps)
+    if res:
+        y64 = y64 + r.detach().double()
+    y64.backward(dy.double())
+    rel = lambda a, b: float((a.double() - b).abs().max() / b.abs().max())
+    e = (rel(y, y64.detach()), rel(x.grad, x64.grad), rel(norm.weight.grad, w64.grad), rel(norm.bias.grad, b64.grad))
+    print(f'[ln train] {shape}: y {e[0]:.1e}  dx {e[1]:.1e}  dgamma {e[2]:.1e}  dbeta {e[3]:.1e}')
+    assert max(e) < 5e-6
+    if res:
+        assert torch.equal(r.grad, dy)
+    gw = norm.weight.grad.clone()
+    norm.weight.grad = None
+    x.grad = None
+    ops.layernorm_train(x, norm, residual=r).backward(dy)
+    assert torch.equal(gw, norm.weight.grad)
+
+
+@pytest.mark.parametrize('d_model,tokens,self_attn', [(256, 4800, True), (256, 4800, False), (128, 25, True), (128, 25, False)])
+def test_encoder_layer_node_equals_per_operator_path(d_model, tokens, self_attn):
+    """The one-node-per-layer training path (loftr/layer_train.py) against the one-node-per-operator path (layer_node = False):
+    the same kernels, so the output is bit-identical; gradients differ only by the order input-gradient contributions are
+    added in; and against the vendor-op modules (hip_training = False)."""
+    from far_amd.loftr.transformer import LoFTREncoderLayer
+    torch.manual_seed(d_model + tokens)
+    layer = LoFTREncoderLayer(d_model, 8).cuda().train()
+    for p in layer.parameters():
+        if p.dim() > 1:
+            torch.nn.init.xavier_uniform_(p)
+    bs = 2 if tokens > 100 else 300
+    x0 = torch.randn(bs, tokens, d_model, device='cuda')
+    s0 = torch.randn(bs, tokens, d_model, device='cuda')
+    g = torch.randn(bs, tokens, d_model, device='cuda') * 1e-4
+    res = {}
+    for mode in ('node', 'ops', 'vendor'):
+        layer.hip_training, layer.layer_node = mode != 'vendor', mode == 'node'
+        layer.zero_grad()
+        x, s = x0.clone().requires_grad_(True), s0.clone().requires_grad_(True)
+        y = layer(x, x if self_attn else s)
+        y.backward(g)
+        res[mode] = (y.detach(), x.grad, None if self_attn else s.grad, {k: p.grad.clone() for k, p in layer.named_parameters()})
+    layer.hip_training, layer.layer_node = True, True
+    assert torch.equal(res['node'][0], res['ops'][0])
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    worst = 0.0
+    # (against the vendor-op modules the bar is loose: a hidden unit whose pre-activation is within rounding of zero -- 1e-7 in
+    #  the case traced -- gets a different ReLU mask in the two forwards, and one such unit with a large upstream gradient moves
+    #  every gradient behind it by ~1e-3; each kernel call of the path is within 3e-7 of a float64 evaluation of its own inputs.
+    #  test_encoder_layer_training_on_hip_matches_vendor_autograd holds the 1e-5 bar on a seed without such a unit.)
+    for other, bar in (('ops', 2e-6), ('vendor', 5e-3)):
+        errs = [rel(res['node'][1], res[other][1])] + ([] if self_attn else [rel(res['node'][2], res[other][2])])
+        errs += [rel(res['node'][3][k], res[other][3][k]) for k in res[other][3]]
+        print(f'[layer node] d{d_model} x {tokens} {"self" if self_attn else "cross"} vs {other}: worst gradient deviation {max(errs):.2e}')
+        assert max(errs) < bar, (other, errs)
+        worst = max(worst, max(errs))
