@@ -60,6 +60,7 @@ SIGNATURES = {
     'far_conv_pack_f32': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     'far_weight_scale_f32': (c_i, [c_p, c_l, c_p, c_p]),
     'far_conv_pack_view_f32': (c_i, [c_p, c_l, c_l, c_l, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),
+    'far_conv_pack_view_scaled_f32': (c_i, [c_p, c_l, c_l, c_l, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
     'far_conv_pack_auto_f32': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),
     'far_grad_scale_f32': (c_i, [c_p, c_l, c_p, c_p]),
     'far_conv_nhwc_f32': (c_i, [c_p, c_p]),                  # (const far_conv_desc*, stream): see ConvDesc

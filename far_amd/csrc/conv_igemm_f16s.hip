@@ -954,8 +954,13 @@ __global__ void k_pack_scale(float* __restrict__ s) {
 //  taps reversed, w_base pointing at the last tap: no flipped / transposed copy is ever made)
 __global__ void k_conv_pack(const float* __restrict__ w, long s_co, long s_ci, long s_tap, int Cin, int Cout, int taps, int nchunks,
                             int nblkY, int NT, int planes, float wmul, const float* __restrict__ wmul_dev,
-                            _Float16* __restrict__ out) {
+                            _Float16* __restrict__ out, const float* __restrict__ base_scale = nullptr,
+                            float* __restrict__ scale_vec = nullptr) {
     if (wmul_dev) wmul = *wmul_dev;                      // the scale chosen on the device (far_conv_pack_auto_f32)
+    // the epilogue's scale vector of this image, written here too: base_scale[co] (1 without) x 2^-(w_exp + 4) -- a training step
+    // re-packs every weight, and two more launches per weight (ones, multiply) are what this saves
+    if (scale_vec && blockIdx.x == 0)
+        for (int co = threadIdx.x; co < Cout; co += blockDim.x) scale_vec[co] = (base_scale ? base_scale[co] : 1.0f) * wmul_dev[1];
     const long total = (long)taps * nchunks * 2 * nblkY * NT * 2;
     if (blockIdx.x == 0 && threadIdx.x < 16) out[(size_t)total * 8 * planes + threadIdx.x] = (_Float16)0.f;   // the zero row
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -1037,6 +1042,9 @@ extern "C" {
 int far_weight_scale_f32(const float* w, long n, float* scale_out, hipStream_t stream);
 int far_conv_pack_view_f32(const float* w, long s_co, long s_ci, long s_tap, int Cin, int Cout, int ksize, int stride, int split,
                            const float* scale_in, void* packed, hipStream_t stream);
+int far_conv_pack_view_scaled_f32(const float* w, long s_co, long s_ci, long s_tap, int Cin, int Cout, int ksize, int stride, int split,
+                                  const float* scale_in, void* packed, const float* base_scale, float* scale_vec_out,
+                                  hipStream_t stream);
 
 // Bytes of the packed weight image for a [Cout][Cin][ksize][ksize] weight (split = 1: hi + lo planes).
 size_t far_conv_packed_bytes(int Cin, int Cout, int ksize, int stride, int split) {
@@ -1080,12 +1088,23 @@ int far_weight_scale_f32(const float* w, long n, float* scale_out, hipStream_t s
 // swapped, taps reversed -- with Cin / Cout exchanged; a transposed Linear weight is (1, K, 0).  No copy of w is made.
 int far_conv_pack_view_f32(const float* w, long s_co, long s_ci, long s_tap, int Cin, int Cout, int ksize, int stride, int split,
                            const float* scale_in, void* packed, hipStream_t stream) {
+    return far_conv_pack_view_scaled_f32(w, s_co, s_ci, s_tap, Cin, Cout, ksize, stride, split, scale_in, packed, nullptr, nullptr, stream);
+}
+
+// The same, also writing the launch's epilogue scale vector: scale_vec_out[co] = base_scale[co] (1 when NULL) * scale_in[1], the
+// vector far_conv_nhwc_f32 takes as `scale` (scale_vec_out may be NULL: then exactly far_conv_pack_view_f32).
+int far_conv_pack_view_scaled_f32(const float* w, long s_co, long s_ci, long s_tap, int Cin, int Cout, int ksize, int stride, int split,
+                                  const float* scale_in, void* packed, const float* base_scale, float* scale_vec_out,
+                                  hipStream_t stream) {
     far_clear_errors();
     if (!w || !packed || !scale_in || far_conv_packed_bytes(Cin, Cout, ksize, stride, split) == 0) return FAR_EINVAL;
     const int NT = cfg_for(Cout, stride).nt;
     const int nchunks = (Cin + 31) / 32, nblkY = (Cout + NT - 1) / NT;
-    hipLaunchKernelGGL(k_conv_pack, dim3(512), dim3(256), 0, stream, w, s_co, s_ci, s_tap, Cin, Cout, ksize * ksize, nchunks, nblkY, NT,
-                       split ? 2 : 1, 1.0f, scale_in, (_Float16*)packed);
+    const long items = (long)ksize * ksize * nchunks * 2 * nblkY * NT * 2;
+    long blocks = (items + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks);
+    hipLaunchKernelGGL(k_conv_pack, dim3((unsigned)blocks), dim3(256), 0, stream, w, s_co, s_ci, s_tap, Cin, Cout, ksize * ksize, nchunks, nblkY, NT,
+                       split ? 2 : 1, 1.0f, scale_in, (_Float16*)packed, base_scale, scale_vec_out);
     return far_check_launch();
 }
 

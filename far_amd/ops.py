@@ -471,13 +471,15 @@ def linear_train(x, weight, bias, cache, name, split=True):
 
 def train_pack(cache, name, weight, bias=None, split=True):
     """The K9 image of a Linear layer's weight for the training forward (re-packed when the weight's version changes)."""
-    return cache.get((name, split), [weight] + ([bias] if bias is not None else []), lambda: PackedConv(weight, None, bias, split=split))
+    return cache.get((name, split), [weight] + ([bias] if bias is not None else []), lambda: PackedConv(weight, None, bias, split=split),
+                     refresh=(lambda pc: pc.refresh(weight)) if bias is None else None)
 
 
 def train_pack_t(cache, name, weight, bias=None, split=True):
     """The transposed image (dgrad): the same tensor read through strides, with the forward image's scale (same maximum)."""
-    return cache.get((name, 'T', split), [weight],
-                     lambda: PackedConv(weight, split=split, dgrad=True, pack_scale=train_pack(cache, name, weight, bias, split).pack_scale))
+    fwd = train_pack(cache, name, weight, bias, split)             # first: the transposed image borrows its (refreshed) scale
+    return cache.get((name, 'T', split), [weight], lambda: PackedConv(weight, split=split, dgrad=True, pack_scale=fwd.pack_scale),
+                     refresh=lambda pc: pc.refresh(weight))
 
 
 class _ConvF16sFn(torch.autograd.Function):
@@ -567,9 +569,10 @@ def conv_train(x, weight, stride, cache, name, split=True):
     if not x.is_cuda:
         raise _lib.FarHipError('far_amd ops need tensors on the GPU (no CPU fallback exists)')
     ks = int(weight.shape[-1])
-    pack = lambda: cache.get((name, 'fwd', split), [weight], lambda: PackedConv(weight, split=split, stride=stride if ks == 3 else 1))
-    pack_d = lambda: cache.get((name, 'dgrad', split), [weight],
-                               lambda: PackedConv(weight, split=split, dgrad=True, pack_scale=pack().pack_scale))
+    re = lambda pc: pc.refresh(weight)                 # after an optimizer step: same buffers, one launch (the forward image first:
+    pack = lambda: cache.get((name, 'fwd', split), [weight], lambda: PackedConv(weight, split=split, stride=stride if ks == 3 else 1), refresh=re)
+    pack_d = lambda: cache.get((name, 'dgrad', split), [weight],   # the dgrad image borrows its scale; the forward ran before the backward)
+                               lambda: PackedConv(weight, split=split, dgrad=True, pack_scale=pack().pack_scale), refresh=re)
     return _ConvF16sFn.apply(x, weight, int(stride), pack, pack_d)
 
 
@@ -879,17 +882,36 @@ class PackedConv:
         self.packed = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
         # the power-of-two weight scale 2^w_exp (max |w| 2^w_exp in [2^13, 2^14)) is chosen on the device: no host read of the
         # weights, so re-packing after every optimizer step costs two small launches and no synchronisation
-        if pack_scale is None:
-            pack_scale = torch.empty(2, dtype=torch.float32, device=w.device)          # { 2^w_exp, 2^-(w_exp + 4) }
-            _lib.check(lib.far_weight_scale_f32(_p(w, torch.float32), w.numel(), _p(pack_scale), _stream()), 'far_weight_scale_f32')
-        self.pack_scale = pack_scale
-        rc = lib.far_conv_pack_view_f32(ctypes.c_void_p(w.data_ptr() + 4 * view[3]), view[0], view[1], view[2], Cin, Cout, kh, stride,
-                                        int(self.split), _p(pack_scale), _p(self.packed), _stream())
-        _lib.check(rc, 'far_conv_pack_view_f32')
-        self._w = w                                               # keeps the (possibly temporary) contiguous weight alive until the pack ran
-        s = torch.ones(Cout, device=w.device) if scale is None else scale.detach().float()
-        self.scale = (s * self.pack_scale[1]).contiguous()        # power-of-two factor: exact
+        self._own_scale = pack_scale is None
+        self.pack_scale = torch.empty(2, dtype=torch.float32, device=w.device) if pack_scale is None else pack_scale   # { 2^w_exp, 2^-(w_exp + 4) }
+        self._view, self._wshape = view, tuple(w.shape)
+        self._base = None if scale is None else scale.detach().float().contiguous()
+        self.scale = torch.empty(Cout, dtype=torch.float32, device=w.device)      # base scale x 2^-(w_exp + 4), written by the pack kernel
         self.shift = None if shift is None else shift.detach().float().contiguous()
+        self._pack(w)
+
+    def _pack(self, w):
+        lib = _lib.load()
+        if self._own_scale:
+            _lib.check(lib.far_weight_scale_f32(_p(w, torch.float32), w.numel(), _p(self.pack_scale), _stream()), 'far_weight_scale_f32')
+        v = self._view
+        rc = lib.far_conv_pack_view_scaled_f32(ctypes.c_void_p(w.data_ptr() + 4 * v[3]), v[0], v[1], v[2], self.Cin, self.Cout, self.ksize,
+                                               self.stride, int(self.split), _p(self.pack_scale), _p(self.packed),
+                                               _p(self._base) if self._base is not None else None, _p(self.scale), _stream())
+        _lib.check(rc, 'far_conv_pack_view_scaled_f32')
+        self._w = w                                               # keeps the (possibly temporary) contiguous weight alive until the pack ran
+
+    def refresh(self, weight):
+        """Re-pack in place after the weight changed (an optimizer step): the same buffers, one launch (+ the scale reduction when
+        this image owns it; an image that borrows another's pack_scale must be refreshed after that one).  Epilogue scale / shift
+        vectors passed at construction are kept as they were."""
+        w = weight.detach()
+        if w.dim() == 2:
+            w = w[:, :, None, None]
+        if tuple(w.shape) != self._wshape or w.dtype != torch.float32 or not w.is_contiguous() or w.device != self.packed.device:
+            raise _lib.FarHipError('PackedConv.refresh: the weight changed shape, dtype, layout or device')
+        self._pack(w)
+        return self
 
 
 class PackedMlp:
@@ -1020,11 +1042,14 @@ class PackCache:
     def __init__(self):
         self._store = {}
 
-    def get(self, key, tensors, build):
+    def get(self, key, tensors, build, refresh=None):
+        """refresh(obj): optional in-place update of the stored object when only tensor versions changed (same storage): a
+        training step re-packs every weight, and reusing the buffers saves the allocations and two launches per image."""
         stamp = tuple((t.data_ptr(), tensor_version(t)) for t in tensors)
         hit = self._store.get(key)
         if hit is None or hit[0] != stamp:
-            hit = (stamp, build())
+            same_storage = hit is not None and refresh is not None and tuple(p for p, _ in hit[0]) == tuple(p for p, _ in stamp)
+            hit = (stamp, refresh(hit[1]) if same_storage else build())
             self._store[key] = hit
         return hit[1]
 

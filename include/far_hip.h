@@ -300,6 +300,11 @@ int far_conv_pack_f32(const float* w, int Cin, int Cout, int ksize, int stride, 
 int far_weight_scale_f32(const float* w, long n, float* scale_out, far_stream_t stream);
 int far_conv_pack_view_f32(const float* w, long s_co, long s_ci, long s_tap, int Cin, int Cout, int ksize, int stride, int split,
                            const float* scale_in, void* packed, far_stream_t stream);
+/* ... and the launch's epilogue scale vector in the same kernel: scale_vec_out[co] = base_scale[co] (1 when NULL) * scale_in[1],
+ * what far_conv_nhwc_f32 takes as `scale` (a training step re-packs every weight after every optimizer update). */
+int far_conv_pack_view_scaled_f32(const float* w, long s_co, long s_ci, long s_tap, int Cin, int Cout, int ksize, int stride, int split,
+                                  const float* scale_in, void* packed, const float* base_scale, float* scale_vec_out,
+                                  far_stream_t stream);
 /* The same with w_exp chosen on the device from max|w| (no host read: training re-packs every layer after every optimizer
  * step): scale_out (2 device floats) = { 2^w_exp, 2^-(w_exp + 4) }; the caller multiplies its `scale` vector by scale_out[1]. */
 int far_conv_pack_auto_f32(const float* w, int Cin, int Cout, int ksize, int stride, int split, void* packed, float* scale_out,
