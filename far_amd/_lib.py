@@ -60,6 +60,9 @@ SIGNATURES = {
     'far_conv_pack_f32': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     'far_weight_scale_f32': (c_i, [c_p, c_l, c_p, c_p]),
     'far_conv_pack_view_f32': (c_i, [c_p, c_l, c_l, c_l, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),
+    'far_pack_table_bytes': (c_l, [c_i]),
+    'far_pack_table_build': (c_i, [c_p, c_i, c_p, c_p]),
+    'far_pack_table_run': (c_i, [c_p, c_i, c_p]),
     'far_conv_pack_view_scaled_f32': (c_i, [c_p, c_l, c_l, c_l, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
     'far_conv_pack_auto_f32': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),
     'far_grad_scale_f32': (c_i, [c_p, c_l, c_p, c_p]),
@@ -100,6 +103,14 @@ class ConvDesc(ctypes.Structure):
                                             'out_planes', 'res_group')] + \
                [('slope', ctypes.c_float), ('ln_eps', ctypes.c_float), ('act_exp', ctypes.c_int), ('overflow', ctypes.c_void_p),
                 ('act_scale_dev', ctypes.c_void_p)]
+
+
+class PackItem(ctypes.Structure):
+    """far_pack_item of include/far_hip.h (field order and types must match)."""
+    _fields_ = [('w', ctypes.c_void_p), ('s_co', ctypes.c_long), ('s_ci', ctypes.c_long), ('s_tap', ctypes.c_long)] + \
+               [(n, ctypes.c_int) for n in ('Cin', 'Cout', 'ksize', 'stride', 'split', 'scale_owner')] + \
+               [('w_all', ctypes.c_void_p), ('n_all', ctypes.c_long), ('pack_scale', ctypes.c_void_p), ('packed', ctypes.c_void_p),
+                ('base_scale', ctypes.c_void_p), ('scale_vec', ctypes.c_void_p)]
 
 
 _lib = None

@@ -46,6 +46,7 @@
 // the part sustains under this load, tools/k9_timing.py) including the fused epilogue, against 100-125 TFLOP/s for
 // the vendor fp32 Winograd convolution alone.
 #include "common.h"
+#include <vector>
 #include <type_traits>
 
 namespace {
@@ -987,6 +988,80 @@ __global__ void k_conv_pack(const float* __restrict__ w, long s_co, long s_ci, l
     }
 }
 
+// ---- the weight images of a whole model, re-packed after an optimizer step in TWO launches (far_pack_table_run): a table row
+// per image; k_pack_table_scales reduces max|w| of every row that owns its scale (ticketed like k_amax_scale_multi, a slot
+// per row), k_pack_table_images is k_conv_pack over blockIdx.y = row.
+struct PackRow {
+    const float* w;            // element of tap 0 in execution order
+    long s_co, s_ci, s_tap;
+    int Cin, Cout, taps, nchunks, nblkY, NT, planes, owns_scale;
+    const float* w_all;        // the whole weight tensor (scale owners)
+    long n_all;
+    float* pack_scale;         // { 2^w_exp, 2^-(w_exp + 4) }
+    _Float16* out;
+    const float* base_scale;   // or null
+    float* scale_vec;          // or null
+};
+__device__ AmaxSlot g_pack_slots[4096];
+
+__global__ __launch_bounds__(256) void k_pack_table_scales(const PackRow* __restrict__ rows) {
+    const PackRow r = rows[blockIdx.y];
+    if (!r.owns_scale) return;
+    __shared__ unsigned part[256];
+    unsigned m = 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < r.n_all; i += (long)gridDim.x * 256) {
+        const unsigned b = __float_as_uint(fabsf(r.w_all[i]));
+        m = b > m ? b : m;
+    }
+    part[threadIdx.x] = m;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d && part[threadIdx.x + d] > part[threadIdx.x]) part[threadIdx.x] = part[threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        AmaxSlot* const sl = g_pack_slots + (blockIdx.y & 4095);
+        atomicMax(&sl->max_bits, part[0]);
+        __threadfence();
+        if (atomicAdd(&sl->ticket, 1u) == gridDim.x - 1) {
+            __threadfence();
+            const unsigned bits = atomicExch(&sl->max_bits, 0u);
+            atomicExch(&sl->ticket, 0u);
+            write_scales<0>(__uint_as_float(bits), r.pack_scale);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pack_table_images(const PackRow* __restrict__ rows) {
+    const PackRow r = rows[blockIdx.y];
+    const float wmul = r.pack_scale[0];
+    if (r.scale_vec && blockIdx.x == 0)
+        for (int co = threadIdx.x; co < r.Cout; co += 256) r.scale_vec[co] = (r.base_scale ? r.base_scale[co] : 1.0f) * r.pack_scale[1];
+    const long total = (long)r.taps * r.nchunks * 2 * r.nblkY * r.NT * 2;
+    if (blockIdx.x == 0 && threadIdx.x < 16) r.out[(size_t)total * 8 * r.planes + threadIdx.x] = (_Float16)0.f;   // the zero row
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        long t = i;
+        const int s = (int)(t & 1); t >>= 1;
+        const int nn = (int)(t % r.NT); t /= r.NT;
+        const int by = (int)(t % r.nblkY); t /= r.nblkY;
+        const int ks = (int)(t & 1); t >>= 1;
+        const int tap = (int)(t % r.taps);
+        const int chunk = (int)(t / r.taps);
+        const int n = by * r.NT + nn;
+        const size_t row = r.planes == 2 ? ((((size_t)(chunk * r.taps + tap) * 2 + ks) * r.nblkY + by) * 2) * r.NT + nn
+                                         : ((((size_t)(chunk * r.taps + tap) * r.nblkY + by) * 2 + ks)) * r.NT + nn;
+        _Float16* dst = r.out + row * 16 + ((s ^ ((nn >> 3) & 1)) * 8);
+        for (int e = 0; e < 8; ++e) {
+            const int ch = 32 * chunk + 16 * ks + 8 * s + e;
+            float v = 0.f;
+            if (n < r.Cout && ch < r.Cin) v = r.w[(long)n * r.s_co + (long)ch * r.s_ci + (long)tap * r.s_tap] * wmul;
+            const _Float16 hh = (_Float16)v;
+            dst[e] = hh;
+            if (r.planes == 2) dst[(size_t)r.NT * 16 + e] = (_Float16)(v - (float)hh);
+        }
+    }
+}
+
 // Tile configuration by output width: up to 128 channels -> 256 pixels x 128 channels (4 x 1 waves), wider ->
 // 128 pixels x 256 channels per block (2 x 2 waves); every wave owns 64 pixels x 128 channels.  (Measured on
 // MI355X: 8-wave workgroups of the same wave tile and 64-channel wave tiles were equal or slower.)
@@ -1233,6 +1308,57 @@ int far_conv_nhwc_f32(const far_conv_desc* desc, hipStream_t stream) {
     if (stride == 2) return split ? launch_stride2<true>(a, grid, stream) : launch_stride2<false>(a, grid, stream);
     if (ksize == 3) return split ? launch_cfg<3, true>(c, a, grid, stream) : launch_cfg<3, false>(c, a, grid, stream);
     return split ? launch_cfg<1, true>(c, a, grid, stream, small) : launch_cfg<1, false>(c, a, grid, stream, small);
+}
+
+// ---- every weight image of a model in two launches (training: all weights change at every optimizer step).
+// far_pack_item (include/far_hip.h) describes one image as far_conv_pack_view_scaled_f32's arguments do; scale_owner = the
+// index of the item whose max|w| reduction this image uses (its own index: it reduces w_all[0 .. n_all) itself; a dgrad /
+// transposed image names its forward image and shares that item's pack_scale pointer).
+struct far_pack_item {          // mirrors include/far_hip.h
+    const float* w;
+    long s_co, s_ci, s_tap;
+    int Cin, Cout, ksize, stride, split, scale_owner;
+    const float* w_all;
+    long n_all;
+    float* pack_scale;
+    void* packed;
+    const float* base_scale;
+    float* scale_vec;
+};
+long far_pack_table_bytes(int n) { return n > 0 ? (long)n * (long)sizeof(PackRow) : 0; }
+
+int far_pack_table_build(const far_pack_item* items, int n, void* table_dev, hipStream_t stream) {
+    far_clear_errors();
+    if (!items || !table_dev || n <= 0 || n > 4096) return FAR_EINVAL;
+    std::vector<PackRow> rows((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        const far_pack_item& it = items[i];
+        if (!it.w || !it.packed || !it.pack_scale || it.scale_owner < 0 || it.scale_owner >= n ||
+            far_conv_packed_bytes(it.Cin, it.Cout, it.ksize, it.stride, it.split) == 0)
+            return FAR_EINVAL;
+        const bool owns = it.scale_owner == i;
+        if (owns ? (!it.w_all || it.n_all <= 0) : (items[it.scale_owner].pack_scale != it.pack_scale)) return FAR_EINVAL;
+        PackRow& r = rows[(size_t)i];
+        const int NT = cfg_for(it.Cout, it.stride).nt;
+        r.w = it.w; r.s_co = it.s_co; r.s_ci = it.s_ci; r.s_tap = it.s_tap;
+        r.Cin = it.Cin; r.Cout = it.Cout; r.taps = it.ksize * it.ksize; r.nchunks = (it.Cin + 31) / 32; r.nblkY = (it.Cout + NT - 1) / NT;
+        r.NT = NT; r.planes = it.split ? 2 : 1; r.owns_scale = owns ? 1 : 0;
+        r.w_all = it.w_all; r.n_all = it.n_all; r.pack_scale = it.pack_scale; r.out = (_Float16*)it.packed;
+        r.base_scale = it.base_scale; r.scale_vec = it.scale_vec;
+    }
+    // (the copy is from pageable host memory: the runtime stages it before returning, `rows` may die afterwards)
+    if (hipMemcpyAsync(table_dev, rows.data(), rows.size() * sizeof(PackRow), hipMemcpyHostToDevice, stream) != hipSuccess)
+        return far_check_launch();
+    return FAR_OK;
+}
+
+int far_pack_table_run(const void* table_dev, int n, hipStream_t stream) {
+    far_clear_errors();
+    if (!table_dev || n <= 0 || n > 4096) return FAR_EINVAL;
+    const PackRow* rows = reinterpret_cast<const PackRow*>(table_dev);
+    hipLaunchKernelGGL(k_pack_table_scales, dim3(16, (unsigned)n), dim3(256), 0, stream, rows);
+    hipLaunchKernelGGL(k_pack_table_images, dim3(32, (unsigned)n), dim3(256), 0, stream, rows);
+    return far_check_launch();
 }
 
 #ifdef FAR_K9_TIMING

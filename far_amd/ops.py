@@ -1035,6 +1035,89 @@ def attn_block(x, source, pack, nhead, gamma, beta, ln_eps, attn_eps=1e-6, out=N
     return y if out is None else _written(y)
 
 
+class _PackTable:
+    """Every refreshable weight image of the process (training: PackedConv objects whose cache entry depends on the weight
+    alone), re-packed together after an optimizer step: far_pack_table_run = two launches for all of them instead of two per
+    image.  Entries are weak: an image lives as long as the PackCache of its module does."""
+
+    def __init__(self):
+        self.entries = []          # (weakref(cache), key, weakref(weight), weakref(pc))
+        self.table = None          # (device table tensor, n, [entry indices], device) built from the live entries
+        self.dirty = True
+
+    def register(self, cache, key, weight, pc):
+        import weakref
+        self.entries.append((weakref.ref(cache), key, weakref.ref(weight), weakref.ref(pc)))
+        self.dirty = True
+
+    def _live(self):
+        out = []
+        for e in self.entries:
+            cache, w, pc = e[0](), e[2](), e[3]()
+            if cache is not None and w is not None and pc is not None and cache._store.get(e[1], (None, None))[1] is pc:
+                out.append((cache, e[1], w, pc))
+        return out
+
+    def _build(self, live):
+        lib = _lib.load()
+        dev = live[0][3].packed.device
+        live = [e for e in live if e[3].packed.device == dev and e[2].is_contiguous() and e[2].dtype == torch.float32]
+        owner = {}
+        for i, (_, _, _, pc) in enumerate(live):
+            if pc._own_scale:
+                owner[pc.pack_scale.data_ptr()] = i
+        keep = [e for e in live if e[3].pack_scale.data_ptr() in owner]
+        owner = {pc.pack_scale.data_ptr(): i for i, (_, _, _, pc) in enumerate(keep) if pc._own_scale}
+        keep = [e for e in keep if e[3].pack_scale.data_ptr() in owner]          # (a borrower whose owner dropped out goes too)
+        n = len(keep)
+        if n == 0 or n > 4096:
+            return None
+        items = (_lib.PackItem * n)()
+        for i, (_, _, w, pc) in enumerate(keep):
+            v, it = pc._view, items[i]
+            it.w, it.s_co, it.s_ci, it.s_tap = w.data_ptr() + 4 * v[3], v[0], v[1], v[2]
+            it.Cin, it.Cout, it.ksize, it.stride, it.split = pc.Cin, pc.Cout, pc.ksize, pc.stride, int(pc.split)
+            it.scale_owner = owner[pc.pack_scale.data_ptr()]
+            it.w_all, it.n_all = w.data_ptr(), w.numel()
+            it.pack_scale, it.packed = pc.pack_scale.data_ptr(), pc.packed.data_ptr()
+            it.base_scale = pc._base.data_ptr() if pc._base is not None else None
+            it.scale_vec = pc.scale.data_ptr()
+        table = torch.empty(int(lib.far_pack_table_bytes(n)), dtype=torch.uint8, device=dev)
+        _lib.check(lib.far_pack_table_build(ctypes.cast(items, ctypes.c_void_p), n, _p(table), _stream()), 'far_pack_table_build')
+        return table, n, keep
+
+    def refresh_all(self):
+        """Re-packs every live image whose weight version changed, through the table when most of them did.  Returns True when
+        the table ran (the caller's entry is then fresh)."""
+        if self.dirty:
+            live = self._live()
+            self.entries = [e for e in self.entries if e[0]() is not None and e[3]() is not None]
+            self.table = self._build(live) if live else None
+            self.dirty = False
+        if self.table is None:
+            return False
+        table, n, keep = self.table
+        stamps, stale = [], 0
+        for cache, key, w, pc in keep:
+            st = ((w.data_ptr(), tensor_version(w)),)
+            stamps.append(st)
+            hit = cache._store.get(key)
+            if hit is None or hit[1] is not pc or hit[0][0][0] != st[0][0]:
+                self.dirty = True                       # an entry was replaced or its weight moved: rebuild next time, per-entry now
+                return False
+            stale += hit[0] != st
+        if 2 * stale < n:
+            return False                                # a few images only (fine-tuning a sub-module): per-entry refresh
+        _lib.check(_lib.load().far_pack_table_run(_p(table), n, _stream()), 'far_pack_table_run')
+        for (cache, key, w, pc), st in zip(keep, stamps):
+            cache._store[key] = (st, pc)
+        return True
+
+
+PACK_TABLE = _PackTable()
+USE_PACK_TABLE = True       # False: every stale image re-packs itself (two launches each)
+
+
 class PackCache:
     """K9 weight images keyed by name, rebuilt when any tensor they were derived from changes (in-place update,
     load_state_dict, optimizer step: data_ptr / _version stamp)."""
@@ -1049,8 +1132,15 @@ class PackCache:
         hit = self._store.get(key)
         if hit is None or hit[0] != stamp:
             same_storage = hit is not None and refresh is not None and tuple(p for p, _ in hit[0]) == tuple(p for p, _ in stamp)
-            hit = (stamp, refresh(hit[1]) if same_storage else build())
+            if same_storage and USE_PACK_TABLE and len(tensors) == 1 and isinstance(hit[1], PackedConv) and PACK_TABLE.refresh_all():
+                hit = self._store[key]                   # the whole model's images were re-packed together
+                if hit[0] == stamp:
+                    return hit[1]
+            new = refresh(hit[1]) if same_storage else build()
+            hit = (stamp, new)
             self._store[key] = hit
+            if refresh is not None and not same_storage and len(tensors) == 1 and isinstance(new, PackedConv):
+                PACK_TABLE.register(self, key, tensors[0], new)
         return hit[1]
 
 

@@ -309,6 +309,25 @@ int far_conv_pack_view_scaled_f32(const float* w, long s_co, long s_ci, long s_t
  * step): scale_out (2 device floats) = { 2^w_exp, 2^-(w_exp + 4) }; the caller multiplies its `scale` vector by scale_out[1]. */
 int far_conv_pack_auto_f32(const float* w, int Cin, int Cout, int ksize, int stride, int split, void* packed, float* scale_out,
                            far_stream_t stream);
+/* Every weight image of a model in two launches (training: all weights change at every optimizer step).  One far_pack_item per
+ * image, with far_conv_pack_view_scaled_f32's meaning; scale_owner = index of the item whose max|w| reduction this image uses (its
+ * own index: it reduces w_all[0 .. n_all) into pack_scale; a dgrad / transposed image names its forward image and passes the same
+ * pack_scale pointer).  far_pack_table_build writes the device table (far_pack_table_bytes(n) bytes) once; far_pack_table_run
+ * re-packs all n images from the weights' current values.  n <= 4096. */
+typedef struct far_pack_item {
+    const float* w;
+    long s_co, s_ci, s_tap;
+    int Cin, Cout, ksize, stride, split, scale_owner;
+    const float* w_all;
+    long n_all;
+    float* pack_scale;
+    void* packed;
+    const float* base_scale;
+    float* scale_vec;
+} far_pack_item;
+long far_pack_table_bytes(int n);
+int far_pack_table_build(const far_pack_item* items, int n, void* table_dev, far_stream_t stream);
+int far_pack_table_run(const void* table_dev, int n, far_stream_t stream);
 
 /* One K9 launch.  y = LN?( act(scale[co] * conv(X, W)[.., co] + shift[co] (+ res)) ) (+ post_res):
  *   X = x [N][H][W][Cin1] or, with x2 != NULL, the channel concatenation [x | x2] (x2 [N][H][W][Cin - Cin1],

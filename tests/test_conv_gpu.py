@@ -466,3 +466,58 @@ def test_linear_half_height_tiles_equal_full_height(rows, K, Co):
     for a, bb in zip(small, full):
         assert torch.equal(a, bb)
     assert _rel(small[0], x.double() @ w.double().t())[0] < 4e-6
+
+
+def test_pack_table_repacks_every_training_image_like_a_fresh_pack():
+    """After an optimizer-style in-place update of ALL weights the first stale lookup re-packs every registered training image in
+    two launches (ops.PACK_TABLE -> far_pack_table_run); the images, their scales and the epilogue scale vectors must equal
+    freshly built ones bit for bit, for forward and dgrad / transposed images, 1x1, 3x3 and stride 2.  A partial update (one
+    weight) takes the per-image path and gives the same."""
+    ops = _ops()
+    g = torch.Generator(device='cuda').manual_seed(3)
+    ws = {'lin': torch.randn(256, 128, device='cuda', generator=g) * 0.05, 'c3': torch.randn(196, 128, 3, 3, device='cuda', generator=g) * 0.03,
+          'c3s2': torch.randn(256, 196, 3, 3, device='cuda', generator=g) * 0.02, 'c1': torch.randn(196, 256, 1, 1, device='cuda', generator=g)}
+    for w in ws.values():
+        w.requires_grad_(True)
+    cache = ops.PackCache()
+
+    def images():
+        out = {'lin': ops.train_pack(cache, 'lin', ws['lin']), 'linT': ops.train_pack_t(cache, 'lin', ws['lin'])}
+        for name, st in (('c3', 1), ('c3s2', 2), ('c1', 1)):
+            x = torch.randn(1, ws[name].shape[1], 16, 16, device='cuda', generator=g).requires_grad_(True)
+            ops.conv_train(x, ws[name], st, cache, name).sum().backward()           # forward + dgrad images get (re)built
+            out[name] = cache.get((name, 'fwd', True), [ws[name]], None)
+            out[name + 'd'] = cache.get((name, 'dgrad', True), [ws[name]], None)
+        return out
+
+    def fresh():
+        f = {'lin': ops.PackedConv(ws['lin']), 'c3': ops.PackedConv(ws['c3']), 'c3s2': ops.PackedConv(ws['c3s2'], stride=2), 'c1': ops.PackedConv(ws['c1'])}
+        f['linT'] = ops.PackedConv(ws['lin'], dgrad=True, pack_scale=f['lin'].pack_scale)
+        for n in ('c3', 'c3s2', 'c1'):
+            f[n + 'd'] = ops.PackedConv(ws[n], dgrad=True, pack_scale=f[n].pack_scale)
+        return f
+
+    def same(a, b):
+        for k in b:
+            assert torch.equal(a[k].packed, b[k].packed) and torch.equal(a[k].pack_scale, b[k].pack_scale) and torch.equal(a[k].scale, b[k].scale), k
+
+    first = images()
+    same(first, fresh())
+    ptrs = {k: v.packed.data_ptr() for k, v in first.items()}
+    with torch.no_grad():
+        for i, w in enumerate(ws.values()):
+            w.mul_(1.7 + i).add_(0.01)                       # "optimizer step": every weight changes in place
+    second = images()
+    assert all(second[k] is first[k] and second[k].packed.data_ptr() == ptrs[k] for k in first)       # same objects, same buffers
+    same(second, fresh())
+    with torch.no_grad():
+        ws['c3'].mul_(0.5)                                   # one weight only: per-image refresh
+    same(images(), fresh())
+    ops.USE_PACK_TABLE = False
+    try:
+        with torch.no_grad():
+            for w in ws.values():
+                w.mul_(1.1)
+        same(images(), fresh())
+    finally:
+        ops.USE_PACK_TABLE = True
