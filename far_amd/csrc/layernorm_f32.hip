@@ -207,29 +207,31 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ x, con
     }
 }
 
-// dgamma | dbeta [c] = sum over the workgroups' partials, in a fixed order: four strided quarter sums per channel (b = g, g + 4, ...)
-// by four threads, then ((q0 + q1) + q2) + q3.  64 channels per workgroup.
-__global__ __launch_bounds__(256) void k_ln_bwd_reduce(const float* __restrict__ part, int nblocks, int C, float* __restrict__ dgamma,
-                                                       float* __restrict__ dbeta) {
-    __shared__ float q[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+// dgamma | dbeta [c] = sum over the workgroups' partials, in a fixed order: sixteen strided sums per channel (b = g, g + 16, ...)
+// by sixteen threads, then added in g order.  64 channels per workgroup of 1024 threads.
+__global__ __launch_bounds__(1024) void k_ln_bwd_reduce(const float* __restrict__ part, int nblocks, int C, float* __restrict__ dgamma,
+                                                        float* __restrict__ dbeta) {
+    __shared__ float q[16][64];
+    const int l = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + l;
     float s = 0.f;
     if (c < 2 * C) {
         const int which = c >= C, cc = c - which * C;
-        for (int b = grp; b < nblocks; b += 4) s += part[((size_t)b * 2 + which) * C + cc];
+        for (int b = grp; b < nblocks; b += 16) s += part[((size_t)b * 2 + which) * C + cc];
     }
-    q[grp][threadIdx.x & 63] = s;
+    q[grp][l] = s;
     __syncthreads();
     if (grp == 0 && c < 2 * C) {
-        const int l = threadIdx.x;
-        const float t = ((q[0][l] + q[1][l]) + q[2][l]) + q[3][l];
+        float t = q[0][l];
+#pragma unroll
+        for (int g = 1; g < 16; ++g) t += q[g][l];
         if (c >= C) dbeta[c - C] = t; else dgamma[c] = t;
     }
 }
 
 inline int ln_bwd_blocks(long rows) {
-    long b = (rows + 15) / 16;                                 // >= 4 rows per wave
-    return (int)(b < 1 ? 1 : (b > 128 ? 128 : b));             // few partials: the reduction reads nblocks x 2C floats
+    long b = (rows + 7) / 8;                                   // >= 2 rows per wave: enough waves to cover the load latency
+    return (int)(b < 1 ? 1 : (b > 512 ? 512 : b));             // <= 512 partials: the reduction reads nblocks x 2C floats
 }
 
 }  // namespace
@@ -255,7 +257,7 @@ int far_layernorm_bwd_f32(const float* x, const float* gamma, const float* dy, l
     if (C <= 256) hipLaunchKernelGGL(k_ln_bwd<1>, dim3(nb), dim3(256), 0, stream, x, gamma, dy, rows, C, eps, dx, part);
     else if (C <= 512) hipLaunchKernelGGL(k_ln_bwd<2>, dim3(nb), dim3(256), 0, stream, x, gamma, dy, rows, C, eps, dx, part);
     else hipLaunchKernelGGL(k_ln_bwd<4>, dim3(nb), dim3(256), 0, stream, x, gamma, dy, rows, C, eps, dx, part);
-    hipLaunchKernelGGL(k_ln_bwd_reduce, dim3((unsigned)((2 * C + 63) / 64)), dim3(256), 0, stream, part, nb, C, dgamma, dbeta);
+    hipLaunchKernelGGL(k_ln_bwd_reduce, dim3((unsigned)((2 * C + 63) / 64)), dim3(1024), 0, stream, part, nb, C, dgamma, dbeta);
     return far_check_launch();
 }
 

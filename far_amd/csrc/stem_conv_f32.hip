@@ -152,20 +152,29 @@ __global__ __launch_bounds__(256) void k_stem_wgrad(const float* __restrict__ im
             for (int r = 0; r < 16; ++r) slab[(32 * ct + mfma32_row(r, h)) * 64 + 32 * tt + l31] = acc[ct][tt][r];
 }
 
-__global__ void k_stem_wgrad_reduce(const float* __restrict__ part, int slabs, int C, float* __restrict__ dw) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // over [C][64]
-    if (i >= C * 64) return;
-    const int co = i >> 6, tap = i & 63;
-    if (tap >= 49) return;
+// dw[co][tap] = sum over the slabs, in a fixed order: sixteen strided sums per element by sixteen threads, added in group order
+__global__ __launch_bounds__(1024) void k_stem_wgrad_reduce(const float* __restrict__ part, int slabs, int C, float* __restrict__ dw) {
+    __shared__ float q[16][64];
+    const int l = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + l;                               // over [C][64]
     float s = 0.f;
-    for (int k = 0; k < slabs; ++k) s += part[(size_t)k * C * 64 + i];
-    dw[co * 49 + tap] = s;
+    if (i < C * 64)
+        for (int k = grp; k < slabs; k += 16) s += part[(size_t)k * C * 64 + i];
+    q[grp][l] = s;
+    __syncthreads();
+    if (grp == 0 && i < C * 64) {
+        float t = q[0][l];
+#pragma unroll
+        for (int g = 1; g < 16; ++g) t += q[g][l];
+        const int co = i >> 6, tap = i & 63;
+        if (tap < 49) dw[co * 49 + tap] = t;
+    }
 }
 
 int stem_wgrad_wgs(int N, int Ho, int Wo, int* tiles_per_wg, long* ntiles) {
     const int tilesX = (Wo + SC - 1) / SC, tilesY = (Ho + SR - 1) / SR;
     *ntiles = (long)N * tilesX * tilesY;
-    long per = (*ntiles + 511) / 512;
+    long per = (*ntiles + 255) / 256;                            // <= 256 workgroups = 1024 slabs of [Cout][64]
     if (per < 1) per = 1;
     *tiles_per_wg = (int)per;
     return (int)((*ntiles + per - 1) / per);
@@ -222,7 +231,7 @@ int far_stem7x7_wgrad_f32(const float* img, const float* dy, int N, int H, int W
         hipLaunchKernelGGL(k_stem_wgrad<4>, dim3((unsigned)wgs), dim3(256), 0, stream, img, dy, N, H, W, Ho, Wo, tilesX, tilesY, per, nt, part);
     else
         hipLaunchKernelGGL(k_stem_wgrad<2>, dim3((unsigned)wgs), dim3(256), 0, stream, img, dy, N, H, W, Ho, Wo, tilesX, tilesY, per, nt, part);
-    hipLaunchKernelGGL(k_stem_wgrad_reduce, dim3((unsigned)((Cout * 64 + 255) / 256)), dim3(256), 0, stream, part, wgs * 4, Cout, dw);
+    hipLaunchKernelGGL(k_stem_wgrad_reduce, dim3((unsigned)(Cout)), dim3(1024), 0, stream, part, wgs * 4, Cout, dw);
     return far_check_launch();
 }
 
