@@ -410,6 +410,9 @@ def bench_c3(a, dev, world, rank, dist):
     model = LoFTR(cfg['loftr'])
     synth.load_synthetic(model, seed=0)
     model = model.to(dev).train()
+    if os.environ.get('FAR_C3_NO_OVERLAP') == '1':     # A/B aid: the layer node without side streams
+        from far_amd.loftr.transformer import LoFTREncoderLayer as _L2
+        _L2.overlap = False
     if os.environ.get('FAR_C3_PER_OP') == '1':         # A/B aid: one autograd node per operator (round-3 mid state) instead of per layer
         from far_amd import ops as _ops_ln
         from far_amd.loftr.transformer import LoFTREncoderLayer as _L

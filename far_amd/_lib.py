@@ -60,6 +60,8 @@ SIGNATURES = {
     'far_conv_pack_f32': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     'far_weight_scale_f32': (c_i, [c_p, c_l, c_p, c_p]),
     'far_conv_pack_view_f32': (c_i, [c_p, c_l, c_l, c_l, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),
+    'far_stream_fork': (c_p, [c_p, c_i]),
+    'far_stream_join': (c_i, [c_p, c_i]),
     'far_pack_table_bytes': (c_l, [c_i]),
     'far_pack_table_build': (c_i, [c_p, c_i, c_p, c_p]),
     'far_pack_table_run': (c_i, [c_p, c_i, c_p]),

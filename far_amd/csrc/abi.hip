@@ -19,3 +19,50 @@ extern "C" int far_set_tuning(int key, int value) {
     return FAR_OK;
 }
 int far_get_tuning(int key) { return (key >= 0 && key < 8) ? g_tuning[key].load(std::memory_order_relaxed) : 0; }
+
+// ---- side streams: launches that do not depend on each other (the weight gradient of a layer next to its input gradient; the
+// q, k, v projections of a layer) overlap when they are issued on different streams, and at batch 1 each of them fills a
+// fraction of the CUs.  The library keeps FAR_SIDE_STREAMS non-blocking streams per device, created on first use.
+//   far_stream_fork(main, i): side stream i waits for everything issued on `main` so far; returns the side stream.
+//   far_stream_join(main, i): `main` waits for everything issued on side stream i so far.
+// Buffers used on a side stream must stay allocated until the join (the caller's allocator knows only `main`).
+#define FAR_SIDE_STREAMS 4
+namespace {
+struct SideStreams {
+    hipStream_t s[FAR_SIDE_STREAMS];
+    hipEvent_t fork[FAR_SIDE_STREAMS], join[FAR_SIDE_STREAMS];
+    std::atomic<int> ready{0};
+};
+SideStreams g_side[64];
+SideStreams* side_streams() {
+    SideStreams& d = g_side[far_current_device()];
+    if (d.ready.load(std::memory_order_acquire) == 2) return &d;
+    int expect = 0;
+    if (d.ready.compare_exchange_strong(expect, 1)) {
+        bool ok = true;
+        for (int i = 0; i < FAR_SIDE_STREAMS; ++i) {
+            ok = ok && hipStreamCreateWithFlags(&d.s[i], hipStreamNonBlocking) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&d.fork[i], hipEventDisableTiming) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&d.join[i], hipEventDisableTiming) == hipSuccess;
+        }
+        d.ready.store(ok ? 2 : 0, std::memory_order_release);
+        return ok ? &d : nullptr;
+    }
+    while (d.ready.load(std::memory_order_acquire) == 1) {}
+    return d.ready.load(std::memory_order_acquire) == 2 ? &d : nullptr;
+}
+}  // namespace
+
+extern "C" void* far_stream_fork(hipStream_t main, int i) {
+    SideStreams* d = side_streams();
+    if (!d || i < 0 || i >= FAR_SIDE_STREAMS) return nullptr;
+    if (hipEventRecord(d->fork[i], main) != hipSuccess || hipStreamWaitEvent(d->s[i], d->fork[i], 0) != hipSuccess) return nullptr;
+    return (void*)d->s[i];
+}
+
+extern "C" int far_stream_join(hipStream_t main, int i) {
+    SideStreams* d = side_streams();
+    if (!d || i < 0 || i >= FAR_SIDE_STREAMS) return FAR_EINVAL;
+    if (hipEventRecord(d->join[i], d->s[i]) != hipSuccess || hipStreamWaitEvent(main, d->join[i], 0) != hipSuccess) return far_check_launch();
+    return FAR_OK;
+}

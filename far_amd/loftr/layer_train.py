@@ -29,9 +29,18 @@ class _EncoderLayerFn(torch.autograd.Function):
         sp = layer.split_operands
         P = lambda w, name: ops.train_pack(pk, ('train', name), w, None, sp)
         nh = layer.nhead
-        q = ops.linear_f16s(xc, P(wq, 'q'))
-        k = ops.linear_f16s(sc, P(wk, 'k'))
-        v = ops.linear_f16s(sc, P(wv, 'v'))
+        # the three projections are independent and each fills a fraction of the CUs: k and v on side streams
+        Pq, Pk, Pv = P(wq, 'q'), P(wk, 'k'), P(wv, 'v')
+        if layer.overlap:
+            with ops.side(0):
+                k = ops.linear_f16s(sc, Pk)
+            with ops.side(1):
+                v = ops.linear_f16s(sc, Pv)
+            q = ops.linear_f16s(xc, Pq)
+            ops.join(0)
+            ops.join(1)
+        else:
+            q, k, v = ops.linear_f16s(xc, Pq), ops.linear_f16s(sc, Pk), ops.linear_f16s(sc, Pv)
         msg0 = ops.linear_attention(q, k, v, nh, None, None, layer.attention.eps)
         m1 = ops.linear_f16s(msg0, P(wm, 'merge'))
         n1 = ops.layernorm(m1, g1.detach(), b1.detach(), layer.norm1.eps)
@@ -53,41 +62,48 @@ class _EncoderLayerFn(torch.autograd.Function):
         C = xc.shape[-1]
         flat = lambda t: t.reshape(-1, t.shape[-1])
         gy = gy.float().contiguous()
+        # Every weight gradient (K16 + its reduction: ~25 us on a fraction of the CUs) goes to side stream 0 and overlaps with the
+        # chain of input-gradient launches on the main stream; `keep` holds what the side launches touch until the join.
+        keep = []
+        ov = layer.overlap
+
+        def wgrad(xin, dy, s):
+            if not ov:
+                return ops.linear_wgrad(flat(xin), flat(dy), s, ae)
+            with ops.side(0):
+                return ops.linear_wgrad(flat(xin), flat(dy), s, ae, keep)
         # norm2 (+ residual: its gradient is gy itself) and mlp[2]
         dm2, dg2, db2 = ops.layernorm_bwd(m2, g2, gy, layer.norm2.eps)
-        s = ops.grad_scale(dm2)
-        dh = ops.linear_f16s(dm2, PT(w2, 'mlp2'), act_scale_dev=s)
-        dw2 = ops.linear_wgrad(flat(h), flat(dm2), s, ae)
+        s2 = ops.grad_scale(dm2)
+        dw2 = wgrad(h, dm2, s2)
+        dh = ops.linear_f16s(dm2, PT(w2, 'mlp2'), act_scale_dev=s2)
         # ReLU, mlp[0]: the gradient of cat([x, norm1(..)]) as two planes
         dh = torch.ops.aten.threshold_backward(dh, h, 0.0)
-        s = ops.grad_scale(dh)
-        dcat = ops.linear_f16s(dh, PT(w0, 'mlp0'), out_planes=2, act_scale_dev=s)
-        dw0 = ops.linear_wgrad(flat(xcat), flat(dh), s, ae)
+        s0 = ops.grad_scale(dh)
+        dw0 = wgrad(xcat, dh, s0)
+        dcat = ops.linear_f16s(dh, PT(w0, 'mlp0'), out_planes=2, act_scale_dev=s0)
         dxa = gy + dcat[0]
         # norm1, merge
         dm1, dg1, db1 = ops.layernorm_bwd(m1, g1, dcat[1], layer.norm1.eps)
-        s = ops.grad_scale(dm1)
-        dmsg = ops.linear_f16s(dm1, PT(wm, 'merge'), act_scale_dev=s)
-        dwm = ops.linear_wgrad(flat(msg0), flat(dm1), s, ae)
+        sm = ops.grad_scale(dm1)
+        dwm = wgrad(msg0, dm1, sm)
+        dmsg = ops.linear_f16s(dm1, PT(wm, 'merge'), act_scale_dev=sm)
         # attention core
         dq, dk, dv = ops.linear_attention_bwd(q, k, v, dmsg, layer.nhead, None, None, layer.attention.eps)
         # the three projections: input gradients accumulate through the dgrad launches' residual input
-        s = ops.grad_scale(dq)
-        dx = ops.linear_f16s(dq, PT(wq, 'q'), residual=dxa, act_scale_dev=s)
-        dwq = ops.linear_wgrad(flat(xc), flat(dq), s, ae)
-        s = ops.grad_scale(dk)
+        sq, sk, sv = ops.grad_scale(dq), ops.grad_scale(dk), ops.grad_scale(dv)
+        dwq, dwk, dwv = wgrad(xc, dq, sq), wgrad(sc, dk, sk), wgrad(sc, dv, sv)
+        dx = ops.linear_f16s(dq, PT(wq, 'q'), residual=dxa, act_scale_dev=sq)
         if ctx.self_attn:
-            dx = ops.linear_f16s(dk, PT(wk, 'k'), residual=dx, act_scale_dev=s)
-        else:
-            ds = ops.linear_f16s(dk, PT(wk, 'k'), act_scale_dev=s)
-        dwk = ops.linear_wgrad(flat(sc), flat(dk), s, ae)
-        s = ops.grad_scale(dv)
-        if ctx.self_attn:
-            dx = ops.linear_f16s(dv, PT(wv, 'v'), residual=dx, act_scale_dev=s)
+            dx = ops.linear_f16s(dk, PT(wk, 'k'), residual=dx, act_scale_dev=sk)
+            dx = ops.linear_f16s(dv, PT(wv, 'v'), residual=dx, act_scale_dev=sv)
             ds = None
         else:
-            ds = ops.linear_f16s(dv, PT(wv, 'v'), residual=ds, act_scale_dev=s)
-        dwv = ops.linear_wgrad(flat(sc), flat(dv), s, ae)
+            ds = ops.linear_f16s(dk, PT(wk, 'k'), act_scale_dev=sk)
+            ds = ops.linear_f16s(dv, PT(wv, 'v'), residual=ds, act_scale_dev=sv)
+        if ov:
+            ops.join(0)
+        del keep
         return dx, ds, dwq, dwk, dwv, dwm, dw0, dw2, dg1, db1, dg2, db2, None
 
 

@@ -51,6 +51,7 @@ class LoFTREncoderLayer(nn.Module):
     split_operands = True        # K9 operand precision of the Linear layers (False: plain fp16, LoFTR.set_precision)
     hip_training = True          # training on the GPU runs K9 / K5 (forward + backward kernels); False: vendor ops + autograd
     layer_node = True            # ... as one autograd node per layer call (layer_train.py); False: one node per operator
+    overlap = True               # layer node: weight gradients and the k / v projections on the library's side streams
     fused_mlp = True             # d_model 128, split operands: the MLP block as one K13 launch (False: two K9 launches)
     fused_attn = True            # d_model 128, sequences <= 32 tokens, no masks: the attention block as one K14 launch
 

@@ -11,8 +11,38 @@ import torch
 from . import _lib
 
 
+_TLS = threading.local()          # .side: the library side stream this thread's launches currently go to (ops.side), or absent
+
+
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    s = getattr(_TLS, 'side', None)
+    return s if s is not None else ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class side:
+    """`with ops.side(i):` -- the launches inside go to the library's side stream i, which first waits for everything the
+    current torch stream holds (far_stream_fork); they overlap with what the caller launches afterwards until ops.join(i).
+    torch's allocator knows only the current stream, so every tensor the side launches touch must outlive the join: locals of
+    the caller do; temporaries of the ops called inside are appended to a `keep` list by those ops (their `keep=` argument)."""
+
+    def __init__(self, i):
+        self.i = i
+
+    def __enter__(self):
+        h = _lib.load().far_stream_fork(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), self.i)
+        if not h:
+            raise _lib.FarHipError('far_stream_fork failed')
+        self.prev = getattr(_TLS, 'side', None)
+        _TLS.side = ctypes.c_void_p(h)
+
+    def __exit__(self, *exc):
+        _TLS.side = self.prev
+        return False
+
+
+def join(i):
+    """The current torch stream waits for side stream i (far_stream_join)."""
+    _lib.check(_lib.load().far_stream_join(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), i), 'far_stream_join')
 
 
 def _p(t, dtype=None):
@@ -529,7 +559,7 @@ class _ConvF16sFn(torch.autograd.Function):
         return dx, dw, None, None, None
 
 
-def conv_wgrad(xn, gn, ks, stride, dy_scale=None, act_exp=None):
+def conv_wgrad(xn, gn, ks, stride, dy_scale=None, act_exp=None, keep=None):
     """K16.  dW (Cout, Cin, ks, ks) of a 'same' bias-free convolution from its NHWC input xn (N, H, W, Cin) and NHWC output
     gradient gn (N, Ho, Wo, Cout); split-fp16 operands, deterministic two-stage sum.  dy_scale = grad_scale(gn) if the caller has
     it already; act_exp: the activation exponent xn was consumed with in the forward (default: the current one).  None only on
@@ -548,20 +578,22 @@ def conv_wgrad(xn, gn, ks, stride, dy_scale=None, act_exp=None):
                                  _p(dy_scale) if dy_scale is not None else None, _p(ws), nb, _p(dw),
                                  overflow_flag(xn.device).data_ptr(), _stream())
     _lib.check(rc, 'far_conv_wgrad_f16s')
+    if keep is not None:
+        keep += [ws, xn, gn]                     # launched on a side stream: alive until the caller's join
     return dw
 
 
 USE_HIP_WGRAD = True       # False: the vendor's backward-weights / GEMM (comparison leg of bench.py --workload c3 --vendor-train)
 
 
-def linear_wgrad(x2, g2, dy_scale=None, act_exp=None):
+def linear_wgrad(x2, g2, dy_scale=None, act_exp=None, keep=None):
     """K16 as a Linear layer's weight gradient: dW (N_out, K) = g2^T x2 for x2 (rows, K), g2 (rows, N_out); None -> caller's GEMM
     (comparison leg only)."""
     rows, K = x2.shape
     if not USE_HIP_WGRAD or rows == 0:
         return None
     h = rows // 32 if rows % 32 == 0 else 1                     # 1x1 kernel: any factoring of the rows into H x W is the same sum
-    return conv_wgrad(x2.reshape(1, h, rows // h, K), g2.reshape(1, h, rows // h, g2.shape[1]), 1, 1, dy_scale, act_exp).reshape(g2.shape[1], K)
+    return conv_wgrad(x2.reshape(1, h, rows // h, K), g2.reshape(1, h, rows // h, g2.shape[1]), 1, 1, dy_scale, act_exp, keep).reshape(g2.shape[1], K)
 
 
 def conv_train(x, weight, stride, cache, name, split=True):

@@ -35,6 +35,14 @@ int far_last_hip_error(void);
  * wave-slot issue-priority staggering (1 k_stats, 2 k_match, 4 k_emm_pv). */
 int far_set_tuning(int key, int value);
 
+/* Side streams (FAR_SIDE_STREAMS = 4 per device, created on first use): independent launches of a batch-1 training step -- a
+ * layer's weight gradient next to its input gradient, its q / k / v projections -- each fill a fraction of the CUs and overlap
+ * when issued on different streams.  far_stream_fork(main, i): side stream i waits for what `main` holds so far; returns the
+ * stream to launch on (NULL on failure).  far_stream_join(main, i): `main` waits for side stream i.  Buffers used on a side
+ * stream must stay allocated until the join. */
+void* far_stream_fork(far_stream_t main, int i);
+int far_stream_join(far_stream_t main, int i);
+
 /* Measurement aid (no reference counterpart): the f16 matrix-pipe rate this part SUSTAINS under dense
  * v_mfma_f32_32x32x16_f16 issue with the register / LDS footprint of K9 / K1 / K2 (2 x 4 accumulator tiles per wave,
  * 4 waves per workgroup, 2 workgroups per CU), pseudo-random operands.  mode 0: operands in registers; mode 1: the six
