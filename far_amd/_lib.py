@@ -60,6 +60,13 @@ SIGNATURES = {
     'far_conv_pack_f32': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     'far_weight_scale_f32': (c_i, [c_p, c_l, c_p, c_p]),
     'far_conv_pack_view_f32': (c_i, [c_p, c_l, c_l, c_l, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),
+    'far_enc_layer_saved_floats': (c_l, [c_p]),
+    'far_enc_layer_grads_floats': (c_l, [c_p]),
+    'far_enc_layer_fwd_ws_bytes': (c_l, [c_p]),
+    'far_enc_layer_bwd_ws_bytes': (c_l, [c_p]),
+    'far_enc_layer_grads_offsets': (c_i, [c_p, c_p]),
+    'far_enc_layer_fwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_p]),
+    'far_enc_layer_bwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_p]),
     'far_stream_fork': (c_p, [c_p, c_i]),
     'far_stream_join': (c_i, [c_p, c_i]),
     'far_pack_table_bytes': (c_l, [c_i]),
@@ -113,6 +120,15 @@ class PackItem(ctypes.Structure):
                [(n, ctypes.c_int) for n in ('Cin', 'Cout', 'ksize', 'stride', 'split', 'scale_owner')] + \
                [('w_all', ctypes.c_void_p), ('n_all', ctypes.c_long), ('pack_scale', ctypes.c_void_p), ('packed', ctypes.c_void_p),
                 ('base_scale', ctypes.c_void_p), ('scale_vec', ctypes.c_void_p)]
+
+
+class EncLayer(ctypes.Structure):
+    """far_enc_layer of include/far_hip.h (field order and types must match)."""
+    _fields_ = [('bs', ctypes.c_long), ('L', ctypes.c_long), ('S', ctypes.c_long)] + \
+               [(n, ctypes.c_int) for n in ('C', 'nhead', 'self_attn', 'split', 'act_exp', 'overlap')] + \
+               [(n, ctypes.c_float) for n in ('eps1', 'eps2', 'attn_eps')] + \
+               [('img', ctypes.c_void_p * 6), ('img_scale', ctypes.c_void_p * 6), ('imgT', ctypes.c_void_p * 6), ('imgT_scale', ctypes.c_void_p * 6)] + \
+               [(n, ctypes.c_void_p) for n in ('g1', 'b1', 'g2', 'b2', 'overflow')]
 
 
 _lib = None

@@ -14,6 +14,8 @@ K16 wgrad, K5 backward) and folds what was elementwise glue into them:
 Same arithmetic as the per-op path kernel for kernel; `LoFTREncoderLayer.layer_node = False` selects that path (the tests
 compare the two).
 """
+import ctypes
+
 import torch
 
 from .. import ops
@@ -107,10 +109,82 @@ class _EncoderLayerFn(torch.autograd.Function):
         return dx, ds, dwq, dwk, dwv, dwm, dw0, dw2, dg1, db1, dg2, db2, None
 
 
+class _EncoderLayerNativeFn(torch.autograd.Function):
+    """The same node with its launch sequences issued by the library (far_enc_layer_fwd / far_enc_layer_bwd,
+    csrc/encoder_layer_train.hip): two calls per layer instead of ~50 launches' worth of Python."""
+
+    @staticmethod
+    def _desc(layer, ws_, bs, L, S, C, self_attn, act_exp):
+        lib = ops._lib.load()
+        pk = layer.__dict__.setdefault('_packs', ops.PackCache())
+        sp = layer.split_operands
+        d = ops._lib.EncLayer()
+        d.bs, d.L, d.S, d.C, d.nhead, d.self_attn, d.split = bs, L, S, C, layer.nhead, int(self_attn), int(sp)
+        d.act_exp, d.overlap = act_exp, int(layer.overlap)
+        d.eps1, d.eps2, d.attn_eps = layer.norm1.eps, layer.norm2.eps, layer.attention.eps
+        keep = []
+        for i, (w, name) in enumerate(zip(ws_, ('q', 'k', 'v', 'merge', 'mlp0', 'mlp2'))):
+            f = ops.train_pack(pk, ('train', name), w, None, sp)
+            t = ops.train_pack_t(pk, ('train', name), w, None, sp)
+            d.img[i], d.img_scale[i], d.imgT[i], d.imgT_scale[i] = f.packed.data_ptr(), f.scale.data_ptr(), t.packed.data_ptr(), t.scale.data_ptr()
+            keep += [f, t]
+        d.overflow = ops.overflow_flag(ws_[0].device).data_ptr()
+        return d, keep, lib
+
+    @staticmethod
+    def forward(ctx, x, source, wq, wk, wv, wm, w0, w2, g1, b1, g2, b2, layer):
+        self_attn = source is None
+        xc = x.detach().float().contiguous()
+        sc = xc if self_attn else source.detach().float().contiguous()
+        bs, L, C = xc.shape
+        ae = ops.activation_exponent_value()
+        d, keep, lib = _EncoderLayerNativeFn._desc(layer, (wq, wk, wv, wm, w0, w2), bs, L, sc.shape[1], C, self_attn, ae)
+        d.g1, d.b1, d.g2, d.b2 = g1.data_ptr(), b1.data_ptr(), g2.data_ptr(), b2.data_ptr()
+        dref = ctypes.byref(d)
+        saved = torch.empty(int(lib.far_enc_layer_saved_floats(dref)), dtype=torch.float32, device=xc.device)
+        nws = int(lib.far_enc_layer_fwd_ws_bytes(dref))
+        if saved.numel() == 0 or nws == 0:
+            raise ops._lib.FarHipError('far_enc_layer_fwd: layer shape not covered')
+        ws = torch.empty(nws, dtype=torch.uint8, device=xc.device)
+        y = torch.empty_like(xc)
+        rc = lib.far_enc_layer_fwd(dref, xc.data_ptr(), None if self_attn else sc.data_ptr(), saved.data_ptr(), y.data_ptr(), ws.data_ptr(), nws,
+                                   ops._stream())
+        ops._lib.check(rc, 'far_enc_layer_fwd')
+        ctx.save_for_backward(xc, sc, saved, wq, wk, wv, wm, w0, w2, g1, b1, g2, b2)
+        ctx.layer, ctx.self_attn, ctx.act_exp = layer, self_attn, ae
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xc, sc, saved, wq, wk, wv, wm, w0, w2, g1, b1, g2, b2 = ctx.saved_tensors
+        layer = ctx.layer
+        bs, L, C = xc.shape
+        d, keep, lib = _EncoderLayerNativeFn._desc(layer, (wq, wk, wv, wm, w0, w2), bs, L, sc.shape[1], C, ctx.self_attn, ctx.act_exp)
+        d.g1, d.b1, d.g2, d.b2 = g1.data_ptr(), b1.data_ptr(), g2.data_ptr(), b2.data_ptr()
+        dref = ctypes.byref(d)
+        gy = gy.float().contiguous()
+        grads = torch.empty(int(lib.far_enc_layer_grads_floats(dref)), dtype=torch.float32, device=xc.device)
+        nws = int(lib.far_enc_layer_bwd_ws_bytes(dref))
+        ws = torch.empty(nws, dtype=torch.uint8, device=xc.device)
+        rc = lib.far_enc_layer_bwd(dref, xc.data_ptr(), None if ctx.self_attn else sc.data_ptr(), saved.data_ptr(), gy.data_ptr(), grads.data_ptr(),
+                                   ws.data_ptr(), nws, ops._stream())
+        ops._lib.check(rc, 'far_enc_layer_bwd')
+        off = (ctypes.c_long * 12)()
+        ops._lib.check(lib.far_enc_layer_grads_offsets(dref, off), 'far_enc_layer_grads_offsets')
+        R, Rs = bs * L, bs * sc.shape[1]
+        piece = lambda i, n, shape: grads.narrow(0, off[i], n).view(shape)
+        dx = piece(0, R * C, xc.shape)
+        ds = None if ctx.self_attn else piece(1, Rs * C, sc.shape)
+        dws = [piece(2 + i, w.numel(), w.shape) for i, w in enumerate((wq, wk, wv, wm, w0, w2))]
+        dgb = [piece(8 + i, C, (C,)) for i in range(4)]
+        return (dx, ds, *dws, *dgb, None)
+
+
 def encoder_layer_train(layer, x, source):
     """LoFTREncoderLayer.forward(x, source) (no masks) with gradients as one autograd node; `source is x` = self-attention."""
     if any(m.bias is not None for m in (layer.q_proj, layer.k_proj, layer.v_proj, layer.merge, layer.mlp[0], layer.mlp[2])):
         raise ops._lib.FarHipError('encoder_layer_train: the FAR encoder layers have bias-free Linear layers')
-    return _EncoderLayerFn.apply(x, None if source is x else source, layer.q_proj.weight, layer.k_proj.weight, layer.v_proj.weight,
+    fn = _EncoderLayerNativeFn if layer.native_node else _EncoderLayerFn
+    return fn.apply(x, None if source is x else source, layer.q_proj.weight, layer.k_proj.weight, layer.v_proj.weight,
                                  layer.merge.weight, layer.mlp[0].weight, layer.mlp[2].weight, layer.norm1.weight, layer.norm1.bias,
                                  layer.norm2.weight, layer.norm2.bias, layer)

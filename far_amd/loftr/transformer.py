@@ -52,6 +52,7 @@ class LoFTREncoderLayer(nn.Module):
     hip_training = True          # training on the GPU runs K9 / K5 (forward + backward kernels); False: vendor ops + autograd
     layer_node = True            # ... as one autograd node per layer call (layer_train.py); False: one node per operator
     overlap = True               # layer node: weight gradients and the k / v projections on the library's side streams
+    native_node = True           # layer node: launch sequences issued by the library (far_enc_layer_fwd / _bwd) instead of Python
     fused_mlp = True             # d_model 128, split operands: the MLP block as one K13 launch (False: two K9 launches)
     fused_attn = True            # d_model 128, sequences <= 32 tokens, no masks: the attention block as one K14 launch
 
@@ -273,8 +274,10 @@ class CrossAttention(nn.Module):
             ts = [self.qkv.weight] + ([self.qkv.bias] if self.qkv.bias is not None else [])
             pc = pk.get('qkv', ts, lambda: ops.PackedConv(self.qkv.weight, None, self.qkv.bias))
             # the two images are the two halves of one (2B, N, C) buffer when they come from CrossBlock: no copy
-            adjacent = (x1.is_contiguous() and x2.is_contiguous() and
-                        x2.data_ptr() == x1.data_ptr() + x1.numel() * x1.element_size())
+            # (same storage, x2 right behind x1: neighbours in the allocator's pool do not qualify)
+            adjacent = (x1.is_contiguous() and x2.is_contiguous() and x1.shape == x2.shape and
+                        x1.untyped_storage().data_ptr() == x2.untyped_storage().data_ptr() and
+                        x2.storage_offset() == x1.storage_offset() + x1.numel())
             x12 = torch.as_strided(x1, (2, B, N, C), (B * N * C, N * C, C, 1)) if adjacent else torch.stack([x1, x2], 0)
             planes = ops.linear_f16s(x12.reshape(2 * B, N, C), pc, out_planes=3 * h)     # (3h, 2B, N, d)
             if self.exact_f32:
@@ -415,8 +418,11 @@ class LocalFeatureTransformerRegressor(nn.Module):
         if self.config['regress_loftr_layers'] > 0:
             f0, f1 = self.loftr(f0, f1, loftr_preds=loftr_preds, inv_loftr_preds=inv_loftr_preds, joint_out=True)
         B = f0.shape[0]
-        adjacent = (f0.is_cuda and f0.is_contiguous() and f1.is_contiguous() and
-                    f1.data_ptr() == f0.data_ptr() + f0.numel() * f0.element_size())
+        # the two halves of ONE buffer (joint_out): same storage, f1 right behind f0 -- two separate allocations that happen to be
+        # neighbours in the allocator's pool do not qualify (as_strided may not reach past f0's storage)
+        adjacent = (f0.is_cuda and f0.is_contiguous() and f1.is_contiguous() and f0.shape == f1.shape and
+                    f0.untyped_storage().data_ptr() == f1.untyped_storage().data_ptr() and
+                    f1.storage_offset() == f0.storage_offset() + f0.numel())
         x01 = torch.as_strided(f0, (2 * B,) + tuple(f0.shape[1:]), f0.stride()) if adjacent else torch.cat([f0, f1], dim=0)
         x = self.emm(x01, loftr_preds=loftr_preds, inv_loftr_preds=inv_loftr_preds)
         if ag.needs_grad(x, self.norm.weight) or not x.is_cuda:

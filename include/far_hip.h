@@ -243,6 +243,38 @@ int far_layernorm_bwd_f32(const float* x, const float* gamma, const float* dy, l
                           float* dgamma, float* dbeta, void* ws, long ws_bytes, far_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * Training driver of one LoFTR encoder layer: LoFTREncoderLayer.forward under autograd
+ * (src/loftr/loftr_module/transformer.py:44-67) as one call for the forward and one for the backward.
+ * No arithmetic of its own: K9 / K5 / K6 / K16 / far_grad_scale_f32 launched in sequence (the k / v projections and every weight
+ * gradient on side streams when `overlap`), so that a layer costs the host two calls instead of ~50 launches' worth of
+ * interpreter time.  x (bs, L, C), source (bs, S, C) fp32 contiguous (self_attn: source ignored, S = L);
+ * C % 4 == 0, C <= 512, C / nhead in {16, 32}; bias-free Linear layers.  img[i] / img_scale[i]: the K9 image and epilogue scale
+ * vector of q, k, v, merge, mlp[0], mlp[2] (far_conv_pack_view_scaled_f32); imgT / imgT_scale: the transposed (dgrad) images.
+ * Buffers are the caller's: `saved` (forward -> backward), `grads` (layout by far_enc_layer_grads_offsets: dx, ds (-1 for
+ * self-attention), dW x 6 in the weights' torch layouts, dgamma1, dbeta1, dgamma2, dbeta2), scratch `ws`.
+ * --------------------------------------------------------------------------------------------------- */
+typedef struct far_enc_layer {
+    long bs, L, S;
+    int C, nhead, self_attn, split, act_exp, overlap;
+    float eps1, eps2, attn_eps;
+    const void* img[6];
+    const float* img_scale[6];
+    const void* imgT[6];
+    const float* imgT_scale[6];
+    const float *g1, *b1, *g2, *b2;
+    int* overflow;
+} far_enc_layer;
+long far_enc_layer_saved_floats(const far_enc_layer* d);
+long far_enc_layer_grads_floats(const far_enc_layer* d);
+long far_enc_layer_fwd_ws_bytes(const far_enc_layer* d);
+long far_enc_layer_bwd_ws_bytes(const far_enc_layer* d);
+int far_enc_layer_grads_offsets(const far_enc_layer* d, long* out12);
+int far_enc_layer_fwd(const far_enc_layer* d, const float* x, const float* source, float* saved, float* y, void* ws, long ws_bytes,
+                      far_stream_t stream);
+int far_enc_layer_bwd(const far_enc_layer* d, const float* x, const float* source, const float* saved, const float* gy, float* grads,
+                      void* ws, long ws_bytes, far_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * K13  the MLP block of a LoFTR encoder layer at d_model = 128 (the fine-level transformer) in one launch
  * replaces src/loftr/loftr_module/transformer.py:64-67:  x + norm2(mlp(cat[x, message]))  with
  *          mlp = Linear(2d, 2d, no bias) -> ReLU -> Linear(2d, d, no bias); the hidden tensor never reaches memory.

@@ -475,7 +475,8 @@ def test_layernorm_train_matches_float64(shape, res):
 
 @pytest.mark.parametrize('d_model,tokens,self_attn', [(256, 4800, True), (256, 4800, False), (128, 25, True), (128, 25, False)])
 def test_encoder_layer_node_equals_per_operator_path(d_model, tokens, self_attn):
-    """The one-node-per-layer training path (loftr/layer_train.py) against the one-node-per-operator path (layer_node = False):
+    """The one-node-per-layer training path (loftr/layer_train.py; driven from Python and by the library's far_enc_layer_fwd /
+    far_enc_layer_bwd) against the one-node-per-operator path (layer_node = False):
     the same kernels, so the output is bit-identical; gradients differ only by the order input-gradient contributions are
     added in; and against the vendor-op modules (hip_training = False)."""
     from far_amd.loftr.transformer import LoFTREncoderLayer
@@ -489,15 +490,20 @@ def test_encoder_layer_node_equals_per_operator_path(d_model, tokens, self_attn)
     s0 = torch.randn(bs, tokens, d_model, device='cuda')
     g = torch.randn(bs, tokens, d_model, device='cuda') * 1e-4
     res = {}
-    for mode in ('node', 'ops', 'vendor'):
-        layer.hip_training, layer.layer_node = mode != 'vendor', mode == 'node'
+    for mode in ('native', 'node', 'ops', 'vendor'):
+        layer.hip_training, layer.layer_node, layer.native_node = mode != 'vendor', mode in ('node', 'native'), mode == 'native'
         layer.zero_grad()
         x, s = x0.clone().requires_grad_(True), s0.clone().requires_grad_(True)
         y = layer(x, x if self_attn else s)
         y.backward(g)
         res[mode] = (y.detach(), x.grad, None if self_attn else s.grad, {k: p.grad.clone() for k, p in layer.named_parameters()})
-    layer.hip_training, layer.layer_node = True, True
+    layer.hip_training, layer.layer_node, layer.native_node = True, True, True
     assert torch.equal(res['node'][0], res['ops'][0])
+    # the library-driven node (far_enc_layer_fwd / _bwd) issues the same launches as the Python-driven one: equal bit for bit
+    assert torch.equal(res['native'][0], res['node'][0]) and torch.equal(res['native'][1], res['node'][1])
+    assert self_attn or torch.equal(res['native'][2], res['node'][2])
+    for k_ in res['node'][3]:
+        assert torch.equal(res['native'][3][k_], res['node'][3][k_]), k_
     rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
     worst = 0.0
     # (against the vendor-op modules the bar is loose: a hidden unit whose pre-activation is within rounding of zero -- 1e-7 in
