@@ -410,6 +410,9 @@ def bench_c3(a, dev, world, rank, dist):
     model = LoFTR(cfg['loftr'])
     synth.load_synthetic(model, seed=0)
     model = model.to(dev).train()
+    if os.environ.get('FAR_C3_NO_STACK') == '1':       # A/B aid: the two self-attention calls of a layer separately
+        from far_amd.loftr.transformer import LocalFeatureTransformer as _T
+        _T.stack_self = False
     if os.environ.get('FAR_C3_PY_NODE') == '1':        # A/B aid: the layer node driven from Python instead of far_enc_layer_fwd / _bwd
         from far_amd.loftr.transformer import LoFTREncoderLayer as _L3
         _L3.native_node = False

@@ -155,6 +155,8 @@ class LoFTREncoderLayer(nn.Module):
 
 
 class LocalFeatureTransformer(nn.Module):
+    stack_self = True            # training on the GPU: the two self-attention calls of a layer as one call on both images
+
     def __init__(self, config):
         super().__init__()
         self.config = config
@@ -184,7 +186,15 @@ class LocalFeatureTransformer(nn.Module):
                 o0, o1 = buf[:n], buf[n:]
             kw0 = {} if o0 is None else {'out': o0}
             kw1 = {} if o1 is None else {'out': o1}
-            if name == 'self':
+            if (name == 'self' and self.stack_self and feat0.is_cuda and feat0.shape == feat1.shape and mask0 is None and mask1 is None
+                    and layer.hip_training and layer.layer_node and torch.is_grad_enabled() and ag.needs_grad(feat0, feat1, layer.norm1.weight)):
+                # training: the two self-attention calls of a layer are independent -- one call on both images (at batch 1 a
+                # launch fills a fraction of the CUs; rows are independent, the attention core works per image); unbind's
+                # backward is one stack, where two slices' would be two zero-fills, two copies and an add
+                x01 = torch.cat([feat0, feat1], 0)
+                y01 = layer(x01, x01)
+                feat0, feat1 = y01.view(2, n, *feat0.shape[1:]).unbind(0)
+            elif name == 'self':
                 feat0 = layer(feat0, feat0, mask0, mask0, inv_loftr_preds, **kw0)
                 feat1 = layer(feat1, feat1, mask1, mask1, loftr_preds, **kw1)
             elif name == 'cross':
