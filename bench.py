@@ -410,9 +410,6 @@ def bench_c3(a, dev, world, rank, dist):
     model = LoFTR(cfg['loftr'])
     synth.load_synthetic(model, seed=0)
     model = model.to(dev).train()
-    if os.environ.get('FAR_C3_NO_STACK') == '1':       # A/B aid: the two self-attention calls of a layer separately
-        from far_amd.loftr.transformer import LocalFeatureTransformer as _T
-        _T.stack_self = False
     if os.environ.get('FAR_C3_PY_NODE') == '1':        # A/B aid: the layer node driven from Python instead of far_enc_layer_fwd / _bwd
         from far_amd.loftr.transformer import LoFTREncoderLayer as _L3
         _L3.native_node = False
@@ -635,6 +632,9 @@ def main():
         import torch.distributed as dist
         dist.init_process_group(a.backend, device_id=dev if a.backend == 'nccl' else None)
         world = dist.get_world_size()            # the rank count the backend (RCCL) reports
+    if os.environ.get('FAR_NO_STACK') == '1':          # A/B aid (any workload): 'self' layers on the two images separately
+        from far_amd.loftr.transformer import LocalFeatureTransformer as _T0
+        _T0.stack_self = False
     if a.workload == 'c4':
         return bench_c4(a, dev, world, rank, dist)
     if a.workload == 'c3':

@@ -154,8 +154,14 @@ class LoFTREncoderLayer(nn.Module):
                                post_residual=x, out=out)
 
 
+def _halves_of_one_buffer(a, b):
+    """a and b are contiguous, equally shaped, in the same storage, b right behind a (cat([a, b], 0) is then a free view)."""
+    return (a.is_contiguous() and b.is_contiguous() and a.shape == b.shape and
+            a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr() and b.storage_offset() == a.storage_offset() + a.numel())
+
+
 class LocalFeatureTransformer(nn.Module):
-    stack_self = True            # training on the GPU: the two self-attention calls of a layer as one call on both images
+    stack_self = True            # on the GPU: the two self-attention calls of a layer as one call on both images
 
     def __init__(self, config):
         super().__init__()
@@ -181,12 +187,21 @@ class LocalFeatureTransformer(nn.Module):
         last = len(self.layers) - 1
         for li, (layer, name) in enumerate(zip(self.layers, self.layer_names)):
             o0 = o1 = None
-            if joint_out and li == last:
+            # inference: every layer writes feat0 / feat1 into the two halves of one buffer, so that the next 'self' layer can
+            # run ONCE on both images (rows are independent, the attention core works per image: identical results, half the
+            # launches, fewer partial rounds of workgroups per launch)
+            infer_joint = (self.stack_self and feat0.is_cuda and feat0.dtype == torch.float32 and feat0.shape == feat1.shape
+                           and mask0 is None and mask1 is None and not ag.needs_grad(feat0, feat1, layer.norm1.weight))
+            if (joint_out and li == last) or infer_joint:
                 buf = torch.empty(2 * n, *feat0.shape[1:], dtype=torch.float32, device=feat0.device)
                 o0, o1 = buf[:n], buf[n:]
             kw0 = {} if o0 is None else {'out': o0}
             kw1 = {} if o1 is None else {'out': o1}
-            if (name == 'self' and self.stack_self and feat0.is_cuda and feat0.shape == feat1.shape and mask0 is None and mask1 is None
+            if name == 'self' and infer_joint and _halves_of_one_buffer(feat0, feat1):
+                x01 = torch.as_strided(feat0, (2 * n,) + tuple(feat0.shape[1:]), feat0.stride())
+                layer(x01, x01, None, None, None, out=buf)
+                feat0, feat1 = o0, o1
+            elif (name == 'self' and self.stack_self and feat0.is_cuda and feat0.shape == feat1.shape and mask0 is None and mask1 is None
                     and layer.hip_training and layer.layer_node and torch.is_grad_enabled() and ag.needs_grad(feat0, feat1, layer.norm1.weight)):
                 # training: the two self-attention calls of a layer are independent -- one call on both images (at batch 1 a
                 # launch fills a fraction of the CUs; rows are independent, the attention core works per image); unbind's
