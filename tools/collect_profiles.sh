@@ -5,12 +5,13 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-r02}
 mkdir -p $R/gpurun_out
+# the un-profiled headline line first: counter collection can leave the clocks in the profiler's fixed state for a while
+(cd $R; timeout 400 python bench.py > gpurun_out/bench_plain.log 2> gpurun_out/bench_plain.err)
 cd /tmp; export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_bench -o bench -- python3 $R/bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-other-modes > $R/gpurun_out/bench_prof.log 2>&1
 timeout 200 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/pmc_fetch -o f -- python3 $R/tools/kprobe.py pmc 32 2 > $R/gpurun_out/pmc_fetch.log 2>&1
 timeout 200 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/pmc_write -o w -- python3 $R/tools/kprobe.py pmc 32 2 > $R/gpurun_out/pmc_write.log 2>&1
 cd $R
-timeout 400 python bench.py > gpurun_out/bench_plain.log 2> gpurun_out/bench_plain.err
 timeout 300 python bench.py --workload c4 > gpurun_out/bench_c4.log 2> gpurun_out/bench_c4.err
 timeout 300 python bench.py --workload c3 --no-cpu-baseline --no-other-modes > gpurun_out/bench_c3.log 2> gpurun_out/bench_c3.err
 timeout 300 python bench.py --workload c3 --vendor-train --no-cpu-baseline --no-other-modes > gpurun_out/bench_c3_vendor.log 2> gpurun_out/bench_c3_vendor.err
