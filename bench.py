@@ -515,7 +515,7 @@ def bench_c3(a, dev, world, rank, dist):
             'dtype': 'f32', 'data': 'synthetic',
             'dtype_note': 'fp32 tensors and accumulation; K1 / K9 (Linear and backbone convolutions) / K2 forward on split-f16x3 operands, their '
                           'backward kernels on fp16 (K1, K2) or split-f16x3 (K9 dgrad, K16 wgrad) operands; stem forward + wgrad exact fp32 '
-                          'MFMA (K10); BatchNorm, LayerNorm backward, interpolation: vendor fp32',
+                          'MFMA (K10); LayerNorm forward + backward K6; BatchNorm, interpolation, elementwise glue: vendor fp32',
             'vendor_convolution': 'none' if not a.vendor_train else 'all (comparison leg)',
             'config': {'workload': 'Matterport3D-shaped training step (BASELINE configs[2]): ' + str(B) + ' pair(s) @ 640x480 per GPU, '
                                    'matcher in training mode (sampled / padded coarse matches), solver x2, head x2 (last with grad), '
@@ -523,8 +523,9 @@ def bench_c3(a, dev, world, rank, dist):
                        'pairs_per_gpu': B, 'hypotheses': a.hyp,
                        'training_kernels': 'vendor ops + autograd (comparison leg)' if a.vendor_train else
                                            'HIP forward+backward: K1 sparse-position conf, K5, K9 Linear + backbone convolutions (dgrad), K16 '
-                                           'convolution / Linear / stem weight gradients (deterministic), K3 window gather / scatter, K2; weight '
-                                           'packing and gradient scaling without host synchronisation',
+                                           'convolution / Linear / stem weight gradients (deterministic), K6, K3 window gather / scatter, K2; one '
+                                           'autograd node per encoder layer driven by the library (far_enc_layer_fwd / _bwd, side streams), both '
+                                           'images through a self-attention layer in one call; all weight images re-packed in two launches per step',
                        'gt_coarse_matches_per_pair': n_gt, 'sampled_matches': int(last['b_ids'].numel()),
                        'losses': sc,
                        'parallelism': f'ddp{world} (gradient all-reduce over RCCL)' if world > 1 else 'single GPU (no exchange step)'},
