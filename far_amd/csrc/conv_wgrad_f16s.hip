@@ -306,8 +306,10 @@ Plan plan_for(int N, int Ho, int Wo, int Cin, int Cout, int taps, int stride) {
         if (r > pl.units / 4) r = pl.units / 4 > 0 ? pl.units / 4 : 1;
         const long per = (pl.units + r - 1) / r;
         const long wgs = r * pl.wgs_per_range;
-        const double rounds = wgs <= 256 ? 1.3 : (resident == 512 ? 2.0 * (double)((wgs + 511) / 512)  // 1 wave per SIMD hides less latency
-                                                                   : 1.3 * (double)((wgs + 255) / 256));
+        // 3x3: matrix-pipe bound -- two resident workgroups per CU share the pipe (x 2 per round of 512); one per CU hides less
+        // latency (x 1.3).  1x1: three MFMAs per row, a chain of load round trips -- resident workgroups do not slow each other.
+        const double rounds = taps == 1 ? (double)((wgs + 511) / 512)
+                            : wgs <= 256 ? 1.3 : (resident == 512 ? 2.0 * (double)((wgs + 511) / 512) : 1.3 * (double)((wgs + 255) / 256));
         const double cost = (per + 4) * step_us * rounds + r * slab_us;
         if (cost < best) { best = cost; best_r = r; }
     }
