@@ -43,6 +43,9 @@ def build(force=False, verbose=True):
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f'hipcc failed on {src}')
+    for f in os.listdir(LIBDIR):                      # objects of sources that no longer exist
+        if f.endswith('.o') and os.path.join(LIBDIR, f) not in objs:
+            os.remove(os.path.join(LIBDIR, f))
     if force or procs or _stale(LIB, objs):
         cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
         if verbose:

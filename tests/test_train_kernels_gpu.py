@@ -516,3 +516,58 @@ def test_encoder_layer_node_equals_per_operator_path(d_model, tokens, self_attn)
         print(f'[layer node] d{d_model} x {tokens} {"self" if self_attn else "cross"} vs {other}: worst gradient deviation {max(errs):.2e}')
         assert max(errs) < bar, (other, errs)
         worst = max(worst, max(errs))
+
+
+def test_conv_wgrad_random_shapes_sweep():
+    """K16 on 24 random shapes: ragged strips (W not a multiple of 16), odd sizes under stride 2, channel counts that are not
+    multiples of 32 or of 4, one-row and one-column images, N up to 3 -- against float64 autograd."""
+    import random
+    import torch.nn.functional as F
+    from far_amd import ops
+    rnd = random.Random(7)
+    g = torch.Generator(device='cuda').manual_seed(7)
+    worst = 0.0
+    for case in range(24):
+        ks = rnd.choice([1, 3, 3])
+        st = rnd.choice([1, 1, 2])
+        N = rnd.choice([1, 2, 3])
+        H, W = rnd.choice([1, 2, 5, 17, 33, 40]), rnd.choice([1, 3, 15, 16, 17, 47, 64])
+        Cin, Cout = rnd.choice([1, 4, 20, 36, 100, 128, 196]), rnd.choice([2, 8, 33, 64, 130, 196])
+        x = torch.randn(N, H, W, Cin, device='cuda', generator=g)
+        Ho, Wo = (H - 1) // st + 1, (W - 1) // st + 1
+        dy = torch.randn(N, Ho, Wo, Cout, device='cuda', generator=g) * 1e-3
+        dw = ops.conv_wgrad(x, dy, ks, st)
+        w = torch.zeros(Cout, Cin, ks, ks, device='cuda', dtype=torch.float64, requires_grad=True)
+        y = F.conv2d(x.permute(0, 3, 1, 2).double(), w, stride=st, padding=ks // 2)
+        (y * dy.permute(0, 3, 1, 2).double()).sum().backward()
+        scale = float(w.grad.abs().max())
+        err = float((dw.double() - w.grad).abs().max()) / max(scale, 1e-30)
+        worst = max(worst, err)
+        assert dw.shape == w.shape and err < 5e-6, (case, N, H, W, Cin, Cout, ks, st, err)
+    print(f'[wgrad sweep] worst relative error over 24 shapes {worst:.1e}')
+
+
+def test_encoder_layer_native_node_ragged_cross_attention():
+    """far_enc_layer_fwd / _bwd with L != S, a row count that is no multiple of 32 and batch 3: equal to the Python-driven node
+    bit for bit, and close to the per-operator path."""
+    from far_amd.loftr.transformer import LoFTREncoderLayer
+    torch.manual_seed(11)
+    layer = LoFTREncoderLayer(128, 8).cuda().train()
+    for p in layer.parameters():
+        if p.dim() > 1:
+            torch.nn.init.xavier_uniform_(p)
+    x0, s0 = torch.randn(3, 37, 128, device='cuda'), torch.randn(3, 53, 128, device='cuda')
+    g = torch.randn(3, 37, 128, device='cuda') * 1e-2
+    res = {}
+    for mode in ('native', 'node', 'ops'):
+        layer.layer_node, layer.native_node = mode != 'ops', mode == 'native'
+        layer.zero_grad()
+        x, s = x0.clone().requires_grad_(True), s0.clone().requires_grad_(True)
+        y = layer(x, s)
+        y.backward(g)
+        res[mode] = [y.detach(), x.grad, s.grad] + [p.grad.clone() for p in layer.parameters()]
+    layer.layer_node = layer.native_node = True
+    for a, b in zip(res['native'], res['node']):
+        assert torch.equal(a, b)
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    assert torch.equal(res['node'][0], res['ops'][0]) and max(rel(a, b) for a, b in zip(res['node'][1:], res['ops'][1:])) < 2e-6
