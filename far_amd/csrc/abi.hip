@@ -9,7 +9,9 @@ extern "C" int far_abi_version(void) { return 2; }
 extern "C" int far_last_hip_error(void) { return g_last_hip_error; }
 
 // Tuning knobs for A/B experiments (speed only; never change results).  key 0: bit mask of kernels that use
-// wave-slot priority staggering (1 = k_stats, 2 = k_match, 4 = k_emm_pv).
+// wave-slot priority staggering (1 = k_stats, 2 = k_match, 4 = k_emm_pv); 1: K1 f32 tile variant; 2, 3: conf_matrix writer
+// variants; 4: 1 = K9 without the seven-tile mode / K5 windows on the generic path; 5: K5 apply tiles per unit; 6: K5 tokens per
+// KV chunk; 7: 1 = K9 Linear launches always on full-height tiles.
 // This is the library's ONLY process-global state (declared as such in include/far_hip.h); atomics, so that a tuning
 // call from one thread is well-defined against launches on another.
 static std::atomic<int> g_tuning[8] = {{3}, {0}, {0}, {0}, {0}, {0}, {0}, {0}};

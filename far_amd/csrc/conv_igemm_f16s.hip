@@ -1300,7 +1300,7 @@ int far_conv_nhwc_f32(const far_conv_desc* desc, hipStream_t stream) {
     a.scale_dev = d.act_scale_dev;
     long nbx = ksize == 1 ? (a.npix + 64 * c.mw - 1) / (64 * c.mw) : N * a.tilesX * a.tilesY;
     // a Linear layer over the tokens of one pair fills a fraction of the CUs with full-height tiles: halve them
-    const bool small = ksize == 1 && !up && nbx * a.nblkY < 192 && far_get_tuning(5) == 0;
+    const bool small = ksize == 1 && !up && nbx * a.nblkY < 192 && far_get_tuning(7) == 0;
     if (small) nbx = (a.npix + 32 * c.mw - 1) / (32 * c.mw);
     a.ntiles = nbx;
     if (nbx * a.nblkY > 0x7fffffffL) return FAR_EINVAL;

@@ -110,8 +110,8 @@ __global__ void k_la_kv_reduce(const float* __restrict__ part, int nchunk, int p
 
 // out[l][h,v] = (sum_d Q'[l][h,d] KV[h][d][v]) / (sum_d Q'[l][h,d] ksum[h][d] + eps) * S.
 // One wave per (n, head, block of token tiles): D[m = token][n = v]; A = Q' loaded as contiguous channel runs per
-// lane, B = the head's KV columns held in registers for the whole block; the normaliser comes from a second MFMA
-// against a B whose columns all equal ksum, so it lands in the same (token, v) register layout as the numerator.
+// lane, B = the head's KV columns held in registers for the whole block; the normaliser is a dot product over the channels a
+// token's lanes already hold (fma chain + cross-lane adds).
 template <int D>
 __global__ __launch_bounds__(256) void k_la_apply(const float* __restrict__ q, const float* __restrict__ kv,
                                                   const uint8_t* __restrict__ q_mask, int N, int L, int S, int H,
@@ -166,17 +166,22 @@ __global__ __launch_bounds__(256) void k_la_apply(const float* __restrict__ q, c
         // transposed product D[m = v][n = token]: the lane that fed token `col` gets that token's outputs for the channels
         // v = row(r, kk) -- groups of four consecutive channels -> 16-byte stores (32 contiguous bytes per token and
         // instruction with the kk twin) instead of 4-byte ones
-        typename M::acc_t num, den;
+        typename M::acc_t num;
 #pragma unroll
-        for (int r = 0; r < M::NACC; ++r) { num[r] = 0.f; den[r] = 0.f; }
+        for (int r = 0; r < M::NACC; ++r) num[r] = 0.f;
+        // the normaliser Q'[l] . ksum is a dot product of what this token's lanes already hold (channels NK kk + t): an fma
+        // chain and one or two cross-lane adds instead of a second MFMA chain (half of this kernel's matrix work)
+        float den = 0.f;
 #pragma unroll
         for (int t = 0; t < NK; ++t) {
             num = M::mma(bkv[t], qa[t], num);
-            den = M::mma(bks[t], qa[t], den);
+            den = fmaf(qa[t], bks[t], den);
         }
+#pragma unroll
+        for (int m = D; m < 64; m <<= 1) den += shfl_xor_f(den, m);
         const int lo = ti * TT + col;
         if (lo < L) {
-            const float zz = 1.0f / (den[0] + eps);                                  // linear_attention.py:46 (every row of den is the token's normaliser)
+            const float zz = 1.0f / (den + eps);                                     // linear_attention.py:46
             float* op = out + ((size_t)n * L + lo) * HD + h * D;
 #pragma unroll
             for (int g = 0; g < M::NACC / 4; ++g)                                    // :50
