@@ -571,3 +571,31 @@ def test_encoder_layer_native_node_ragged_cross_attention():
         assert torch.equal(a, b)
     rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
     assert torch.equal(res['node'][0], res['ops'][0]) and max(rel(a, b) for a, b in zip(res['node'][1:], res['ops'][1:])) < 2e-6
+
+
+def test_encoder_layer_node_is_run_to_run_deterministic_with_side_streams():
+    """The layer node with its weight gradients and k / v projections on side streams: ten repetitions of forward + backward on
+    the same inputs give bit-identical outputs and gradients (a missing fork / join or a buffer freed before its join would
+    show up here as a difference)."""
+    from far_amd.loftr.transformer import LoFTREncoderLayer
+    torch.manual_seed(3)
+    layer = LoFTREncoderLayer(256, 8).cuda().train()
+    for p in layer.parameters():
+        if p.dim() > 1:
+            torch.nn.init.xavier_uniform_(p)
+    x0, s0 = torch.randn(2, 4800, 256, device='cuda'), torch.randn(2, 4800, 256, device='cuda')
+    g = torch.randn(2, 4800, 256, device='cuda') * 1e-3
+    ref = None
+    for rep in range(10):
+        junk = torch.randn(1 << 22, device='cuda')                    # churn the allocator between repetitions
+        layer.zero_grad()
+        x, s = x0.clone().requires_grad_(True), s0.clone().requires_grad_(True)
+        y = layer(x, s if rep % 2 == 0 else s)
+        y.backward(g)
+        cur = [y.detach().clone(), x.grad.clone(), s.grad.clone()] + [p.grad.clone() for p in layer.parameters()]
+        del junk
+        if ref is None:
+            ref = cur
+        else:
+            for a, b in zip(cur, ref):
+                assert torch.equal(a, b), rep
