@@ -46,6 +46,7 @@
 // the part sustains under this load, tools/k9_timing.py) including the fused epilogue, against 100-125 TFLOP/s for
 // the vendor fp32 Winograd convolution alone.
 #include "common.h"
+#include "linear_small.h"
 #include <vector>
 #include <type_traits>
 
@@ -1299,6 +1300,15 @@ int far_conv_nhwc_f32(const far_conv_desc* desc, hipStream_t stream) {
     a.act_scale = ldexpf(1.0f, d.act_exp); a.out_mul = ldexpf(1.0f, ACT_EXP_DEFAULT - d.act_exp); a.overflow = d.overflow;
     a.scale_dev = d.act_scale_dev;
     long nbx = ksize == 1 ? (a.npix + 64 * c.mw - 1) / (64 * c.mw) : N * a.tilesX * a.tilesY;
+    // a Linear layer over the tokens of one or two images: the few-row kernel (linear_small_f16s.hip; same image, same arithmetic)
+    if (ksize == 1 && !up && !x2 && !ln_gamma && !post_res && res_group == 1 && split && nbx * a.nblkY < 512 &&
+        far_get_tuning(7) == 0 && far_linear_small_covers(a.npix, Cin, Cout)) {
+        LinSmallArgs s;
+        s.x = x; s.w = a.w; s.scale = scale; s.shift = shift; s.res = res; s.y = y; s.rows = a.npix;
+        s.Cin = Cin; s.Cout = Cout; s.Csub = a.Csub; s.NT = c.nt; s.nblkY = a.nblkY; s.act = act; s.slope = slope;
+        s.act_scale = a.act_scale; s.out_mul = a.out_mul; s.scale_dev = a.scale_dev; s.overflow = a.overflow;
+        return far_linear_small_launch(s, stream);
+    }
     // a Linear layer over the tokens of one pair fills a fraction of the CUs with full-height tiles: halve them
     const bool small = ksize == 1 && !up && nbx * a.nblkY < 192 && far_get_tuning(7) == 0;
     if (small) nbx = (a.npix + 32 * c.mw - 1) / (32 * c.mw);

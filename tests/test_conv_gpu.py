@@ -435,10 +435,10 @@ def test_conv_is_run_to_run_deterministic_under_load():
 
 
 @pytest.mark.parametrize('rows,K,Co', [(4800, 256, 256), (1500, 128, 128), (4800, 256, 768), (333, 512, 256), (9600, 256, 128), (70, 256, 196)])
-def test_linear_half_height_tiles_equal_full_height(rows, K, Co):
-    """Few-row Linear launches (fewer workgroups than CUs) run 32 MW-row tiles instead of 64 MW: the same products in the same
-    order per output, so every epilogue (bias / activation / residual / LayerNorm / output planes) equals the full-height launch
-    bit for bit (tuning knob 7 forces the full-height path)."""
+def test_linear_few_row_paths_equal_full_height(rows, K, Co):
+    """Few-row Linear launches run the few-row kernel (linear_small_f16s.hip: K % 32 == 0, K <= 512, no fused LayerNorm) or K9 on
+    32 MW-row tiles instead of 64 MW: the same products in the same order per output, so every epilogue (bias / activation /
+    residual / LayerNorm / output planes) equals the full-height K9 launch bit for bit (tuning knob 7 forces that path)."""
     from far_amd import _lib
     ops = _ops()
     lib = _lib.load()
