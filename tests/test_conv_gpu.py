@@ -456,6 +456,11 @@ def test_linear_few_row_paths_equal_full_height(rows, K, Co):
             out.append(ops.linear_f16s(x, pc, ln=(gamma, beta, 1e-5), post_residual=r))
         if Co % 3 == 0 and (Co // 3) % 4 == 0:
             out.append(ops.linear_f16s(x, pc, out_planes=3))
+        # the dgrad form of the training path: device activation scale, residual accumulation, two output planes
+        gsc = ops.grad_scale(x * 1e-5)
+        out.append(ops.linear_f16s(x * 1e-5, pc, residual=r, act_scale_dev=gsc))
+        if Co % 8 == 0:
+            out.append(ops.linear_f16s(x * 1e-5, pc, out_planes=2, act_scale_dev=gsc))
         return out
     small = variants()
     lib.far_set_tuning(7, 1)
