@@ -5,7 +5,7 @@
 //
 // Replaces the nn.Linear layers of mp3d_loftr/src/loftr/loftr_module/transformer.py:25-35 at training / small-batch sizes.
 //
-// Shape of the work: a wave owns 32 rows x 32 NCT columns (NCT = 2 up to 256 input channels, 1 up to 512) for the WHOLE K.
+// Shape of the work: a wave owns 32 rows x 64 columns (NCT = 2 column tiles; up to 256 input channels) for the WHOLE K.
 // The four waves of a workgroup take four row tiles and share one column block, whose weights (all of K: <= 64 KiB) are
 // brought into LDS by ONE round of LDS-DMA, waited for once, behind ONE barrier -- no ring, no phases.  The rows are read
 // straight from global memory as the MFMA A operand (8 consecutive channels per lane), 128 channels per register buffer, two
@@ -166,11 +166,10 @@ int launch(const LinSmallArgs& a, hipStream_t stream) {
 }  // namespace
 
 bool far_linear_small_covers(long rows, int Cin, int Cout) {
-    // whole k-steps and chunks, weights of a column block within 64 KiB of LDS, and few enough rows that K9's tiles would leave
-    // CUs idle (beyond that K9's larger tiles re-read the weights less often)
-    return rows > 0 && rows <= 40960 && Cin >= 32 && Cin <= 512 && (Cin & 31) == 0 && Cout > 0;
+    // whole k-steps and chunks; at most 256 input channels: every column block re-reads its rows, and at K = 512 (32-column
+    // blocks) that costs more than K9's staging saves (19200 x 512 -> 512: 113 us against K9's 52); at most 320 workgroups:
+    // beyond that K9's staged rows win (19200 x 256 -> 256: 29 us here, 28 us there; 4800 rows: 13.4 against 17.6)
+    return rows > 0 && Cin >= 32 && Cin <= 256 && (Cin & 31) == 0 && Cout > 0 && ((rows + 127) / 128) * ((Cout + 63) / 64) <= 320;
 }
 
-int far_linear_small_launch(const LinSmallArgs& a, hipStream_t stream) {
-    return a.Cin <= 256 ? launch<2>(a, stream) : launch<1>(a, stream);
-}
+int far_linear_small_launch(const LinSmallArgs& a, hipStream_t stream) { return launch<2>(a, stream); }
