@@ -11,16 +11,17 @@ extern "C" int far_last_hip_error(void) { return g_last_hip_error; }
 // Tuning knobs for A/B experiments (speed only; never change results).  key 0: bit mask of kernels that use
 // wave-slot priority staggering (1 = k_stats, 2 = k_match, 4 = k_emm_pv); 1: K1 f32 tile variant; 2, 3: conf_matrix writer
 // variants; 4: 1 = K9 without the seven-tile mode / K5 windows on the generic path; 5: K5 apply tiles per unit; 6: K5 tokens per
-// KV chunk; 7: 1 = K9 Linear launches always on full-height tiles.
+// KV chunk; 7: 1 = K9 Linear launches always on full-height tiles; 8: 1 = K17 (Winograd) splits its operands with the five-instruction
+// split2 instead of v_fma_mix (same values); 9: 1 = K17 off (every 3x3 layer on K9).
 // This is the library's ONLY process-global state (declared as such in include/far_hip.h); atomics, so that a tuning
 // call from one thread is well-defined against launches on another.
-static std::atomic<int> g_tuning[8] = {{3}, {0}, {0}, {0}, {0}, {0}, {0}, {0}};
+static std::atomic<int> g_tuning[16] = {{3}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}};
 extern "C" int far_set_tuning(int key, int value) {
-    if (key < 0 || key >= 8) return FAR_EINVAL;
+    if (key < 0 || key >= 16) return FAR_EINVAL;
     g_tuning[key].store(value, std::memory_order_relaxed);
     return FAR_OK;
 }
-int far_get_tuning(int key) { return (key >= 0 && key < 8) ? g_tuning[key].load(std::memory_order_relaxed) : 0; }
+int far_get_tuning(int key) { return (key >= 0 && key < 16) ? g_tuning[key].load(std::memory_order_relaxed) : 0; }
 
 // ---- side streams: launches that do not depend on each other (the weight gradient of a layer next to its input gradient; the
 // q, k, v projections of a layer) overlap when they are issued on different streams, and at batch 1 each of them fills a

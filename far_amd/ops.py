@@ -946,6 +946,61 @@ class PackedConv:
         return self
 
 
+class PackedWino:
+    """Weights of one stride-1 3x3 convolution in K17's Winograd image (U = G g G^T, split fp16 planes), plus the folded epilogue
+    vectors; the same constructor meaning as PackedConv (scale / shift: the inference BatchNorm as a per-channel affine map)."""
+
+    ksize, stride, split = 3, 1, True
+
+    def __init__(self, weight, scale=None, shift=None):
+        lib = _lib.load()
+        w = weight.detach()
+        if w.dim() != 4 or tuple(w.shape[2:]) != (3, 3):
+            raise _lib.FarHipError(f'K17 is a 3x3 kernel, got a weight of shape {tuple(w.shape)}')
+        w = w.contiguous().float()
+        self.Cout, self.Cin = int(w.shape[0]), int(w.shape[1])
+        if self.Cin % 4:
+            raise _lib.FarHipError('K17 needs Cin % 4 == 0')
+        self.packed = torch.empty(lib.far_wino_packed_bytes(self.Cin, self.Cout), dtype=torch.uint8, device=w.device)
+        self.pack_scale = torch.empty(2, dtype=torch.float32, device=w.device)       # { 2^w_exp, 2^-(w_exp + 4) }
+        self._base = None if scale is None else scale.detach().float().contiguous()
+        self.scale = torch.empty(self.Cout, dtype=torch.float32, device=w.device)
+        self.shift = None if shift is None else shift.detach().float().contiguous()
+        _lib.check(lib.far_weight_scale_f32(_p(w, torch.float32), w.numel(), _p(self.pack_scale), _stream()), 'far_weight_scale_f32')
+        rc = lib.far_wino_pack_view_scaled_f32(_p(w), 9 * self.Cin, 9, 1, self.Cin, self.Cout, _p(self.pack_scale), _p(self.packed),
+                                               _p(self._base) if self._base is not None else None, _p(self.scale), _stream())
+        _lib.check(rc, 'far_wino_pack_view_scaled_f32')
+        self._w = w
+
+
+WINO_MIN_ACT_EXP = 0        # K17 splits its operands unscaled (|a| <= 16376): used while the activation exponent is >= 0
+
+
+def conv3x3_wino(x, pw, residual=None, act='none', slope=0.01, out=None):
+    """K17.  x (N, H, W, Cin) fp32 contiguous -> act(conv3x3(x) * scale + shift (+ residual)) as (N, H, W, Cout): conv_nhwc's
+    result for a stride-1 3x3 layer, on the Winograd kernel."""
+    lib = _lib.load()
+    N, H, W, Cin = x.shape
+    if Cin != pw.Cin:
+        raise _lib.FarHipError(f'conv3x3_wino: input has {Cin} channels, weights expect {pw.Cin}')
+    shape = (N, H, W, pw.Cout)
+    if out is None:
+        y = torch.empty(shape, dtype=torch.float32, device=x.device)
+    else:
+        y = out
+        if y.numel() != N * H * W * pw.Cout or not y.is_contiguous() or y.dtype != torch.float32:
+            raise _lib.FarHipError('conv3x3_wino: `out` must be a contiguous fp32 tensor of the output size')
+    if residual is not None and (residual.numel() != y.numel() or not residual.is_contiguous()):
+        raise _lib.FarHipError('conv3x3_wino: `residual` must be a contiguous tensor of the output size')
+    ptr = lambda t: _p(t, torch.float32).value
+    d = _lib.ConvDesc(x=ptr(x), x2=None, packed=_p(pw.packed).value, scale=ptr(pw.scale), shift=ptr(pw.shift), res=ptr(residual),
+                      ln_gamma=None, ln_beta=None, post_res=None, up=None, y=ptr(y), N=N, H=H, W=W, Cin=Cin, Cin1=Cin, Cout=pw.Cout,
+                      ksize=3, stride=1, act=_ACT[act], split=1, out_planes=1, res_group=1, slope=float(slope), ln_eps=0.0,
+                      act_exp=max(activation_exponent_value(), 0), overflow=overflow_flag(x.device).data_ptr(), act_scale_dev=None)
+    _lib.check(lib.far_conv3x3_wino_f32(ctypes.byref(d), _stream()), 'far_conv3x3_wino_f32')
+    return y if out is None else _written(y)
+
+
 class PackedMlp:
     """Weight image of far_mlp_fused_f16s (K13): mlp[0] (2d x 2d) and mlp[2] (d x 2d) of a LoFTR encoder layer at d = 128 as
     24 slabs of 16 KiB in execution order, fp16 (hi, lo) planes, each tensor scaled by a power of two taken from its maximum

@@ -417,6 +417,22 @@ typedef struct far_conv_desc {
 } far_conv_desc;
 
 int far_conv_nhwc_f32(const far_conv_desc* desc, far_stream_t stream);
+
+/* K17: the stride-1 3x3 convolutions as Winograd F(2x2, 3x3) on the f16 matrix cores with split operands (conv_wino_f16s.hip):
+ * far_conv_nhwc_f32's contract for ksize = 3, stride = 1, split = 1 at 2.25x fewer matrix instructions -- resnet_fpn.py:5-12
+ * (conv3x3), :15-43 (BasicBlock), :101-119 (layer*_outconv2).
+ *   far_wino_packed_bytes: bytes of the weight image [64-channel block][16-channel k-step][transform rows {0,1} | {2,3}][32 KiB].
+ *   far_wino_pack_view_scaled_f32: packs U = G g G^T (float64, then x scale_in[0] and the fp16 hi / lo split) of a [Cout][Cin][3][3]
+ *   weight read through element strides like far_conv_pack_view_scaled_f32 (w = the element of tap 0; contiguous: 9 Cin, 9, 1);
+ *   scale_in = { 2^w_exp, 2^-(w_exp + 4) } from far_weight_scale_f32; scale_vec_out[co] = base_scale[co] (1 when NULL) x scale_in[1]
+ *   (may be NULL).
+ *   far_conv3x3_wino_f32: one launch; desc as far_conv_nhwc_f32 with `packed` a Winograd image, ksize 3, stride 1, split 1, and
+ *   x2 / ln_* / post_res / up / act_scale_dev NULL, out_planes = res_group = 1, act_exp >= 0 (else -22).  The activations are
+ *   split unscaled (|input| <= 16376: the transformed operand is at most 4 |input|); *overflow is raised beyond that, as by K9. */
+size_t far_wino_packed_bytes(int Cin, int Cout);
+int far_wino_pack_view_scaled_f32(const float* w, long s_co, long s_ci, long s_tap, int Cin, int Cout, const float* scale_in,
+                                  void* packed, const float* base_scale, float* scale_vec_out, far_stream_t stream);
+int far_conv3x3_wino_f32(const far_conv_desc* desc, far_stream_t stream);
 /* Activation scale for an input of unknown magnitude (the output gradient in a dgrad launch): out2 = { 2^e, 2^(4 - e) } with
  * max|x| 2^e in [2^9, 2^10), computed on the device -- pass out2 as far_conv_desc.act_scale_dev. */
 int far_grad_scale_f32(const float* x, long n, float* out2, far_stream_t stream);

@@ -478,6 +478,134 @@ def g16_eval_metrics():
     print('g16:', dict(zip(out['agg_keys'].tolist(), out['agg_vals'].tolist())))
 
 
+def five_point_samples(kind, n, seed):
+    """n calibrated five-point samples (float64) of two-view scenes: 'general' depths, 'two_planes' (3 + 2 points on two planes),
+    'plane' (five coplanar points).  Returns p1, p2 (n, 5, 2) and the true E (n, 3, 3), unit Frobenius norm."""
+    rng = np.random.default_rng(seed)
+    P1, P2, Et = [], [], []
+    for _ in range(n):
+        ang = rng.uniform(-0.4, 0.4, 3)
+        cx, sx, cy, sy, cz, sz = np.cos(ang[0]), np.sin(ang[0]), np.cos(ang[1]), np.sin(ang[1]), np.cos(ang[2]), np.sin(ang[2])
+        R = (np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]]) @ np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+             @ np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]]))
+        t = rng.uniform(-1, 1, 3)
+        X = np.stack([rng.uniform(-2, 2, 5), rng.uniform(-1.5, 1.5, 5), rng.uniform(3, 8, 5)], 1)
+        if kind == 'plane':
+            X[:, 2] = 5 + 0.2 * X[:, 0] - 0.1 * X[:, 1]
+        elif kind == 'two_planes':
+            X[:3, 2] = 5 + 0.3 * X[:3, 0]
+            X[3:, 2] = 4 - 0.2 * X[3:, 1]
+        X2 = X @ R.T + t
+        tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+        E = tx @ R
+        P1.append(X[:, :2] / X[:, 2:]); P2.append(X2[:, :2] / X2[:, 2:]); Et.append(E / np.linalg.norm(E))
+    return np.stack(P1), np.stack(P2), np.stack(Et)
+
+
+def g17_fivepoint():
+    """The reference's torch five-point solver and its loop.
+    (a) run_5point_our_kornia (third_party/prior_ransac/cv_geometry.py:861-1043) on committed five-point samples -- general,
+        two-plane and coplanar -- one sample per call (its singular_filter :959-961 drops samples from a batch without saying
+        which), in float64 (the function is dtype-agnostic; RANSAC feeds it float32) and in float32: the ten models per sample
+        (the real parts of ALL ten companion-matrix eigenvalues, :994: models of complex roots included, identity rows when a
+        sample is dropped).
+    (b) RANSAC(model_type='essential') (ransac.py:146-150: that solver, sample size 5, Sampson error) through RANSAC.forward
+        (:340-442) with `sample` replaced by committed index sets, as G12 does for the 8-point: models, remove_bad_models mask,
+        per-model inlier counts, best model, the three masks; once without and once with a prior.
+    kornia.geometry.solvers: multiply_deg_one_poly / multiply_deg_two_one_poly are tools/ref_shim.py restatements (NOTE below),
+    determinant_to_polynomial is the reference's own copy (cv_geometry.py:23-551)."""
+    cvg = ref_shim.bind_reference_solvers()
+    from ransac import RANSAC
+    out = {}
+    with torch.no_grad():
+        for kind, n, seed in (('general', 40, 171), ('two_planes', 20, 172), ('plane', 20, 173)):
+            p1, p2, Et = five_point_samples(kind, n, seed)
+            m64 = np.zeros((n, 10, 3, 3))
+            m32 = np.zeros((n, 10, 3, 3), np.float32)
+            for i in range(n):
+                a, b = torch.from_numpy(p1[i:i + 1]), torch.from_numpy(p2[i:i + 1])
+                try:
+                    m64[i] = cvg.run_5point_our_kornia(a, b, torch.ones(1, 5, dtype=torch.float64)).numpy().reshape(10, 3, 3)
+                except Exception as e:             # every sample of the batch filtered out: torch.cat of an empty list
+                    print('g17', kind, i, 'float64: no model:', type(e).__name__)
+                    m64[i] = np.eye(3)
+                try:
+                    m32[i] = cvg.run_5point_our_kornia(a.float(), b.float(), torch.ones(1, 5)).numpy().reshape(10, 3, 3)
+                except Exception as e:
+                    print('g17', kind, i, 'float32: no model:', type(e).__name__)
+                    m32[i] = np.eye(3)
+            out.update({f'{kind}_p1': p1, f'{kind}_p2': p2, f'{kind}_E_true': Et, f'{kind}_models64': m64, f'{kind}_models32': m32})
+            x1 = np.concatenate([p1, np.ones((n, 5, 1))], -1)
+            x2 = np.concatenate([p2, np.ones((n, 5, 1))], -1)
+            epi = np.abs(np.einsum('hsi,hkij,hsj->hks', x2, m64, x1)).max(-1)
+            d = np.minimum(np.abs(m64 - Et[:, None]).max((-1, -2)), np.abs(m64 + Et[:, None]).max((-1, -2))).min(1)
+            print(f'g17 {kind}: models with |x2^T E x1| < 1e-9 per sample: mean {float((epi < 1e-9).sum(1).mean()):.2f}; '
+                  f'truth among the models (1e-6): {100 * float((d < 1e-6).mean()):.1f} %')
+        # ---- (b) the loop
+        for tag, seed, with_prior in (('p', 177, True), ('n', 178, False)):
+            k0, k1, K, Rgt, tgt = two_view_scene(400, seed=seed, outlier_frac=0.3)
+            kn0 = ((torch.from_numpy(k0) - torch.from_numpy(K)[[0, 1], [2, 2]][None]) / torch.from_numpy(K)[[0, 1], [0, 1]][None]).numpy()
+            kn1 = ((torch.from_numpy(k1) - torch.from_numpy(K)[[0, 1], [2, 2]][None]) / torch.from_numpy(K)[[0, 1], [0, 1]][None]).numpy()
+            kp1, kp2 = torch.FloatTensor(kn0), torch.FloatTensor(kn1)
+            rng = np.random.default_rng(seed)
+            Hn = 96
+            samples = np.stack([rng.choice(len(k0), 5, replace=False) for _ in range(Hn)]).astype(np.int64)
+            ang = 0.05
+            dR = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]])
+            prior = np.concatenate([dR @ Rgt, (1.7 * tgt + 0.03)[:, None]], 1).astype(np.float32)
+            pcl = np.random.RandomState(0).uniform(low=-3.0, high=3.0, size=(300, 3)).astype(np.float32)
+            pp = {'rotation_pcl_error': True, 'rotation_error': False, 'K1': torch.eye(3), 'K2': torch.eye(3),
+                  'RT': torch.FloatTensor(prior.copy()), 'pcl': torch.FloatTensor(pcl), 'lambda': 0.3,
+                  'biased_sampling': 'biased'} if with_prior else {}
+            rs = RANSAC(model_type='essential', max_iter=1, inl_th=3e-7, prior_params=pp, max_lo_iters=0, batch_size=Hn,
+                        use_noexp_prior_scoring=with_prior, use_linear_bias_sampling=with_prior,
+                        **({'bias_sigma_sq': 0.1} if with_prior else {}))
+            seen = {}
+
+            def sample(sample_size, pop_size, batch_size, weight=None, device=None, _s=samples, _seen=seen):
+                assert sample_size == 5 and batch_size == len(_s)
+                _seen['weight'] = None if weight is None else weight.detach().clone()
+                return torch.from_numpy(_s)
+            rs.sample = sample
+            rbm = rs.remove_bad_models
+
+            def remove_bad_models(models, _seen=seen):
+                _seen['models_all'] = models.detach().clone()
+                diag = torch.diagonal(models, dim1=1, dim2=2)
+                _seen['keep'] = (diag.abs().min(dim=1)[0] > 1e-4)
+                return rbm(models)
+            rs.remove_bad_models = remove_bad_models
+            ver = rs.verify
+
+            def verify(kp1_, kp2_, models, inl_th, prior_score, _seen=seen, _rs=rs):
+                _seen['prior_score'] = prior_score.detach().clone()
+                errs = _rs.error_fn(kp1_[None].expand(len(models), -1, 2), kp2_[None].expand(len(models), -1, 2), models, squared=True)
+                _seen['count'] = (errs <= inl_th).sum(1)
+                tot = (errs <= inl_th).to(kp1_).sum(1) + prior_score.to(kp1_)
+                _seen['best_kept'] = int(tot.argmax())
+                _seen['score'] = tot.detach().clone()
+                _seen['err_best'] = errs[_seen['best_kept']].detach().clone()
+                return ver(kp1_, kp2_, models, inl_th, prior_score)
+            rs.verify = verify
+            E, inl, tight, ultra = rs.forward(kp1=kp1, kp2=kp2)
+            keep = seen['keep'].numpy()
+            assert len(seen['models_all']) == 10 * Hn, 'a sample was dropped by singular_filter: model <-> sample bookkeeping lost'
+            best_all = int(np.nonzero(keep)[0][seen['best_kept']])
+            out.update({f'{tag}_kpts0': k0, f'{tag}_kpts1': k1, f'{tag}_K': K, f'{tag}_samples': samples,
+                        f'{tag}_models': seen['models_all'].numpy(), f'{tag}_keep': keep,
+                        f'{tag}_prior_score': seen['prior_score'].numpy().astype(np.float32),
+                        f'{tag}_count': seen['count'].numpy(), f'{tag}_score': seen['score'].numpy(),
+                        f'{tag}_best': best_all, f'{tag}_E': E.numpy(), f'{tag}_inliers': inl.numpy().reshape(-1),
+                        f'{tag}_tight': tight.numpy().reshape(-1), f'{tag}_ultra': ultra.numpy().reshape(-1),
+                        f'{tag}_err_best': seen['err_best'].numpy(), f'{tag}_R_gt': Rgt, f'{tag}_t_gt': tgt})
+            if with_prior:
+                out.update({'p_prior': prior, 'p_pcl': pcl, 'p_bias_weight': seen['weight'].numpy()})
+            print(tag, 'models', len(keep), 'kept', int(keep.sum()), 'best', best_all, 'count', int(seen['count'][seen['best_kept']]),
+                  'inliers', int(inl.sum()), int(tight.sum()), int(ultra.sum()))
+    save('g17_fivepoint', note=NOTE_KORNIA + '; kornia.geometry.solvers.multiply_deg_one_poly / multiply_deg_two_one_poly restated in '
+         'tools/ref_shim.py, determinant_to_polynomial = the reference\'s own cv_geometry.py:23-551', **out)
+
+
 def g8_manifest(m):
     man = {k: list(v.shape) for k, v in m.state_dict().items()}
     with open(os.path.join(OUT, 'g8_state_dict_manifest.json'), 'w') as f:
@@ -512,6 +640,9 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'g12':
         g12_ransac_loop()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'g17':
+        g17_fivepoint()
+        sys.exit(0)
     g1_coarse()
     g9_metrics()
     g5_solver()
@@ -529,3 +660,4 @@ if __name__ == '__main__':
     g14_spvs_coarse()
     g15_losses()
     g16_eval_metrics()
+    g17_fivepoint()

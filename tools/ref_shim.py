@@ -14,6 +14,9 @@ restatements of its *published* definitions, so anything that depends on them is
   kornia.geometry.epipolar.{sampson_epipolar_distance, symmetrical_epipolar_distance,
                             essential_from_Rt}
   kornia.geometry.conversions.convert_points_to_homogeneous
+  kornia.geometry.solvers.{multiply_deg_one_poly, multiply_deg_two_one_poly}   (the monomial bookkeeping of Nister's five-point
+      solver; kornia.geometry.solvers.determinant_to_polynomial is bound to the reference's OWN copy of that function,
+      third_party/prior_ransac/cv_geometry.py:23-551, by bind_reference_solvers() -- not restated)
 """
 import sys
 import types
@@ -122,6 +125,59 @@ def _essential_from_Rt(R1, t1, R2, t2):
     return _cross_product_matrix(t[..., 0]) @ R
 
 
+def _multiply_deg_one_poly(a, b):
+    # kornia 0.7.1 kornia/geometry/solvers/polynomial_solver.py: two linear polynomials in (x, y, z, 1) ->
+    # the quadratic in (x^2, xy, xz, x, y^2, yz, y, z^2, z, 1)
+    return torch.stack([
+        a[:, 0] * b[:, 0],
+        a[:, 0] * b[:, 1] + a[:, 1] * b[:, 0],
+        a[:, 0] * b[:, 2] + a[:, 2] * b[:, 0],
+        a[:, 0] * b[:, 3] + a[:, 3] * b[:, 0],
+        a[:, 1] * b[:, 1],
+        a[:, 1] * b[:, 2] + a[:, 2] * b[:, 1],
+        a[:, 1] * b[:, 3] + a[:, 3] * b[:, 1],
+        a[:, 2] * b[:, 2],
+        a[:, 2] * b[:, 3] + a[:, 3] * b[:, 2],
+        a[:, 3] * b[:, 3],
+    ], dim=-1)
+
+
+def _multiply_deg_two_one_poly(a, b):
+    # kornia 0.7.1, same file: a quadratic (order above) times a linear polynomial -> the cubic in Nister's order
+    # (x^3, y^3, x^2 y, x y^2, x^2 z, x^2, y^2 z, y^2, xyz, xy, x z^2, xz, x, y z^2, yz, y, z^3, z^2, z, 1)
+    return torch.stack([
+        a[:, 0] * b[:, 0],
+        a[:, 4] * b[:, 1],
+        a[:, 0] * b[:, 1] + a[:, 1] * b[:, 0],
+        a[:, 1] * b[:, 1] + a[:, 4] * b[:, 0],
+        a[:, 0] * b[:, 2] + a[:, 2] * b[:, 0],
+        a[:, 0] * b[:, 3] + a[:, 3] * b[:, 0],
+        a[:, 4] * b[:, 2] + a[:, 5] * b[:, 1],
+        a[:, 4] * b[:, 3] + a[:, 6] * b[:, 1],
+        a[:, 1] * b[:, 2] + a[:, 2] * b[:, 1] + a[:, 5] * b[:, 0],
+        a[:, 1] * b[:, 3] + a[:, 3] * b[:, 1] + a[:, 6] * b[:, 0],
+        a[:, 2] * b[:, 2] + a[:, 7] * b[:, 0],
+        a[:, 2] * b[:, 3] + a[:, 3] * b[:, 2] + a[:, 8] * b[:, 0],
+        a[:, 3] * b[:, 3] + a[:, 9] * b[:, 0],
+        a[:, 5] * b[:, 2] + a[:, 7] * b[:, 1],
+        a[:, 5] * b[:, 3] + a[:, 6] * b[:, 2] + a[:, 8] * b[:, 1],
+        a[:, 6] * b[:, 3] + a[:, 9] * b[:, 1],
+        a[:, 7] * b[:, 2],
+        a[:, 7] * b[:, 3] + a[:, 8] * b[:, 2],
+        a[:, 8] * b[:, 3] + a[:, 9] * b[:, 2],
+        a[:, 9] * b[:, 3],
+    ], dim=-1)
+
+
+def bind_reference_solvers():
+    """kornia.geometry.solvers.determinant_to_polynomial := the reference's own copy (cv_geometry.py:23-551; its call site
+    :977 uses the kornia name, the local one is commented out at :978).  Call after install(); imports cv_geometry."""
+    import cv_geometry
+    sys.modules['kornia.geometry'].solvers.determinant_to_polynomial = cv_geometry.determinant_to_polynomial
+    cv_geometry.solvers.determinant_to_polynomial = cv_geometry.determinant_to_polynomial
+    return cv_geometry
+
+
 _installed = False
 
 
@@ -177,7 +233,8 @@ def install():
               'find_homography_lines_dlt', 'find_homography_lines_dlt_iterated']:
         setattr(kg, n, None)
     kg.symmetrical_epipolar_distance = _symmetrical_epipolar_distance
-    kg.solvers = types.SimpleNamespace()
+    kg.solvers = types.SimpleNamespace(multiply_deg_one_poly=_multiply_deg_one_poly,
+                                       multiply_deg_two_one_poly=_multiply_deg_two_one_poly)
     kge = _mk('kornia.geometry.epipolar')
     kge.sampson_epipolar_distance = _sampson_epipolar_distance
     kge.symmetrical_epipolar_distance = _symmetrical_epipolar_distance
