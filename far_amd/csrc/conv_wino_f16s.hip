@@ -24,20 +24,30 @@
 //    8h .. 8h+7 of its tile, so the split result IS the MFMA A operand of that lane: V never touches LDS.  (xi = 2 computes
 //    d1 - d2 = -V; its weights are packed negated.)
 //  * raw fp32 input: per 16-channel k-step the 18x18 pixel patch (20.25 KiB) comes in by LDS-DMA (global_load_lds_dwordx4) into
-//    a 2-slot ring; even and odd columns are stored apart and the four 16-byte channel quads of a pixel are XOR-swizzled by
+//    a 3-slot ring; even and odd columns are stored apart and the four 16-byte channel quads of a pixel are XOR-swizzled by
 //    (row >> 1) & 3 -- on the SOURCE address, the LDS image being lane-linear -- so that the transform's ds_read_b128 (lanes =
-//    tiles two pixels apart) are conflict free.
+//    tiles two pixels apart) are conflict free (measured: SQ_LDS_BANK_CONFLICT = 0; tools/wino_banks.py searches the layouts).
 //  * weights: per k-step and transform-row pair {0,1} / {2,3} one 32 KiB half-slab [xi][nu][co tile][plane][lane][8] in execution
 //    order (the global image IS the LDS image) into a 3-slot ring two intervals ahead; shared by the two tile blocks.
 //  * schedule: the waves 0-3 (xi = 0, 1) and 4-7 (xi = 2, 3) -- paired on the four SIMDs -- alternate roles every interval:
-//    one group issues its 24 MFMAs of k-step k while the other transforms its A operands (16 LDS reads, 64 fp32 adds, 48
-//    conversion instructions); one raw s_barrier per interval, counted vmcnt (the barrier never drains the DMA queue).
+//    one group issues its 24 MFMAs of k-step k, with the LDS-DMA requests behind them, while the other transforms its A operands
+//    (16 LDS reads, 64 scalar fp32 adds, 48 conversion instructions); one raw s_barrier per interval, counted vmcnt (the barrier
+//    never drains the request queue; the requests come from inline asm so that the compiler's wait insertion does not either).
 //  * epilogue: in-lane output transform over nu, the xi sums through LDS (128 KiB, the K-loop buffers are dead), scale / shift /
-//    residual / activation, 128-byte segments per pixel and wave store.
+//    residual / activation, 16-byte stores (256 contiguous bytes per pixel and workgroup).
 // Numerics: the input transform adds two roundings of 2^-24 to every A operand and the output transform sums nine products;
-// measured against a float64 convolution in tests/test_conv_gpu.py next to K9 (bar 2e-6 of max |ref|).
+// measured against a float64 convolution in tests/test_conv_gpu.py next to K9: 3.5e-7 of max |ref| (K9: 1.2e-6 -- fewer
+// accumulation steps per output), bar 2e-6.
 // No input scaling: |a| <= 16376 survives the split (|V| <= 4 |a|); beyond it the accumulators turn non-finite and the launch
 // raises the activation-overflow flag like K9 (the host then takes K9 with a lower activation exponent).
+//
+// STATUS (round 4): correct and deterministic, NOT dispatched by the model: 128 -> 128 @240x320 x 64 images runs in 3.1 ms
+// against K9's 3.45 ms (1.11x; the go / no-go bar was 1.3x), the 196-channel layers slower than K9's seven-tile mode (256 of
+// 196 output channels computed).  Where the time goes (tools/wino_timing*.py, tools/wino_pmc.sh): the matrix
+// pipe is busy 27 % -- 2.25x fewer MFMAs than K9 -- but a workgroup moves 84 KiB per k-step from L2 into LDS (weights 64 KiB:
+// 1.8x K9's traffic per output, because only 64 tiles x 64 channels of accumulators fit next to the 16 positions), every
+// request costs its wave ~55 cycles of issue stall (more when the in-order vector L1 is held up by the raw patches' HBM misses),
+// and with 160 KiB of LDS the rings reach only one to two intervals ahead of a ~2 us request latency under load.
 #include "common.h"
 #include <type_traits>
 
@@ -50,9 +60,14 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 constexpr int SLAB = 32768;                 // weight half-slab: 2 xi x 4 nu x 2 co tiles x 2 planes x 1 KiB
 constexpr int RAW_SLOTS = 18 * 18 * 4;      // 16-byte slots of one raw patch (pixel x channel quad)
-constexpr int RAWB = 24576;                 // raw ring slot (24 wave-DMAs of 1 KiB; the tail past RAW_SLOTS receives zeros)
+constexpr int RAW_PIECES = (RAW_SLOTS + 63) / 64;       // 21 wave-DMAs of 1 KiB (the tail of the last one receives zeros)
+constexpr int RAWB = RAW_PIECES * 1024;     // raw ring slot
 constexpr int RAW_OFF = 3 * SLAB;
-constexpr int SMEM = RAW_OFF + 2 * RAWB;    // 147456 B
+#ifdef FAR_WINO_TIMING2
+constexpr int SMEM = 163840;
+#else
+constexpr int SMEM = RAW_OFF + 3 * RAWB;    // 162816 B of the CU's 163840
+#endif
 constexpr int SMEM_EPI = 8 * 16384;         // Z exchange of the epilogue
 static_assert(SMEM_EPI <= SMEM, "epilogue exchange fits the loop buffers");
 
@@ -107,12 +122,22 @@ __device__ __forceinline__ void split8w(const float (&v)[8], f16x8& hi, f16x8& l
 
 #ifdef FAR_WINO_TIMING
 // Development instrumentation (tools/wino_timing.py; never defined in the product build): s_memtime stamps of waves 0 and 4 of
-// the first 4096 workgroups: [0] entry, [1] prologue done, [2 + 2 i] interval i work issued, [3 + 2 i] interval i barrier passed,
+// the first 4096 workgroups (every wave): [0] entry, [1] prologue done, [2 + 2 i] interval i work issued, [3 + 2 i] interval i barrier passed,
 // [60] K loop drained, [61] Z exchanged, [62] stores issued, [63] stores acknowledged.
-__device__ unsigned long long g_wino_stamps[4096 * 2 * 64];
-#define FAR_WINO_STAMP(i) do { if ((threadIdx.x & 255) == 0 && blockIdx.x < 4096) g_wino_stamps[(blockIdx.x * 2 + (threadIdx.x >> 8)) * 64 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ unsigned long long g_wino_stamps[4096 * 8 * 64];
+#define FAR_WINO_STAMP(i) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096) g_wino_stamps[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 64 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define FAR_WINO_STAMP(i) do {} while (0)
+#endif
+#ifdef FAR_WINO_TIMING2
+// Second instrumentation (tools/wino_timing2.py): s_memtime stamps of k-steps 2 and 3 kept in the last KiB of LDS (no memory traffic
+// that would disturb the request queue), copied out at the end: per wave 16 stamps: [8 (k - 2) + e], e = 0 interval start, 1 work done,
+// 2 requests waited for, 3 barrier passed, 4 work done (odd interval), 5 requests waited for, 6 barrier passed.
+__device__ unsigned long long g_wino_stamps2[4096 * 8 * 16];
+#define FAR_WINO_T2(k, e) do { if ((k) >= 2 && (k) < 4 && (threadIdx.x & 63) == 0) \
+    *reinterpret_cast<volatile unsigned long long*>(smem + 162816 + (threadIdx.x >> 6) * 128 + (8 * ((k) - 2) + (e)) * 8) = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FAR_WINO_T2(k, e) do {} while (0)
 #endif
 #ifndef FAR_WINO_EXP
 #define FAR_WINO_EXP 0      // experiment builds only (tools/wino_exp.sh): 1 no transform, 2 no MFMAs, 4 no weight requests, 8 no raw
@@ -155,58 +180,59 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p) {
     }
 
     // ---- requests.  All LDS-DMA pieces (1 KiB per wave instruction) are issued by the group that is MULTIPLYING in the
-    // interval, one piece behind every second or third MFMA (the matrix pipe leaves its wave's issue slots free; in front of a
-    // transform they cost that wave ~100 cycles apiece): per interval the 32 pieces of one weight half-slab (8 per wave), in the
-    // odd intervals also the 24 pieces of one raw patch (6 per wave of the xi = 2, 3 group).
-    // Weight half-slabs: slab i = 2 k + half of the k-step sequence, which starts at k0 and wraps (FAR_WINO_EXP & 64: k0 from the
-    // tile block's position).
+    // interval, behind its MFMAs (the matrix pipe leaves its wave's issue slots free; in front of a transform they cost that
+    // wave ~100 cycles apiece): per interval the 32 pieces of one weight half-slab (8 per wave, behind the first eight MFMAs),
+    // in the even intervals also the 21 pieces of a raw patch (6 per wave of the xi = 0, 1 group -- the older waves, which win the
+    // issue arbitration on their SIMDs and finish their 24 MFMAs first).
+    // Weight half-slabs: slab i = 2 k + half is read in interval i, from ring slot i % 3.
     const int wsel = wave & 3;                      // this wave among the four of its group
     const int nslab = 2 * nk;
-    const int k0 = (FAR_WINO_EXP & 64) ? (bx * 3 + by * 5 + cb * 7) % nk : 0;
     const unsigned char* const wbase = p.w + (size_t)cb * nslab * SLAB + wsel * 1024 + lane * 16;
     const unsigned bs_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(lptr_t)(Bs + wsel * 1024));
-    const unsigned rs_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(lptr_t)(Rs + wsel * 1024));
+    const unsigned rs_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(lptr_t)Rs);
     auto slab_src = [&](int slab) {                 // this lane's source of piece 0 of a slab (past the end: the last slab again)
         const int i = slab < nslab ? slab : nslab - 1;
-        int kk = k0 + (i >> 1);
-        kk = kk >= nk ? kk - nk : kk;
-        return wbase + (size_t)(2 * kk + (i & 1)) * SLAB;
+        return wbase + (size_t)i * SLAB;
     };
     auto b_piece = [&](const unsigned char* src0, int slot, int j) {          // piece j (0..7) of this wave
         if (!(FAR_WINO_EXP & 4)) glds16(src0 + j * 4096, bs_base + slot * SLAB + j * 4096);
     };
 
-    // ---- raw patch: slot S = ((piece j 0..5) x 4 waves + wsel) x 64 + lane; S -> (pixel index', quad') -> source address.  Only the
-    // xi = 2, 3 group requests raw patches (in its multiplying intervals).
-    const char* rsrc[6];
-    int rinc[6];
-    bool rtail[6];
+    // ---- raw patch of a k-step (16 channels of the 18 x 18 pixels) in a 3-slot ring: 16-byte slot S = 4 index' + quad',
+    // index' = 18 row + 9 (col & 1) + (col >> 1) (even and odd columns apart), quad' = quad ^ ((row >> 1) & 3); the swizzle is on
+    // the SOURCE address (the LDS image of a request is lane-linear).  Piece pc = 4 j + wsel, j < 6, of the xi = 0, 1 waves; a
+    // wave's slots past the 21 pieces repeat its first piece (the same request twice: harmless, and every wave issues exactly six,
+    // which the counted waits rely on).
+    constexpr int NRP = 6;
+    const char* rsrc[NRP];
+    int rinc[NRP], rpiece[NRP];
+    unsigned rtailm = 0;                            // bit j: the lane's quad lies beyond Cin in the last k-step
     const int rem_ch = p.Cin - 16 * (nk - 1);       // channels of the last k-step (1..16)
-    if (Q) {
+    if (!Q) {
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const int S = (j * 4 + wsel) * 64 + lane;
-            int idx = S >> 2, sp = S & 3;
-            if (FAR_WINO_EXP & 256) { idx = S >> 3; sp = S & 7; }       // experiment: whole 128-byte lines (same bytes, wrong data)
+        for (int j = 0; j < NRP; ++j) {
+            int pc = 4 * j + wsel;
+            if (pc >= RAW_PIECES) pc = wsel;
+            rpiece[j] = pc;
+            const int S = pc * 64 + lane;
+            const int idx = S >> 2, sp = S & 3;
             const int prow = idx / 18, rem = idx - prow * 18;
-            int pcol = rem < 9 ? 2 * rem : 2 * (rem - 9) + 1;
-            if (FAR_WINO_EXP & 256) pcol = rem;
-            const int quad = (FAR_WINO_EXP & 256) ? sp : sp ^ ((prow >> 1) & 3);
+            const int pcol = rem < 9 ? 2 * rem : 2 * (rem - 9) + 1;
+            const int quad = sp ^ ((prow >> 1) & 3);
             const int iy = oy0 - 1 + prow, ix = ox0 - 1 + pcol;
-            const bool ok = ((FAR_WINO_EXP & 256) || S < RAW_SLOTS) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            const bool ok = S < RAW_SLOTS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
             const long pix = ((long)img * p.H + iy) * p.W + ix;
             rsrc[j] = ok ? reinterpret_cast<const char*>(p.x + pix * p.Cin + 4 * quad) : reinterpret_cast<const char*>(p.zeros);
-            rinc[j] = ok ? ((FAR_WINO_EXP & 256) ? 128 : 64) : 0;
-            rtail[j] = 4 * quad >= rem_ch;
+            rinc[j] = ok ? 64 : 0;
+            if (4 * quad >= rem_ch) rtailm |= 1u << j;
         }
     }
     auto raw_piece = [&](int rk, int slot, int j) {                           // piece j (0..5) of raw patch rk
-        if (!Q) return;
-        int kk = k0 + (rk < nk ? rk : nk - 1);
-        kk = kk >= nk ? kk - nk : kk;
-        const bool tail = kk == nk - 1;             // wave-uniform
-        const char* s = (tail && rtail[j]) ? reinterpret_cast<const char*>(p.zeros) : rsrc[j] + (long)kk * rinc[j];
-        if (!(FAR_WINO_EXP & 8)) glds16(s, rs_base + slot * RAWB + j * 4096);
+        if (Q) return;
+        const int kk = rk < nk ? rk : nk - 1;       // past the end: the last patch again, into a slot nobody reads
+        const bool tail = kk == nk - 1 && ((rtailm >> j) & 1u);
+        const char* s = tail ? reinterpret_cast<const char*>(p.zeros) : rsrc[j] + (long)kk * rinc[j];
+        if (!(FAR_WINO_EXP & 8)) glds16(s, rs_base + slot * RAWB + rpiece[j] * 1024);
     };
 
     // ---- transform addressing: lane (tile m = l31: row tyl = m >> 3 of the block's four, column tx = m & 7; k-group h)
@@ -238,30 +264,43 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p) {
             return;
         }
         const unsigned char* R0 = Rs + slot * RAWB;
-        // everything in channel PAIRS (the halves of the 16-byte LDS reads are register pairs already): packed fp32 adds, the packed
-        // conversion, one v_fma_mix per lo half -- no register shuffling in between
-        f32x2 R[4][4];
-        const f32x2 sb2 = {sb, sb};
+        // Scalar fp32 instructions from inline asm on purpose: next to a wave that issues MFMAs, v_pk_fma_f32 waits for a gap in the
+        // matrix pipe (tools/ubench/valu_cost.hip: 370 cycles per instruction against 5 alone) and the packed adds cost more than
+        // the two scalar ones; left to itself the compiler packs every pair.  All sixteen reads first.
+        f32x4 raw[4][4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int co = (c & 1) * (9 * 64) + (c >> 1) * 64;
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(R0 + aoff[0][0] + co);
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(R0 + aoff[0][1] + co);
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(R0 + aoff[1][0] + co);
-            const f32x4 b1 = *reinterpret_cast<const f32x4*>(R0 + aoff[1][1] + co);
-            R[c][0] = __builtin_elementwise_fma(b0.xy, sb2, a0.xy);
-            R[c][1] = __builtin_elementwise_fma(b0.zw, sb2, a0.zw);
-            R[c][2] = __builtin_elementwise_fma(b1.xy, sb2, a1.xy);
-            R[c][3] = __builtin_elementwise_fma(b1.zw, sb2, a1.zw);
+            raw[c][0] = *reinterpret_cast<const f32x4*>(R0 + aoff[0][0] + co);
+            raw[c][1] = *reinterpret_cast<const f32x4*>(R0 + aoff[0][1] + co);
+            raw[c][2] = *reinterpret_cast<const f32x4*>(R0 + aoff[1][0] + co);
+            raw[c][3] = *reinterpret_cast<const f32x4*>(R0 + aoff[1][1] + co);
         }
+        float Rr[4][8];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float a = raw[c][e >> 2][e & 3], b = raw[c][2 + (e >> 2)][e & 3];
+                asm("v_fma_f32 %0, %1, %2, %3" : "=v"(Rr[c][e]) : "v"(b), "v"(sb), "v"(a));
+            }
 #pragma unroll
         for (int pr = 0; pr < 4; ++pr) {
-            const f32x2 v0 = R[0][pr] - R[2][pr], v1 = R[1][pr] + R[2][pr], v2 = R[2][pr] - R[1][pr], v3 = R[1][pr] - R[3][pr];
-            f16x2 h, l;
-            split_pair<MIX>(v0.x, v0.y, h, l); Ah[0][pr] = __builtin_bit_cast(unsigned, h); Al[0][pr] = __builtin_bit_cast(unsigned, l);
-            split_pair<MIX>(v1.x, v1.y, h, l); Ah[1][pr] = __builtin_bit_cast(unsigned, h); Al[1][pr] = __builtin_bit_cast(unsigned, l);
-            split_pair<MIX>(v2.x, v2.y, h, l); Ah[2][pr] = __builtin_bit_cast(unsigned, h); Al[2][pr] = __builtin_bit_cast(unsigned, l);
-            split_pair<MIX>(v3.x, v3.y, h, l); Ah[3][pr] = __builtin_bit_cast(unsigned, h); Al[3][pr] = __builtin_bit_cast(unsigned, l);
+            float v[4][2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int ch = 2 * pr + e;
+                asm("v_sub_f32 %0, %1, %2" : "=v"(v[0][e]) : "v"(Rr[0][ch]), "v"(Rr[2][ch]));
+                asm("v_add_f32 %0, %1, %2" : "=v"(v[1][e]) : "v"(Rr[1][ch]), "v"(Rr[2][ch]));
+                asm("v_sub_f32 %0, %1, %2" : "=v"(v[2][e]) : "v"(Rr[2][ch]), "v"(Rr[1][ch]));
+                asm("v_sub_f32 %0, %1, %2" : "=v"(v[3][e]) : "v"(Rr[1][ch]), "v"(Rr[3][ch]));
+            }
+#pragma unroll
+            for (int nu = 0; nu < 4; ++nu) {
+                f16x2 h, l;
+                split_pair<MIX>(v[nu][0], v[nu][1], h, l);
+                Ah[nu][pr] = __builtin_bit_cast(unsigned, h); Al[nu][pr] = __builtin_bit_cast(unsigned, l);
+            }
         }
     };
 
@@ -306,7 +345,7 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p) {
                 bool any = false;
 #pragma unroll
                 for (int i = 0; i < NP; ++i)
-                    if ((i * 24) / NP == mi) { piece(i); any = true; }
+                    if ((i < 8 ? i : 9 + 2 * (i - 8)) == mi) { piece(i); any = true; }
                 if (any) __builtin_amdgcn_sched_barrier(0);        // the request stays behind this MFMA
             }
         }
@@ -318,9 +357,9 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) b_piece(s0, Q ? 1 : 0, j);
 #pragma unroll
-        for (int j = 0; j < 6; ++j) raw_piece(0, 0, j);
+        for (int j = 0; j < NRP; ++j) raw_piece(0, 0, j);
 #pragma unroll
-        for (int j = 0; j < 6; ++j) raw_piece(1, 1, j);
+        for (int j = 0; j < NRP; ++j) raw_piece(1, 1, j);
     }
     FAR_WINO_STAMP(0);
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
@@ -328,46 +367,75 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p) {
     if (!Q) transform(0);
     FAR_WINO_STAMP(1);
 
-    // ---- K loop: two intervals per k-step.  Interval 2k: waves 0-3 multiply k-step k (slab 2k) and request slab 2k+2, waves 4-7
-    // transform k-step k; interval 2k+1: waves 4-7 multiply (slab 2k+1) and request slab 2k+3 and raw patch k+2, waves 0-3 transform
-    // k-step k+1.  Slab i sits in ring slot i % 3 (slab i+3 is requested in interval i+1, after its last reader), raw patch k in
-    // slot k % 2 (patch k+2 is requested in interval 2k+1; patch k is last read in interval 2k, by the xi = 2, 3 transform).  A wave's
-    // requests are one interval old at the end of its transform interval: it waits for all of them there (vmcnt(0)) and they are
-    // visible to everybody behind that barrier -- the slab's readers start right there, the raw patch's one interval later.
+    // ---- K loop: two intervals per k-step.  Interval 2k: waves 0-3 multiply k-step k (slab 2k) and request slab 2k+2, then raw
+    // patch k+2; waves 4-7 transform k-step k.  Interval 2k+1: waves 4-7 multiply (slab 2k+1) and request slab 2k+3; waves 0-3
+    // transform k-step k+1.  Slab i sits in ring slot i % 3 (slab i+3 is requested in interval i+1, after its last reader), raw
+    // patch k in slot k % 3 (patch k+3 is requested in interval 2k+2; patch k is last read in interval 2k).
+    // Waits (vmcnt retires in order; a wave never waits for a request younger than one interval):
+    //   waves 0-3, end of a multiplying interval: vmcnt(14) -- all but this interval's 8 + 6 requests: the raw patch requested
+    //     two intervals ago has landed, one interval before its first reader starts;
+    //   waves 0-3, end of a transforming interval: vmcnt(6) -- the slab requested in the interval before, which is read next;
+    //   waves 4-7, end of a transforming interval: vmcnt(0) -- their slab of the interval before; multiplying: none.
     int slot_e = 0, slot_o = 1;                     // ring slots of slabs 2k, 2k+1
+    int rs0 = 0, rs1 = 1, rs2 = 2;                  // ring slots of raw patches k, k+1, k+2
     for (int k = 0; k < nk; ++k) {
         const int slot_n = 3 - slot_e - slot_o;     // the third slot: slab 2k+2
         if (!Q) {
             const unsigned char* sn = slab_src(2 * k + 2);
-            mma(slot_e, std::integral_constant<int, 8>{}, [&](int i) { b_piece(sn, slot_n, i); });
+            mma(slot_e, std::integral_constant<int, 14>{}, [&](int i) {
+                if (i < 8) b_piece(sn, slot_n, i);
+                else raw_piece(k + 2, rs2, i - 8);
+            });
         } else {
-            transform(k & 1);
+            transform(rs0);
         }
         __builtin_amdgcn_sched_barrier(0);          // the interval's work stays on this side of the barrier
         if (k < 14) FAR_WINO_STAMP(2 + 4 * k);
-        if (Q) asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        FAR_WINO_T2(k, 1);
+#ifdef FAR_WINO_TIMING2
+        if (Q) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+        FAR_WINO_T2(k, 2);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+        if (Q || (FAR_WINO_EXP & 32)) asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(14)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
         if (k < 14) FAR_WINO_STAMP(3 + 4 * k);
+        FAR_WINO_T2(k, 3);
         __builtin_amdgcn_sched_barrier(0);
         if (Q) {
             const unsigned char* sn = slab_src(2 * k + 3);
-            mma(slot_o, std::integral_constant<int, 14>{}, [&](int i) {
-                if (i < 8) b_piece(sn, slot_e, i);                 // slab 2k+3 -> the slot slab 2k just left
-                else raw_piece(k + 2, k & 1, i - 8);               // raw patch k+2 -> the slot patch k just left
-            });
+            mma(slot_o, std::integral_constant<int, 8>{}, [&](int i) { b_piece(sn, slot_e, i); });       // -> the slot slab 2k just left
         } else if (k + 1 < nk) {
-            transform((k + 1) & 1);
+            transform(rs1);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (k < 14) FAR_WINO_STAMP(4 + 4 * k);
-        if (!Q) asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        FAR_WINO_T2(k, 4);
+#ifdef FAR_WINO_TIMING2
+        if (!Q) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        FAR_WINO_T2(k, 5);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+        if (FAR_WINO_EXP & 32) asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else if (!Q) asm volatile("s_waitcnt vmcnt(6)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
         if (k < 14) FAR_WINO_STAMP(5 + 4 * k);
+        FAR_WINO_T2(k, 6);
+        FAR_WINO_T2(k + 1, 0);
         __builtin_amdgcn_sched_barrier(0);
         slot_o = slot_e;                            // slab 2k+3 took the slot slab 2k left
         slot_e = slot_n;                            // slab 2k+2
+        const int t0 = rs0;
+        rs0 = rs1; rs1 = rs2; rs2 = t0;             // raw patch k+3 takes the slot patch k left
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // trailing requests landed before LDS is reused
+#ifdef FAR_WINO_TIMING2
+    if (blockIdx.x < 4096 && (threadIdx.x & 63) < 16)
+        g_wino_stamps2[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (threadIdx.x & 63)] =
+            *reinterpret_cast<volatile unsigned long long*>(smem + 162816 + (threadIdx.x >> 6) * 128 + (threadIdx.x & 63) * 8);
+#endif
     FAR_WINO_STAMP(60);
     if (FAR_WINO_EXP & 16) {
         float tsum = 0.f;
@@ -595,9 +663,14 @@ int far_conv3x3_wino_f32(const far_conv_desc* desc, hipStream_t stream) {
     return far_check_launch();
 }
 
+#ifdef FAR_WINO_TIMING2
+int far_wino_timing2_dump(void* host, int nblocks) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wino_stamps2), (size_t)nblocks * 8 * 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -5;
+}
+#endif
 #ifdef FAR_WINO_TIMING
 int far_wino_timing_dump(void* host, int nblocks) {
-    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wino_stamps), (size_t)nblocks * 2 * 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -5;
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wino_stamps), (size_t)nblocks * 8 * 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -5;
 }
 #endif
 

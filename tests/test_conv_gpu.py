@@ -526,3 +526,78 @@ def test_pack_table_repacks_every_training_image_like_a_fresh_pack():
         same(images(), fresh())
     finally:
         ops.USE_PACK_TABLE = True
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# K17: Winograd F(2x2, 3x3) on split-fp16 operands (far_conv3x3_wino_f32) -- the same contract as K9's stride-1 3x3 mode
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('N,H,W,Cin,Cout', [
+    (1, 16, 16, 16, 64),             # one tile block, one k-step
+    (2, 24, 40, 32, 64),
+    (3, 30, 37, 196, 196),           # ragged tile blocks, a partial last k-step (196 = 12 x 16 + 4), 4 channel blocks (256 > 196)
+    (1, 17, 16, 128, 128),
+    (2, 9, 50, 256, 196),
+    (1, 5, 7, 196, 128),             # smaller than one tile block
+    (1, 33, 18, 20, 4),              # Cin, Cout far below a block
+])
+def test_conv_winograd_matches_float64(N, H, W, Cin, Cout):
+    """K17 against a float64 convolution, next to K9 on the same tensors: the go / no-go bar of the Winograd kernel was
+    2e-6 of max |ref| (measured 2-4e-7: fewer accumulation steps per output than the direct kernel's 9 Cin)."""
+    ops = _ops()
+    g = torch.Generator(device='cuda').manual_seed(N * 1000 + Cin + Cout)
+    x = (torch.randn(N, H, W, Cin, device='cuda', generator=g) * 1.5).relu_()
+    w = torch.randn(Cout, Cin, 3, 3, device='cuda', generator=g) * (2.0 / (Cin * 9)) ** 0.5
+    scale = torch.rand(Cout, device='cuda', generator=g) + 0.5
+    shift = torch.randn(Cout, device='cuda', generator=g) * 0.1
+    res = torch.randn(N, H, W, Cout, device='cuda', generator=g)
+    ref_bn = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), padding=1).permute(0, 2, 3, 1) * scale.double() + shift.double()
+    pw, pc = ops.PackedWino(w, scale, shift), ops.PackedConv(w, scale, shift)
+    ops.overflow_flag('cuda').zero_()
+    for act, residual in (('none', None), ('relu', res), ('leaky', None)):
+        y = ops.conv3x3_wino(x, pw, residual=residual, act=act, slope=0.01)
+        r = ref_bn + (residual.double() if residual is not None else 0)
+        r = {'none': lambda t: t, 'relu': torch.relu, 'leaky': lambda t: F.leaky_relu(t, 0.01)}[act](r)
+        emax, erms = _rel(y, r)
+        kmax, _ = _rel(ops.conv_nhwc(x, pc, residual=residual, act=act, slope=0.01), r)
+        assert emax < 2e-6 and erms < 1e-6, (act, emax, erms)
+        assert emax < 2.5 * kmax + 2e-7, (act, emax, kmax)          # never worse than the direct kernel by more than noise
+    assert not ops.activation_overflowed('cuda')
+
+
+def test_conv_winograd_is_deterministic_and_independent_of_the_batch():
+    """Run-to-run bit equality over many launches (the request rings are waited for by counting: a stale LDS read would show
+    as a difference in some workgroups of some launches), and image n of a batch == the same image alone."""
+    ops = _ops()
+    g = torch.Generator(device='cuda').manual_seed(5)
+    x = torch.randn(16, 64, 96, 128, device='cuda', generator=g).relu_()
+    w = torch.randn(128, 128, 3, 3, device='cuda', generator=g) * 0.03
+    pw = ops.PackedWino(w)
+    y0 = ops.conv3x3_wino(x, pw, act='relu')
+    for _ in range(20):
+        assert torch.equal(ops.conv3x3_wino(x, pw, act='relu'), y0)
+    for n in (0, 7, 15):
+        assert torch.equal(ops.conv3x3_wino(x[n:n + 1].contiguous(), pw, act='relu')[0], y0[n])
+
+
+def test_conv_winograd_activation_range_flag():
+    """|a| <= 16376 survives K17's unscaled split (the transformed operand is at most 4 |a|); beyond it the launch raises the
+    device flag like K9, and the entry point refuses an activation exponent below 0 (the host then uses K9)."""
+    from far_amd import _lib
+    ops = _ops()
+    g = torch.Generator(device='cuda').manual_seed(9)
+    x = torch.randn(1, 16, 16, 32, device='cuda', generator=g)
+    w = torch.randn(64, 32, 3, 3, device='cuda', generator=g) * 0.05
+    pw = ops.PackedWino(w)
+    ops.overflow_flag('cuda').zero_()
+    x[0, 3, 3, 5] = 16000.0
+    y = ops.conv3x3_wino(x, pw)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), padding=1).permute(0, 2, 3, 1)
+    assert not ops.activation_overflowed('cuda') and _rel(y, ref)[0] < 2e-6
+    x[0, 3, 3, 5] = 40000.0
+    ops.conv3x3_wino(x, pw)
+    assert ops.activation_overflowed('cuda')
+    with ops.activation_exponent(-4):
+        y = ops.conv3x3_wino(x, pw)          # the wrapper clamps the exponent it passes to 0: same launch, flag again
+    assert ops.activation_overflowed('cuda')
+    with pytest.raises(_lib.FarHipError):
+        ops.conv3x3_wino(x[..., :30].contiguous(), ops.PackedWino(w[:, :28].contiguous()))      # channel count mismatch

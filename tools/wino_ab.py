@@ -1,5 +1,6 @@
 """K17 (Winograd F(2x2,3x3), split fp16) against K9 and a float64 convolution: errors on small shapes, then same-box timings
 at the bench shapes (64 images).  Usage: python tools/wino_ab.py [--quick] [--no-time]"""
+import os
 import sys
 sys.path.insert(0, '.')
 import torch
@@ -43,7 +44,7 @@ def check(N, H, W, ci, co, seed=0, mix=0):
     lib.far_set_tuning(8, 0)
 
 
-for mix in (1, 0):
+for mix in (() if os.environ.get('WINO_NOCHECK') else (1, 0)):
     check(1, 16, 16, 16, 64, mix=mix)
     check(1, 16, 16, 32, 32, mix=mix)
     check(2, 24, 40, 32, 64, mix=mix)
@@ -63,7 +64,8 @@ if '--no-time' not in sys.argv:
     if quick:
         shapes = {'128->128 @240x320': (240, 320, 128, 128)}
     for label, (H, W, ci, co) in shapes.items():
-        x = torch.randn(64, H, W, ci, device='cuda', generator=g).relu_()
+        NB = int(os.environ.get('WINO_N', '64'))
+        x = torch.randn(NB, H, W, ci, device='cuda', generator=g).relu_()
         w = torch.randn(co, ci, 3, 3, device='cuda', generator=g) * (2.0 / (ci * 9)) ** 0.5
         pc = ops.PackedConv(w, torch.ones(co, device='cuda'), torch.zeros(co, device='cuda'))
         pw = ops.PackedWino(w, torch.ones(co, device='cuda'), torch.zeros(co, device='cuda'))
@@ -75,6 +77,6 @@ if '--no-time' not in sys.argv:
             lib.far_set_tuning(8, 1)
             tw5.append(bench.event_time_ms(lambda: ops.conv3x3_wino(x, pw, act='relu'), iters=5, warm=2))
             lib.far_set_tuning(8, 0)
-        fl = 2.0 * 64 * H * W * ci * co * 9
-        print(f'{label}: K9 {min(tk):.3f} ms  K17 {min(tw):.3f} ms (split2: {min(tw5):.3f})  speedup {min(tk) / min(tw):.2f}x  '
+        fl = 2.0 * NB * H * W * ci * co * 9
+        print(f'{label} x{NB}: K9 {min(tk):.3f} ms  K17 {min(tw):.3f} ms (split2: {min(tw5):.3f})  speedup {min(tk) / min(tw):.2f}x  '
               f'-> {fl / min(tw) / 1e9:.1f} TFLOP/s direct-equivalent = {fl / min(tw) / 1e9 / 2500:.4f} of peak', flush=True)

@@ -12,6 +12,10 @@ for e in ${FAR_WINO_EXPS:-1 2 3 4 8 12 16 32}; do
 done
 ( /opt/rocm/bin/hipcc $FL -DFAR_WINO_TIMING -c far_amd/csrc/conv_wino_f16s.hip -o far_amd/lib/exp/wino_timing.o.tmp && \
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o far_amd/lib/exp/libfar_timing.so $OBJS far_amd/lib/exp/wino_timing.o.tmp ) &
+for e in ${FAR_WINO_TEXPS:-}; do
+  ( /opt/rocm/bin/hipcc $FL -DFAR_WINO_TIMING -DFAR_WINO_EXP=$e -c far_amd/csrc/conv_wino_f16s.hip -o far_amd/lib/exp/wino_texp$e.o.tmp && \
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o far_amd/lib/exp/libfar_timing_exp$e.so $OBJS far_amd/lib/exp/wino_texp$e.o.tmp ) &
+done
 wait
 rm -f far_amd/lib/exp/*.tmp
 ls -la far_amd/lib/exp

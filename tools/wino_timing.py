@@ -17,7 +17,7 @@ for _ in range(3):
     ops.conv3x3_wino(x, pw, act='relu')
 torch.cuda.synchronize()
 NB = 4096
-buf = np.zeros((NB, 2, 64), dtype=np.uint64)
+buf = np.zeros((NB, 8, 64), dtype=np.uint64)
 fn = lib.far_wino_timing_dump
 fn.restype = ctypes.c_int
 fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -25,7 +25,7 @@ assert fn(buf.ctypes.data_as(ctypes.c_void_p), NB) == 0
 t = buf[1024:].astype(np.int64)
 nk = (ci + 15) // 16
 nki = min(nk, 14)
-for wsel, name in ((0, 'wave 0 (xi 0: multiplies in even intervals)'), (1, 'wave 4 (xi 2: multiplies in odd intervals)')):
+for wsel, name in [(w, f'wave {w} (xi {w >> 1}, tile block {w & 1}: multiplies in {"even" if w < 4 else "odd"} intervals)') for w in range(8)]:
     s = t[:, wsel, :]
     tot = s[:, 63] - s[:, 0]
     print(f'{name}: lifetime {tot.mean():.0f} cycles (min {tot.min()}, max {tot.max()})')
