@@ -589,11 +589,11 @@ def test_conv_winograd_activation_range_flag():
     w = torch.randn(64, 32, 3, 3, device='cuda', generator=g) * 0.05
     pw = ops.PackedWino(w)
     ops.overflow_flag('cuda').zero_()
-    x[0, 3, 3, 5] = 16000.0
+    x[0, 2:4, 2:4, 5] = 16000.0          # a whole 2 x 2 tile: one transformed operand is the sum of the four
     y = ops.conv3x3_wino(x, pw)
     ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), padding=1).permute(0, 2, 3, 1)
     assert not ops.activation_overflowed('cuda') and _rel(y, ref)[0] < 2e-6
-    x[0, 3, 3, 5] = 40000.0
+    x[0, 2:4, 2:4, 5] = 17000.0          # 4 x 17000 > 65504: the fp16 hi part of that operand is inf
     ops.conv3x3_wino(x, pw)
     assert ops.activation_overflowed('cuda')
     with ops.activation_exponent(-4):
