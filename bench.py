@@ -48,6 +48,8 @@ def parse():
                     help='backbone convolution arithmetic (far_amd.loftr.LoFTR.set_precision): fp32 = split-fp16 operand pairs (fp32-grade)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-other-modes', action='store_true', help='skip the informational fp16-operand leg of the default run')
+    ap.add_argument('--no-other-workloads', action='store_true',
+                    help='skip the short legs of the other BASELINE configs (c3, c4, c5) and the one-pair latency leg of the default run')
     ap.add_argument('--cpu-pairs', type=int, default=3)
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help="torch.distributed backend of the N > 1 run ('nccl' is RCCL on ROCm; 'gloo' only for the CPU self-test)")
@@ -206,6 +208,58 @@ def pmc_traffic(kernel_label, n_pairs, precision):
     return None if ent is None else {'bytes': ent['total_bytes'], 'read_bytes': ent['read_bytes'],
                                      'write_bytes': ent['write_bytes'], 'precision': doc.get('precision', 'fp32'),
                                      'source': os.path.relpath(path, ROOT), 'commit': doc.get('commit')}
+
+
+def rocprof_launch_ms(kernel_label):
+    """Average duration of the roofline launch in the newest committed rocprofv3 kernel trace (profiles/r*_bench_fp32_kernel_trace.txt,
+    the `roofline_launch_rocprof:` line tools/profile_report.py writes, or the per-grid table of the round 1-2 files), so that the
+    HIP-event time measured here and the profiler's average for the same launch stand next to each other.  A COMMITTED measurement
+    (another run, maybe another box and build): the entry names its file."""
+    import glob
+    import re
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_bench_fp32_kernel_trace.txt')), reverse=True):
+        txt = open(path).read()
+        m = re.search(r'roofline_launch_rocprof: kernel=' + re.escape(kernel_label) + r' calls=(\d+) avg_us=([0-9.]+)', txt)
+        if m is None and kernel_label == 'k_conv[K9 3x3 196->196 @240x320]':
+            m = re.search(r'grid \(9830400, 1, 1\) calls (\d+)\s+avg ([0-9.]+) us', txt)
+        if m:
+            return {'ms': round(float(m.group(2)) / 1e3, 3), 'calls': int(m.group(1)), 'source': os.path.relpath(path, ROOT)}
+    return None
+
+
+def other_workloads(a):
+    """Short legs of the other BASELINE configs and of the reference's deployment shape (one pair per step), each as a child process
+    started AFTER this process has finished its own timing (python bench.py --workload ...: its own line, parsed here), so that
+    every workload number is in the line the driver records.  Informational: never `value`."""
+    import subprocess
+    legs = [('c3_training_step', ['--workload', 'c3', '--steps', '5', '--warmup', '3']),
+            ('c4_cached_path', ['--workload', 'c4', '--steps', '3', '--warmup', '2']),
+            ('c5_mapfree_544x720', ['--workload', 'c5', '--steps', '3', '--warmup', '2']),
+            ('c2_one_pair_latency', ['--pairs', '1', '--steps', '20', '--warmup', '5'])]
+    out = {}
+    for name, args in legs:
+        cmd = [sys.executable, os.path.abspath(__file__)] + args + ['--hyp', str(a.hyp), '--no-cpu-baseline', '--no-other-modes',
+                                                                  '--no-other-workloads']
+        t0 = time.perf_counter()
+        try:
+            pr = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+            lines = [l for l in pr.stdout.splitlines() if l.startswith('{')]
+            if pr.returncode != 0 or not lines:
+                out[name] = {'error': f'rc {pr.returncode}', 'stderr_tail': pr.stderr[-300:]}
+                continue
+            r = json.loads(lines[-1])
+            ent = {'value': r['value'], 'unit': r['unit'], 'ms_per_step': r['ms_per_step'], 'steps': r['steps'], 'warmup': r['warmup'],
+                   'pairs_per_step': r['config'].get('pairs_per_gpu'), 'metric': r['metric'], 'wall_s': round(time.perf_counter() - t0, 1)}
+            for k in ('k4', 'k1', 'vendor_convolution'):
+                if k in r:
+                    ent[k] = r[k]
+            if name == 'c2_one_pair_latency':
+                ent['note'] = ('the reference\'s deployment shape (scripts/eval_matterport.sh: batch_size 1): ms_per_step IS the latency of one '
+                               'pair through match + 2 solver rounds + 2 head calls')
+            out[name] = ent
+        except Exception as e:                      # a leg must never take the headline line down
+            out[name] = {'error': repr(e)[:300]}
+    return out
 
 
 def cpu_baseline(n_pairs, hyp):
@@ -505,6 +559,10 @@ def bench_c3(a, dev, world, rank, dist):
                     'step_ms_without_exchange': round(nosync_ms, 3),
                     'exposed_ms_in_step': round(1000 * dt / a.steps - nosync_ms, 3),
                     'backend': dist.get_backend(), 'ranks': world}
+    per_rank_peak = None
+    if dist is not None:                # every rank's sustained dense-f16 MFMA rate, all ranks at once (see main())
+        pk = max(v['tflops'] for v in mfma_sustained_peak().values())
+        per_rank_peak = [round(x, 1) for x in parallel.gather_floats(pk, device=dev)]
     if rank == 0:
         sc = {k_: round(float(v_), 5) for k_, v_ in last['loss_scalars'].items() if k_.startswith('loss')}
         res = {
@@ -529,7 +587,7 @@ def bench_c3(a, dev, world, rank, dist):
                        'gt_coarse_matches_per_pair': n_gt, 'sampled_matches': int(last['b_ids'].numel()),
                        'losses': sc,
                        'parallelism': f'ddp{world} (gradient all-reduce over RCCL)' if world > 1 else 'single GPU (no exchange step)'},
-            'exchange': exchange,
+            'exchange': exchange, 'per_rank_sustained_peak': per_rank_peak,
         }
         print(json.dumps(res), flush=True)
     if dist is not None:
@@ -704,6 +762,12 @@ def main():
                 'head_median_R_deg': round(float(Re2.median()), 3), 'head_median_t_deg': round(float(te2.median()), 3),
                 'note': 'vs synthetic GT (R=I, t=-x); random-weight head; Matterport accuracy pending (no ckpt/data offline)'}
 
+    # N > 1: the dense-f16 MFMA rate every rank sustains right now (far_mfma_probe_f16 on all ranks at once): under one node's
+    # power envelope a sub-linear scaling curve can then be told apart from ranks that simply clock lower together
+    per_rank_peak = None
+    if world > 1:
+        pk = max(v['tflops'] for v in mfma_sustained_peak().values())
+        per_rank_peak = [round(x, 1) for x in parallel.gather_floats(pk, device=dev)]
     if rank == 0:
         kr = kernel_rooflines(a.pairs)
         # dominant kernel of the step: K9 (60 % of the kernel-busy time, profiles/); its costliest launch is reported
@@ -726,7 +790,8 @@ def main():
                 # HBM/fabric bytes per launch from the committed PMC passes (null when they do not match this geometry
                 # and precision); `committed_profile` names the file / commit they were measured at
                 'traffic': (tr or {}).get('bytes'), 'committed_profile': tr,
-                'launch_ms': round(kr[dom]['ms'], 3), 'mfma_issue_frac': round(kr[dom]['mfma_issue_frac'], 4),
+                'launch_ms': round(kr[dom]['ms'], 3), 'launch_ms_rocprof': rocprof_launch_ms(dom),
+                'mfma_issue_frac': round(kr[dom]['mfma_issue_frac'], 4),
                 'note': 'algorithmic convolution flops per launch / event-timed launch duration against the dense f16 '
                         'MFMA peak; the kernel executes 3 f16 MFMAs per fp32-grade product (split operands), so the '
                         'matrix pipe is busy mfma_issue_frac of the time AT THE NOMINAL 2.4 GHz; the shader clock '
@@ -776,6 +841,10 @@ def main():
                                                             'accumulation; informational, not the parity line'}}
         if world == 1 and not a.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(a.cpu_pairs, a.hyp)
+        if per_rank_peak is not None:
+            res['per_rank_sustained_peak'] = per_rank_peak
+        if world == 1 and a.precision == 'fp32' and a.pairs == PAIRS_PER_GPU and not a.no_other_workloads:
+            res['other_workloads'] = other_workloads(a)
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()

@@ -134,6 +134,7 @@ class EncLayer(ctypes.Structure):
                [(n, ctypes.c_void_p) for n in ('g1', 'b1', 'g2', 'b2', 'overflow')]
 
 
+EXPECTED_ABI = 3          # far_abi_version() of the library these signatures describe (include/far_hip.h)
 _lib = None
 
 
@@ -156,6 +157,14 @@ def load():
     # streams fail with hipErrorNoDevice (observed; see INTEGRATION.md "load order").
     import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
+    lib.far_abi_version.restype = ctypes.c_int
+    lib.far_abi_version.argtypes = []
+    abi = lib.far_abi_version()
+    if abi != EXPECTED_ABI:
+        # a stale build (or a library of another revision selected through FAR_HIP_LIB) would be called with shifted arguments:
+        # silent memory corruption or a wrong stream, not an error
+        raise FarHipError(f'{LIB_PATH} has ABI version {abi}, these bindings expect {EXPECTED_ABI}: rebuild it with '
+                          '`python -m far_amd.build --force` (or point FAR_HIP_LIB at a library of this revision)')
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res

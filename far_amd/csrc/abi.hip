@@ -4,7 +4,7 @@
 static thread_local int g_last_hip_error = 0;
 void far_record_hip_error(int e) { g_last_hip_error = e; }
 
-extern "C" int far_abi_version(void) { return 2; }
+extern "C" int far_abi_version(void) { return 3; }
 // hipError_t of the most recent failed launch on this thread (0 = none); for diagnostics after a -5 return.
 extern "C" int far_last_hip_error(void) { return g_last_hip_error; }
 
@@ -13,8 +13,8 @@ extern "C" int far_last_hip_error(void) { return g_last_hip_error; }
 // variants; 4: 1 = K9 without the seven-tile mode / K5 windows on the generic path; 5: K5 apply tiles per unit; 6: K5 tokens per
 // KV chunk; 7: 1 = K9 Linear launches always on full-height tiles; 8: 1 = K17 (Winograd) splits its operands with the five-instruction
 // split2 instead of v_fma_mix (same values); 9: 1 = K17 off (every 3x3 layer on K9).
-// This is the library's ONLY process-global state (declared as such in include/far_hip.h); atomics, so that a tuning
-// call from one thread is well-defined against launches on another.
+// Process-global state of the library: these knobs (atomics, so that a tuning call from one thread is well-defined against
+// launches on another) and the per-device one-time kernel attribute setup; the side streams below are per host thread.
 static std::atomic<int> g_tuning[16] = {{3}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}};
 extern "C" int far_set_tuning(int key, int value) {
     if (key < 0 || key >= 16) return FAR_EINVAL;
@@ -25,7 +25,10 @@ int far_get_tuning(int key) { return (key >= 0 && key < 16) ? g_tuning[key].load
 
 // ---- side streams: launches that do not depend on each other (the weight gradient of a layer next to its input gradient; the
 // q, k, v projections of a layer) overlap when they are issued on different streams, and at batch 1 each of them fills a
-// fraction of the CUs.  The library keeps FAR_SIDE_STREAMS non-blocking streams per device, created on first use.
+// fraction of the CUs.  Every HOST THREAD keeps FAR_SIDE_STREAMS non-blocking streams (and their fork / join events) per device,
+// created on first use: two threads driving one device (a loader thread running inference next to
+// the training thread) never record into each other's events -- a side stream then waited on the other thread's record and lost
+// the dependency on its own main stream.
 //   far_stream_fork(main, i): side stream i waits for everything issued on `main` so far; returns the side stream.
 //   far_stream_join(main, i): `main` waits for everything issued on side stream i so far.
 // Buffers used on a side stream must stay allocated until the join (the caller's allocator knows only `main`).
@@ -34,25 +37,23 @@ namespace {
 struct SideStreams {
     hipStream_t s[FAR_SIDE_STREAMS];
     hipEvent_t fork[FAR_SIDE_STREAMS], join[FAR_SIDE_STREAMS];
-    std::atomic<int> ready{0};
+    bool ready = false;
 };
-SideStreams g_side[64];
+struct ThreadSides {
+    SideStreams dev[64];          // (never destroyed: a thread's exit may come after the HIP runtime's own teardown, and a process has
+};                                //  a handful of threads that launch; twelve handles per (thread, device) stay with the runtime)
+thread_local ThreadSides t_sides;
 SideStreams* side_streams() {
-    SideStreams& d = g_side[far_current_device()];
-    if (d.ready.load(std::memory_order_acquire) == 2) return &d;
-    int expect = 0;
-    if (d.ready.compare_exchange_strong(expect, 1)) {
-        bool ok = true;
-        for (int i = 0; i < FAR_SIDE_STREAMS; ++i) {
-            ok = ok && hipStreamCreateWithFlags(&d.s[i], hipStreamNonBlocking) == hipSuccess;
-            ok = ok && hipEventCreateWithFlags(&d.fork[i], hipEventDisableTiming) == hipSuccess;
-            ok = ok && hipEventCreateWithFlags(&d.join[i], hipEventDisableTiming) == hipSuccess;
-        }
-        d.ready.store(ok ? 2 : 0, std::memory_order_release);
-        return ok ? &d : nullptr;
+    SideStreams& d = t_sides.dev[far_current_device()];
+    if (d.ready) return &d;
+    bool ok = true;
+    for (int i = 0; i < FAR_SIDE_STREAMS; ++i) {
+        ok = ok && hipStreamCreateWithFlags(&d.s[i], hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&d.fork[i], hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&d.join[i], hipEventDisableTiming) == hipSuccess;
     }
-    while (d.ready.load(std::memory_order_acquire) == 1) {}
-    return d.ready.load(std::memory_order_acquire) == 2 ? &d : nullptr;
+    d.ready = ok;
+    return ok ? &d : nullptr;
 }
 }  // namespace
 

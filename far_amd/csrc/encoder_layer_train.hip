@@ -187,6 +187,17 @@ inline unsigned ew_blocks(long n4) {
 
 #define FAR_TRY(call) do { const int rc_ = (call); if (rc_ != FAR_OK) return rc_; } while (0)
 
+// Joins the forked side streams when its scope ends -- on the error returns of FAR_TRY too: the caller frees `ws`, `saved` and
+// `grads` as soon as the call returns, and work forked onto a side stream must not still be reading them then.
+struct SideJoin {
+    hipStream_t main;
+    unsigned forked = 0;               // bit i: side stream i holds work since the last join
+    explicit SideJoin(hipStream_t m) : main(m) {}
+    void* fork(int i) { forked |= 1u << i; return far_stream_fork(main, i); }
+    int join(int i) { forked &= ~(1u << i); return far_stream_join(main, i); }
+    ~SideJoin() { for (int i = 0; i < 4; ++i) if (forked & (1u << i)) (void)far_stream_join(main, i); }
+};
+
 }  // namespace
 
 extern "C" {
@@ -222,15 +233,16 @@ int far_enc_layer_fwd(const far_enc_layer* d, const float* x, const float* sourc
           *h = saved + s.h, *m2 = saved + s.m2;
     // q | k | v: independent, each a fraction of the CUs -> k and v on side streams
     hipStream_t sk = stream, sv = stream;
+    SideJoin sides(stream);
     if (L.overlap) {
-        sk = (hipStream_t)far_stream_fork(stream, 0);
-        sv = (hipStream_t)far_stream_fork(stream, 1);
+        sk = (hipStream_t)sides.fork(0);
+        sv = (hipStream_t)sides.fork(1);
         if (!sk || !sv) return FAR_ELAUNCH;
     }
     FAR_TRY(linear(L, src, Rs, C, C, L.img[1], L.img_scale[1], k, 0, nullptr, 1, nullptr, sk));
     FAR_TRY(linear(L, src, Rs, C, C, L.img[2], L.img_scale[2], v, 0, nullptr, 1, nullptr, sv));
     FAR_TRY(linear(L, x, R, C, C, L.img[0], L.img_scale[0], q, 0, nullptr, 1, nullptr, stream));
-    if (L.overlap) { FAR_TRY(far_stream_join(stream, 0)); FAR_TRY(far_stream_join(stream, 1)); }
+    if (L.overlap) { FAR_TRY(sides.join(0)); FAR_TRY(sides.join(1)); }
     FAR_TRY(far_linear_attention_f32(q, k, v, (int)L.bs, (int)L.L, (int)L.S, L.nhead, C / L.nhead, nullptr, nullptr, L.attn_eps, msg0, ws, stream));
     FAR_TRY(linear(L, msg0, R, C, C, L.img[3], L.img_scale[3], m1, 0, nullptr, 1, nullptr, stream));
     // norm1 into the scratch half of y's buffer would alias: y is free until the end -> use it for norm1's output
@@ -263,11 +275,12 @@ int far_enc_layer_bwd(const far_enc_layer* d, const float* x, const float* sourc
           *dk = F(w.dk), *dv = F(w.dv), *t1 = F(w.t1), *t2 = F(w.t2);
     auto scale = [&](int i) { return F(w.scales + 256 * i); };
     int nw = 0;
+    SideJoin sides(stream);
     // a weight gradient: on side stream 0 (behind everything `stream` holds now), its own scratch slab
     auto wgrad = [&](const float* xin, const float* dy, long rows, int K, int N, const float* sc, float* dw) -> int {
         hipStream_t st = stream;
         if (L.overlap) {
-            st = (hipStream_t)far_stream_fork(stream, 0);
+            st = (hipStream_t)sides.fork(0);
             if (!st) return FAR_ELAUNCH;
         }
         const int hh = rows % 32 == 0 ? (int)(rows / 32) : 1;
@@ -309,7 +322,7 @@ int far_enc_layer_bwd(const far_enc_layer* d, const float* x, const float* sourc
         FAR_TRY(linear(L, dk, Rs, C, C, L.imgT[1], L.imgT_scale[1], t1, 0, nullptr, 1, scale(4), stream));
         FAR_TRY(linear(L, dv, Rs, C, C, L.imgT[2], L.imgT_scale[2], grads + g.ds, 0, t1, 1, scale(5), stream));
     }
-    if (L.overlap) FAR_TRY(far_stream_join(stream, 0));
+    if (L.overlap) FAR_TRY(sides.join(0));
     return far_check_launch();
 }
 

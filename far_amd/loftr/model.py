@@ -281,16 +281,54 @@ class LoFTR(nn.Module):
         warnings.warn(f'far_amd: an activation exceeded the split-fp16 range; re-running with activation exponent {self.act_exp} '
                       f'(|a| <= {65504.0 / 2.0 ** self.act_exp:.3g}), unfused fine-level layers and the exact-f32 K1 / K2 variants')
 
-    def _guarded(self, fn, device):
-        """Runs fn() under this module's activation exponent; on an overflow report widens the range and runs it again."""
+    def _range_state(self):
+        """What _widen_activation_range changes: (act_exp, per-module fused / variant settings)."""
+        from .transformer import CrossAttention, LoFTREncoderLayer
+        mods = []
+        for m in self.modules():
+            if isinstance(m, LoFTREncoderLayer):
+                mods.append((m, 'layer', m.fused_attn, m.fused_mlp))
+            elif isinstance(m, CrossAttention):
+                mods.append((m, 'cross', m.exact_f32, None))
+        cm = self.coarse_matching.variant if hasattr(self, 'coarse_matching') else None
+        return self.act_exp, mods, cm
+
+    def _restore_range_state(self, state):
+        self.act_exp, mods, cm = state
+        for m, kind, a, b in mods:
+            if kind == 'layer':
+                m.fused_attn, m.fused_mlp = a, b
+            else:
+                m.exact_f32 = a
+        if cm is not None:
+            self.coarse_matching.variant = cm
+
+    def _guarded(self, fn, device, inputs=()):
+        """Runs fn() under this module's activation exponent; on an overflow report widens the range and runs it again.
+        The per-device flag is cleared on entry: backward launches (K9 dgrad, K16, the layer node) and other modules OR the same
+        flag and nobody reads it after them, so a stale report would otherwise widen this module for good on its next clean call.
+        A widening persists only if it produced a clean run: non-finite inputs (which raise the flag at every exponent) and
+        activations beyond the widest range leave the module exactly as it was and raise ActivationOverflow."""
         if device.type != 'cuda':
             return fn()
+        ops.overflow_flag(device).zero_()
+        saved = None
         while True:
             with ops.activation_exponent(self.act_exp):
                 out = fn()
             if not ops.activation_overflowed(device):      # one host read per call
                 return out
-            self._widen_activation_range()
+            if saved is None:
+                saved = self._range_state()
+                bad = [t for t in inputs if torch.is_tensor(t) and t.is_floating_point() and not bool(torch.isfinite(t).all())]
+                if bad:
+                    raise ops.ActivationOverflow('non-finite values in the inputs (image / feature tensors): the outputs of this call '
+                                                 'contain inf / NaN; the activation range was left unchanged')
+            try:
+                self._widen_activation_range()
+            except ops.ActivationOverflow:
+                self._restore_range_state(saved)             # nothing that did not yield finite outputs is kept
+                raise
 
     def check_activation_range(self, data):
         """For callers that drive forward_feature_extraction / forward_correspondence_prediction themselves: raises
@@ -304,7 +342,7 @@ class LoFTR(nn.Module):
         def run():
             self.forward_feature_extraction(data)
             self.forward_correspondence_prediction(data, train=train)
-        self._guarded(run, data['image0'].device)
+        self._guarded(run, data['image0'].device, (data['image0'], data['image1']))
         return data
 
     def load_state_dict(self, state_dict, *args, **kwargs):

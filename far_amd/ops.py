@@ -508,8 +508,9 @@ def train_pack(cache, name, weight, bias=None, split=True):
 def train_pack_t(cache, name, weight, bias=None, split=True):
     """The transposed image (dgrad): the same tensor read through strides, with the forward image's scale (same maximum)."""
     fwd = train_pack(cache, name, weight, bias, split)             # first: the transposed image borrows its (refreshed) scale
-    return cache.get((name, 'T', split), [weight], lambda: PackedConv(weight, split=split, dgrad=True, pack_scale=fwd.pack_scale),
-                     refresh=lambda pc: pc.refresh(weight))
+    pt = cache.get((name, 'T', split), [weight], lambda: PackedConv(weight, split=split, dgrad=True, pack_scale=fwd.pack_scale),
+                   refresh=lambda pc: pc.refresh(weight))
+    return pt.follow_scale(fwd, weight)
 
 
 class _ConvF16sFn(torch.autograd.Function):
@@ -604,7 +605,8 @@ def conv_train(x, weight, stride, cache, name, split=True):
     re = lambda pc: pc.refresh(weight)                 # after an optimizer step: same buffers, one launch (the forward image first:
     pack = lambda: cache.get((name, 'fwd', split), [weight], lambda: PackedConv(weight, split=split, stride=stride if ks == 3 else 1), refresh=re)
     pack_d = lambda: cache.get((name, 'dgrad', split), [weight],   # the dgrad image borrows its scale; the forward ran before the backward)
-                               lambda: PackedConv(weight, split=split, dgrad=True, pack_scale=pack().pack_scale), refresh=re)
+                               lambda: PackedConv(weight, split=split, dgrad=True, pack_scale=pack().pack_scale),
+                               refresh=re).follow_scale(pack(), weight)
     return _ConvF16sFn.apply(x, weight, int(stride), pack, pack_d)
 
 
@@ -933,6 +935,16 @@ class PackedConv:
         _lib.check(rc, 'far_conv_pack_view_scaled_f32')
         self._w = w                                               # keeps the (possibly temporary) contiguous weight alive until the pack ran
 
+    def follow_scale(self, owner, weight):
+        """For an image that borrows another image's pack_scale (dgrad / transposed images): when the owner was REBUILT rather than
+        refreshed (a biased layer, a changed stamp) it holds a new scale tensor and this image would keep packing with the orphaned,
+        never-updated one -- rebind to the owner's current tensor and re-pack.  Returns self."""
+        if not self._own_scale and self.pack_scale.data_ptr() != owner.pack_scale.data_ptr():
+            self.pack_scale = owner.pack_scale
+            self.refresh(weight)
+            PACK_TABLE.dirty = True                     # the device table holds the old scale pointer
+        return self
+
     def refresh(self, weight):
         """Re-pack in place after the weight changed (an optimizer step): the same buffers, one launch (+ the scale reduction when
         this image owns it; an image that borrows another's pack_scale must be refreshed after that one).  Epilogue scale / shift
@@ -1129,8 +1141,9 @@ class _PackTable:
 
     def __init__(self):
         self.entries = []          # (weakref(cache), key, weakref(weight), weakref(pc))
-        self.table = None          # (device table tensor, n, [entry indices], device) built from the live entries
+        self.table = None          # (device table tensor, n, [(weakref(cache), key, weakref(weight), weakref(pc))]): weak, like entries
         self.dirty = True
+        self._skip = 0             # stale lookups still to come in the step for which the per-entry path was chosen
 
     def register(self, cache, key, weight, pc):
         import weakref
@@ -1146,6 +1159,7 @@ class _PackTable:
         return out
 
     def _build(self, live):
+        import weakref
         lib = _lib.load()
         dev = live[0][3].packed.device
         live = [e for e in live if e[3].packed.device == dev and e[2].is_contiguous() and e[2].dtype == torch.float32]
@@ -1171,11 +1185,16 @@ class _PackTable:
             it.scale_vec = pc.scale.data_ptr()
         table = torch.empty(int(lib.far_pack_table_bytes(n)), dtype=torch.uint8, device=dev)
         _lib.check(lib.far_pack_table_build(ctypes.cast(items, ctypes.c_void_p), n, _p(table), _stream()), 'far_pack_table_build')
-        return table, n, keep
+        # only weak references are kept next to the device table (which holds raw pointers): the table must not pin the weights,
+        # images and caches of a model that was deleted; a dead reference found later marks the table dirty
+        return table, n, [(weakref.ref(c), k, weakref.ref(w), weakref.ref(pc)) for c, k, w, pc in keep]
 
     def refresh_all(self):
         """Re-packs every live image whose weight version changed, through the table when most of them did.  Returns True when
         the table ran (the caller's entry is then fresh)."""
+        if self._skip > 0:                              # the rest of a step's stale lookups after the per-entry path was chosen
+            self._skip -= 1
+            return False
         if self.dirty:
             live = self._live()
             self.entries = [e for e in self.entries if e[0]() is not None and e[3]() is not None]
@@ -1183,18 +1202,27 @@ class _PackTable:
             self.dirty = False
         if self.table is None:
             return False
-        table, n, keep = self.table
-        stamps, stale = [], 0
-        for cache, key, w, pc in keep:
+        table, n, refs = self.table
+        keep, stamps, stale = [], [], 0
+        for rc, key, rw, rpc in refs:
+            cache, w, pc = rc(), rw(), rpc()
+            if cache is None or w is None or pc is None:
+                self.dirty = True                       # a model went away: the table's raw pointers are stale, rebuild next time
+                self.table = None
+                return False
             st = ((w.data_ptr(), tensor_version(w)),)
-            stamps.append(st)
             hit = cache._store.get(key)
             if hit is None or hit[1] is not pc or hit[0][0][0] != st[0][0]:
                 self.dirty = True                       # an entry was replaced or its weight moved: rebuild next time, per-entry now
                 return False
+            keep.append((cache, key, w, pc))
+            stamps.append(st)
             stale += hit[0] != st
         if 2 * stale < n:
-            return False                                # a few images only (fine-tuning a sub-module): per-entry refresh
+            # a few images only (fine-tuning a sub-module): per-entry refresh -- and no second walk over all n entries for each of
+            # the other stale images of this step (they each come through here once)
+            self._skip = max(stale - 1, 0)
+            return False
         _lib.check(_lib.load().far_pack_table_run(_p(table), n, _stream()), 'far_pack_table_run')
         for (cache, key, w, pc), st in zip(keep, stamps):
             cache._store[key] = (st, pc)

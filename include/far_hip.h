@@ -11,8 +11,9 @@
  *   - every function enqueues on `stream` and returns immediately: 0 = enqueued, negative errno otherwise
  *     (-22 invalid argument, -5 launch failure); nothing throws, nothing prints;
  *   - process-global state is limited to (a) per-device one-time kernel attribute setup and (b) the speed-only
- *     A/B knobs of far_set_tuning() (atomics; they never change results); the usual deployment is one process
- *     per GPU, but launching on several devices from one process is supported;
+ *     A/B knobs of far_set_tuning() (atomics; they never change results); the side streams of far_stream_fork /
+ *     far_stream_join belong to the calling host thread (per device); the usual deployment is one process per GPU,
+ *     but launching on several devices, or from several threads, of one process is supported;
  *   - "Z" is a flat batch (image pairs, or pairs x heads x directions for the head).
  */
 #ifndef FAR_HIP_H
@@ -27,7 +28,8 @@ extern "C" {
 
 typedef struct ihipStream_t* far_stream_t; /* == hipStream_t */
 
-/* ABI version of this header; bumped when a signature changes (2: activation exponent / overflow flag of K9, K13, K14). */
+/* ABI version of this header; bumped when a signature changes (2: activation exponent / overflow flag of K9, K13, K14; 3: the
+ * far_wino_* / far_conv3x3_wino_f32 entry points, 16 tuning keys).  far_amd/_lib.py refuses a library whose version differs. */
 int far_abi_version(void);
 /* hipError_t of the most recent failed launch on the calling thread (0 = none): detail behind a -5 return. */
 int far_last_hip_error(void);
@@ -37,7 +39,7 @@ int far_set_tuning(int key, int value);
 
 /* Side streams (FAR_SIDE_STREAMS = 4 per device, created on first use): independent launches of a batch-1 training step -- a
  * layer's weight gradient next to its input gradient, its q / k / v projections -- each fill a fraction of the CUs and overlap
- * when issued on different streams.  far_stream_fork(main, i): side stream i waits for what `main` holds so far; returns the
+ * when issued on different streams; the streams belong to the calling host thread.  far_stream_fork(main, i): side stream i waits for what `main` holds so far; returns the
  * stream to launch on (NULL on failure).  far_stream_join(main, i): `main` waits for side stream i.  Buffers used on a side
  * stream must stay allocated until the join. */
 void* far_stream_fork(far_stream_t main, int i);

@@ -21,7 +21,7 @@ def test_header_symbols_exported_and_bound():
         assert hasattr(lib, n), f'{n} declared in far_hip.h but not exported'
         assert n in _lib.SIGNATURES, f'{n} has no ctypes signature in far_amd/_lib.py'
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.far_abi_version() >= 1
+    assert lib.far_abi_version() == _lib.EXPECTED_ABI        # load() refuses any other library
 
 
 def test_workspace_query_needs_no_gpu():

@@ -636,3 +636,33 @@ def test_activation_range_recovery_end_to_end(model):
         warnings.simplefilter('always')
         big(data2)
     assert not [w for w in rec2 if 'activation' in str(w.message)] and len(data2['b_ids']) > 100
+
+
+def test_activation_range_guard_ignores_stale_flags_and_keeps_its_state_on_bad_inputs(model):
+    """ADVICE r3 (medium).  (1) A flag left set by somebody else -- a backward launch with an inf gradient, another module --
+    must not widen this module on its next clean forward: _guarded clears it on entry.  (2) Non-finite INPUTS raise the flag
+    at every exponent: the forward must raise ActivationOverflow at once and leave act_exp, the fused fine layers and the K1 /
+    K2 variants exactly as they were (round 3 walked down to act_exp = -24 and stayed there)."""
+    import copy
+    import warnings
+    from far_amd import ops
+    m = copy.deepcopy(model)
+    data1, _, _ = _batch(1, 5)
+    state0 = (m.act_exp, m.coarse_matching.variant, m.loftr_fine.layers[0].fused_attn, m.loftr_fine.layers[0].fused_mlp)
+    ops.overflow_flag('cuda').fill_(1)                       # stale report
+    with torch.no_grad(), warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter('always')
+        m(data1)
+    assert not [w for w in rec if 'activation' in str(w.message)]
+    assert (m.act_exp, m.coarse_matching.variant, m.loftr_fine.layers[0].fused_attn, m.loftr_fine.layers[0].fused_mlp) == state0
+    assert len(data1['b_ids']) > 100
+    bad, _, _ = _batch(1, 6)
+    bad['image0'] = bad['image0'].clone()
+    bad['image0'][0, 0, 100, 100] = float('nan')
+    with torch.no_grad(), warnings.catch_warnings(record=True), pytest.raises(ops.ActivationOverflow):
+        m(bad)
+    assert (m.act_exp, m.coarse_matching.variant, m.loftr_fine.layers[0].fused_attn, m.loftr_fine.layers[0].fused_mlp) == state0
+    good, _, _ = _batch(1, 7)                                # and the module still works, at the default setting
+    with torch.no_grad():
+        m(good)
+    assert len(good['b_ids']) > 100 and torch.isfinite(good['mconf']).all()

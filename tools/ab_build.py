@@ -25,6 +25,12 @@ for n in sorted(os.listdir(tmp)):
         else:
             subprocess.check_call([B.HIPCC] + B.FLAGS + ['-I', tmp, '-c', os.path.join(tmp, n), '-o', o])
         objs.append(o)
+# a base of another ABI would be called with this tree's argument lists (far_amd/_lib.py checks it at load: refuse here already)
+import re  # noqa: E402
+abi_of = lambda txt: int(re.search(r'far_abi_version\(void\) \{ return (\d+); \}', txt).group(1))
+a_base, a_cur = abi_of(open(os.path.join(tmp, 'abi.hip')).read()), abi_of(open(os.path.join(B.CSRC, 'abi.hip')).read())
+if a_base != a_cur:
+    sys.exit(f'{rev} has ABI version {a_base}, the working tree {a_cur}: not loadable through these bindings')
 out = os.path.join(B.LIBDIR, 'libfar_hip_base.so')
 subprocess.check_call([B.HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out] + objs)
 print(out)

@@ -8,16 +8,16 @@ mkdir -p $R/gpurun_out
 # the un-profiled headline line first: counter collection can leave the clocks in the profiler's fixed state for a while
 (cd $R; timeout 400 python bench.py > gpurun_out/bench_plain.log 2> gpurun_out/bench_plain.err)
 cd /tmp; export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_bench -o bench -- python3 $R/bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-other-modes > $R/gpurun_out/bench_prof.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_bench -o bench -- python3 $R/bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-other-modes --no-other-workloads > $R/gpurun_out/bench_prof.log 2>&1
 timeout 200 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/pmc_fetch -o f -- python3 $R/tools/kprobe.py pmc 32 2 > $R/gpurun_out/pmc_fetch.log 2>&1
 timeout 200 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/pmc_write -o w -- python3 $R/tools/kprobe.py pmc 32 2 > $R/gpurun_out/pmc_write.log 2>&1
 cd $R
 timeout 300 python bench.py --workload c4 > gpurun_out/bench_c4.log 2> gpurun_out/bench_c4.err
-timeout 300 python bench.py --workload c3 --no-cpu-baseline --no-other-modes > gpurun_out/bench_c3.log 2> gpurun_out/bench_c3.err
-timeout 300 python bench.py --workload c3 --vendor-train --no-cpu-baseline --no-other-modes > gpurun_out/bench_c3_vendor.log 2> gpurun_out/bench_c3_vendor.err
-timeout 300 python bench.py --workload c5 --no-cpu-baseline --no-other-modes > gpurun_out/bench_c5.log 2> gpurun_out/bench_c5.err
+timeout 300 python bench.py --workload c3 --no-cpu-baseline --no-other-modes --no-other-workloads > gpurun_out/bench_c3.log 2> gpurun_out/bench_c3.err
+timeout 300 python bench.py --workload c3 --vendor-train --no-cpu-baseline --no-other-modes --no-other-workloads > gpurun_out/bench_c3_vendor.log 2> gpurun_out/bench_c3_vendor.err
+timeout 300 python bench.py --workload c5 --no-cpu-baseline --no-other-modes --no-other-workloads > gpurun_out/bench_c5.log 2> gpurun_out/bench_c5.err
 timeout 200 python tools/wgrad_time.py > gpurun_out/${TAG}_wgrad_time.txt 2>&1
-(cd /tmp; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_c3 -o c3 -- python3 $R/bench.py --workload c3 --steps 10 --warmup 3 --no-cpu-baseline --no-other-modes > $R/gpurun_out/bench_c3_prof.log 2>&1)
+(cd /tmp; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_c3 -o c3 -- python3 $R/bench.py --workload c3 --steps 10 --warmup 3 --no-cpu-baseline --no-other-modes --no-other-workloads > $R/gpurun_out/bench_c3_prof.log 2>&1)
 python tools/profile_report.py /tmp/prof_c3/c3_results.db > gpurun_out/${TAG}_c3_trace.txt 2>&1
 python tools/aten_in_step.py /tmp/prof_c3/c3_results.db > gpurun_out/${TAG}_c3_vendor_kernels.txt 2>&1
 python tools/profile_report.py gpurun_out/prof_bench/bench_results.db > gpurun_out/${TAG}_trace.txt 2>&1

@@ -57,7 +57,7 @@ if os.path.exists(G + f'{tag}_c3_trace.txt') and os.path.exists(G + 'bench_c3.lo
 {win3.strip()}
 
 ## vendor / ATen kernels left in that step (tools/aten_in_step.py)
-{vk.strip()}
+{vk.strip(chr(10))}
 
 ## K16 (far_conv_wgrad_f16s + reduction) against the vendor's backward-weights on the backbone's layer shapes (tools/wgrad_time.py, wall per call)
 {wg.strip()}
