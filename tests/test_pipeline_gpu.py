@@ -658,10 +658,18 @@ def test_activation_range_guard_ignores_stale_flags_and_keeps_its_state_on_bad_i
     assert len(data1['b_ids']) > 100
     bad, _, _ = _batch(1, 6)
     bad['image0'] = bad['image0'].clone()
-    bad['image0'][0, 0, 100, 100] = float('nan')
+    bad['image0'][0, 0, 96:104, 96:104] = float('inf')        # (a NaN pixel alone can vanish in the stem's ReLU: max(NaN, 0) = 0)
     with torch.no_grad(), warnings.catch_warnings(record=True), pytest.raises(ops.ActivationOverflow):
         m(bad)
     assert (m.act_exp, m.coarse_matching.variant, m.loftr_fine.layers[0].fused_attn, m.loftr_fine.layers[0].fused_mlp) == state0
+    # a non-finite WEIGHT: finite inputs, the flag fires at every exponent down to the floor -> the walk is undone, not kept
+    m2 = copy.deepcopy(model)
+    with torch.no_grad():
+        m2.backbone.layer1[0].conv1.weight[3, 5, 1, 1] = float('nan')
+    ok_in, _, _ = _batch(1, 6)
+    with torch.no_grad(), warnings.catch_warnings(record=True), pytest.raises(ops.ActivationOverflow):
+        m2(ok_in)
+    assert (m2.act_exp, m2.coarse_matching.variant, m2.loftr_fine.layers[0].fused_attn, m2.loftr_fine.layers[0].fused_mlp) == state0
     good, _, _ = _batch(1, 7)                                # and the module still works, at the default setting
     with torch.no_grad():
         m(good)
