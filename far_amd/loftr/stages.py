@@ -95,10 +95,10 @@ class CoarseMatching(nn.Module):
     # reference's own dense loss.
     # ------------------------------------------------------------------------------------------------------
     def _forward_train(self, feat_c0, feat_c1, data, mask_c0=None, mask_c1=None):
-        if 'mask0' in data:
-            raise NotImplementedError('padded-mask datasets are not wired into the training path yet')
+        # padded-mask batches (coarse_matching.py:28-43, 110-117, 199-204: images of different sizes padded to one grid) take the
+        # dense differentiable form: the sparse training kernels of K1 (far_coarse_pos_conf_*) carry no masks
         sparse = (feat_c0.is_cuda and feat_c0.shape[-1] == 256 and not self.materialize_conf and 'spv_b_ids' in data
-                  and self.config.get('sparse_spvs', True))
+                  and self.config.get('sparse_spvs', True) and 'mask0' not in data)
         if not sparse:
             conf = ag.conf_matrix(feat_c0, feat_c1, self.temperature, mask_c0, mask_c1)
             data.update({'conf_matrix': conf})
@@ -125,7 +125,14 @@ class CoarseMatching(nn.Module):
         b = self.border_rm
         if b > 0:
             mask[:, :b] = False; mask[:, :, :b] = False; mask[:, :, :, :b] = False; mask[:, :, :, :, :b] = False
-            mask[:, -b:] = False; mask[:, :, -b:] = False; mask[:, :, :, -b:] = False; mask[:, :, :, :, -b:] = False
+            if 'mask0' not in data:                                                        # mask_border :8-25
+                mask[:, -b:] = False; mask[:, :, -b:] = False; mask[:, :, :, -b:] = False; mask[:, :, :, :, -b:] = False
+            else:                                                                          # mask_border_with_padding :28-43: the far
+                m0, m1 = data['mask0'], data['mask1']                                      # border follows each image's valid extent
+                h0s, w0s = m0.sum(1).max(-1)[0].int().tolist(), m0.sum(-1).max(-1)[0].int().tolist()
+                h1s, w1s = m1.sum(1).max(-1)[0].int().tolist(), m1.sum(-1).max(-1)[0].int().tolist()
+                for n, (a0, c0, a1, c1) in enumerate(zip(h0s, w0s, h1s, w1s)):
+                    mask[n, a0 - b:] = False; mask[n, :, c0 - b:] = False; mask[n, :, :, a1 - b:] = False; mask[n, :, :, :, c1 - b:] = False
         mask = mask.view(N, L, S)
         mask = mask * (conf == conf.max(dim=2, keepdim=True)[0]) * (conf == conf.max(dim=1, keepdim=True)[0])
         mask_v, all_j = mask.max(dim=2)
@@ -143,7 +150,14 @@ class CoarseMatching(nn.Module):
         L, S = h0 * w0, h1 * w1
         dev = b_ids.device
         if self.training:
-            n_train = int(N * max(L, S) * self.train_coarse_percent)                       # :205-210
+            if 'mask0' not in data:
+                n_cand = N * max(L, S)                                                     # :202-203
+            else:                                                                          # compute_max_candidates :46-57
+                m0, m1 = data['mask0'], data['mask1']
+                a0 = m0.sum(1).max(-1)[0] * m0.sum(-1).max(-1)[0]
+                a1 = m1.sum(1).max(-1)[0] * m1.sum(-1).max(-1)[0]
+                n_cand = torch.sum(torch.min(torch.stack([a0, a1], -1), -1)[0])
+            n_train = int(n_cand * self.train_coarse_percent)                              # :205-210
             n_pred = len(b_ids)
             assert self.train_pad_num_gt_min < n_train, "min-num-gt-pad should be less than num-train-matches"
             if n_pred <= n_train - self.train_pad_num_gt_min:                              # :216-222

@@ -674,3 +674,54 @@ def test_activation_range_guard_ignores_stale_flags_and_keeps_its_state_on_bad_i
     with torch.no_grad():
         m(good)
     assert len(good['b_ids']) > 100 and torch.isfinite(good['mconf']).all()
+
+
+def test_train_step_with_padded_masks(model):
+    """A padded-mask batch (images of different valid sizes on one 480 x 640 canvas, data['mask0'] / ['mask1'] at the coarse grid:
+    coarse_matching.py:28-57, 110-117, loftr.py:103-111) through pipeline.train_step on the GPU: round 3 raised NotImplementedError.
+    The coarse stage takes the dense differentiable form (pinned to the reference by golden G18 on CPU tensors); here: no predicted
+    or sampled match touches a padded cell, conf_matrix is zero there, the coarse loss weights follow compute_c_weight
+    (loftr_loss.py:184-191), every parameter gets a finite gradient, and the batch without masks still takes the sparse kernels."""
+    import copy
+    from far_amd.config import far_train_config, RunCfg
+    from far_amd.losses import LoFTRLoss
+    from far_amd.pipeline import train_step
+    cfg = far_train_config()
+    m = copy.deepcopy(model).train()
+    loss_fn = LoFTRLoss(cfg).train()
+    base = synth.synth_training_batch(2, seed=78, device='cuda')
+    # valid extents at the coarse grid: pair 0: 52 x 80 / 60 x 70; pair 1: 60 x 64 / 48 x 80 (rows x columns); pixels beyond are zero
+    ext0, ext1 = [(52, 80), (60, 64)], [(60, 70), (48, 80)]
+    m0 = torch.zeros(2, 60, 80, dtype=torch.bool, device='cuda')
+    m1 = torch.zeros(2, 60, 80, dtype=torch.bool, device='cuda')
+    batch = dict(base)
+    batch['image0'], batch['image1'] = base['image0'].clone(), base['image1'].clone()
+    for n in range(2):
+        m0[n, :ext0[n][0], :ext0[n][1]] = True
+        m1[n, :ext1[n][0], :ext1[n][1]] = True
+        batch['image0'][n, :, 8 * ext0[n][0]:, :] = 0; batch['image0'][n, :, :, 8 * ext0[n][1]:] = 0
+        batch['image1'][n, :, 8 * ext1[n][0]:, :] = 0; batch['image1'][n, :, :, 8 * ext1[n][1]:] = 0
+    keep = m0.flatten(1)[base['spv_b_ids'], base['spv_i_ids']] & m1.flatten(1)[base['spv_b_ids'], base['spv_j_ids']]
+    for k in ('spv_b_ids', 'spv_i_ids', 'spv_j_ids'):
+        batch[k] = base[k][keep]
+    batch['mask0'], batch['mask1'] = m0, m1
+    torch.manual_seed(5)
+    train_step(m, batch, loss_fn, RunCfg('prior_ransac', 2), H=512, seed=0)
+    conf = batch['conf_matrix']
+    assert conf is not None and conf.shape == (2, 4800, 4800) and conf.requires_grad          # the dense form
+    pad0, pad1 = ~m0.flatten(1), ~m1.flatten(1)
+    assert float(conf.detach()[0][pad0[0]].abs().max()) == 0.0 and float(conf.detach()[1][:, pad1[1]].abs().max()) == 0.0
+    b, i, j = batch['b_ids'], batch['i_ids'], batch['j_ids']
+    assert bool(m0.flatten(1)[b, i].all()) and bool(m1.flatten(1)[b, j].all())
+    a0 = torch.tensor([e[0] * e[1] for e in ext0]); a1 = torch.tensor([e[0] * e[1] for e in ext1])
+    n_train = int(int(torch.minimum(a0, a1).sum()) * m.coarse_matching.train_coarse_percent)   # compute_max_candidates :46-57
+    assert len(b) == n_train, (len(b), n_train)
+    assert torch.isfinite(batch['loss']).all()
+    batch['loss'].backward()
+    for k, p_ in m.named_parameters():
+        assert p_.grad is not None and torch.isfinite(p_.grad).all(), k
+    # the same module, a batch without masks: back on the sparse kernels
+    plain = dict(base)
+    torch.manual_seed(5)
+    train_step(m, plain, loss_fn, RunCfg('prior_ransac', 2), H=512, seed=0)
+    assert plain['conf_matrix'] is None and plain['conf_pos'].shape == base['spv_b_ids'].shape

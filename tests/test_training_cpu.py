@@ -107,3 +107,47 @@ def test_ddp_two_ranks_gloo_gradient_allreduce():
     assert l0 != l1                                      # different data per rank ...
     assert s0 == pytest.approx(s1, rel=1e-6) and n0 == pytest.approx(n1, rel=1e-6)   # ... identical averaged grads
     assert b0 == pytest.approx(b1, rel=1e-6) and n0 > 0
+
+
+@pytest.mark.parametrize('mode', ['train', 'eval'])
+def test_g18_masked_coarse_matching_matches_reference(mode):
+    """Padded-mask batches through far_amd.loftr.stages.CoarseMatching on CPU tensors (the dense differentiable form, which is
+    also what GPU training uses for masked batches) against the reference's own module on the same tensors and seed (golden
+    G18): masked dual softmax, mask_border_with_padding, compute_max_candidates, the training-time sampling / GT padding
+    (coarse_matching.py:28-57, 110-117, 199-240) -- ids bit-identical, confidences and the gradient through the masked
+    softmax to fp32 round-off."""
+    from far_amd.loftr.stages import CoarseMatching
+    from tests.util import masked_coarse_inputs
+    g = np.load(os.path.join(G, 'g18_masked_training_coarse.npz'))
+    inp = masked_coarse_inputs()
+    h, w = inp['h'], inp['w']
+    cm = CoarseMatching(far_eval_config()['match_coarse'])
+    cm.train(mode == 'train')
+    cm.materialize_conf = True
+    data = {'hw0_i': (8 * h, 8 * w), 'hw1_i': (8 * h, 8 * w), 'hw0_c': (h, w), 'hw1_c': (h, w),
+            'mask0': torch.from_numpy(inp['mask0']), 'mask1': torch.from_numpy(inp['mask1']),
+            'spv_b_ids': torch.from_numpy(inp['spv_b_ids']), 'spv_i_ids': torch.from_numpy(inp['spv_i_ids']),
+            'spv_j_ids': torch.from_numpy(inp['spv_j_ids'])}
+    f0 = torch.from_numpy(inp['f0']).requires_grad_(mode == 'train')
+    f1 = torch.from_numpy(inp['f1']).requires_grad_(mode == 'train')
+    torch.manual_seed(1234)
+    if mode == 'train':
+        cm(f0, f1, data, mask_c0=data['mask0'].flatten(-2), mask_c1=data['mask1'].flatten(-2))
+    else:
+        with torch.no_grad():
+            cm._forward_train(f0, f1, data, data['mask0'].flatten(-2), data['mask1'].flatten(-2))    # the dense form, eval-mode selection
+    for k in ('b_ids', 'i_ids', 'j_ids', 'gt_mask', 'm_bids'):
+        np.testing.assert_array_equal(data[k].numpy(), g[f'{mode}_{k}'], err_msg=k)
+    np.testing.assert_allclose(data['mkpts0_c'].numpy(), g[f'{mode}_mkpts0_c'])
+    np.testing.assert_allclose(data['mkpts1_c'].numpy(), g[f'{mode}_mkpts1_c'])
+    np.testing.assert_allclose(data['mconf'].detach().numpy(), g[f'{mode}_mconf'], rtol=2e-5, atol=1e-7)
+    conf = data['conf_matrix']
+    np.testing.assert_allclose(conf.detach().sum((1, 2)).numpy(), g[f'{mode}_conf_sum'], rtol=1e-5)
+    np.testing.assert_allclose(conf.detach()[:, ::37, ::41].numpy(), g[f'{mode}_conf_sample'], rtol=2e-5, atol=1e-8)
+    if mode == 'train':
+        pos = conf[data['spv_b_ids'], data['spv_i_ids'], data['spv_j_ids']]
+        pos.sum().backward()
+        np.testing.assert_allclose(pos.detach().numpy(), g['train_pos_conf'], rtol=2e-5, atol=1e-8)
+        np.testing.assert_allclose(f0.grad.norm().item(), float(g['train_df0_norm']), rtol=1e-4)
+        np.testing.assert_allclose(f1.grad.norm().item(), float(g['train_df1_norm']), rtol=1e-4)
+        np.testing.assert_allclose(f0.grad[:, ::53, ::17].numpy(), g['train_df0_sample'], rtol=1e-3, atol=1e-6)

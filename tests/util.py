@@ -267,3 +267,31 @@ def planar_scene(M, seed, kind, noise=0.3, outl=0.2, K=None):
         idx = rng.choice(M, no, replace=False)
         p1[idx] = np.stack([rng.uniform(0, 640, no), rng.uniform(0, 480, no)], 1)
     return p0.astype(np.float32), p1.astype(np.float32), R, t / np.linalg.norm(t)
+
+
+def masked_coarse_inputs(seed=91, N=2, h=24, w=32, C=256):
+    """Shared by tools/make_goldens.py:g18 and the tests: coarse feature maps of a padded-mask batch (images of different sizes
+    padded to one h x w grid, as MegaDepth / ScanNet-style batches are): correlated features, validity masks, sparse ground-truth
+    ids inside the valid regions."""
+    rng = np.random.default_rng(seed)
+    L = h * w
+    f0 = (1.2 * rng.standard_normal((N, L, C))).astype(np.float32)
+    f1 = np.zeros_like(f0)
+    ii, jj, bb = [], [], []
+    valid0 = [(h, w - 8), (h - 6, w)]
+    valid1 = [(h - 4, w), (h, w - 10)]
+    m0 = np.zeros((N, h, w), bool)
+    m1 = np.zeros((N, h, w), bool)
+    for n in range(N):
+        m0[n, :valid0[n][0], :valid0[n][1]] = True
+        m1[n, :valid1[n][0], :valid1[n][1]] = True
+        perm = rng.permutation(L)
+        f1[n] = f0[n][perm] + 0.15 * rng.standard_normal((L, C)).astype(np.float32)
+        inv = np.argsort(perm)                               # f1[j] ~ f0[perm[j]]  ->  i = perm[j]
+        for j in range(L):
+            i = perm[j]
+            if m0[n].reshape(-1)[i] and m1[n].reshape(-1)[j] and rng.uniform() < 0.5:
+                bb.append(n); ii.append(i); jj.append(j)
+    order = np.lexsort((np.array(ii), np.array(bb)))
+    return {'f0': f0, 'f1': f1, 'mask0': m0, 'mask1': m1, 'spv_b_ids': np.array(bb, np.int64)[order],
+            'spv_i_ids': np.array(ii, np.int64)[order], 'spv_j_ids': np.array(jj, np.int64)[order], 'h': h, 'w': w}

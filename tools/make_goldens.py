@@ -606,6 +606,43 @@ def g17_fivepoint():
          'tools/ref_shim.py, determinant_to_polynomial = the reference\'s own cv_geometry.py:23-551', **out)
 
 
+def g18_masked_training_coarse():
+    """CoarseMatching.forward in TRAINING mode on a padded-mask batch (coarse_matching.py:86-147: masked_fill of the similarity,
+    dual softmax; get_coarse_match :150-265 with mask_border_with_padding :28-43, compute_max_candidates :46-57 and the training-time
+    sampling / GT padding :199-240), run from the reference's own module with a seeded generator; and its eval-mode output on the
+    same tensors."""
+    from src.loftr.utils.coarse_matching import CoarseMatching
+    from tests.util import masked_coarse_inputs
+    inp = masked_coarse_inputs()
+    cfg = ref_shim.far_eval_config()['match_coarse']
+    h, w = inp['h'], inp['w']
+    out = {}
+    for mode in ('train', 'eval'):
+        cm = CoarseMatching(cfg)
+        cm.train(mode == 'train')
+        data = {'hw0_i': (8 * h, 8 * w), 'hw1_i': (8 * h, 8 * w), 'hw0_c': (h, w), 'hw1_c': (h, w),
+                'mask0': torch.from_numpy(inp['mask0']), 'mask1': torch.from_numpy(inp['mask1']),
+                'spv_b_ids': torch.from_numpy(inp['spv_b_ids']), 'spv_i_ids': torch.from_numpy(inp['spv_i_ids']),
+                'spv_j_ids': torch.from_numpy(inp['spv_j_ids'])}
+        f0 = torch.from_numpy(inp['f0']).requires_grad_(mode == 'train')
+        f1 = torch.from_numpy(inp['f1']).requires_grad_(mode == 'train')
+        torch.manual_seed(1234)
+        cm(f0, f1, data, mask_c0=data['mask0'].flatten(-2), mask_c1=data['mask1'].flatten(-2))
+        conf = data['conf_matrix']
+        out.update({f'{mode}_b_ids': data['b_ids'].numpy(), f'{mode}_i_ids': data['i_ids'].numpy(), f'{mode}_j_ids': data['j_ids'].numpy(),
+                    f'{mode}_gt_mask': data['gt_mask'].numpy(), f'{mode}_m_bids': data['m_bids'].numpy(),
+                    f'{mode}_mkpts0_c': data['mkpts0_c'].numpy(), f'{mode}_mkpts1_c': data['mkpts1_c'].numpy(),
+                    f'{mode}_mconf': data['mconf'].detach().numpy(), f'{mode}_conf_sum': conf.detach().sum((1, 2)).numpy(),
+                    f'{mode}_conf_sample': conf.detach()[:, ::37, ::41].numpy()})
+        if mode == 'train':                      # a gradient through the masked dual softmax: d sum(conf[gt]) / d feat
+            pos = conf[data['spv_b_ids'], data['spv_i_ids'], data['spv_j_ids']]
+            pos.sum().backward()
+            out.update({'train_pos_conf': pos.detach().numpy(), 'train_df0_sample': f0.grad[:, ::53, ::17].numpy(),
+                        'train_df0_norm': np.array(f0.grad.norm().item()), 'train_df1_norm': np.array(f1.grad.norm().item())})
+        print('g18', mode, 'matches', len(data['b_ids']), 'kept', len(data['mconf']), 'gt', len(inp['spv_b_ids']))
+    save('g18_masked_training_coarse', **out)
+
+
 def g8_manifest(m):
     man = {k: list(v.shape) for k, v in m.state_dict().items()}
     with open(os.path.join(OUT, 'g8_state_dict_manifest.json'), 'w') as f:
@@ -640,6 +677,9 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'g12':
         g12_ransac_loop()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'g18':
+        g18_masked_training_coarse()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'g17':
         g17_fivepoint()
         sys.exit(0)
@@ -661,3 +701,4 @@ if __name__ == '__main__':
     g15_losses()
     g16_eval_metrics()
     g17_fivepoint()
+    g18_masked_training_coarse()
