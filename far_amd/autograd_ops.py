@@ -1,11 +1,12 @@
 """Differentiable vendor-op forms of the fused operators (torch compositions, autograd supplies the backward).
 
-Who uses them: (1) CPU tensors in training mode (the golden G10 / gloo DDP tests); (2) the explicit comparison legs
-`hip_training = False` / `materialize_conf = True` (bench.py --workload c3 --vendor-train); (3) on the GPU only the
-pieces that have no HIP backward kernel yet (the fine-window gather / expectation; the backbone's training-mode
-convolutions run on the vendor library).  K1 (sparse positions), K2, K5 and K9-Linear have HIP forward + backward
-kernels; the inference path never comes here (it raises on CPU tensors).  Citations as in the kernels they stand
-in for.
+Who uses them: (1) CPU tensors in training mode (the golden G10 / G18 / gloo DDP tests); (2) the explicit comparison legs
+`hip_training = False` / `materialize_conf = True` (bench.py --workload c3 --vendor-train); (3) on the GPU the pieces that have
+no HIP backward kernel: the dense coarse stage of padded-mask batches (`conf_matrix` with masks), the fine-window expectation,
+and -- as plain torch modules, not through this file -- BatchNorm with batch statistics and the FPN interpolation.  Everything
+else of the GPU training step has HIP forward + backward kernels: K1 (sparse positions), K2, K5, K6, K9 (Linear layers and the
+backbone's convolutions, forward + dgrad), K16 (every weight gradient), K10 (stem), K3 gather / scatter;
+the inference path never comes here (it raises on CPU tensors).  Citations as in the kernels they stand in for.
 """
 import torch
 import torch.nn.functional as F

@@ -17,7 +17,7 @@ def _softmax(x, axis):
 def conf_matrix(feat_c0, feat_c1, temperature, mask_c0=None, mask_c1=None, dtype=np.float32):
     """coarse_matching.py:101-118.  feat (N,L,C)/(N,S,C) float32 -> conf (N,L,S).
 
-    dtype=float32 follows the reference's arithmetic type.  NOTE (measured, tests/test_oracle_coarse.py):
+    dtype=float32 follows the reference's arithmetic type.  NOTE (measured, tests/test_oracle_golden.py::test_g1_coarse_full_grid_and_fp32_swamping):
     an fp32 softmax over 4800 entries where one term is ~1 and the rest ~1e-7 loses the small terms to
     swamping; the reference's own torch-CPU result (and this function in float32) deviates up to ~7e-5
     from the exact value.  dtype=float64 evaluates the same formulas on the same fp32 inputs without that
