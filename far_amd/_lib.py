@@ -42,6 +42,7 @@ SIGNATURES = {
     'far_emm_pv_f32': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_p]),
     'far_fine_gather_f32': (c_i, [c_p, c_l, c_l, c_l, c_l, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
     'far_fine_scatter_f32': (c_i, [c_p, c_l, c_l, c_l, c_l, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
+    'far_fine_scatter_det_f32': (c_i, [c_p, c_l, c_l, c_l, c_l, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     'far_fine_expect_f32': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_f, c_p, c_p, c_p, c_p, c_p]),
     'far_linear_attention_workspace_bytes': (c_sz, [c_i, c_i, c_i, c_i]),
     'far_linear_attention_f32': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_p, c_p, c_p]),
@@ -56,6 +57,7 @@ SIGNATURES = {
     'far_mlp_fused_f16s': (c_i, [c_p, c_p, c_p, c_l, c_i, c_f, c_f, c_p, c_p, c_f, c_p, c_p, c_p]),
     'far_affine_act_f32': (c_i, [c_p, c_p, c_p, c_p, c_l, c_i, c_l, c_i, c_i, c_f, c_p, c_p]),
     'far_upsample2x_add_f32': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
+    'far_upsample2x_bwd_f32': (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
     'far_conv_packed_bytes': (c_sz, [c_i, c_i, c_i, c_i, c_i]),
     'far_conv_pack_f32': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     'far_weight_scale_f32': (c_i, [c_p, c_l, c_p, c_p]),

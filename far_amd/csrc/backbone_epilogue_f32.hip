@@ -119,6 +119,58 @@ __global__ __launch_bounds__(256) void k_upsample2x_add(const float4* __restrict
     }
 }
 
+// Gradient of the 2x bilinear upsampling with respect to its input, in gather form: one thread per input pixel (x 4 channels,
+// channels_last) sums the output-gradient pixels whose footprint contains it, rows then columns in increasing order, with the
+// interpolation weights recomputed exactly as the forward computes them.  No atomics: the result is the same bits on every
+// run (ATen's upsample_bilinear2d_backward scatters with atomicAdd and is not).
+__global__ __launch_bounds__(256) void k_upsample2x_bwd(const float4* __restrict__ dout, int N, int h, int w, int cvec,
+                                                        float4* __restrict__ dlo) {
+    const int H = 2 * h, W = 2 * w;
+    const long nvec = (long)N * h * w * cvec;
+    const float ry = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
+    const float rx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < nvec; t += stride) {
+        const int c4 = (int)(t % cvec);
+        long p = t / cvec;
+        const int j = (int)(p % w); p /= w;
+        const int i = (int)(p % h);
+        const int n = (int)(p / h);
+        // output rows Y with floor(ry * Y) in {i - 1, i}: Y in [2i - 2, 2i + 3] covers them for every h (ry in [1/3, 1/2))
+        const int Ya = max(2 * i - 2, 0), Yb = min(2 * i + 3, H - 1);
+        const int Xa = max(2 * j - 2, 0), Xb = min(2 * j + 3, W - 1);
+        float wx[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int X = Xa + k;
+            const float sx = rx * (float)X;
+            const int x0 = (int)sx, x1 = x0 + (x0 < w - 1 ? 1 : 0);
+            const float lx = sx - (float)x0, hx = 1.f - lx;
+            wx[k] = X <= Xb ? (x0 == j ? hx : 0.f) + (x1 == j ? lx : 0.f) : 0.f;
+        }
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4* base = dout + (long)n * H * W * cvec + c4;
+        for (int Y = Ya; Y <= Yb; ++Y) {
+            const float sy = ry * (float)Y;
+            const int y0 = (int)sy, y1 = y0 + (y0 < h - 1 ? 1 : 0);
+            const float ly = sy - (float)y0, hy = 1.f - ly;
+            const float wy = (y0 == i ? hy : 0.f) + (y1 == i ? ly : 0.f);
+            if (wy == 0.f) continue;
+            float4 row = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                if (wx[k] == 0.f) continue;
+                const float4 g = base[((long)Y * W + Xa + k) * cvec];
+                row.x = fmaf(wx[k], g.x, row.x); row.y = fmaf(wx[k], g.y, row.y);
+                row.z = fmaf(wx[k], g.z, row.z); row.w = fmaf(wx[k], g.w, row.w);
+            }
+            acc.x = fmaf(wy, row.x, acc.x); acc.y = fmaf(wy, row.y, acc.y);
+            acc.z = fmaf(wy, row.z, acc.z); acc.w = fmaf(wy, row.w, acc.w);
+        }
+        dlo[t] = acc;
+    }
+}
+
 inline unsigned grid_for(long nvec) {
     long b = (nvec + 255) / 256;
     return (unsigned)(b < 256L * 16 ? (b > 0 ? b : 1) : 256L * 16);
@@ -161,6 +213,18 @@ int far_upsample2x_add_f32(const float* lo, const float* hi, int N, int h, int w
     else
         hipLaunchKernelGGL(k_upsample2x_add_nchw, dim3(grid_for(nvec)), dim3(256), 0, stream, lo, (const float4*)hi,
                            (long)N * C, h, w, (float4*)out);
+    return far_check_launch();
+}
+
+// dlo [N][h][w][C] = gradient of upsample2x_bilinear_align_corners(lo) given dout [N][2h][2w][C] (channels_last, C % 4 == 0);
+// fixed summation order, run-to-run bit-identical.  Replaces ATen upsample_bilinear2d_backward (atomics) on the training path.
+int far_upsample2x_bwd_f32(const float* dout, int N, int h, int w, int C, float* dlo, hipStream_t stream) {
+    far_clear_errors();
+    if (N == 0) return FAR_OK;
+    if (!dout || !dlo || N < 0 || h <= 0 || w <= 0 || C <= 0 || (C & 3)) return FAR_EINVAL;
+    const long nvec = (long)N * h * w * (C / 4);
+    hipLaunchKernelGGL(k_upsample2x_bwd, dim3(grid_for(nvec)), dim3(256), 0, stream, (const float4*)dout, N, h, w, C / 4,
+                       (float4*)dlo);
     return far_check_launch();
 }
 

@@ -51,6 +51,46 @@ __global__ void k_fine_scatter(const float* __restrict__ dout, long sn, long sc,
     }
 }
 
+// The same backward with a FIXED summation order (the training step's other reductions are all fixed-order: K16, K6, the stem):
+// pixel-centric instead of match-centric.  The host sorts the matches by (image, coarse cell) -- a stable sort of the key
+// b * ncell + cell -- and passes `order` (match indices in that order) and `start` (first position of every (image, cell) group,
+// Z * ncell + 1 entries).  One wave per fine-map pixel: the (at most ceil(W / stride)^2) coarse cells whose window covers it are
+// visited in ascending (row, column) order, their matches in sorted order, channels across the lanes: every dfeat element is one
+// thread's sequential sum.  Pixels no window covers are left as they are.
+__global__ __launch_bounds__(256) void k_fine_scatter_det(const float* __restrict__ dout, long sn, long sc, long sh, long sw, int C, int Hf,
+                                                          int Wf, const int64_t* __restrict__ order, const int* __restrict__ start, int wc,
+                                                          int hc, int W, int stride, long npix, float* __restrict__ dfeat) {
+    const long pix = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (pix >= npix) return;
+    const int x = (int)(pix % Wf);
+    const int y = (int)((pix / Wf) % Hf);
+    const long b = pix / ((long)Wf * Hf);
+    const int WW = W * W, pad = W / 2;
+    // cells (cy, cx) with cy * stride - pad <= y <= cy * stride + pad
+    int cy0 = (y - pad + stride - 1) / stride, cy1 = (y + pad) / stride;
+    int cx0 = (x - pad + stride - 1) / stride, cx1 = (x + pad) / stride;
+    cy0 = cy0 < 0 ? 0 : cy0; cx0 = cx0 < 0 ? 0 : cx0;
+    cy1 = cy1 >= hc ? hc - 1 : cy1; cx1 = cx1 >= wc ? wc - 1 : cx1;
+    const long ncell = (long)hc * wc;
+    float* const dst = dfeat + b * sn + (long)y * sh + (long)x * sw;
+    for (int c0 = lane; c0 < C; c0 += 64) {
+        float acc = 0.f;
+        bool any = false;
+        for (int cy = cy0; cy <= cy1; ++cy)
+            for (int cx = cx0; cx <= cx1; ++cx) {
+                const long g = b * ncell + (long)cy * wc + cx;
+                const int s0 = start[g], s1 = start[g + 1];
+                const int ww = (y - (cy * stride - pad)) * W + (x - (cx * stride - pad));
+                for (int s = s0; s < s1; ++s) {
+                    acc += dout[((size_t)order[s] * WW + ww) * C + c0];
+                    any = true;
+                }
+            }
+        if (any) dst[(long)c0 * sc] += acc;
+    }
+}
+
 // One wave per match.  feat0/feat1 [M][WW][C].  expec [M][3] = (E[x], E[y], std); mkpts1_f [M][2].
 __global__ void k_fine_expect(const float* __restrict__ feat0, const float* __restrict__ feat1, int M, int W,
                               int C, const float* __restrict__ mkpts1_c, float win_scale,
@@ -134,6 +174,25 @@ int far_fine_scatter_f32(const float* dout, long sn, long sc, long sh, long sw, 
     if (!dout || !b_ids || !cell_ids || !dfeat || M < 0 || C <= 0 || W <= 0 || (W & 1) == 0 || wc <= 0) return FAR_EINVAL;
     hipLaunchKernelGGL(k_fine_scatter, dim3(M), dim3(256), 0, stream, dout, sn, sc, sh, sw, C, Hf, Wf, b_ids, cell_ids,
                        wc, W, stride, M, dfeat);
+    return far_check_launch();
+}
+
+// The same with a fixed summation order (bit-identical from run to run): `order` = the match indices sorted (stably) by
+// b_ids * (hc * wc) + cell_ids, `start` = Z * hc * wc + 1 int32 offsets of the (image, cell) groups in that order (start[g + 1] -
+// start[g] = matches of group g).  Z images of Hf x Wf pixels; the matches' windows are W x W at `stride` around the cells of the
+// hc x wc coarse grid.
+int far_fine_scatter_det_f32(const float* dout, long sn, long sc, long sh, long sw, int C, int Hf, int Wf, const int64_t* order,
+                             const int* start, int Z, int hc, int wc, int W, int stride, int M, float* dfeat, hipStream_t stream) {
+    far_clear_errors();
+    if (M == 0 || Z == 0) return FAR_OK;
+    if (!dout || !order || !start || !dfeat || M < 0 || Z < 0 || C <= 0 || W <= 0 || (W & 1) == 0 || wc <= 0 || hc <= 0 || stride <= 0 ||
+        Hf <= 0 || Wf <= 0)
+        return FAR_EINVAL;
+    const long npix = (long)Z * Hf * Wf;
+    const long blocks = (npix + 3) / 4;
+    if (blocks > 0x7fffffffL) return FAR_EINVAL;
+    hipLaunchKernelGGL(k_fine_scatter_det, dim3((unsigned)blocks), dim3(256), 0, stream, dout, sn, sc, sh, sw, C, Hf, Wf, order, start, wc, hc,
+                       W, stride, npix, dfeat);
     return far_check_launch();
 }
 

@@ -105,11 +105,16 @@ class ResNetFPN_8_2(nn.Module):
     def _outconv2(self, seq, x):
         return _conv(seq[3], seq[2](seq[1](_conv(seq[0], x, self))), self)
 
+    def _merge(self, lateral, coarse):
+        """lateral + 2x bilinear upsampling of the coarser level (:108-109, :113-114)."""
+        if (ResNetFPN_8_2.hip_training and lateral.is_cuda and lateral.dtype == torch.float32 and torch.is_grad_enabled()
+                and lateral.shape[1] % 4 == 0 and tuple(lateral.shape[2:]) == (2 * coarse.shape[2], 2 * coarse.shape[3])):
+            return ops.upsample2x_add_train(coarse, lateral)          # K8 + its fixed-order gradient
+        return lateral + F.interpolate(coarse, scale_factor=2., mode='bilinear', align_corners=True)
+
     def _fpn_plain(self, x1, x2, x3_out):
-        up3 = F.interpolate(x3_out, scale_factor=2., mode='bilinear', align_corners=True)
-        x2_out = self._outconv2(self.layer2_outconv2, _conv(self.layer2_outconv, x2, self) + up3)
-        up2 = F.interpolate(x2_out, scale_factor=2., mode='bilinear', align_corners=True)
-        return self._outconv2(self.layer1_outconv2, _conv(self.layer1_outconv, x1, self) + up2)
+        x2_out = self._outconv2(self.layer2_outconv2, self._merge(_conv(self.layer2_outconv, x2, self), x3_out))
+        return self._outconv2(self.layer1_outconv2, self._merge(_conv(self.layer1_outconv, x1, self), x2_out))
 
     # ---- inference fast path: NHWC activations, K10 + K9 + K8 (tensors below are (N, H, W, C)) ----------------
     # K9 operand precision: True = split fp16 pairs (fp32-grade, the parity configuration), False = plain fp16.

@@ -343,6 +343,9 @@ def fine_gather(feat_f, b_ids, cell_ids, wc, W, stride, out=None):
     return _written(out)
 
 
+DETERMINISTIC_FINE_SCATTER = True      # False: far_fine_scatter_f32 (fp32 atomics: the summation order varies from run to run)
+
+
 class _FineWindowsFn(torch.autograd.Function):
     """K3a with its HIP backward: the M x 25 x C windows gathered directly (forward) and their gradients scattered back
     into the fine map (backward) -- the reference unfolds both full fine maps (123 MB per pair, fine_preprocess.py:40-44)
@@ -366,10 +369,23 @@ class _FineWindowsFn(torch.autograd.Function):
         M = int(b_ids.shape[0])
         if M:
             g = g.float().contiguous()
-            rc = lib.far_fine_scatter_f32(_p(g, torch.float32), strides[0], strides[1], strides[2], strides[3], C, Hf, Wf,
-                                          _p(b_ids, torch.int64), _p(cell_ids, torch.int64), wc, W, stride, M,
-                                          ctypes.c_void_p(d.data_ptr()), _stream())
-            _lib.check(rc, 'far_fine_scatter_f32')
+            hc = -(-Hf // stride)                                 # the coarse grid the cell ids index (Hf = stride * hc)
+            if DETERMINISTIC_FINE_SCATTER and cell_ids.numel() and int(wc) * hc < (1 << 31) // max(N, 1):
+                # fixed summation order: matches grouped by (image, cell) with a stable sort; one wave per fine-map pixel
+                ncell = int(wc) * hc
+                key = b_ids * ncell + cell_ids
+                order = torch.argsort(key, stable=True)
+                start = torch.zeros(N * ncell + 1, dtype=torch.int32, device=g.device)
+                start[1:] = torch.cumsum(torch.bincount(key, minlength=N * ncell), 0).to(torch.int32)
+                rc = lib.far_fine_scatter_det_f32(_p(g, torch.float32), strides[0], strides[1], strides[2], strides[3], C, Hf, Wf,
+                                                  _p(order, torch.int64), _p(start, torch.int32), N, hc, wc, W, stride, M,
+                                                  ctypes.c_void_p(d.data_ptr()), _stream())
+                _lib.check(rc, 'far_fine_scatter_det_f32')
+            else:
+                rc = lib.far_fine_scatter_f32(_p(g, torch.float32), strides[0], strides[1], strides[2], strides[3], C, Hf, Wf,
+                                              _p(b_ids, torch.int64), _p(cell_ids, torch.int64), wc, W, stride, M,
+                                              ctypes.c_void_p(d.data_ptr()), _stream())
+                _lib.check(rc, 'far_fine_scatter_f32')
         return d.to(dt), None, None, None, None, None
 
 
@@ -815,6 +831,35 @@ def upsample2x_add(lo, hi):
                                     ctypes.c_void_p(out.data_ptr()), _stream())
     _lib.check(rc, 'far_upsample2x_add_f32')
     return out
+
+
+class _Upsample2xAddFn(torch.autograd.Function):
+    """hi + F.interpolate(lo, scale_factor=2, mode='bilinear', align_corners=True) with gradients (resnet_fpn.py:108-109,
+    :113-114 under autograd): forward K8, backward far_upsample2x_bwd_f32 -- a gather in a fixed order, where the node torch
+    records for F.interpolate scatters with atomics (the one source of run-to-run differences in the backbone gradients)."""
+
+    @staticmethod
+    def forward(ctx, lo, hi):
+        cl = torch.channels_last
+        return upsample2x_add(lo.detach().contiguous(memory_format=cl), hi.detach().contiguous(memory_format=cl))
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        N, C, H, W = g.shape
+        dlo = None
+        if ctx.needs_input_grad[0]:
+            gn = g.float().contiguous(memory_format=torch.channels_last)
+            dlo = torch.empty(N, C, H // 2, W // 2, dtype=torch.float32, device=g.device, memory_format=torch.channels_last)
+            rc = lib.far_upsample2x_bwd_f32(ctypes.c_void_p(gn.data_ptr()), N, H // 2, W // 2, C, ctypes.c_void_p(dlo.data_ptr()),
+                                            _stream())
+            _lib.check(rc, 'far_upsample2x_bwd_f32')
+        return dlo, (g if ctx.needs_input_grad[1] else None)
+
+
+def upsample2x_add_train(lo, hi):
+    """K8 with gradients; lo (N, C, h, w), hi (N, C, 2h, 2w) fp32 GPU, C % 4 == 0."""
+    return _Upsample2xAddFn.apply(lo, hi)
 
 
 _ACT = {'none': 0, 'relu': 1, 'leaky': 2}

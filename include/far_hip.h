@@ -204,6 +204,11 @@ int far_fine_gather_f32(const float* feat, long sn, long sc, long sh, long sw, i
 int far_fine_scatter_f32(const float* dout, long sn, long sc, long sh, long sw, int C, int Hf, int Wf,
                          const int64_t* b_ids, const int64_t* cell_ids, int wc, int W, int stride, int M,
                          float* dfeat, far_stream_t stream);
+/* The same backward with a fixed summation order (run-to-run bit-identical; far_fine_scatter_f32 adds with fp32 atomics):
+ * order = the match indices sorted stably by b_ids * (hc * wc) + cell_ids, start = Z * hc * wc + 1 int32 group offsets in that
+ * order.  One wave per fine-map pixel sums the windows that cover it, cells in ascending (row, column) order. */
+int far_fine_scatter_det_f32(const float* dout, long sn, long sc, long sh, long sw, int C, int Hf, int Wf, const int64_t* order,
+                             const int* start, int Z, int hc, int wc, int W, int stride, int M, float* dfeat, far_stream_t stream);
 int far_fine_expect_f32(const float* feat0, const float* feat1, int M, int W, int C, const float* mkpts1_c,
                         float win_scale, const float* scale1, const int64_t* b_ids, float* expec_f,
                         float* mkpts1_f, far_stream_t stream);
@@ -315,6 +320,12 @@ int far_affine_act_f32(const float* x, const float* scale, const float* shift, c
  * layout selected by nhwc (0: NCHW, w even; 1: channels_last, C % 4 == 0). */
 int far_upsample2x_add_f32(const float* lo, const float* hi, int N, int h, int w, int C, int nhwc, float* out,
                            far_stream_t stream);
+
+/* Gradient of that upsampling with respect to lo: dlo [N][h][w][C] from dout [N][2h][2w][C] (channels_last memory, C % 4 == 0),
+ * gathered in a fixed order -- bit-identical from run to run.  Replaces the autograd node torch records for
+ * F.interpolate(..., scale_factor=2, mode='bilinear', align_corners=True) at resnet_fpn.py:108,113 (its ATen backward scatters
+ * with atomics). */
+int far_upsample2x_bwd_f32(const float* dout, int N, int h, int w, int C, float* dlo, far_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * K9  implicit-GEMM convolution / linear layer on the f16 matrix cores with split-precision operands

@@ -337,6 +337,21 @@ def test_fine_window_gather_backward_matches_unfold_autograd():
     err = float((f1.grad.double() - f2.grad).abs().max()) / float(f2.grad.abs().max())
     print(f'[k3 bwd] fine-map gradient: relative max error {err:.2e}')
     assert err < 1e-6 and f1.grad.shape == feat.shape
+    # round 4: the fixed-order scatter (far_fine_scatter_det_f32, the default) is bit-identical from run to run; the atomic form
+    # (ops.DETERMINISTIC_FINE_SCATTER = False) gives the same values to round-off
+    grads = []
+    for _ in range(5):
+        f3 = feat.clone().requires_grad_(True)
+        (ops.fine_windows_train(f3, b, cell, wc, W, stride) * up).sum().backward()
+        grads.append(f3.grad)
+    assert all(torch.equal(grads[0], x) for x in grads[1:]) and torch.equal(grads[0], f1.grad)
+    ops.DETERMINISTIC_FINE_SCATTER = False
+    try:
+        f4 = feat.clone().requires_grad_(True)
+        (ops.fine_windows_train(f4, b, cell, wc, W, stride) * up).sum().backward()
+    finally:
+        ops.DETERMINISTIC_FINE_SCATTER = True
+    assert float((f4.grad.double() - f2.grad).abs().max()) / float(f2.grad.abs().max()) < 1e-6
 
 
 @pytest.mark.parametrize('Cin,Cout,ks,stride,H,W', [(128, 128, 3, 1, 24, 32), (128, 196, 3, 2, 24, 32), (196, 256, 3, 2, 13, 17),
@@ -599,3 +614,30 @@ def test_encoder_layer_node_is_run_to_run_deterministic_with_side_streams():
         else:
             for a, b in zip(cur, ref):
                 assert torch.equal(a, b), rep
+
+
+@pytest.mark.parametrize('N,C,h,w', [(2, 196, 15, 20), (1, 256, 8, 10), (3, 4, 1, 1), (1, 8, 2, 3), (2, 128, 30, 40), (1, 12, 7, 1)])
+def test_upsample_add_train_matches_float64_autograd_and_is_deterministic(N, C, h, w):
+    """The FPN merge under autograd (resnet_fpn.py:108-109, :113-114): K8 forward, far_upsample2x_bwd_f32 backward (gather form,
+    fixed order) against torch's own fp32 F.interpolate under autograd -- the source coordinate is computed in fp32 by both, which
+    a float64 evaluation does not reproduce to better than 1e-5 -- and bit-identical over repeated runs."""
+    import torch.nn.functional as F
+    from far_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(N * 100 + C + h)
+    lo = torch.randn(N, C, h, w, device='cuda', generator=g).contiguous(memory_format=torch.channels_last).requires_grad_()
+    hi = torch.randn(N, C, 2 * h, 2 * w, device='cuda', generator=g).contiguous(memory_format=torch.channels_last).requires_grad_()
+    up = torch.randn(N, C, 2 * h, 2 * w, device='cuda', generator=g)
+    lod, hid = lo.detach().clone().requires_grad_(), hi.detach().clone().requires_grad_()
+    ref = hid + F.interpolate(lod, scale_factor=2., mode='bilinear', align_corners=True)
+    ref.backward(up)
+    outs = []
+    for _ in range(4):
+        lo.grad = hi.grad = None
+        y = ops.upsample2x_add_train(lo, hi)
+        y.backward(up)
+        outs.append((y.detach().clone(), lo.grad.clone(), hi.grad.clone()))
+    torch.testing.assert_close(outs[0][0], ref.detach(), atol=2e-6, rtol=1e-6)
+    torch.testing.assert_close(outs[0][1], lod.grad, atol=4e-6, rtol=1e-6)
+    assert torch.equal(outs[0][2], up)
+    for o in outs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(o, outs[0]))
