@@ -164,20 +164,35 @@ def kernel_rooflines(n_pairs):
     # K9: split-fp16 implicit GEMM.  tflops = ALGORITHMIC convolution flops (2 N H W Cin Cout 9) / time, priced
     # against the dense f16 MFMA peak; the kernel issues three MFMAs per fp32-grade product, so its matrix-pipe
     # occupancy is mfma_issue_frac = 3 x frac.
+    # K17 (the inference step's stride-1 3x3 layers since round 4): Winograd F(2x2, 3x3) on the same split operands -- 16 products
+    # per 2x2 outputs where the direct form has 36, so it EXECUTES 3 * 16/36 = 1.33 MFMA flops per algorithmic flop (times
+    # the padding of Cin to 16, Cout to 64 and the map to 16 x 16-pixel workgroup tiles); `tflops` stays algorithmic.
     nimg = 2 * n_pairs
+    use_wino = ops.USE_WINO
     for label, (H, W, ci, co, ks) in {'k_conv[K9 3x3 196->196 @240x320]': (240, 320, 196, 196, 3),
                                       'k_conv[K9 3x3 128->128 @240x320]': (240, 320, 128, 128, 3),
                                       'k_conv[K9 3x3 256->256 @120x160]': (120, 160, 256, 256, 3),
                                       'k_conv[K9 linear 256->256, 4800 rows/image]': (1, 4800, 256, 256, 1)}.items():
         x = torch.randn(nimg, H, W, ci, device=dev, generator=g).relu_()
-        pc = ops.PackedConv(torch.randn(co, ci, ks, ks, device=dev, generator=g) * (2.0 / (ci * ks * ks)) ** 0.5,
-                            torch.ones(co, device=dev), torch.zeros(co, device=dev))
+        wt = torch.randn(co, ci, ks, ks, device=dev, generator=g) * (2.0 / (ci * ks * ks)) ** 0.5
+        pc = ops.PackedConv(wt, torch.ones(co, device=dev), torch.zeros(co, device=dev))
+        ops.USE_WINO = False
         t9 = event_time_ms(lambda: ops.conv_nhwc(x, pc, act='relu'), iters=3, warm=1)
+        ops.USE_WINO = use_wino
         fl9 = 2.0 * nimg * H * W * ci * co * ks * ks
         # MFMAs the launch executes: output channels padded to the 128-wide channel block, input channels to 16 per tap
         pad = (-(-co // 128) * 128 / co) * (-(-ci // 16) * 16 / ci)
         out[label] = dict(ms=t9, tflops=fl9 / t9 / 1e9, frac=fl9 / t9 / 1e9 / F16_MFMA_PEAK_TFLOPS,
                           mfma_issue_frac=3 * fl9 / t9 / 1e9 / F16_MFMA_PEAK_TFLOPS, mfma_executed_tflops=3 * pad * fl9 / t9 / 1e9)
+        if ks == 3:
+            pw = ops.PackedWino(wt, torch.ones(co, device=dev), torch.zeros(co, device=dev))
+            t17 = event_time_ms(lambda: ops.conv3x3_wino(x, pw, act='relu'), iters=3, warm=1)
+            padw = (-(-co // 64) * 64 / co) * (-(-ci // 16) * 16 / ci) * (-(-H // 16) * 16 / H) * (-(-W // 16) * 16 / W)
+            ex = 3.0 * 16.0 / 36.0 * padw
+            out[label.replace('k_conv[K9', 'k_wino[K17')] = dict(
+                ms=t17, tflops=fl9 / t17 / 1e9, frac=fl9 / t17 / 1e9 / F16_MFMA_PEAK_TFLOPS,
+                mfma_issue_frac=ex * fl9 / t17 / 1e9 / F16_MFMA_PEAK_TFLOPS, mfma_executed_tflops=ex * fl9 / t17 / 1e9,
+                speedup_over_k9=t9 / t17)
         del x
     return out
 
@@ -203,7 +218,7 @@ def pmc_traffic(kernel_label, n_pairs, precision):
         if val.get('label') == kernel_label:
             ent = val
             break
-    if ent is None and name == 'k_conv':          # round-1 file: keyed by template instantiation and grid
+    if ent is None and name == 'k_conv' and 'profiles/r01' in path:          # round-1 file: keyed by template instantiation and grid
         ent = per.get(f'k_conv<3, 2, 2, 4, true, 1>|grid={2 * n_pairs * 30 * 20 * 256}')
     return None if ent is None else {'bytes': ent['total_bytes'], 'read_bytes': ent['read_bytes'],
                                      'write_bytes': ent['write_bytes'], 'precision': doc.get('precision', 'fp32'),
@@ -220,7 +235,7 @@ def rocprof_launch_ms(kernel_label):
     for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_bench_fp32_kernel_trace.txt')), reverse=True):
         txt = open(path).read()
         m = re.search(r'roofline_launch_rocprof: kernel=' + re.escape(kernel_label) + r' calls=(\d+) avg_us=([0-9.]+)', txt)
-        if m is None and kernel_label == 'k_conv[K9 3x3 196->196 @240x320]':
+        if m is None and kernel_label == 'k_conv[K9 3x3 196->196 @240x320]' and re.search(r'r0[12]_bench', path):
             m = re.search(r'grid \(9830400, 1, 1\) calls (\d+)\s+avg ([0-9.]+) us', txt)
         if m:
             return {'ms': round(float(m.group(2)) / 1e3, 3), 'calls': int(m.group(1)), 'source': os.path.relpath(path, ROOT)}
@@ -770,12 +785,16 @@ def main():
         per_rank_peak = [round(x, 1) for x in parallel.gather_floats(pk, device=dev)]
     if rank == 0:
         kr = kernel_rooflines(a.pairs)
-        # dominant kernel of the step: K9 (60 % of the kernel-busy time, profiles/); its costliest launch is reported
-        dom = 'k_conv[K9 3x3 196->196 @240x320]'
+        # dominant kernel of the step: the backbone's 3x3 convolutions (45 % of the kernel-busy time, profiles/); its costliest launch
+        # is reported -- K17 (Winograd) since round 4, K9 (direct) when ops.USE_WINO is off
+        from far_amd import ops as _ops
+        wino = _ops.USE_WINO
+        dom = 'k_wino[K17 3x3 196->196 @240x320]' if wino else 'k_conv[K9 3x3 196->196 @240x320]'
         tr = pmc_traffic(dom, a.pairs, a.precision)
         probe = mfma_sustained_peak()
         sustained = max(v['tflops'] for v in probe.values())
-        executed = kr[dom].get('mfma_executed_tflops', 3 * kr[dom]['tflops'])
+        executed = kr[dom]['mfma_executed_tflops']
+        per_alg = 3.0 * 16.0 / 36.0 if wino else 3.0          # MFMA flops issued per algorithmic flop, before padding
         roof = {'kernel': dom, 'bound': 'mfma', 'achieved': round(kr[dom]['tflops'], 2), 'peak': F16_MFMA_PEAK_TFLOPS,
                 'unit': 'TFLOP/s', 'frac': round(kr[dom]['frac'], 4),
                 # what the part sustains under dense f16 MFMA issue, measured on THIS box just now (far_mfma_probe_f16: K9's
@@ -783,21 +802,32 @@ def main():
                 # 2.4 GHz, the power-limited clock under this load is 1.5-1.8 GHz
                 'sustained_peak': sustained, 'sustained_probe': probe,
                 'frac_of_sustained': round(kr[dom]['tflops'] / sustained, 4),
-                'mfma_issue_frac_of_sustained': round(3 * kr[dom]['tflops'] / sustained, 4),
+                'mfma_issue_frac_of_sustained': round(per_alg * kr[dom]['tflops'] / sustained, 4),
                 'mfma_executed_frac_of_sustained': round(executed / sustained, 4),
-                'sustained_note': 'frac_of_sustained = algorithmic flops / sustained; mfma_issue = x3 (three f16 MFMAs per fp32-grade '
-                                  'product); mfma_executed also counts the MFMAs spent on channel padding (what the pipe actually ran)',
+                'sustained_note': 'frac_of_sustained = algorithmic (direct-convolution) flops / sustained; mfma_issue = x MFMA flops issued '
+                                  'per algorithmic flop (K9: 3 = three f16 MFMAs per fp32-grade product; K17: 3 x 16/36, Winograd F(2x2,3x3) '
+                                  'needs 16 products per 2x2 outputs instead of 36); mfma_executed also counts the MFMAs spent on channel / '
+                                  'tile padding (what the pipe actually ran)',
                 # HBM/fabric bytes per launch from the committed PMC passes (null when they do not match this geometry
                 # and precision); `committed_profile` names the file / commit they were measured at
                 'traffic': (tr or {}).get('bytes'), 'committed_profile': tr,
                 'launch_ms': round(kr[dom]['ms'], 3), 'launch_ms_rocprof': rocprof_launch_ms(dom),
                 'mfma_issue_frac': round(kr[dom]['mfma_issue_frac'], 4),
-                'note': 'algorithmic convolution flops per launch / event-timed launch duration against the dense f16 '
-                        'MFMA peak; the kernel executes 3 f16 MFMAs per fp32-grade product (split operands), so the '
-                        'matrix pipe is busy mfma_issue_frac of the time AT THE NOMINAL 2.4 GHz; the shader clock '
-                        'measured inside this kernel is 1.5-1.8 GHz (power limit under dense MFMA: s_memtime stamps in '
-                        'profiles/r01_k9_workgroup_timeline.txt, GRBM_GUI_ACTIVE in profiles/r02_pmc_util.txt: 1.59 GHz, '
-                        'SQ_VALU_MFMA_BUSY_CYCLES = 72 % of those cycles)'}
+                'same_launch_on_k9': {'launch_ms': round(kr['k_conv[K9 3x3 196->196 @240x320]']['ms'], 3),
+                                      'frac': round(kr['k_conv[K9 3x3 196->196 @240x320]']['frac'], 4)} if wino else None,
+                'note': ('algorithmic convolution flops per launch (2 N H W Cin Cout 9, the direct form) / event-timed launch duration '
+                         'against the dense f16 MFMA peak.  K17 executes 1.33 f16 MFMA flops per algorithmic flop (split operands x '
+                         'Winograd), so the matrix pipe is busy mfma_issue_frac of the time at the nominal 2.4 GHz; what bounds it is not '
+                         'the matrix pipe but the L2 -> LDS operand stream: a workgroup holds 16 accumulator planes for its 256 outputs x 64 '
+                         'channels (half the register file of a CU) and re-streams the 16 transformed weight planes for every such tile -- '
+                         '26 GB through L2 per launch of the 128-channel layer in 1.85 ms (DESIGN section 4, K17; '
+                         'profiles/r04_k17_winograd.txt)') if wino else
+                        ('algorithmic convolution flops per launch / event-timed launch duration against the dense f16 '
+                         'MFMA peak; the kernel executes 3 f16 MFMAs per fp32-grade product (split operands), so the '
+                         'matrix pipe is busy mfma_issue_frac of the time AT THE NOMINAL 2.4 GHz; the shader clock '
+                         'measured inside this kernel is 1.5-1.8 GHz (power limit under dense MFMA: s_memtime stamps in '
+                         'profiles/r01_k9_workgroup_timeline.txt, GRBM_GUI_ACTIVE in profiles/r02_pmc_util.txt: 1.59 GHz, '
+                         'SQ_VALU_MFMA_BUSY_CYCLES = 72 % of those cycles)')}
         res = {
             'metric': 'image-pairs/sec (match+solve+regress) at 640x480',
             'value': round(world * a.pairs * a.steps / dt, 3), 'unit': 'image-pairs/sec',

@@ -3,6 +3,7 @@
 PyTorch supplies device memory and the current HIP stream; all arithmetic of these ops happens in
 libfar_hip.so.  Every op raises on CPU tensors -- there is no eager fallback.
 """
+import os
 import ctypes
 import threading
 
@@ -967,6 +968,7 @@ class PackedConv:
         self._base = None if scale is None else scale.detach().float().contiguous()
         self.scale = torch.empty(Cout, dtype=torch.float32, device=w.device)      # base scale x 2^-(w_exp + 4), written by the pack kernel
         self.shift = None if shift is None else shift.detach().float().contiguous()
+        self._wino = None
         self._pack(w)
 
     def _pack(self, w):
@@ -1000,7 +1002,18 @@ class PackedConv:
         if tuple(w.shape) != self._wshape or w.dtype != torch.float32 or not w.is_contiguous() or w.device != self.packed.device:
             raise _lib.FarHipError('PackedConv.refresh: the weight changed shape, dtype, layout or device')
         self._pack(w)
+        self._wino = None                                         # the Winograd image of the old weights
         return self
+
+    def wino(self):
+        """The K17 image of the same layer (built at the first inference launch that can use it, from the weight this image was
+        packed from); None for layers K17 does not serve (1x1, stride 2, plain-fp16 operands, dgrad images, channel counts not
+        divisible by four)."""
+        if self._wino is None:
+            ok = (self.ksize == 3 and self.stride == 1 and self.split and self._view[3] == 0 and self.Cin % 4 == 0 and self.Cout % 4 == 0
+                  and self._w.dim() == 4)
+            self._wino = PackedWino(self._w, self._base, self.shift) if ok else False
+        return self._wino or None
 
 
 class PackedWino:
@@ -1031,6 +1044,8 @@ class PackedWino:
 
 
 WINO_MIN_ACT_EXP = 0        # K17 splits its operands unscaled (|a| <= 16376): used while the activation exponent is >= 0
+WINO_MIN_PIXELS = 1024      # per image; below, a 16x16-output workgroup tile is mostly padding
+USE_WINO = os.environ.get('FAR_NO_WINO', '0') in ('', '0')      # inference 3x3 stride-1 layers on K17 (conv_nhwc dispatches); False: K9 everywhere
 
 
 def conv3x3_wino(x, pw, residual=None, act='none', slope=0.01, out=None):
@@ -1322,6 +1337,13 @@ def conv_nhwc(x, pc, residual=None, act='none', slope=0.01, x2=None, out_planes=
     in the epilogue (the FPN merge)."""
     lib = _lib.load()
     N, H, W, Cin1 = x.shape
+    if (USE_WINO and pc.ksize == 3 and pc.stride == 1 and pc.split and x2 is None and out_planes == 1 and res_group == 1 and ln is None
+            and post_residual is None and up is None and act_scale_dev is None and not torch.is_grad_enabled()
+            and activation_exponent_value() >= WINO_MIN_ACT_EXP and H * W >= WINO_MIN_PIXELS):
+        pw = pc.wino()
+        if pw is not None:
+            # K17 (Winograd F(2x2, 3x3)): 1.03-1.26x K9 on the backbone's stride-1 3x3 layers at one third of its error (DESIGN 4)
+            return conv3x3_wino(x, pw, residual=residual, act=act, slope=slope, out=out)
     if up is not None and (tuple(up.shape) != (N, H // 2, W // 2, pc.Cout) or not up.is_contiguous()):
         raise _lib.FarHipError(f'conv_nhwc: `up` must be a contiguous ({N}, {H // 2}, {W // 2}, {pc.Cout}) tensor')
     Cin = Cin1 + (x2.shape[-1] if x2 is not None else 0)

@@ -601,3 +601,47 @@ def test_conv_winograd_activation_range_flag():
     assert ops.activation_overflowed('cuda')
     with pytest.raises(_lib.FarHipError):
         ops.conv3x3_wino(x[..., :30].contiguous(), ops.PackedWino(w[:, :28].contiguous()))      # channel count mismatch
+
+
+def test_conv_nhwc_dispatches_inference_3x3_layers_to_winograd_and_everything_else_to_k9():
+    """Round 4: under no_grad, conv_nhwc runs a stride-1 3x3 split-precision layer on K17 (bit-identical to conv3x3_wino, and to
+    float64 within the K9 bar); with gradients enabled, below activation exponent 0, with USE_WINO off, and for stride-2 / 1x1 /
+    plain-fp16 / fused-input layers it stays on K9 (bit-identical to the K9 launch)."""
+    ops = _ops()
+    g = torch.Generator(device='cuda').manual_seed(21)
+    x = torch.randn(2, 40, 48, 64, device='cuda', generator=g).relu_()
+    w = torch.randn(128, 64, 3, 3, device='cuda', generator=g) * 0.05
+    sc, sh = torch.rand(128, device='cuda', generator=g) + 0.5, torch.randn(128, device='cuda', generator=g)
+    res = torch.randn(2, 40, 48, 128, device='cuda', generator=g)
+    pc = ops.PackedConv(w, sc, sh)
+    ref = torch.relu(F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), padding=1).permute(0, 2, 3, 1) * sc.double() + sh.double() + res.double())
+    y9 = ops.conv_nhwc(x, pc, residual=res, act='relu')                      # gradients enabled: K9
+    with torch.no_grad():
+        assert ops.USE_WINO
+        y17 = ops.conv_nhwc(x, pc, residual=res, act='relu')
+        assert pc.wino() is not None
+        assert torch.equal(y17, ops.conv3x3_wino(x, pc.wino(), residual=res, act='relu'))
+        assert not torch.equal(y17, y9)                                      # two different kernels ...
+        e17, e9 = _rel(y17, ref)[0], _rel(y9, ref)[0]
+        print(f'[deviation] conv_nhwc 64->128 3x3: K17 {e17:.2e}, K9 {e9:.2e} of max|ref| vs float64')
+        assert e17 < 2e-6 and e9 < 2e-6                                      # ... both at the float64 bar
+        with ops.activation_exponent(-4):                                    # widened range: K9
+            ya = ops.conv_nhwc(x, pc, residual=res, act='relu')
+        with ops.activation_exponent(-4):
+            yb = ops.conv_nhwc(x, pc, residual=res, act='relu')
+        assert torch.equal(ya, yb) and _rel(ya, ref)[0] < 1e-4
+        ops.USE_WINO = False
+        try:
+            assert torch.equal(ops.conv_nhwc(x, pc, residual=res, act='relu'), y9)
+        finally:
+            ops.USE_WINO = True
+        # layers K17 does not serve keep their K9 image only
+        assert ops.PackedConv(w, sc, sh, stride=2).wino() is None
+        assert ops.PackedConv(w[:, :, :1, :1].contiguous(), sc, sh).wino() is None
+        assert ops.PackedConv(w, sc, sh, split=False).wino() is None
+        assert ops.PackedConv(w, dgrad=True).wino() is None
+        small = x[:, :16, :16].contiguous()                                   # below WINO_MIN_PIXELS: K9
+        ops.USE_WINO = False
+        ys = ops.conv_nhwc(small, pc, act='relu')
+        ops.USE_WINO = True
+        assert torch.equal(ops.conv_nhwc(small, pc, act='relu'), ys)

@@ -43,8 +43,10 @@ if which in ('pmc',):
     x = torch.randn(2 * n, 240, 320, 196, device=dev, generator=g).relu_()
     w = torch.randn(196, 196, 3, 3, device=dev, generator=g) * 0.03
     pc = ops.PackedConv(w, torch.ones(196, device=dev), torch.zeros(196, device=dev))
+    pw = ops.PackedWino(w, torch.ones(196, device=dev), torch.zeros(196, device=dev))
     for _ in range(it):
-        ops.conv_nhwc(x, pc, act='relu')
+        ops.conv_nhwc(x, pc, act='relu')          # K9 (gradients enabled here: conv_nhwc does not dispatch to K17)
+        ops.conv3x3_wino(x, pw, act='relu')       # K17, the kernel the inference step runs for this layer
     del x
     r = torch.randn(1, 1, n * L, 256, device=dev, generator=g)
     pl = ops.PackedConv(torch.randn(256, 256, device=dev, generator=g) * 0.05)

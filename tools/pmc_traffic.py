@@ -22,7 +22,7 @@ def short(name):
         for tail in (', false>', ', false, false>', ', false, true>'):
             if key + tail in name:
                 return key + '>'
-    for key in ['k1_conf_wide', 'k1_conf_fix', 'k1_bwd', 'k2_bwd', 'k1_rowstatsILb1', 'k_cvw_apply', 'k_stats_f32', 'k_match_f32', 'k_emm_pv_f32', 'k_la_kv_partial<32>', 'k_la_apply<32>', 'k_layernorm',
+    for key in ['k_wino<', 'k1_conf_wide', 'k1_conf_fix', 'k1_bwd', 'k2_bwd', 'k1_rowstatsILb1', 'k_cvw_apply', 'k_stats_f32', 'k_match_f32', 'k_emm_pv_f32', 'k_la_kv_partial<32>', 'k_la_apply<32>', 'k_layernorm',
                 'k_conv<3, 2, 2, 4, true, 1>', 'k_conv<1, 2, 2, 4, true, 1>', 'k_pv', 'k_rowstats', 'k1_rowstats', 'k1_matchILb0', 'k1_matchILb1']:
         if key in name:
             return key
@@ -42,6 +42,9 @@ if __name__ == '__main__':
         # the launch bench.py prices as the dominant kernel: 196 -> 196 3x3 at 240 x 320 on 64 images = 64 * 30 * 20 tiles of 256 threads
         if s == 'k_conv<3, 2, 2, 4, true, 1>' and g == 64 * 30 * 20 * 256:
             ent['label'] = 'k_conv[K9 3x3 196->196 @240x320]'
+        # K17 on the same layer: 64 images x 15 x 20 tiles of 16 x 16 outputs x 4 blocks of 64 output channels, 512 threads each
+        if s == 'k_wino<' and g == 64 * 15 * 20 * 4 * 512:
+            ent['label'] = 'k_wino[K17 3x3 196->196 @240x320]'
         out[f'{s}|grid={g}'] = ent
     import os
     import subprocess

@@ -21,5 +21,12 @@ if gcols:
         print('grid', row[:len(gcols[:3])], f'calls {row[-4]}  avg {row[-3]:.1f} us  min {row[-2]:.1f}  max {row[-1]:.1f}')
         if row[0] == 9830400:          # machine-readable: bench.py prints it next to its own event timing (roofline.launch_ms_rocprof)
             print(f'roofline_launch_rocprof: kernel=k_conv[K9 3x3 196->196 @240x320] calls={row[-4]} avg_us={row[-3]:.1f}')
+    print('\n## launches of k_wino<...> (K17, Winograd F(2x2,3x3): the stride-1 3x3 layers of the inference step) by grid; the 196->196 @240x320 '
+          'roofline launch of bench.py is grid x = 39321600 threads (64 images x 15 x 20 tiles x 4 channel blocks x 512 threads)')
+    for row in cur.execute(f"select {sel}, count(*), avg(end-start)/1e3, min(end-start)/1e3, max(end-start)/1e3 from kernels "
+                           f"where name like '%k_wino<%' group by {sel} order by 5 desc"):
+        print('grid', row[:len(gcols[:3])], f'calls {row[-4]}  avg {row[-3]:.1f} us  min {row[-2]:.1f}  max {row[-1]:.1f}')
+        if row[0] == 39321600:
+            print(f'roofline_launch_rocprof: kernel=k_wino[K17 3x3 196->196 @240x320] calls={row[-4]} avg_us={row[-3]:.1f}')
 else:
     print('no grid columns in', cols)
