@@ -41,13 +41,16 @@
 // No input scaling: |a| <= 16376 survives the split (|V| <= 4 |a|); beyond it the accumulators turn non-finite and the launch
 // raises the activation-overflow flag like K9 (the host then takes K9 with a lower activation exponent).
 //
-// STATUS (round 4): correct and deterministic, NOT dispatched by the model: 128 -> 128 @240x320 x 64 images runs in 3.1 ms
-// against K9's 3.45 ms (1.11x; the go / no-go bar was 1.3x), the 196-channel layers slower than K9's seven-tile mode (256 of
-// 196 output channels computed).  Where the time goes (tools/wino_timing*.py, tools/wino_pmc.sh): the matrix
-// pipe is busy 27 % -- 2.25x fewer MFMAs than K9 -- but a workgroup moves 84 KiB per k-step from L2 into LDS (weights 64 KiB:
-// 1.8x K9's traffic per output, because only 64 tiles x 64 channels of accumulators fit next to the 16 positions), every
-// request costs its wave ~55 cycles of issue stall (more when the in-order vector L1 is held up by the raw patches' HBM misses),
-// and with 160 KiB of LDS the rings reach only one to two intervals ahead of a ~2 us request latency under load.
+// STATUS (round 4): dispatched by ops.conv_nhwc for the inference step's stride-1 3x3 layers (ops.USE_WINO): same-box step
+// 99.8 -> 94.5 ms.  Against K9 at 64 images (profiles/r04_k17_winograd.txt): 128 -> 128 @240x320 3.04 vs 3.39 ms (1.11x),
+// 196 -> 196 @240x320 8.83 vs 9.45 (1.07x), 196 -> 128 1.16x, 256 -> 256 @120x160 1.19x, 256 -> 256 @60x80 1.26x -- short of the
+// 2.25x fewer matrix instructions, and of the 1.3x the round set as its bar.  Where the time goes (tools/wino_timing*.py,
+// tools/wino_pmc.sh): the matrix pipe is busy 27 %; the K loop WITHOUT its MFMAs still takes 1.85 of the
+// 2.5 ms, because a workgroup moves 84 KiB per k-step from L2 into LDS (64 KiB of them transformed weights).  That is the
+// structural cost of F(2x2, 3x3): 16 accumulator planes per 4 outputs, so only 256 outputs x 64 channels of accumulators fit in
+// half the register file of a CU (K9 holds 1024 x 64 ... per the same registers), and the 16 weight planes are re-streamed for
+// every such tile: 26 GB through L2 per launch, ~14 TB/s, 3.5e8 L2 requests in 3 ms.  Every request also costs its wave ~55
+// cycles of issue stall, and with 160 KiB of LDS the rings reach one to two intervals ahead of a ~2 us request latency under load.
 #include "common.h"
 #include <type_traits>
 

@@ -10,6 +10,8 @@ Training (gradients) on the GPU runs the same module graph with every 3x3 / 1x1 
 (ops.conv_train; BatchNorm with batch statistics, activations and the FPN interpolation stay torch ops); CPU tensors and
 the optional half-precision modes run the plain torch modules.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -31,14 +33,39 @@ def _fused_ok(m, x):
 class _PackCache(ops.PackCache):
     """K9 weight images per convolution with the following BatchNorm folded into the epilogue vectors."""
 
+    pad = False          # set by ResNetFPN_8_2._forward_fused: feature maps padded to multiples of 16 channels in HBM
+
     def get(self, key, conv, bn=None, split=True):
         ts = [conv.weight] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
 
         def build():
             scale, shift = _fold(bn) if bn is not None else (None, None)
             stride = conv.stride[0] if conv.kernel_size[0] == 3 else 1      # 1x1 stride 2: the caller subsamples
-            return ops.PackedConv(conv.weight, scale, shift, split=split, stride=stride)
-        return super().get((key, split), ts, build)
+            w = conv.weight.detach()
+            co, ci = w.shape[:2]
+            cop, cip = (_pad16(co), _pad16(ci)) if self.pad else (co, ci)
+            if (cop, cip) != (co, ci):
+                # the 196-channel maps live in HBM with 208 channels (832-byte pixels, 64-byte aligned k-step chunks): zero weights
+                # for the extra input channels, zero weights / unit scale / zero shift for the extra output channels, which
+                # therefore hold exact zeros through ReLU, LeakyReLU, residual adds and the FPN merge.  Same matrix work (the
+                # kernels pad a k-step to 16 channels anyway), bit-identical real channels; K17 196 -> 196 @240x320 8.78 ->
+                # 8.21 ms (profiles/r04_pmc_traffic.json, tools/stride_ab.py)
+                wp = w.new_zeros(cop, cip, *w.shape[2:])
+                wp[:co, :ci] = w
+                w = wp
+                if scale is not None:
+                    scale = torch.cat([scale.detach(), scale.new_ones(cop - co)])
+                    shift = torch.cat([shift.detach(), shift.new_zeros(cop - co)])
+            return ops.PackedConv(w, scale, shift, split=split, stride=stride)
+        return super().get((key, split, self.pad), ts, build)
+
+
+def _pad16(c):
+    """Channel count of a feature map in HBM on the inference path: the next multiple of 16 (196 -> 208)."""
+    return -(-c // 16) * 16
+
+
+PAD_CHANNELS = os.environ.get('FAR_NO_PAD', '0') in ('', '0')
 
 
 def _c1(i, o, s=1):
@@ -134,6 +161,9 @@ class ResNetFPN_8_2(nn.Module):
 
     def _forward_fused(self, x):
         pk = self.__dict__.setdefault('_packs', _PackCache())
+        # only the middle level may need padding: the stem's and the two returned maps' channel counts are what the callers see
+        b = self.config['block_dims']
+        pk.pad = PAD_CHANNELS and self.config['initial_dim'] % 16 == 0 and b[0] % 16 == 0 and b[2] % 16 == 0
         sp = self.trunk_split
         x0 = ops.stem7x7(x, self.conv1.weight, *_fold(self.bn1))
         x1 = self._block_fused('layer1.1', self.layer1[1], self._block_fused('layer1.0', self.layer1[0], x0, pk), pk)

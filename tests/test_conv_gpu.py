@@ -240,6 +240,24 @@ def test_fused_backbone_matches_reference_modules(H, W):
         c_r, f_r = bb64(x.double())
         assert c_f.shape == c_r.shape and f_f.shape == f_r.shape
         assert _rel(c_f, c_r)[0] < 2e-5 and _rel(f_f, f_r)[0] < 2e-5
+        # round 4: the 196-channel maps are stored with 208 channels (zero weights for the extra ones) -- bit-identical to the
+        # unpadded layout; and K17 vs K9 on the 3x3 layers -- both within the bar above
+        from far_amd.loftr import backbone as bbm
+        ops = _ops()
+        bbm.PAD_CHANNELS = False
+        try:
+            c_u, f_u = bb(x)
+        finally:
+            bbm.PAD_CHANNELS = True
+        assert torch.equal(c_u, c_f) and torch.equal(f_u, f_f)
+        ops.USE_WINO = False
+        try:
+            c_9, f_9 = bb(x)
+        finally:
+            ops.USE_WINO = True
+        assert _rel(c_9, c_r)[0] < 2e-5 and _rel(f_9, f_r)[0] < 2e-5
+        print(f'[deviation] backbone {H}x{W} vs float64 modules: K17 path {_rel(c_f, c_r)[0]:.2e} / {_rel(f_f, f_r)[0]:.2e}, '
+              f'K9 path {_rel(c_9, c_r)[0]:.2e} / {_rel(f_9, f_r)[0]:.2e} (coarse / fine, of the map maximum)')
         bb.trunk_split = bb.fpn_split = False                 # plain fp16 operands
         c_h, f_h = bb(x)
         assert _rel(c_h, c_r)[1] < 5e-3 and _rel(f_h, f_r)[1] < 5e-3

@@ -17,6 +17,7 @@ timeout 300 python bench.py --workload c3 --no-cpu-baseline --no-other-modes --n
 timeout 300 python bench.py --workload c3 --vendor-train --no-cpu-baseline --no-other-modes --no-other-workloads > gpurun_out/bench_c3_vendor.log 2> gpurun_out/bench_c3_vendor.err
 timeout 300 python bench.py --workload c5 --no-cpu-baseline --no-other-modes --no-other-workloads > gpurun_out/bench_c5.log 2> gpurun_out/bench_c5.err
 timeout 200 python tools/wgrad_time.py > gpurun_out/${TAG}_wgrad_time.txt 2>&1
+timeout 300 python tools/stride_ab.py > gpurun_out/${TAG}_stride_ab.json 2> gpurun_out/stride_ab.err
 (cd /tmp; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_c3 -o c3 -- python3 $R/bench.py --workload c3 --steps 10 --warmup 3 --no-cpu-baseline --no-other-modes --no-other-workloads > $R/gpurun_out/bench_c3_prof.log 2>&1)
 python tools/profile_report.py /tmp/prof_c3/c3_results.db > gpurun_out/${TAG}_c3_trace.txt 2>&1
 python tools/aten_in_step.py /tmp/prof_c3/c3_results.db > gpurun_out/${TAG}_c3_vendor_kernels.txt 2>&1

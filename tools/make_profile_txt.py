@@ -34,7 +34,11 @@ out = f"""# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --war
 """
 open(ROOT + f'/profiles/{tag}_bench_fp32_kernel_trace.txt', 'w').write(out)
 if os.path.exists(G + f'{tag}_pmc_traffic.json'):
-    shutil.copy(G + f'{tag}_pmc_traffic.json', ROOT + f'/profiles/{tag}_pmc_traffic.json')
+    import json
+    doc = json.load(open(G + f'{tag}_pmc_traffic.json'))
+    if os.path.exists(G + f'{tag}_stride_ab.json'):          # what a padded pixel stride is worth, measured
+        doc['padded_stride_experiment'] = json.loads(last_json(G + f'{tag}_stride_ab.json'))
+    json.dump(doc, open(ROOT + f'/profiles/{tag}_pmc_traffic.json', 'w'), indent=1)
 print('wrote', f'profiles/{tag}_bench_fp32_kernel_trace.txt')
 
 # ---- the training step (BASELINE configs[2]): kernel trace of bench.py --workload c3, both legs' bench lines, K16 vs the vendor
