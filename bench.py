@@ -185,7 +185,15 @@ def kernel_rooflines(n_pairs):
         out[label] = dict(ms=t9, tflops=fl9 / t9 / 1e9, frac=fl9 / t9 / 1e9 / F16_MFMA_PEAK_TFLOPS,
                           mfma_issue_frac=3 * fl9 / t9 / 1e9 / F16_MFMA_PEAK_TFLOPS, mfma_executed_tflops=3 * pad * fl9 / t9 / 1e9)
         if ks == 3:
-            pw = ops.PackedWino(wt, torch.ones(co, device=dev), torch.zeros(co, device=dev))
+            # in the layout the step uses: channel counts padded to multiples of 16 in HBM (196 -> 208, zero weights for the rest)
+            cip, cop = -(-ci // 16) * 16, -(-co // 16) * 16
+            wp = torch.zeros(cop, cip, 3, 3, device=dev)
+            wp[:co, :ci] = wt
+            pw = ops.PackedWino(wp, torch.ones(cop, device=dev), torch.zeros(cop, device=dev))
+            if cip != ci:
+                xp = torch.zeros(nimg, H, W, cip, device=dev)
+                xp[..., :ci] = x
+                x = xp
             t17 = event_time_ms(lambda: ops.conv3x3_wino(x, pw, act='relu'), iters=3, warm=1)
             padw = (-(-co // 64) * 64 / co) * (-(-ci // 16) * 16 / ci) * (-(-H // 16) * 16 / H) * (-(-W // 16) * 16 / W)
             ex = 3.0 * 16.0 / 36.0 * padw

@@ -43,11 +43,17 @@ if which in ('pmc',):
     x = torch.randn(2 * n, 240, 320, 196, device=dev, generator=g).relu_()
     w = torch.randn(196, 196, 3, 3, device=dev, generator=g) * 0.03
     pc = ops.PackedConv(w, torch.ones(196, device=dev), torch.zeros(196, device=dev))
-    pw = ops.PackedWino(w, torch.ones(196, device=dev), torch.zeros(196, device=dev))
+    # K17, the kernel the inference step runs for this layer, in the layout the step uses: the 196-channel maps are stored with
+    # 208 channels (zero weights for the extra ones; far_amd/loftr/backbone.py)
+    wp = torch.zeros(208, 208, 3, 3, device=dev)
+    wp[:196, :196] = w
+    pw = ops.PackedWino(wp, torch.ones(208, device=dev), torch.zeros(208, device=dev))
+    xp = torch.zeros(2 * n, 240, 320, 208, device=dev)
+    xp[..., :196] = x
     for _ in range(it):
         ops.conv_nhwc(x, pc, act='relu')          # K9 (gradients enabled here: conv_nhwc does not dispatch to K17)
-        ops.conv3x3_wino(x, pw, act='relu')       # K17, the kernel the inference step runs for this layer
-    del x
+        ops.conv3x3_wino(xp, pw, act='relu')
+    del x, xp
     r = torch.randn(1, 1, n * L, 256, device=dev, generator=g)
     pl = ops.PackedConv(torch.randn(256, 256, device=dev, generator=g) * 0.05)
     for _ in range(it):

@@ -42,7 +42,8 @@ if __name__ == '__main__':
         # the launch bench.py prices as the dominant kernel: 196 -> 196 3x3 at 240 x 320 on 64 images = 64 * 30 * 20 tiles of 256 threads
         if s == 'k_conv<3, 2, 2, 4, true, 1>' and g == 64 * 30 * 20 * 256:
             ent['label'] = 'k_conv[K9 3x3 196->196 @240x320]'
-        # K17 on the same layer: 64 images x 15 x 20 tiles of 16 x 16 outputs x 4 blocks of 64 output channels, 512 threads each
+        # K17 on the same layer (tensors stored with 208 channels, as in the step): 64 images x 15 x 20 tiles of 16 x 16 outputs x 4 blocks
+        # of 64 output channels, 512 threads each
         if s == 'k_wino<' and g == 64 * 15 * 20 * 4 * 512:
             ent['label'] = 'k_wino[K17 3x3 196->196 @240x320]'
         out[f'{s}|grid={g}'] = ent
