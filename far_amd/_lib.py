@@ -81,9 +81,6 @@ SIGNATURES = {
     'far_wino_packed_bytes': (c_sz, [c_i, c_i]),
     'far_wino_pack_view_scaled_f32': (c_i, [c_p, c_l, c_l, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
     'far_conv3x3_wino_f32': (c_i, [c_p, c_p]),                # (const far_conv_desc*, stream): K17
-    'far_wino1d_packed_bytes': (c_sz, [c_i, c_i]),
-    'far_wino1d_pack_view_scaled_f32': (c_i, [c_p, c_l, c_l, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
-    'far_conv3x3_wino1d_f32': (c_i, [c_p, c_p]),              # (const far_conv_desc*, stream): K18
     'far_emm_pv_f16s_workspace_bytes': (c_sz, [c_i, c_i]),
     'far_emm_pv_f16s': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_i, c_l, c_l, c_i, c_p, c_p, c_p, c_p]),
     'far_emm_pv_f16s_copy_stats': (c_i, [c_p, c_i, c_i, c_p, c_p, c_p]),

@@ -1048,7 +1048,7 @@ WINO_MIN_PIXELS = 1024      # per image; below, a 16x16-output workgroup tile is
 USE_WINO = os.environ.get('FAR_NO_WINO', '0') in ('', '0')      # inference 3x3 stride-1 layers on K17 (conv_nhwc dispatches); False: K9 everywhere
 
 
-def conv3x3_wino(x, pw, residual=None, act='none', slope=0.01, out=None, _entry='far_conv3x3_wino_f32'):
+def conv3x3_wino(x, pw, residual=None, act='none', slope=0.01, out=None):
     """K17.  x (N, H, W, Cin) fp32 contiguous -> act(conv3x3(x) * scale + shift (+ residual)) as (N, H, W, Cout): conv_nhwc's
     result for a stride-1 3x3 layer, on the Winograd kernel."""
     lib = _lib.load()
@@ -1069,37 +1069,8 @@ def conv3x3_wino(x, pw, residual=None, act='none', slope=0.01, out=None, _entry=
                       ln_gamma=None, ln_beta=None, post_res=None, up=None, y=ptr(y), N=N, H=H, W=W, Cin=Cin, Cin1=Cin, Cout=pw.Cout,
                       ksize=3, stride=1, act=_ACT[act], split=1, out_planes=1, res_group=1, slope=float(slope), ln_eps=0.0,
                       act_exp=max(activation_exponent_value(), 0), overflow=overflow_flag(x.device).data_ptr(), act_scale_dev=None)
-    _lib.check(getattr(lib, _entry)(ctypes.byref(d), _stream()), _entry)
+    _lib.check(lib.far_conv3x3_wino_f32(ctypes.byref(d), _stream()), 'far_conv3x3_wino_f32')
     return y if out is None else _written(y)
-
-class PackedWino1d(PackedWino):
-    """Weights of one stride-1 3x3 convolution in K18's F(2, 3) image (U = G g[ky], split fp16 planes); as PackedWino."""
-
-    def __init__(self, weight, scale=None, shift=None):
-        lib = _lib.load()
-        w = weight.detach()
-        if w.dim() != 4 or tuple(w.shape[2:]) != (3, 3):
-            raise _lib.FarHipError(f'K18 is a 3x3 kernel, got a weight of shape {tuple(w.shape)}')
-        w = w.contiguous().float()
-        self.Cout, self.Cin = int(w.shape[0]), int(w.shape[1])
-        if self.Cin % 4:
-            raise _lib.FarHipError('K18 needs Cin % 4 == 0')
-        self.packed = torch.empty(lib.far_wino1d_packed_bytes(self.Cin, self.Cout), dtype=torch.uint8, device=w.device)
-        self.pack_scale = torch.empty(2, dtype=torch.float32, device=w.device)       # { 2^w_exp, 2^-(w_exp + 4) }
-        self._base = None if scale is None else scale.detach().float().contiguous()
-        self.scale = torch.empty(self.Cout, dtype=torch.float32, device=w.device)
-        self.shift = None if shift is None else shift.detach().float().contiguous()
-        _lib.check(lib.far_weight_scale_f32(_p(w, torch.float32), w.numel(), _p(self.pack_scale), _stream()), 'far_weight_scale_f32')
-        rc = lib.far_wino1d_pack_view_scaled_f32(_p(w), 9 * self.Cin, 9, 1, self.Cin, self.Cout, _p(self.pack_scale), _p(self.packed),
-                                                 _p(self._base) if self._base is not None else None, _p(self.scale), _stream())
-        _lib.check(rc, 'far_wino1d_pack_view_scaled_f32')
-        self._w = w
-
-
-def conv3x3_wino1d(x, pw, residual=None, act='none', slope=0.01, out=None):
-    """K18.  As conv3x3_wino, on the F(2, 3) kernel (pw: a PackedWino1d)."""
-    return conv3x3_wino(x, pw, residual=residual, act=act, slope=slope, out=out, _entry='far_conv3x3_wino1d_f32')
-
 
 class PackedMlp:
     """Weight image of far_mlp_fused_f16s (K13): mlp[0] (2d x 2d) and mlp[2] (d x 2d) of a LoFTR encoder layer at d = 128 as

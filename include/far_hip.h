@@ -29,7 +29,7 @@ extern "C" {
 typedef struct ihipStream_t* far_stream_t; /* == hipStream_t */
 
 /* ABI version of this header; bumped when a signature changes (2: activation exponent / overflow flag of K9, K13, K14; 3: the
- * far_wino_* / far_conv3x3_wino_f32 entry points, 16 tuning keys; 4: far_wino1d_* / far_conv3x3_wino1d_f32, far_upsample2x_bwd_f32, far_fine_scatter_det_f32).  far_amd/_lib.py refuses a library whose version differs. */
+ * far_wino_* / far_conv3x3_wino_f32 entry points, 16 tuning keys; 4: far_upsample2x_bwd_f32, far_fine_scatter_det_f32).  far_amd/_lib.py refuses a library whose version differs. */
 int far_abi_version(void);
 /* hipError_t of the most recent failed launch on the calling thread (0 = none): detail behind a -5 return. */
 int far_last_hip_error(void);
@@ -446,16 +446,6 @@ size_t far_wino_packed_bytes(int Cin, int Cout);
 int far_wino_pack_view_scaled_f32(const float* w, long s_co, long s_ci, long s_tap, int Cin, int Cout, const float* scale_in,
                                   void* packed, const float* base_scale, float* scale_vec_out, far_stream_t stream);
 int far_conv3x3_wino_f32(const far_conv_desc* desc, far_stream_t stream);
-
-/* K18: the same layers as ONE-DIMENSIONAL Winograd F(2, 3) along x, direct along y (conv_wino1d_f16s.hip): 12 products per 2
- * outputs (K9: 18, K17: 8) but a quarter of K17's accumulator planes per output, so a workgroup covers 16 x 32 outputs x 64
- * channels and streams 0.375x the weight bytes per output.  Same three entry points and descriptor rules as K17 (act_exp >= 0,
- * no x2 / ln_* / post_res / up / act_scale_dev, out_planes = res_group = 1); the image is [64-channel block][unit 3 k + ky][16 KiB];
- * |input| <= 32752. */
-size_t far_wino1d_packed_bytes(int Cin, int Cout);
-int far_wino1d_pack_view_scaled_f32(const float* w, long s_co, long s_ci, long s_tap, int Cin, int Cout, const float* scale_in,
-                                    void* packed, const float* base_scale, float* scale_vec_out, far_stream_t stream);
-int far_conv3x3_wino1d_f32(const far_conv_desc* desc, far_stream_t stream);
 /* Activation scale for an input of unknown magnitude (the output gradient in a dgrad launch): out2 = { 2^e, 2^(4 - e) } with
  * max|x| 2^e in [2^9, 2^10), computed on the device -- pass out2 as far_conv_desc.act_scale_dev. */
 int far_grad_scale_f32(const float* x, long n, float* out2, far_stream_t stream);

@@ -1,3 +1,7 @@
+// EXPERIMENT, not part of libfar_hip.so (round 4).  Measured 0.92x of K17 on every bench shape (128->128 @240x320 x 64 images: 3.25-3.4 ms
+// against 3.0-3.1; errors 2-6e-7 of max|ref| vs float64, deterministic): the wiring (C ABI, far_amd/ops.py:PackedWino1d, tools/wino1d_ab.py,
+// tools/w1d_timing.py) is in git revision f7158f3; DESIGN.md section 4 (K17, 'what was tried') has the numbers and the reasons.
+//
 // K18: the stride-1 3x3 convolutions as ONE-DIMENSIONAL Winograd F(2, 3) along x, direct along y, on the f16 matrix cores with
 // split-precision operands -- 12 products per 2 outputs where the direct form (K9) has 18 and the 2-D form (K17) has 8, but only
 // 4 accumulator planes per 2 outputs (K17: 16 per 4), so a workgroup holds 512 outputs x 64 channels in the registers K17 needs for
