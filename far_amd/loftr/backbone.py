@@ -76,6 +76,12 @@ def _c3(i, o, s=1):
     return nn.Conv2d(i, o, 3, stride=s, padding=1, bias=False)
 
 
+def _bn_hip(bn, x):
+    """BatchNorm with batch statistics on K19: training-mode module, fp32 GPU tensor, gradients enabled."""
+    return (ResNetFPN_8_2.hip_training and ops.USE_HIP_BATCHNORM_TRAIN and bn.training and x.is_cuda and x.dtype == torch.float32
+            and torch.is_grad_enabled())
+
+
 def _conv(conv, x, owner):
     """conv(x) for the reference-style (training / CPU) forward: on the GPU with gradients enabled the bias-free 3x3 / 1x1
     convolutions run K9 forward and K9 dgrad (ops.conv_train); otherwise the nn.Conv2d itself."""
@@ -97,6 +103,11 @@ class BasicBlock(nn.Module):
         self.downsample = None if stride == 1 else nn.Sequential(_c1(in_planes, planes, stride), nn.BatchNorm2d(planes))
 
     def forward(self, x):          # reference-style modules: training, CPU, autocast (inference runs _forward_fused)
+        if _bn_hip(self.bn1, x):   # training on the GPU: BatchNorm (batch statistics) + activation + shortcut add on K19 / K7
+            h = ops.bn_act_train(_conv(self.conv1, x, self), self.bn1, 'relu')
+            if self.downsample is not None:
+                x = ops.bn_act_train(_conv(self.downsample[0], x, self), self.downsample[1], 'none')
+            return ops.bn_act_train(_conv(self.conv2, h, self), self.bn2, 'relu', residual=x)
         y = self.bn2(_conv(self.conv2, self.relu(self.bn1(_conv(self.conv1, x, self))), self))
         if self.downsample is not None:
             x = self.downsample[1](_conv(self.downsample[0], x, self))
@@ -130,6 +141,8 @@ class ResNetFPN_8_2(nn.Module):
     hip_training = True          # training on the GPU: convolutions on K9 (forward + dgrad); False: vendor convolutions + autograd
 
     def _outconv2(self, seq, x):
+        if _bn_hip(seq[1], x):
+            return _conv(seq[3], ops.bn_act_train(_conv(seq[0], x, self), seq[1], 'leaky', seq[2].negative_slope), self)
         return _conv(seq[3], seq[2](seq[1](_conv(seq[0], x, self))), self)
 
     def _merge(self, lateral, coarse):
@@ -194,7 +207,8 @@ class ResNetFPN_8_2(nn.Module):
             return self._forward_fused(x)
         if (ResNetFPN_8_2.hip_training and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and x.shape[1] == 1
                 and self.conv1.weight.requires_grad and self.conv1.out_channels in (64, 128)):
-            x0 = self.relu(self.bn1(ops.stem_train(x, self.conv1.weight)))           # K10 + its weight gradient
+            x0 = ops.stem_train(x, self.conv1.weight)                                # K10 + its weight gradient
+            x0 = ops.bn_act_train(x0, self.bn1, 'relu') if _bn_hip(self.bn1, x0) else self.relu(self.bn1(x0))
         else:
             x0 = self.relu(self.bn1(self.conv1(x)))
         x1 = self.layer1(x0)

@@ -834,6 +834,77 @@ def upsample2x_add(lo, hi):
     return out
 
 
+def _raw(t):
+    """Device pointer of a tensor whose memory layout the caller has established (channels_last 4-D tensors are not `contiguous`)."""
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+class _BatchNormActFn(torch.autograd.Function):
+    """act(bn(x) (+ residual)) with BATCH statistics and gradients (resnet_fpn.py:24-41, 60-62, 75-91 under autograd, nn.BatchNorm2d
+    in training mode): K19 statistics + K7 normalise / activate / add forward, far_bn_train_bwd_f32 backward; deterministic.
+    Tensors (N, C, H, W) logical, channels_last memory.  The running statistics of `bn` are updated as the module does."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, bn, act, slope, residual):
+        lib = _lib.load()
+        cl = torch.channels_last
+        xc = x.detach().contiguous(memory_format=cl)
+        N, C, H, W = xc.shape
+        M = N * H * W
+        nb = int(lib.far_bn_train_ws_bytes(M, C))
+        buf = torch.empty(4 * C + nb // 4, dtype=torch.float32, device=xc.device)     # { scale, shift, mean, rstd } + partial sums
+        y = torch.empty_like(xc)
+        track = bn.track_running_stats and bn.running_mean is not None
+        r = None if residual is None else residual.detach().contiguous(memory_format=cl)
+        vp = buf.data_ptr()
+        rc = lib.far_bn_act_train_fwd_f32(xc.data_ptr(), 0 if r is None else r.data_ptr(), M, C,
+                                          0 if weight is None else weight.data_ptr(), 0 if bias is None else bias.data_ptr(), float(bn.eps),
+                                          float(bn.momentum), bn.running_mean.data_ptr() if track else 0,
+                                          bn.running_var.data_ptr() if track else 0, _ACT[act], float(slope), y.data_ptr(), vp,
+                                          vp + 16 * C, nb, _stream())
+        _lib.check(rc, 'far_bn_act_train_fwd_f32')
+        if track:
+            bn.num_batches_tracked += 1
+        ctx.save_for_backward(xc, y, buf, weight)
+        ctx.act, ctx.slope, ctx.has_res, ctx.nb = _ACT[act], float(slope), residual is not None, nb
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        xc, y, buf, weight = ctx.saved_tensors
+        N, C, H, W = xc.shape
+        M = N * H * W
+        gc = g.contiguous(memory_format=torch.channels_last)
+        dx = torch.empty_like(xc)
+        dres = torch.empty_like(xc) if ctx.has_res else None
+        dgb = torch.empty(2, C, dtype=torch.float32, device=xc.device)
+        vp = buf.data_ptr()
+        rc = lib.far_bn_train_bwd_f32(xc.data_ptr(), gc.data_ptr(), y.data_ptr(), vp + 8 * C, vp + 12 * C,
+                                      0 if weight is None else weight.data_ptr(), M, C, ctx.act, ctx.slope, dx.data_ptr(), dgb.data_ptr(),
+                                      dgb.data_ptr() + 4 * C, 0 if dres is None else dres.data_ptr(), vp + 16 * C, ctx.nb, _stream())
+        _lib.check(rc, 'far_bn_train_bwd_f32')
+        return (dx, dgb[0] if weight is not None else None, dgb[1] if weight is not None else None, None, None, None, dres)
+
+
+USE_HIP_BATCHNORM_TRAIN = os.environ.get('FAR_NO_BN', '0') in ('', '0')      # False: nn.BatchNorm2d + torch activations under autograd (comparison leg, --vendor-train)
+
+
+def bn_act_train(x, bn, act='none', slope=0.01, residual=None):
+    """K19.  act(bn(x) (+ residual)) for an nn.BatchNorm2d in TRAINING mode (batch statistics) on a GPU tensor, with gradients;
+    what the kernels do not cover (eval-mode modules, momentum None, C % 4 != 0, C > 1024) runs the module and torch activations."""
+    if not x.is_cuda:
+        raise _lib.FarHipError('far_amd ops need tensors on the GPU (no CPU fallback exists)')
+    C = x.shape[1]
+    if (not USE_HIP_BATCHNORM_TRAIN or not bn.training or bn.momentum is None or (C & 3) or C > 1024 or x.dtype != torch.float32
+            or x.numel() == 0 or (bn.weight is None) != (bn.bias is None)):
+        y = bn(x)
+        if residual is not None:
+            y = y + residual
+        return torch.relu(y) if act == 'relu' else (torch.nn.functional.leaky_relu(y, slope) if act == 'leaky' else y)
+    return _BatchNormActFn.apply(x, bn.weight, bn.bias, bn, act, slope, residual)
+
+
 class _Upsample2xAddFn(torch.autograd.Function):
     """hi + F.interpolate(lo, scale_factor=2, mode='bilinear', align_corners=True) with gradients (resnet_fpn.py:108-109,
     :113-114 under autograd): forward K8, backward far_upsample2x_bwd_f32 -- a gather in a fixed order, where the node torch

@@ -29,7 +29,7 @@ extern "C" {
 typedef struct ihipStream_t* far_stream_t; /* == hipStream_t */
 
 /* ABI version of this header; bumped when a signature changes (2: activation exponent / overflow flag of K9, K13, K14; 3: the
- * far_wino_* / far_conv3x3_wino_f32 entry points, 16 tuning keys; 4: far_upsample2x_bwd_f32, far_fine_scatter_det_f32).  far_amd/_lib.py refuses a library whose version differs. */
+ * far_wino_* / far_conv3x3_wino_f32 entry points, 16 tuning keys; 4: far_upsample2x_bwd_f32, far_fine_scatter_det_f32, far_bn_train_*).  far_amd/_lib.py refuses a library whose version differs. */
 int far_abi_version(void);
 /* hipError_t of the most recent failed launch on the calling thread (0 = none): detail behind a -5 return. */
 int far_last_hip_error(void);
@@ -320,6 +320,27 @@ int far_affine_act_f32(const float* x, const float* scale, const float* shift, c
  * layout selected by nhwc (0: NCHW, w even; 1: channels_last, C % 4 == 0). */
 int far_upsample2x_add_f32(const float* lo, const float* hi, int N, int h, int w, int C, int nhwc, float* out,
                            far_stream_t stream);
+
+/* K19: BatchNorm2d with BATCH statistics (training mode) on channels_last fp32 tensors [M = N H W][C], C % 4 == 0, C <= 1024
+ * (batchnorm_train_f32.hip) -- resnet_fpn.py:24-41, 60-62, 75-91 under autograd; deterministic (fixed-order two-stage sums).
+ *   far_bn_train_stats_f32: scale[c] = gamma[c] rstd[c], shift[c] = beta[c] - mean[c] scale[c] (the normalisation + activation +
+ *     residual is then far_affine_act_f32), mean_out / rstd_out for the backward; running_mean / running_var updated in place as
+ *     nn.BatchNorm2d(momentum) does (biased variance for the normalisation, unbiased for the running estimate); NULL gamma / beta = 1 / 0.
+ *   far_bn_train_bwd_f32: backward of y = act(bn(x) (+ residual)): g = dy act'(y) (act 0 none, 1 ReLU, 2 LeakyReLU(slope); y read
+ *     only when act != 0), dbeta = sum g, dgamma = sum g xhat, dx = gamma rstd (g - dbeta / M - xhat dgamma / M), dres = g when
+ *     dres != NULL.  ws: far_bn_train_ws_bytes(M, C) bytes of device scratch. */
+long far_bn_train_ws_bytes(long M, int C);
+/* far_bn_act_train_fwd_f32: the whole training forward in one call (statistics, then y = act(x scale + shift (+ res))); vec = 4 C
+ * floats { scale, shift, mean, rstd } kept for the backward. */
+int far_bn_act_train_fwd_f32(const float* x, const float* res, long M, int C, const float* gamma, const float* beta, float eps,
+                             float momentum, float* running_mean, float* running_var, int act, float slope, float* y, float* vec,
+                             void* ws, long ws_bytes, far_stream_t stream);
+int far_bn_train_stats_f32(const float* x, long M, int C, const float* gamma, const float* beta, float eps, float momentum,
+                           float* running_mean, float* running_var, float* scale, float* shift, float* mean_out, float* rstd_out,
+                           void* ws, long ws_bytes, far_stream_t stream);
+int far_bn_train_bwd_f32(const float* x, const float* dy, const float* y, const float* mean, const float* rstd, const float* gamma,
+                         long M, int C, int act, float slope, float* dx, float* dgamma, float* dbeta, float* dres, void* ws,
+                         long ws_bytes, far_stream_t stream);
 
 /* Gradient of that upsampling with respect to lo: dlo [N][h][w][C] from dout [N][2h][2w][C] (channels_last memory, C % 4 == 0),
  * gathered in a fixed order -- bit-identical from run to run.  Replaces the autograd node torch records for

@@ -641,3 +641,52 @@ def test_upsample_add_train_matches_float64_autograd_and_is_deterministic(N, C, 
     assert torch.equal(outs[0][2], up)
     for o in outs[1:]:
         assert all(torch.equal(a, b) for a, b in zip(o, outs[0]))
+
+
+@pytest.mark.parametrize('N,C,H,W,act,res', [(2, 128, 24, 32, 'relu', False), (2, 196, 15, 20, 'relu', True), (1, 256, 8, 10, 'leaky', False),
+                                             (3, 196, 30, 40, 'none', False), (2, 64, 60, 80, 'relu', True), (1, 4, 1, 3, 'relu', False)])
+def test_batchnorm_train_matches_float64_autograd_and_the_module(N, C, H, W, act, res):
+    """K19: act(bn(x) (+ residual)) with batch statistics (resnet_fpn.py:24-41 under autograd) against float64 autograd of the same
+    formula: output, dx, dgamma, dbeta, the residual's gradient; the running statistics against nn.BatchNorm2d's own update;
+    bit-identical over repeated runs.  Inputs with a large mean (no cancellation in the variance)."""
+    import torch.nn.functional as F
+    from far_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(C + H)
+    x = (torch.randn(N, C, H, W, device='cuda', generator=g) * 1.7 + 30.0).contiguous(memory_format=torch.channels_last).requires_grad_()
+    r = torch.randn(N, C, H, W, device='cuda', generator=g).contiguous(memory_format=torch.channels_last).requires_grad_() if res else None
+    up = torch.randn(N, C, H, W, device='cuda', generator=g) * 1e-3
+    bn = torch.nn.BatchNorm2d(C).cuda().train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5, generator=g); bn.bias.normal_(generator=g)
+    ref_bn = torch.nn.BatchNorm2d(C).cuda().train().double()
+    ref_bn.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in bn.state_dict().items()})
+    xd = x.detach().double().requires_grad_()
+    rd = r.detach().double().requires_grad_() if res else None
+    z = ref_bn(xd) + (rd if res else 0)
+    yd = {'relu': torch.relu, 'leaky': lambda t: F.leaky_relu(t, 0.01), 'none': lambda t: t}[act](z)
+    yd.backward(up.double())
+    outs = []
+    for rep in range(3):
+        bn2 = torch.nn.BatchNorm2d(C).cuda().train()
+        bn2.load_state_dict(bn.state_dict())
+        x.grad = None
+        if res:
+            r.grad = None
+        y = ops.bn_act_train(x, bn2, act, 0.01, residual=r)
+        y.backward(up)
+        outs.append((y.detach().clone(), x.grad.clone(), bn2.weight.grad.clone(), bn2.bias.grad.clone(), bn2.running_mean.clone(),
+                     bn2.running_var.clone()) + ((r.grad.clone(),) if res else ()))
+        assert int(bn2.num_batches_tracked) == 1
+    y, dx, dg, db, rm, rv = outs[0][:6]
+    scale = float(yd.abs().max())
+    assert float((y.double() - yd.detach()).abs().max()) < 3e-6 * max(scale, 1.0)
+    for got, want, name in ((dx, xd.grad, 'dx'), (dg, ref_bn.weight.grad, 'dgamma'), (db, ref_bn.bias.grad, 'dbeta')):
+        err = float((got.double() - want).abs().max() / want.abs().max().clamp_min(1e-30))
+        print(f'[deviation] bn_act_train {N}x{C}x{H}x{W} {act}: {name} {err:.2e}')
+        assert err < 2e-5, (name, err)
+    if res:
+        assert float((outs[0][6].double() - rd.grad).abs().max()) < 1e-9
+    torch.testing.assert_close(rm.double(), ref_bn.running_mean, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(rv.double(), ref_bn.running_var, rtol=1e-5, atol=1e-6)
+    for o in outs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(o, outs[0]))
