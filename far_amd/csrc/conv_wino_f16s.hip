@@ -144,7 +144,7 @@ __device__ unsigned long long g_wino_stamps2[4096 * 8 * 16];
 #endif
 #ifndef FAR_WINO_EXP
 #define FAR_WINO_EXP 0      // experiment builds only (tools/wino_exp.sh): 1 no transform, 2 no MFMAs, 4 no weight requests, 8 no raw
-#endif                      // requests, 16 no epilogue, 32 every wait drains the queue (vmcnt(0))
+#endif                      // requests, 16 no epilogue, 32 every wait drains the queue (vmcnt(0)), 64 raw requests to a cache-resident region
 
 template <bool Q, bool MIX>
 __device__ __forceinline__ void wino_body(const WinoArgs& p) {
@@ -235,6 +235,10 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p) {
         const int kk = rk < nk ? rk : nk - 1;       // past the end: the last patch again, into a slot nobody reads
         const bool tail = kk == nk - 1 && ((rtailm >> j) & 1u);
         const char* s = tail ? reinterpret_cast<const char*>(p.zeros) : rsrc[j] + (long)kk * rinc[j];
+        if (FAR_WINO_EXP & 64) {         // experiment: every workgroup reads the same 128 KiB (cache hits), same request count and shape
+            const char* f = reinterpret_cast<const char*>(p.x) + ((rpiece[j] * 1024 + (kk & 3) * 32768 + (threadIdx.x & 63) * 16) & 131071);
+            glds16(f, rs_base + slot * RAWB + rpiece[j] * 1024);
+        } else
         if (!(FAR_WINO_EXP & 8)) glds16(s, rs_base + slot * RAWB + rpiece[j] * 1024);
     };
 
