@@ -175,6 +175,9 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
+    for kv in filter(None, os.environ.get('FAR_TUNING', '').split(',')):      # A/B aid: FAR_TUNING="10=1,8=1" -> far_set_tuning(key, value)
+        k, v = kv.split('=')
+        lib.far_set_tuning(int(k), int(v))
     _lib = lib
     return lib
 

@@ -58,10 +58,13 @@ __device__ __forceinline__ float max32_to_upper_row(float v) {
 
 // x [Z][N][256] fp32 -> hi / lo [Z][Np][256] fp16 (rows >= N zero), slot ^= row & 15
 // overflow (device int or null): |= 1 when a feature is beyond the range of the 2^4-scaled split (|x| > 4094: hi = inf)
+// nmax (device uint or null): atomic maximum of the bit pattern of max_rows sum_c (2^4 x)^2 -- the squared norm bound of the match
+// pass's tile prescreen (non-negative floats order like unsigned integers); the caller zeroes it.
 __global__ void k1_prep(const float* __restrict__ x, int Z, int N, int Np, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
-                        int* __restrict__ overflow) {
+                        int* __restrict__ overflow, unsigned* __restrict__ nmax) {
     const long total = (long)Z * Np * 32;
     bool bad = false;
+    float n2max = 0.f;
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
         const int slot = (int)(t & 31);
         const long row = t >> 5;
@@ -86,6 +89,20 @@ __global__ void k1_prep(const float* __restrict__ x, int Z, int N, int Np, _Floa
         const int s2 = slot ^ (i & 15);
         *reinterpret_cast<f16x8*>(hi + (size_t)row * C + s2 * 8) = vh;
         *reinterpret_cast<f16x8*>(lo + (size_t)row * C + s2 * 8) = vl;
+        if (nmax) {                                  // the row's 32 slots are the 32 lanes of a half-wave (total is a multiple of 32)
+            float n2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float q = (float)vh[e] + (float)vl[e]; n2 = fmaf(q, q, n2); }
+#pragma unroll
+            for (int m = 1; m < 32; m <<= 1) n2 += shfl_xor_f(n2, m);
+            n2max = fmaxf(n2max, n2);
+        }
+    }
+    if (nmax) {
+        n2max = fmaxf(n2max, shfl_xor_f(n2max, 32));
+        // one atomic per wave on one address would serialise 78 k of them in L2 (0.8 ms): only a wave that can still raise the
+        // maximum issues it (the plain read may be stale -- then the atomic is merely redundant; the maximum only grows)
+        if ((threadIdx.x & 63) == 0 && n2max > __uint_as_float(*reinterpret_cast<volatile unsigned*>(nmax))) atomicMax(nmax, __float_as_uint(n2max));
     }
     if (overflow && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(overflow, 1);
 }
@@ -256,6 +273,72 @@ __global__ __launch_bounds__(256, 2) void k1_rowstats(const _Float16* __restrict
     }
 }
 
+// Tile prescreen of the match pass (round 4).  An entry can be a match only with conf > thr, and conf <= 2^(2x - rowmax_i - colmax_j)
+// (both softmax sums are >= 1).  The hi.hi product alone bounds x from above: x <= x_hh + e, e = c1 |a|max |b|max (2^-10 (1 + 2^-11) +
+// 2^-13) -- the two cross terms are at most 2^-11 |a_k| |b_k| each (Cauchy-Schwarz over the channels), 2^-13 covers the 768 fp32
+// accumulation steps (4.6e-5); |a|max, |b|max from k1_prep.  tmask[z][row block of 128][tile][wave] = 1 when the wave's 32 rows x 64
+// columns hold an entry with 2 (x_hh + e) - rowmax - colmax > log2 thr; k1_match skips the others: their entries cannot pass `> thr`,
+// so neither the row bests that matter nor the column maxima (entries above thr only) change -- the same matches bit for bit (the
+// surviving tiles are computed by score_tile as before: the SAME x the statistics passes summed), at a third of the matrix
+// instructions and half the tile traffic for the 97 % of the tiles without a candidate (bench workload, tools/prescreen_stats.py).
+__global__ __launch_bounds__(256, 2) void k1_screen(const _Float16* __restrict__ ah, const _Float16* __restrict__ bh, int Z, int L, int S,
+                                                    int Lp, int Sp, float c1, const float2* __restrict__ rowstat,
+                                                    const float* __restrict__ cmax, float thr, const unsigned* __restrict__ nmax,
+                                                    uint8_t* __restrict__ tmask) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int nI = Lp / 128;
+    int z, Ib;
+    tile_coords(nI, Z, z, Ib);
+    const int irow = Ib * 128 + 32 * wave + l31;
+    f16x8 rh[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        rh[s] = *reinterpret_cast<const f16x8*>(ah + ((size_t)z * Lp + irow) * C + 8 * ((2 * s + h) ^ (irow & 15)));
+    const float rmax = irow < L ? rowstat[(size_t)z * L + irow].x : HUGE_F;
+    const float c2 = 2.0f * c1;
+    const float slack2 = c2 * __builtin_sqrtf(__uint_as_float(nmax[0]) * __uint_as_float(nmax[1])) *
+                         (1.0f / 1024.0f * (1.0f + 1.0f / 2048.0f) + 1.0f / 8192.0f);
+    const float lim = __builtin_amdgcn_logf(thr) + rmax - slack2;       // candidate: 2 x_hh - colmax > lim
+    const int ntile = (S + KT - 1) / KT;
+    for (int jt = 0; jt < ntile; ++jt) {
+        __syncthreads();
+        {                                                               // the hi plane of the tile only
+            const unsigned char* sh = reinterpret_cast<const unsigned char*>(bh + ((size_t)z * Sp + jt * KT) * C) + tid * 16;
+#pragma unroll
+            for (int j = 0; j < TILE_PLANE / 4096; ++j)
+                __builtin_amdgcn_global_load_lds((gptr_t)(sh + j * 4096), (lptr_t)(lds + j * 4096 + wave * 1024), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        f32x16 acc[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const int row = 32 * ct + l31;
+                const f16x8 ch = *reinterpret_cast<const f16x8*>(lds + row * ROWB + (((2 * s + h) ^ (row & 15)) * 16));
+                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch, rh[s], acc[ct], 0, 0, 0);
+            }
+        float top = -HUGE_F;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const float4 a = *reinterpret_cast<const float4*>(cmax + (size_t)z * Sp + jt * KT + 32 * ct + 8 * q4 + 4 * h);
+                top = fmaxf(top, fmaxf(fmaxf(fmaf(acc[ct][4 * q4 + 0], c2, -a.x), fmaf(acc[ct][4 * q4 + 1], c2, -a.y)),
+                                       fmaxf(fmaf(acc[ct][4 * q4 + 2], c2, -a.z), fmaf(acc[ct][4 * q4 + 3], c2, -a.w))));
+            }
+        const bool can = !(top <= lim);                                 // also true for NaN
+        const bool any = __builtin_amdgcn_ballot_w64(can) != 0ull;
+        if (lane == 0) tmask[(((size_t)z * nI + Ib) * ntile + jt) * 4 + wave] = any ? 1 : 0;
+    }
+}
+
 template <bool CONF>
 __global__ __launch_bounds__(256, 2) void k1_match(const _Float16* __restrict__ ah, const _Float16* __restrict__ al,
                                                    const _Float16* __restrict__ bh, const _Float16* __restrict__ bl,
@@ -264,7 +347,7 @@ __global__ __launch_bounds__(256, 2) void k1_match(const _Float16* __restrict__ 
                                                    const float2* __restrict__ rowstat, const float* __restrict__ cmax,
                                                    const float* __restrict__ cinv, float* __restrict__ conf,
                                                    float* __restrict__ rowbest_v, int* __restrict__ rowbest_j,
-                                                   unsigned* __restrict__ colbest, float thr) {
+                                                   unsigned* __restrict__ colbest, float thr, const uint8_t* __restrict__ tmask) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     const int nI = Lp / 128;
@@ -283,10 +366,14 @@ __global__ __launch_bounds__(256, 2) void k1_match(const _Float16* __restrict__ 
     int bestj = 0x7fffffff;
     const int ntile = (S + KT - 1) / KT;
     for (int jt = 0; jt < ntile; ++jt) {
+        // k1_screen's verdict on this workgroup's four 32-row blocks: no candidate in any of them -> nothing to do for the tile
+        // (workgroup-uniform: the barriers below are skipped by all four waves together)
+        if (tmask && *reinterpret_cast<const unsigned*>(tmask + (((size_t)z * nI + Ib) * ntile + jt) * 4) == 0u) continue;
         __syncthreads();                       // previous tile's fragments and column exchange consumed
         dma_tile(lds, bh, bl, (size_t)z * Sp + jt * KT, tid, wave);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (tmask && tmask[(((size_t)z * nI + Ib) * ntile + jt) * 4 + wave] == 0) continue;      // this wave's 32 rows: no candidate
         f32x16 acc[2];
         score_tile(acc, lds, rf, l31, h);
         const bool masks = mask0 != nullptr || mask1 != nullptr;                 // wave-uniform
@@ -359,6 +446,8 @@ struct Ws16 {
     float2* colstat2;
     float *cmax, *cinv;
     float* rthr;             // [Z][Lp]: rowmax + log2(rowsum) - 12 (candidate threshold of the conf_matrix writer)
+    uint8_t* tmask;          // [Z][Lp / 128][tiles of 64 columns][4 waves]: k1_screen's verdicts for k1_match
+    unsigned* nmax;          // [2]: bit patterns of max row |2^4 f0|^2, max row |2^4 f1|^2 (prescreen bound of k1_match)
     int* fix_count;          // [Z][S][2]: entries each (column, half-wave) wanted to list for the writer's exact pass
     uint2* fix_list;         // [Z][S][2][CAND_SLOTS]: (i, bits of x)
     size_t bytes;
@@ -375,6 +464,8 @@ inline Ws16 carve16(void* ws, int Z, int L, int S) {
     w.colstat2 = (float2*)take((size_t)Z * S * 8);
     w.cmax = (float*)take((size_t)Z * Sp * 4); w.cinv = (float*)take((size_t)Z * Sp * 4);
     w.rthr = (float*)take((size_t)Z * Lp * 4);
+    w.nmax = (unsigned*)take(2 * sizeof(unsigned));
+    w.tmask = (uint8_t*)take((size_t)Z * (Lp / 128) * ((S + KT - 1) / KT) * 4);
     w.fix_count = (int*)take((size_t)Z * S * 2 * sizeof(int));
     w.fix_list = (uint2*)take((size_t)Z * S * 2 * CAND_SLOTS * sizeof(uint2));
     w.bytes = o;
@@ -397,8 +488,8 @@ int far_k1_stats_launch(const float* f0, const float* f1, int Z, int L, int S, f
     const int Lp = (L + 127) / 128 * 128, Sp = (S + 127) / 128 * 128;
     const float c1 = k1_c1(temperature), fill2 = -1e9f * 1.44269504088896341f;
     auto gridp = [](long n) { long b = (n + 255) / 256; return (unsigned)(b < 65536L * 4 ? b : 65536L * 4); };
-    hipLaunchKernelGGL(k1_prep, dim3(gridp((long)Z * Lp * 32)), dim3(256), 0, stream, f0, Z, L, Lp, w.ah, w.al, overflow);
-    hipLaunchKernelGGL(k1_prep, dim3(gridp((long)Z * Sp * 32)), dim3(256), 0, stream, f1, Z, S, Sp, w.bh, w.bl, overflow);
+    hipLaunchKernelGGL(k1_prep, dim3(gridp((long)Z * Lp * 32)), dim3(256), 0, stream, f0, Z, L, Lp, w.ah, w.al, overflow, (unsigned*)nullptr);
+    hipLaunchKernelGGL(k1_prep, dim3(gridp((long)Z * Sp * 32)), dim3(256), 0, stream, f1, Z, S, Sp, w.bh, w.bl, overflow, (unsigned*)nullptr);
     const size_t smem_s = 2 * TILE_PLANE + KT * sizeof(float);
     FAR_ONCE_PER_DEVICE(hipFuncSetAttribute((const void*)k1_rowstats<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_s));
     hipLaunchKernelGGL(k1_rowstats<false>, dim3((Lp / 128) * Z), dim3(256), smem_s, stream, w.ah, w.al, w.bh, w.bl, Z, L, S, Lp, Sp,
@@ -442,8 +533,10 @@ int far_coarse_match_f16s(const float* f0, const float* f1, int Z, int L, int S,
     const float c1 = (float)(1.4426950408889634 / ((double)C * (double)temperature * PRESCALE * PRESCALE));
     const float fill2 = -1e9f * 1.44269504088896341f;
     auto gridp = [](long n) { long b = (n + 255) / 256; return (unsigned)(b < 65536L * 4 ? b : 65536L * 4); };
-    hipLaunchKernelGGL(k1_prep, dim3(gridp((long)Z * Lp * 32)), dim3(256), 0, stream, f0, Z, L, Lp, w.ah, w.al, overflow);
-    hipLaunchKernelGGL(k1_prep, dim3(gridp((long)Z * Sp * 32)), dim3(256), 0, stream, f1, Z, S, Sp, w.bh, w.bl, overflow);
+    const bool screen = !conf_out && !mask0 && !mask1 && far_get_tuning(10) == 0;      // the match pass's tile prescreen (tuning 10: 1 = off)
+    if (screen) hipMemsetAsync(w.nmax, 0, 2 * sizeof(unsigned), stream);
+    hipLaunchKernelGGL(k1_prep, dim3(gridp((long)Z * Lp * 32)), dim3(256), 0, stream, f0, Z, L, Lp, w.ah, w.al, overflow, screen ? w.nmax : (unsigned*)nullptr);
+    hipLaunchKernelGGL(k1_prep, dim3(gridp((long)Z * Sp * 32)), dim3(256), 0, stream, f1, Z, S, Sp, w.bh, w.bl, overflow, screen ? w.nmax + 1 : (unsigned*)nullptr);
     int* counts = counts_out ? counts_out : w.k.counts;
     hipMemsetAsync(counts, 0, sizeof(int) * Z, stream);
     const size_t smem_s = 2 * TILE_PLANE + KT * sizeof(float), smem_m = 2 * TILE_PLANE + 4 * 64 * sizeof(float);
@@ -459,12 +552,19 @@ int far_coarse_match_f16s(const float* f0, const float* f1, int Z, int L, int S,
                        (int*)nullptr, (uint2*)nullptr);
     const int nI = Lp / 128;
     hipMemsetAsync(w.k.colbest_part, 0, sizeof(float) * (size_t)Z * S, stream);      // the atomic column maxima start at 0
+    if (screen) {
+        FAR_ONCE_PER_DEVICE(hipFuncSetAttribute((const void*)k1_screen, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TILE_PLANE));
+        hipLaunchKernelGGL(k1_screen, dim3(nI * Z), dim3(256), TILE_PLANE, stream, w.ah, w.bh, Z, L, S, Lp, Sp, c1, w.k.rowstat, w.cmax, thr,
+                           (const unsigned*)w.nmax, w.tmask);
+    }
     if (conf_out)
         hipLaunchKernelGGL(k1_match<true>, dim3(nI * Z), dim3(256), smem_m, stream, w.ah, w.al, w.bh, w.bl, Z, L, S, Lp, Sp, c1,
-                           fill2, mask0, mask1, w.k.rowstat, w.cmax, w.cinv, conf_out, w.k.rowbest_v, w.k.rowbest_j, reinterpret_cast<unsigned*>(w.k.colbest_part), thr);
+                           fill2, mask0, mask1, w.k.rowstat, w.cmax, w.cinv, conf_out, w.k.rowbest_v, w.k.rowbest_j, reinterpret_cast<unsigned*>(w.k.colbest_part), thr,
+                           screen ? (const uint8_t*)w.tmask : (const uint8_t*)nullptr);
     else
         hipLaunchKernelGGL(k1_match<false>, dim3(nI * Z), dim3(256), smem_m, stream, w.ah, w.al, w.bh, w.bl, Z, L, S, Lp, Sp, c1,
-                           fill2, mask0, mask1, w.k.rowstat, w.cmax, w.cinv, conf_out, w.k.rowbest_v, w.k.rowbest_j, reinterpret_cast<unsigned*>(w.k.colbest_part), thr);
+                           fill2, mask0, mask1, w.k.rowstat, w.cmax, w.cinv, conf_out, w.k.rowbest_v, w.k.rowbest_j, reinterpret_cast<unsigned*>(w.k.colbest_part), thr,
+                           screen ? (const uint8_t*)w.tmask : (const uint8_t*)nullptr);
     // colbest_part doubles as the single [Z][S] array of atomic column maxima (nI = 1 for k_finalize)
     hipLaunchKernelGGL(k_finalize, dim3((L + 255) / 256, Z), dim3(256), 0, stream, w.k.rowbest_v, w.k.rowbest_j,
                        w.k.colbest_part, 1, L, S, thr, border, h0, w0, h1, w1, valid_hw, w.k.match_j, counts);
@@ -491,8 +591,8 @@ int far_conf_matrix_f16s(const float* f0, const float* f1, int Z, int L, int S, 
     const float fill2 = -1e9f * 1.44269504088896341f;
     if (stages & 1) {
         auto gridp = [](long n) { long b = (n + 255) / 256; return (unsigned)(b < 65536L * 4 ? b : 65536L * 4); };
-        hipLaunchKernelGGL(k1_prep, dim3(gridp((long)Z * Lp * 32)), dim3(256), 0, stream, f0, Z, L, Lp, w.ah, w.al, overflow);
-        hipLaunchKernelGGL(k1_prep, dim3(gridp((long)Z * Sp * 32)), dim3(256), 0, stream, f1, Z, S, Sp, w.bh, w.bl, overflow);
+        hipLaunchKernelGGL(k1_prep, dim3(gridp((long)Z * Lp * 32)), dim3(256), 0, stream, f0, Z, L, Lp, w.ah, w.al, overflow, (unsigned*)nullptr);
+        hipLaunchKernelGGL(k1_prep, dim3(gridp((long)Z * Sp * 32)), dim3(256), 0, stream, f1, Z, S, Sp, w.bh, w.bl, overflow, (unsigned*)nullptr);
         const size_t smem_s = 2 * TILE_PLANE + KT * sizeof(float);
         FAR_ONCE_PER_DEVICE(
             hipFuncSetAttribute((const void*)k1_rowstats<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_s);

@@ -279,3 +279,42 @@ def test_conf_matrix_writer_with_masks():
     got = conf.cpu().numpy()
     assert np.abs(got - ref64)[valid].max() <= ATOL64
     assert got[~valid].max() <= 1e-30 or np.abs(got - ref64)[~valid].max() <= ATOL64
+
+
+@pytest.mark.parametrize('kind', ['peaky', 'diffuse', 'mixed_norms', 'near_threshold'])
+def test_f16s_match_pass_prescreen_changes_nothing(kind):
+    """Round 4: k1_match skips the tiles for which k1_screen's hi.hi scores prove that no entry can exceed `thr` (bound in the kernel).  With the prescreen on (default) and off (tuning key 10) the matches and their confidences must be
+    IDENTICAL bit for bit -- on confident permutation matches, on a diffuse matrix where nothing may be skipped, with rows whose
+    norms differ by 30x (the bound uses the largest norm), and with confidences straddling the threshold."""
+    from far_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    hw = (40, 48)
+    L = hw[0] * hw[1]
+    if kind == 'peaky':
+        f0, f1, _ = correlated_features(2, hw, 256, seed=31, amp=1.2, frac=0.9)
+    elif kind == 'diffuse':
+        f0 = (0.25 * rng.standard_normal((2, L, 256))).astype(np.float32)
+        f1 = (0.25 * rng.standard_normal((2, L, 256))).astype(np.float32)
+    elif kind == 'mixed_norms':
+        f0, f1, _ = correlated_features(2, hw, 256, seed=32, amp=1.0, frac=0.8)
+        sc = np.where(rng.random((2, L, 1)) < 0.1, 6.0, 0.2).astype(np.float32)
+        f0, f1 = f0 * sc, f1 * sc
+    else:
+        f0, f1, _ = correlated_features(2, hw, 256, seed=33, amp=0.88, noise=0.1, frac=0.9)       # best confidences around 0.2
+    outs = []
+    for off in (0, 1, 0):
+        lib.far_set_tuning(10, off)
+        try:
+            outs.append(_run(f0, f1, hw, False, variant='f16s'))
+        finally:
+            lib.far_set_tuning(10, 0)
+    a, b, c = outs
+    print(f'[prescreen] {kind}: {len(a["b_ids"])} matches')
+    for k in ('b_ids', 'i_ids', 'j_ids', 'mconf', 'mkpts0_c', 'mkpts1_c'):
+        assert torch.equal(a[k], b[k]) and torch.equal(a[k], c[k]), k
+    if kind == 'peaky':
+        assert len(a['b_ids']) > 2000
+    if kind == 'near_threshold':
+        m = a['mconf']
+        assert len(m) > 20 and float(m.min()) < 0.3            # matches close to the threshold exist
