@@ -7,6 +7,8 @@
 //   k1_rowstats  x2: log2-domain softmax statistics of every row of the similarity matrix -- (f0, f1) for the softmax
 //                over columns j, (f1, f0) for the softmax over rows i (a lane owns one row of the transposed score
 //                tile: no cross-lane reductions); the second call also leaves dense, padded column arrays
+//   k1_screen    (round 4, unmasked non-materialising calls) hi.hi scores + a norm bound -> which 32-row x 64-column tiles can hold
+//                an entry with conf > thr at all; k1_match skips the others (3 % survive on the bench workload)
 //   k1_match     conf = 2^(2 x - rowmax - colmax) / (rowsum colsum): ONE exp per score; per row the best (conf, j)
 //                (ties -> smaller j, as mask.max(dim=2) on CPU), per 128-row block the column maxima (32-lane max of
 //                each accumulator register); optional conf_matrix with 16-byte stores
