@@ -5,7 +5,10 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-r02}
 mkdir -p $R/gpurun_out
-# the un-profiled headline line first: counter collection can leave the clocks in the profiler's fixed state for a while
+# page the image in first (the first process on a fresh box runs with a slow host for a while: 107-113 ms steps were measured there
+# against 94-95 ms in every later process), then the un-profiled headline line: counter collection can leave the clocks in the
+# profiler's fixed state for a while
+(cd $R; timeout 300 python tools/step_times.py 3 > /dev/null 2>&1)
 (cd $R; timeout 400 python bench.py > gpurun_out/bench_plain.log 2> gpurun_out/bench_plain.err)
 cd /tmp; export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_bench -o bench -- python3 $R/bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-other-modes --no-other-workloads > $R/gpurun_out/bench_prof.log 2>&1
