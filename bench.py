@@ -519,7 +519,9 @@ def bench_c3(a, dev, world, rank, dist):
         # _recursive_to, which rebuilds them -- LoFTR.forward writes its results into the dict it is given
         # (pipeline._trainval_inference merges a returned copy back, tests/test_multirank_gpu.py covers both forms)
         fwd = DDP(model)
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-5, weight_decay=0.1)      # src/optimizers/__init__.py:5-16, default.py TRAINER.*
+    # src/optimizers/__init__.py:5-16, default.py TRAINER.*: AdamW; K20 (one launch over all 189 tensors) unless --vendor-train
+    from far_amd.optim import AdamW as _FarAdamW
+    opt = (torch.optim.AdamW if (a.vendor_train or os.environ.get('FAR_TORCH_ADAMW') == '1') else _FarAdamW)(model.parameters(), lr=1e-5, weight_decay=0.1)
     # synthetic supervision: banded lateral disparities -> ground-truth coarse matches + warped grid (far_amd/synth.py)
     base = synth.synth_training_batch(B, seed=1234 + rank, device=dev)
     n_gt = int(base['spv_b_ids'].numel()) // B

@@ -29,7 +29,7 @@ extern "C" {
 typedef struct ihipStream_t* far_stream_t; /* == hipStream_t */
 
 /* ABI version of this header; bumped when a signature changes (2: activation exponent / overflow flag of K9, K13, K14; 3: the
- * far_wino_* / far_conv3x3_wino_f32 entry points, 16 tuning keys; 4: far_upsample2x_bwd_f32, far_fine_scatter_det_f32, far_bn_train_*).  far_amd/_lib.py refuses a library whose version differs. */
+ * far_wino_* / far_conv3x3_wino_f32 entry points, 16 tuning keys; 4: far_upsample2x_bwd_f32, far_fine_scatter_det_f32, far_bn_train_*, far_adamw_*).  far_amd/_lib.py refuses a library whose version differs. */
 int far_abi_version(void);
 /* hipError_t of the most recent failed launch on the calling thread (0 = none): detail behind a -5 return. */
 int far_last_hip_error(void);
@@ -320,6 +320,15 @@ int far_affine_act_f32(const float* x, const float* scale, const float* shift, c
  * layout selected by nhwc (0: NCHW, w even; 1: channels_last, C % 4 == 0). */
 int far_upsample2x_add_f32(const float* lo, const float* hi, int N, int h, int w, int C, int nhwc, float* out,
                            far_stream_t stream);
+
+/* K20: AdamW over all parameter tensors of a model in one launch (adamw_f32.hip) -- torch.optim.AdamW's arithmetic in its order
+ * (src/optimizers/__init__.py:5-16): p *= 1 - lr wd; m += (1 - beta1)(g - m); v = beta2 v + (1 - beta2) g g;
+ * p -= (lr / bc1) m / (sqrt(v) / bc2_sqrt + eps).  table: far_adamw_table_bytes(n, nblocks) bytes on the device: n rows
+ * { float* p; const float* g; float* m; float* v; long n; } then nblocks int2 { tensor, chunk of 4096 elements }; a row with g = NULL
+ * is skipped.  far_amd/optim.py:AdamW builds it once and refreshes the gradient pointers every step. */
+long far_adamw_table_bytes(int n, long nblocks);
+int far_adamw_step_f32(const void* table, int n, long nblocks, double lr, double beta1, double beta2, double eps, double wd, double bc1,
+                       double bc2_sqrt, far_stream_t stream);
 
 /* K19: BatchNorm2d with BATCH statistics (training mode) on channels_last fp32 tensors [M = N H W][C], C % 4 == 0, C <= 1024
  * (batchnorm_train_f32.hip) -- resnet_fpn.py:24-41, 60-62, 75-91 under autograd; deterministic (fixed-order two-stage sums).

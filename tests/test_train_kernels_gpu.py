@@ -690,3 +690,30 @@ def test_batchnorm_train_matches_float64_autograd_and_the_module(N, C, H, W, act
     torch.testing.assert_close(rv.double(), ref_bn.running_var, rtol=1e-5, atol=1e-6)
     for o in outs[1:]:
         assert all(torch.equal(a, b) for a, b in zip(o, outs[0]))
+
+
+def test_adamw_one_launch_matches_torch_adamw():
+    """K20 (far_amd.optim.AdamW, one launch per step over a device table) against torch.optim.AdamW on a small model with tensors of
+    odd sizes: parameters and both moments after five steps (gradients re-allocated every step, one parameter without a gradient)."""
+    from far_amd.optim import AdamW
+    torch.manual_seed(3)
+    shapes = [(5000,), (64, 33, 3, 3), (1,), (4097,), (256, 256), (7,)]
+    pa = [torch.nn.Parameter(torch.randn(s, device='cuda')) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa = AdamW(pa, lr=3e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.1)
+    ob = torch.optim.AdamW(pb, lr=3e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.1)
+    for it in range(5):
+        oa.zero_grad(set_to_none=True); ob.zero_grad(set_to_none=True)
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            if i == 5:
+                continue                                  # never gets a gradient: both optimizers leave it alone
+            g = torch.randn_like(a) * (10.0 ** (it - 2))
+            a.grad, b.grad = g.clone(), g.clone()
+        oa.step(); ob.step()
+    for i, (a, b) in enumerate(zip(pa, pb)):
+        torch.testing.assert_close(a, b, rtol=2e-6, atol=1e-7)
+        if i != 5:
+            for key in ('exp_avg', 'exp_avg_sq'):           # absolute tolerance relative to the moment's scale (m cancels against g)
+                want = ob.state[b][key]
+                torch.testing.assert_close(oa.state[a][key], want, rtol=2e-6, atol=2e-7 * float(want.abs().max()))
+    assert torch.equal(pa[5], pb[5])
