@@ -85,6 +85,7 @@ struct WinoArgs {
     int* overflow;
     long ntb;                    // tile blocks = N * tilesX * tilesY
     int H, W, Cin, Cout, nk, ncb, tilesX, tilesY, act;
+    int half_ok;                 // the last channel block holds at most 32 channels: its workgroups run the HALF body
     float slope, out_mul;
 };
 
@@ -146,8 +147,12 @@ __device__ unsigned long long g_wino_stamps2[4096 * 8 * 16];
 #define FAR_WINO_EXP 0      // experiment builds only (tools/wino_exp.sh): 1 no transform, 2 no MFMAs, 4 no weight requests, 8 no raw
 #endif                      // requests, 16 no epilogue, 32 every wait drains the queue (vmcnt(0)), 64 raw requests to a cache-resident region
 
-template <bool Q, bool MIX>
+// HALF: the last channel block of a layer whose channel count leaves it at most 32 channels (196 / 208 outputs: 4 or 16 of 64) --
+// only the first 32-channel tile is multiplied (12 MFMAs per interval), and the waves whose weight pieces belong to the second
+// tile (wave & 2: piece 4 j + wave = [xi & 1][nu][co tile][plane]) request none.
+template <bool Q, bool MIX, bool HALF>
 __device__ __forceinline__ void wino_body(const WinoArgs& p) {
+    constexpr int NCT = HALF ? 1 : 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const Bs = smem;
     unsigned char* const Rs = smem + RAW_OFF;
@@ -197,7 +202,9 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p) {
         const int i = slab < nslab ? slab : nslab - 1;
         return wbase + (size_t)i * SLAB;
     };
+    const bool wskip = HALF && (wsel & 2);            // wave-uniform
     auto b_piece = [&](const unsigned char* src0, int slot, int j) {          // piece j (0..7) of this wave
+        if (wskip) return;
         if (!(FAR_WINO_EXP & 4)) glds16(src0 + j * 4096, bs_base + slot * SLAB + j * 4096);
     };
 
@@ -311,11 +318,11 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p) {
         }
     };
 
-    f32x16 acc[4][2];
+    f32x16 acc[4][NCT];
 #pragma unroll
     for (int nu = 0; nu < 4; ++nu)
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
+        for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nu][ct][r] = 0.f;
 
@@ -329,13 +336,14 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p) {
             return;
         }
         const unsigned char* B = Bs + slot * SLAB + b_lane;
-        f16x8 bh[2][2], bl[2][2];
+        f16x8 bh[2][NCT], bl[2][NCT];
         auto read_b = [&](int nu) {
             const int q = nu & 1;
-            bh[q][0] = *reinterpret_cast<const f16x8*>(B + (nu * 4 + 0) * 1024);
-            bl[q][0] = *reinterpret_cast<const f16x8*>(B + (nu * 4 + 1) * 1024);
-            bh[q][1] = *reinterpret_cast<const f16x8*>(B + (nu * 4 + 2) * 1024);
-            bl[q][1] = *reinterpret_cast<const f16x8*>(B + (nu * 4 + 3) * 1024);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                bh[q][ct] = *reinterpret_cast<const f16x8*>(B + (nu * 4 + 2 * ct) * 1024);
+                bl[q][ct] = *reinterpret_cast<const f16x8*>(B + (nu * 4 + 2 * ct + 1) * 1024);
+            }
         };
         read_b(0);
 #pragma unroll
@@ -343,16 +351,16 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p) {
             const int q = nu & 1;
             if (nu + 1 < 4) read_b(nu + 1);
 #pragma unroll
-            for (int m = 0; m < 6; ++m) {
-                const int ct = m & 1;
-                const f16x8 a = __builtin_bit_cast(f16x8, m < 4 ? Ah[nu] : Al[nu]);
-                const f16x8 bb = (m >> 1) == 1 ? bl[q][ct] : bh[q][ct];             // hi.hi, hi.lo, lo.hi
+            for (int m = 0; m < 3 * NCT; ++m) {
+                const int ct = HALF ? 0 : m & 1, term = HALF ? m : m >> 1;       // hi.hi, hi.lo, lo.hi
+                const f16x8 a = __builtin_bit_cast(f16x8, term < 2 ? Ah[nu] : Al[nu]);
+                const f16x8 bb = term == 1 ? bl[q][ct] : bh[q][ct];
                 acc[nu][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bb, acc[nu][ct], 0, 0, 0);
-                const int mi = 6 * nu + m;
+                const int mi = 3 * NCT * nu + m;
                 bool any = false;
 #pragma unroll
                 for (int i = 0; i < NP; ++i)
-                    if ((i < 8 ? i : 9 + 2 * (i - 8)) == mi) { piece(i); any = true; }
+                    if ((HALF ? (i * 12) / (NP > 12 ? NP : 12) : (i < 8 ? i : 9 + 2 * (i - 8))) == mi) { piece(i); any = true; }
                 if (any) __builtin_amdgcn_sched_barrier(0);        // the request stays behind this MFMA
             }
         }
@@ -400,11 +408,12 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p) {
         if (k < 14) FAR_WINO_STAMP(2 + 4 * k);
         FAR_WINO_T2(k, 1);
 #ifdef FAR_WINO_TIMING2
-        if (Q) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+        if (Q) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else if (wskip) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
         FAR_WINO_T2(k, 2);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #else
         if (Q || (FAR_WINO_EXP & 32)) asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else if (wskip) asm volatile("s_waitcnt vmcnt(6)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // this interval's six raw requests only
         else asm volatile("s_waitcnt vmcnt(14)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
         if (k < 14) FAR_WINO_STAMP(3 + 4 * k);
@@ -446,7 +455,7 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p) {
     FAR_WINO_STAMP(60);
     if (FAR_WINO_EXP & 16) {
         float tsum = 0.f;
-        for (int nu = 0; nu < 4; ++nu) for (int ct = 0; ct < 2; ++ct) for (int r = 0; r < 16; ++r) tsum += acc[nu][ct][r];
+        for (int nu = 0; nu < 4; ++nu) for (int ct = 0; ct < NCT; ++ct) for (int r = 0; r < 16; ++r) tsum += acc[nu][ct][r];
         if (tsum == 123.456f) p.y[0] = tsum;
         return;
     }
@@ -457,7 +466,7 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p) {
 #pragma unroll
         for (int nu = 0; nu < 4; ++nu)
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
+            for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) chk += acc[nu][ct][r];
         const bool bad = !(fabsf(chk) <= FLT_MAX);
@@ -473,7 +482,7 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p) {
     {
         float* const zw = zb + ((xi * 2) * 64 + 32 * tb + 4 * h) * 64 + l31;
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
+        for (int ct = 0; ct < NCT; ++ct)          // (HALF: the image's second channel tile keeps stale bytes; its lanes store nothing)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = 8 * (r >> 2) + (r & 3);                         // + 4 h: the tile inside the block
@@ -539,8 +548,17 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p) {
 
 template <bool MIX>
 __global__ __launch_bounds__(512, 2) void k_wino(const WinoArgs p) {
-    if (threadIdx.x >= 256) wino_body<true, MIX>(p);
-    else wino_body<false, MIX>(p);
+    // the workgroup's channel block (as wino_body maps it): the last one may hold at most 32 channels
+    const long seq = (p.ntb & 7) == 0 ? (long)blockIdx.x >> 3 : (long)blockIdx.x;
+    const int cb = (int)(seq % p.ncb);
+    const bool half = p.half_ok && cb == p.ncb - 1;            // workgroup-uniform
+    if (half) {
+        if (threadIdx.x >= 256) wino_body<true, MIX, true>(p);
+        else wino_body<false, MIX, true>(p);
+    } else {
+        if (threadIdx.x >= 256) wino_body<true, MIX, false>(p);
+        else wino_body<false, MIX, false>(p);
+    }
 }
 
 // Packs w (read through element strides like K9's pack: s_co, s_ci per channel, s_tap per tap in execution order ky * 3 + kx)
@@ -658,6 +676,7 @@ int far_conv3x3_wino_f32(const far_conv_desc* desc, hipStream_t stream) {
     a.tilesX = (d.W + 15) / 16; a.tilesY = (d.H + 15) / 16;
     a.ntb = d.N * a.tilesX * a.tilesY;
     a.act = d.act; a.slope = d.slope; a.out_mul = 16.0f;
+    a.half_ok = (d.Cout - 64 * (a.ncb - 1) <= 32 && far_get_tuning(9) == 0) ? 1 : 0;      // tuning 9: 1 = every block on the full body
     const long nblk = a.ntb * a.ncb;
     if (nblk > 0x7fffffffL || (long)d.H * d.W * d.Cout > 0x7fffffffL) return FAR_EINVAL;
     const bool mix = far_get_tuning(8) == 0;
