@@ -1409,7 +1409,7 @@ def conv_nhwc(x, pc, residual=None, act='none', slope=0.01, x2=None, out_planes=
     N, H, W, Cin1 = x.shape
     if (USE_WINO and pc.ksize == 3 and pc.stride == 1 and pc.split and x2 is None and out_planes == 1 and res_group == 1 and ln is None
             and post_residual is None and up is None and act_scale_dev is None and not torch.is_grad_enabled()
-            and activation_exponent_value() >= WINO_MIN_ACT_EXP and H * W >= WINO_MIN_PIXELS):
+            and activation_exponent_value() >= WINO_MIN_ACT_EXP and H * W >= WINO_MIN_PIXELS and H * W * pc.Cout < 2 ** 31):
         pw = pc.wino()
         if pw is not None:
             # K17 (Winograd F(2x2, 3x3)): 1.03-1.26x K9 on the backbone's stride-1 3x3 layers at one third of its error
