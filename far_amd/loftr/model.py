@@ -58,6 +58,17 @@ def _tokens(fmap, pos_enc):
     return pos_enc(fmap).flatten(2).transpose(1, 2).contiguous()
 
 
+_POSE_STATS = {}
+
+
+def _pose_stats(device):
+    """pose_mean_6d / pose_std_6d on `device` (uploaded once)."""
+    key = str(device)
+    if key not in _POSE_STATS:
+        _POSE_STATS[key] = (pose_mean_6d.to(device), pose_std_6d.to(device))
+    return _POSE_STATS[key]
+
+
 class LoFTR(nn.Module):
     """Reference interface (loftr.py:14-211): forward / forward_feature_extraction /
     forward_correspondence_prediction / forward_rt_prediction / preprocess_helper / load_state_dict."""
@@ -219,11 +230,27 @@ class LoFTR(nn.Module):
         if rc['save_gating_weights']:
             data['gating_reg_weights'] = gate
         if self.config['solver'] == 'prior_ransac':
-            p = pose.detach().float().cpu()
-            R = rotation_6d_to_matrix(p[:, 3:] * pose_std_6d[3:] + pose_mean_6d[3:]).numpy()
-            t = (p[:, :3] * pose_std_6d[:3] + pose_mean_6d[:3]).numpy()
-            prior = np.concatenate([R, t[:, :, None]], axis=-1)                # (B, 3, 4)
-            data['priorRT'] = prior[0] if len(prior) == 1 else prior
+            # The reference hands the prior on as a numpy array (loftr.py:186-192).  Formed on the device and copied to pinned host
+            # memory WITHOUT a synchronisation of its own: the copy is complete when forward_rt_prediction returns (the activation-range
+            # read of _guarded synchronises behind it); the next solver round takes the device tensor (far_amd.supervision.spvs_RT).
+            p = pose.detach().float()
+            if p.is_cuda:
+                mean, std = _pose_stats(p.device)
+                R = rotation_6d_to_matrix(p[:, 3:] * std[3:] + mean[3:])
+                t = p[:, :3] * std[:3] + mean[:3]
+                prior_dev = torch.cat([R, t[:, :, None]], dim=-1).contiguous()    # (B, 3, 4)
+                host = torch.empty(prior_dev.shape, dtype=torch.float32, pin_memory=True)
+                host.copy_(prior_dev, non_blocking=True)
+                prior = host.numpy()
+                out = prior[0] if len(prior) == 1 else prior
+                data['priorRT'] = out
+                data['_priorRT_device'] = (out, prior_dev)
+            else:
+                R = rotation_6d_to_matrix(p[:, 3:] * pose_std_6d[3:] + pose_mean_6d[3:]).numpy()
+                t = (p[:, :3] * pose_std_6d[:3] + pose_mean_6d[:3]).numpy()
+                prior = np.concatenate([R, t[:, :, None]], axis=-1)                # (B, 3, 4)
+                data['priorRT'] = prior[0] if len(prior) == 1 else prior
+                data.pop('_priorRT_device', None)
 
     # The evaluation loop calls forward_rt_prediction FINE_PRED_STEPS times on one batch with only the 13 solver numbers
     # changing (lightning_loftr.py:338-343); the head's feature stage does not read them, so its result is kept IN THE

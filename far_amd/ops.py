@@ -640,7 +640,7 @@ def solve_pose_batch(kpts0, kpts1, offsets_host, K0, K1, inl_th, many_thr, prior
     B = offs.numel() - 1
     Mtot = int(offs[-1])
     Mmax = int((offs[1:] - offs[:-1]).max()) if B > 0 else 0
-    offs_d = offs.to(dev)
+    offs_d = offs.pin_memory().to(dev, non_blocking=True)          # pageable memory would make this upload a stream synchronisation
     P = 0 if pcl is None else int(pcl.shape[0])
     ws = _ws(lib.far_solver_workspace_bytes(B, Mtot, H, P), dev)
     f64, i32 = torch.float64, torch.int32

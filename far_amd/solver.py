@@ -55,7 +55,10 @@ def estimate_pose_batch(kpts0, kpts1, counts, K0, K1, thresh, solver='ransac', p
         inl_th = (thresh / f) ** 2
     prior = pcl = None
     if mode == 'prior':
-        prior = torch.as_tensor(np.asarray(priorRT), dtype=torch.float32).reshape(-1, 3, 4).to(dev).contiguous()
+        if torch.is_tensor(priorRT) and priorRT.is_cuda:          # the head's prior, still on the device (no round trip through the host)
+            prior = priorRT.to(device=dev, dtype=torch.float32).reshape(-1, 3, 4).contiguous()
+        else:
+            prior = torch.as_tensor(np.asarray(priorRT), dtype=torch.float32).reshape(-1, 3, 4).pin_memory().to(dev, non_blocking=True)
         pcl = prior_point_cloud(dev)
     return ops.solve_pose_batch(kpts0.float().contiguous(), kpts1.float().contiguous(), offs, K0d, K1d,
                                 inl_th.contiguous(), many, priorRT=prior, pcl=pcl, prior_lambda=0.3, H=H, seed=seed,

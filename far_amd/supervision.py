@@ -18,6 +18,9 @@ def spvs_RT(data, config, H=2048, seed=0):
     B = K0.shape[0]
     dev = data['mkpts0_f'].device
     prior = data['priorRT'] if (solver == 'prior_ransac' and 'priorRT' in data) else None     # :198-201
+    dev_prior = data.get('_priorRT_device')          # (the numpy array it mirrors, the same values as a device tensor): forward_rt_prediction
+    if prior is not None and dev_prior is not None and dev_prior[0] is prior:
+        prior = dev_prior[1]                          # the caller did not replace data['priorRT']: skip the upload
     mk0, mk1, m_bids = data['mkpts0_f'], data['mkpts1_f'], data['m_bids']
     M = int(mk0.shape[0])
     if mk1.shape[0] != M or m_bids.shape[0] != M:
