@@ -47,6 +47,32 @@ struct VLds {
     __device__ __forceinline__ void set(int i, double x) { base[i * stride] = x; }
 };
 
+// 9 x 9 eigenvectors of k_hypotheses: rows 0-7 in the LDS slab ([72][thread]: 36 KiB per 64 threads, so that FOUR workgroups fit a CU and
+// the 1024 workgroups of 32 pairs x 2048 hypotheses run in one round -- [81][64] allowed three: two rounds, the second a third full),
+// row 8 in registers (every index the Jacobi code passes is a compile-time constant once unrolled; the one run-time column
+// lookup goes through top_dyn).
+struct VHybrid {
+    double* base;
+    int stride;
+    double t0, t1, t2, t3, t4, t5, t6, t7, t8;          // named scalars: an array member ends up in scratch
+    __device__ __forceinline__ double get(int i) const {
+        if (i < 72) return base[i * stride];
+        switch (i) { case 72: return t0; case 73: return t1; case 74: return t2; case 75: return t3; case 76: return t4;
+                     case 77: return t5; case 78: return t6; case 79: return t7; default: return t8; }
+    }
+    __device__ __forceinline__ void set(int i, double x) {
+        if (i < 72) { base[i * stride] = x; return; }
+        switch (i) { case 72: t0 = x; break; case 73: t1 = x; break; case 74: t2 = x; break; case 75: t3 = x; break; case 76: t4 = x; break;
+                     case 77: t5 = x; break; case 78: t6 = x; break; case 79: t7 = x; break; default: t8 = x; break; }
+    }
+    __device__ __forceinline__ double top_dyn(int k) const {
+        double r = t0;
+        r = k == 1 ? t1 : r; r = k == 2 ? t2 : r; r = k == 3 ? t3 : r; r = k == 4 ? t4 : r;
+        r = k == 5 ? t5 : r; r = k == 6 ? t6 : r; r = k == 7 ? t7 : r; r = k == 8 ? t8 : r;
+        return r;
+    }
+};
+
 template <int N, int P, int Q, class VS>
 __device__ __forceinline__ void jacobi_rot(double (&a)[N * (N + 1) / 2], VS& v) {
     const double apq = a[tri<N>(P, Q)];
@@ -392,8 +418,9 @@ __global__ __launch_bounds__(64, 1) void k_hypotheses(
 #pragma unroll
             for (int q = p; q < 9; ++q) a[tri<9>(p, q)] += row[p] * row[q];
     }
-    extern __shared__ __attribute__((aligned(16))) double vslab[];   // [81][blockDim.x]
-    VLds v{vslab + threadIdx.x, (int)blockDim.x};
+    extern __shared__ __attribute__((aligned(16))) double vslab[];   // [72][blockDim.x]
+    VHybrid v;
+    v.base = vslab + threadIdx.x; v.stride = (int)blockDim.x;
     jacobi_eig<9>(a, v, 20);
     // eigenvector of the smallest eigenvalue (cv_geometry.py:820-821)
     int km = 0; double lm = a[tri<9>(0, 0)];
@@ -401,9 +428,8 @@ __global__ __launch_bounds__(64, 1) void k_hypotheses(
     for (int p = 1; p < 9; ++p) { double l = a[tri<9>(p, p)]; if (l < lm) { lm = l; km = p; } }
     double Fm[9];
 #pragma unroll
-    for (int r = 0; r < 9; ++r) {
-        Fm[r] = v.get(r * 9 + km);
-    }
+    for (int r = 0; r < 8; ++r) Fm[r] = v.base[(r * 9 + km) * v.stride];
+    Fm[8] = v.top_dyn(km);
     // rank-2 projection: F - (F v3) v3^T  == U diag(s1, s2, 0) V^T  (cv_geometry.py:824-827)
     double V3[9], lam[3];
     right_singular_3x3(Fm, V3, lam);
@@ -748,7 +774,7 @@ int far_solver_f64(const float* kpts0, const float* kpts1, const int* offsets, i
     const int* s8 = minimal == 8 ? samples_in : nullptr;
     const int* s5 = minimal == 5 ? samples_in : nullptr;
     if (minimal == 8)
-        hipLaunchKernelGGL(k_hypotheses, dim3((H + 63) / 64, B), dim3(64), 81 * 64 * sizeof(double), stream, w.kp, offsets,
+        hipLaunchKernelGGL(k_hypotheses, dim3((H + 63) / 64, B), dim3(64), 72 * 64 * sizeof(double), stream, w.kp, offsets,
                            (prior && !samples_in) ? w.cdf : nullptr, s8, H, minimal, seed, prior ? w.pp : nullptr, pcl, w.tgt,
                            P, prior_lambda, F_all, w.pscore, minimal == 8 ? samples_out : nullptr);
     {
