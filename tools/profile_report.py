@@ -27,6 +27,14 @@ if gcols:
                            f"where name like '%k_wino<%' group by {sel} order by 5 desc"):
         print('grid', row[:len(gcols[:3])], f'calls {row[-4]}  avg {row[-3]:.1f} us  min {row[-2]:.1f}  max {row[-1]:.1f}')
         if row[0] == 39321600:
-            print(f'roofline_launch_rocprof: kernel=k_wino[K17 3x3 196->196 @240x320] calls={row[-4]} avg_us={row[-3]:.1f}')
+            # bench.py times this launch in isolation (kernel_rooflines: one warm-up + three timed launches, the LAST four of this grid
+            # in the process); the launches before them are the layer inside the warm-up / timed steps, on the model's activations
+            last = [r[0] for r in cur.execute(f"select (end-start)/1e3 from kernels where name like '%k_wino<%' and {gcols[0]}=39321600 "
+                                              "order by start desc limit 3")]
+            inside = cur.execute(f"select avg(end-start)/1e3, count(*) from kernels where name like '%k_wino<%' and {gcols[0]}=39321600 "
+                                 f"and start < (select min(start) from (select start from kernels where name like '%k_wino<%' and "
+                                 f"{gcols[0]}=39321600 order by start desc limit 4))").fetchone()
+            print(f'roofline_launch_rocprof: kernel=k_wino[K17 3x3 196->196 @240x320] calls={len(last)} avg_us={sum(last) / len(last):.1f}'
+                  f'   (the three isolated launches bench.py times; the same layer inside the steps: {inside[1]} launches, avg {inside[0]:.1f} us)')
 else:
     print('no grid columns in', cols)
