@@ -663,3 +663,20 @@ def test_conv_nhwc_dispatches_inference_3x3_layers_to_winograd_and_everything_el
         ys = ops.conv_nhwc(small, pc, act='relu')
         ops.USE_WINO = True
         assert torch.equal(ops.conv_nhwc(small, pc, act='relu'), ys)
+
+
+def test_conv_winograd_beyond_2_gib():
+    """K17 on an input of 2.75 GiB (72 images x 240 x 320 x 128 fp32: byte offsets beyond 2^31, element offsets beyond 2^29): the last
+    image of the batch equals the same image convolved alone, bit for bit."""
+    ops = _ops()
+    g = torch.Generator(device='cuda').manual_seed(77)
+    w = torch.randn(128, 128, 3, 3, device='cuda', generator=g) * 0.03
+    pw = ops.PackedWino(w, torch.rand(128, device='cuda', generator=g) + 0.5, torch.randn(128, device='cuda', generator=g))
+    x = torch.empty(72, 240, 320, 128, device='cuda')
+    x.normal_(generator=g).relu_()
+    y = ops.conv3x3_wino(x, pw, act='relu')
+    for n in (0, 41, 71):
+        assert torch.equal(ops.conv3x3_wino(x[n:n + 1].contiguous(), pw, act='relu')[0], y[n]), n
+    ref = F.conv2d(x[71:72, :64, :64].permute(0, 3, 1, 2).double(), w.double(), padding=1).permute(0, 2, 3, 1)[0, 1:-1, 1:-1]
+    got = ops.conv3x3_wino(x[71:72, :64, :64].contiguous(), ops.PackedWino(w))[0, 1:-1, 1:-1]
+    assert _rel(got, ref)[0] < 2e-6
