@@ -145,7 +145,7 @@ __device__ unsigned long long g_wino_stamps2[4096 * 8 * 16];
 #endif
 #ifndef FAR_WINO_EXP
 #define FAR_WINO_EXP 0      // experiment builds only (tools/wino_exp.sh): 1 no transform, 2 no MFMAs, 4 no weight requests, 8 no raw
-#endif                      // requests, 16 no epilogue, 32 every wait drains the queue (vmcnt(0)), 64 raw requests to a cache-resident region
+#endif                      // requests, 16 no epilogue, 32 every wait drains the queue (vmcnt(0)), 64 raw requests to a cache-resident region, 128 no wait for the prologue's requests
 
 // HALF: the last channel block of a layer whose channel count leaves it at most 32 channels (196 / 208 outputs: 4 or 16 of 64) --
 // only the first 32-channel tile is multiplied (12 MFMAs per interval), and the waves whose weight pieces belong to the second
@@ -377,7 +377,8 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p) {
         for (int j = 0; j < NRP; ++j) raw_piece(1, 1, j);
     }
     FAR_WINO_STAMP(0);
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (FAR_WINO_EXP & 128) asm volatile("s_barrier" ::: "memory");      // experiment: what the exposed prologue latency costs
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     if (FAR_WINO_EXP & 1) transform(-1);
     if (!Q) transform(0);
     FAR_WINO_STAMP(1);
