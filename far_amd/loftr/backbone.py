@@ -77,9 +77,11 @@ def _c3(i, o, s=1):
 
 
 def _bn_hip(bn, x):
-    """BatchNorm with batch statistics on K19: training-mode module, fp32 GPU tensor, gradients enabled."""
-    return (ResNetFPN_8_2.hip_training and ops.USE_HIP_BATCHNORM_TRAIN and bn.training and x.is_cuda and x.dtype == torch.float32
-            and torch.is_grad_enabled())
+    """BatchNorm with batch statistics on K19: a plain nn.BatchNorm2d in training mode (NOT SyncBatchNorm -- the reference's multi-GPU
+    training converts the modules, train.py:342: their statistics span the ranks and stay with torch), fp32 GPU tensor, gradients
+    enabled."""
+    return (ResNetFPN_8_2.hip_training and ops.USE_HIP_BATCHNORM_TRAIN and type(bn) is nn.BatchNorm2d and bn.training and x.is_cuda
+            and x.dtype == torch.float32 and torch.is_grad_enabled())
 
 
 def _conv(conv, x, owner):

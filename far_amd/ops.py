@@ -896,7 +896,7 @@ def bn_act_train(x, bn, act='none', slope=0.01, residual=None):
     if not x.is_cuda:
         raise _lib.FarHipError('far_amd ops need tensors on the GPU (no CPU fallback exists)')
     C = x.shape[1]
-    if (not USE_HIP_BATCHNORM_TRAIN or not bn.training or bn.momentum is None or (C & 3) or C > 1024 or x.dtype != torch.float32
+    if (not USE_HIP_BATCHNORM_TRAIN or type(bn) is not torch.nn.BatchNorm2d or not bn.training or bn.momentum is None or (C & 3) or C > 1024 or x.dtype != torch.float32
             or x.numel() == 0 or (bn.weight is None) != (bn.bias is None)):
         y = bn(x)
         if residual is not None:

@@ -151,3 +151,16 @@ def test_g18_masked_coarse_matching_matches_reference(mode):
         np.testing.assert_allclose(f0.grad.norm().item(), float(g['train_df0_norm']), rtol=1e-4)
         np.testing.assert_allclose(f1.grad.norm().item(), float(g['train_df1_norm']), rtol=1e-4)
         np.testing.assert_allclose(f0.grad[:, ::53, ::17].numpy(), g['train_df0_sample'], rtol=1e-3, atol=1e-6)
+
+
+def test_sync_batchnorm_modules_are_not_taken_by_the_batch_statistics_kernel():
+    """The reference's multi-GPU training converts every BatchNorm2d to SyncBatchNorm (train.py:342): K19 computes LOCAL batch statistics
+    and must leave those modules to torch (the predicate is a plain type test, checked here without a GPU)."""
+    from far_amd.loftr import backbone as bb
+    x = torch.zeros(1, 4, 2, 2)
+    plain, sync = torch.nn.BatchNorm2d(4).train(), torch.nn.SyncBatchNorm(4).train()
+
+    class _Cuda:                      # the predicate only looks at is_cuda / dtype
+        is_cuda, dtype = True, torch.float32
+    assert bb._bn_hip(plain, _Cuda) and not bb._bn_hip(sync, _Cuda)
+    assert not bb._bn_hip(plain.eval(), _Cuda) and not bb._bn_hip(torch.nn.BatchNorm2d(4).train(), x)
