@@ -21,10 +21,6 @@ class AdamW(torch.optim.Optimizer):
 
     def _table(self, gi, group):
         ps = [p for p in group['params'] if p.requires_grad]
-        key = tuple((p.data_ptr(), p.numel()) for p in ps)
-        t = self._tables.get(gi)
-        if t is not None and t['key'] == key:
-            return t
         if not ps:
             return None
         dev = ps[0].device
@@ -36,6 +32,14 @@ class AdamW(torch.optim.Optimizer):
                 st['step'] = 0
                 st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            elif (st['exp_avg'].dtype != torch.float32 or not st['exp_avg'].is_contiguous() or st['exp_avg'].device != dev
+                  or not st['exp_avg_sq'].is_contiguous()):
+                raise _lib.FarHipError('far_amd.optim.AdamW: loaded moment tensors must be contiguous fp32 on the parameters\' GPU')
+        # the table holds raw pointers: rebuilt when a parameter or a moment tensor was replaced (load_state_dict, .to(), a new model)
+        key = tuple((p.data_ptr(), p.numel(), self.state[p]['exp_avg'].data_ptr(), self.state[p]['exp_avg_sq'].data_ptr()) for p in ps)
+        t = self._tables.get(gi)
+        if t is not None and t['key'] == key:
+            return t
         n = len(ps)
         rows = np.zeros((n, 5), dtype=np.int64)                              # {p, g, m, v, n}
         blocks = []
@@ -78,7 +82,7 @@ class AdamW(torch.optim.Optimizer):
                     raise _lib.FarHipError('far_amd.optim.AdamW needs dense contiguous fp32 gradients')
                 t['rows'][i, 1] = g.data_ptr()
                 st = self.state[p]
-                st['step'] += 1
+                st['step'] = int(st['step']) + 1          # (a state dict written by torch.optim.AdamW carries the step as a tensor)
                 steps.add(st['step'])
             if not steps:
                 continue

@@ -717,3 +717,15 @@ def test_adamw_one_launch_matches_torch_adamw():
                 want = ob.state[b][key]
                 torch.testing.assert_close(oa.state[a][key], want, rtol=2e-6, atol=2e-7 * float(want.abs().max()))
     assert torch.equal(pa[5], pb[5])
+    # a state dict written by torch.optim.AdamW loads (new moment tensors, the step as a tensor) and the next step still agrees
+    import copy
+    oa.load_state_dict(copy.deepcopy(ob.state_dict()))          # (load_state_dict does not copy tensors that already fit: no aliasing with ob)
+    for i, (a, b) in enumerate(zip(pa, pb)):
+        with torch.no_grad():
+            a.copy_(b)
+        if i != 5:
+            g = torch.randn_like(a)
+            a.grad, b.grad = g.clone(), g.clone()
+    oa.step(); ob.step()
+    for a, b in zip(pa, pb):
+        torch.testing.assert_close(a, b, rtol=2e-6, atol=1e-7)
