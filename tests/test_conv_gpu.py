@@ -680,3 +680,35 @@ def test_conv_winograd_beyond_2_gib():
     ref = F.conv2d(x[71:72, :64, :64].permute(0, 3, 1, 2).double(), w.double(), padding=1).permute(0, 2, 3, 1)[0, 1:-1, 1:-1]
     got = ops.conv3x3_wino(x[71:72, :64, :64].contiguous(), ops.PackedWino(w))[0, 1:-1, 1:-1]
     assert _rel(got, ref)[0] < 2e-6
+
+
+def test_conv_winograd_random_shapes_sweep():
+    """K17 over 30 random layer shapes (ragged 16 x 16 workgroup tiles, channel counts that are multiples of 4 only, last channel
+    blocks of every width incl. the HALF body's <= 32, single-pixel rows / columns): 2e-6 of max|ref| vs float64, with and without
+    residual, and bit-identical to the same layer on K9's contract (conv_nhwc under no_grad dispatches here)."""
+    ops = _ops()
+    rng = torch.Generator().manual_seed(2024)
+    g = torch.Generator(device='cuda').manual_seed(2024)
+    worst = 0.0
+    for it in range(30):
+        N = int(torch.randint(1, 4, (1,), generator=rng))
+        H = int(torch.randint(1, 70, (1,), generator=rng))
+        W = int(torch.randint(1, 70, (1,), generator=rng))
+        ci = 4 * int(torch.randint(1, 70, (1,), generator=rng))
+        co = 4 * int(torch.randint(1, 70, (1,), generator=rng))
+        x = torch.randn(N, H, W, ci, device='cuda', generator=g)
+        w = torch.randn(co, ci, 3, 3, device='cuda', generator=g) * (2.0 / (ci * 9)) ** 0.5
+        sc, sh = torch.rand(co, device='cuda', generator=g) + 0.5, torch.randn(co, device='cuda', generator=g) * 0.1
+        res = torch.randn(N, H, W, co, device='cuda', generator=g) if it % 2 else None
+        act = ('none', 'relu', 'leaky')[it % 3]
+        ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), padding=1).permute(0, 2, 3, 1) * sc.double() + sh.double()
+        if res is not None:
+            ref = ref + res.double()
+        ref = {'none': lambda t: t, 'relu': torch.relu, 'leaky': lambda t: F.leaky_relu(t, 0.01)}[act](ref)
+        y = ops.conv3x3_wino(x, ops.PackedWino(w, sc, sh), residual=res, act=act, slope=0.01)
+        e = _rel(y, ref)[0]
+        worst = max(worst, e)
+        assert e < 2e-6, (it, N, H, W, ci, co, act, e)
+        assert torch.isfinite(y).all()
+    print(f'[deviation] K17 random sweep: worst {worst:.2e} of max|ref| over 30 shapes')
+    assert not ops.activation_overflowed('cuda')
