@@ -1,5 +1,6 @@
-// K10: the backbone stem -- 7x7 stride-2 convolution of a 1-channel image + BatchNorm + ReLU -- on the exact-f32
-// matrix cores (v_mfma_f32_32x32x2_f32: bitwise an fmaf chain), writing NHWC for K9.
+// K10: the backbone stem -- 7x7 stride-2 convolution of a 1-channel image + BatchNorm + ReLU -- writing NHWC for K9 / K17.  The bare
+// convolution of the training forward runs on the exact-f32 matrix cores (v_mfma_f32_32x32x2_f32: bitwise an fmaf chain); the
+// inference form since round 4 on the f16 matrix cores with split-precision operands (k_stem_f16s below).
 //
 // Replaces mp3d_loftr/src/loftr/backbone/resnet_fpn.py:60-62   self.conv1 (7x7, stride 2, pad 3, no bias), bn1, relu
 //                                                     :103      x0 = self.relu(self.bn1(self.conv1(x)))
@@ -79,6 +80,124 @@ __global__ __launch_bounds__(256) void k_stem(const float* __restrict__ img, con
                     const int ox = ox0 + mfma32_row(r, h);
                     if (ox < Wo)
                         y[(((size_t)n * Ho + oy) * Wo + ox) * C + co] = PLAIN ? acc[nt][r] : fmaxf(acc[nt][r] * sc[nt] + sh[nt], 0.f);
+                }
+            }
+        }
+    }
+}
+
+// Round 4: the inference form (BatchNorm folded, ReLU) on the f16 matrix cores with split-precision operands, as K9 computes its
+// layers: K = 49 taps padded to 64 = four k-steps of v_mfma_f32_32x32x16_f16, every product as hi.hi + hi.lo + lo.hi with fp32
+// accumulation (fp32-grade; the exact-f32 instruction above retires 1/16 of the products per cycle and made the kernel run at the
+// SUM of its matrix time and its store time: 1.10 ms per 64 images, of which 0.5 ms matrix work).  Same tiling and patch; the pixel
+// values are scaled by 2^10 and the weights by a power of two taken from their maximum (2^13 <= max |w| 2^e < 2^14; every workgroup
+// derives the same e) so that the lo parts stay normal fp16 numbers; the weights' fragments are split once per workgroup into LDS
+// [k-step][channel tile][plane][lane][8].
+typedef _Float16 f16x8s __attribute__((ext_vector_type(8)));
+
+template <int NTILES>
+__global__ __launch_bounds__(256) void k_stem_f16s(const float* __restrict__ img, const float* __restrict__ w,
+                                                   const float* __restrict__ scale, const float* __restrict__ shift, int N,
+                                                   int H, int W, int Ho, int Wo, int tilesX, int tilesY, float* __restrict__ y) {
+    constexpr int C = 32 * NTILES;
+    __shared__ float patch[PH * PW];
+    __shared__ __attribute__((aligned(16))) _Float16 wf[4 * NTILES * 2 * 64 * 8];
+    __shared__ float wred[256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+    const int nby = (tilesY + YB - 1) / YB;
+    int t = blockIdx.x;
+    const int tx = t % tilesX;
+    t /= tilesX;
+    const int tyb = t % nby, n = t / nby;
+    const int ox0 = tx * SC;
+    const float* im = img + (size_t)n * H * W;
+    // max |w| -> power-of-two weight scale (identical in every workgroup: the same data, a max is order-independent)
+    float m = 0.f;
+    for (int i = tid; i < 49 * C; i += 256) m = fmaxf(m, fabsf(w[i]));
+    wred[tid] = m;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if (tid < d) wred[tid] = fmaxf(wred[tid], wred[tid + d]);
+        __syncthreads();
+    }
+    int ex = 0;
+    (void)frexpf(wred[0], &ex);                                    // max = f 2^ex, f in [0.5, 1)
+    const float wmul = wred[0] > 0.f ? ldexpf(1.0f, 14 - ex) : 1.0f;     // max |w| wmul in [2^13, 2^14)
+    const float outmul = 1.0f / (wmul * 1024.0f);
+    // weight fragments: item = (k-step s, tile nt, lane): 8 taps 16 s + 8 (lane >> 5) + e of channel 32 nt + (lane & 31)
+    for (int i = tid; i < 4 * NTILES * 64; i += 256) {
+        const int ln = i & 63, nt = (i >> 6) % NTILES, ks = i / (64 * NTILES);
+        const int co = 32 * nt + (ln & 31);
+        f16x8s vh, vl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int tap = 16 * ks + 8 * (ln >> 5) + e;
+            const float v = tap < 49 ? w[co * 49 + tap] * wmul : 0.f;
+            const _Float16 hh = (_Float16)v;
+            vh[e] = hh; vl[e] = (_Float16)(v - (float)hh);
+        }
+        _Float16* dst = wf + (size_t)((ks * NTILES + nt) * 2) * 512 + ln * 8;
+        *reinterpret_cast<f16x8s*>(dst) = vh;
+        *reinterpret_cast<f16x8s*>(dst + 512) = vl;
+    }
+    float sc[NTILES], sh[NTILES];
+#pragma unroll
+    for (int nt = 0; nt < NTILES; ++nt) { sc[nt] = scale[32 * nt + l31] * outmul; sh[nt] = shift[32 * nt + l31]; }
+    // patch offsets of this lane's 8 taps per k-step (tap >= 49: offset 0, value masked to zero)
+    int toff[4][8];
+    unsigned tmask = 0;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int tap = 16 * ks + 8 * h + e;
+            toff[ks][e] = tap < 49 ? (tap / 7) * PW + tap % 7 : 0;
+            if (tap < 49) tmask |= 1u << (8 * ks + e);
+        }
+    for (int ty = tyb * YB; ty < min(tilesY, (tyb + 1) * YB); ++ty) {
+        const int oy0 = ty * SR;
+        __syncthreads();                                       // the previous tile's patch is consumed (and wf is written)
+        for (int i = tid; i < PH * PW; i += 256) {
+            const int py = i / PW, px = i - py * PW;
+            const int iy = 2 * oy0 - 3 + py, ix = 2 * ox0 - 3 + px;
+            patch[i] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? im[(size_t)iy * W + ix] * 1024.0f : 0.f;
+        }
+        __syncthreads();
+        f32x16 acc[NTILES];
+#pragma unroll
+        for (int nt = 0; nt < NTILES; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+        const int abase = (2 * wave) * PW + 2 * l31;           // patch offset of this lane's output pixel (row wave, col l31)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            f16x8s ah, al;
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const float v0 = ((tmask >> (8 * ks + e)) & 1u) ? patch[abase + toff[ks][e]] : 0.f;
+                const float v1 = ((tmask >> (8 * ks + e + 1)) & 1u) ? patch[abase + toff[ks][e + 1]] : 0.f;
+                f16x2 hh, ll;
+                split2(f32x2{v0, v1}, hh, ll);
+                ah[e] = hh.x; ah[e + 1] = hh.y; al[e] = ll.x; al[e + 1] = ll.y;
+            }
+#pragma unroll
+            for (int nt = 0; nt < NTILES; ++nt) {
+                const _Float16* src = wf + (size_t)((ks * NTILES + nt) * 2) * 512 + lane * 8;
+                const f16x8s bh = *reinterpret_cast<const f16x8s*>(src), bl = *reinterpret_cast<const f16x8s*>(src + 512);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[nt], 0, 0, 0);
+            }
+        }
+        const int oy = oy0 + wave;
+        if (oy < Ho) {
+#pragma unroll
+            for (int nt = 0; nt < NTILES; ++nt) {
+                const int co = 32 * nt + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ox = ox0 + mfma32_row(r, h);
+                    if (ox < Wo) y[(((size_t)n * Ho + oy) * Wo + ox) * C + co] = fmaxf(acc[nt][r] * sc[nt] + sh[nt], 0.f);
                 }
             }
         }
@@ -199,9 +318,11 @@ int far_stem7x7_nhwc_f32(const float* img, const float* w, const float* scale, c
     const bool plain = !scale && !shift;
     if (Cout == 128) {
         if (plain) hipLaunchKernelGGL((k_stem<4, true>), dim3((unsigned)nb), dim3(256), 0, stream, img, w, scale, shift, N, H, W, Ho, Wo, tilesX, tilesY, y);
+        else if (far_get_tuning(12) == 0) hipLaunchKernelGGL((k_stem_f16s<4>), dim3((unsigned)nb), dim3(256), 0, stream, img, w, scale, shift, N, H, W, Ho, Wo, tilesX, tilesY, y);
         else hipLaunchKernelGGL((k_stem<4, false>), dim3((unsigned)nb), dim3(256), 0, stream, img, w, scale, shift, N, H, W, Ho, Wo, tilesX, tilesY, y);
     } else {
         if (plain) hipLaunchKernelGGL((k_stem<2, true>), dim3((unsigned)nb), dim3(256), 0, stream, img, w, scale, shift, N, H, W, Ho, Wo, tilesX, tilesY, y);
+        else if (far_get_tuning(12) == 0) hipLaunchKernelGGL((k_stem_f16s<2>), dim3((unsigned)nb), dim3(256), 0, stream, img, w, scale, shift, N, H, W, Ho, Wo, tilesX, tilesY, y);
         else hipLaunchKernelGGL((k_stem<2, false>), dim3((unsigned)nb), dim3(256), 0, stream, img, w, scale, shift, N, H, W, Ho, Wo, tilesX, tilesY, y);
     }
     return far_check_launch();
