@@ -197,7 +197,10 @@ __global__ __launch_bounds__(256) void k_stem_f16s(const float* __restrict__ img
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ox = ox0 + mfma32_row(r, h);
-                    if (ox < Wo) y[(((size_t)n * Ho + oy) * Wo + ox) * C + co] = fmaxf(acc[nt][r] * sc[nt] + sh[nt], 0.f);
+                    // ReLU that keeps NaN (an inf / NaN pixel turns into NaN in the split; fmaxf(NaN, 0) = 0 would hide it from the
+                    // activation-range flag of the layers behind: a non-finite image must stay loud)
+                    const float v = acc[nt][r] * sc[nt] + sh[nt];
+                    if (ox < Wo) y[(((size_t)n * Ho + oy) * Wo + ox) * C + co] = v < 0.f ? 0.f : v;
                 }
             }
         }
