@@ -90,10 +90,12 @@ __global__ __launch_bounds__(256) void k_stem(const float* __restrict__ img, con
 // layers: K = 49 taps padded to 64 = four k-steps of v_mfma_f32_32x32x16_f16, every product as hi.hi + hi.lo + lo.hi with fp32
 // accumulation (fp32-grade; the exact-f32 instruction above retires 1/16 of the products per cycle and made the kernel run at the
 // SUM of its matrix time and its store time: 1.10 ms per 64 images, of which 0.5 ms matrix work).  Same tiling and patch; the pixel
-// values are scaled by 2^10 and the weights by a power of two taken from their maximum (2^13 <= max |w| 2^e < 2^14; every workgroup
+// values are scaled by 2^4 and the weights by a power of two taken from their maximum (2^13 <= max |w| 2^e < 2^14; every workgroup
 // derives the same e) so that the lo parts stay normal fp16 numbers; the weights' fragments are split once per workgroup into LDS
 // [k-step][channel tile][plane][lane][8].
 typedef _Float16 f16x8s __attribute__((ext_vector_type(8)));
+constexpr float PIX_SCALE = 16.0f;      // as K9's default activation scale: |pixel| <= 4094 (images in 0..1 or 0..255); a darker pixel's lo part may be a
+                                        // subnormal fp16 number: absolute error <= 2^-29 of unit scale, below fp32 resolution of the 49-term sum
 
 template <int NTILES>
 __global__ __launch_bounds__(256) void k_stem_f16s(const float* __restrict__ img, const float* __restrict__ w,
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(256) void k_stem_f16s(const float* __restrict__ img
     int ex = 0;
     (void)frexpf(wred[0], &ex);                                    // max = f 2^ex, f in [0.5, 1)
     const float wmul = wred[0] > 0.f ? ldexpf(1.0f, 14 - ex) : 1.0f;     // max |w| wmul in [2^13, 2^14)
-    const float outmul = 1.0f / (wmul * 1024.0f);
+    const float outmul = 1.0f / (wmul * PIX_SCALE);
     // weight fragments: item = (k-step s, tile nt, lane): 8 taps 16 s + 8 (lane >> 5) + e of channel 32 nt + (lane & 31)
     for (int i = tid; i < 4 * NTILES * 64; i += 256) {
         const int ln = i & 63, nt = (i >> 6) % NTILES, ks = i / (64 * NTILES);
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(256) void k_stem_f16s(const float* __restrict__ img
         for (int i = tid; i < PH * PW; i += 256) {
             const int py = i / PW, px = i - py * PW;
             const int iy = 2 * oy0 - 3 + py, ix = 2 * ox0 - 3 + px;
-            patch[i] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? im[(size_t)iy * W + ix] * 1024.0f : 0.f;
+            patch[i] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? im[(size_t)iy * W + ix] * PIX_SCALE : 0.f;
         }
         __syncthreads();
         f32x16 acc[NTILES];

@@ -218,6 +218,15 @@ def test_stem_matches_float64(N, H, W, Cout):
     assert y.shape == ref.shape
     emax, erms = _rel(y, ref)
     assert emax < 2e-6 and erms < 5e-7, (emax, erms)
+    # round 4 (split-fp16 inference form): images in 0..255 and very dark images keep the accuracy; a non-finite pixel stays visible
+    for amp in (255.0, 1e-3):
+        ya = ops.stem7x7(img * amp, w, scale, shift)
+        ra = torch.relu(F.conv2d((img * amp).double(), w.double(), stride=2, padding=3) * scale.double()[None, :, None, None]
+                        + shift.double()[None, :, None, None]).permute(0, 2, 3, 1)
+        assert _rel(ya, ra)[0] < 2e-6, (amp, _rel(ya, ra))
+    bad = img.clone()
+    bad[0, 0, H // 2, W // 2] = float('inf')
+    assert not torch.isfinite(ops.stem7x7(bad, w, scale, shift)).all()
 
 
 @pytest.mark.parametrize('H,W', [(96, 128), (136, 184), (64, 96)])      # whole tiles; ragged tiles at every level (BASELINE C5 is 544x720); a level narrower than 32 (merge through K8)
