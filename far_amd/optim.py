@@ -71,7 +71,10 @@ class AdamW(torch.optim.Optimizer):
             t = self._table(gi, group)
             if t is None:
                 continue
-            # the gradient pointers change whenever autograd re-allocates them (zero_grad(set_to_none=True)): refresh that column
+            # the gradient pointers change whenever autograd re-allocates them (zero_grad(set_to_none=True)): refresh that column --
+            # after the previous step's upload has left the pinned buffer (nothing else orders the host against it)
+            if t.get('uploaded') is not None:
+                t['uploaded'].synchronize()
             steps = set()
             for i, p in enumerate(t['params']):
                 g = p.grad
@@ -92,6 +95,9 @@ class AdamW(torch.optim.Optimizer):
             k = steps.pop()
             n = t['n']
             t['dev'][:n * 40].copy_(t['host'][:n * 40], non_blocking=True)
+            if t.get('uploaded') is None:
+                t['uploaded'] = torch.cuda.Event()
+            t['uploaded'].record(torch.cuda.current_stream(t['dev'].device))
             b1, b2 = group['betas']
             rc = lib.far_adamw_step_f32(ctypes.c_void_p(t['dev'].data_ptr()), n, t['nblocks'], float(group['lr']), float(b1), float(b2),
                                         float(group['eps']), float(group['weight_decay']), 1.0 - b1 ** k, math.sqrt(1.0 - b2 ** k),
