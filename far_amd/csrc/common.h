@@ -14,12 +14,23 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-// The fp16 (hi, lo) split of two values at once: hi = fp16(x), lo = fp16(x - hi), round to nearest -- the same arithmetic
-// as the scalar split, on the packed instructions of gfx950 (v_cvt_pk_f16_f32, v_pk_add_f32): 5 instructions per pair
-// instead of 8.
+// The fp16 (hi, lo) split of two values at once: hi = fp16(x), lo = fp16(x - hi), round to nearest.  Round 3: the packed instructions
+// of gfx950 (v_cvt_pk_f16_f32, v_cvt_f32_f16 x2, v_pk_add_f32, v_cvt_pk_f16_f32: 5 per pair instead of the 8 scalar ones); round 4:
+// v_cvt_pk_f16_f32 + one v_fma_mix per lo half (3 per pair) -- the same bits (K17 found and measured it first: 3.00 vs 3.12 ms;
+// the whole step 93.35 -> 93.05 ms, the training step 38.0 -> 37.7 ms).  -DFAR_SPLIT2_PACKED selects the round-3 form.
 __device__ __forceinline__ void split2(f32x2 x, f16x2& hi, f16x2& lo) {
     hi = __builtin_convertvector(x, f16x2);
+#ifdef FAR_SPLIT2_PACKED
     lo = __builtin_convertvector(x - __builtin_convertvector(hi, f32x2), f16x2);
+#else
+    // round 4: one v_fma_mix per lo half -- the fp16 operand is widened, subtracted from x in fp32 (exactly) and the result rounded to
+    // fp16 by the same instruction: the same bits as the packed form above in 3 instructions per pair instead of 5
+    const unsigned h = __builtin_bit_cast(unsigned, hi);
+    unsigned l;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(x.x));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(x.y));
+    lo = __builtin_bit_cast(f16x2, l);
+#endif
 }
 
 // Row index inside a 32x32 MFMA accumulator tile for accumulator register `r` (0..15) of a lane
