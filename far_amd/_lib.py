@@ -60,6 +60,7 @@ SIGNATURES = {
     'far_upsample2x_bwd_f32': (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
     'far_adamw_table_bytes': (c_l, [c_i, c_l]),
     'far_adamw_step_f32': (c_i, [c_p, c_i, c_l] + [ctypes.c_double] * 7 + [c_p]),
+    'far_prior_from_pose_f32': (c_i, [c_p, c_p, c_p, c_i, c_p, c_p]),
     'far_bn_train_ws_bytes': (c_l, [c_l, c_i]),
     'far_bn_act_train_fwd_f32': (c_i, [c_p, c_p, c_l, c_i, c_p, c_p, c_f, c_f, c_p, c_p, c_i, c_f, c_p, c_p, c_p, c_l, c_p]),
     'far_bn_train_stats_f32': (c_i, [c_p, c_l, c_i, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_p]),

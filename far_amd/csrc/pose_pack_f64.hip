@@ -90,7 +90,39 @@ __global__ void k_pose_features(const double* __restrict__ rt, int B, const void
 
 }  // namespace
 
+// prior [B][3][4] = [ rotation_6d_to_matrix(pose[3:9] std[3:9] + mean[3:9]) | pose[0:3] std[0:3] + mean[0:3] ]: the head's regressed
+// pose as the next solver round's prior (loftr.py:186-192).  Gram-Schmidt as far_amd/pose6d.py does it with torch ops (F.normalize:
+// x / max(|x|, 1e-12); b2 from a2 - (b1 . a2) b1; b3 = b1 x b2), in fp32.
+__global__ void k_prior_from_pose(const float* __restrict__ pose, const float* __restrict__ mean, const float* __restrict__ stdv, int B,
+                                  float* __restrict__ prior) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float v[9];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) v[e] = pose[b * 9 + e] * stdv[e] + mean[e];
+    const float n1 = fmaxf(sqrtf(v[3] * v[3] + v[4] * v[4] + v[5] * v[5]), 1e-12f);
+    const float b1[3] = {v[3] / n1, v[4] / n1, v[5] / n1};
+    const float d = b1[0] * v[6] + b1[1] * v[7] + b1[2] * v[8];
+    const float c[3] = {v[6] - d * b1[0], v[7] - d * b1[1], v[8] - d * b1[2]};
+    const float n2 = fmaxf(sqrtf(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]), 1e-12f);
+    const float b2[3] = {c[0] / n2, c[1] / n2, c[2] / n2};
+    const float b3[3] = {b1[1] * b2[2] - b1[2] * b2[1], b1[2] * b2[0] - b1[0] * b2[2], b1[0] * b2[1] - b1[1] * b2[0]};
+    float* o = prior + b * 12;
+    o[0] = b1[0]; o[1] = b1[1]; o[2] = b1[2]; o[3] = v[0];
+    o[4] = b2[0]; o[5] = b2[1]; o[6] = b2[2]; o[7] = v[1];
+    o[8] = b3[0]; o[9] = b3[1]; o[10] = b3[2]; o[11] = v[2];
+}
+
 extern "C" {
+
+// pose [B][9] fp32 (normalised [t | 6D rotation]), mean / std [9] fp32 on the device -> prior [B][12] fp32 = [R | t] rows.
+int far_prior_from_pose_f32(const float* pose, const float* mean, const float* stdv, int B, float* prior, hipStream_t stream) {
+    far_clear_errors();
+    if (B == 0) return FAR_OK;
+    if (B < 0 || !pose || !mean || !stdv || !prior) return FAR_EINVAL;
+    hipLaunchKernelGGL(k_prior_from_pose, dim3((B + 63) / 64), dim3(64), 0, stream, pose, mean, stdv, B, prior);
+    return far_check_launch();
+}
 
 // R, E [B][9], t [B][3] float64 and status / num_after / tight / ultra [B] int32 as far_solver_f64 leaves them;
 // offsets [B+1] int32 (the solver's correspondence offsets).  Outputs: rt_out [B][12] = [R | t] row-major 3x4

@@ -236,9 +236,7 @@ class LoFTR(nn.Module):
             p = pose.detach().float()
             if p.is_cuda:
                 mean, std = _pose_stats(p.device)
-                R = rotation_6d_to_matrix(p[:, 3:] * std[3:] + mean[3:])
-                t = p[:, :3] * std[:3] + mean[:3]
-                prior_dev = torch.cat([R, t[:, :, None]], dim=-1).contiguous()    # (B, 3, 4)
+                prior_dev = ops.prior_from_pose(p, mean, std)                       # (B, 3, 4): one launch (K11)
                 host = torch.empty(prior_dev.shape, dtype=torch.float32, pin_memory=True)
                 host.copy_(prior_dev, non_blocking=True)
                 prior = host.numpy()

@@ -671,6 +671,19 @@ def solve_pose_batch(kpts0, kpts1, offsets_host, K0, K1, inl_th, many_thr, prior
     return out
 
 
+def prior_from_pose(pose, mean, std):
+    """K11c.  pose (B, 9) fp32 GPU (normalised [t | 6D rotation]), mean / std (9,) fp32 GPU -> (B, 3, 4) fp32 [R | t]: the head's pose as the
+    next solver round's prior (loftr.py:186-192) in one launch."""
+    lib = _lib.load()
+    pose = pose.detach().float().contiguous()
+    B = pose.shape[0]
+    out = torch.empty(B, 3, 4, dtype=torch.float32, device=pose.device)
+    rc = lib.far_prior_from_pose_f32(_p(pose, torch.float32), _p(mean.contiguous(), torch.float32), _p(std.contiguous(), torch.float32), B,
+                                     _p(out), _stream())
+    _lib.check(rc, 'far_prior_from_pose_f32')
+    return out
+
+
 def pose_pack(sol, offsets_dev):
     """K11a.  The solver's result dict -> the data-dict tensors of spvs_RT (supervision.py:218-233) in one launch:
     rt (B, 3, 4) and E (B, 3, 3) float64 with the identity fallback, before (B,) int64, after / tight / ultra (B,) int32

@@ -529,6 +529,9 @@ int far_pose_pack_f64(const double* R, const double* t, const double* E, const i
 int far_pose_features_f32(const double* rt, int B, const void* cnt0, int elem_bytes0, const void* cnt1, int elem_bytes1,
                           const void* cnt2, int elem_bytes2, const void* cnt3, int elem_bytes3, float* preds,
                           float* inv_preds, far_stream_t stream);
+/* The head's regressed pose as the next solver round's prior (loftr.py:186-192): pose [B][9] fp32 (normalised [t | 6D rotation]),
+ * mean / std [9] fp32 (device) -> prior [B][3][4] fp32 = [ rotation_6d_to_matrix(pose[3:9] std + mean) | pose[0:3] std + mean ]. */
+int far_prior_from_pose_f32(const float* pose, const float* mean, const float* stdv, int B, float* prior, far_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * K15  the small dense layers of the regression head, row-independent and in exact fp32 (fixed summation order)

@@ -382,3 +382,24 @@ def test_planar_scenes_eight_point_vs_five_point():
                   f'translation-direction error median {np.median(te):.2f} max {np.max(te):.2f} deg')
             if minimal == 5 and kind != 'plane':        # (a two-plane scene whose second plane holds a handful of points stays hard)
                 assert got['status'].all() and np.median(Re) < 0.5 and np.median(te) < 2.5 and np.mean(np.array(te) < 6.0) > 0.85
+
+
+def test_prior_from_pose_matches_the_torch_formula():
+    """K11c: the head's normalised 9-vector -> [R | t] prior (loftr.py:186-192) in one launch, against far_amd.pose6d's torch ops
+    (rotation_6d_to_matrix after de-normalisation) in float64; R orthonormal; a degenerate 6D vector does not produce NaN."""
+    from far_amd import ops
+    from far_amd.pose6d import pose_mean_6d, pose_std_6d, rotation_6d_to_matrix
+    g = torch.Generator(device='cuda').manual_seed(4)
+    p = torch.randn(37, 9, device='cuda', generator=g) * 2.0
+    mean, std = pose_mean_6d.cuda(), pose_std_6d.cuda()
+    got = ops.prior_from_pose(p, mean, std)
+    pd = p.double().cpu()
+    R = rotation_6d_to_matrix(pd[:, 3:] * pose_std_6d[3:].double() + pose_mean_6d[3:].double())
+    t = pd[:, :3] * pose_std_6d[:3].double() + pose_mean_6d[:3].double()
+    ref = torch.cat([R, t[:, :, None]], -1)
+    assert float((got.double().cpu() - ref).abs().max()) < 2e-6
+    RtR = got[:, :, :3] @ got[:, :, :3].transpose(1, 2)
+    assert float((RtR - torch.eye(3, device='cuda')).abs().max()) < 1e-5
+    z = torch.zeros(1, 9, device='cuda')
+    z[0, 3:] = -(mean[3:] / std[3:])                      # de-normalises to the zero 6D vector
+    assert torch.isfinite(ops.prior_from_pose(z, mean, std)).all()
