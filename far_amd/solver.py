@@ -37,22 +37,38 @@ def _branch(solver, has_prior):
     return 'ransac'
 
 
-def estimate_pose_batch(kpts0, kpts1, counts, K0, K1, thresh, solver='ransac', priorRT=None, H=2048, seed=0, minimal=8):
+def estimate_pose_batch(kpts0, kpts1, counts, K0, K1, thresh, solver='ransac', priorRT=None, H=2048, seed=0, minimal=8, cache=None):
     """kpts0/kpts1: (Mtot, 2) fp32 GPU, concatenated per pair in order; counts: per-pair M (host ints);
-    K0/K1: (B, 3, 3); priorRT: None or (B, 3, 4) numpy/tensor.  Returns the dict of ops.solve_pose_batch."""
+    K0/K1: (B, 3, 3); priorRT: None or (B, 3, 4) numpy/tensor.  Returns the dict of ops.solve_pose_batch.
+    cache: a dict living as long as the batch (the data dict's): the float64 intrinsics and the inlier thresholds of one solver round are
+    reused by the next (they are a handful of tiny launches each, in a stretch of the step where the host is the bottleneck)."""
     dev = kpts0.device
     counts = [int(c) for c in counts]
     offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
-    K0d = K0.to(device=dev, dtype=torch.float64)
-    K1d = K1.to(device=dev, dtype=torch.float64)
     mode = _branch(solver, priorRT is not None)
     many = mode != 'ransac'
-    if many:
-        inl_th = torch.full((len(counts),), 3e-7, dtype=torch.float64, device=dev)            # metrics.py:117
+    tens = torch.is_tensor(K0) and torch.is_tensor(K1)
+    kkey = ('K', K0.data_ptr(), K1.data_ptr(), tuple(K0.shape), str(dev)) if (cache is not None and tens) else None
+    if kkey is not None and kkey in cache:
+        K0d, K1d = cache[kkey]
     else:
-        # metrics.py:94 -- note the reference averages K0[0,0], K1[1,1] twice
-        f = (K0d[:, 0, 0] + K1d[:, 1, 1] + K0d[:, 0, 0] + K1d[:, 1, 1]) / 4
-        inl_th = (thresh / f) ** 2
+        K0d = K0.to(device=dev, dtype=torch.float64)
+        K1d = K1.to(device=dev, dtype=torch.float64)
+        if kkey is not None:
+            cache[kkey] = (K0d, K1d)
+    tkey = ('th', kkey, float(thresh), many, len(counts)) if kkey is not None else None
+    if tkey is not None and tkey in cache:
+        inl_th = cache[tkey]
+    else:
+        if many:
+            inl_th = torch.full((len(counts),), 3e-7, dtype=torch.float64, device=dev)            # metrics.py:117
+        else:
+            # metrics.py:94 -- note the reference averages K0[0,0], K1[1,1] twice
+            f = (K0d[:, 0, 0] + K1d[:, 1, 1] + K0d[:, 0, 0] + K1d[:, 1, 1]) / 4
+            inl_th = (thresh / f) ** 2
+        inl_th = inl_th.contiguous()
+        if tkey is not None:
+            cache[tkey] = inl_th
     prior = pcl = None
     if mode == 'prior':
         if torch.is_tensor(priorRT) and priorRT.is_cuda:          # the head's prior, still on the device (no round trip through the host)

@@ -45,7 +45,7 @@ def spvs_RT(data, config, H=2048, seed=0):
             mk0, mk1 = mk0[order], mk1[order]
     assert sum(counts) == M
     out = estimate_pose_batch(mk0, mk1, counts, K0, K1, pixel_thr, solver, prior, H=H, seed=seed,
-                              minimal=getattr(config.LOFTR, 'MINIMAL_SOLVER', 8))
+                              minimal=getattr(config.LOFTR, 'MINIMAL_SOLVER', 8), cache=data.setdefault('_solver_cache', {}))
     if order is not None:                                  # the mask back in the order the caller's matches are in
         mask = torch.empty_like(out['mask'])
         mask[order] = out['mask']
