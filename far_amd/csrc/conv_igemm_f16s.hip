@@ -99,6 +99,8 @@ struct ConvArgs {
     float out_mul;               // 2^(4 - act_exp): `scale` folds 2^-4, this corrects it for the scale actually used
     int* overflow;               // device flag, |= 1 when an accumulator of this launch is not finite (may be null)
     const float* scale_dev;      // device { act_scale, out_mul } overriding the two fields above (may be null)
+    float* kv_part;              // far_linear_kv_f16s (the KVE instantiations): the columns are the k | v projections of a LoFTR
+    int kv_by0, kv_S, kv_nslot;  // layer, head-interleaved, and the epilogue is la_kv_epilogue (K'^T V partial sums), not a store
 };
 
 __device__ __forceinline__ void split8(const float4& u, const float4& v, float act_scale, f16x8& hi, f16x8& lo) {
@@ -528,13 +530,128 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvArgs& p, const f32x
     }
 }
 
+// ---- The K'^T V state of LinearAttention (linear_attention.py:38-45) straight from the accumulators of the k | v projection
+// (far_linear_kv_f16s): k and v never reach HBM.  The packed weight holds the two projections head by head -- columns
+// 64 j + [0, 32) = k of head j, 64 j + [32, 64) = v of head j -- so a wave's four 32-column tiles are (k, v) of two heads for its
+// 64 rows, and an accumulator register holds ONE row for the lane's channel in both.  Eight registers of a lane (with the
+// eight of its lane + 32 twin: 16 rows) therefore ARE an MFMA operand [channel][k = row] of
+//     KV[d][v] += K'[row][d] * V[row][v]           (x 1 / S at the end: linear_attention.py:43 divides V first, same value to an ulp)
+// -- A from the k tile, B from the v tile, no data movement; products as everywhere: hi * hi + hi * lo + lo * hi of fp16 pairs
+// (operands x act_scale like the activations of the main loop: the same range, the same overflow flag).  ksum[d] = sum of K' is an
+// in-lane sum.  One partial sum per 64-row block of the launch (the rows of a wave), written to part[block][slot][H D][D + 1]
+// (slot 1: the rows behind an image boundary inside the block, only when S % 64 != 0); k_kv_blocks_reduce adds the blocks of an
+// image in block order: deterministic, no atomics, and at S % 64 == 0 independent of how many images share the launch.
+// F.elu(x) + 1 = x + 1 (x > 0), e^x otherwise, as 2^(x log2 e) on the hardware exponential: the rounding of the argument costs
+// |x| e^x 2^-24 <= 2^-25 in absolute terms (half an ulp of 1.0, the size of a K'), where expm1f(x) + 1 rounds twice and, like expf,
+// costs a dozen instructions per value (64 feature maps per lane in this epilogue: measured 349 -> 330 us per launch).
+__device__ __forceinline__ float la_elu1(float x) { return x > 0.f ? x + 1.f : __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+
+template <bool FULL>
+__device__ __forceinline__ void la_kv_pass(const ConvArgs& p, const f32x16 (&acc)[2][4], const float (&sc)[4], const float (&sh)[4],
+                                           int lo, int hi, int pass, long blk, int head0, int HD, int l31, int h, float act_scale) {
+    const float unscale = 1.0f / (act_scale * act_scale), fS = (float)p.kv_S;
+#pragma unroll
+    for (int hd = 0; hd < 2; ++hd) {
+        f32x16 kv;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) kv[r] = 0.f;
+        float ks = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                float ka[8], vb[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int r = 8 * g + i;
+                    ka[i] = la_elu1(acc[mt][2 * hd][r] * sc[2 * hd] + sh[2 * hd]);
+                    vb[i] = acc[mt][2 * hd + 1][r] * sc[2 * hd + 1] + sh[2 * hd + 1];
+                    if (!FULL) {
+                        const int q = 32 * mt + 16 * (r >> 3) + (r & 3) + 8 * ((r >> 2) & 1) + 4 * h;          // row of the wave
+                        const bool in = q >= lo && q < hi;
+                        ka[i] = in ? ka[i] : 0.f;
+                        vb[i] = in ? vb[i] : 0.f;
+                    }
+                    ks += ka[i];
+                }
+                f16x8 ah, al, bh, bl;
+                split8(make_float4(ka[0], ka[1], ka[2], ka[3]), make_float4(ka[4], ka[5], ka[6], ka[7]), act_scale, ah, al);
+                split8(make_float4(vb[0], vb[1], vb[2], vb[3]), make_float4(vb[4], vb[5], vb[6], vb[7]), act_scale, bh, bl);
+                kv = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, kv, 0, 0, 0);
+                kv = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, kv, 0, 0, 0);
+                kv = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, kv, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);       // one 16-row group at a time: hoisting all feature maps spills
+            }
+        ks += shfl_xor_f(ks, 32);
+        if (p.overflow) {                                  // a K' or V beyond the split's range (as the main loop's guard)
+            float chk = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) chk += kv[r];
+            if (__any(!(fabsf(chk) <= FLT_MAX)) && (l31 | h) == 0) atomicOr(p.overflow, 1);
+        }
+        float* o = p.kv_part + (((size_t)blk * p.kv_nslot + pass) * HD + (head0 + hd) * 32) * 33;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + 4 * h) * 33 + l31] = (kv[r] * unscale) / fS;
+        if (h == 0) o[l31 * 33 + 32] = ks;
+    }
+}
+
+__device__ __forceinline__ void la_kv_epilogue(const ConvArgs& p, const f32x16 (&acc)[2][4], long pixw, int cout_w, int lane,
+                                               float act_scale) {
+    const int l31 = lane & 31, h = lane >> 5;
+    const long leftl = p.npix - pixw;
+    if (leftl <= 0) return;
+    const int left = leftl > 64 ? 64 : (int)leftl;
+    const int S = p.kv_S;
+    const long img = pixw / S;
+    const long bl = (img + 1) * S - pixw;                // rows [0, b) of the wave belong to image `img`
+    const int b = bl > 64 ? 64 : (int)bl;
+    const int HD = p.Cout >> 1, head0 = cout_w >> 6;
+    float sc[4], sh[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int co = cout_w + 32 * nt + l31;
+        sc[nt] = p.scale[co] * p.out_mul;
+        sh[nt] = p.shift ? p.shift[co] : 0.f;
+    }
+    const long blk = pixw >> 6;
+    if (b == 64 && left == 64) {                           // wave-uniform: 64 rows of one image (always, when S % 64 == 0)
+        la_kv_pass<true>(p, acc, sc, sh, 0, 64, 0, blk, head0, HD, l31, h, act_scale);
+        return;
+    }
+    const int hi0 = b < left ? b : left;
+    la_kv_pass<false>(p, acc, sc, sh, 0, hi0, 0, blk, head0, HD, l31, h, act_scale);
+    if (left > b) la_kv_pass<false>(p, acc, sc, sh, b, left, 1, blk, head0, HD, l31, h, act_scale);
+}
+
+// kv[n][HD][33] = the partial sums of image n's 64-row blocks, in block order.  Block g's slot 0 holds the rows of the image its
+// first row belongs to, slot 1 (nslot = 2) the rows of the next image.
+__global__ __launch_bounds__(256) void k_kv_blocks_reduce(const float* __restrict__ part, int S, int nslot, int per,
+                                                          float* __restrict__ kv) {
+    const int n = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= per) return;
+    const long g0 = ((long)n * S) >> 6, g1 = ((long)(n + 1) * S - 1) >> 6;
+    float s = 0.f;
+    if (nslot == 1) {                                      // S % 64 == 0: every block belongs to one image
+        const float* src = part + (size_t)g0 * per + e;
+#pragma unroll 8
+        for (long g = g0; g <= g1; ++g, src += per) s += *src;
+    } else {
+        for (long g = g0; g <= g1; ++g) {
+            const int slot = ((g << 6) / S == n) ? 0 : 1;
+            s += part[((size_t)g * nslot + slot) * per + e];
+        }
+    }
+    kv[(size_t)n * per + e] = s;
+}
+
 // Workgroup = MW x NW waves: wave (wm, wn) owns 64 pixels (4 tile rows x 16) x 32 NTW output channels.
 // N7 (2 x 2 wave layout, 192 < Cout <= 224, e.g. the 196-channel layers): the workgroup covers SEVEN 32-channel tiles
 // instead of eight.  Wave column wn = 0 owns tiles 0..3, wn = 1 tiles 3..6; the shared tile 3 is computed by wn = 0 for its
 // first 32-pixel tile (mt = 0) and by wn = 1 for its second (mt = 1), so that every wave issues 7 of the 8 MFMA triples of a
 // k-step: 12.5 % fewer MFMAs, evenly over the four SIMDs (dropping the all-padding eighth tile from the wn = 1 waves alone
 // leaves the SIMDs of the wn = 0 waves as the bottleneck: measured in round 1, -2 %).
-template <int KS, int MW, int NW, int NTW, bool SPLIT, int ST, bool UP, bool N7, int WN>
+template <int KS, int MW, int NW, int NTW, bool SPLIT, int ST, bool UP, bool N7, int WN, bool KVE = false>
 __device__ __forceinline__ void conv_body(const ConvArgs& p) {
     using G = Geo<KS, MW, ST>;
     constexpr int NTHR = 64 * MW * NW;
@@ -785,6 +902,11 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p) {
 #endif
     ConvArgs pe = p;                 // the epilogues read the output multiplier from their argument block
     pe.out_mul = out_mul;
+    if constexpr (KVE) {
+        static_assert(KS == 1 && NW == 2 && NTW == 4 && !UP && !N7, "the K'^T V epilogue is a mode of the 256-column Linear tiles");
+        la_kv_epilogue(pe, acc, tp.pix0 + 64 * wm, cout_w, lane, act_scale);      // every column block holds k | v (kv_by0 = 0)
+        return;
+    }
     if (NTW == 4 && ((p.Cout | p.Csub) & 3) == 0) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave is past its last LDS fragment read
         // N7: channels 96..127 of the workgroup (the shared tile) are stored by wn = 0 for mt = 0 and by wn = 1 for mt = 1
@@ -806,13 +928,13 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p) {
 #endif
 }
 
-template <int KS, int MW, int NW, int NTW, bool SPLIT, int ST, bool UP = false, bool N7 = false>
+template <int KS, int MW, int NW, int NTW, bool SPLIT, int ST, bool UP = false, bool N7 = false, bool KVE = false>
 __global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const ConvArgs p) {
     if constexpr (N7) {                       // two copies of the body, one per wave column: which tile a wave skips is static
         if (((threadIdx.x >> 6) % NW) == 1) conv_body<KS, MW, NW, NTW, SPLIT, ST, UP, N7, 1>(p);
         else conv_body<KS, MW, NW, NTW, SPLIT, ST, UP, N7, 0>(p);
     } else {
-        conv_body<KS, MW, NW, NTW, SPLIT, ST, UP, N7, 0>(p);
+        conv_body<KS, MW, NW, NTW, SPLIT, ST, UP, N7, 0, KVE>(p);
     }
 }
 
@@ -1073,7 +1195,7 @@ inline TileCfg cfg_for(int Cout, int stride) {
     return (stride == 1 && pad128 < pad256) ? TileCfg{4, 1, 128} : TileCfg{2, 2, 256};
 }
 
-template <int KS, int MW, int NW, int NTW, bool SPLIT, int ST = 1, bool UP = false, bool N7 = false>
+template <int KS, int MW, int NW, int NTW, bool SPLIT, int ST = 1, bool UP = false, bool N7 = false, bool KVE = false>
 int launch_conv(const ConvArgs& a, dim3 grid, hipStream_t stream) {
     using G = Geo<KS, MW, ST>;
     constexpr int PLANES = SPLIT ? 2 : 1;
@@ -1081,10 +1203,10 @@ int launch_conv(const ConvArgs& a, dim3 grid, hipStream_t stream) {
     constexpr int smem_epi = MW * NW * (32 * 128 * 4 + 32 * 4);  // conv_epilogue_wide: 16 KiB per wave + LayerNorm exchange
     constexpr int smem = smem_loop > smem_epi ? smem_loop : smem_epi;
     bool cfg_failed = false;
-    FAR_ONCE_PER_DEVICE(cfg_failed = hipFuncSetAttribute((const void*)k_conv<KS, MW, NW, NTW, SPLIT, ST, UP, N7>,
+    FAR_ONCE_PER_DEVICE(cfg_failed = hipFuncSetAttribute((const void*)k_conv<KS, MW, NW, NTW, SPLIT, ST, UP, N7, KVE>,
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess);
     if (cfg_failed) return far_check_launch();
-    hipLaunchKernelGGL((k_conv<KS, MW, NW, NTW, SPLIT, ST, UP, N7>), grid, dim3(64 * MW * NW), smem, stream, a);
+    hipLaunchKernelGGL((k_conv<KS, MW, NW, NTW, SPLIT, ST, UP, N7, KVE>), grid, dim3(64 * MW * NW), smem, stream, a);
     return far_check_launch();
 }
 
@@ -1258,7 +1380,12 @@ struct far_conv_desc {          // mirrors include/far_hip.h
     const float* act_scale_dev;
 };
 
-int far_conv_nhwc_f32(const far_conv_desc* desc, hipStream_t stream) {
+}  // extern "C"
+
+namespace {
+struct KvMode { float* part; int by0, S, nslot; };     // far_linear_kv_f16s: the k | v column blocks feed la_kv_epilogue
+
+int conv_nhwc_impl(const far_conv_desc* desc, const KvMode* kvm, hipStream_t stream) {
     if (!desc) return FAR_EINVAL;
     const far_conv_desc& d = *desc;
     const float *x = d.x, *x2 = d.x2, *scale = d.scale, *shift = d.shift, *res = d.res;
@@ -1272,9 +1399,9 @@ int far_conv_nhwc_f32(const far_conv_desc* desc, hipStream_t stream) {
     far_clear_errors();
     if (d.act_exp < -24 || d.act_exp > 8) return FAR_EINVAL;
     if (N == 0) return FAR_OK;
-    if (!x || !packed || !scale || !y || N < 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) || Cout <= 0 ||
+    if (!x || !packed || !scale || (!y && !kvm) || N < 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) || Cout <= 0 ||
         (ksize != 1 && ksize != 3) || stride < 1 || stride > 2 || (stride == 2 && ksize != 3) || act < 0 || act > 2 ||
-        (act == 2 && !(slope >= 0.f && slope <= 1.f)) || x == y || x2 == y || out_planes < 1 || Cout % out_planes)
+        (act == 2 && !(slope >= 0.f && slope <= 1.f)) || x == y || (x2 && x2 == y) || out_planes < 1 || Cout % out_planes)
         return FAR_EINVAL;
     if (res_group < 1 || (res_group > 1 && (!res || ksize != 1 || out_planes != 1 || (N * H * W) % res_group))) return FAR_EINVAL;
     if (x2 ? (Cin1 <= 0 || Cin1 >= Cin || (Cin1 & 7)) : (Cin1 != Cin)) return FAR_EINVAL;
@@ -1299,9 +1426,10 @@ int far_conv_nhwc_f32(const far_conv_desc* desc, hipStream_t stream) {
     a.act = act; a.slope = slope;
     a.act_scale = ldexpf(1.0f, d.act_exp); a.out_mul = ldexpf(1.0f, ACT_EXP_DEFAULT - d.act_exp); a.overflow = d.overflow;
     a.scale_dev = d.act_scale_dev;
+    a.kv_part = kvm ? kvm->part : nullptr; a.kv_by0 = kvm ? kvm->by0 : 0; a.kv_S = kvm ? kvm->S : 0; a.kv_nslot = kvm ? kvm->nslot : 0;
     long nbx = ksize == 1 ? (a.npix + 64 * c.mw - 1) / (64 * c.mw) : N * a.tilesX * a.tilesY;
     // a Linear layer over the tokens of one or two images: the few-row kernel (linear_small_f16s.hip; same image, same arithmetic)
-    if (ksize == 1 && !up && !x2 && !ln_gamma && !post_res && res_group == 1 && split && nbx * a.nblkY < 512 &&
+    if (ksize == 1 && !kvm && !up && !x2 && !ln_gamma && !post_res && res_group == 1 && split && nbx * a.nblkY < 512 &&
         far_get_tuning(7) == 0 && far_linear_small_covers(a.npix, Cin, Cout)) {
         LinSmallArgs s;
         s.x = x; s.w = a.w; s.scale = scale; s.shift = shift; s.res = res; s.y = y; s.rows = a.npix;
@@ -1317,7 +1445,46 @@ int far_conv_nhwc_f32(const far_conv_desc* desc, hipStream_t stream) {
     dim3 grid((unsigned)(nbx * a.nblkY));
     if (stride == 2) return split ? launch_stride2<true>(a, grid, stream) : launch_stride2<false>(a, grid, stream);
     if (ksize == 3) return split ? launch_cfg<3, true>(c, a, grid, stream) : launch_cfg<3, false>(c, a, grid, stream);
+    if (kvm) {                                     // (validated by far_linear_kv_f16s: 256-column blocks, split operands)
+        if (c.mw != 2 || !split) return FAR_EINVAL;
+        return small ? launch_conv<1, 1, 2, 4, true, 1, false, false, true>(a, grid, stream)
+                     : launch_conv<1, 2, 2, 4, true, 1, false, false, true>(a, grid, stream);
+    }
     return split ? launch_cfg<1, true>(c, a, grid, stream, small) : launch_cfg<1, false>(c, a, grid, stream, small);
+}
+}  // namespace
+
+extern "C" {
+
+int far_conv_nhwc_f32(const far_conv_desc* desc, hipStream_t stream) { return conv_nhwc_impl(desc, nullptr, stream); }
+
+// The k | v projections of a LoFTR encoder layer at d_model 256 / 8 heads in ONE launch that never writes k or v: desc describes a
+// Linear layer (ksize 1, N = H = 1, W = rows, split operands) with Cout = 512, out_planes = 2, whose packed weight is Wk and Wv
+// interleaved head by head (weight rows 64 j + [0, 32) = Wk's rows of head j, 64 j + [32, 64) = Wv's); y is not used (NULL).
+// rows = n_img * S tokens, image after image (S >= 64); kv [n_img][256][33] = K'^T (V / S) per head (33rd column: sum of K'), the
+// state far_linear_attention_apply_f32 consumes -- what far_linear_attention_f32 computes from k and v in its first two launches.
+// ws: far_linear_kv_workspace_bytes(rows, S) bytes.  No masks, no residual / LayerNorm / activation on this launch.
+size_t far_linear_kv_workspace_bytes(long rows, int S) {
+    if (rows <= 0 || S < 64) return 0;
+    return (size_t)((rows + 63) / 64) * ((S & 63) ? 2 : 1) * 256 * 33 * sizeof(float);
+}
+
+int far_linear_kv_f16s(const far_conv_desc* desc, int S, void* ws, float* kv, hipStream_t stream) {
+    if (!desc) return FAR_EINVAL;
+    const far_conv_desc& d = *desc;
+    far_clear_errors();
+    const long rows = d.N * d.H * d.W;
+    if (rows == 0) return FAR_OK;
+    if (!ws || !kv || S < 64 || rows < 0 || rows % S || d.ksize != 1 || d.stride != 1 || !d.split || d.Cout != 512 ||
+        d.out_planes != 2 || d.act != 0 || d.res || d.ln_gamma || d.post_res || d.up || d.x2 || d.res_group != 1 || rows / S > 65535)
+        return FAR_EINVAL;
+    KvMode m{(float*)ws, 0, S, (S & 63) ? 2 : 1};
+    const int rc = conv_nhwc_impl(desc, &m, stream);
+    if (rc != FAR_OK) return rc;
+    const int per = 256 * 33;
+    hipLaunchKernelGGL(k_kv_blocks_reduce, dim3((per + 255) / 256, (unsigned)(rows / S)), dim3(256), 0, stream, (const float*)ws, S,
+                       m.nslot, per, kv);
+    return far_check_launch();
 }
 
 // ---- every weight image of a model in two launches (training: all weights change at every optimizer step).

@@ -319,6 +319,23 @@ int far_linear_attention_f32(const float* q, const float* k, const float* v, int
     return FAR_EINVAL;
 }
 
+// The second half alone: out [N][L][H*32] from q [N][L][H*32] and the state kv [N][H*32][33] (K'^T (V / S) and, in the 33rd
+// column, the sum of K') that far_linear_kv_f16s leaves -- the same k_la_apply launch far_linear_attention_f32 ends with.
+int far_linear_attention_apply_f32(const float* q, const float* kv, int N, int L, int S, int H, const uint8_t* q_mask, float eps,
+                                   float* out, hipStream_t stream) {
+    far_clear_errors();
+    if (N == 0) return FAR_OK;
+    if (!q || !kv || !out || N < 0 || L <= 0 || S <= 0 || H <= 0 || H * 32 > 1024) return FAR_EINVAL;
+    const int ntile = (L + 31) / 32;
+    int tiles_per_unit = ntile >= 64 ? 4 : ntile;
+    if (far_get_tuning(5) > 0) tiles_per_unit = std::min(ntile, far_get_tuning(5));
+    const int nblk = (ntile + tiles_per_unit - 1) / tiles_per_unit;
+    const long aunits = (long)N * nblk * H;
+    hipLaunchKernelGGL(k_la_apply<32>, dim3((unsigned)((aunits + 3) / 4)), dim3(256), 0, stream, q, kv, q_mask, N, L, S, H,
+                       tiles_per_unit, eps, out);
+    return far_check_launch();
+}
+
 }  // extern "C"
 
 // =====================================================================================================================

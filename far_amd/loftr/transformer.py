@@ -14,6 +14,7 @@ broadcasts :466-469 break for B > 1).  Here B pairs 
 independent B = 1 problems stacked along dim 0; for B = 1 every tensor has the reference's shape.
 """
 import copy
+import os
 from functools import partial
 
 import torch
@@ -55,6 +56,7 @@ class LoFTREncoderLayer(nn.Module):
     native_node = True           # layer node: launch sequences issued by the library (far_enc_layer_fwd / _bwd) instead of Python
     fused_mlp = True             # d_model 128, split operands: the MLP block as one K13 launch (False: two K9 launches)
     fused_attn = True            # d_model 128, sequences <= 32 tokens, no masks: the attention block as one K14 launch
+    fused_kv = os.environ.get('FAR_NO_KV', '') != '1'    # d_model 256, 8 heads, no masks: k | v projection + K'^T V in one launch (k, v never stored)
 
     def __init__(self, d_model, nhead, attention='linear', use_num_corres=False):
         super().__init__()
@@ -127,17 +129,30 @@ class LoFTREncoderLayer(nn.Module):
             h = ops.linear_f16s(x, lin('mlp0', self.mlp[0]), act='relu', x2=msg)
             return ops.linear_f16s(h, lin('mlp2', self.mlp[2]), ln=(self.norm2.weight, self.norm2.bias, self.norm2.eps),
                                    post_residual=x, out=out)
-        if fuse and source is x:  # self attention: q | k | v of the one input in a single launch, three output tensors
-            q, k, v = ops.linear_f16s(x, lin('qkv', self.q_proj, self.k_proj, self.v_proj), out_planes=3)
-        elif fuse:
+        if (self.fused_kv and sp and x.shape[-1] == 256 and self.nhead == 8 and source.shape[1] >= 64 and source.shape[1] % 64 == 0
+                and x_mask is None and source_mask is None):
+            # d_model 256 (the coarse level, the head's layers): the k | v projection ends in K'^T V (linear_attention.py:38-45)
+            # instead of a store -- k and v (4 of the layer's 19 passes over a (rows, 256) tensor) never exist.  Only for whole
+            # 64-token blocks per image (4800 = 75 x 64): the partial sums are then per image and an image's bits do not depend on
+            # the rest of the batch (the kernel itself handles any S >= 64)
+            pkv = pk.get(('kv-state', sp), [self.k_proj.weight, self.v_proj.weight],
+                         lambda: ops.PackedConv(ops.kv_interleaved_weight(self.k_proj.weight, self.v_proj.weight, self.nhead), split=sp))
+            S = source.shape[1]
+            kv = ops.linear_kv_state(source, pkv, S)
             q = ops.linear_f16s(x, lin('q', self.q_proj))
-            k, v = ops.linear_f16s(source, lin('kv', self.k_proj, self.v_proj), out_planes=2)
+            msg = ops.linear_attention_apply(q, kv, self.nhead, S, eps=self.attention.eps)
         else:
-            q = ops.linear_f16s(x, lin('q', self.q_proj))
-            k = ops.linear_f16s(source, lin('k', self.k_proj))
-            v = ops.linear_f16s(source, lin('v', self.v_proj))
-        q, k, v = heads(q), heads(k), heads(v)
-        msg = self.attention(q, k, v, q_mask=x_mask, kv_mask=source_mask, loftr_preds=loftr_preds)
+            if fuse and source is x:  # self attention: q | k | v of the one input in a single launch, three output tensors
+                q, k, v = ops.linear_f16s(x, lin('qkv', self.q_proj, self.k_proj, self.v_proj), out_planes=3)
+            elif fuse:
+                q = ops.linear_f16s(x, lin('q', self.q_proj))
+                k, v = ops.linear_f16s(source, lin('kv', self.k_proj, self.v_proj), out_planes=2)
+            else:
+                q = ops.linear_f16s(x, lin('q', self.q_proj))
+                k = ops.linear_f16s(source, lin('k', self.k_proj))
+                v = ops.linear_f16s(source, lin('v', self.v_proj))
+            q, k, v = heads(q), heads(k), heads(v)
+            msg = self.attention(q, k, v, q_mask=x_mask, kv_mask=source_mask, loftr_preds=loftr_preds)
         # merge + norm1 (:60-61) in one launch: the LayerNorm runs in the Linear layer's epilogue
         msg = ops.linear_f16s(msg.view(bs, -1, self.nhead * self.dim), lin('merge', self.merge),
                               ln=(self.norm1.weight, self.norm1.bias, self.norm1.eps))

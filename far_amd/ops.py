@@ -1478,6 +1478,54 @@ def linear_f16s(x, pc, residual=None, act='none', x2=None, out_planes=1, res_gro
     return y.reshape(*lead, pc.Cout) if out_planes == 1 else y.reshape(out_planes, *lead, pc.Cout // out_planes)
 
 
+def kv_interleaved_weight(wk, wv, nhead):
+    """The weight image far_linear_kv_f16s expects: the rows of Wk and Wv (each (H * 32, K)) head by head -- 64 j + [0, 32) = Wk's
+    rows of head j, 64 j + [32, 64) = Wv's."""
+    C, K = wk.shape
+    if wv.shape != wk.shape or C != nhead * 32:
+        raise _lib.FarHipError('kv_interleaved_weight: Wk, Wv must be (nhead * 32, K)')
+    return torch.stack([wk.reshape(nhead, 32, K), wv.reshape(nhead, 32, K)], 1).reshape(2 * C, K)
+
+
+def linear_kv_state(x, pc, S):
+    """K9 + the K'^T V epilogue (far_linear_kv_f16s).  x (..., K) fp32 = n_img * S tokens, image after image; pc = PackedConv of
+    kv_interleaved_weight(Wk, Wv, 8).  Returns the LinearAttention state (n_img, 256, 33) of linear_attention.py:38-45 --
+    K'^T (V / S) per head and, in the last column, the sum of K' -- without k or v ever reaching memory."""
+    lib = _lib.load()
+    rows = 1
+    for d in x.shape[:-1]:
+        rows *= d
+    if pc.Cout != 512 or pc.ksize != 1 or not pc.split or S < 64 or rows % S or x.shape[-1] != pc.Cin:
+        raise _lib.FarHipError('linear_kv_state: needs a split-operand 512-row k | v weight image and whole images of S >= 64 tokens')
+    kv = torch.empty(rows // S, 256, 33, dtype=torch.float32, device=x.device)
+    if rows == 0:
+        return kv
+    ws = _ws(lib.far_linear_kv_workspace_bytes(rows, S), x.device)
+    ptr = lambda t: _p(t, torch.float32).value
+    d = _lib.ConvDesc(x=ptr(x), x2=None, packed=_p(pc.packed).value, scale=ptr(pc.scale), shift=ptr(pc.shift), res=None, ln_gamma=None,
+                      ln_beta=None, post_res=None, up=None, y=None, N=1, H=1, W=rows, Cin=pc.Cin, Cin1=pc.Cin, Cout=512, ksize=1,
+                      stride=1, act=0, split=1, out_planes=2, res_group=1, slope=0.0, ln_eps=0.0, act_exp=activation_exponent_value(),
+                      overflow=overflow_flag(x.device).data_ptr(), act_scale_dev=None)
+    rc = lib.far_linear_kv_f16s(ctypes.byref(d), int(S), _p(ws), _p(kv), _stream())
+    _lib.check(rc, 'far_linear_kv_f16s')
+    return kv
+
+
+def linear_attention_apply(q, kv, nhead, S, q_mask=None, eps=1e-6):
+    """The second half of K5: q (N, L, nhead * 32) raw projection and the state kv (N, nhead * 32, 33) -> (N, L, nhead * 32)."""
+    lib = _lib.load()
+    N, L, C = q.shape
+    if C != nhead * 32 or tuple(kv.shape) != (N, C, 33):
+        raise _lib.FarHipError('linear_attention_apply: q (N, L, nhead * 32), kv (N, nhead * 32, 33)')
+    out = torch.empty(N, L, C, dtype=torch.float32, device=q.device)
+    if N == 0:
+        return out
+    rc = lib.far_linear_attention_apply_f32(_p(q, torch.float32), _p(kv, torch.float32), N, L, int(S), nhead, _p(q_mask, torch.uint8),
+                                            float(eps), _p(out), _stream())
+    _lib.check(rc, 'far_linear_attention_apply_f32')
+    return out
+
+
 def stem7x7(img, weight, scale=None, shift=None):
     """K10.  img (N, 1, H, W) fp32 -> relu(bn(conv7x7 stride 2)) as NHWC (N, H/2, W/2, Cout); without scale / shift the bare
     convolution (training: BatchNorm follows with batch statistics)."""

@@ -225,6 +225,11 @@ int far_linear_attention_f32(const float* q, const float* k, const float* v, int
                              const uint8_t* q_mask, const uint8_t* kv_mask, float eps, float* out, void* ws,
                              far_stream_t stream);
 
+/* The second half alone: out from q and the per-image state kv [N][H*32][33] (K'^T (V / S) per head; 33rd column: the sum of K')
+ * that far_linear_kv_f16s leaves (D = 32) -- the launch far_linear_attention_f32 ends with (linear_attention.py:46-50). */
+int far_linear_attention_apply_f32(const float* q, const float* kv, int N, int L, int S, int H, const uint8_t* q_mask, float eps,
+                                   float* out, far_stream_t stream);
+
 /* K5 backward (training path): gradients of far_linear_attention_f32 w.r.t. the raw projections q, k, v given
  * g = dL/dout -- what autograd derives from linear_attention.py:31-50 in the reference.  Token-parallel kernels with the
  * head's D x D matrices in LDS; the token reductions (dKV, dksum) in fixed order (deterministic). */
@@ -460,6 +465,17 @@ typedef struct far_conv_desc {
 } far_conv_desc;
 
 int far_conv_nhwc_f32(const far_conv_desc* desc, far_stream_t stream);
+
+/* The k and v projections of a LoFTREncoderLayer at d_model 256 / 8 heads (transformer.py:52-56 with linear_attention.py:38-45) in
+ * ONE launch that never writes k or v: K9's Linear mode ending in the K'^T V product instead of a store.
+ * desc: a Linear layer (ksize 1, N = H = 1, W = rows, split = 1) with Cout = 512, out_planes = 2, no activation / residual /
+ * LayerNorm; its packed weight = Wk and Wv interleaved head by head (weight rows 64 j + [0, 32) = Wk's rows of head j,
+ * 64 j + [32, 64) = Wv's); y unused (NULL).  rows = n_img * S tokens, image after image, S >= 64.
+ * kv [n_img][256][33] = the state far_linear_attention_apply_f32 consumes (what far_linear_attention_f32 builds from k and v in
+ * its first two launches); fixed summation order per image (64-row blocks in order): run-to-run and batch-size independent bits.
+ * ws: far_linear_kv_workspace_bytes(rows, S) bytes. */
+size_t far_linear_kv_workspace_bytes(long rows, int S);
+int far_linear_kv_f16s(const far_conv_desc* desc, int S, void* ws, float* kv, far_stream_t stream);
 
 /* K17: the stride-1 3x3 convolutions as Winograd F(2x2, 3x3) on the f16 matrix cores with split operands (conv_wino_f16s.hip):
  * far_conv_nhwc_f32's contract for ksize = 3, stride = 1, split = 1 at 2.25x fewer matrix instructions -- resnet_fpn.py:5-12

@@ -66,6 +66,45 @@ def test_linear_attention(N, L, S, C):
     np.testing.assert_allclose(got, ref, atol=1e-5 * np.abs(ref).max(), rtol=1e-4)
 
 
+@pytest.mark.parametrize('N,L,S', [(3, 4800, 4800), (2, 77, 100), (5, 200, 64), (2, 300, 6120), (4, 64, 150), (1, 33, 65)])
+def test_linear_kv_state_projection_fused_with_ktv(N, L, S):
+    """far_linear_kv_f16s: the k | v projection of a d_model-256 layer ending in K'^T V (k, v never stored) + the apply half of K5.
+    Against float64 (the state and the attention output), against the unfused launches, run to run, and image by image (at
+    S % 64 == 0 the bits of an image's state must not depend on what else is in the launch)."""
+    from far_amd import ops
+    from oracle import attention as oa
+    rng = np.random.default_rng(S + L)
+    src = rng.standard_normal((N, S, 256)).astype(np.float32)
+    xq = rng.standard_normal((N, L, 256)).astype(np.float32)
+    wq, wk, wv = (rng.standard_normal((256, 256)).astype(np.float32) / 16 for _ in range(3))
+    cu = lambda a: torch.from_numpy(a).cuda()
+    pkv = ops.PackedConv(ops.kv_interleaved_weight(cu(wk), cu(wv), 8), split=True)
+    kv = ops.linear_kv_state(cu(src), pkv, S)
+    k64, v64 = src.astype(np.float64) @ wk.T.astype(np.float64), src.astype(np.float64) @ wv.T.astype(np.float64)
+    kf = (np.where(k64 > 0, k64, np.expm1(k64)) + 1).reshape(N, S, 8, 32)
+    ref_kv = np.einsum('nshd,nshv->nhdv', kf, v64.reshape(N, S, 8, 32) / S).reshape(N, 256, 32)
+    ref_ks = kf.sum(1).reshape(N, 256)
+    got = kv.cpu().numpy()
+    np.testing.assert_allclose(got[:, :, :32], ref_kv, atol=3e-6 * np.abs(ref_kv).max(), rtol=0)
+    np.testing.assert_allclose(got[:, :, 32], ref_ks, atol=3e-6 * np.abs(ref_ks).max(), rtol=0)
+    q = ops.linear_f16s(cu(xq), ops.PackedConv(cu(wq), split=True))
+    out = ops.linear_attention_apply(q, kv, 8, S)
+    ref = oa.linear_attention(xq.astype(np.float64) @ wq.T.astype(np.float64), k64, v64, 8, dtype=np.float64)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, atol=1e-5 * np.abs(ref).max(), rtol=1e-4)
+    k, v = ops.linear_f16s(cu(src), ops.PackedConv(torch.cat([cu(wk), cu(wv)], 0), split=True), out_planes=2)
+    unf = ops.linear_attention(q, k, v, 8)
+    d = float((out - unf).abs().max()) / float(unf.abs().max())
+    print(f'[kv state] N={N} L={L} S={S}: fused vs unfused max rel diff {d:.2e}')
+    assert d < 2e-6
+    assert torch.equal(kv, ops.linear_kv_state(cu(src), pkv, S))
+    for n in range(N):
+        alone = ops.linear_kv_state(cu(src[n:n + 1]), pkv, S)
+        if S % 64 == 0:     # whole 64-row blocks per image: the same sums in the same order whatever else is in the launch
+            assert torch.equal(kv[n:n + 1], alone), f'image {n}'
+        else:               # an image boundary inside a block regroups the partial sums (the layer uses the fused form at S % 64 == 0)
+            assert float((kv[n:n + 1] - alone).abs().max()) <= 1e-6 * float(alone.abs().max()), f'image {n}'
+
+
 @pytest.mark.parametrize('N,L,S', [(700, 25, 25), (5, 32, 32), (7, 17, 9), (3, 1, 1), (4, 9, 30)])
 def test_linear_attention_short_windows_fused_kernel(N, L, S):
     """The one-kernel form used for short sequences with 16-channel heads (the fine-level windows): against the float64

@@ -28,3 +28,19 @@ for name, (fn, w, nbytes, flops) in cases.items():
     tot[0] += t; tot[1] += hbm; tot[2] += mf
     print(f'{name:32s} {1e3 * t:6.0f} us   HBM floor {1e3 * hbm:5.0f} us   MFMA floor {1e3 * mf:5.0f} us   -> {t / max(hbm, mf):.2f}x the larger floor')
 print(f'layer: {1e3 * tot[0]:.0f} us measured, {1e3 * tot[1]:.0f} us HBM, {1e3 * tot[2]:.0f} us MFMA')
+
+# the attention core around them: unfused (k | v stored, K5's three launches) against the k | v projection that ends in K'^T V
+N, S = R // 4800, 4800
+wkv = W(2 * d, d)
+pkv2 = ops.PackedConv(wkv)
+pst = ops.PackedConv(ops.kv_interleaved_weight(wkv[:d], wkv[d:], 8))
+q = torch.randn(N, S, d, device='cuda', generator=g)
+xs = x.view(N, S, d)
+def unfused():
+    k, v = ops.linear_f16s(xs, pkv2, out_planes=2)
+    return ops.linear_attention(q, k, v, 8)
+def fused():
+    return ops.linear_attention_apply(q, ops.linear_kv_state(xs, pst, S), 8, S)
+for name, fn in (('k|v + K5 (three launches)', unfused), ('k|v -> K^T V state + apply', fused), ('   the state launch alone', lambda: ops.linear_kv_state(xs, pst, S))):
+    t = min(bench.event_time_ms(fn, iters=10, warm=3) for _ in range(3))
+    print(f'{name:32s} {1e3 * t:6.0f} us')
