@@ -99,8 +99,10 @@ struct ConvArgs {
     float out_mul;               // 2^(4 - act_exp): `scale` folds 2^-4, this corrects it for the scale actually used
     int* overflow;               // device flag, |= 1 when an accumulator of this launch is not finite (may be null)
     const float* scale_dev;      // device { act_scale, out_mul } overriding the two fields above (may be null)
-    float* kv_part;              // far_linear_kv_f16s (the KVE instantiations): the columns are the k | v projections of a LoFTR
+    float* kv_part;              // far_linear_kv_f16s (the EPI = 1 instantiations): the columns are the k | v projections of a LoFTR
     int kv_by0, kv_S, kv_nslot;  // layer, head-interleaved, and the epilogue is la_kv_epilogue (K'^T V partial sums), not a store
+    const unsigned char* kv_img; // far_linear_q_apply_f16s (EPI = 2): per image the K'^T V state as MFMA operands + ksum (KV_IMG_BYTES)
+    float la_eps, la_vlen;       // (EPI = 2: kv_S = tokens per image on the query side, la_vlen = the source's length S)
 };
 
 __device__ __forceinline__ void split8(const float4& u, const float4& v, float act_scale, f16x8& hi, f16x8& lo) {
@@ -625,9 +627,13 @@ __device__ __forceinline__ void la_kv_epilogue(const ConvArgs& p, const f32x16 (
 }
 
 // kv[n][HD][33] = the partial sums of image n's 64-row blocks, in block order.  Block g's slot 0 holds the rows of the image its
-// first row belongs to, slot 1 (nslot = 2) the rows of the next image.
+// first row belongs to, slot 1 (nslot = 2) the rows of the next image.  img (optional, HD = 256): the same state as the operands of
+// la_apply_epilogue -- per image [head][k-step u][plane hi | lo][lane][8] fp16 = KV[head][d = 16 u + 8 (lane >> 5) + i][v = lane & 31]
+// x act_scale, then ksum [256] fp32 (KV_IMG_BYTES per image).
+constexpr int KV_IMG_BYTES = 8 * 2 * 2 * 1024 + 256 * 4;
+
 __global__ __launch_bounds__(256) void k_kv_blocks_reduce(const float* __restrict__ part, int S, int nslot, int per,
-                                                          float* __restrict__ kv) {
+                                                          float* __restrict__ kv, unsigned char* __restrict__ img, float act_scale) {
     const int n = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
     if (e >= per) return;
     const long g0 = ((long)n * S) >> 6, g1 = ((long)(n + 1) * S - 1) >> 6;
@@ -643,6 +649,101 @@ __global__ __launch_bounds__(256) void k_kv_blocks_reduce(const float* __restric
         }
     }
     kv[(size_t)n * per + e] = s;
+    if (img) {
+        unsigned char* im = img + (size_t)n * KV_IMG_BYTES;
+        const int dg = e / 33, col = e - dg * 33;
+        if (col == 32) {
+            reinterpret_cast<float*>(im + 32768)[dg] = s;
+        } else {
+            const int head = dg >> 5, d = dg & 31, u = d >> 4, hh = (d >> 3) & 1, i = d & 7, ln = col + 32 * hh;
+            const float x = s * act_scale;
+            const _Float16 hi = (_Float16)x, lo = (_Float16)(x - (float)hi);
+            _Float16* o = reinterpret_cast<_Float16*>(im + ((head * 2 + u) * 2) * 1024 + ln * 16) + i;
+            o[0] = hi;
+            o[512] = lo;                                   // the lo plane: 1 KiB further
+        }
+    }
+}
+
+// ---- LinearAttention's second half (linear_attention.py:46-50) in the epilogue of the q projection (far_linear_q_apply_f16s): the
+// launch writes the attention message, q never reaches HBM and K5's apply launch (a read of q, a write of the message) disappears.
+// Per 32-row x 128-channel accumulator tile of a wave (4 heads): Q' = elu(q) + 1 goes to the wave's LDS tile in [row][channel]
+// order (row stride LDW = 132 floats: the 16-byte reads below are conflict free); lane (row, h) reads its row back as the A operand
+// of  num[row][v] = sum_d Q'[row][d] KV[d][v]  (B = the image k_kv_blocks_reduce wrote; products hi * hi + hi * lo + lo * hi),
+// forms den = Q'[row] . ksum from the same registers (an fma chain + one cross-lane add), passes Z = 1 / (den + eps) to the lanes that
+// hold the row's outputs through the tile's four spare columns, and the message (num Z) S replaces Q' in the tile; 16-byte stores.
+constexpr int LDW = 132;
+
+__device__ __forceinline__ void la_apply_epilogue(const ConvArgs& p, const f32x16 (&acc)[2][4], long pixw, int cout_w, int lane,
+                                                  float* lw, float act_scale) {
+    const int l31 = lane & 31, h = lane >> 5;
+    const int L = p.kv_S;
+    const float unscale = 1.0f / (act_scale * act_scale), fS = p.la_vlen;
+    const int head0 = cout_w >> 5;
+    float sc[4], sh[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int co = cout_w + 32 * nt + l31;
+        sc[nt] = p.scale[co] * p.out_mul;
+        sh[nt] = p.shift ? p.shift[co] : 0.f;
+    }
+    float chk = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const long pix0 = pixw + 32 * mt;
+        const long leftl = p.npix - pix0;
+        if (leftl <= 0) break;
+        const int left = leftl > 32 ? 32 : (int)leftl;
+        const unsigned char* img = p.kv_img + (size_t)(pix0 / L) * KV_IMG_BYTES;
+        const float* ksum = reinterpret_cast<const float*>(img + 32768);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = 16 * (r >> 3) + (r & 3) + 8 * ((r >> 2) & 1) + 4 * h;                 // pixel of the tile
+                lw[q * LDW + 32 * nt + l31] = la_elu1(acc[mt][nt][r] * sc[nt] + sh[nt]);
+            }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            f32x16 num;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) num[r] = 0.f;
+            float den = 0.f;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const unsigned char* bsrc = img + (((head0 + nt) * 2 + u) * 2) * 1024 + lane * 16;
+                const f16x8 bh = *reinterpret_cast<const f16x8*>(bsrc), bl = *reinterpret_cast<const f16x8*>(bsrc + 1024);
+                const float* kp = ksum + 32 * (head0 + nt) + 16 * u + 8 * h;
+                const float4 k0 = *reinterpret_cast<const float4*>(kp), k1 = *reinterpret_cast<const float4*>(kp + 4);
+                const float* ap = lw + l31 * LDW + 32 * nt + 16 * u + 8 * h;
+                const float4 a0 = *reinterpret_cast<const float4*>(ap), a1 = *reinterpret_cast<const float4*>(ap + 4);
+                den = fmaf(a0.x, k0.x, den); den = fmaf(a0.y, k0.y, den); den = fmaf(a0.z, k0.z, den); den = fmaf(a0.w, k0.w, den);
+                den = fmaf(a1.x, k1.x, den); den = fmaf(a1.y, k1.y, den); den = fmaf(a1.z, k1.z, den); den = fmaf(a1.w, k1.w, den);
+                f16x8 ah, al;
+                split8(a0, a1, act_scale, ah, al);
+                num = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, num, 0, 0, 0);
+                num = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, num, 0, 0, 0);
+                num = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, num, 0, 0, 0);
+            }
+            den += shfl_xor_f(den, 32);
+            if (h == 0) lw[l31 * LDW + 128 + nt] = 1.0f / (den + p.la_eps);                           // linear_attention.py:46
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
+                chk += num[r];
+                lw[m * LDW + 32 * nt + l31] = ((num[r] * unscale) * lw[m * LDW + 128 + nt]) * fS;   // :50
+            }
+            __builtin_amdgcn_sched_barrier(0);             // head by head: the tile's columns are reused in place
+        }
+        float* const ybase = p.y + (pix0 * (long)p.Csub + cout_w + 4 * l31);
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int q = 2 * it + h;
+            const float4 v = *reinterpret_cast<const float4*>(lw + q * LDW + 4 * l31);
+            if (q < left) FAR_K9_STORE4(ybase + (long)q * p.Csub, v);
+        }
+    }
+    if (p.overflow && __any(!(fabsf(chk) <= FLT_MAX)) && lane == 0) atomicOr(p.overflow, 1);
 }
 
 // Workgroup = MW x NW waves: wave (wm, wn) owns 64 pixels (4 tile rows x 16) x 32 NTW output channels.
@@ -651,7 +752,7 @@ __global__ __launch_bounds__(256) void k_kv_blocks_reduce(const float* __restric
 // first 32-pixel tile (mt = 0) and by wn = 1 for its second (mt = 1), so that every wave issues 7 of the 8 MFMA triples of a
 // k-step: 12.5 % fewer MFMAs, evenly over the four SIMDs (dropping the all-padding eighth tile from the wn = 1 waves alone
 // leaves the SIMDs of the wn = 0 waves as the bottleneck: measured in round 1, -2 %).
-template <int KS, int MW, int NW, int NTW, bool SPLIT, int ST, bool UP, bool N7, int WN, bool KVE = false>
+template <int KS, int MW, int NW, int NTW, bool SPLIT, int ST, bool UP, bool N7, int WN, int EPI = 0>
 __device__ __forceinline__ void conv_body(const ConvArgs& p) {
     using G = Geo<KS, MW, ST>;
     constexpr int NTHR = 64 * MW * NW;
@@ -902,7 +1003,13 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p) {
 #endif
     ConvArgs pe = p;                 // the epilogues read the output multiplier from their argument block
     pe.out_mul = out_mul;
-    if constexpr (KVE) {
+    if constexpr (EPI == 2) {
+        static_assert(KS == 1 && NW == 2 && NTW == 4 && !UP && !N7, "the apply epilogue is a mode of the 256-column Linear tiles");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave is past its last LDS fragment read
+        la_apply_epilogue(pe, acc, tp.pix0 + 64 * wm, cout_w, lane, reinterpret_cast<float*>(smem) + wave * (32 * LDW), act_scale);
+        return;
+    }
+    if constexpr (EPI == 1) {
         static_assert(KS == 1 && NW == 2 && NTW == 4 && !UP && !N7, "the K'^T V epilogue is a mode of the 256-column Linear tiles");
         la_kv_epilogue(pe, acc, tp.pix0 + 64 * wm, cout_w, lane, act_scale);      // every column block holds k | v (kv_by0 = 0)
         return;
@@ -928,13 +1035,13 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p) {
 #endif
 }
 
-template <int KS, int MW, int NW, int NTW, bool SPLIT, int ST, bool UP = false, bool N7 = false, bool KVE = false>
+template <int KS, int MW, int NW, int NTW, bool SPLIT, int ST, bool UP = false, bool N7 = false, int EPI = 0>
 __global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const ConvArgs p) {
     if constexpr (N7) {                       // two copies of the body, one per wave column: which tile a wave skips is static
         if (((threadIdx.x >> 6) % NW) == 1) conv_body<KS, MW, NW, NTW, SPLIT, ST, UP, N7, 1>(p);
         else conv_body<KS, MW, NW, NTW, SPLIT, ST, UP, N7, 0>(p);
     } else {
-        conv_body<KS, MW, NW, NTW, SPLIT, ST, UP, N7, 0, KVE>(p);
+        conv_body<KS, MW, NW, NTW, SPLIT, ST, UP, N7, 0, EPI>(p);
     }
 }
 
@@ -1195,18 +1302,19 @@ inline TileCfg cfg_for(int Cout, int stride) {
     return (stride == 1 && pad128 < pad256) ? TileCfg{4, 1, 128} : TileCfg{2, 2, 256};
 }
 
-template <int KS, int MW, int NW, int NTW, bool SPLIT, int ST = 1, bool UP = false, bool N7 = false, bool KVE = false>
+template <int KS, int MW, int NW, int NTW, bool SPLIT, int ST = 1, bool UP = false, bool N7 = false, int EPI = 0>
 int launch_conv(const ConvArgs& a, dim3 grid, hipStream_t stream) {
     using G = Geo<KS, MW, ST>;
     constexpr int PLANES = SPLIT ? 2 : 1;
     constexpr int smem_loop = PLANES * G::A_PLANE + 3 * 2 * 32 * NTW * NW * 32;
-    constexpr int smem_epi = MW * NW * (32 * 128 * 4 + 32 * 4);  // conv_epilogue_wide: 16 KiB per wave + LayerNorm exchange
+    constexpr int smem_epi = EPI == 2 ? MW * NW * 32 * LDW * 4        // la_apply_epilogue: padded rows
+                                      : MW * NW * (32 * 128 * 4 + 32 * 4);  // conv_epilogue_wide: 16 KiB per wave + LayerNorm exchange
     constexpr int smem = smem_loop > smem_epi ? smem_loop : smem_epi;
     bool cfg_failed = false;
-    FAR_ONCE_PER_DEVICE(cfg_failed = hipFuncSetAttribute((const void*)k_conv<KS, MW, NW, NTW, SPLIT, ST, UP, N7, KVE>,
+    FAR_ONCE_PER_DEVICE(cfg_failed = hipFuncSetAttribute((const void*)k_conv<KS, MW, NW, NTW, SPLIT, ST, UP, N7, EPI>,
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess);
     if (cfg_failed) return far_check_launch();
-    hipLaunchKernelGGL((k_conv<KS, MW, NW, NTW, SPLIT, ST, UP, N7, KVE>), grid, dim3(64 * MW * NW), smem, stream, a);
+    hipLaunchKernelGGL((k_conv<KS, MW, NW, NTW, SPLIT, ST, UP, N7, EPI>), grid, dim3(64 * MW * NW), smem, stream, a);
     return far_check_launch();
 }
 
@@ -1383,7 +1491,13 @@ struct far_conv_desc {          // mirrors include/far_hip.h
 }  // extern "C"
 
 namespace {
-struct KvMode { float* part; int by0, S, nslot; };     // far_linear_kv_f16s: the k | v column blocks feed la_kv_epilogue
+struct KvMode {                                       // far_linear_kv_f16s (epi 1) / far_linear_q_apply_f16s (epi 2)
+    int epi;
+    float* part;
+    int S, nslot;
+    const unsigned char* img;
+    float eps, vlen;
+};
 
 int conv_nhwc_impl(const far_conv_desc* desc, const KvMode* kvm, hipStream_t stream) {
     if (!desc) return FAR_EINVAL;
@@ -1399,7 +1513,7 @@ int conv_nhwc_impl(const far_conv_desc* desc, const KvMode* kvm, hipStream_t str
     far_clear_errors();
     if (d.act_exp < -24 || d.act_exp > 8) return FAR_EINVAL;
     if (N == 0) return FAR_OK;
-    if (!x || !packed || !scale || (!y && !kvm) || N < 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) || Cout <= 0 ||
+    if (!x || !packed || !scale || (!y && !(kvm && kvm->epi == 1)) || N < 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) || Cout <= 0 ||
         (ksize != 1 && ksize != 3) || stride < 1 || stride > 2 || (stride == 2 && ksize != 3) || act < 0 || act > 2 ||
         (act == 2 && !(slope >= 0.f && slope <= 1.f)) || x == y || (x2 && x2 == y) || out_planes < 1 || Cout % out_planes)
         return FAR_EINVAL;
@@ -1426,7 +1540,8 @@ int conv_nhwc_impl(const far_conv_desc* desc, const KvMode* kvm, hipStream_t str
     a.act = act; a.slope = slope;
     a.act_scale = ldexpf(1.0f, d.act_exp); a.out_mul = ldexpf(1.0f, ACT_EXP_DEFAULT - d.act_exp); a.overflow = d.overflow;
     a.scale_dev = d.act_scale_dev;
-    a.kv_part = kvm ? kvm->part : nullptr; a.kv_by0 = kvm ? kvm->by0 : 0; a.kv_S = kvm ? kvm->S : 0; a.kv_nslot = kvm ? kvm->nslot : 0;
+    a.kv_part = kvm ? kvm->part : nullptr; a.kv_by0 = 0; a.kv_S = kvm ? kvm->S : 0; a.kv_nslot = kvm ? kvm->nslot : 0;
+    a.kv_img = kvm ? kvm->img : nullptr; a.la_eps = kvm ? kvm->eps : 0.f; a.la_vlen = kvm ? kvm->vlen : 0.f;
     long nbx = ksize == 1 ? (a.npix + 64 * c.mw - 1) / (64 * c.mw) : N * a.tilesX * a.tilesY;
     // a Linear layer over the tokens of one or two images: the few-row kernel (linear_small_f16s.hip; same image, same arithmetic)
     if (ksize == 1 && !kvm && !up && !x2 && !ln_gamma && !post_res && res_group == 1 && split && nbx * a.nblkY < 512 &&
@@ -1447,8 +1562,11 @@ int conv_nhwc_impl(const far_conv_desc* desc, const KvMode* kvm, hipStream_t str
     if (ksize == 3) return split ? launch_cfg<3, true>(c, a, grid, stream) : launch_cfg<3, false>(c, a, grid, stream);
     if (kvm) {                                     // (validated by far_linear_kv_f16s: 256-column blocks, split operands)
         if (c.mw != 2 || !split) return FAR_EINVAL;
-        return small ? launch_conv<1, 1, 2, 4, true, 1, false, false, true>(a, grid, stream)
-                     : launch_conv<1, 2, 2, 4, true, 1, false, false, true>(a, grid, stream);
+        if (kvm->epi == 2)
+            return small ? launch_conv<1, 1, 2, 4, true, 1, false, false, 2>(a, grid, stream)
+                         : launch_conv<1, 2, 2, 4, true, 1, false, false, 2>(a, grid, stream);
+        return small ? launch_conv<1, 1, 2, 4, true, 1, false, false, 1>(a, grid, stream)
+                     : launch_conv<1, 2, 2, 4, true, 1, false, false, 1>(a, grid, stream);
     }
     return split ? launch_cfg<1, true>(c, a, grid, stream, small) : launch_cfg<1, false>(c, a, grid, stream, small);
 }
@@ -1463,28 +1581,50 @@ int far_conv_nhwc_f32(const far_conv_desc* desc, hipStream_t stream) { return co
 // interleaved head by head (weight rows 64 j + [0, 32) = Wk's rows of head j, 64 j + [32, 64) = Wv's); y is not used (NULL).
 // rows = n_img * S tokens, image after image (S >= 64); kv [n_img][256][33] = K'^T (V / S) per head (33rd column: sum of K'), the
 // state far_linear_attention_apply_f32 consumes -- what far_linear_attention_f32 computes from k and v in its first two launches.
+// kv_img (optional, far_linear_kv_image_bytes(n_img) bytes): the same state as far_linear_q_apply_f16s's operands (x 2^act_exp).
 // ws: far_linear_kv_workspace_bytes(rows, S) bytes.  No masks, no residual / LayerNorm / activation on this launch.
 size_t far_linear_kv_workspace_bytes(long rows, int S) {
     if (rows <= 0 || S < 64) return 0;
     return (size_t)((rows + 63) / 64) * ((S & 63) ? 2 : 1) * 256 * 33 * sizeof(float);
 }
+size_t far_linear_kv_image_bytes(long n_img) { return n_img > 0 ? (size_t)n_img * KV_IMG_BYTES : 0; }
 
-int far_linear_kv_f16s(const far_conv_desc* desc, int S, void* ws, float* kv, hipStream_t stream) {
+int far_linear_kv_f16s(const far_conv_desc* desc, int S, void* ws, float* kv, void* kv_img, hipStream_t stream) {
     if (!desc) return FAR_EINVAL;
     const far_conv_desc& d = *desc;
     far_clear_errors();
     const long rows = d.N * d.H * d.W;
     if (rows == 0) return FAR_OK;
     if (!ws || !kv || S < 64 || rows < 0 || rows % S || d.ksize != 1 || d.stride != 1 || !d.split || d.Cout != 512 ||
-        d.out_planes != 2 || d.act != 0 || d.res || d.ln_gamma || d.post_res || d.up || d.x2 || d.res_group != 1 || rows / S > 65535)
+        d.out_planes != 2 || d.act != 0 || d.res || d.ln_gamma || d.post_res || d.up || d.x2 || d.res_group != 1 || rows / S > 65535 ||
+        d.act_scale_dev)
         return FAR_EINVAL;
-    KvMode m{(float*)ws, 0, S, (S & 63) ? 2 : 1};
+    KvMode m{1, (float*)ws, S, (S & 63) ? 2 : 1, nullptr, 0.f, 0.f};
     const int rc = conv_nhwc_impl(desc, &m, stream);
     if (rc != FAR_OK) return rc;
     const int per = 256 * 33;
     hipLaunchKernelGGL(k_kv_blocks_reduce, dim3((per + 255) / 256, (unsigned)(rows / S)), dim3(256), 0, stream, (const float*)ws, S,
-                       m.nslot, per, kv);
+                       m.nslot, per, kv, (unsigned char*)kv_img, ldexpf(1.0f, d.act_exp));
     return far_check_launch();
+}
+
+// The q projection of the same layer with LinearAttention's second half (linear_attention.py:46-50) in its epilogue: desc describes
+// a Linear layer (ksize 1, N = H = 1, W = rows, split operands, Cout = 256, out_planes = 1, no activation / residual / LayerNorm)
+// with the plain Wq image; y [rows][256] receives the attention MESSAGE (Q' KV) Z S -- q itself is never stored.  kv_img: the
+// operand image far_linear_kv_f16s wrote for the SOURCE tokens under the same act_exp (image i serves rows [i L, (i + 1) L));
+// L = tokens per image on the query side (L % 64 == 0), S = v_length of the source (linear_attention.py:43, 50).
+int far_linear_q_apply_f16s(const far_conv_desc* desc, int L, int S, const void* kv_img, float eps, hipStream_t stream) {
+    if (!desc) return FAR_EINVAL;
+    const far_conv_desc& d = *desc;
+    far_clear_errors();
+    const long rows = d.N * d.H * d.W;
+    if (rows == 0) return FAR_OK;
+    if (!kv_img || !d.y || L < 64 || (L & 63) || S <= 0 || rows < 0 || rows % L || d.ksize != 1 || d.stride != 1 || !d.split ||
+        d.Cout != 256 || d.out_planes != 1 || d.act != 0 || d.res || d.ln_gamma || d.post_res || d.up || d.x2 || d.res_group != 1 ||
+        d.act_scale_dev)
+        return FAR_EINVAL;
+    KvMode m{2, nullptr, L, 1, (const unsigned char*)kv_img, eps, (float)S};
+    return conv_nhwc_impl(desc, &m, stream);
 }
 
 // ---- every weight image of a model in two launches (training: all weights change at every optimizer step).

@@ -56,6 +56,7 @@ class LoFTREncoderLayer(nn.Module):
     native_node = True           # layer node: launch sequences issued by the library (far_enc_layer_fwd / _bwd) instead of Python
     fused_mlp = True             # d_model 128, split operands: the MLP block as one K13 launch (False: two K9 launches)
     fused_attn = True            # d_model 128, sequences <= 32 tokens, no masks: the attention block as one K14 launch
+    fused_apply = os.environ.get('FAR_NO_QAPPLY', '') != '1'   # ... and the q projection + LinearAttention's second half in one launch
     fused_kv = os.environ.get('FAR_NO_KV', '') != '1'    # d_model 256, 8 heads, no masks: k | v projection + K'^T V in one launch (k, v never stored)
 
     def __init__(self, d_model, nhead, attention='linear', use_num_corres=False):
@@ -138,9 +139,14 @@ class LoFTREncoderLayer(nn.Module):
             pkv = pk.get(('kv-state', sp), [self.k_proj.weight, self.v_proj.weight],
                          lambda: ops.PackedConv(ops.kv_interleaved_weight(self.k_proj.weight, self.v_proj.weight, self.nhead), split=sp))
             S = source.shape[1]
-            kv = ops.linear_kv_state(source, pkv, S)
-            q = ops.linear_f16s(x, lin('q', self.q_proj))
-            msg = ops.linear_attention_apply(q, kv, self.nhead, S, eps=self.attention.eps)
+            if self.fused_apply and x.shape[1] % 64 == 0:
+                # ... and the q projection ends in (Q' KV) Z S (:46-50): q is never stored either, K5's apply launch disappears
+                _, image = ops.linear_kv_state(source, pkv, S, want_image=True)
+                msg = ops.linear_q_apply(x, lin('q', self.q_proj), image, S, eps=self.attention.eps)
+            else:
+                kv = ops.linear_kv_state(source, pkv, S)
+                q = ops.linear_f16s(x, lin('q', self.q_proj))
+                msg = ops.linear_attention_apply(q, kv, self.nhead, S, eps=self.attention.eps)
         else:
             if fuse and source is x:  # self attention: q | k | v of the one input in a single launch, three output tensors
                 q, k, v = ops.linear_f16s(x, lin('qkv', self.q_proj, self.k_proj, self.v_proj), out_planes=3)

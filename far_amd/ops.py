@@ -1487,10 +1487,19 @@ def kv_interleaved_weight(wk, wv, nhead):
     return torch.stack([wk.reshape(nhead, 32, K), wv.reshape(nhead, 32, K)], 1).reshape(2 * C, K)
 
 
-def linear_kv_state(x, pc, S):
+def _linear_desc(x, pc, rows, y, out_planes):
+    ptr = lambda t: _p(t, torch.float32).value
+    return _lib.ConvDesc(x=ptr(x), x2=None, packed=_p(pc.packed).value, scale=ptr(pc.scale), shift=ptr(pc.shift), res=None, ln_gamma=None,
+                         ln_beta=None, post_res=None, up=None, y=ptr(y), N=1, H=1, W=rows, Cin=pc.Cin, Cin1=pc.Cin, Cout=pc.Cout,
+                         ksize=1, stride=1, act=0, split=1, out_planes=out_planes, res_group=1, slope=0.0, ln_eps=0.0,
+                         act_exp=activation_exponent_value(), overflow=overflow_flag(x.device).data_ptr(), act_scale_dev=None)
+
+
+def linear_kv_state(x, pc, S, want_image=False):
     """K9 + the K'^T V epilogue (far_linear_kv_f16s).  x (..., K) fp32 = n_img * S tokens, image after image; pc = PackedConv of
     kv_interleaved_weight(Wk, Wv, 8).  Returns the LinearAttention state (n_img, 256, 33) of linear_attention.py:38-45 --
-    K'^T (V / S) per head and, in the last column, the sum of K' -- without k or v ever reaching memory."""
+    K'^T (V / S) per head and, in the last column, the sum of K' -- without k or v ever reaching memory; with want_image also the
+    same state as the operand image linear_q_apply reads: (kv, image)."""
     lib = _lib.load()
     rows = 1
     for d in x.shape[:-1]:
@@ -1498,17 +1507,29 @@ def linear_kv_state(x, pc, S):
     if pc.Cout != 512 or pc.ksize != 1 or not pc.split or S < 64 or rows % S or x.shape[-1] != pc.Cin:
         raise _lib.FarHipError('linear_kv_state: needs a split-operand 512-row k | v weight image and whole images of S >= 64 tokens')
     kv = torch.empty(rows // S, 256, 33, dtype=torch.float32, device=x.device)
-    if rows == 0:
-        return kv
-    ws = _ws(lib.far_linear_kv_workspace_bytes(rows, S), x.device)
-    ptr = lambda t: _p(t, torch.float32).value
-    d = _lib.ConvDesc(x=ptr(x), x2=None, packed=_p(pc.packed).value, scale=ptr(pc.scale), shift=ptr(pc.shift), res=None, ln_gamma=None,
-                      ln_beta=None, post_res=None, up=None, y=None, N=1, H=1, W=rows, Cin=pc.Cin, Cin1=pc.Cin, Cout=512, ksize=1,
-                      stride=1, act=0, split=1, out_planes=2, res_group=1, slope=0.0, ln_eps=0.0, act_exp=activation_exponent_value(),
-                      overflow=overflow_flag(x.device).data_ptr(), act_scale_dev=None)
-    rc = lib.far_linear_kv_f16s(ctypes.byref(d), int(S), _p(ws), _p(kv), _stream())
-    _lib.check(rc, 'far_linear_kv_f16s')
-    return kv
+    img = torch.empty(int(lib.far_linear_kv_image_bytes(rows // S)), dtype=torch.uint8, device=x.device) if want_image else None
+    if rows:
+        ws = _ws(lib.far_linear_kv_workspace_bytes(rows, S), x.device)
+        d = _linear_desc(x, pc, rows, None, 2)
+        rc = lib.far_linear_kv_f16s(ctypes.byref(d), int(S), _p(ws), _p(kv), None if img is None else _p(img), _stream())
+        _lib.check(rc, 'far_linear_kv_f16s')
+    return (kv, img) if want_image else kv
+
+
+def linear_q_apply(x, pc, image, S, eps=1e-6):
+    """K9 + LinearAttention's second half in the epilogue (far_linear_q_apply_f16s).  x (N, L, K) fp32 query-side tokens, pc =
+    PackedConv(Wq), image = linear_kv_state(source, ..., want_image=True)[1] of the N source images (S tokens each) -> the attention
+    message (N, L, 256); q is never stored.  L % 64 == 0."""
+    lib = _lib.load()
+    N, L, K = x.shape
+    if pc.Cout != 256 or pc.ksize != 1 or not pc.split or K != pc.Cin or L % 64 or L < 64 or image.numel() != lib.far_linear_kv_image_bytes(N):
+        raise _lib.FarHipError('linear_q_apply: needs a split-operand 256-row Wq image, L % 64 == 0 and the state image of N source images')
+    out = torch.empty(N, L, 256, dtype=torch.float32, device=x.device)
+    if N:
+        d = _linear_desc(x, pc, N * L, out, 1)
+        rc = lib.far_linear_q_apply_f16s(ctypes.byref(d), int(L), int(S), _p(image), float(eps), _stream())
+        _lib.check(rc, 'far_linear_q_apply_f16s')
+    return out
 
 
 def linear_attention_apply(q, kv, nhead, S, q_mask=None, eps=1e-6):

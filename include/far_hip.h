@@ -475,7 +475,17 @@ int far_conv_nhwc_f32(const far_conv_desc* desc, far_stream_t stream);
  * its first two launches); fixed summation order per image (64-row blocks in order): run-to-run and batch-size independent bits.
  * ws: far_linear_kv_workspace_bytes(rows, S) bytes. */
 size_t far_linear_kv_workspace_bytes(long rows, int S);
-int far_linear_kv_f16s(const far_conv_desc* desc, int S, void* ws, float* kv, far_stream_t stream);
+size_t far_linear_kv_image_bytes(long n_img);
+/* kv_img (optional, far_linear_kv_image_bytes(n_img) bytes): the same state as the MFMA operands (fp16 hi / lo pairs x 2^act_exp) and
+ * ksum that far_linear_q_apply_f16s reads. */
+int far_linear_kv_f16s(const far_conv_desc* desc, int S, void* ws, float* kv, void* kv_img, far_stream_t stream);
+
+/* The q projection of the same layer (transformer.py:51, 54) with LinearAttention's second half (linear_attention.py:46-50) in its
+ * epilogue: desc = a Linear layer (ksize 1, N = H = 1, W = rows, split = 1, Cout = 256, out_planes = 1, no activation / residual /
+ * LayerNorm) with the plain Wq image; y [rows][256] receives the attention MESSAGE (Q' KV) Z S -- q is never stored and
+ * far_linear_attention_apply_f32's launch disappears.  kv_img: far_linear_kv_f16s's image of the SOURCE tokens under the same
+ * act_exp (image i serves rows [i L, (i + 1) L)); L = tokens per image on the query side (L % 64 == 0), S = the source's length. */
+int far_linear_q_apply_f16s(const far_conv_desc* desc, int L, int S, const void* kv_img, float eps, far_stream_t stream);
 
 /* K17: the stride-1 3x3 convolutions as Winograd F(2x2, 3x3) on the f16 matrix cores with split operands (conv_wino_f16s.hip):
  * far_conv_nhwc_f32's contract for ksize = 3, stride = 1, split = 1 at 2.25x fewer matrix instructions -- resnet_fpn.py:5-12

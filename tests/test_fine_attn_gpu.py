@@ -66,7 +66,7 @@ def test_linear_attention(N, L, S, C):
     np.testing.assert_allclose(got, ref, atol=1e-5 * np.abs(ref).max(), rtol=1e-4)
 
 
-@pytest.mark.parametrize('N,L,S', [(3, 4800, 4800), (2, 77, 100), (5, 200, 64), (2, 300, 6120), (4, 64, 150), (1, 33, 65)])
+@pytest.mark.parametrize('N,L,S', [(3, 4800, 4800), (2, 77, 100), (5, 200, 64), (2, 320, 6120), (4, 64, 150), (1, 33, 65), (3, 192, 128)])
 def test_linear_kv_state_projection_fused_with_ktv(N, L, S):
     """far_linear_kv_f16s: the k | v projection of a d_model-256 layer ending in K'^T V (k, v never stored) + the apply half of K5.
     Against float64 (the state and the attention output), against the unfused launches, run to run, and image by image (at
@@ -97,6 +97,18 @@ def test_linear_kv_state_projection_fused_with_ktv(N, L, S):
     print(f'[kv state] N={N} L={L} S={S}: fused vs unfused max rel diff {d:.2e}')
     assert d < 2e-6
     assert torch.equal(kv, ops.linear_kv_state(cu(src), pkv, S))
+    if L % 64 == 0:          # the q projection with the apply half in its epilogue (far_linear_q_apply_f16s): q never stored
+        kv2, image = ops.linear_kv_state(cu(src), pkv, S, want_image=True)
+        assert torch.equal(kv2, kv)
+        pq = ops.PackedConv(cu(wq), split=True)
+        msg = ops.linear_q_apply(cu(xq), pq, image, S)
+        np.testing.assert_allclose(msg.cpu().numpy(), ref, atol=1e-5 * np.abs(ref).max(), rtol=1e-4)
+        d2 = float((msg - unf).abs().max()) / float(unf.abs().max())
+        print(f'[q apply] N={N} L={L} S={S}: fused vs unfused max rel diff {d2:.2e}')
+        assert d2 < 2e-6
+        assert torch.equal(msg, ops.linear_q_apply(cu(xq), pq, image, S))
+        one = ops.linear_q_apply(cu(xq[N - 1:]), pq, image[-image.numel() // N:], S)
+        assert torch.equal(one, msg[N - 1:])
     for n in range(N):
         alone = ops.linear_kv_state(cu(src[n:n + 1]), pkv, S)
         if S % 64 == 0:     # whole 64-row blocks per image: the same sums in the same order whatever else is in the launch
