@@ -41,6 +41,17 @@ def unfused():
     return ops.linear_attention(q, k, v, 8)
 def fused():
     return ops.linear_attention_apply(q, ops.linear_kv_state(xs, pst, S), 8, S)
-for name, fn in (('k|v + K5 (three launches)', unfused), ('k|v -> K^T V state + apply', fused), ('   the state launch alone', lambda: ops.linear_kv_state(xs, pst, S))):
+pq = ops.PackedConv(W(d, d))
+_, image = ops.linear_kv_state(xs, pst, S, want_image=True)
+def unfused_all():
+    qq = ops.linear_f16s(xs, pq)
+    k, v = ops.linear_f16s(xs, pkv2, out_planes=2)
+    return ops.linear_attention(qq, k, v, 8)
+def fused_all():
+    _, im = ops.linear_kv_state(xs, pst, S, want_image=True)
+    return ops.linear_q_apply(xs, pq, im, S)
+for name, fn in (('k|v + K5 (three launches)', unfused), ('k|v -> K^T V state + apply', fused), ('   the state launch alone', lambda: ops.linear_kv_state(xs, pst, S)),
+                 ('q, k|v, K5: five launches', unfused_all), ('state + q-with-apply: 3 launches', fused_all),
+                 ('   q-with-apply alone', lambda: ops.linear_q_apply(xs, pq, image, S))):
     t = min(bench.event_time_ms(fn, iters=10, warm=3) for _ in range(3))
     print(f'{name:32s} {1e3 * t:6.0f} us')
