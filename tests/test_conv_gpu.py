@@ -419,10 +419,13 @@ def test_linear_three_planes_of_128_and_residual_activations():
         assert emax < 5e-6, (act, emax)
 
 
-@pytest.mark.parametrize('N,H,W,Cin,Cout', [(2, 24, 32, 128, 196), (1, 30, 44, 196, 256), (3, 16, 64, 64, 128)])
+@pytest.mark.parametrize('N,H,W,Cin,Cout', [(2, 24, 32, 128, 196), (1, 30, 44, 196, 256), (3, 16, 64, 64, 128), (2, 60, 160, 196, 256),
+                                            (1, 10, 320, 128, 208), (2, 6, 96, 32, 100)])
 def test_conv_fused_upsample_merge_is_bit_identical_to_conv_plus_k8(N, H, W, Cin, Cout):
     """The FPN merge in the 1x1 convolution's epilogue (up=) against the two-kernel sequence conv -> K8, and K8's own
-    parity target F.interpolate(scale_factor=2, bilinear, align_corners=True)."""
+    parity target F.interpolate(scale_factor=2, bilinear, align_corners=True).  Rows of whole 32-pixel tiles (W % 32 == 0) take
+    the row-walking form of the epilogue (each lane 16 consecutive pixels, the left source pair reused): same bits as the generic
+    form (tuning knob 13)."""
     ops = _ops()
     g = torch.Generator(device='cuda').manual_seed(N * H + W)
     x = torch.randn(N, H, W, Cin, device='cuda', generator=g)
@@ -432,9 +435,16 @@ def test_conv_fused_upsample_merge_is_bit_identical_to_conv_plus_k8(N, H, W, Cin
     lateral = ops.conv_nhwc(x, pc)
     two = ops.upsample2x_add(coarse.permute(0, 3, 1, 2), lateral.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
     assert torch.equal(fused, two.contiguous())
-    ref = lateral.double() + F.interpolate(coarse.permute(0, 3, 1, 2).double(), scale_factor=2., mode='bilinear',
-                                           align_corners=True).permute(0, 2, 3, 1)
-    assert float((fused.double() - ref).abs().max()) < 1e-5
+    from far_amd import _lib
+    _lib.load().far_set_tuning(13, 1)
+    try:
+        assert torch.equal(fused, ops.conv_nhwc(x, pc, up=coarse))
+    finally:
+        _lib.load().far_set_tuning(13, 0)
+    # torch's own fp32 form is the parity target: its source index rx * X is an fp32 product (at 160 columns a float64 index
+    # already differs by 1e-5 of a unit-variance map)
+    ref = lateral + F.interpolate(coarse.permute(0, 3, 1, 2), scale_factor=2., mode='bilinear', align_corners=True).permute(0, 2, 3, 1)
+    assert float((fused - ref).abs().max()) < 1e-5
     from far_amd._lib import FarHipError
     with pytest.raises(FarHipError):                      # 3x3 convolutions have no fused merge
         ops.conv_nhwc(x, ops.PackedConv(torch.randn(Cout, Cin, 3, 3, device='cuda', generator=g)), up=coarse)
