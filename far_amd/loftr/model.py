@@ -11,6 +11,8 @@ Batched use: loftr_rt may be (3, 4) [reference, B = 1] or (B, 3, 4); count tenso
 import math
 
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 
@@ -98,6 +100,7 @@ class LoFTR(nn.Module):
         self.act_exp = 4
 
     PRECISIONS = ('fp32', 'fp16-fine', 'fp16', 'bf16')
+    head_prefetch = os.environ.get('FAR_NO_PREFETCH', '') != '1'   # inference: the head's feature stage enqueued behind K1 (see below)
 
     def set_precision(self, mode):
         """Arithmetic of the backbone convolutions (everything else is unaffected):
@@ -162,7 +165,15 @@ class LoFTR(nn.Module):
         if 'mask0' in data:
             m0, m1 = data['mask0'].flatten(-2), data['mask1'].flatten(-2)
         tok0, tok1 = self.loftr_coarse(tok0, tok1, m0, m1)
-        self.coarse_matching(tok0, tok1, data, mask_c0=m0, mask_c1=m1)
+        # The head's feature stage (2 LoFTR layers, K2, CrossBlock: ~13 ms per 32 pairs) reads the coarse tokens only -- not the
+        # matches, not the solver's numbers.  Enqueued behind K1 it keeps the GPU busy while the host waits for the match count and
+        # prepares the fine-level launches (0.6 ms of idle GPU per step otherwise); forward_rt_prediction finds it in the data dict
+        # (_head_features: same tensors, same stamps).  It runs inside this call's activation-range guard like everything else here.
+        overlap = None
+        if (self.head_prefetch and self.config['regress_rt'] and tok0.is_cuda and not train and not torch.is_grad_enabled()
+                and not self.training and getattr(self.loftr_regress, 'cache_features', True)):
+            overlap = lambda: self._head_features(data, tok0, tok1, None, None)
+        self.coarse_matching(tok0, tok1, data, mask_c0=m0, mask_c1=m1, overlap=overlap)
         win0, win1 = self.fine_preprocess(data['featmap_f0'], data['featmap_f1'], tok0, tok1, data)
         if win0.size(0) != 0:
             win0, win1 = self.loftr_fine(win0, win1)

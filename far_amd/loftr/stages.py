@@ -45,10 +45,13 @@ class CoarseMatching(nn.Module):
         self.variant = 'f16s'
         self.bf16 = False
 
-    def forward(self, feat_c0, feat_c1, data, mask_c0=None, mask_c1=None):
+    def forward(self, feat_c0, feat_c1, data, mask_c0=None, mask_c1=None, overlap=None):
         """feat_c0 [N, L, C], feat_c1 [N, S, C]; updates data with conf_matrix (optional), b_ids, i_ids,
-        j_ids, gt_mask, m_bids, mkpts0_c, mkpts1_c, mconf (coarse_matching.py:144-147, :243-263)."""
+        j_ids, gt_mask, m_bids, mkpts0_c, mkpts1_c, mconf (coarse_matching.py:144-147, :243-263).
+        overlap (inference on the GPU): see ops.coarse_match -- work enqueued behind K1 while the host waits for the match count."""
         if self.training or ag.needs_grad(feat_c0, feat_c1):
+            if overlap is not None:
+                overlap()
             return self._forward_train(feat_c0, feat_c1, data, mask_c0, mask_c1)
         hw0, hw1 = data['hw0_c'], data['hw1_c']
         valid_hw = None
@@ -64,7 +67,7 @@ class CoarseMatching(nn.Module):
         out = ops.coarse_match(feat_c0.float().contiguous(), feat_c1.float().contiguous(), self.temperature,
                                self.thr, self.border_rm, hw0, hw1, scale, as_u8(mask_c0), as_u8(mask_c1),
                                valid_hw, s0, s1, want_conf=self.materialize_conf,
-                               variant='bf16' if self.bf16 else (self.variant if feat_c0.shape[-1] == 256 else 'f32'))
+                               variant='bf16' if self.bf16 else (self.variant if feat_c0.shape[-1] == 256 else 'f32'), overlap=overlap)
         mconf = out['mconf']
         data.update({
             'conf_matrix': out['conf_matrix'],

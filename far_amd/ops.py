@@ -94,12 +94,14 @@ def dual_softmax_stats(f0, f1, feat_div=1.0, sim_div=1.0, sim_mul=1.0, mask0=Non
 
 
 def coarse_match(f0, f1, temperature, thr, border, hw0, hw1, cell_scale, mask0=None, mask1=None,
-                 valid_hw=None, scale0=None, scale1=None, want_conf=False, bf16=False, variant=None):
+                 valid_hw=None, scale0=None, scale1=None, want_conf=False, bf16=False, variant=None, overlap=None):
     """K1.  Returns dict(b_ids, i_ids, j_ids, mconf, mkpts0_c, mkpts1_c, counts, conf_matrix|None).
     variant: 'f32' exact-f32 MFMA (default), 'f16s' split-fp16 operands (fp32-grade), 'bf16' bf16 operands.
 
     One host synchronisation (reading M) is inherent: the reference's outputs have data-dependent shape
-    (torch.where, coarse_matching.py:193).
+    (torch.where, coarse_matching.py:193).  overlap: a callable that enqueues work which does not depend on the matches; it runs
+    between the (asynchronous) copy of the counts and the wait for it, so the GPU has that work to do while the host reads M and
+    prepares the launches that depend on it.
     """
     lib = _lib.load()
     Z, L, C = f0.shape
@@ -128,7 +130,15 @@ def coarse_match(f0, f1, temperature, thr, border, hw0, hw1, cell_scale, mask0=N
         _p(counts), ctypes.c_void_p(counts.data_ptr() + 4 * Z), _p(ws),
         *([_p(overflow_flag(dev))] if variant == 'f16s' else []), _stream())
     _lib.check(rc, 'far_coarse_match_' + variant)
-    counts_h = counts.cpu()
+    if overlap is None:
+        counts_h = counts.cpu()
+    else:
+        counts_h = torch.empty(Z + 1, dtype=torch.int32, pin_memory=True)
+        counts_h.copy_(counts, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+        overlap()
+        done.synchronize()
     M = int(counts_h[Z])
     return {
         'b_ids': b_ids[:M], 'i_ids': i_ids[:M], 'j_ids': j_ids[:M], 'mconf': mconf[:M],
