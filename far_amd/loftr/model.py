@@ -169,9 +169,11 @@ class LoFTR(nn.Module):
         # matches, not the solver's numbers.  Enqueued behind K1 it keeps the GPU busy while the host waits for the match count and
         # prepares the fine-level launches (0.6 ms of idle GPU per step otherwise); forward_rt_prediction finds it in the data dict
         # (_head_features: same tensors, same stamps).  It runs inside this call's activation-range guard like everything else here.
+        # Only when the caller says the head follows (far_amd.pipeline.test_step sets data['_far_head_follows']): a matcher-only
+        # caller (Map-free: match + solve at another resolution) must not pay for -- or trip over -- a stage it never runs.
         overlap = None
-        if (self.head_prefetch and self.config['regress_rt'] and tok0.is_cuda and not train and not torch.is_grad_enabled()
-                and not self.training and getattr(self.loftr_regress, 'cache_features', True)):
+        if (self.head_prefetch and data.get('_far_head_follows') and self.config['regress_rt'] and tok0.is_cuda and not train
+                and not torch.is_grad_enabled() and not self.training and getattr(self.loftr_regress, 'cache_features', True)):
             overlap = lambda: self._head_features(data, tok0, tok1, None, None)
         self.coarse_matching(tok0, tok1, data, mask_c0=m0, mask_c1=m1, overlap=overlap)
         win0, win1 = self.fine_preprocess(data['featmap_f0'], data['featmap_f1'], tok0, tok1, data)

@@ -165,6 +165,31 @@ def test_pipeline_call_order_runs(model):
     assert data['loftr_rt'].shape == (3, 3, 4)
 
 
+def test_head_prefetch_changes_nothing_and_is_only_for_callers_that_run_the_head(model):
+    """pipeline.test_step lets the head's feature stage run behind the coarse matcher (LoFTR.head_prefetch): the same results to
+    the bit as without it; a matcher-only caller -- here at a resolution the head's 60 x 80 position table does not fit, the
+    Map-free use -- gets no head work at all."""
+    from far_amd.pipeline import test_step
+    d1, _, _ = _batch(2, 7)
+    test_step(model, d1, H=256)
+    assert '_far_head_follows' not in d1
+    model.head_prefetch = False
+    try:
+        d2, _, _ = _batch(2, 7)
+        test_step(model, d2, H=256)
+    finally:
+        del model.head_prefetch                                  # back to the class default
+    for k in ('i_ids', 'j_ids', 'mconf', 'mkpts1_f', 'regressed_rt', 'loftr_rt', 'priorRT'):
+        a, b = d1[k], d2[k]
+        assert (torch.equal(a, b) if torch.is_tensor(a) else np.array_equal(a, b)), k
+    im0, im1 = synth.synth_image_pair(1, seed=3)
+    small = {'image0': torch.from_numpy(np.ascontiguousarray(im0[:, :, :240, :320])).cuda(),
+             'image1': torch.from_numpy(np.ascontiguousarray(im1[:, :, :240, :320])).cuda()}
+    with torch.no_grad():
+        model(small)                                             # 30 x 40 coarse tokens: the head could not take them
+    assert model._HEAD_KEY not in small and small['mkpts0_f'].shape[1] == 2
+
+
 def test_cached_prediction_mode_head_only():
     """BASELINE config 4 / `--from_saved_preds`: the matcher is not constructed (loftr.py:20); the dataset supplies
     featmap0/1 + the solver outputs, and only forward_rt_prediction runs (lightning_loftr.py:326,334)."""
