@@ -163,3 +163,34 @@ def test_trainval_inference_merges_a_copied_dict_and_checks_the_supervision_cont
     silent = lambda d, train=False: None if m(dict(d), train=train) else None       # a wrapper that swallows the dict
     with pytest.raises(AssertionError, match='different dict'):
         _trainval_inference(m, dict(labels, dataset_name=['mp3d']), loss_fn, RunCfg(), True, 16, 0, forward=silent)
+
+
+def test_kv_interleaved_weight_layout_is_what_far_linear_kv_expects():
+    """ops.kv_interleaved_weight: rows 64 j + [0, 32) = Wk's rows of head j, 64 j + [32, 64) = Wv's (include/far_hip.h,
+    far_linear_kv_f16s).  With it, the LinearAttention state (linear_attention.py:38-45) read head by head from the fused
+    projection's columns is the one computed from separate k / v projections (oracle/attention.py)."""
+    import numpy as np
+    import torch
+    from far_amd import ops
+    from oracle import attention as oa
+    rng = np.random.default_rng(3)
+    H, D, K, S = 8, 32, 24, 40
+    wk, wv = (torch.from_numpy(rng.standard_normal((H * D, K))) for _ in range(2))
+    w = ops.kv_interleaved_weight(wk, wv, H)
+    assert w.shape == (2 * H * D, K)
+    for j in range(H):
+        assert torch.equal(w[64 * j:64 * j + 32], wk[32 * j:32 * j + 32]) and torch.equal(w[64 * j + 32:64 * j + 64], wv[32 * j:32 * j + 32])
+    x = rng.standard_normal((1, S, K))
+    kv = x @ w.numpy().T                                                  # the fused launch's columns
+    kf = np.where(kv > 0, kv, np.expm1(kv)) + 1
+    q = rng.standard_normal((1, 5, H * D))
+    state = np.stack([kf[0, :, 64 * j:64 * j + 32].T @ (kv[0, :, 64 * j + 32:64 * j + 64] / S) for j in range(H)])     # [H][d][v]
+    ksum = np.stack([kf[0, :, 64 * j:64 * j + 32].sum(0) for j in range(H)])
+    qf = (np.where(q > 0, q, np.expm1(q)) + 1).reshape(5, H, D)
+    out = np.einsum('lhd,hdv->lhv', qf, state) / (np.einsum('lhd,hd->lh', qf, ksum)[..., None] + 1e-6) * S
+    ref = oa.linear_attention(q, x @ wk.numpy().T, x @ wv.numpy().T, H, dtype=np.float64)
+    np.testing.assert_allclose(out.reshape(1, 5, H * D), ref, rtol=1e-10, atol=1e-12)
+    import pytest
+    from far_amd._lib import FarHipError
+    with pytest.raises(FarHipError):
+        ops.kv_interleaved_weight(wk, wv[:64], H)
