@@ -205,8 +205,8 @@ def kernel_rooflines(n_pairs):
     # The attention half of a d_model-256 encoder layer (round 4): K9's Linear mode ending in LinearAttention -- the k | v projection
     # leaves the K'^T V state, the q projection the attention message; q, k, v never reach HBM.  Priced against HBM (the bytes the
     # three launches have to move: the two inputs, the message, the partial states) next to the unfused five launches.
-    S = 4800
-    xs = torch.randn(nimg, S, 256, device=dev, generator=g)
+    s_tok = 4800
+    xs = torch.randn(nimg, s_tok, 256, device=dev, generator=g)
     wq, wk, wv = (torch.randn(256, 256, device=dev, generator=g) / 16 for _ in range(3))
     pq, pkv = ops.PackedConv(wq), ops.PackedConv(torch.cat([wk, wv], 0))
     pst = ops.PackedConv(ops.kv_interleaved_weight(wk, wv, 8))
@@ -217,14 +217,14 @@ def kernel_rooflines(n_pairs):
         return ops.linear_attention(qq, kk, vv, 8)
 
     def fused():
-        _, im = ops.linear_kv_state(xs, pst, S, want_image=True)
-        return ops.linear_q_apply(xs, pq, im, S)
+        _, im = ops.linear_kv_state(xs, pst, s_tok, want_image=True)
+        return ops.linear_q_apply(xs, pq, im, s_tok)
     tu = event_time_ms(unfused, iters=3, warm=1)
     tf = event_time_ms(fused, iters=3, warm=1)
-    nb = 3.0 * xs.numel() * 4 + 2.0 * (nimg * S // 64) * 256 * 33 * 4
+    nb = 3.0 * xs.numel() * 4 + 2.0 * (nimg * s_tok // 64) * 256 * 33 * 4
     out['k_conv[K9 linear + LinearAttention epilogues: q / k | v projections + attention of a d_model-256 layer]'] = dict(
         ms=tf, gbs=nb / tf / 1e6, frac=nb / tf / 1e6 / HBM_PEAK_GBS, unfused_five_launches_ms=tu, speedup=tu / tf,
-        tflops=3 * 2.0 * nimg * S * 256 * 256 / tf / 1e9)
+        tflops=3 * 2.0 * nimg * s_tok * 256 * 256 / tf / 1e9)
     del xs
     return out
 

@@ -395,6 +395,17 @@ class CrossBlock(nn.Module):
         return self.mlp(ops.layernorm(f, self.norm2.weight, self.norm2.bias, self.norm2.eps), residual=f)   # K6 + K9
 
 
+_POSE_STATS_DEV = {}
+
+
+def _pose_stats_on(device):
+    """(pose_mean_6d, pose_std_6d) on `device`, uploaded once (a .to(device) of a pageable CPU tensor per head call was two blocking copies)."""
+    key = str(device)
+    if key not in _POSE_STATS_DEV:
+        _POSE_STATS_DEV[key] = (pose_mean_6d.to(device), pose_std_6d.to(device))
+    return _POSE_STATS_DEV[key]
+
+
 class HeadFeatures:
     """What LocalFeatureTransformerRegressor.compute_features hands to forward_emm on the GPU inference path: the (B, 35840)
     features of transformer.py:497 plus the feature-only part of the two 35840-wide first layers (encoder[0], moe_predictor[0])."""
@@ -497,19 +508,21 @@ class LocalFeatureTransformerRegressor(nn.Module):
             pre, features = features, features.feats
         if not rc['use_simple_moe']:
             return self.pose_regressor(features), (features if rc['save_mlp_feats'] else None), None
-        mean_t, std_t = pose_mean_6d[:3].to(features.device), pose_std_6d[:3].to(features.device)
         if pre is not None:
-            # inference on the GPU: every remaining Linear of the head on K15 (exact fp32, one fma chain per output in a fixed
-            # order: pair b's pose does not depend on the batch it is computed in)
-            pk = self.__dict__.setdefault('_packs', ops.PackCache())
-            lin = lambda name, m, **kw: pk.get(name, [m.weight, m.bias], lambda: ops.PackedRows(m.weight, m.bias, **kw))
-            enc, reg, moe = self.encoder, self.pose_regressor_simple_moe, self.moe_predictor
-            h = torch.relu(pre.enc0 + enc[0].bias)
-            h = ops.rows_linear(h, lin('enc2', enc[2]))
-            h = ops.rows_linear(h, lin('reg0', reg[0]), act='relu')
-            pred_reg_6d = ops.rows_linear(h, lin('reg2', reg[2]))
-        else:
-            pred_reg_6d = self.pose_regressor_simple_moe(self.encoder(features))
+            # inference on the GPU: the 22-number-dependent remainder of the head.  (Captured as ONE HIP graph -- static shapes, ~45
+            # launches -- and replayed it measured the same 8.7-8.9 ms per pair and 89-91 ms per 32 pairs as launched eagerly: without
+            # a profiler attached a launch costs the host ~10 us, no more than these kernels run)
+            pose, gate = self._tail(pre.enc0, pre.moe0, loftr_preds)
+            return pose, (features if rc['save_mlp_feats'] else None), gate
+        mean_t, std_t = (t[:3] for t in _pose_stats_on(features.device))
+        pred_reg_6d = self.pose_regressor_simple_moe(self.encoder(features))
+        gate_in = lambda: self.moe_predictor(torch.cat([features, pred_reg_6d, loftr_preds], dim=-1))
+        pose, gate = self._blend(pred_reg_6d, loftr_preds, gate_in, mean_t, std_t)
+        return pose, (features if rc['save_mlp_feats'] else None), gate
+
+    def _blend(self, pred_reg_6d, loftr_preds, gate_fn, mean_t, std_t):
+        """transformer.py:432-467: the solver's translation at the regressor's length, the gate, the blended pose."""
+        rc = self.config['regress']
         pred_reg_t = pred_reg_6d[..., :3]
         loftr_pred_t = loftr_preds[..., :3]
         if rc['scale_8pt']:
@@ -521,13 +534,7 @@ class LocalFeatureTransformerRegressor(nn.Module):
             loftr_pred_t = (solver_t - mean_t) / std_t
         extra = self.pose_size_in - self.pose_size
         loftr_pred_R = loftr_preds[..., 3:-extra] if extra > 0 else loftr_preds[..., 3:]   # :452-455
-        if pre is not None:
-            tail = torch.cat([pred_reg_6d, loftr_preds.to(pred_reg_6d.dtype)], dim=-1).contiguous()      # (B, 9 + 13)
-            g = ops.rows_linear(tail, lin('moe0-tail', moe[0], cols=(self.H, moe[0].weight.shape[1])), act='relu', add=pre.moe0)
-            g = ops.rows_linear(g, lin('moe2', moe[2]), act='relu')
-            gate = ops.rows_linear(g, lin('moe4', moe[4]), act='sigmoid')
-        else:
-            gate = self.moe_predictor(torch.cat([features, pred_reg_6d, loftr_preds], dim=-1))
+        gate = gate_fn()
         if rc['use_2wt']:
             if rc['use_5050_weight']:
                 raise NotImplementedError('use_5050_weight is a debugging branch in the reference (:461-464)')
@@ -536,8 +543,28 @@ class LocalFeatureTransformerRegressor(nn.Module):
             w_t = w_r = gate[..., 0:1]
         pred_T = w_t * pred_reg_t + (1 - w_t) * loftr_pred_t                               # :466
         pred_R = w_r * pred_reg_6d[..., 3:] + (1 - w_r) * loftr_pred_R                     # :467
-        pose = torch.cat([pred_T, pred_R], dim=-1)
-        return pose, (features if rc['save_mlp_feats'] else None), gate
+        return torch.cat([pred_T, pred_R], dim=-1), gate
+
+    def _tail(self, enc0, moe0, loftr_preds):
+        """The part of the head that reads the solver's numbers (transformer.py:428-467 behind the 35840-wide first layers, whose
+        feature-only halves enc0 / moe0 come from compute_features): every Linear on K15 (exact fp32, one fma chain per output in a
+        fixed order: pair b's pose does not depend on the batch it is computed in).  A pure function of its three tensors and the
+        weights -- about 45 launches of 2-60 us."""
+        pk = self.__dict__.setdefault('_packs', ops.PackCache())
+        lin = lambda name, m, **kw: pk.get(name, [m.weight, m.bias], lambda: ops.PackedRows(m.weight, m.bias, **kw))
+        enc, reg, moe = self.encoder, self.pose_regressor_simple_moe, self.moe_predictor
+        mean_t, std_t = (t[:3] for t in _pose_stats_on(enc0.device))
+        h = torch.relu(enc0 + enc[0].bias)
+        h = ops.rows_linear(h, lin('enc2', enc[2]))
+        h = ops.rows_linear(h, lin('reg0', reg[0]), act='relu')
+        pred_reg_6d = ops.rows_linear(h, lin('reg2', reg[2]))
+
+        def gate_fn():
+            tail = torch.cat([pred_reg_6d, loftr_preds.to(pred_reg_6d.dtype)], dim=-1).contiguous()      # (B, 9 + 13)
+            g = ops.rows_linear(tail, lin('moe0-tail', moe[0], cols=(self.H, moe[0].weight.shape[1])), act='relu', add=moe0)
+            g = ops.rows_linear(g, lin('moe2', moe[2]), act='relu')
+            return ops.rows_linear(g, lin('moe4', moe[4]), act='sigmoid')
+        return self._blend(pred_reg_6d, loftr_preds, gate_fn, mean_t, std_t)
 
     def forward(self, feat0, feat1, loftr_preds=None, inv_loftr_preds=None, mask0=None, mask1=None, F=None,
                 features=None):
