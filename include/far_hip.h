@@ -29,7 +29,8 @@ extern "C" {
 typedef struct ihipStream_t* far_stream_t; /* == hipStream_t */
 
 /* ABI version of this header; bumped when a signature changes (2: activation exponent / overflow flag of K9, K13, K14; 3: the
- * far_wino_* / far_conv3x3_wino_f32 entry points, 16 tuning keys; 4: far_upsample2x_bwd_f32, far_fine_scatter_det_f32, far_bn_train_*, far_adamw_*).  far_amd/_lib.py refuses a library whose version differs. */
+ * far_wino_* / far_conv3x3_wino_f32 entry points, 16 tuning keys; 4: far_upsample2x_bwd_f32, far_fine_scatter_det_f32, far_bn_train_*, far_adamw_*; 5: far_linear_kv_f16s, far_linear_q_apply_f16s,
+ * far_linear_attention_apply_f32, far_prior_from_pose_f32).  far_amd/_lib.py refuses a library whose version differs. */
 int far_abi_version(void);
 /* hipError_t of the most recent failed launch on the calling thread (0 = none): detail behind a -5 return. */
 int far_last_hip_error(void);
