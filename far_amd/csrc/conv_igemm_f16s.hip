@@ -100,9 +100,10 @@ struct ConvArgs {
     int* overflow;               // device flag, |= 1 when an accumulator of this launch is not finite (may be null)
     const float* scale_dev;      // device { act_scale, out_mul } overriding the two fields above (may be null)
     float* kv_part;              // far_linear_kv_f16s (the EPI = 1 instantiations): the columns are the k | v projections of a LoFTR
-    int kv_by0, kv_S, kv_nslot;  // layer, head-interleaved, and the epilogue is la_kv_epilogue (K'^T V partial sums), not a store
+    int kv_S, kv_nslot;          // layer, head-interleaved, and the epilogue is la_kv_epilogue (K'^T V partial sums), not a store
     const unsigned char* kv_img; // far_linear_q_apply_f16s (EPI = 2): per image the K'^T V state as MFMA operands + ksum (KV_IMG_BYTES)
     float la_eps, la_vlen;       // (EPI = 2: kv_S = tokens per image on the query side, la_vlen = the source's length S)
+    int sub2;                    // 1x1 mode on every second pixel of every second row of x (the stride-2 shortcut, resnet_fpn.py:26-29)
 };
 
 __device__ __forceinline__ void split8(const float4& u, const float4& v, float act_scale, f16x8& hi, f16x8& lo) {
@@ -140,6 +141,11 @@ __device__ __forceinline__ void stage_load(Stage<ITERS>& st, const ConvArgs& p, 
         if (KS == 1) {
             pix = tp.pix0 + hp;
             ok = ok && pix < p.npix;
+            if (p.sub2) {                        // output pixel (n, oy, ox) reads input pixel (n, 2 oy, 2 ox): no subsampled copy of x
+                const unsigned up = (unsigned)pix, rowg = up / (unsigned)p.Wo, ox = up - rowg * (unsigned)p.Wo;
+                const unsigned n = rowg / (unsigned)p.Ho, oy = rowg - n * (unsigned)p.Ho;
+                pix = ((long)n * p.H + 2 * oy) * p.W + 2 * ox;
+            }
         } else {
             const int hy = hp / G::HW, hx = hp - hy * G::HW;
             const int iy = ST * tp.oy0 - KS / 2 + hy, ix = ST * tp.ox0 - KS / 2 + hx;
@@ -1084,7 +1090,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p) {
     }
     if constexpr (EPI == 1) {
         static_assert(KS == 1 && NW == 2 && NTW == 4 && !UP && !N7, "the K'^T V epilogue is a mode of the 256-column Linear tiles");
-        la_kv_epilogue(pe, acc, tp.pix0 + 64 * wm, cout_w, lane, act_scale);      // every column block holds k | v (kv_by0 = 0)
+        la_kv_epilogue(pe, acc, tp.pix0 + 64 * wm, cout_w, lane, act_scale);      // every column block holds k | v
         return;
     }
     if (NTW == 4 && ((p.Cout | p.Csub) & 3) == 0) {
@@ -1531,7 +1537,8 @@ int far_grad_scale_f32(const float* x, long n, float* out2, hipStream_t stream) 
 // y[n][oy][ox][co] = act(scale[co] * sum_{ky,kx,ci} X[n][s oy+ky-p][s ox+kx-p][ci] * W[co][ci][ky][kx] + shift[co] + res)
 // X = x [N][H][W][Cin1] (+ x2 [N][H][W][Cin - Cin1]: the input is their channel concatenation, never materialised;
 // x2 = NULL and Cin1 = Cin for a single input); res / y [N][Ho][Wo][Cout] with Ho = (H - 1) / s + 1 (zero padding
-// p = ksize / 2), all fp32 NHWC contiguous; stride s = 1, or 2 for ksize 3; Cin % 4 == 0, Cin1 % 8 == 0.
+// p = ksize / 2), all fp32 NHWC contiguous; stride s = 1, or 2 for ksize 3 (and for ksize 1: x[:, ::2, ::2] read in place, `packed`
+// the stride-1 image); Cin % 4 == 0, Cin1 % 8 == 0.
 // `scale` must include 2^-(w_exp + 4).  act_exp: the activations are multiplied by 2^act_exp before the fp16 split
 // (4 = the default; the kernel corrects `scale` by 2^(4 - act_exp)): inputs up to 65504 / 2^act_exp survive the split, and
 // act_exp can be lowered (down to -24) for tensors beyond 4094 at the price of the absolute resolution of tiny values
@@ -1588,8 +1595,13 @@ int conv_nhwc_impl(const far_conv_desc* desc, const KvMode* kvm, hipStream_t str
     far_clear_errors();
     if (d.act_exp < -24 || d.act_exp > 8) return FAR_EINVAL;
     if (N == 0) return FAR_OK;
+    // ksize 1 with stride 2: the 1x1 convolution of x[:, ::2, ::2] (the down-sampling shortcut) read in place; the weight image is
+    // the stride-1 one
+    const bool sub2 = ksize == 1 && stride == 2;
+    const int pstride = sub2 ? 1 : stride;
     if (!x || !packed || !scale || (!y && !(kvm && kvm->epi == 1)) || N < 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) || Cout <= 0 ||
-        (ksize != 1 && ksize != 3) || stride < 1 || stride > 2 || (stride == 2 && ksize != 3) || act < 0 || act > 2 ||
+        (ksize != 1 && ksize != 3) || stride < 1 || stride > 2 || act < 0 || act > 2 ||
+        (sub2 && (kvm || up || x2 || res_group != 1 || N * (long)((H - 1) / 2 + 1) * ((W - 1) / 2 + 1) > 0x7fffffffL)) ||
         (act == 2 && !(slope >= 0.f && slope <= 1.f)) || x == y || (x2 && x2 == y) || out_planes < 1 || Cout % out_planes)
         return FAR_EINVAL;
     if (res_group < 1 || (res_group > 1 && (!res || ksize != 1 || out_planes != 1 || (N * H * W) % res_group))) return FAR_EINVAL;
@@ -1601,11 +1613,11 @@ int conv_nhwc_impl(const far_conv_desc* desc, const KvMode* kvm, hipStream_t str
         return FAR_EINVAL;
     ConvArgs a;
     a.x = x; a.x2 = x2; a.Cin1 = Cin1; a.w = (const unsigned char*)packed; a.scale = scale;
-    a.zeros = reinterpret_cast<const float*>((const unsigned char*)packed + far_conv_packed_bytes(Cin, Cout, ksize, stride, split) - 32); a.shift = shift; a.res = res; a.res_group = res_group; a.y = y;
+    a.zeros = reinterpret_cast<const float*>((const unsigned char*)packed + far_conv_packed_bytes(Cin, Cout, ksize, pstride, split) - 32); a.shift = shift; a.res = res; a.res_group = res_group; a.y = y;
     a.ln_gamma = ln_gamma; a.ln_beta = ln_beta; a.ln_eps = ln_eps; a.post_res = post_res; a.up = up;
     a.H = H; a.W = W; a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1; a.Cin = Cin; a.Cout = Cout; a.Csub = Cout / out_planes;
     a.npix = N * a.Ho * a.Wo;
-    const TileCfg c = cfg_for(Cout, stride);
+    const TileCfg c = cfg_for(Cout, pstride);
     if ((ln_gamma || post_res) && (!ln_gamma || !ln_beta || Cout != c.nt || out_planes != 1 || (Cout & 3) || post_res == y))
         return FAR_EINVAL;                    // the fused LayerNorm needs the whole channel row in one block (Cout 128 or 256)
     const int th = 4 * c.mw;
@@ -1615,11 +1627,12 @@ int conv_nhwc_impl(const far_conv_desc* desc, const KvMode* kvm, hipStream_t str
     a.act = act; a.slope = slope;
     a.act_scale = ldexpf(1.0f, d.act_exp); a.out_mul = ldexpf(1.0f, ACT_EXP_DEFAULT - d.act_exp); a.overflow = d.overflow;
     a.scale_dev = d.act_scale_dev;
-    a.kv_part = kvm ? kvm->part : nullptr; a.kv_by0 = 0; a.kv_S = kvm ? kvm->S : 0; a.kv_nslot = kvm ? kvm->nslot : 0;
+    a.kv_part = kvm ? kvm->part : nullptr; a.kv_S = kvm ? kvm->S : 0; a.kv_nslot = kvm ? kvm->nslot : 0;
+    a.sub2 = sub2 ? 1 : 0;
     a.kv_img = kvm ? kvm->img : nullptr; a.la_eps = kvm ? kvm->eps : 0.f; a.la_vlen = kvm ? kvm->vlen : 0.f;
     long nbx = ksize == 1 ? (a.npix + 64 * c.mw - 1) / (64 * c.mw) : N * a.tilesX * a.tilesY;
     // a Linear layer over the tokens of one or two images: the few-row kernel (linear_small_f16s.hip; same image, same arithmetic)
-    if (ksize == 1 && !kvm && !up && !x2 && !ln_gamma && !post_res && res_group == 1 && split && nbx * a.nblkY < 512 &&
+    if (ksize == 1 && !sub2 && !kvm && !up && !x2 && !ln_gamma && !post_res && res_group == 1 && split && nbx * a.nblkY < 512 &&
         far_get_tuning(7) == 0 && far_linear_small_covers(a.npix, Cin, Cout)) {
         LinSmallArgs s;
         s.x = x; s.w = a.w; s.scale = scale; s.shift = shift; s.res = res; s.y = y; s.rows = a.npix;
@@ -1633,7 +1646,7 @@ int conv_nhwc_impl(const far_conv_desc* desc, const KvMode* kvm, hipStream_t str
     a.ntiles = nbx;
     if (nbx * a.nblkY > 0x7fffffffL) return FAR_EINVAL;
     dim3 grid((unsigned)(nbx * a.nblkY));
-    if (stride == 2) return split ? launch_stride2<true>(a, grid, stream) : launch_stride2<false>(a, grid, stream);
+    if (stride == 2 && ksize == 3) return split ? launch_stride2<true>(a, grid, stream) : launch_stride2<false>(a, grid, stream);
     if (ksize == 3) return split ? launch_cfg<3, true>(c, a, grid, stream) : launch_cfg<3, false>(c, a, grid, stream);
     if (kvm) {                                     // (validated by far_linear_kv_f16s: 256-column blocks, split operands)
         if (c.mw != 2 || !split) return FAR_EINVAL;

@@ -171,7 +171,7 @@ class ResNetFPN_8_2(nn.Module):
         if blk.downsample is None:
             res = x
         else:        # 1x1 stride-2 shortcut: K9 on the subsampled pixels, its BatchNorm folded
-            res = ops.conv_nhwc(x[:, ::2, ::2, :].contiguous(), pk.get(name + '.down', blk.downsample[0], blk.downsample[1], sp))
+            res = ops.conv_nhwc(x, pk.get(name + '.down', blk.downsample[0], blk.downsample[1], sp), in_stride=2)   # x[:, ::2, ::2] in place
         return ops.conv_nhwc(y, pk.get(name + '.conv2', blk.conv2, blk.bn2, sp), residual=res, act='relu')
 
     def _forward_fused(self, x):

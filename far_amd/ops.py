@@ -1422,14 +1422,17 @@ def grad_scale(x):
 
 
 def conv_nhwc(x, pc, residual=None, act='none', slope=0.01, x2=None, out_planes=1, res_group=1, ln=None,
-              post_residual=None, out=None, up=None, act_scale_dev=None):
+              post_residual=None, out=None, up=None, act_scale_dev=None, in_stride=1):
     """K9.  x (N, H, W, Cin) fp32 contiguous -> act(conv(x) * scale + shift (+ residual)) as (N, H, W, Cout).
     With x2 (N, H, W, C2) the convolution input is cat([x, x2], -1), read in place.  out_planes = P > 1 returns
     (P, N, H, W, Cout / P): the output channels split into P separate contiguous tensors.
     up (N, H/2, W/2, Cout), 1x1 convolutions: + F.interpolate(up, scale_factor=2, bilinear, align_corners=True)
-    in the epilogue (the FPN merge)."""
+    in the epilogue (the FPN merge).  in_stride = 2 (1x1 weights): the convolution of x[:, ::2, ::2] read in place -- the
+    down-sampling shortcut of a BasicBlock (resnet_fpn.py:26-29) without the subsampled copy."""
     lib = _lib.load()
     N, H, W, Cin1 = x.shape
+    if in_stride not in (1, 2) or (in_stride == 2 and (pc.ksize != 1 or pc.stride != 1 or x2 is not None or up is not None or res_group != 1)):
+        raise _lib.FarHipError('conv_nhwc: in_stride = 2 is the in-place subsampling of a plain 1x1 convolution')
     if (USE_WINO and pc.ksize == 3 and pc.stride == 1 and pc.split and x2 is None and out_planes == 1 and res_group == 1 and ln is None
             and post_residual is None and up is None and act_scale_dev is None and not torch.is_grad_enabled()
             and activation_exponent_value() >= WINO_MIN_ACT_EXP and H * W >= WINO_MIN_PIXELS and H * W * pc.Cout < 2 ** 31):
@@ -1442,7 +1445,7 @@ def conv_nhwc(x, pc, residual=None, act='none', slope=0.01, x2=None, out_planes=
     Cin = Cin1 + (x2.shape[-1] if x2 is not None else 0)
     if Cin != pc.Cin or (x2 is not None and tuple(x2.shape[:3]) != (N, H, W)):
         raise _lib.FarHipError(f'conv_nhwc: input has {Cin} channels, weights expect {pc.Cin}')
-    st = pc.stride
+    st = pc.stride * in_stride
     if pc.Cout % out_planes:
         raise _lib.FarHipError('conv_nhwc: out_planes must divide the output channel count')
     shape = (N, (H - 1) // st + 1, (W - 1) // st + 1, pc.Cout // out_planes)

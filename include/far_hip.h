@@ -422,7 +422,9 @@ int far_pack_table_run(const void* table_dev, int n, far_stream_t stream);
  *   X = x [N][H][W][Cin1] or, with x2 != NULL, the channel concatenation [x | x2] (x2 [N][H][W][Cin - Cin1],
  *   Cin1 % 8 == 0; never materialised: transformer.py:64 torch.cat); Cin1 = Cin when x2 == NULL.
  *   y [N][Ho][Wo][Cout], Ho = (H - 1) / stride + 1; fp32 NHWC, zero padding ksize / 2, Cin % 4 == 0; stride 1, or 2
- *   with ksize 3 (resnet_fpn.py:19 conv3x3(in_planes, planes, stride)).  A linear layer y = x W^T + b is ksize = 1,
+ *   with ksize 3 (resnet_fpn.py:19 conv3x3(in_planes, planes, stride)); ksize 1 with stride 2 = the 1x1 convolution of
+ *   x[:, ::2, ::2] read in place (resnet_fpn.py:26-29, the down-sampling shortcut conv1x1(in_planes, planes, stride=2)): `packed`
+ *   is the stride-1 image of the weight; no x2 / up / res_group.  A linear layer y = x W^T + b is ksize = 1,
  *   N = H = 1, W = rows, shift = b.
  *   packed / scale: from far_conv_pack_f32 (scale includes 2^-(w_exp + 4)); shift, res may be NULL.
  *   act: 0 none, 1 ReLU, 2 LeakyReLU(slope).  split: 1 = hi + lo operand pairs, 0 = plain fp16 operands.

@@ -450,6 +450,24 @@ def test_conv_fused_upsample_merge_is_bit_identical_to_conv_plus_k8(N, H, W, Cin
         ops.conv_nhwc(x, ops.PackedConv(torch.randn(Cout, Cin, 3, 3, device='cuda', generator=g)), up=coarse)
 
 
+@pytest.mark.parametrize('N,H,W,Cin,Cout', [(2, 24, 32, 128, 196), (3, 15, 21, 64, 128), (1, 240, 320, 128, 208), (5, 8, 6, 196, 256)])
+def test_conv1x1_on_subsampled_input_in_place(N, H, W, Cin, Cout):
+    """in_stride = 2: the down-sampling shortcut conv1x1(stride 2) + BatchNorm (resnet_fpn.py:26-29) reading x[:, ::2, ::2] in
+    place -- the same bits as the convolution of the subsampled copy (odd sizes included), with residual and activation."""
+    ops = _ops()
+    g = torch.Generator(device='cuda').manual_seed(H * W + Cin)
+    x = torch.randn(N, H, W, Cin, device='cuda', generator=g)
+    pc = ops.PackedConv(torch.randn(Cout, Cin, 1, 1, device='cuda', generator=g) * 0.1, torch.rand(Cout, device='cuda', generator=g) + 0.5,
+                        torch.randn(Cout, device='cuda', generator=g))
+    sub = x[:, ::2, ::2, :].contiguous()
+    res = torch.randn(*sub.shape[:3], Cout, device='cuda', generator=g)
+    assert torch.equal(ops.conv_nhwc(x, pc, in_stride=2), ops.conv_nhwc(sub, pc))
+    assert torch.equal(ops.conv_nhwc(x, pc, residual=res, act='relu', in_stride=2), ops.conv_nhwc(sub, pc, residual=res, act='relu'))
+    from far_amd._lib import FarHipError
+    with pytest.raises(FarHipError):
+        ops.conv_nhwc(x, ops.PackedConv(torch.randn(Cout, Cin, 3, 3, device='cuda', generator=g)), in_stride=2)
+
+
 def test_conv_is_run_to_run_deterministic_under_load():
     """K9's slab / pixel waits count memory requests; an under-wait would be a race.  Same launch repeated with other
     work in flight on a second stream: every output bit-identical to the first (tools/k9_stress.py is the long form)."""
