@@ -90,6 +90,7 @@ SIGNATURES = {
     'far_linear_kv_image_bytes': (c_sz, [c_l]),
     'far_linear_kv_f16s': (c_i, [c_p, c_i, c_p, c_p, c_p, c_p]),
     'far_linear_q_apply_f16s': (c_i, [c_p, c_i, c_i, c_p, c_f, c_p]),
+    'far_linear_gather_f16s': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_l, c_i, c_i, c_p]),
     'far_wino_packed_bytes': (c_sz, [c_i, c_i]),
     'far_wino_pack_view_scaled_f32': (c_i, [c_p, c_l, c_l, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
     'far_conv3x3_wino_f32': (c_i, [c_p, c_p]),                # (const far_conv_desc*, stream): K17

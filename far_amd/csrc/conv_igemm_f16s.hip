@@ -104,6 +104,9 @@ struct ConvArgs {
     const unsigned char* kv_img; // far_linear_q_apply_f16s (EPI = 2): per image the K'^T V state as MFMA operands + ksum (KV_IMG_BYTES)
     float la_eps, la_vlen;       // (EPI = 2: kv_S = tokens per image on the query side, la_vlen = the source's length S)
     int sub2;                    // 1x1 mode on every second pixel of every second row of x (the stride-2 shortcut, resnet_fpn.py:26-29)
+    const long* g_b;             // far_linear_gather_f16s (EPI = 3): row r of the launch is token r % (W W) of window r / (W W), read
+    const long* g_cell;          // straight from the fine map x [n][Hf][Wf][Cin] at the window's position (fine_preprocess.py:40-47)
+    int g_wc, g_W, g_stride, g_Hf, g_Wf;
 };
 
 __device__ __forceinline__ void split8(const float4& u, const float4& v, float act_scale, f16x8& hi, f16x8& lo) {
@@ -129,7 +132,8 @@ struct TilePos {
 };
 
 template <int KS, int MW, int ST, int NTHR, int ITERS>
-__device__ __forceinline__ void stage_load(Stage<ITERS>& st, const ConvArgs& p, const TilePos& tp, int chunk, int tid, bool live = true) {
+__device__ __forceinline__ void stage_load(Stage<ITERS>& st, const ConvArgs& p, const TilePos& tp, int chunk, int tid, bool live = true,
+                                           const int* rowpix = nullptr) {
     using G = Geo<KS, MW, ST>;
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
@@ -141,7 +145,11 @@ __device__ __forceinline__ void stage_load(Stage<ITERS>& st, const ConvArgs& p, 
         if (KS == 1) {
             pix = tp.pix0 + hp;
             ok = ok && pix < p.npix;
-            if (p.sub2) {                        // output pixel (n, oy, ox) reads input pixel (n, 2 oy, 2 ox): no subsampled copy of x
+            if (rowpix) {                        // gather mode: the input pixel of each row of the tile, from the workgroup's LDS table
+                const int gp = rowpix[hp < 64 * MW ? hp : 0];
+                pix = gp;
+                ok = ok && gp >= 0;
+            } else if (p.sub2) {                 // output pixel (n, oy, ox) reads input pixel (n, 2 oy, 2 ox): no subsampled copy of x
                 const unsigned up = (unsigned)pix, rowg = up / (unsigned)p.Wo, ox = up - rowg * (unsigned)p.Wo;
                 const unsigned n = rowg / (unsigned)p.Ho, oy = rowg - n * (unsigned)p.Ho;
                 pix = ((long)n * p.H + 2 * oy) * p.W + 2 * ox;
@@ -931,9 +939,34 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
+    // ---- gather mode (EPI = 3, far_linear_gather_f16s): the tile's rows are window tokens; where each one lies in the fine map is
+    // worked out ONCE per workgroup (one thread per row: two index loads, three divisions) into a table behind the loop's LDS buffers
+    // -- inside the epilogue's region, which is only used after the last staging pass
+    const int* rowpix = nullptr;
+    if constexpr (EPI == 3) {
+        static_assert(KS == 1 && !UP && !N7, "gather mode is a Linear-mode input form");
+        int* tab = reinterpret_cast<int*>(smem + A_BUF + 3 * B_BUF);
+        if (tid < 64 * MW) {
+            const long row = tp.pix0 + tid;
+            int gp = -1;
+            if (row < p.npix) {
+                const unsigned ww = (unsigned)(p.g_W * p.g_W), urow = (unsigned)row;
+                const unsigned w = urow / ww, t = urow - w * ww;
+                const unsigned cell = (unsigned)p.g_cell[w], b = (unsigned)p.g_b[w];
+                const int cy = (int)(cell / (unsigned)p.g_wc), cx = (int)(cell - (unsigned)cy * (unsigned)p.g_wc);
+                const int ky = (int)(t / (unsigned)p.g_W), kx = (int)(t - (unsigned)ky * (unsigned)p.g_W);
+                const int y = cy * p.g_stride - p.g_W / 2 + ky, x = cx * p.g_stride - p.g_W / 2 + kx;
+                if ((unsigned)y < (unsigned)p.g_Hf && (unsigned)x < (unsigned)p.g_Wf) gp = ((int)b * p.g_Hf + y) * p.g_Wf + x;
+            }
+            tab[tid] = gp;
+        }
+        __syncthreads();
+        rowpix = tab;
+    }
+
     // ---- prologue: pixels of chunk 0, weight slabs of phases 0 and 1 (the ring runs two phases ahead)
     Stage<ITERS> st;
-    stage_load<KS, MW, ST, NTHR, ITERS>(st, p, tp, 0, tid);
+    stage_load<KS, MW, ST, NTHR, ITERS>(st, p, tp, 0, tid, true, rowpix);
     prefetch();
     prefetch();
     stage_store<KS, MW, ST, NTHR, ITERS, SPLIT>(st, As, tid, act_scale);
@@ -1023,7 +1056,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p) {
                 prefetch();
                 if (tap == LOAD_TAP && ks == 0) __builtin_amdgcn_sched_barrier(0);   // the slab's DMAs stay ahead of the pixel loads (the waits count on it)
                 if (tap == LOAD_TAP && ks == 0)            // unconditional (no branch in the body): the last chunk requests zeros
-                    stage_load<KS, MW, ST, NTHR, ITERS>(st, p, tp, chunk + 1, tid, chunk + 1 < nchunks);
+                    stage_load<KS, MW, ST, NTHR, ITERS>(st, p, tp, chunk + 1, tid, chunk + 1 < nchunks, rowpix);
 #pragma unroll
                 for (int grp = 0; grp < NGRP; ++grp) {
                     if (grp + 1 < NGRP) read_b(grp + 1, B);
@@ -1388,7 +1421,8 @@ int launch_conv(const ConvArgs& a, dim3 grid, hipStream_t stream) {
     constexpr int smem_loop = PLANES * G::A_PLANE + 3 * 2 * 32 * NTW * NW * 32;
     constexpr int smem_epi = EPI == 2 ? MW * NW * 32 * LDW * 4        // la_apply_epilogue: padded rows
                                       : MW * NW * (32 * 128 * 4 + 32 * 4);  // conv_epilogue_wide: 16 KiB per wave + LayerNorm exchange
-    constexpr int smem = smem_loop > smem_epi ? smem_loop : smem_epi;
+    constexpr int smem_need = smem_loop + (EPI == 3 ? 64 * MW * 4 : 0);            // gather mode: + the row table behind the loop buffers
+    constexpr int smem = smem_need > smem_epi ? smem_need : smem_epi;
     bool cfg_failed = false;
     FAR_ONCE_PER_DEVICE(cfg_failed = hipFuncSetAttribute((const void*)k_conv<KS, MW, NW, NTW, SPLIT, ST, UP, N7, EPI>,
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess);
@@ -1579,6 +1613,8 @@ struct KvMode {                                       // far_linear_kv_f16s (epi
     int S, nslot;
     const unsigned char* img;
     float eps, vlen;
+    const long *g_b = nullptr, *g_cell = nullptr;     // epi 3 (far_linear_gather_f16s)
+    int g_wc = 0, g_W = 0, g_stride = 0, g_Hf = 0, g_Wf = 0;
 };
 
 int conv_nhwc_impl(const far_conv_desc* desc, const KvMode* kvm, hipStream_t stream) {
@@ -1629,6 +1665,7 @@ int conv_nhwc_impl(const far_conv_desc* desc, const KvMode* kvm, hipStream_t str
     a.scale_dev = d.act_scale_dev;
     a.kv_part = kvm ? kvm->part : nullptr; a.kv_S = kvm ? kvm->S : 0; a.kv_nslot = kvm ? kvm->nslot : 0;
     a.sub2 = sub2 ? 1 : 0;
+    a.g_b = a.g_cell = nullptr; a.g_wc = a.g_W = a.g_stride = a.g_Hf = a.g_Wf = 0;
     a.kv_img = kvm ? kvm->img : nullptr; a.la_eps = kvm ? kvm->eps : 0.f; a.la_vlen = kvm ? kvm->vlen : 0.f;
     long nbx = ksize == 1 ? (a.npix + 64 * c.mw - 1) / (64 * c.mw) : N * a.tilesX * a.tilesY;
     // a Linear layer over the tokens of one or two images: the few-row kernel (linear_small_f16s.hip; same image, same arithmetic)
@@ -1648,6 +1685,14 @@ int conv_nhwc_impl(const far_conv_desc* desc, const KvMode* kvm, hipStream_t str
     dim3 grid((unsigned)(nbx * a.nblkY));
     if (stride == 2 && ksize == 3) return split ? launch_stride2<true>(a, grid, stream) : launch_stride2<false>(a, grid, stream);
     if (ksize == 3) return split ? launch_cfg<3, true>(c, a, grid, stream) : launch_cfg<3, false>(c, a, grid, stream);
+    if (kvm && kvm->epi == 3) {                    // gather mode: rows read from the fine map through the window indices
+        if (!split) return FAR_EINVAL;
+        a.g_b = kvm->g_b; a.g_cell = kvm->g_cell; a.g_wc = kvm->g_wc; a.g_W = kvm->g_W; a.g_stride = kvm->g_stride;
+        a.g_Hf = kvm->g_Hf; a.g_Wf = kvm->g_Wf;
+        if (small) { nbx = (a.npix + 64 * c.mw - 1) / (64 * c.mw); a.ntiles = nbx; grid = dim3((unsigned)(nbx * a.nblkY)); }   // full-height tiles only
+        return c.mw == 4 ? launch_conv<1, 4, 1, 4, true, 1, 0, false, 3>(a, grid, stream)
+                         : launch_conv<1, 2, 2, 4, true, 1, 0, false, 3>(a, grid, stream);
+    }
     if (kvm) {                                     // (validated by far_linear_kv_f16s: 256-column blocks, split operands)
         if (c.mw != 2 || !split) return FAR_EINVAL;
         if (kvm->epi == 2)
@@ -1712,6 +1757,28 @@ int far_linear_q_apply_f16s(const far_conv_desc* desc, int L, int S, const void*
         d.act_scale_dev)
         return FAR_EINVAL;
     KvMode m{2, nullptr, L, 1, (const unsigned char*)kv_img, eps, (float)S};
+    return conv_nhwc_impl(desc, &m, stream);
+}
+
+// merge_feat of FinePreprocess (fine_preprocess.py:40-57) without the window tensor: desc describes a Linear layer (ksize 1, N = H = 1,
+// W = rows, split operands; residual / res_group / activation as far_conv_nhwc_f32) whose input rows are NOT stored anywhere -- row r
+// is token r % (W W) of window r / (W W), i.e. pixel (cy stride - W / 2 + ky, cx stride - W / 2 + kx) of image b_ids[window] of the fine
+// map desc.x [n_img][Hf][Wf][Cin] (NHWC, zero outside), (cy, cx) = divmod(cell_ids[window], wc), (ky, kx) = divmod(token, W): what
+// far_fine_gather_f32 would have written as [windows][W W][Cin] for this launch to read back.  rows % (W W) == 0.
+int far_linear_gather_f16s(const far_conv_desc* desc, const int64_t* b_ids, const int64_t* cell_ids, int wc, int W, int stride,
+                           long n_img, int Hf, int Wf, hipStream_t stream) {
+    if (!desc) return FAR_EINVAL;
+    const far_conv_desc& d = *desc;
+    far_clear_errors();
+    const long rows = d.N * d.H * d.W;
+    if (rows == 0) return FAR_OK;
+    if (!b_ids || !cell_ids || wc <= 0 || W <= 0 || W > 15 || stride <= 0 || n_img <= 0 || Hf <= 0 || Wf <= 0 || rows < 0 ||
+        rows % (W * W) || rows > 0x7fffffffL || n_img * Hf * (long)Wf > 0x7fffffffL || d.ksize != 1 || d.stride != 1 || !d.split ||
+        d.x2 || d.up || d.ln_gamma || d.post_res || d.act_scale_dev || d.out_planes != 1)
+        return FAR_EINVAL;
+    KvMode m{3, nullptr, 0, 0, nullptr, 0.f, 0.f};
+    m.g_b = reinterpret_cast<const long*>(b_ids); m.g_cell = reinterpret_cast<const long*>(cell_ids);
+    m.g_wc = wc; m.g_W = W; m.g_stride = stride; m.g_Hf = Hf; m.g_Wf = Wf;
     return conv_nhwc_impl(desc, &m, stream);
 }
 

@@ -13,6 +13,8 @@ FineMatching on kernel K3b.  Mirrors mp3d_loftr/src/loftr/utils/fine_matching.py
 """
 import math
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -204,6 +206,19 @@ class FinePreprocess(nn.Module):
             if p.dim() > 1:
                 nn.init.kaiming_normal_(p, mode="fan_out", nonlinearity="relu")
 
+    fused_gather = os.environ.get('FAR_NO_GATHER_FUSE', '') != '1'   # inference: merge_feat reads the fine map through the window indices
+
+    def _fused_gather_ok(self, f0, f1, feat_c0, data):
+        """K9's gather mode applies: inference on the GPU with fine_concat_coarse_feat, and the two fine maps are the halves of one
+        NHWC (channels_last) fp32 buffer of equal shape (what the fused backbone returns for equally sized images)."""
+        if not (self.fused_gather and self.cat_c_feat and f0.is_cuda and f0.dtype == torch.float32 and f0.shape == f1.shape
+                and data['hw0_c'][1] == data['hw1_c'][1] and not ag.needs_grad(feat_c0, self.merge_feat.weight, self.down_proj.weight)):
+            return False
+        n, C, H, Wd = f0.shape
+        nhwc = (H * Wd * C, 1, Wd * C, C)
+        return (tuple(f0.stride()) == nhwc and tuple(f1.stride()) == nhwc and C == self.d_model_f and
+                f0.untyped_storage().data_ptr() == f1.untyped_storage().data_ptr() and f1.storage_offset() == f0.storage_offset() + f0.numel())
+
     def forward(self, feat_f0, feat_f1, feat_c0, feat_c1, data):
         W = self.W
         stride = data['hw0_f'][0] // data['hw0_c'][0]
@@ -220,6 +235,26 @@ class FinePreprocess(nn.Module):
             else:
                 w0 = ag.fine_windows(feat_f0, b, i, W, stride)
                 w1 = ag.fine_windows(feat_f1, b, j, W, stride)
+        elif self._fused_gather_ok(feat_f0, feat_f1, feat_c0, data):
+            # the windows are never stored: merge_feat's Linear launch reads its rows through the window indices (K9 gather mode),
+            # both images in one launch -- feat_f0 / feat_f1 are the halves of the backbone's one NHWC buffer
+            M = b.shape[0]
+            n = feat_f0.shape[0]
+            fmap = torch.as_strided(feat_f0, (2 * n, feat_f0.shape[2], feat_f0.shape[3], feat_f0.shape[1]),
+                                    (feat_f0.stride(0), feat_f0.stride(2), feat_f0.stride(3), 1))
+            pk = self.__dict__.setdefault('_packs', ops.PackCache())
+            dw, db = self.down_proj.weight, self.down_proj.bias
+            c_in = torch.cat([feat_c0[b, i], feat_c1[b, j]], 0)
+            c_win = ops.linear_f16s(c_in.contiguous(), pk.get('down', [dw, db], lambda: ops.PackedConv(dw, None, db)))
+            d = self.d_model_f
+            wt = self.merge_feat.weight
+            pf = pk.get('merge_f', [wt], lambda: ops.PackedConv(wt[:, :d].contiguous()))
+            pc = pk.get('merge_c', [wt, self.merge_feat.bias],
+                        lambda: ops.PackedConv(wt[:, d:].contiguous(), None, self.merge_feat.bias))
+            cw = ops.linear_f16s(c_win.contiguous(), pc)                              # (2M, d)
+            both = ops.linear_gather_f16s(fmap, torch.cat([b, b + n]), torch.cat([i, j]), data['hw0_c'][1], W, stride, pf,
+                                          residual=cw, res_group=W ** 2)
+            return both[:M], both[M:]
         else:       # both images' windows into the halves of one buffer: the later cat([w0, w1]) is then free
             M = b.shape[0]
             w01 = torch.empty(2 * M, W ** 2, feat_f0.shape[1], dtype=torch.float32, device=feat_f0.device)

@@ -1500,12 +1500,32 @@ def kv_interleaved_weight(wk, wv, nhead):
     return torch.stack([wk.reshape(nhead, 32, K), wv.reshape(nhead, 32, K)], 1).reshape(2 * C, K)
 
 
-def _linear_desc(x, pc, rows, y, out_planes):
+def _linear_desc(x, pc, rows, y, out_planes, residual=None, res_group=1, act='none'):
     ptr = lambda t: _p(t, torch.float32).value
-    return _lib.ConvDesc(x=ptr(x), x2=None, packed=_p(pc.packed).value, scale=ptr(pc.scale), shift=ptr(pc.shift), res=None, ln_gamma=None,
-                         ln_beta=None, post_res=None, up=None, y=ptr(y), N=1, H=1, W=rows, Cin=pc.Cin, Cin1=pc.Cin, Cout=pc.Cout,
-                         ksize=1, stride=1, act=0, split=1, out_planes=out_planes, res_group=1, slope=0.0, ln_eps=0.0,
-                         act_exp=activation_exponent_value(), overflow=overflow_flag(x.device).data_ptr(), act_scale_dev=None)
+    return _lib.ConvDesc(x=ptr(x), x2=None, packed=_p(pc.packed).value, scale=ptr(pc.scale), shift=ptr(pc.shift), res=ptr(residual),
+                         ln_gamma=None, ln_beta=None, post_res=None, up=None, y=ptr(y), N=1, H=1, W=rows, Cin=pc.Cin, Cin1=pc.Cin,
+                         Cout=pc.Cout, ksize=1, stride=1, act=_ACT[act], split=1, out_planes=out_planes, res_group=int(res_group),
+                         slope=0.0, ln_eps=0.0, act_exp=activation_exponent_value(), overflow=overflow_flag(x.device).data_ptr(),
+                         act_scale_dev=None)
+
+
+def linear_gather_f16s(fmap, b_ids, cell_ids, wc, W, stride, pc, residual=None, res_group=1, act='none'):
+    """K9 reading its rows through K3's window indices (far_linear_gather_f16s): fmap (n_img, Hf, Wf, C) fp32 NHWC contiguous,
+    b_ids / cell_ids (M,) int64 -> act(windows W^T * scale + shift (+ residual)) as (M, W * W, Cout), where `windows` =
+    fine_gather(fmap, b_ids, cell_ids, wc, W, stride) is never stored.  residual / res_group as linear_f16s."""
+    lib = _lib.load()
+    n_img, Hf, Wf, C = fmap.shape
+    M = int(b_ids.shape[0])
+    if not fmap.is_contiguous() or fmap.dtype != torch.float32 or C != pc.Cin or pc.ksize != 1 or not pc.split:
+        raise _lib.FarHipError('linear_gather_f16s: needs a contiguous fp32 NHWC map and a split-operand Linear image of its channel count')
+    rows = M * W * W
+    out = torch.empty(M, W * W, pc.Cout, dtype=torch.float32, device=fmap.device)
+    if rows:
+        d = _linear_desc(fmap, pc, rows, out, 1, residual=residual, res_group=res_group, act=act)
+        rc = lib.far_linear_gather_f16s(ctypes.byref(d), _p(b_ids, torch.int64), _p(cell_ids, torch.int64), int(wc), int(W), int(stride),
+                                        int(n_img), int(Hf), int(Wf), _stream())
+        _lib.check(rc, 'far_linear_gather_f16s')
+    return out
 
 
 def linear_kv_state(x, pc, S, want_image=False):

@@ -30,7 +30,7 @@ typedef struct ihipStream_t* far_stream_t; /* == hipStream_t */
 
 /* ABI version of this header; bumped when a signature changes (2: activation exponent / overflow flag of K9, K13, K14; 3: the
  * far_wino_* / far_conv3x3_wino_f32 entry points, 16 tuning keys; 4: far_upsample2x_bwd_f32, far_fine_scatter_det_f32, far_bn_train_*, far_adamw_*; 5: far_linear_kv_f16s, far_linear_q_apply_f16s,
- * far_linear_attention_apply_f32, far_prior_from_pose_f32).  far_amd/_lib.py refuses a library whose version differs. */
+ * far_linear_gather_f16s, far_linear_attention_apply_f32, far_prior_from_pose_f32).  far_amd/_lib.py refuses a library whose version differs. */
 int far_abi_version(void);
 /* hipError_t of the most recent failed launch on the calling thread (0 = none): detail behind a -5 return. */
 int far_last_hip_error(void);
@@ -489,6 +489,15 @@ int far_linear_kv_f16s(const far_conv_desc* desc, int S, void* ws, float* kv, vo
  * far_linear_attention_apply_f32's launch disappears.  kv_img: far_linear_kv_f16s's image of the SOURCE tokens under the same
  * act_exp (image i serves rows [i L, (i + 1) L)); L = tokens per image on the query side (L % 64 == 0), S = the source's length. */
 int far_linear_q_apply_f16s(const far_conv_desc* desc, int L, int S, const void* kv_img, float eps, far_stream_t stream);
+
+/* merge_feat of FinePreprocess (fine_preprocess.py:40-57) without the window tensor: K9's Linear mode reading its input rows
+ * straight from the fine feature map.  desc: a Linear layer (ksize 1, N = H = 1, W = rows, split = 1; shift / res / res_group / act
+ * as far_conv_nhwc_f32) with desc.x = the fine map [n_img][Hf][Wf][Cin] (NHWC); row r of the launch is token r % (W W) of window
+ * r / (W W): pixel (cy stride - W / 2 + ky, cx stride - W / 2 + kx) of image b_ids[window], zero outside the map, (cy, cx) =
+ * divmod(cell_ids[window], wc), (ky, kx) = divmod(token, W) -- the rows far_fine_gather_f32 would have written for the launch to
+ * read back.  rows % (W W) == 0, W <= 15. */
+int far_linear_gather_f16s(const far_conv_desc* desc, const int64_t* b_ids, const int64_t* cell_ids, int wc, int W, int stride,
+                           long n_img, int Hf, int Wf, far_stream_t stream);
 
 /* K17: the stride-1 3x3 convolutions as Winograd F(2x2, 3x3) on the f16 matrix cores with split operands (conv_wino_f16s.hip):
  * far_conv_nhwc_f32's contract for ksize = 3, stride = 1, split = 1 at 2.25x fewer matrix instructions -- resnet_fpn.py:5-12

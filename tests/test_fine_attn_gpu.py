@@ -66,6 +66,26 @@ def test_linear_attention(N, L, S, C):
     np.testing.assert_allclose(got, ref, atol=1e-5 * np.abs(ref).max(), rtol=1e-4)
 
 
+@pytest.mark.parametrize('N,Hf,Wf,M,Cout', [(4, 48, 64, 300, 128), (2, 30, 44, 777, 128), (3, 24, 32, 1, 128), (2, 48, 64, 500, 256)])
+def test_linear_reads_fine_windows_through_the_indices(N, Hf, Wf, M, Cout):
+    """far_linear_gather_f16s (K9 gather mode): merge_feat's Linear layer on windows that are never stored == the same layer on
+    fine_gather's window tensor, bit for bit (border windows with zero padding, grouped residual, ragged last tile)."""
+    from far_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(M + Hf)
+    fmap = torch.randn(N, Hf, Wf, 128, device='cuda', generator=g)
+    wc, hc = Wf // 4, Hf // 4
+    b = torch.sort(torch.randint(0, N, (M,), device='cuda', generator=g))[0]
+    cells = torch.randint(0, hc * wc, (M,), device='cuda', generator=g)
+    cells[:min(M, 4)] = torch.tensor([0, wc - 1, (hc - 1) * wc, hc * wc - 1], device='cuda')[:min(M, 4)]     # the corners
+    pc = ops.PackedConv(torch.randn(Cout, 128, device='cuda', generator=g) * 0.1, None, torch.randn(Cout, device='cuda', generator=g))
+    res = torch.randn(M, Cout, device='cuda', generator=g)
+    win = ops.fine_gather(fmap.permute(0, 3, 1, 2), b, cells, wc, 5, 4)
+    ref = ops.linear_f16s(win, pc, residual=res, res_group=25)
+    got = ops.linear_gather_f16s(fmap, b, cells, wc, 5, 4, pc, residual=res, res_group=25)
+    assert got.shape == ref.shape and torch.equal(got, ref)
+    assert torch.equal(ops.linear_gather_f16s(fmap, b, cells, wc, 5, 4, pc, act='relu'), ops.linear_f16s(win, pc, act='relu'))
+
+
 @pytest.mark.parametrize('N,L,S', [(3, 4800, 4800), (2, 77, 100), (5, 200, 64), (2, 320, 6120), (4, 64, 150), (1, 33, 65), (3, 192, 128)])
 def test_linear_kv_state_projection_fused_with_ktv(N, L, S):
     """far_linear_kv_f16s: the k | v projection of a d_model-256 layer ending in K'^T V (k, v never stored) + the apply half of K5.
