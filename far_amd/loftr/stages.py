@@ -244,16 +244,25 @@ class FinePreprocess(nn.Module):
                                     (feat_f0.stride(0), feat_f0.stride(2), feat_f0.stride(3), 1))
             pk = self.__dict__.setdefault('_packs', ops.PackCache())
             dw, db = self.down_proj.weight, self.down_proj.bias
-            c_in = torch.cat([feat_c0[b, i], feat_c1[b, j]], 0)
-            c_win = ops.linear_f16s(c_in.contiguous(), pk.get('down', [dw, db], lambda: ops.PackedConv(dw, None, db)))
+            b01, c01 = torch.cat([b, b + n]), torch.cat([i, j])
+            pdown = pk.get('down', [dw, db], lambda: ops.PackedConv(dw, None, db))
+            if (feat_c0.shape == feat_c1.shape and feat_c0.is_contiguous() and feat_c1.is_contiguous() and feat_c0.dtype == torch.float32
+                    and feat_c0.untyped_storage().data_ptr() == feat_c1.untyped_storage().data_ptr()
+                    and feat_c1.storage_offset() == feat_c0.storage_offset() + feat_c0.numel()):
+                # down_proj(cat[feat_c0[b, i], feat_c1[b, j]]) (:50-51) the same way: a 1 x 1 "window" per match, read from the coarse
+                # transformer's joint output buffer -- no index / cat kernels, no (2M, 256) tensor
+                tok = torch.as_strided(feat_c0, (2 * n, 1, feat_c0.shape[1], feat_c0.shape[2]),
+                                       (feat_c0.stride(0), feat_c0.stride(0), feat_c0.stride(1), 1))
+                c_win = ops.linear_gather_f16s(tok, b01, c01, feat_c0.shape[1], 1, 1, pdown).view(2 * M, -1)
+            else:
+                c_win = ops.linear_f16s(torch.cat([feat_c0[b, i], feat_c1[b, j]], 0).contiguous(), pdown)
             d = self.d_model_f
             wt = self.merge_feat.weight
             pf = pk.get('merge_f', [wt], lambda: ops.PackedConv(wt[:, :d].contiguous()))
             pc = pk.get('merge_c', [wt, self.merge_feat.bias],
                         lambda: ops.PackedConv(wt[:, d:].contiguous(), None, self.merge_feat.bias))
             cw = ops.linear_f16s(c_win.contiguous(), pc)                              # (2M, d)
-            both = ops.linear_gather_f16s(fmap, torch.cat([b, b + n]), torch.cat([i, j]), data['hw0_c'][1], W, stride, pf,
-                                          residual=cw, res_group=W ** 2)
+            both = ops.linear_gather_f16s(fmap, b01, c01, data['hw0_c'][1], W, stride, pf, residual=cw, res_group=W ** 2)
             return both[:M], both[M:]
         else:       # both images' windows into the halves of one buffer: the later cat([w0, w1]) is then free
             M = b.shape[0]

@@ -84,6 +84,9 @@ def test_linear_reads_fine_windows_through_the_indices(N, Hf, Wf, M, Cout):
     got = ops.linear_gather_f16s(fmap, b, cells, wc, 5, 4, pc, residual=res, res_group=25)
     assert got.shape == ref.shape and torch.equal(got, ref)
     assert torch.equal(ops.linear_gather_f16s(fmap, b, cells, wc, 5, 4, pc, act='relu'), ops.linear_f16s(win, pc, act='relu'))
+    # a 1 x 1 "window": rows picked from a token tensor (down_proj on feat_c[b_ids, i_ids], fine_preprocess.py:50-51)
+    tok = torch.randn(N, 1, hc * wc, 128, device='cuda', generator=g)
+    assert torch.equal(ops.linear_gather_f16s(tok, b, cells, hc * wc, 1, 1, pc).view(M, -1), ops.linear_f16s(tok[b, 0, cells].contiguous(), pc))
 
 
 @pytest.mark.parametrize('N,L,S', [(3, 4800, 4800), (2, 77, 100), (5, 200, 64), (2, 320, 6120), (4, 64, 150), (1, 33, 65), (3, 192, 128)])
