@@ -100,9 +100,12 @@ struct ConvArgs {
     int* overflow;               // device flag, |= 1 when an accumulator of this launch is not finite (may be null)
     const float* scale_dev;      // device { act_scale, out_mul } overriding the two fields above (may be null)
     float* kv_part;              // far_linear_kv_f16s (the EPI = 1 instantiations): the columns are the k | v projections of a LoFTR
-    int kv_S, kv_nslot;          // layer, head-interleaved, and the epilogue is la_kv_epilogue (K'^T V partial sums), not a store
+    int kv_S, kv_valid;          // layer, head-interleaved, and the epilogue is la_kv_epilogue (K'^T V partial sums), not a store
     const unsigned char* kv_img; // far_linear_q_apply_f16s (EPI = 2): per image the K'^T V state as MFMA operands + ksum (KV_IMG_BYTES)
     float la_eps, la_vlen;       // (EPI = 2: kv_S = tokens per image on the query side, la_vlen = the source's length S)
+    // EPI 1 / 2, image lengths that are no multiple of 64: the launch runs on a PADDED geometry -- kv_S = the length rounded up to 64
+    // rows per image, kv_valid = the real length (= kv_S otherwise) -- so that a 64-row block never holds rows of two images; the
+    // rows behind an image's end read nothing (row table, as the gather mode) and are masked / not stored
     int sub2;                    // 1x1 mode on every second pixel of every second row of x (the stride-2 shortcut, resnet_fpn.py:26-29)
     const long* g_b;             // far_linear_gather_f16s (EPI = 3): row r of the launch is token r % (W W) of window r / (W W), read
     const long* g_cell;          // straight from the fine map x [n][Hf][Wf][Cin] at the window's position (fine_preprocess.py:40-47)
@@ -627,9 +630,9 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvArgs& p, const f32x
 //     KV[d][v] += K'[row][d] * V[row][v]           (x 1 / S at the end: linear_attention.py:43 divides V first, same value to an ulp)
 // -- A from the k tile, B from the v tile, no data movement; products as everywhere: hi * hi + hi * lo + lo * hi of fp16 pairs
 // (operands x act_scale like the activations of the main loop: the same range, the same overflow flag).  ksum[d] = sum of K' is an
-// in-lane sum.  One partial sum per 64-row block of the launch (the rows of a wave), written to part[block][slot][H D][D + 1]
-// (slot 1: the rows behind an image boundary inside the block, only when S % 64 != 0); k_kv_blocks_reduce adds the blocks of an
-// image in block order: deterministic, no atomics, and at S % 64 == 0 independent of how many images share the launch.
+// in-lane sum.  One partial sum per 64-row block of the launch (the rows of a wave), written to part[block][H D][D + 1];
+// k_kv_blocks_reduce adds the blocks of an image in block order: deterministic, no atomics, and independent of how many images
+// share the launch (image lengths that are no multiple of 64 run on a padded geometry, ConvArgs: a block never holds two images).
 // F.elu(x) + 1 = x + 1 (x > 0), e^x otherwise, as 2^(x log2 e) on the hardware exponential: the rounding of the argument costs
 // |x| e^x 2^-24 <= 2^-25 in absolute terms (half an ulp of 1.0, the size of a K'), where expm1f(x) + 1 rounds twice and, like expf,
 // costs a dozen instructions per value (64 feature maps per lane in this epilogue: measured 349 -> 330 us per launch).
@@ -637,8 +640,8 @@ __device__ __forceinline__ float la_elu1(float x) { return x > 0.f ? x + 1.f : _
 
 template <bool FULL>
 __device__ __forceinline__ void la_kv_pass(const ConvArgs& p, const f32x16 (&acc)[2][4], const float (&sc)[4], const float (&sh)[4],
-                                           int lo, int hi, int pass, long blk, int head0, int HD, int l31, int h, float act_scale) {
-    const float unscale = 1.0f / (act_scale * act_scale), fS = (float)p.kv_S;
+                                           int lo, int hi, long blk, int head0, int HD, int l31, int h, float act_scale) {
+    const float unscale = 1.0f / (act_scale * act_scale), fS = (float)p.kv_valid;
 #pragma unroll
     for (int hd = 0; hd < 2; ++hd) {
         f32x16 kv;
@@ -655,11 +658,9 @@ __device__ __forceinline__ void la_kv_pass(const ConvArgs& p, const f32x16 (&acc
                     const int r = 8 * g + i;
                     ka[i] = la_elu1(acc[mt][2 * hd][r] * sc[2 * hd] + sh[2 * hd]);
                     vb[i] = acc[mt][2 * hd + 1][r] * sc[2 * hd + 1] + sh[2 * hd + 1];
-                    if (!FULL) {
+                    if (!FULL) {                         // the rows behind the image's end (zero inputs: K' = 1 there, V = its bias)
                         const int q = 32 * mt + 16 * (r >> 3) + (r & 3) + 8 * ((r >> 2) & 1) + 4 * h;          // row of the wave
-                        const bool in = q >= lo && q < hi;
-                        ka[i] = in ? ka[i] : 0.f;
-                        vb[i] = in ? vb[i] : 0.f;
+                        ka[i] = (q >= lo && q < hi) ? ka[i] : 0.f;
                     }
                     ks += ka[i];
                 }
@@ -678,7 +679,7 @@ __device__ __forceinline__ void la_kv_pass(const ConvArgs& p, const f32x16 (&acc
             for (int r = 0; r < 16; ++r) chk += kv[r];
             if (__any(!(fabsf(chk) <= FLT_MAX)) && (l31 | h) == 0) atomicOr(p.overflow, 1);
         }
-        float* o = p.kv_part + (((size_t)blk * p.kv_nslot + pass) * HD + (head0 + hd) * 32) * 33;
+        float* o = p.kv_part + ((size_t)blk * HD + (head0 + hd) * 32) * 33;
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + 4 * h) * 33 + l31] = (kv[r] * unscale) / fS;
         if (h == 0) o[l31 * 33 + 32] = ks;
@@ -688,13 +689,10 @@ __device__ __forceinline__ void la_kv_pass(const ConvArgs& p, const f32x16 (&acc
 __device__ __forceinline__ void la_kv_epilogue(const ConvArgs& p, const f32x16 (&acc)[2][4], long pixw, int cout_w, int lane,
                                                float act_scale) {
     const int l31 = lane & 31, h = lane >> 5;
-    const long leftl = p.npix - pixw;
-    if (leftl <= 0) return;
-    const int left = leftl > 64 ? 64 : (int)leftl;
-    const int S = p.kv_S;
-    const long img = pixw / S;
-    const long bl = (img + 1) * S - pixw;                // rows [0, b) of the wave belong to image `img`
-    const int b = bl > 64 ? 64 : (int)bl;
+    if (pixw >= p.npix) return;                          // (npix = images x kv_S: whole 64-row blocks)
+    const long img = pixw / p.kv_S;
+    const long vl = (long)p.kv_valid - (pixw - img * p.kv_S);    // rows [0, valid) of the wave are tokens of image `img`
+    const int valid = vl > 64 ? 64 : (int)vl;
     const int HD = p.Cout >> 1, head0 = cout_w >> 6;
     float sc[4], sh[4];
 #pragma unroll
@@ -704,37 +702,25 @@ __device__ __forceinline__ void la_kv_epilogue(const ConvArgs& p, const f32x16 (
         sh[nt] = p.shift ? p.shift[co] : 0.f;
     }
     const long blk = pixw >> 6;
-    if (b == 64 && left == 64) {                           // wave-uniform: 64 rows of one image (always, when S % 64 == 0)
-        la_kv_pass<true>(p, acc, sc, sh, 0, 64, 0, blk, head0, HD, l31, h, act_scale);
-        return;
-    }
-    const int hi0 = b < left ? b : left;
-    la_kv_pass<false>(p, acc, sc, sh, 0, hi0, 0, blk, head0, HD, l31, h, act_scale);
-    if (left > b) la_kv_pass<false>(p, acc, sc, sh, b, left, 1, blk, head0, HD, l31, h, act_scale);
+    if (valid == 64) la_kv_pass<true>(p, acc, sc, sh, 0, 64, blk, head0, HD, l31, h, act_scale);     // wave-uniform
+    else la_kv_pass<false>(p, acc, sc, sh, 0, valid, blk, head0, HD, l31, h, act_scale);             // the image's last block
 }
 
-// kv[n][HD][33] = the partial sums of image n's 64-row blocks, in block order.  Block g's slot 0 holds the rows of the image its
-// first row belongs to, slot 1 (nslot = 2) the rows of the next image.  img (optional, HD = 256): the same state as the operands of
+// kv[n][HD][33] = the partial sums of image n's 64-row blocks (Sp / 64 of them, Sp = the padded image length), in block order.
+// img (optional, HD = 256): the same state as the operands of
 // la_apply_epilogue -- per image [head][k-step u][plane hi | lo][lane][8] fp16 = KV[head][d = 16 u + 8 (lane >> 5) + i][v = lane & 31]
 // x act_scale, then ksum [256] fp32 (KV_IMG_BYTES per image).
 constexpr int KV_IMG_BYTES = 8 * 2 * 2 * 1024 + 256 * 4;
 
-__global__ __launch_bounds__(256) void k_kv_blocks_reduce(const float* __restrict__ part, int S, int nslot, int per,
+__global__ __launch_bounds__(256) void k_kv_blocks_reduce(const float* __restrict__ part, int Sp, int per,
                                                           float* __restrict__ kv, unsigned char* __restrict__ img, float act_scale) {
     const int n = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
     if (e >= per) return;
-    const long g0 = ((long)n * S) >> 6, g1 = ((long)(n + 1) * S - 1) >> 6;
+    const int nb = Sp >> 6;
     float s = 0.f;
-    if (nslot == 1) {                                      // S % 64 == 0: every block belongs to one image
-        const float* src = part + (size_t)g0 * per + e;
+    const float* src = part + (size_t)n * nb * per + e;
 #pragma unroll 8
-        for (long g = g0; g <= g1; ++g, src += per) s += *src;
-    } else {
-        for (long g = g0; g <= g1; ++g) {
-            const int slot = ((g << 6) / S == n) ? 0 : 1;
-            s += part[((size_t)g * nslot + slot) * per + e];
-        }
-    }
+    for (int g = 0; g < nb; ++g, src += per) s += *src;
     kv[(size_t)n * per + e] = s;
     if (img) {
         unsigned char* im = img + (size_t)n * KV_IMG_BYTES;
@@ -764,7 +750,7 @@ constexpr int LDW = 132;
 __device__ __forceinline__ void la_apply_epilogue(const ConvArgs& p, const f32x16 (&acc)[2][4], long pixw, int cout_w, int lane,
                                                   float* lw, float act_scale) {
     const int l31 = lane & 31, h = lane >> 5;
-    const int L = p.kv_S;
+    const int Lp = p.kv_S, L = p.kv_valid;               // rows per image in the launch's geometry / real tokens per image
     const float unscale = 1.0f / (act_scale * act_scale), fS = p.la_vlen;
     const int head0 = cout_w >> 5;
     float sc[4], sh[4];
@@ -778,10 +764,12 @@ __device__ __forceinline__ void la_apply_epilogue(const ConvArgs& p, const f32x1
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         const long pix0 = pixw + 32 * mt;
-        const long leftl = p.npix - pix0;
-        if (leftl <= 0) break;
+        if (pix0 >= p.npix) break;
+        const long im = pix0 / Lp;
+        const long t0 = pix0 - im * Lp, leftl = (long)L - t0;      // the tile's rows t0 .. of image `im`; the ones behind L are padding
+        if (leftl <= 0) continue;
         const int left = leftl > 32 ? 32 : (int)leftl;
-        const unsigned char* img = p.kv_img + (size_t)(pix0 / L) * KV_IMG_BYTES;
+        const unsigned char* img = p.kv_img + (size_t)im * KV_IMG_BYTES;
         const float* ksum = reinterpret_cast<const float*>(img + 32768);
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
@@ -822,7 +810,7 @@ __device__ __forceinline__ void la_apply_epilogue(const ConvArgs& p, const f32x1
             }
             __builtin_amdgcn_sched_barrier(0);             // head by head: the tile's columns are reused in place
         }
-        float* const ybase = p.y + (pix0 * (long)p.Csub + cout_w + 4 * l31);
+        float* const ybase = p.y + ((im * L + t0) * (long)p.Csub + cout_w + 4 * l31);
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
             const int q = 2 * it + h;
@@ -943,6 +931,21 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p) {
     // worked out ONCE per workgroup (one thread per row: two index loads, three divisions) into a table behind the loop's LDS buffers
     // -- inside the epilogue's region, which is only used after the last staging pass
     const int* rowpix = nullptr;
+    if constexpr (EPI == 1 || EPI == 2) {
+        // the LinearAttention epilogues on image lengths that are no multiple of 64: the launch's rows are images padded to whole
+        // 64-row blocks; the same kind of table says which input row (if any) each row of the tile is
+        if (p.kv_valid != p.kv_S) {                      // launch-uniform
+            int* tab = reinterpret_cast<int*>(smem + A_BUF + 3 * B_BUF);
+            if (tid < 64 * MW) {
+                const long row = tp.pix0 + tid;
+                const long im = row / p.kv_S;
+                const int t = (int)(row - im * p.kv_S);
+                tab[tid] = (row < p.npix && t < p.kv_valid) ? (int)(im * p.kv_valid + t) : -1;
+            }
+            __syncthreads();
+            rowpix = tab;
+        }
+    }
     if constexpr (EPI == 3) {
         static_assert(KS == 1 && !UP && !N7, "gather mode is a Linear-mode input form");
         int* tab = reinterpret_cast<int*>(smem + A_BUF + 3 * B_BUF);
@@ -1421,7 +1424,7 @@ int launch_conv(const ConvArgs& a, dim3 grid, hipStream_t stream) {
     constexpr int smem_loop = PLANES * G::A_PLANE + 3 * 2 * 32 * NTW * NW * 32;
     constexpr int smem_epi = EPI == 2 ? MW * NW * 32 * LDW * 4        // la_apply_epilogue: padded rows
                                       : MW * NW * (32 * 128 * 4 + 32 * 4);  // conv_epilogue_wide: 16 KiB per wave + LayerNorm exchange
-    constexpr int smem_need = smem_loop + (EPI == 3 ? 64 * MW * 4 : 0);            // gather mode: + the row table behind the loop buffers
+    constexpr int smem_need = smem_loop + (EPI != 0 ? 64 * MW * 4 : 0);            // gather / padded modes: + the row table behind the loop buffers
     constexpr int smem = smem_need > smem_epi ? smem_need : smem_epi;
     bool cfg_failed = false;
     FAR_ONCE_PER_DEVICE(cfg_failed = hipFuncSetAttribute((const void*)k_conv<KS, MW, NW, NTW, SPLIT, ST, UP, N7, EPI>,
@@ -1610,7 +1613,7 @@ namespace {
 struct KvMode {                                       // far_linear_kv_f16s (epi 1) / far_linear_q_apply_f16s (epi 2)
     int epi;
     float* part;
-    int S, nslot;
+    int S, valid;                                     // rows per image in the launch's geometry (a multiple of 64) / real tokens per image
     const unsigned char* img;
     float eps, vlen;
     const long *g_b = nullptr, *g_cell = nullptr;     // epi 3 (far_linear_gather_f16s)
@@ -1653,6 +1656,7 @@ int conv_nhwc_impl(const far_conv_desc* desc, const KvMode* kvm, hipStream_t str
     a.ln_gamma = ln_gamma; a.ln_beta = ln_beta; a.ln_eps = ln_eps; a.post_res = post_res; a.up = up;
     a.H = H; a.W = W; a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1; a.Cin = Cin; a.Cout = Cout; a.Csub = Cout / out_planes;
     a.npix = N * a.Ho * a.Wo;
+    if (kvm && kvm->epi != 3 && kvm->valid != kvm->S) a.npix = a.npix / kvm->valid * kvm->S;      // padded geometry: images x rounded-up length
     const TileCfg c = cfg_for(Cout, pstride);
     if ((ln_gamma || post_res) && (!ln_gamma || !ln_beta || Cout != c.nt || out_planes != 1 || (Cout & 3) || post_res == y))
         return FAR_EINVAL;                    // the fused LayerNorm needs the whole channel row in one block (Cout 128 or 256)
@@ -1663,7 +1667,7 @@ int conv_nhwc_impl(const far_conv_desc* desc, const KvMode* kvm, hipStream_t str
     a.act = act; a.slope = slope;
     a.act_scale = ldexpf(1.0f, d.act_exp); a.out_mul = ldexpf(1.0f, ACT_EXP_DEFAULT - d.act_exp); a.overflow = d.overflow;
     a.scale_dev = d.act_scale_dev;
-    a.kv_part = kvm ? kvm->part : nullptr; a.kv_S = kvm ? kvm->S : 0; a.kv_nslot = kvm ? kvm->nslot : 0;
+    a.kv_part = kvm ? kvm->part : nullptr; a.kv_S = kvm ? kvm->S : 0; a.kv_valid = kvm ? kvm->valid : 0;
     a.sub2 = sub2 ? 1 : 0;
     a.g_b = a.g_cell = nullptr; a.g_wc = a.g_W = a.g_stride = a.g_Hf = a.g_Wf = 0;
     a.kv_img = kvm ? kvm->img : nullptr; a.la_eps = kvm ? kvm->eps : 0.f; a.la_vlen = kvm ? kvm->vlen : 0.f;
@@ -1717,8 +1721,8 @@ int far_conv_nhwc_f32(const far_conv_desc* desc, hipStream_t stream) { return co
 // kv_img (optional, far_linear_kv_image_bytes(n_img) bytes): the same state as far_linear_q_apply_f16s's operands (x 2^act_exp).
 // ws: far_linear_kv_workspace_bytes(rows, S) bytes.  No masks, no residual / LayerNorm / activation on this launch.
 size_t far_linear_kv_workspace_bytes(long rows, int S) {
-    if (rows <= 0 || S < 64) return 0;
-    return (size_t)((rows + 63) / 64) * ((S & 63) ? 2 : 1) * 256 * 33 * sizeof(float);
+    if (rows <= 0 || S < 64 || rows % S) return 0;
+    return (size_t)(rows / S) * ((S + 63) / 64) * 256 * 33 * sizeof(float);
 }
 size_t far_linear_kv_image_bytes(long n_img) { return n_img > 0 ? (size_t)n_img * KV_IMG_BYTES : 0; }
 
@@ -1732,12 +1736,14 @@ int far_linear_kv_f16s(const far_conv_desc* desc, int S, void* ws, float* kv, vo
         d.out_planes != 2 || d.act != 0 || d.res || d.ln_gamma || d.post_res || d.up || d.x2 || d.res_group != 1 || rows / S > 65535 ||
         d.act_scale_dev)
         return FAR_EINVAL;
-    KvMode m{1, (float*)ws, S, (S & 63) ? 2 : 1, nullptr, 0.f, 0.f};
+    const int Sp = (S + 63) / 64 * 64;                   // the launch's rows per image: whole 64-row blocks (the row table skips the rest)
+    if (rows / S * (long)Sp > 0x7fffffffL) return FAR_EINVAL;
+    KvMode m{1, (float*)ws, Sp, S, nullptr, 0.f, 0.f};
     const int rc = conv_nhwc_impl(desc, &m, stream);
     if (rc != FAR_OK) return rc;
     const int per = 256 * 33;
-    hipLaunchKernelGGL(k_kv_blocks_reduce, dim3((per + 255) / 256, (unsigned)(rows / S)), dim3(256), 0, stream, (const float*)ws, S,
-                       m.nslot, per, kv, (unsigned char*)kv_img, ldexpf(1.0f, d.act_exp));
+    hipLaunchKernelGGL(k_kv_blocks_reduce, dim3((per + 255) / 256, (unsigned)(rows / S)), dim3(256), 0, stream, (const float*)ws, Sp,
+                       per, kv, (unsigned char*)kv_img, ldexpf(1.0f, d.act_exp));
     return far_check_launch();
 }
 
@@ -1745,18 +1751,20 @@ int far_linear_kv_f16s(const far_conv_desc* desc, int S, void* ws, float* kv, vo
 // a Linear layer (ksize 1, N = H = 1, W = rows, split operands, Cout = 256, out_planes = 1, no activation / residual / LayerNorm)
 // with the plain Wq image; y [rows][256] receives the attention MESSAGE (Q' KV) Z S -- q itself is never stored.  kv_img: the
 // operand image far_linear_kv_f16s wrote for the SOURCE tokens under the same act_exp (image i serves rows [i L, (i + 1) L));
-// L = tokens per image on the query side (L % 64 == 0), S = v_length of the source (linear_attention.py:43, 50).
+// L = tokens per image on the query side (>= 64), S = v_length of the source (linear_attention.py:43, 50).
 int far_linear_q_apply_f16s(const far_conv_desc* desc, int L, int S, const void* kv_img, float eps, hipStream_t stream) {
     if (!desc) return FAR_EINVAL;
     const far_conv_desc& d = *desc;
     far_clear_errors();
     const long rows = d.N * d.H * d.W;
     if (rows == 0) return FAR_OK;
-    if (!kv_img || !d.y || L < 64 || (L & 63) || S <= 0 || rows < 0 || rows % L || d.ksize != 1 || d.stride != 1 || !d.split ||
+    if (!kv_img || !d.y || L < 64 || S <= 0 || rows < 0 || rows % L || d.ksize != 1 || d.stride != 1 || !d.split ||
         d.Cout != 256 || d.out_planes != 1 || d.act != 0 || d.res || d.ln_gamma || d.post_res || d.up || d.x2 || d.res_group != 1 ||
         d.act_scale_dev)
         return FAR_EINVAL;
-    KvMode m{2, nullptr, L, 1, (const unsigned char*)kv_img, eps, (float)S};
+    const int Lp = (L + 63) / 64 * 64;
+    if (rows / L * (long)Lp > 0x7fffffffL) return FAR_EINVAL;
+    KvMode m{2, nullptr, Lp, L, (const unsigned char*)kv_img, eps, (float)S};
     return conv_nhwc_impl(desc, &m, stream);
 }
 

@@ -130,16 +130,16 @@ class LoFTREncoderLayer(nn.Module):
             h = ops.linear_f16s(x, lin('mlp0', self.mlp[0]), act='relu', x2=msg)
             return ops.linear_f16s(h, lin('mlp2', self.mlp[2]), ln=(self.norm2.weight, self.norm2.bias, self.norm2.eps),
                                    post_residual=x, out=out)
-        if (self.fused_kv and sp and x.shape[-1] == 256 and self.nhead == 8 and source.shape[1] >= 64 and source.shape[1] % 64 == 0
-                and x_mask is None and source_mask is None):
+        if (self.fused_kv and sp and x.shape[-1] == 256 and self.nhead == 8 and source.shape[1] >= 64 and x_mask is None
+                and source_mask is None):
             # d_model 256 (the coarse level, the head's layers): the k | v projection ends in K'^T V (linear_attention.py:38-45)
-            # instead of a store -- k and v (4 of the layer's 19 passes over a (rows, 256) tensor) never exist.  Only for whole
-            # 64-token blocks per image (4800 = 75 x 64): the partial sums are then per image and an image's bits do not depend on
-            # the rest of the batch (the kernel itself handles any S >= 64)
+            # instead of a store -- k and v (4 of the layer's 19 passes over a (rows, 256) tensor) never exist.  Partial sums are
+            # per 64-token block of an image (lengths that are no multiple of 64 run on a padded launch geometry): an image's bits
+            # do not depend on the rest of the batch
             pkv = pk.get(('kv-state', sp), [self.k_proj.weight, self.v_proj.weight],
                          lambda: ops.PackedConv(ops.kv_interleaved_weight(self.k_proj.weight, self.v_proj.weight, self.nhead), split=sp))
             S = source.shape[1]
-            if self.fused_apply and x.shape[1] % 64 == 0:
+            if self.fused_apply and x.shape[1] >= 64:
                 # ... and the q projection ends in (Q' KV) Z S (:46-50): q is never stored either, K5's apply launch disappears
                 _, image = ops.linear_kv_state(source, pkv, S, want_image=True)
                 msg = ops.linear_q_apply(x, lin('q', self.q_proj), image, S, eps=self.attention.eps)

@@ -1552,11 +1552,11 @@ def linear_kv_state(x, pc, S, want_image=False):
 def linear_q_apply(x, pc, image, S, eps=1e-6):
     """K9 + LinearAttention's second half in the epilogue (far_linear_q_apply_f16s).  x (N, L, K) fp32 query-side tokens, pc =
     PackedConv(Wq), image = linear_kv_state(source, ..., want_image=True)[1] of the N source images (S tokens each) -> the attention
-    message (N, L, 256); q is never stored.  L % 64 == 0."""
+    message (N, L, 256); q is never stored.  L >= 64."""
     lib = _lib.load()
     N, L, K = x.shape
-    if pc.Cout != 256 or pc.ksize != 1 or not pc.split or K != pc.Cin or L % 64 or L < 64 or image.numel() != lib.far_linear_kv_image_bytes(N):
-        raise _lib.FarHipError('linear_q_apply: needs a split-operand 256-row Wq image, L % 64 == 0 and the state image of N source images')
+    if pc.Cout != 256 or pc.ksize != 1 or not pc.split or K != pc.Cin or L < 64 or image.numel() != lib.far_linear_kv_image_bytes(N):
+        raise _lib.FarHipError('linear_q_apply: needs a split-operand 256-row Wq image, L >= 64 and the state image of N source images')
     out = torch.empty(N, L, 256, dtype=torch.float32, device=x.device)
     if N:
         d = _linear_desc(x, pc, N * L, out, 1)

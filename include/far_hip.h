@@ -473,9 +473,10 @@ int far_conv_nhwc_f32(const far_conv_desc* desc, far_stream_t stream);
  * ONE launch that never writes k or v: K9's Linear mode ending in the K'^T V product instead of a store.
  * desc: a Linear layer (ksize 1, N = H = 1, W = rows, split = 1) with Cout = 512, out_planes = 2, no activation / residual /
  * LayerNorm; its packed weight = Wk and Wv interleaved head by head (weight rows 64 j + [0, 32) = Wk's rows of head j,
- * 64 j + [32, 64) = Wv's); y unused (NULL).  rows = n_img * S tokens, image after image, S >= 64.
+ * 64 j + [32, 64) = Wv's); y unused (NULL).  rows = n_img * S tokens, image after image, S >= 64 (any S: lengths that are no
+ * multiple of 64 run on a padded launch geometry, so that a 64-row partial sum never holds rows of two images).
  * kv [n_img][256][33] = the state far_linear_attention_apply_f32 consumes (what far_linear_attention_f32 builds from k and v in
- * its first two launches); fixed summation order per image (64-row blocks in order): run-to-run and batch-size independent bits.
+ * its first two launches); fixed summation order per image (its 64-row blocks in order): run-to-run and batch-size independent bits.
  * ws: far_linear_kv_workspace_bytes(rows, S) bytes. */
 size_t far_linear_kv_workspace_bytes(long rows, int S);
 size_t far_linear_kv_image_bytes(long n_img);
@@ -487,7 +488,7 @@ int far_linear_kv_f16s(const far_conv_desc* desc, int S, void* ws, float* kv, vo
  * epilogue: desc = a Linear layer (ksize 1, N = H = 1, W = rows, split = 1, Cout = 256, out_planes = 1, no activation / residual /
  * LayerNorm) with the plain Wq image; y [rows][256] receives the attention MESSAGE (Q' KV) Z S -- q is never stored and
  * far_linear_attention_apply_f32's launch disappears.  kv_img: far_linear_kv_f16s's image of the SOURCE tokens under the same
- * act_exp (image i serves rows [i L, (i + 1) L)); L = tokens per image on the query side (L % 64 == 0), S = the source's length. */
+ * act_exp (image i serves rows [i L, (i + 1) L)); L = tokens per image on the query side (>= 64), S = the source's length. */
 int far_linear_q_apply_f16s(const far_conv_desc* desc, int L, int S, const void* kv_img, float eps, far_stream_t stream);
 
 /* merge_feat of FinePreprocess (fine_preprocess.py:40-57) without the window tensor: K9's Linear mode reading its input rows
