@@ -7,7 +7,7 @@
 // These are a few hundred MFLOP on B <= 32 rows: nothing for the matrix cores, but a vendor GEMM picks its kernel (tile,
 // split-K factor) by the row count, so a pair's regressed pose depended on how many other pairs shared the batch (1e-7
 // relative; the batch-32 test needed a 1e-4 bar).  Here every output is one fp32 fma chain over k in a FIXED order --
-// the k range is cut into slices of 256 whatever the row count, slice partials are summed in slice order -- so row r of a
+// the k range is cut into slices of a size that depends on K alone (slice_of), slice partials are summed in slice order -- so row r of a
 // batch of 32 is bit-identical to the same pair run alone.  Memory-bound on the weights (35840 x 512 fp32 = 73 MB per big
 // layer), which are packed once as [k / 4][n][4] so that a wave reads 1 KiB contiguous per load.
 #include "common.h"
@@ -15,23 +15,28 @@
 namespace {
 
 constexpr int RB = 32;            // rows per launch block (zero-filled beyond B)
-constexpr int KSL = 256;          // k per slice (fixed: the summation order must not depend on anything else)
-constexpr int KT4 = 32;           // k per LDS tile / 4
+// k per slice: fixed per K (the summation order must not depend on the row count or on anything else): 256 for the two 35840-wide
+// first layers, 64 for the 512- / 22-wide ones behind them -- those are 2 x 2 workgroups of one 256-k slice each otherwise, and a
+// launch of theirs is one thread's chain of 8192 fmas (50-64 us, thirteen of them per step and per pair at batch 1)
+__host__ __device__ constexpr int slice_of(int K) { return K > 2048 ? 256 : 64; }
 
-// partial[s][b][n] = sum_{k in slice s} x[b][k] W[n][k]
+// partial[s][b][n] = sum_{k in slice s} x[b][k] W[n][k].  RBT = row slots of the block (32, or 4 / 1 for small batches: a row's
+// chain is its own, so fewer slots change no bit -- at batch 1 the 32-slot form spent 31 of 32 fmas on zero rows).
+template <int RBT, int KSLT>
 __global__ __launch_bounds__(256) void k_rows_partial(const float* __restrict__ x, long ldx, const float4* __restrict__ wp,
                                                       int B, int K, int N, float* __restrict__ partial) {
-    __shared__ float4 xs[RB][KT4];                                  // 16 KiB: 32 rows x 128 k
+    constexpr int KT4 = KSLT >= 128 ? 32 : KSLT / 4;                // k per LDS tile / 4
+    __shared__ float4 xs[RBT][KT4];
     const int s = blockIdx.x, n = blockIdx.y * 256 + threadIdx.x;
-    const int k0 = s * KSL;
-    float acc[RB];
+    const int k0 = s * KSLT;
+    float acc[RBT];
 #pragma unroll
-    for (int b = 0; b < RB; ++b) acc[b] = 0.f;
+    for (int b = 0; b < RBT; ++b) acc[b] = 0.f;
     const int K4 = (K + 3) >> 2;
-    for (int sub = 0; sub < KSL / (4 * KT4); ++sub) {
+    for (int sub = 0; sub < KSLT / (4 * KT4); ++sub) {
         const int kb = k0 + sub * 4 * KT4;
         __syncthreads();
-        for (int i = threadIdx.x; i < RB * KT4; i += 256) {
+        for (int i = threadIdx.x; i < RBT * KT4; i += 256) {
             const int b = i / KT4, q = i - b * KT4, k = kb + 4 * q;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (b < B) {
@@ -49,7 +54,7 @@ __global__ __launch_bounds__(256) void k_rows_partial(const float* __restrict__ 
                 if (k4 >= K4) break;
                 const float4 w = wp[(size_t)k4 * N + n];
 #pragma unroll
-                for (int b = 0; b < RB; ++b) {
+                for (int b = 0; b < RBT; ++b) {
                     const float4 v = xs[b][q];                      // same address in every lane: an LDS broadcast
                     acc[b] = __builtin_fmaf(v.x, w.x, acc[b]);
                     acc[b] = __builtin_fmaf(v.y, w.y, acc[b]);
@@ -60,7 +65,7 @@ __global__ __launch_bounds__(256) void k_rows_partial(const float* __restrict__ 
         }
     }
     if (n < N)
-        for (int b = 0; b < B; ++b) partial[((size_t)s * B + b) * N + n] = acc[b];
+        for (int b = 0; b < B && b < RBT; ++b) partial[((size_t)s * B + b) * N + n] = acc[b];
 }
 
 // y[b][n] = act(bias[n] + add[b][n] + sum_s partial[s][b][n]), slices in order.  act: 0 none, 1 ReLU, 2 sigmoid, 3 GELU (erf)
@@ -167,7 +172,7 @@ extern "C" {
 
 size_t far_rows_linear_packed_bytes(int N, int K) { return (N > 0 && K > 0) ? (size_t)((K + 3) / 4) * N * 16 : 0; }
 size_t far_rows_linear_workspace_bytes(int B, int N, int K) {
-    return (B > 0 && N > 0 && K > 0) ? (size_t)((K + KSL - 1) / KSL) * (B < RB ? B : RB) * N * 4 : 0;
+    return (B > 0 && N > 0 && K > 0) ? (size_t)((K + slice_of(K) - 1) / slice_of(K)) * (B < RB ? B : RB) * N * 4 : 0;
 }
 
 // w [N][K] fp32 (torch nn.Linear layout) -> packed (far_rows_linear_packed_bytes bytes)
@@ -188,11 +193,15 @@ int far_rows_linear_f32(const float* x, long ldx, const void* packed, const floa
     if (B == 0) return FAR_OK;
     if (!x || !packed || !y || !ws || B < 0 || K <= 0 || N <= 0 || act < 0 || act > 3 || ldx < K || ldy < N || (add && ld_add < N))
         return FAR_EINVAL;
-    const int S = (K + KSL - 1) / KSL;
+    const int ksl = slice_of(K), S = (K + ksl - 1) / ksl;
     for (int b0 = 0; b0 < B; b0 += RB) {
         const int nb = B - b0 < RB ? B - b0 : RB;
-        hipLaunchKernelGGL(k_rows_partial, dim3(S, (N + 255) / 256), dim3(256), 0, stream, x + (long)b0 * ldx, ldx,
-                           (const float4*)packed, nb, K, N, (float*)ws);
+        const dim3 grid(S, (N + 255) / 256);
+        const float* xb = x + (long)b0 * ldx;
+#define FAR_ROWS_LAUNCH(RBT, KSLT) hipLaunchKernelGGL((k_rows_partial<RBT, KSLT>), grid, dim3(256), 0, stream, xb, ldx, (const float4*)packed, nb, K, N, (float*)ws)
+        if (ksl == 256) { if (nb == 1) FAR_ROWS_LAUNCH(1, 256); else if (nb <= 4) FAR_ROWS_LAUNCH(4, 256); else FAR_ROWS_LAUNCH(32, 256); }
+        else { if (nb == 1) FAR_ROWS_LAUNCH(1, 64); else if (nb <= 4) FAR_ROWS_LAUNCH(4, 64); else FAR_ROWS_LAUNCH(32, 64); }
+#undef FAR_ROWS_LAUNCH
         hipLaunchKernelGGL(k_rows_reduce, dim3((unsigned)(((long)nb * N + 255) / 256)), dim3(256), 0, stream, (const float*)ws, bias,
                            add ? add + (long)b0 * ld_add : nullptr, ld_add, S, nb, N, act, y + (long)b0 * ldy, ldy);
     }
