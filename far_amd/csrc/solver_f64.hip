@@ -532,11 +532,12 @@ __global__ void k_select(const double4* __restrict__ kp, const int* __restrict__
                          const double* __restrict__ inl_th, int H, int many_thr, int minimal,
                          int* __restrict__ best_out, double* __restrict__ E_out, uint8_t* __restrict__ mask,
                          int* __restrict__ n_inl, int* __restrict__ n_tight, int* __restrict__ n_ultra,
-                         int* __restrict__ status) {
+                         int* __restrict__ status, int* __restrict__ good_g) {
     __shared__ double sv[256];
     __shared__ int si[256];
     __shared__ int cnt[3];
     const int b = blockIdx.x, t = threadIdx.x;
+    if (t < 4) good_g[b * 4 + t] = 0;                      // the cheirality counters of k_recover_bits (next launch)
     const int o = offsets[b], M = offsets[b + 1] - o;
     double bv = -INFINITY; int bi = 0x7fffffff;
     for (int h = t; h < H; h += 256) {
@@ -643,18 +644,19 @@ __device__ __forceinline__ uint8_t cheirality_bits(const double (&R1)[9], const 
     return bits;
 }
 
-__global__ __launch_bounds__(256) void k_recover(const double4* __restrict__ kn, const int* __restrict__ offsets,
+// recoverPose in two launches.  k_recover_bits: the four candidate poses' cheirality tests -- a 4 x 4 eigen decomposition per
+// (correspondence, candidate), cv::triangulatePoints' DLT -- one correspondence per thread, ceil(M / 256) workgroups per pair (as one
+// workgroup per pair, 32 pairs kept 32 CUs busy for 0.37 ms with ~30 serial decompositions per thread); the per-candidate counts
+// are integer atomics (order-free).  k_recover_final: the candidate with the most points in front, the mask rewritten in place, outputs.
+__global__ __launch_bounds__(256) void k_recover_bits(const double4* __restrict__ kn, const int* __restrict__ offsets,
                           const double* __restrict__ E_in, const int* __restrict__ status_in, double dist,
-                          uint8_t* __restrict__ mask, uint8_t* __restrict__ bits_ws, double* __restrict__ R_out,
-                          double* __restrict__ t_out, int* __restrict__ n_out, int* __restrict__ num_after,
-                          int* __restrict__ status_out) {
+                          const uint8_t* __restrict__ mask, uint8_t* __restrict__ bits_ws, int* __restrict__ good_g,
+                          double* __restrict__ rt_ws) {
     __shared__ int good[4];
-    __shared__ int chosen;
-    __shared__ int after;
-    const int b = blockIdx.x, tdx = threadIdx.x;
+    const int b = blockIdx.y, tdx = threadIdx.x;
     const int o = offsets[b], M = offsets[b + 1] - o;
+    if ((int)blockIdx.x * 256 >= M && blockIdx.x != 0) return;            // (workgroup 0 always runs: it hands on R1, R2, t)
     if (tdx < 4) good[tdx] = 0;
-    if (tdx == 0) after = 0;
     __syncthreads();
     const bool ok = status_in[b] != 0;
     double E[9], R1[9], R2[9], t[3];
@@ -666,29 +668,43 @@ __global__ __launch_bounds__(256) void k_recover(const double4* __restrict__ kn,
         for (int e = 0; e < 9; ++e) { R1[e] = (e % 4 == 0); R2[e] = R1[e]; }
         t[0] = t[1] = t[2] = 0.0;
     }
-    int g0 = 0, g1 = 0, g2 = 0, g3 = 0;
-    if (ok) {
-        for (int i = tdx; i < M; i += blockDim.x) {
-            const double4 p = kn[o + i];
-            uint8_t bits = cheirality_bits(R1, R2, t, p.x, p.y, p.z, p.w, dist);
-            if (!mask[o + i]) bits = 0;                                   // AND with the RANSAC mask
-            bits_ws[o + i] = bits;
-            g0 += bits & 1; g1 += (bits >> 1) & 1; g2 += (bits >> 2) & 1; g3 += (bits >> 3) & 1;
-        }
-        atomicAdd(&good[0], g0); atomicAdd(&good[1], g1); atomicAdd(&good[2], g2); atomicAdd(&good[3], g3);
+    if (blockIdx.x == 0 && tdx == 0) {
+        double* w = rt_ws + (size_t)b * 21;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) { w[e] = R1[e]; w[9 + e] = R2[e]; }
+        w[18] = t[0]; w[19] = t[1]; w[20] = t[2];
+    }
+    const int i = blockIdx.x * 256 + tdx;
+    if (ok && i < M) {
+        const double4 p = kn[o + i];
+        uint8_t bits = cheirality_bits(R1, R2, t, p.x, p.y, p.z, p.w, dist);
+        if (!mask[o + i]) bits = 0;                                       // AND with the RANSAC mask
+        bits_ws[o + i] = bits;
+        if (bits & 1) atomicAdd(&good[0], 1);
+        if (bits & 2) atomicAdd(&good[1], 1);
+        if (bits & 4) atomicAdd(&good[2], 1);
+        if (bits & 8) atomicAdd(&good[3], 1);
     }
     __syncthreads();
-    if (tdx == 0) {
-        const int a = good[0], bb = good[1], c = good[2], d = good[3];
-        int ch;
-        if (a >= bb && a >= c && a >= d) ch = 0;
-        else if (bb >= a && bb >= c && bb >= d) ch = 1;
-        else if (c >= a && c >= bb && c >= d) ch = 2;
-        else ch = 3;
-        chosen = ch;
-    }
+    if (tdx < 4 && good[tdx]) atomicAdd(&good_g[b * 4 + tdx], good[tdx]);
+}
+
+__global__ __launch_bounds__(256) void k_recover_final(const int* __restrict__ offsets, const int* __restrict__ status_in,
+                          const int* __restrict__ good_g, const double* __restrict__ rt_ws, uint8_t* __restrict__ mask,
+                          const uint8_t* __restrict__ bits_ws, double* __restrict__ R_out, double* __restrict__ t_out,
+                          int* __restrict__ n_out, int* __restrict__ num_after, int* __restrict__ status_out) {
+    __shared__ int after;
+    const int b = blockIdx.x, tdx = threadIdx.x;
+    const int o = offsets[b], M = offsets[b + 1] - o;
+    if (tdx == 0) after = 0;
     __syncthreads();
-    const int ch = chosen;
+    const bool ok = status_in[b] != 0;
+    const int a = good_g[b * 4], bb = good_g[b * 4 + 1], c = good_g[b * 4 + 2], d = good_g[b * 4 + 3];
+    int ch;
+    if (a >= bb && a >= c && a >= d) ch = 0;
+    else if (bb >= a && bb >= c && bb >= d) ch = 1;
+    else if (c >= a && c >= bb && c >= d) ch = 2;
+    else ch = 3;
     int aft = 0;
     for (int i = tdx; i < M; i += blockDim.x) {
         uint8_t m = ok ? ((bits_ws[o + i] >> ch) & 1) : 0;
@@ -698,12 +714,13 @@ __global__ __launch_bounds__(256) void k_recover(const double4* __restrict__ kn,
     atomicAdd(&after, aft);
     __syncthreads();
     if (tdx == 0) {
-        const double* R = (ch & 1) ? R2 : R1;
+        const double* w = rt_ws + (size_t)b * 21;
+        const double* R = (ch & 1) ? w + 9 : w;
         const double sg = (ch & 2) ? -1.0 : 1.0;
 #pragma unroll
         for (int e = 0; e < 9; ++e) R_out[b * 9 + e] = R[e];
-        t_out[b * 3] = sg * t[0]; t_out[b * 3 + 1] = sg * t[1]; t_out[b * 3 + 2] = sg * t[2];
-        const int n = ok ? good[ch] : 0;
+        t_out[b * 3] = sg * w[18]; t_out[b * 3 + 1] = sg * w[19]; t_out[b * 3 + 2] = sg * w[20];
+        const int n = ok ? (ch == 0 ? a : ch == 1 ? bb : ch == 2 ? c : d) : 0;
         n_out[b] = n;
         num_after[b] = after;
         status_out[b] = (ok && n > 0) ? 1 : 0;                            // metrics.py:166 (n > best_num_inliers = 0)
@@ -715,6 +732,7 @@ inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 struct SolverWs {
     double4* kn; double4* kp; uint32_t* wq; uint32_t* cdf; PairPrior* pp; double* tgt;
     double* F_all; double* pscore; int* count_all; double* score_all; uint8_t* bits; int* status_sel; int* n_inl;
+    int* good; double* rt;
     size_t bytes;
 };
 
@@ -736,6 +754,8 @@ SolverWs carve(void* ws, int B, int Mtot, int H, int P) {
     w.bits = (uint8_t*)take((size_t)Mtot);
     w.status_sel = (int*)take(sizeof(int) * (size_t)B);
     w.n_inl = (int*)take(sizeof(int) * (size_t)B);
+    w.good = (int*)take(sizeof(int) * (size_t)B * 4);
+    w.rt = (double*)take(sizeof(double) * (size_t)B * 21);
     w.bytes = off;
     return w;
 }
@@ -799,9 +819,12 @@ int far_solver_f64(const float* kpts0, const float* kpts1, const int* offsets, i
     hipLaunchKernelGGL(k_score, dim3((H + 63) / 64, B), dim3(256), 0, stream, w.kp, offsets, F_all, w.pscore, inl_th, H,
                        count_all, score_all);
     hipLaunchKernelGGL(k_select, dim3(B), dim3(256), 0, stream, w.kp, offsets, F_all, score_all, inl_th, H, many_thr,
-                       minimal, best_out, E_out, mask_out, w.n_inl, n_tight_out, n_ultra_out, w.status_sel);
-    hipLaunchKernelGGL(k_recover, dim3(B), dim3(256), 0, stream, w.kn, offsets, E_out, w.status_sel, 1e9, mask_out,
-                       w.bits, R_out, t_out, n_cheir_out, num_after_out, status_out);
+                       minimal, best_out, E_out, mask_out, w.n_inl, n_tight_out, n_ultra_out, w.status_sel, w.good);
+    const int nsplit = Mmax > 0 ? (Mmax + 255) / 256 : 1;
+    hipLaunchKernelGGL(k_recover_bits, dim3(nsplit, B), dim3(256), 0, stream, w.kn, offsets, E_out, w.status_sel, 1e9,
+                       (const uint8_t*)mask_out, w.bits, w.good, w.rt);
+    hipLaunchKernelGGL(k_recover_final, dim3(B), dim3(256), 0, stream, offsets, w.status_sel, (const int*)w.good, (const double*)w.rt,
+                       mask_out, (const uint8_t*)w.bits, R_out, t_out, n_cheir_out, num_after_out, status_out);
     return far_check_launch();
 }
 
