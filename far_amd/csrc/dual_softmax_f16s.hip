@@ -70,8 +70,9 @@ __global__ void k1_prep(const float* __restrict__ x, int Z, int N, int Np, _Floa
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
         const int slot = (int)(t & 31);
         const long row = t >> 5;
-        const int i = (int)(row % Np);
-        const long z = row / Np;
+        const unsigned urow = (unsigned)row, uz = urow / (unsigned)Np;      // Z Np < 2^31 (host check): 32-bit division
+        const int i = (int)(urow - uz * (unsigned)Np);
+        const long z = uz;
         f16x8 vh, vl;
         if (i < N) {
             const float* src = x + ((size_t)z * N + i) * C + slot * 8;
@@ -528,7 +529,7 @@ int far_coarse_match_f16s(const float* f0, const float* f1, int Z, int L, int S,
     far_clear_errors();
     if (!f0 || !f1 || !ws || !b_ids || !i_ids || !j_ids || !mconf || !mkpts0_c || !mkpts1_c || !total_out)
         return FAR_EINVAL;
-    if (Z <= 0 || L <= 0 || S <= 0 || Cc != C || h0 * w0 != L || h1 * w1 != S) return FAR_EINVAL;
+    if (Z <= 0 || L <= 0 || S <= 0 || Cc != C || h0 * w0 != L || h1 * w1 != S || (long)Z * (L > S ? L : S) > 0x7ff00000L) return FAR_EINVAL;
     const Ws16 w = carve16(ws, Z, L, S);
     const int Lp = (L + 127) / 128 * 128, Sp = (S + 127) / 128 * 128;
     // sim = <f0 / sqrt(C), f1 / sqrt(C)> / temperature  ->  log2 domain, operands pre-scaled by 2^4 each
@@ -586,7 +587,7 @@ int far_conf_matrix_f16s(const float* f0, const float* f1, int Z, int L, int S, 
                          const uint8_t* mask0, const uint8_t* mask1, int stages, float* conf_out, int* fix_info_out,
                          void* ws, int* overflow, hipStream_t stream) {
     far_clear_errors();
-    if (!f0 || !f1 || !ws || !conf_out || Z <= 0 || L <= 0 || S <= 0 || Cc != C || !(stages & 3)) return FAR_EINVAL;
+    if (!f0 || !f1 || !ws || !conf_out || Z <= 0 || L <= 0 || S <= 0 || Cc != C || !(stages & 3) || (long)Z * (L > S ? L : S) > 0x7ff00000L) return FAR_EINVAL;
     const Ws16 w = carve16(ws, Z, L, S);
     const int Lp = (L + 127) / 128 * 128, Sp = (S + 127) / 128 * 128;
     const float c1 = (float)(1.4426950408889634 / ((double)C * (double)temperature * PRESCALE * PRESCALE));
