@@ -59,6 +59,24 @@ if which in ('pmc',):
     for _ in range(it):
         ops.conv_nhwc(r, pl)
     del r
+    # round 4: the LinearAttention epilogues of K9 (k | v projection -> K'^T V state, q projection -> attention message) on the
+    # tokens of 2n images, and FinePreprocess's merge_feat in gather mode on n x 1880 windows of a 240 x 320 fine map pair
+    xs = torch.randn(2 * n, L, 256, device=dev, generator=g)
+    wq, wk, wv = (torch.randn(256, 256, device=dev, generator=g) / 16 for _ in range(3))
+    pq, pst = ops.PackedConv(wq), ops.PackedConv(ops.kv_interleaved_weight(wk, wv, 8))
+    for _ in range(it):
+        _, im = ops.linear_kv_state(xs, pst, L, want_image=True)
+        ops.linear_q_apply(xs, pq, im, L)
+    del xs
+    fmap = torch.randn(2 * n, 240, 320, 128, device=dev, generator=g)
+    M = 1880 * 2 * n
+    bi = torch.sort(torch.randint(0, 2 * n, (M,), device=dev, generator=g))[0]
+    ci = torch.randint(0, 60 * 80, (M,), device=dev, generator=g)
+    pm = ops.PackedConv(torch.randn(128, 128, device=dev, generator=g) * 0.1)
+    cw = torch.randn(M, 128, device=dev, generator=g)
+    for _ in range(it):
+        ops.linear_gather_f16s(fmap, bi, ci, 80, 5, 4, pm, residual=cw, res_group=25)
+    del fmap
     f0 = 1.2 * torch.randn(n, L, 256, device=dev, generator=g)
     f1 = f0[:, torch.randperm(L, device=dev, generator=g)] + 0.1 * torch.randn(n, L, 256, device=dev, generator=g)
     conf = torch.empty(n, L, L, device=dev)

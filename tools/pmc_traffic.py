@@ -19,9 +19,15 @@ def short(name):
     # K9 instantiations carry a trailing template argument (the fused-merge flag): report them under the plain key
     # (round 3: two trailing flags -- fused FPN merge, seven-tile mode; both forms of the plain kernels map to one key)
     for key in ['k_conv<3, 2, 2, 4, true, 1', 'k_conv<1, 2, 2, 4, true, 1']:
-        for tail in (', false>', ', false, false>', ', false, true>'):
+        for tail in (', false>', ', false, false>', ', false, true>', ', 0, false, 0>', ', 0, true, 0>'):
             if key + tail in name:
                 return key + '>'
+    for key, lab in (('k_conv<1, 2, 2, 4, true, 1, 0, false, 1>', 'k_conv<1,2,2,4> EPI 1 (k | v projection -> K^T V state)'),
+                     ('k_conv<1, 2, 2, 4, true, 1, 0, false, 2>', 'k_conv<1,2,2,4> EPI 2 (q projection -> attention message)'),
+                     ('k_conv<1, 4, 1, 4, true, 1, 0, false, 3>', 'k_conv<1,4,1,4> EPI 3 (merge_feat, rows gathered through the match indices)'),
+                     ('k_kv_blocks_reduce', 'k_kv_blocks_reduce')):
+        if key in name:
+            return lab
     for key in ['k_wino<', 'k1_conf_wide', 'k1_conf_fix', 'k1_bwd', 'k2_bwd', 'k1_rowstatsILb1', 'k_cvw_apply', 'k_stats_f32', 'k_match_f32', 'k_emm_pv_f32', 'k_la_kv_partial<32>', 'k_la_apply<32>', 'k_layernorm',
                 'k_conv<3, 2, 2, 4, true, 1>', 'k_conv<1, 2, 2, 4, true, 1>', 'k_pv', 'k_rowstats', 'k1_rowstats', 'k1_matchILb0', 'k1_matchILb1']:
         if key in name:
