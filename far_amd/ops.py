@@ -888,6 +888,8 @@ class _BatchNormActFn(torch.autograd.Function):
         _lib.check(rc, 'far_bn_act_train_fwd_f32')
         if track:
             bn.num_batches_tracked += 1
+            _written(bn.running_mean)                # K19 updated them through raw pointers: the inference image folded from the
+            _written(bn.running_var)                 # old statistics (PackCache stamps on their versions) must not be reused
         ctx.save_for_backward(xc, y, buf, weight)
         ctx.act, ctx.slope, ctx.has_res, ctx.nb = _ACT[act], float(slope), residual is not None, nb
         return y
@@ -1062,7 +1064,7 @@ class PackedConv:
         self._base = None if scale is None else scale.detach().float().contiguous()
         self.scale = torch.empty(Cout, dtype=torch.float32, device=w.device)      # base scale x 2^-(w_exp + 4), written by the pack kernel
         self.shift = None if shift is None else shift.detach().float().contiguous()
-        self._wino = None
+        self._wino, self._wino_stale = None, False
         self._pack(w)
 
     def _pack(self, w):
@@ -1096,8 +1098,14 @@ class PackedConv:
         if tuple(w.shape) != self._wshape or w.dtype != torch.float32 or not w.is_contiguous() or w.device != self.packed.device:
             raise _lib.FarHipError('PackedConv.refresh: the weight changed shape, dtype, layout or device')
         self._pack(w)
-        self._wino = None                                         # the Winograd image of the old weights
+        self.invalidate_wino()
         return self
+
+    def invalidate_wino(self):
+        """The weight changed: the K17 image (if one was built) holds the old weights.  It is re-packed in place at its next use
+        (wino()); every path that re-packs this image -- refresh() and the whole-model table (_PackTable.refresh_all) -- ends here."""
+        if self._wino:
+            self._wino_stale = True
 
     def wino(self):
         """The K17 image of the same layer (built at the first inference launch that can use it, from the weight this image was
@@ -1107,6 +1115,10 @@ class PackedConv:
             ok = (self.ksize == 3 and self.stride == 1 and self.split and self._view[3] == 0 and self.Cin % 4 == 0 and self.Cout % 4 == 0
                   and self._w.dim() == 4)
             self._wino = PackedWino(self._w, self._base, self.shift) if ok else False
+            self._wino_stale = False
+        elif self._wino and self._wino_stale:
+            self._wino.refresh(self._w)                           # self._w shares the parameter's storage: the current weights
+            self._wino_stale = False
         return self._wino or None
 
 
@@ -1130,11 +1142,21 @@ class PackedWino:
         self._base = None if scale is None else scale.detach().float().contiguous()
         self.scale = torch.empty(self.Cout, dtype=torch.float32, device=w.device)
         self.shift = None if shift is None else shift.detach().float().contiguous()
+        self._wshape = tuple(w.shape)
+        self.refresh(w)
+
+    def refresh(self, weight):
+        """(Re-)packs the image from `weight` into the same buffers: two launches, no allocation."""
+        lib = _lib.load()
+        w = weight.detach()
+        if tuple(w.shape) != self._wshape or w.dtype != torch.float32 or not w.is_contiguous() or w.device != self.packed.device:
+            raise _lib.FarHipError('PackedWino.refresh: the weight changed shape, dtype, layout or device')
         _lib.check(lib.far_weight_scale_f32(_p(w, torch.float32), w.numel(), _p(self.pack_scale), _stream()), 'far_weight_scale_f32')
         rc = lib.far_wino_pack_view_scaled_f32(_p(w), 9 * self.Cin, 9, 1, self.Cin, self.Cout, _p(self.pack_scale), _p(self.packed),
                                                _p(self._base) if self._base is not None else None, _p(self.scale), _stream())
         _lib.check(rc, 'far_wino_pack_view_scaled_f32')
         self._w = w
+        return self
 
 
 WINO_MIN_ACT_EXP = 0        # K17 splits its operands unscaled (|a| <= 16376): used while the activation exponent is >= 0
@@ -1379,6 +1401,7 @@ class _PackTable:
         _lib.check(_lib.load().far_pack_table_run(_p(table), n, _stream()), 'far_pack_table_run')
         for (cache, key, w, pc), st in zip(keep, stamps):
             cache._store[key] = (st, pc)
+            pc.invalidate_wino()                        # the table re-packs K9's images only: K17's follow lazily, in place
         return True
 
 

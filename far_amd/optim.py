@@ -29,7 +29,7 @@ class AdamW(torch.optim.Optimizer):
                 raise _lib.FarHipError('far_amd.optim.AdamW needs contiguous fp32 parameters on one GPU')
             st = self.state[p]
             if 'exp_avg' not in st:
-                st['step'] = 0
+                st['step'] = torch.tensor(0.0, dtype=torch.float32)      # a CPU float tensor, as torch.optim.AdamW keeps it
                 st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
             elif (st['exp_avg'].dtype != torch.float32 or not st['exp_avg'].is_contiguous() or st['exp_avg'].device != dev
@@ -75,24 +75,29 @@ class AdamW(torch.optim.Optimizer):
             # after the previous step's upload has left the pinned buffer (nothing else orders the host against it)
             if t.get('uploaded') is not None:
                 t['uploaded'].synchronize()
-            steps = set()
+            # validate first, mutate after: a raise must leave the optimizer state as it was
+            active = []
             for i, p in enumerate(t['params']):
                 g = p.grad
-                if g is None:
-                    t['rows'][i, 1] = 0
-                    continue
-                if g.dtype != torch.float32 or not g.is_contiguous() or g.is_sparse:
-                    raise _lib.FarHipError('far_amd.optim.AdamW needs dense contiguous fp32 gradients')
-                t['rows'][i, 1] = g.data_ptr()
-                st = self.state[p]
-                st['step'] = int(st['step']) + 1          # (a state dict written by torch.optim.AdamW carries the step as a tensor)
-                steps.add(st['step'])
-            if not steps:
-                continue
-            if len(steps) != 1:
+                if g is not None:
+                    if g.dtype != torch.float32 or not g.is_contiguous() or g.is_sparse:
+                        raise _lib.FarHipError('far_amd.optim.AdamW needs dense contiguous fp32 gradients')
+                    active.append((i, p, g))
+            steps = {int(self.state[p]['step']) for _, p, _ in active}
+            if len(steps) > 1:
                 raise _lib.FarHipError('far_amd.optim.AdamW: parameters of one group have different step counts '
                                        '(a parameter skipped earlier steps): use torch.optim.AdamW')
-            k = steps.pop()
+            t['rows'][:, 1] = 0
+            if not steps:
+                continue
+            k = steps.pop() + 1
+            for i, p, g in active:
+                t['rows'][i, 1] = g.data_ptr()
+                st = self.state[p]
+                if torch.is_tensor(st['step']):           # the step stays a tensor (torch.optim.AdamW can resume this state dict)
+                    st['step'] += 1
+                else:
+                    st['step'] = k
             n = t['n']
             t['dev'][:n * 40].copy_(t['host'][:n * 40], non_blocking=True)
             if t.get('uploaded') is None:

@@ -22,10 +22,13 @@ def test_step(matcher, batch, run_cfg=None, H=2048, seed=0):
     if cfg.LOFTR.FINE_PRED_STEPS > 0:
         # the head WILL be called on this batch: its feature stage may be enqueued behind the coarse matcher (LoFTR.head_prefetch)
         batch['_far_head_follows'] = True
-    out = matcher(batch)                                                            # :328
+    try:
+        out = matcher(batch)                                                        # :328
+    finally:
+        batch.pop('_far_head_follows', None)               # also when the matcher raised: a later matcher-only call must not prefetch
     if isinstance(out, dict) and out is not batch:         # a wrapper that copied the dict (DDP with device_ids): merge its writes
         batch.update(out)
-    batch.pop('_far_head_follows', None)
+        batch.pop('_far_head_follows', None)
     batch['translation_scale'] = None                                               # :335
     compute_supervision_RT(batch, cfg, H=H, seed=seed)                              # :336
     steps = cfg.LOFTR.FINE_PRED_STEPS

@@ -48,14 +48,20 @@ def estimate_pose_batch(kpts0, kpts1, counts, K0, K1, thresh, solver='ransac', p
     mode = _branch(solver, priorRT is not None)
     many = mode != 'ransac'
     tens = torch.is_tensor(K0) and torch.is_tensor(K1)
-    kkey = ('K', K0.data_ptr(), K1.data_ptr(), tuple(K0.shape), str(dev)) if (cache is not None and tens) else None
-    if kkey is not None and kkey in cache:
-        K0d, K1d = cache[kkey]
+    # the cache entry holds the K0 / K1 tensor objects themselves (so their addresses cannot be handed to another tensor while the
+    # entry lives) and their versions: a replaced batch['K0'] or an in-place rescale of the intrinsics misses
+    kkey = ('K', tuple(K0.shape), str(dev)) if (cache is not None and tens) else None
+    hit = cache.get(kkey) if kkey is not None else None
+    stamp = (ops.tensor_version(K0), ops.tensor_version(K1)) if kkey is not None else None
+    if hit is not None and hit[0] is K0 and hit[1] is K1 and hit[2] == stamp:
+        K0d, K1d = hit[3], hit[4]
     else:
         K0d = K0.to(device=dev, dtype=torch.float64)
         K1d = K1.to(device=dev, dtype=torch.float64)
         if kkey is not None:
-            cache[kkey] = (K0d, K1d)
+            cache[kkey] = (K0, K1, stamp, K0d, K1d)
+            for k in [k for k in cache if isinstance(k, tuple) and k and k[0] == 'th']:      # thresholds derived from the old intrinsics
+                del cache[k]
     tkey = ('th', kkey, float(thresh), many, len(counts)) if kkey is not None else None
     if tkey is not None and tkey in cache:
         inl_th = cache[tkey]

@@ -583,6 +583,54 @@ def test_pack_table_repacks_every_training_image_like_a_fresh_pack():
         ops.USE_PACK_TABLE = True
 
 
+@pytest.mark.parametrize('table', [True, False])
+def test_training_forward_on_k17_follows_the_weights_after_an_optimizer_step(table):
+    """The training forward of a stride-1 3x3 layer runs on K17 at >= 32x32 inputs (autograd.Function.forward has grad mode
+    off).  Its Winograd image must follow every re-pack of the K9 image -- the per-image refresh AND the whole-model table
+    (far_pack_table_run re-packs K9 images only): after an in-place update of all weights the next forward equals the forward
+    of a freshly built pack bit for bit, in the same buffers."""
+    ops = _ops()
+    g = torch.Generator(device='cuda').manual_seed(11)
+    ws = {n: (torch.randn(co, ci, 3, 3, device='cuda', generator=g) * 0.03).requires_grad_(True)
+          for n, (co, ci) in {'a': (128, 128), 'b': (196, 128), 'c': (64, 196)}.items()}
+    cache = ops.PackCache()
+    xs = {n: torch.randn(2, w.shape[1], 40, 36, device='cuda', generator=g) for n, w in ws.items()}
+
+    def step():
+        out = {}
+        for n, w in ws.items():
+            x = xs[n].clone().requires_grad_(True)
+            y = ops.conv_train(x, w, 1, cache, n)
+            y.sum().backward()
+            out[n] = y.detach().clone()
+        return out
+
+    def fresh():
+        with torch.no_grad():
+            return {n: ops.conv_nhwc(xs[n].permute(0, 2, 3, 1).contiguous(), ops.PackedConv(w)).permute(0, 3, 1, 2) for n, w in ws.items()}
+
+    ops.USE_PACK_TABLE = table
+    try:
+        first = step()
+        pcs = {n: cache.get((n, 'fwd', True), [w], None) for n, w in ws.items()}
+        assert all(pc._wino for pc in pcs.values()), 'the training forward did not take K17 at this size'
+        ptrs = {n: pc._wino.packed.data_ptr() for n, pc in pcs.items()}
+        for n in ws:
+            assert torch.equal(first[n], fresh()[n])
+        for it in range(2):
+            with torch.no_grad():
+                for i, w in enumerate(ws.values()):
+                    w.mul_(1.3 + i).add_(0.004)
+                    w.grad = None
+            got, exp = step(), fresh()
+            for n in ws:
+                assert torch.equal(got[n], exp[n]), (n, it)
+                assert not torch.equal(got[n], first[n])
+            assert all(pcs[n]._wino.packed.data_ptr() == ptrs[n] for n in ws)          # re-packed in place
+    finally:
+        ops.USE_PACK_TABLE = True
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # K17: Winograd F(2x2, 3x3) on split-fp16 operands (far_conv3x3_wino_f32) -- the same contract as K9's stride-1 3x3 mode
 # ---------------------------------------------------------------------------------------------------------------------

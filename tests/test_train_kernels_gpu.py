@@ -729,3 +729,25 @@ def test_adamw_one_launch_matches_torch_adamw():
     oa.step(); ob.step()
     for a, b in zip(pa, pb):
         torch.testing.assert_close(a, b, rtol=2e-6, atol=1e-7)
+    # the reverse: a state dict written by far_amd.optim.AdamW resumes under torch.optim.AdamW (the step is a tensor, as torch keeps it)
+    oc = torch.optim.AdamW(pb, lr=3e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.1)
+    oc.load_state_dict(copy.deepcopy(oa.state_dict()))
+    assert all(torch.is_tensor(oa.state[a]['step']) for a in pa[:5])
+    for i, (a, b) in enumerate(zip(pa, pb)):
+        with torch.no_grad():
+            b.copy_(a)
+        if i != 5:
+            g = torch.randn_like(a)
+            a.grad, b.grad = g.clone(), g.clone()
+    oa.step(); oc.step()
+    for a, b in zip(pa, pb):
+        torch.testing.assert_close(a, b, rtol=2e-6, atol=1e-7)
+    # differing step counts raise BEFORE anything is mutated
+    oa.state[pa[0]]['step'] += 3
+    before = [float(oa.state[a]['step']) for a in pa[:5]]
+    snap = [a.detach().clone() for a in pa]
+    with pytest.raises(Exception, match='different step counts'):
+        oa.step()
+    torch.cuda.synchronize()
+    assert before == [float(oa.state[a]['step']) for a in pa[:5]]
+    assert all(torch.equal(a, s) for a, s in zip(pa, snap))
