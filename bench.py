@@ -44,15 +44,27 @@ def parse():
                     help="c2 = BASELINE configs[1] (the headline metric: match + solve + regress, batch 32); "
                          "c4 = BASELINE configs[3] (cached-LoFTR path: GPU solver on cached correspondences + head, batch 256)")
     ap.add_argument('--hyp', type=int, default=2048, help='RANSAC hypotheses per pair (metrics.py:120)')
+    ap.add_argument('--minimal', type=int, default=8, choices=[8, 5],
+                    help="c2: minimal solver of the RANSAC hypotheses: 8 = the normalized 8-point north_star names (default), 5 = Nister's "
+                         "five-point for every pair -- the solver class the reference actually executes (OpenCV's five-point, "
+                         "ransac.py:151-157)")
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'fp16-fine', 'fp16', 'bf16'],
                     help='backbone convolution arithmetic (far_amd.loftr.LoFTR.set_precision): fp32 = split-fp16 operand pairs (fp32-grade)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--skip-rooflines', action='store_true',
+                    help='c2 child legs of other_workloads only: no isolated kernel timings / roofline object (the parent line carries them)')
     ap.add_argument('--no-other-modes', action='store_true', help='skip the informational fp16-operand leg of the default run')
     ap.add_argument('--no-other-workloads', action='store_true',
                     help='skip the short legs of the other BASELINE configs (c3, c4, c5) and the one-pair latency leg of the default run')
     ap.add_argument('--cpu-pairs', type=int, default=3)
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help="torch.distributed backend of the N > 1 run ('nccl' is RCCL on ROCm; 'gloo' only for the CPU self-test)")
+    ap.add_argument('--dist-at-world-1', action='store_true',
+                    help="join the process group even when WORLD_SIZE is 1 (a single rank, under torch.distributed.run "
+                         "--nproc-per-node 1 or plain python): init_process_group('nccl', device_id=...) = RCCL comes up, the barrier / "
+                         "max-over-ranks / per-rank gather run as collectives on device tensors, and the training workload builds "
+                         "SyncBatchNorm + DistributedDataParallel over it and all-reduces its gradients (to itself).  The one-GPU box's "
+                         "way of executing the code path the 8-GPU run takes.")
     ap.add_argument('--share-gpu', action='store_true',
                     help="functional check of the N > 1 path on a one-GPU box: every rank uses cuda:0 (needs --backend gloo; RCCL "
                          "refuses two ranks on one device).  The timings of such a run mean nothing.")
@@ -279,10 +291,11 @@ def other_workloads(a):
     started AFTER this process has finished its own timing (python bench.py --workload ...: its own line, parsed here), so that
     every workload number is in the line the driver records.  Informational: never `value`."""
     import subprocess
-    legs = [('c3_training_step', ['--workload', 'c3', '--steps', '5', '--warmup', '3']),
-            ('c4_cached_path', ['--workload', 'c4', '--steps', '3', '--warmup', '2']),
-            ('c5_mapfree_544x720', ['--workload', 'c5', '--steps', '3', '--warmup', '2']),
-            ('c2_one_pair_latency', ['--pairs', '1', '--steps', '20', '--warmup', '5'])]
+    legs = [('c3_training_step', ['--workload', 'c3', '--steps', '12', '--warmup', '3']),
+            ('c4_cached_path', ['--workload', 'c4', '--steps', '10', '--warmup', '2']),
+            ('c5_mapfree_544x720', ['--workload', 'c5', '--steps', '10', '--warmup', '3']),
+            ('c2_one_pair_latency', ['--pairs', '1', '--steps', '20', '--warmup', '5', '--skip-rooflines']),
+            ('c2_five_point_solver', ['--minimal', '5', '--steps', '10', '--warmup', '3', '--skip-rooflines'])]
     out = {}
     for name, args in legs:
         cmd = [sys.executable, os.path.abspath(__file__)] + args + ['--hyp', str(a.hyp), '--no-cpu-baseline', '--no-other-modes',
@@ -300,6 +313,11 @@ def other_workloads(a):
             for k in ('k4', 'k1', 'vendor_convolution'):
                 if k in r:
                     ent[k] = r[k]
+            if name == 'c2_five_point_solver':
+                ent['pose_error'] = r['config'].get('pose_error')
+                ent['note'] = ("the headline workload with Nister's five-point solver as the minimal solver of every pair (H = 2048 models "
+                               "from H / 10 samples): the solver CLASS the reference executes (OpenCV's five-point on the host, "
+                               "ransac.py:151-157, cv_geometry.py:836-859); the headline uses the normalized 8-point north_star names")
             if name == 'c2_one_pair_latency':
                 ent['note'] = ('the reference\'s deployment shape (scripts/eval_matterport.sh: batch_size 1): ms_per_step IS the latency of one '
                                'pair through match + 2 solver rounds + 2 head calls')
@@ -635,8 +653,11 @@ def bench_c3(a, dev, world, rank, dist):
                                            'images through a self-attention layer in one call; all weight images re-packed in two launches per step',
                        'gt_coarse_matches_per_pair': n_gt, 'sampled_matches': int(last['b_ids'].numel()),
                        'losses': sc,
-                       'parallelism': f'ddp{world} (gradient all-reduce over RCCL)' if world > 1 else 'single GPU (no exchange step)'},
+                       'parallelism': (f'ddp{world} (gradient all-reduce over {"RCCL" if a.backend == "nccl" else a.backend})' if dist is not None
+                                       else 'single GPU (no exchange step)')},
             'exchange': exchange, 'per_rank_sustained_peak': per_rank_peak,
+            'process_group': {'backend': dist.get_backend(), 'world_size': dist.get_world_size(),
+                              'sync_batchnorm': any(isinstance(m_, torch.nn.SyncBatchNorm) for m_ in model.modules())} if dist is not None else None,
         }
         print(json.dumps(res), flush=True)
     if dist is not None:
@@ -736,9 +757,13 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist = None
-    if world > 1:
+    if world > 1 or a.dist_at_world_1:
         import torch.distributed as dist
-        dist.init_process_group(a.backend, device_id=dev if a.backend == 'nccl' else None)
+        kw = {}
+        if 'MASTER_ADDR' not in os.environ or 'RANK' not in os.environ:      # plain `python bench.py --dist-at-world-1`: no launcher
+            from far_amd import parallel as _par
+            kw = dict(init_method=f'tcp://127.0.0.1:{_par.free_port()}', rank=0, world_size=1)
+        dist.init_process_group(a.backend, device_id=dev if a.backend == 'nccl' else None, **kw)
         world = dist.get_world_size()            # the rank count the backend (RCCL) reports
     if os.environ.get('FAR_NO_STACK') == '1':          # A/B aid (any workload): 'self' layers on the two images separately
         from far_amd.loftr.transformer import LocalFeatureTransformer as _T0
@@ -766,9 +791,12 @@ def main():
     base = {'image0': torch.from_numpy(im0).to(dev), 'image1': torch.from_numpy(im1).to(dev), 'K0': K, 'K1': K.clone(),
             'dataset_name': ['mp3d']}
 
+    from far_amd.config import RunCfg as _RunCfg
+    run_cfg = _RunCfg(cfg['solver'], cfg.get('fine_pred_steps', 2), minimal_solver=a.minimal)
+
     def step():
         batch = dict(base)
-        test_step(model, batch, H=a.hyp, seed=0)
+        test_step(model, batch, run_cfg=run_cfg, H=a.hyp, seed=0)
         return batch
 
     # the caching allocator still grows (multi-GB hipMallocs) during the first three steps: when fewer warm-up steps
@@ -818,50 +846,52 @@ def main():
         pk = max(v['tflops'] for v in mfma_sustained_peak().values())
         per_rank_peak = [round(x, 1) for x in parallel.gather_floats(pk, device=dev)]
     if rank == 0:
-        kr = kernel_rooflines(a.pairs)
-        # dominant kernel of the step: the backbone's 3x3 convolutions (45 % of the kernel-busy time, profiles/); its costliest launch
-        # is reported -- K17 (Winograd) since round 4, K9 (direct) when ops.USE_WINO is off
-        from far_amd import ops as _ops
-        wino = _ops.USE_WINO
-        dom = 'k_wino[K17 3x3 196->196 @240x320]' if wino else 'k_conv[K9 3x3 196->196 @240x320]'
-        tr = pmc_traffic(dom, a.pairs, a.precision)
-        probe = mfma_sustained_peak()
-        sustained = max(v['tflops'] for v in probe.values())
-        executed = kr[dom]['mfma_executed_tflops']
-        per_alg = 3.0 * 16.0 / 36.0 if wino else 3.0          # MFMA flops issued per algorithmic flop, before padding
-        roof = {'kernel': dom, 'bound': 'mfma', 'achieved': round(kr[dom]['tflops'], 2), 'peak': F16_MFMA_PEAK_TFLOPS,
-                'unit': 'TFLOP/s', 'frac': round(kr[dom]['frac'], 4),
-                # what the part sustains under dense f16 MFMA issue, measured on THIS box just now (far_mfma_probe_f16: K9's
-                # accumulator / fragment footprint, random operands, nothing else in the loop): the nominal 2.5 PFLOP/s assumes
-                # 2.4 GHz, the power-limited clock under this load is 1.5-1.8 GHz
-                'sustained_peak': sustained, 'sustained_probe': probe,
-                'frac_of_sustained': round(kr[dom]['tflops'] / sustained, 4),
-                'mfma_issue_frac_of_sustained': round(per_alg * kr[dom]['tflops'] / sustained, 4),
-                'mfma_executed_frac_of_sustained': round(executed / sustained, 4),
-                'sustained_note': 'frac_of_sustained = algorithmic (direct-convolution) flops / sustained; mfma_issue = x MFMA flops issued '
-                                  'per algorithmic flop (K9: 3 = three f16 MFMAs per fp32-grade product; K17: 3 x 16/36, Winograd F(2x2,3x3) '
-                                  'needs 16 products per 2x2 outputs instead of 36); mfma_executed also counts the MFMAs spent on channel / '
-                                  'tile padding (what the pipe actually ran)',
-                # HBM/fabric bytes per launch from the committed PMC passes (null when they do not match this geometry
-                # and precision); `committed_profile` names the file / commit they were measured at
-                'traffic': (tr or {}).get('bytes'), 'committed_profile': tr,
-                'launch_ms': round(kr[dom]['ms'], 3), 'launch_ms_rocprof': rocprof_launch_ms(dom),
-                'mfma_issue_frac': round(kr[dom]['mfma_issue_frac'], 4),
-                'same_launch_on_k9': {'launch_ms': round(kr['k_conv[K9 3x3 196->196 @240x320]']['ms'], 3),
-                                      'frac': round(kr['k_conv[K9 3x3 196->196 @240x320]']['frac'], 4)} if wino else None,
-                'note': ('algorithmic convolution flops per launch (2 N H W Cin Cout 9, the direct form) / event-timed launch duration '
-                         'against the dense f16 MFMA peak.  K17 executes 1.33 f16 MFMA flops per algorithmic flop (split operands x '
-                         'Winograd), so the matrix pipe is busy mfma_issue_frac of the time at the nominal 2.4 GHz; what bounds it is not '
-                         'the matrix pipe but the L2 -> LDS operand stream: a workgroup holds 16 accumulator planes for its 256 outputs x 64 '
-                         'channels (half the register file of a CU) and re-streams the 16 transformed weight planes for every such tile -- '
-                         '26 GB through L2 per launch of the 128-channel layer in 1.85 ms (DESIGN section 4, K17; '
-                         'profiles/r04_k17_winograd.txt)') if wino else
-                        ('algorithmic convolution flops per launch / event-timed launch duration against the dense f16 '
-                         'MFMA peak; the kernel executes 3 f16 MFMAs per fp32-grade product (split operands), so the '
-                         'matrix pipe is busy mfma_issue_frac of the time AT THE NOMINAL 2.4 GHz; the shader clock '
-                         'measured inside this kernel is 1.5-1.8 GHz (power limit under dense MFMA: s_memtime stamps in '
-                         'profiles/r01_k9_workgroup_timeline.txt, GRBM_GUI_ACTIVE in profiles/r02_pmc_util.txt: 1.59 GHz, '
-                         'SQ_VALU_MFMA_BUSY_CYCLES = 72 % of those cycles)')}
+        kr, roof = {}, None
+        if not a.skip_rooflines:
+            kr = kernel_rooflines(a.pairs)
+            # dominant kernel of the step: the backbone's 3x3 convolutions (45 % of the kernel-busy time, profiles/); its costliest launch
+            # is reported -- K17 (Winograd) since round 4, K9 (direct) when ops.USE_WINO is off
+            from far_amd import ops as _ops
+            wino = _ops.USE_WINO
+            dom = 'k_wino[K17 3x3 196->196 @240x320]' if wino else 'k_conv[K9 3x3 196->196 @240x320]'
+            tr = pmc_traffic(dom, a.pairs, a.precision)
+            probe = mfma_sustained_peak()
+            sustained = max(v['tflops'] for v in probe.values())
+            executed = kr[dom]['mfma_executed_tflops']
+            per_alg = 3.0 * 16.0 / 36.0 if wino else 3.0          # MFMA flops issued per algorithmic flop, before padding
+            roof = {'kernel': dom, 'bound': 'mfma', 'achieved': round(kr[dom]['tflops'], 2), 'peak': F16_MFMA_PEAK_TFLOPS,
+                    'unit': 'TFLOP/s', 'frac': round(kr[dom]['frac'], 4),
+                    # what the part sustains under dense f16 MFMA issue, measured on THIS box just now (far_mfma_probe_f16: K9's
+                    # accumulator / fragment footprint, random operands, nothing else in the loop): the nominal 2.5 PFLOP/s assumes
+                    # 2.4 GHz, the power-limited clock under this load is 1.5-1.8 GHz
+                    'sustained_peak': sustained, 'sustained_probe': probe,
+                    'frac_of_sustained': round(kr[dom]['tflops'] / sustained, 4),
+                    'mfma_issue_frac_of_sustained': round(per_alg * kr[dom]['tflops'] / sustained, 4),
+                    'mfma_executed_frac_of_sustained': round(executed / sustained, 4),
+                    'sustained_note': 'frac_of_sustained = algorithmic (direct-convolution) flops / sustained; mfma_issue = x MFMA flops issued '
+                                      'per algorithmic flop (K9: 3 = three f16 MFMAs per fp32-grade product; K17: 3 x 16/36, Winograd F(2x2,3x3) '
+                                      'needs 16 products per 2x2 outputs instead of 36); mfma_executed also counts the MFMAs spent on channel / '
+                                      'tile padding (what the pipe actually ran)',
+                    # HBM/fabric bytes per launch from the committed PMC passes (null when they do not match this geometry
+                    # and precision); `committed_profile` names the file / commit they were measured at
+                    'traffic': (tr or {}).get('bytes'), 'committed_profile': tr,
+                    'launch_ms': round(kr[dom]['ms'], 3), 'launch_ms_rocprof': rocprof_launch_ms(dom),
+                    'mfma_issue_frac': round(kr[dom]['mfma_issue_frac'], 4),
+                    'same_launch_on_k9': {'launch_ms': round(kr['k_conv[K9 3x3 196->196 @240x320]']['ms'], 3),
+                                          'frac': round(kr['k_conv[K9 3x3 196->196 @240x320]']['frac'], 4)} if wino else None,
+                    'note': ('algorithmic convolution flops per launch (2 N H W Cin Cout 9, the direct form) / event-timed launch duration '
+                             'against the dense f16 MFMA peak.  K17 executes 1.33 f16 MFMA flops per algorithmic flop (split operands x '
+                             'Winograd), so the matrix pipe is busy mfma_issue_frac of the time at the nominal 2.4 GHz; what bounds it is not '
+                             'the matrix pipe but the L2 -> LDS operand stream: a workgroup holds 16 accumulator planes for its 256 outputs x 64 '
+                             'channels (half the register file of a CU) and re-streams the 16 transformed weight planes for every such tile -- '
+                             '26 GB through L2 per launch of the 128-channel layer in 1.85 ms (DESIGN section 4, K17; '
+                             'profiles/r04_k17_winograd.txt)') if wino else
+                            ('algorithmic convolution flops per launch / event-timed launch duration against the dense f16 '
+                             'MFMA peak; the kernel executes 3 f16 MFMAs per fp32-grade product (split operands), so the '
+                             'matrix pipe is busy mfma_issue_frac of the time AT THE NOMINAL 2.4 GHz; the shader clock '
+                             'measured inside this kernel is 1.5-1.8 GHz (power limit under dense MFMA: s_memtime stamps in '
+                             'profiles/r01_k9_workgroup_timeline.txt, GRBM_GUI_ACTIVE in profiles/r02_pmc_util.txt: 1.59 GHz, '
+                             'SQ_VALU_MFMA_BUSY_CYCLES = 72 % of those cycles)')}
         res = {
             'metric': 'image-pairs/sec (match+solve+regress) at 640x480',
             'value': round(world * a.pairs * a.steps / dt, 3), 'unit': 'image-pairs/sec',
@@ -880,11 +910,12 @@ def main():
                                    'layers, CrossAttention K2, CrossBlock MLP -- does not read the solver numbers and is computed ONCE per '
                                    'step, the second call re-runs only the 13-number-dependent MLPs / gate on it; exact reuse, '
                                    'tests/test_pipeline_gpu.py), seeded random weights',
-                       'pairs_per_gpu': a.pairs, 'hypotheses': a.hyp, 'fine_pred_steps': 2,
+                       'pairs_per_gpu': a.pairs, 'hypotheses': a.hyp, 'minimal_solver': a.minimal, 'fine_pred_steps': 2,
                        'matches_per_pair': round(matches, 1), 'solver_success_frac': ok_frac, 'pose_error': pose_err,
                        'parallelism': f'dp{world} (independent pairs, no data-path collective)'},
             'roofline': roof,
             'kernels': {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in kr.items()},
+            'process_group': {'backend': dist.get_backend(), 'world_size': dist.get_world_size()} if dist is not None else None,
         }
         if world == 1 and a.precision == 'fp32' and not a.no_other_modes:
             # informational: the same step with plain fp16 matrix operands in every K9 launch (the precision class BASELINE

@@ -117,6 +117,10 @@ SIGNATURES = {
     'far_solver_workspace_bytes': (c_sz, [c_i, c_i, c_i, c_i]),
     'far_solver_f64': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_d, c_i, c_i, c_u32, c_p]
                        + [c_p] * 14 + [c_p, c_p]),
+    'far_ransac_f64': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_d, c_i, c_i, c_u32, c_p] + [c_p] * 6 + [c_p, c_p]),
+    'far_eightpoint_f64': (c_i, [c_p, c_p, c_p, c_i, c_i, c_p, c_p]),
+    'far_decompose_essential_f64': (c_i, [c_p, c_l, c_p, c_p, c_p, c_p]),
+    'far_build_id': (ctypes.c_char_p, []),
 }
 
 
@@ -149,7 +153,7 @@ class EncLayer(ctypes.Structure):
                [(n, ctypes.c_void_p) for n in ('g1', 'b1', 'g2', 'b2', 'overflow')]
 
 
-EXPECTED_ABI = 5          # far_abi_version() of the library these signatures describe (include/far_hip.h)
+EXPECTED_ABI = 6          # far_abi_version() of the library these signatures describe (include/far_hip.h)
 _lib = None
 
 
@@ -184,6 +188,14 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
+    # provenance: the library travels outside git (built in-tree, snapshot-copied to the GPU box).  Its build id must equal the id of
+    # the sources it is loaded next to; FAR_HIP_LIB (tools/ab_build.py: a library of another revision, on purpose) skips the check
+    if 'FAR_HIP_LIB' not in os.environ:
+        from . import build as _build
+        want, have = _build.source_id(), lib.far_build_id().decode()
+        if have != want:
+            raise FarHipError(f'{LIB_PATH} was built from other sources (build id {have}, far_amd/csrc is {want}): rebuild it with '
+                              '`python -m far_amd.build`')
     for kv in filter(None, os.environ.get('FAR_TUNING', '').split(',')):      # A/B aid: FAR_TUNING="10=1,8=1" -> far_set_tuning(key, value)
         k, v = kv.split('=')
         lib.far_set_tuning(int(k), int(v))

@@ -4,7 +4,13 @@
 static thread_local int g_last_hip_error = 0;
 void far_record_hip_error(int e) { g_last_hip_error = e; }
 
-extern "C" int far_abi_version(void) { return 5; }
+extern "C" int far_abi_version(void) { return 6; }
+// The id of the sources this library was built from: sha256/16 over far_amd/csrc/* and the compiler flags (far_amd/build.py
+// source_id(), passed as -DFAR_BUILD_ID when this file is compiled).  "unknown" for a build that did not go through build.py.
+#ifndef FAR_BUILD_ID
+#define FAR_BUILD_ID "unknown"
+#endif
+extern "C" const char* far_build_id(void) { return FAR_BUILD_ID; }
 // hipError_t of the most recent failed launch on this thread (0 = none); for diagnostics after a -5 return.
 extern "C" int far_last_hip_error(void) { return g_last_hip_error; }
 

@@ -367,6 +367,53 @@ __device__ __forceinline__ double prior_score_of(const double (&Fe)[9], int b, c
     return -(err * err) / lambda;
 }
 
+// The normalized 8-point from the 9 x 9 normal matrix on (cv_geometry.py:814-833): null vector (Jacobi), rank-2 projection,
+// de-normalisation with the two Hartley transforms T = [[s, 0, tx], [0, s, ty], [0, 0, 1]], normalize_transformation.
+// Shared by k_hypotheses (8 sampled correspondences) and k_eightpoint (run_8point's N weighted correspondences).
+__device__ __forceinline__ void eightpoint_from_normal(double (&a)[45], VHybrid& v, double s1, double t1x, double t1y,
+                                                       double s2, double t2x, double t2y, double (&Fe)[9]) {
+    jacobi_eig<9>(a, v, 20);
+    // eigenvector of the smallest eigenvalue (cv_geometry.py:820-821)
+    int km = 0; double lm = a[tri<9>(0, 0)];
+#pragma unroll
+    for (int p = 1; p < 9; ++p) { double l = a[tri<9>(p, p)]; if (l < lm) { lm = l; km = p; } }
+    double Fm[9];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) Fm[r] = v.base[(r * 9 + km) * v.stride];
+    Fm[8] = v.top_dyn(km);
+    // rank-2 projection: F - (F v3) v3^T  == U diag(s1, s2, 0) V^T  (cv_geometry.py:824-827)
+    double V3[9], lam[3];
+    right_singular_3x3(Fm, V3, lam);
+    {
+        const double n0 = V3[2], n1 = V3[5], n2 = V3[8];
+        double Fv[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) Fv[r] = Fm[r * 3] * n0 + Fm[r * 3 + 1] * n1 + Fm[r * 3 + 2] * n2;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { Fm[r * 3] -= Fv[r] * n0; Fm[r * 3 + 1] -= Fv[r] * n1; Fm[r * 3 + 2] -= Fv[r] * n2; }
+    }
+    // F_est = T2^T Fp T1 (cv_geometry.py:828), T = [[s,0,tx],[0,s,ty],[0,0,1]]
+    double G[9];  // Fp T1
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        G[r * 3 + 0] = Fm[r * 3 + 0] * s1;
+        G[r * 3 + 1] = Fm[r * 3 + 1] * s1;
+        G[r * 3 + 2] = Fm[r * 3 + 0] * t1x + Fm[r * 3 + 1] * t1y + Fm[r * 3 + 2];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        Fe[0 + c] = s2 * G[0 + c];
+        Fe[3 + c] = s2 * G[3 + c];
+        Fe[6 + c] = t2x * G[0 + c] + t2y * G[3 + c] + G[6 + c];
+    }
+    // normalize_transformation (cv_geometry.py:753-769)
+    const double nv = Fe[8];
+    if (fabs(nv) > 1e-8) {
+#pragma unroll
+        for (int e = 0; e < 9; ++e) Fe[e] = Fe[e] / (nv + 1e-8);
+    }
+}
+
 __global__ __launch_bounds__(64, 1) void k_hypotheses(
     const double4* __restrict__ kp, const int* __restrict__ offsets, const uint32_t* __restrict__ cdf_all,
     const int* __restrict__ samples_in, int H, int minimal, uint32_t seed, const PairPrior* __restrict__ pp,
@@ -421,47 +468,8 @@ __global__ __launch_bounds__(64, 1) void k_hypotheses(
     extern __shared__ __attribute__((aligned(16))) double vslab[];   // [72][blockDim.x]
     VHybrid v;
     v.base = vslab + threadIdx.x; v.stride = (int)blockDim.x;
-    jacobi_eig<9>(a, v, 20);
-    // eigenvector of the smallest eigenvalue (cv_geometry.py:820-821)
-    int km = 0; double lm = a[tri<9>(0, 0)];
-#pragma unroll
-    for (int p = 1; p < 9; ++p) { double l = a[tri<9>(p, p)]; if (l < lm) { lm = l; km = p; } }
-    double Fm[9];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) Fm[r] = v.base[(r * 9 + km) * v.stride];
-    Fm[8] = v.top_dyn(km);
-    // rank-2 projection: F - (F v3) v3^T  == U diag(s1, s2, 0) V^T  (cv_geometry.py:824-827)
-    double V3[9], lam[3];
-    right_singular_3x3(Fm, V3, lam);
-    {
-        const double n0 = V3[2], n1 = V3[5], n2 = V3[8];
-        double Fv[3];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) Fv[r] = Fm[r * 3] * n0 + Fm[r * 3 + 1] * n1 + Fm[r * 3 + 2] * n2;
-#pragma unroll
-        for (int r = 0; r < 3; ++r) { Fm[r * 3] -= Fv[r] * n0; Fm[r * 3 + 1] -= Fv[r] * n1; Fm[r * 3 + 2] -= Fv[r] * n2; }
-    }
-    // F_est = T2^T Fp T1 (cv_geometry.py:828), T = [[s,0,tx],[0,s,ty],[0,0,1]]
-    double G[9];  // Fp T1
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        G[r * 3 + 0] = Fm[r * 3 + 0] * s1;
-        G[r * 3 + 1] = Fm[r * 3 + 1] * s1;
-        G[r * 3 + 2] = Fm[r * 3 + 0] * t1x + Fm[r * 3 + 1] * t1y + Fm[r * 3 + 2];
-    }
     double Fe[9];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        Fe[0 + c] = s2 * G[0 + c];
-        Fe[3 + c] = s2 * G[3 + c];
-        Fe[6 + c] = t2x * G[0 + c] + t2y * G[3 + c] + G[6 + c];
-    }
-    // normalize_transformation (cv_geometry.py:753-769)
-    const double nv = Fe[8];
-    if (fabs(nv) > 1e-8) {
-#pragma unroll
-        for (int e = 0; e < 9; ++e) Fe[e] = Fe[e] / (nv + 1e-8);
-    }
+    eightpoint_from_normal(a, v, s1, t1x, t1y, s2, t2x, t2y, Fe);
     bool finite = true;
 #pragma unroll
     for (int e = 0; e < 9; ++e) finite = finite && (fabs(Fe[e]) < 1e300);
@@ -477,6 +485,68 @@ __global__ __launch_bounds__(64, 1) void k_hypotheses(
     double ps = 0.0;
     if (valid && pp) ps = prior_score_of(Fe, b, pcl, tgt, P, lambda);
     pscore[hid] = valid ? ps : -INFINITY;
+}
+
+
+// run_8point (cv_geometry.py:772-833) as a function of its own: B problems of N >= 8 weighted correspondences each, one thread
+// per problem (the function-level API of far_amd/ransac.py; K4's hypothesis stage above is the same arithmetic on 8 sampled points).
+// p1, p2 [B][N][2], w [B][N] or null (all ones), F_out [B][9]; float64.
+__global__ __launch_bounds__(64, 1) void k_eightpoint(const double* __restrict__ p1, const double* __restrict__ p2,
+                                                      const double* __restrict__ w, int B, int N, double* __restrict__ F_out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const double* a1 = p1 + (size_t)b * N * 2;
+    const double* a2 = p2 + (size_t)b * N * 2;
+    double m1x = 0, m1y = 0, m2x = 0, m2y = 0;
+    for (int i = 0; i < N; ++i) { m1x += a1[2 * i]; m1y += a1[2 * i + 1]; m2x += a2[2 * i]; m2y += a2[2 * i + 1]; }
+    m1x /= N; m1y /= N; m2x /= N; m2y /= N;
+    double d1 = 0, d2 = 0;
+    for (int i = 0; i < N; ++i) {
+        d1 += sqrt((a1[2 * i] - m1x) * (a1[2 * i] - m1x) + (a1[2 * i + 1] - m1y) * (a1[2 * i + 1] - m1y));
+        d2 += sqrt((a2[2 * i] - m2x) * (a2[2 * i] - m2x) + (a2[2 * i + 1] - m2y) * (a2[2 * i + 1] - m2y));
+    }
+    const double s1 = sqrt(2.0) / (d1 / N + 1e-8), s2 = sqrt(2.0) / (d2 / N + 1e-8);
+    const double t1x = -s1 * m1x, t1y = -s1 * m1y, t2x = -s2 * m2x, t2y = -s2 * m2y;
+    double a[45];
+#pragma unroll
+    for (int e = 0; e < 45; ++e) a[e] = 0.0;
+    for (int i = 0; i < N; ++i) {
+        const double ax = a1[2 * i] * s1 + t1x, ay = a1[2 * i + 1] * s1 + t1y, bx = a2[2 * i] * s2 + t2x, by = a2[2 * i + 1] * s2 + t2y;
+        const double wi = w ? w[(size_t)b * N + i] : 1.0;
+        const double row[9] = {bx * ax, bx * ay, bx, by * ax, by * ay, by, ax, ay, 1.0};
+#pragma unroll
+        for (int p = 0; p < 9; ++p)
+#pragma unroll
+            for (int q = p; q < 9; ++q) a[tri<9>(p, q)] += (row[p] * wi) * row[q];         // X^T diag(w) X (:814-817)
+    }
+    extern __shared__ __attribute__((aligned(16))) double vslab[];   // [72][blockDim.x]
+    VHybrid v;
+    v.base = vslab + threadIdx.x; v.stride = (int)blockDim.x;
+    double Fe[9];
+    eightpoint_from_normal(a, v, s1, t1x, t1y, s2, t2x, t2y, Fe);
+#pragma unroll
+    for (int e = 0; e < 9; ++e) F_out[(size_t)b * 9 + e] = Fe[e];
+}
+
+__global__ void k_identity9(double* __restrict__ K, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) K[(size_t)b * 9 + e] = (e % 4 == 0) ? 1.0 : 0.0;
+}
+
+// decompose_essential_matrix (essential.py:99-139) for n matrices: R1 = U W V^T, R2 = U W^T V^T, t = u3, with this build's sign
+// convention (decompose_E above; the reference's follows LAPACK's -- the set {R1, R2} x {t, -t} is the same).
+__global__ void k_decompose(const double* __restrict__ E, long n, double* __restrict__ R1o, double* __restrict__ R2o, double* __restrict__ to) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double Em[9], R1[9], R2[9], t[3];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) Em[e] = E[i * 9 + e];
+    decompose_E(Em, R1, R2, t);
+#pragma unroll
+    for (int e = 0; e < 9; ++e) { R1o[i * 9 + e] = R1[e]; R2o[i * 9 + e] = R2[e]; }
+    to[i * 3] = t[0]; to[i * 3 + 1] = t[1]; to[i * 3 + 2] = t[2];
 }
 
 #include "solver5_f64.inc"
@@ -532,7 +602,7 @@ __global__ void k_select(const double4* __restrict__ kp, const int* __restrict__
                          const double* __restrict__ inl_th, int H, int many_thr, int minimal,
                          int* __restrict__ best_out, double* __restrict__ E_out, uint8_t* __restrict__ mask,
                          int* __restrict__ n_inl, int* __restrict__ n_tight, int* __restrict__ n_ultra,
-                         int* __restrict__ status, int* __restrict__ good_g) {
+                         int* __restrict__ status, int* __restrict__ good_g, int mask_bits) {
     __shared__ double sv[256];
     __shared__ int si[256];
     __shared__ int cnt[3];
@@ -571,9 +641,11 @@ __global__ void k_select(const double4* __restrict__ kp, const int* __restrict__
             const double4 p = kp[o + i];
             const double e = sampson(F, p.x, p.y, p.z, p.w);
             m = e <= thr;
+            const bool tight = e <= thr / 10.0, ultra = e <= thr / 100.0;  // ransac.py:284-285
             c0 += m;
-            c1 += e <= thr / 10.0;                                         // ransac.py:284-285
-            c2 += e <= thr / 100.0;
+            c1 += tight;
+            c2 += ultra;
+            if (mask_bits) m |= (tight ? 2 : 0) | (ultra ? 4 : 0);         // far_ransac_f64: the three masks RANSAC.forward returns
         }
         mask[o + i] = m;
     }
@@ -760,6 +832,48 @@ SolverWs carve(void* ws, int B, int Mtot, int H, int P) {
     return w;
 }
 
+// Stages 1-3 of the solver (prior set-up, normalisation + bias weights, hypotheses, verification), shared by far_solver_f64 and
+// far_ransac_f64.  false: a launch-configuration call failed (far_check_launch reports it).
+static bool solver_stages_1to3(const float* kpts0, const float* kpts1, const int* offsets, int B, int Mtot, int Mmax, const double* K0,
+                               const double* K1, const double* inl_th, const float* priorRT, const float* pcl, int P, double prior_lambda,
+                               int H, int minimal, uint32_t seed, const int* samples_in, double* F_all_out, int* count_all_out,
+                               double* score_all_out, int* samples_out, const SolverWs& w, hipStream_t stream, double*& F_all,
+                               double*& score_all) {
+    const bool prior = priorRT != nullptr;
+    if (prior)
+        hipLaunchKernelGGL(k_prior_setup, dim3(B), dim3(128), 0, stream, priorRT, B, w.pp, pcl, P, w.tgt);
+    if (Mtot > 0 && Mmax > 0) {
+        hipLaunchKernelGGL(k_prepare, dim3((Mmax + 255) / 256, B), dim3(256), 0, stream, kpts0, kpts1, offsets, K0, K1,
+                           prior ? w.pp : nullptr, w.kn, w.kp, w.wq);
+        if (prior && !samples_in) hipLaunchKernelGGL(k_cdf, dim3(B), dim3(256), 0, stream, w.wq, offsets, w.cdf);
+    }
+    F_all = F_all_out ? F_all_out : w.F_all;
+    int* count_all = count_all_out ? count_all_out : w.count_all;
+    score_all = score_all_out ? score_all_out : w.score_all;
+    // hypotheses: the normalized 8-point for pairs with >= 8 correspondences (minimal = 8), the five-point solver for pairs
+    // with 5..7 -- and for every pair when minimal = 5.  Explicit samples (tests) follow the mode: [B][H][8] or [B][H/10][5].
+    const int* s8 = minimal == 8 ? samples_in : nullptr;
+    const int* s5 = minimal == 5 ? samples_in : nullptr;
+    if (minimal == 8)
+        hipLaunchKernelGGL(k_hypotheses, dim3((H + 63) / 64, B), dim3(64), 72 * 64 * sizeof(double), stream, w.kp, offsets,
+                           (prior && !samples_in) ? w.cdf : nullptr, s8, H, minimal, seed, prior ? w.pp : nullptr, pcl, w.tgt,
+                           P, prior_lambda, F_all, w.pscore, minimal == 8 ? samples_out : nullptr);
+    {
+        const int H5 = H / 10 > 0 ? H / 10 : 1;
+        constexpr int smem5 = 200 * 64 * sizeof(double);
+        bool cfg_failed = false;
+        FAR_ONCE_PER_DEVICE(cfg_failed = hipFuncSetAttribute((const void*)k_hypotheses5, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                             smem5) != hipSuccess);
+        if (cfg_failed) return false;
+        hipLaunchKernelGGL(k_hypotheses5, dim3((H5 + 63) / 64, B), dim3(64), smem5, stream, w.kp, offsets,
+                           (prior && !samples_in) ? w.cdf : nullptr, s5, H, minimal, seed, prior ? w.pp : nullptr, pcl, w.tgt,
+                           P, prior_lambda, F_all, w.pscore, minimal == 5 ? samples_out : nullptr);
+    }
+    hipLaunchKernelGGL(k_score, dim3((H + 63) / 64, B), dim3(256), 0, stream, w.kp, offsets, F_all, w.pscore, inl_th, H,
+                       count_all, score_all);
+    return true;
+}
+
 }  // namespace
 
 extern "C" {
@@ -786,45 +900,66 @@ int far_solver_f64(const float* kpts0, const float* kpts1, const int* offsets, i
     if (Mtot > 0 && (!kpts0 || !kpts1 || !mask_out)) return FAR_EINVAL;
     if (priorRT && (!pcl || P <= 0)) return FAR_EINVAL;
     SolverWs w = carve(ws, B, Mtot > 0 ? Mtot : 1, H, P > 0 ? P : 1);
-    const bool prior = priorRT != nullptr;
-    if (prior)
-        hipLaunchKernelGGL(k_prior_setup, dim3(B), dim3(128), 0, stream, priorRT, B, w.pp, pcl, P, w.tgt);
-    if (Mtot > 0 && Mmax > 0) {
-        hipLaunchKernelGGL(k_prepare, dim3((Mmax + 255) / 256, B), dim3(256), 0, stream, kpts0, kpts1, offsets, K0, K1,
-                           prior ? w.pp : nullptr, w.kn, w.kp, w.wq);
-        if (prior && !samples_in) hipLaunchKernelGGL(k_cdf, dim3(B), dim3(256), 0, stream, w.wq, offsets, w.cdf);
-    }
-    double* F_all = F_all_out ? F_all_out : w.F_all;
-    int* count_all = count_all_out ? count_all_out : w.count_all;
-    double* score_all = score_all_out ? score_all_out : w.score_all;
-    // hypotheses: the normalized 8-point for pairs with >= 8 correspondences (minimal = 8), the five-point solver for pairs
-    // with 5..7 -- and for every pair when minimal = 5.  Explicit samples (tests) follow the mode: [B][H][8] or [B][H/10][5].
-    const int* s8 = minimal == 8 ? samples_in : nullptr;
-    const int* s5 = minimal == 5 ? samples_in : nullptr;
-    if (minimal == 8)
-        hipLaunchKernelGGL(k_hypotheses, dim3((H + 63) / 64, B), dim3(64), 72 * 64 * sizeof(double), stream, w.kp, offsets,
-                           (prior && !samples_in) ? w.cdf : nullptr, s8, H, minimal, seed, prior ? w.pp : nullptr, pcl, w.tgt,
-                           P, prior_lambda, F_all, w.pscore, minimal == 8 ? samples_out : nullptr);
-    {
-        const int H5 = H / 10 > 0 ? H / 10 : 1;
-        constexpr int smem5 = 200 * 64 * sizeof(double);
-        bool cfg_failed = false;
-        FAR_ONCE_PER_DEVICE(cfg_failed = hipFuncSetAttribute((const void*)k_hypotheses5, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                             smem5) != hipSuccess);
-        if (cfg_failed) return far_check_launch();
-        hipLaunchKernelGGL(k_hypotheses5, dim3((H5 + 63) / 64, B), dim3(64), smem5, stream, w.kp, offsets,
-                           (prior && !samples_in) ? w.cdf : nullptr, s5, H, minimal, seed, prior ? w.pp : nullptr, pcl, w.tgt,
-                           P, prior_lambda, F_all, w.pscore, minimal == 5 ? samples_out : nullptr);
-    }
-    hipLaunchKernelGGL(k_score, dim3((H + 63) / 64, B), dim3(256), 0, stream, w.kp, offsets, F_all, w.pscore, inl_th, H,
-                       count_all, score_all);
+    double* F_all = nullptr;
+    double* score_all = nullptr;
+    if (!solver_stages_1to3(kpts0, kpts1, offsets, B, Mtot, Mmax, K0, K1, inl_th, priorRT, pcl, P, prior_lambda, H, minimal, seed,
+                            samples_in, F_all_out, count_all_out, score_all_out, samples_out, w, stream, F_all, score_all))
+        return far_check_launch();
     hipLaunchKernelGGL(k_select, dim3(B), dim3(256), 0, stream, w.kp, offsets, F_all, score_all, inl_th, H, many_thr,
-                       minimal, best_out, E_out, mask_out, w.n_inl, n_tight_out, n_ultra_out, w.status_sel, w.good);
+                       minimal, best_out, E_out, mask_out, w.n_inl, n_tight_out, n_ultra_out, w.status_sel, w.good, 0);
     const int nsplit = Mmax > 0 ? (Mmax + 255) / 256 : 1;
     hipLaunchKernelGGL(k_recover_bits, dim3(nsplit, B), dim3(256), 0, stream, w.kn, offsets, E_out, w.status_sel, 1e9,
                        (const uint8_t*)mask_out, w.bits, w.good, w.rt);
     hipLaunchKernelGGL(k_recover_final, dim3(B), dim3(256), 0, stream, offsets, w.status_sel, (const int*)w.good, (const double*)w.rt,
                        mask_out, (const uint8_t*)w.bits, R_out, t_out, n_cheir_out, num_after_out, status_out);
+    return far_check_launch();
+}
+
+// RANSAC.forward (third_party/prior_ransac/ransac.py:340-442) on its own: stages 1-4 of far_solver_f64 WITHOUT recoverPose, for
+// correspondences that are already in the coordinates the caller wants the model in (the reference passes K-normalised points,
+// metrics.py:124-127): K0 = K1 = identity inside.  Arguments as far_solver_f64; outputs: E_out [B][9] (zeros when no model scored
+// above the minimal sample size, as best_model_total stays zeros(3, 3), :354), mask_out [Mtot] with bit 0 = inlier at inl_th,
+// bit 1 = at inl_th / 10, bit 2 = at inl_th / 100 (:284-287), the three counts, best_out [B] (-1: none).
+int far_ransac_f64(const float* kp1, const float* kp2, const int* offsets, int B, int Mtot, int Mmax, const double* inl_th,
+                   const float* priorRT, const float* pcl, int P, double prior_lambda, int H, int minimal, uint32_t seed,
+                   const int* samples_in, double* E_out, uint8_t* mask_out, int* n_inl_out, int* n_tight_out, int* n_ultra_out,
+                   int* best_out, void* ws, hipStream_t stream) {
+    far_clear_errors();
+    if (B <= 0) return FAR_OK;
+    if (!offsets || !inl_th || !E_out || !n_inl_out || !n_tight_out || !n_ultra_out || !best_out || !ws || H <= 0 || Mtot < 0 ||
+        (minimal != 8 && minimal != 5) || (minimal == 5 && H < 10) || (Mtot > 0 && (!kp1 || !kp2 || !mask_out)) ||
+        (priorRT && (!pcl || P <= 0)))
+        return FAR_EINVAL;
+    SolverWs w = carve(ws, B, Mtot > 0 ? Mtot : 1, H, P > 0 ? P : 1);
+    // identity intrinsics for k_prepare: [B][9] packed into the workspace's R | t scratch (21 doubles per pair, unused without recoverPose)
+    double* Kid = w.rt;
+    hipLaunchKernelGGL(k_identity9, dim3((B + 63) / 64), dim3(64), 0, stream, Kid, B);
+    double* F_all = nullptr;
+    double* score_all = nullptr;
+    if (!solver_stages_1to3(kp1, kp2, offsets, B, Mtot, Mmax, Kid, Kid, inl_th, priorRT, pcl, P, prior_lambda, H, minimal, seed,
+                            samples_in, nullptr, nullptr, nullptr, nullptr, w, stream, F_all, score_all))
+        return far_check_launch();
+    hipLaunchKernelGGL(k_select, dim3(B), dim3(256), 0, stream, w.kp, offsets, F_all, score_all, inl_th, H, 1, minimal, best_out, E_out,
+                       mask_out, n_inl_out, n_tight_out, n_ultra_out, w.status_sel, w.good, 1);
+    return far_check_launch();
+}
+
+// run_8point(points1, points2, weights) (cv_geometry.py:772-833): B problems x N >= 8 correspondences, float64 in and out.
+// p1, p2 [B][N][2]; w [B][N] or NULL (ones); F_out [B][9] = normalize_transformation(T2^T F_rank2 T1).
+int far_eightpoint_f64(const double* p1, const double* p2, const double* w, int B, int N, double* F_out, hipStream_t stream) {
+    far_clear_errors();
+    if (B <= 0) return FAR_OK;
+    if (!p1 || !p2 || !F_out || N < 8) return FAR_EINVAL;
+    hipLaunchKernelGGL(k_eightpoint, dim3((B + 63) / 64), dim3(64), 72 * 64 * sizeof(double), stream, p1, p2, w, B, N, F_out);
+    return far_check_launch();
+}
+
+// decompose_essential_matrix(E) (essential.py:99-139): n matrices [n][9] -> R1, R2 [n][9], t [n][3], float64.
+int far_decompose_essential_f64(const double* E, long n, double* R1_out, double* R2_out, double* t_out, hipStream_t stream) {
+    far_clear_errors();
+    if (n <= 0) return FAR_OK;
+    if (!E || !R1_out || !R2_out || !t_out) return FAR_EINVAL;
+    hipLaunchKernelGGL(k_decompose, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, stream, E, n, R1_out, R2_out, t_out);
     return far_check_launch();
 }
 

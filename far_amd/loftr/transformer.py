@@ -285,24 +285,57 @@ def positional_table(h=60, w=80):
     return torch.stack([p3 * p3, p4 * p4, p3 * p4, p3, p4, torch.ones_like(p3)], dim=1).contiguous()
 
 
+def positional_table_vit(h=24, w=24, intrinsics=None):
+    """(h*w, 6) fp32 table [p3^2, p4^2, p3 p4, p3, p4, 1] of the 8-Point-ViT's CrossAttention
+    (interiornetStreetlearn_8ptVit/src/modules/vision_transformer.py:90-158): cell (j, k) -- row j, column k -- sits at index
+    n = k*w + j there (:150-151; mp3d's table uses j*w + k), and the intrinsics (fx, fy, cx, cy) on the feature grid are an
+    argument instead of constants; None = the plain linspace coordinates (:109-110).  h == w as in the reference (24 x 24)."""
+    if h != w:
+        raise ValueError('the reference indexes this table with k*w + j, which covers the grid only when h == w (24 x 24)')
+    ys = torch.linspace(-1, 1, steps=h)
+    xs = torch.linspace(-1, 1, steps=w)
+    if intrinsics is None:
+        p3 = ys.repeat(w)                                          # :109  p3[n] = ys[n % h]
+        p4 = xs.repeat_interleave(h)                               # :110  p4[n] = xs[n // h]
+    else:
+        fx, fy, cx, cy = (torch.tensor(float(v), dtype=torch.float32) for v in intrinsics)
+        hpix, wpix = cy * 2, cx * 2
+        K = torch.zeros(3, 3)
+        K[0, 0] = (fx / wpix) * 2
+        K[1, 1] = (fy / hpix) * 2
+        K[0, 2] = (cx / wpix) * 2 - 1
+        K[1, 2] = (cy / hpix) * 2 - 1
+        K[2, 2] = 1
+        Kinv = torch.inverse(K)
+        gx, gy = torch.meshgrid(xs, ys, indexing='ij')            # n = k*w + j  ->  (xs[k], ys[j])
+        pts = torch.stack([gx.reshape(-1), gy.reshape(-1), torch.ones(h * w)], 0)
+        wv = Kinv @ pts
+        p4 = wv[0] / wv[2]
+        p3 = wv[1] / wv[2]
+    return torch.stack([p3 * p3, p4 * p4, p3 * p4, p3, p4, torch.ones_like(p3)], dim=1).contiguous()
+
+
 class CrossAttention(nn.Module):
     hip_training = True          # training on the GPU runs K2's forward + backward kernels; False: vendor ops + autograd
     exact_f32 = False            # inference: K2 on the exact-f32 MFMA kernels (no operand range limit; LoFTR sets it after an
                                  # activation-range overflow of the split-fp16 variant, model.py:_widen_activation_range)
 
-    def __init__(self, dim, num_heads=8, qkv_bias=False, attn_drop=0., proj_drop=0.):
+    def __init__(self, dim, num_heads=8, qkv_bias=False, attn_drop=0., proj_drop=0., pos=None):
+        """pos: the (N, 6) positional table appended to v (default: mp3d's 60 x 80 table with its hard-coded intrinsics,
+        transformer.py:194-196; the 8-Point-ViT form -- dim 192, 3 heads, N = 576 -- passes positional_table_vit(24, 24, intrinsics))."""
         super().__init__()
         self.num_heads = num_heads
         self.scale = (dim // num_heads) ** -0.5
         self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
         self.proj_fundamental = nn.Linear(dim + 6 * num_heads, dim)
-        self.register_buffer('pos6', positional_table(), persistent=False)
+        self.register_buffer('pos6', positional_table() if pos is None else pos.detach().float().contiguous(), persistent=False)
 
     def forward(self, x1, x2, intrinsics=None, loftr_preds=None, inv_loftr_preds=None):
         B, N, C = x1.shape
         h, d = self.num_heads, C // self.num_heads
         if self.pos6.shape[0] != N:
-            raise ValueError(f'the head is tied to a 60x80 coarse grid (N=4800), got N={N} (transformer.py:194)')
+            raise ValueError(f'the positional table of this CrossAttention has {self.pos6.shape[0]} rows (mp3d: the 60x80 coarse grid, '
+                             f'transformer.py:194), got N={N} tokens')
         if ag.needs_grad(x1, x2, self.qkv.weight) or not x1.is_cuda:
             # (2, B, N, 3, h, d) -> (3, 2, B, h, N, d): one packed copy feeds both directions
             qkv = self.qkv(torch.stack([x1, x2], 0)).reshape(2, B, N, 3, h, d).permute(3, 0, 1, 4, 2, 5).contiguous()
@@ -362,10 +395,10 @@ def _init_vit(m):
 
 class CrossBlock(nn.Module):
     def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, drop=0., attn_drop=0., drop_path=0.,
-                 act_layer=nn.GELU, norm_layer=nn.LayerNorm, use_pos_embedding=False, distilled=False):
+                 act_layer=nn.GELU, norm_layer=nn.LayerNorm, use_pos_embedding=False, distilled=False, pos=None):
         super().__init__()
         self.norm1 = norm_layer(dim)
-        self.cross_attn = CrossAttention(dim, num_heads=num_heads, qkv_bias=qkv_bias)
+        self.cross_attn = CrossAttention(dim, num_heads=num_heads, qkv_bias=qkv_bias, pos=pos)
         self.norm2 = norm_layer(dim)
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer)
         self.h, self.w = 60, 80

@@ -21,6 +21,12 @@ def world():
     return 0, 1
 
 
+def _group_up():
+    """A process group exists (also one of world size 1: its collectives still run through the backend -- bench.py
+    --dist-at-world-1 executes RCCL that way on a one-GPU box)."""
+    return dist.is_available() and dist.is_initialized()
+
+
 def shard_indices(n_pairs, rank=None, world_size=None):
     """Indices of the pairs this rank processes: rank::world (every pair exactly once, sizes differ by <= 1)."""
     r, w = world()
@@ -32,7 +38,7 @@ def shard_indices(n_pairs, rank=None, world_size=None):
 def max_over_ranks(seconds, device='cpu'):
     """bench.py's timing rule: the slowest rank defines the step time."""
     _, w = world()
-    if w == 1:
+    if not _group_up():
         return float(seconds)
     t = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -90,7 +96,7 @@ def launch_ranks(n_ranks, script_argv, port=None, env=None):
 def gather_floats(value, device='cpu'):
     """Every rank's scalar as a python list on every rank (per-rank step times of bench.py)."""
     _, w = world()
-    if w == 1:
+    if not _group_up():
         return [float(value)]
     t = torch.zeros(w, dtype=torch.float64, device=device)
     t[dist.get_rank()] = float(value)

@@ -32,6 +32,9 @@ typedef struct ihipStream_t* far_stream_t; /* == hipStream_t */
  * far_wino_* / far_conv3x3_wino_f32 entry points, 16 tuning keys; 4: far_upsample2x_bwd_f32, far_fine_scatter_det_f32, far_bn_train_*, far_adamw_*; 5: far_linear_kv_f16s, far_linear_q_apply_f16s,
  * far_linear_gather_f16s, far_linear_attention_apply_f32, far_prior_from_pose_f32).  far_amd/_lib.py refuses a library whose version differs. */
 int far_abi_version(void);
+/* Id of the sources the library was built from: sha256/16 over far_amd/csrc/* and the compiler flags (far_amd/build.py
+ * source_id()).  far_amd/_lib.py refuses a library whose id differs from the sources it sits next to. */
+const char* far_build_id(void);
 /* hipError_t of the most recent failed launch on the calling thread (0 = none): detail behind a -5 return. */
 int far_last_hip_error(void);
 /* Tuning knobs for A/B experiments; they change speed only, never results.  key 0 = bit mask of kernels using
@@ -632,6 +635,25 @@ int far_solver_f64(const float* kpts0, const float* kpts1, const int* offsets, i
                    int* num_after_out, int* n_tight_out, int* n_ultra_out, int* n_cheir_out, int* best_out,
                    double* F_all_out, int* count_all_out, double* score_all_out, int* samples_out,
                    void* ws, far_stream_t stream);
+
+/* The function-level API of the solver (host side: far_amd/ransac.py).
+ *
+ * far_ransac_f64 = RANSAC(...).forward(kp1, kp2) (third_party/prior_ransac/ransac.py:340-442): stages 1-4 of far_solver_f64
+ *   (bias weights, hypotheses, verification, selection) WITHOUT recoverPose, on correspondences already in the coordinates the
+ *   model is wanted in (the reference passes K-normalised points, metrics.py:124-127).  Arguments as far_solver_f64.
+ *   E_out [B][9] (zeros when no model scored above the minimal sample size: best_model_total stays zeros(3, 3), :354);
+ *   mask_out [Mtot]: bit 0 = inlier at inl_th, bit 1 = at inl_th / 10, bit 2 = at inl_th / 100 (:284-287);
+ *   n_inl_out / n_tight_out / n_ultra_out / best_out [B] int32 (best = -1: none).  ws: far_solver_workspace_bytes(B, Mtot, H, P).
+ * far_eightpoint_f64 = run_8point(points1, points2, weights) (cv_geometry.py:772-833): B problems of N >= 8 correspondences,
+ *   p1, p2 [B][N][2], w [B][N] or NULL (ones), F_out [B][9] = normalize_transformation(T2^T F_rank2 T1); float64.
+ * far_decompose_essential_f64 = decompose_essential_matrix(E) (essential.py:99-139): E [n][9] -> R1, R2 [n][9], t [n][3]
+ *   (sign convention of DESIGN.md "K4": the set {R1, R2} x {t, -t} equals the reference's). */
+int far_ransac_f64(const float* kp1, const float* kp2, const int* offsets, int B, int Mtot, int Mmax, const double* inl_th,
+                   const float* priorRT, const float* pcl, int P, double prior_lambda, int H, int minimal, uint32_t seed,
+                   const int* samples_in, double* E_out, uint8_t* mask_out, int* n_inl_out, int* n_tight_out, int* n_ultra_out,
+                   int* best_out, void* ws, far_stream_t stream);
+int far_eightpoint_f64(const double* p1, const double* p2, const double* w, int B, int N, double* F_out, far_stream_t stream);
+int far_decompose_essential_f64(const double* E, long n, double* R1_out, double* R2_out, double* t_out, far_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * K12  correlation-volume warp of the Map-free 6DReg aggregator

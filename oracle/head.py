@@ -49,6 +49,41 @@ def positional_encodings(h=60, w=80, dtype=np.float32):
     return pos.astype(dtype)
 
 
+def positional_encodings_vit(h=24, w=24, intrinsics=None, dtype=np.float32):
+    """interiornetStreetlearn_8ptVit/src/modules/vision_transformer.py:90-158 for one sample; returns (h*w, 6).
+
+    Without intrinsics p3 = ys.repeat(w), p4 = xs.repeat_interleave(h) (:109-110); with intrinsics (fx, fy, cx, cy) the cell loop
+    of :146-151 writes index k*w + j (NOT j*w + k as mp3d's table) with Kinv @ [xs[k], ys[j], 1] in fp32."""
+    import torch
+    f32 = np.float32
+    ys = torch.linspace(-1, 1, steps=h).numpy()
+    xs = torch.linspace(-1, 1, steps=w).numpy()
+    p3 = np.tile(ys, w).astype(f32)
+    p4 = np.repeat(xs, h).astype(f32)
+    if intrinsics is not None:
+        fx, fy, cx, cy = (f32(v) for v in intrinsics)
+        hpix, wpix = cy * f32(2), cx * f32(2)
+        K = np.zeros((3, 3), f32)
+        K[0, 0] = (fx / wpix) * f32(2)
+        K[1, 1] = (fy / hpix) * f32(2)
+        K[0, 2] = (cx / wpix) * f32(2) - f32(1)
+        K[1, 2] = (cy / hpix) * f32(2) - f32(1)
+        K[2, 2] = 1
+        Kinv = torch.inverse(torch.from_numpy(K)).numpy()
+        for j in range(h):
+            for k in range(w):
+                vec = Kinv @ np.array([xs[k], ys[j], 1], f32)
+                p3[k * w + j] = vec[1] / vec[2]
+                p4[k * w + j] = vec[0] / vec[2]
+    pos = np.ones((h * w, 6), f32)
+    pos[:, 0] = p3 * p3
+    pos[:, 1] = p4 * p4
+    pos[:, 2] = p3 * p4
+    pos[:, 3] = p3
+    pos[:, 4] = p4
+    return pos.astype(dtype)
+
+
 def bilinear_attention(q, k, vt, scale, dtype=np.float32):
     """transformer.py:275-292 for one direction.  q, k: (..., N, D); vt: (..., N, DV) -> (..., DV, DV).
 

@@ -204,9 +204,10 @@ def preprocess_helper(cfg, loftr_rt, num_corr, num_before, tight, ultra):
     return preds[None].astype(np.float32), inv[None].astype(np.float32)
 
 
-def cross_attention(w, x1, x2, pos, num_heads=4):
-    """transformer.py:266-303 for B = 1.  x (1,N,C) -> (fundamental_2, fundamental_1), each (1,70,256)."""
-    p = 'loftr_regress.emm.cross_attn.'
+def cross_attention(w, x1, x2, pos, num_heads=4, prefix='loftr_regress.emm.cross_attn.'):
+    """transformer.py:266-303 for B = 1.  x (1,N,C) -> (fundamental_2, fundamental_1), each (1,70,256).
+    The 8-Point-ViT's CrossAttention (vision_transformer.py:160-208) is the same arithmetic at C = 192, 3 heads, N = 576."""
+    p = prefix
     B, N, C = x1.shape
     d = C // num_heads
 

@@ -82,3 +82,48 @@ def test_ddp_built_with_device_ids_still_hands_the_results_back():
         np.testing.assert_allclose(losses[0], losses[1], rtol=1e-6)
     finally:
         dist.destroy_process_group()
+
+
+def _run_rccl_world1(extra, launcher):
+    """One rank that still joins an RCCL process group (`--dist-at-world-1 --backend nccl`): the child is started before this
+    process touches the GPU state it needs (a subprocess, never an exec)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    args = [os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--backend', 'nccl', '--dist-at-world-1', '--steps', '1', '--warmup', '1',
+            '--no-cpu-baseline', '--no-other-workloads', '--no-other-modes'] + extra
+    if launcher:
+        from far_amd import parallel
+        cmd = parallel.launch_command(1, args)
+    else:
+        cmd = [sys.executable] + args
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(1800)
+def test_rccl_comes_up_at_world_size_1_eval_step():
+    """init_process_group('nccl', device_id=cuda:0) under torch.distributed.run --nproc-per-node 1: RCCL initialises, the fence's
+    barrier and the max-over-ranks / per-rank-gather all-reduces run on device tensors through it (mp3d_loftr/train.py:337-359
+    is the deployment this stands in for; no 8-GPU node is available to the tests)."""
+    res = _run_rccl_world1(['--pairs', '2', '--hyp', '256'], launcher=True)
+    assert res['process_group'] == {'backend': 'nccl', 'world_size': 1}
+    assert res['n_gpus'] == 1 and len(res['per_rank_ms_per_step']) == 1 and res['value'] > 0
+    assert res['config']['solver_success_frac'] > 0.5
+
+
+@pytest.mark.timeout(1800)
+def test_rccl_world_size_1_training_step_under_ddp_and_syncbn():
+    """The training workload over RCCL at world size 1: SyncBatchNorm conversion (left to torch by far_amd.ops.bn_act_train's
+    predicate), DistributedDataParallel's bucketed all-reduce of the 204 MB of gradients (to itself), the stand-alone all-reduce
+    and the no_sync() leg of the `exchange` block."""
+    res = _run_rccl_world1(['--workload', 'c3', '--pairs', '1', '--hyp', '256'], launcher=False)
+    pg = res['process_group']
+    assert pg['backend'] == 'nccl' and pg['world_size'] == 1 and pg['sync_batchnorm'] is True
+    assert res['config']['parallelism'].startswith('ddp1') and 'RCCL' in res['config']['parallelism']
+    ex = res['exchange']
+    assert ex['backend'] == 'nccl' and ex['ranks'] == 1 and ex['bytes'] > 200e6 and ex['standalone_ms'] >= 0
+    assert all(v == v and abs(v) < 1e4 for v in res['config']['losses'].values())

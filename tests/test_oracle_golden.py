@@ -659,3 +659,31 @@ def test_g16_eval_metrics_match_reference():
     assert list(pr.keys()) == g['prec_keys'].tolist()
     np.testing.assert_allclose(list(pr.values()), g['prec_vals'], rtol=1e-12)
     np.testing.assert_allclose(list(om.epidist_prec(m['epi_errs'], [1e-4, 5e-4, 1e-3]).values()), g['prec_vals'], rtol=1e-12)
+
+
+# ------------------------------------------------------------------------------------------------ G19
+def test_g19_vit_shape_cross_attention_oracle():
+    """The 8-Point-ViT shape of K2 (N = 576, 3 heads x 64, positional index k*w + j: SURVEY.md section 2.5) -- golden produced by
+    the reference's own vision_transformer.CrossBlock (tools/make_golden_vit.py): the oracle's positional tables bit for bit, its
+    CrossAttention within fp32 round-off, and the product's table builder (host code, no GPU needed)."""
+    import torch
+    from far_amd.loftr.transformer import CrossBlock, positional_table_vit
+    from oracle import head as oh
+    from oracle import model as om
+    from tests.util import VIT_INTRINSICS, vit_seeded_fill
+    g = load('g19_vit_crossblock')
+    assert tuple(np.round(g['intrinsics'], 4)) == tuple(np.round(np.float32(VIT_INTRINSICS), 4))
+    for intr, key in ((VIT_INTRINSICS, 'pos_intr'), (None, 'pos_none')):
+        np.testing.assert_array_equal(oh.positional_encodings_vit(24, 24, intr), g[key])
+        np.testing.assert_array_equal(positional_table_vit(24, 24, intr).numpy(), g[key])
+    assert not np.array_equal(g['pos_intr'][:, 3].reshape(24, 24), g['pos_intr'][:, 3].reshape(24, 24).T)      # k*w + j is not j*w + k
+    blk = CrossBlock(192, 3, qkv_bias=True, pos=positional_table_vit(24, 24, VIT_INTRINSICS)).eval()
+    x = vit_seeded_fill(blk, seed=19)
+    w = om.Weights({k: v.detach() for k, v in blk.state_dict().items()})
+    ln = lambda a: torch.nn.functional.layer_norm(a, (192,), blk.norm1.weight, blk.norm1.bias, blk.norm1.eps).detach().numpy()
+    fa, fb = om.cross_attention(w, ln(x[0:1]), ln(x[1:2]), g['pos_intr'], num_heads=3, prefix='cross_attn.')
+    sc = np.abs(g['xattn_a']).max()
+    assert np.abs(fa - g['xattn_a']).max() < 2e-5 * sc and np.abs(fb - g['xattn_b']).max() < 2e-5 * sc
+    with pytest.raises(Exception, match='no CPU fallback'):    # the product module has no CPU inference path: loud, not a fallback
+        with torch.no_grad():
+            blk(x)

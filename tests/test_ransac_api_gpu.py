@@ -1,0 +1,220 @@
+"""The function-level solver API (far_amd/ransac.py: RANSAC.forward, run_8point, decompose_essential_matrix -- the names of
+mp3d_loftr/third_party/prior_ransac/{ransac,cv_geometry,essential}.py) through the C ABI, against the goldens produced by the
+reference's own functions (G5: run_8point / decompose_essential_matrix on committed samples; G12: RANSAC.forward's whole loop)
+and against oracle/solver.py."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+cu = lambda a, dt=None: torch.from_numpy(np.ascontiguousarray(a)).cuda() if dt is None else torch.from_numpy(np.ascontiguousarray(a)).to(dt).cuda()
+
+
+def _g5_norm():
+    from oracle import solver as osv
+    g = np.load(os.path.join(GOLD, 'g5_solver.npz'))
+    kn0, kn1 = osv.normalize_keypoints(g['kpts0'], g['kpts1'], g['K'], g['K'])
+    return g, kn0.astype(np.float32), kn1.astype(np.float32)
+
+
+def test_run_8point_matches_the_reference_and_the_oracle():
+    """run_8point(points1 (B, 8, 2), points2, weights) on G5's committed samples: the oracle bit-for-bit-grade (float64 both,
+    1e-9), the float32 reference within its own round-off (bars of test_g5_eight_point_decomposition_and_scores)."""
+    from far_amd.ransac import run_8point
+    from oracle import solver as osv
+    g, kp1, kp2 = _g5_norm()
+    s = g['samples']
+    F = run_8point(cu(kp1[s]), cu(kp2[s]), torch.ones(len(s), 8, device='cuda'))
+    assert F.shape == (len(s), 3, 3) and F.dtype == torch.float32
+    F64 = run_8point(cu(kp1[s], torch.float64), cu(kp2[s], torch.float64)).cpu().numpy()
+    Fo = osv.run_8point(kp1[s].astype(np.float64), kp2[s].astype(np.float64))
+    np.testing.assert_allclose(F64, Fo, rtol=1e-7, atol=1e-9)
+    rel = np.abs(F64 - g['F']).reshape(len(F64), -1).max(1) / np.abs(g['F']).reshape(len(F64), -1).max(1)
+    assert np.median(rel) < 2e-3 and (rel < 5e-2).mean() > 0.9, (np.median(rel), (rel < 5e-2).mean())
+    np.testing.assert_allclose(F.cpu().numpy(), F64, rtol=2e-6, atol=1e-6)
+
+
+def test_run_8point_more_than_eight_weighted_points():
+    """N = 40 correspondences with weights: X^T diag(w) X (cv_geometry.py:814-817) against a float64 numpy restatement of the same
+    lines; zero weights switch outliers off (the fit equals the fit on the kept subset)."""
+    from far_amd.ransac import run_8point
+    g, kp1, kp2 = _g5_norm()
+    rs = np.random.RandomState(3)
+    idx = np.stack([rs.choice(len(kp1), 40, replace=False) for _ in range(7)])
+    w = rs.uniform(0.2, 1.0, idx.shape)
+    w[:, 30:] = 0.0
+    a, b = kp1[idx].astype(np.float64), kp2[idx].astype(np.float64)
+    F = run_8point(cu(a), cu(b), cu(w)).cpu().numpy()
+
+    def ref(p1, p2, ww):                                        # cv_geometry.py:713-750, :772-833 in numpy float64
+        def norm(p):
+            m = p.mean(0)
+            sc = np.sqrt(2.0) / (np.linalg.norm(p - m, axis=1).mean() + 1e-8)
+            T = np.array([[sc, 0, -sc * m[0]], [0, sc, -sc * m[1]], [0, 0, 1]])
+            return p * sc + T[:2, 2], T
+        n1, T1 = norm(p1)
+        n2, T2 = norm(p2)
+        X = np.stack([n2[:, 0] * n1[:, 0], n2[:, 0] * n1[:, 1], n2[:, 0], n2[:, 1] * n1[:, 0], n2[:, 1] * n1[:, 1], n2[:, 1],
+                      n1[:, 0], n1[:, 1], np.ones(len(n1))], 1)
+        _, V = np.linalg.eigh(X.T @ np.diag(ww) @ X)
+        Fm = V[:, 0].reshape(3, 3)
+        U, S, Vt = np.linalg.svd(Fm)
+        Fe = T2.T @ (U @ np.diag([S[0], S[1], 0]) @ Vt) @ T1
+        return Fe / (Fe[2, 2] + 1e-8) if abs(Fe[2, 2]) > 1e-8 else Fe
+    for i in range(len(idx)):
+        # the eigenvector's sign is free: normalize_transformation (F / F[2, 2]) removes it
+        np.testing.assert_allclose(F[i], ref(a[i], b[i], w[i]), rtol=1e-6, atol=1e-8)
+    # NB the Hartley normalisation uses ALL N points, weighted or not (as the reference's does): only the system is weighted
+    with pytest.raises(AssertionError):
+        run_8point(cu(a[:, :7]), cu(b[:, :7]))
+    with pytest.raises(AssertionError):
+        run_8point(cu(a), cu(b[:, :39]))
+    with pytest.raises(AssertionError):
+        run_8point(cu(a), cu(b), cu(w[:, :10]))
+
+
+def test_decompose_essential_matrix_matches_the_reference():
+    """decompose_essential_matrix on G5's matrices: {R1, R2} as a set and t up to sign equal the reference's (LAPACK's sign
+    freedom, bars of test_g5_eight_point_decomposition_and_scores); proper rotations; shapes (*, 3, 3) -> (*, 3, 1)."""
+    from far_amd.ransac import decompose_essential_matrix
+    g, _, _ = _g5_norm()
+    E = cu(g['F'].astype(np.float64))
+    R1, R2, T = decompose_essential_matrix(E)
+    assert R1.shape == E.shape and R2.shape == E.shape and T.shape == E.shape[:-2] + (3, 1)
+    R1, R2, t = R1.cpu().numpy(), R2.cpu().numpy(), T.cpu().numpy()[..., 0]
+    n = len(R1)
+    a = np.minimum(np.abs(R1 - g['R1']).reshape(n, -1).max(1) + np.abs(R2 - g['R2']).reshape(n, -1).max(1),
+                   np.abs(R1 - g['R2']).reshape(n, -1).max(1) + np.abs(R2 - g['R1']).reshape(n, -1).max(1))
+    tt = g['T'][..., 0]
+    dt = np.minimum(np.abs(t - tt).max(1), np.abs(t + tt).max(1))
+    assert np.median(a) < 1e-4 and (a < 1e-2).mean() > 0.95, (np.median(a), (a < 1e-2).mean())
+    assert np.median(dt) < 1e-4 and (dt < 1e-2).mean() > 0.95
+    np.testing.assert_allclose(np.linalg.det(R1), 1.0, atol=1e-9)
+    np.testing.assert_allclose(np.linalg.det(R2), 1.0, atol=1e-9)
+    # leading batch dimensions and the input dtype are kept
+    R1b, R2b, Tb = decompose_essential_matrix(E[:12].float().reshape(3, 4, 3, 3))
+    assert R1b.shape == (3, 4, 3, 3) and Tb.shape == (3, 4, 3, 1) and R1b.dtype == torch.float32
+    np.testing.assert_allclose(R1b.reshape(12, 3, 3).cpu().numpy(), R1[:12], atol=5e-5)   # (float32 copies of E in)
+    with pytest.raises(AssertionError):
+        decompose_essential_matrix(E[:, :2])
+
+
+@pytest.mark.parametrize('tag', ['p', 'n'])
+def test_ransac_forward_matches_the_reference_loop(tag):
+    """RANSAC(...).forward(kp1, kp2) -- constructed as estimate_pose constructs it (metrics.py:100-153) -- on G12's committed
+    sample indices: the reference's selected model (up to its float32 round-off and scale), the three inlier masks exactly off
+    the decision margin, and the same result as the full solver (far_solver_f64) before cheirality."""
+    from far_amd.ransac import RANSAC
+    from oracle import solver as osv
+    g = np.load(os.path.join(GOLD, 'g12_ransac_loop.npz'))
+    K = g[f'{tag}_K']
+    kn0, kn1 = osv.normalize_keypoints(g[f'{tag}_kpts0'], g[f'{tag}_kpts1'], K, K)
+    kp1, kp2 = cu(kn0.astype(np.float32)), cu(kn1.astype(np.float32))
+    prior_params = {}
+    if tag == 'p':
+        prior_params = {'rotation_pcl_error': True, 'rotation_error': False, 'K1': cu(K, torch.float32), 'K2': cu(K, torch.float32),
+                        'RT': cu(g['p_prior'], torch.float32), 'pcl': cu(g['p_pcl'], torch.float32), 'lambda': 0.3,
+                        'biased_sampling': 'biased'}
+    smp = g[f'{tag}_samples'].astype(np.int32)
+    m = RANSAC(model_type='essential_cv2', max_iter=1, inl_th=3e-7, prior_params=prior_params, max_lo_iters=0, batch_size=len(smp),
+               use_noexp_prior_scoring=True, use_linear_bias_sampling=True, bias_sigma_sq=0.1)
+    E, inl, tight, ultra = m.forward(kp1=kp1, kp2=kp2, samples=smp)
+    assert E.shape == (3, 3) and inl.shape == (len(kn0),) and inl.dtype == torch.bool
+    assert int(m.last_best) == int(g[f'{tag}_best'])
+    if tag == 'p':                                             # setup_prior normalised the prior translation in place (ransac.py:183)
+        assert abs(float(torch.linalg.norm(prior_params['RT'][:, 3])) - 1.0) < 1e-6
+    Eg = g[f'{tag}_E'].astype(np.float64)
+    En = E.double().cpu().numpy()
+    cos = abs((En * Eg).sum()) / (np.linalg.norm(En) * np.linalg.norm(Eg))
+    assert cos > 1 - 2e-4, cos                                  # (the float32 reference's winning E is 0.9 % off its float64 value)
+    eb = g[f'{tag}_err_best']
+    for mine, ref, thr in ((inl, g[f'{tag}_inliers'], 3e-7), (tight, g[f'{tag}_tight'], 3e-8), (ultra, g[f'{tag}_ultra'], 3e-9)):
+        safe = (eb < thr / 3) | (eb > 3 * thr)
+        np.testing.assert_array_equal(mine.cpu().numpy()[safe], ref[safe])
+        assert int((mine.cpu().numpy() ^ ref).sum()) <= 0.02 * ref.size
+    # the same stages inside the full solver
+    from far_amd import ops
+    offs = np.array([0, len(kn0)], np.int32)
+    full = ops.solve_pose_batch(cu(g[f'{tag}_kpts0'].astype(np.float32)), cu(g[f'{tag}_kpts1'].astype(np.float32)), offs, cu(K[None]), cu(K[None]),
+                                cu(np.array([3e-7])), True, priorRT=cu(g['p_prior'][None].astype(np.float32)) if tag == 'p' else None,
+                                pcl=cu(g['p_pcl'].astype(np.float32)) if tag == 'p' else None, H=len(smp), samples=cu(smp[None]), debug=True)
+    assert int(full['best'][0]) == int(m.last_best)
+    np.testing.assert_allclose(full['E'][0].cpu().numpy(), En, rtol=1e-5, atol=1e-7)
+    assert int(full['tight'][0]) == int(tight.sum()) and int(full['ultra'][0]) == int(ultra.sum())
+
+
+def test_ransac_own_sampling_and_error_behaviour():
+    """Without explicit samples the hash sampler runs: a two-view scene with 30 % outliers is solved ('fundamental' = 8-point,
+    'essential' = five-point), too few points raise ValueError as the reference's validate_inputs, unknown model types
+    NotImplementedError, options K4 does not implement NotImplementedError (never a silently different computation), CPU tensors
+    FarHipError."""
+    from far_amd import _lib
+    from far_amd.ransac import RANSAC
+    from oracle import solver as osv
+    from tests.util import two_view_scene
+    k0, k1, K, R_gt, t_gt = two_view_scene(600, seed=5, outlier_frac=0.3)[:5]
+    kn0, kn1 = osv.normalize_keypoints(k0, k1, K, K)
+    a, b = cu(kn0.astype(np.float32)), cu(kn1.astype(np.float32))
+    for mt in ('fundamental', 'essential'):
+        E, inl, tight, ultra = RANSAC(model_type=mt, inl_th=3e-7, batch_size=512, max_iter=1, max_lo_iters=0).forward(a, b)
+        assert 350 < int(inl.sum()) <= 600 and int(ultra.sum()) <= int(tight.sum()) <= int(inl.sum())
+        samp = osv.sampson_distance(kn0.astype(np.float32).astype(np.float64), kn1.astype(np.float32).astype(np.float64), E.double().cpu().numpy()[None])[0]
+        np.testing.assert_array_equal(inl.cpu().numpy(), samp <= 3e-7)
+    with pytest.raises(ValueError):
+        RANSAC(model_type='fundamental', inl_th=3e-7, batch_size=64, max_iter=1).forward(a[:7], b[:7])
+    with pytest.raises(NotImplementedError):
+        RANSAC(model_type='homography')
+    with pytest.raises(NotImplementedError):
+        RANSAC(model_type='essential', perform_early_stopping=True)
+    with pytest.raises(_lib.FarHipError):
+        RANSAC(model_type='fundamental', inl_th=3e-7, batch_size=64, max_iter=1).forward(a.cpu(), b.cpu())
+    # an unsolvable input: zeros(3, 3) and empty masks (ransac.py:354-355), no exception
+    z = torch.zeros(20, 2, device='cuda')
+    E, inl, _, _ = RANSAC(model_type='fundamental', inl_th=3e-7, batch_size=64, max_iter=1).forward(z, z)
+    assert float(E.abs().sum()) == 0.0 and int(inl.sum()) == 0
+
+
+def test_solver_cache_follows_replaced_and_rescaled_intrinsics():
+    """The data-dict solver cache (far_amd/solver.py) keys on the K0 / K1 tensor objects and their versions: a batch dict that is
+    reused with another K0 (the allocator hands back the same address) or with intrinsics rescaled in place must not see the old
+    float64 copies / thresholds."""
+    from far_amd.solver import estimate_pose_batch
+    from tests.util import two_view_scene
+    k0, k1, K, _, _ = two_view_scene(500, seed=9, outlier_frac=0.2)[:5]
+    a, b = cu(k0.astype(np.float32)), cu(k1.astype(np.float32))
+
+    def run(K0, K1, cache):
+        out = estimate_pose_batch(a, b, [len(k0)], K0, K1, 0.5, solver='ransac', H=256, seed=3, cache=cache)
+        return out['R'][0].cpu().numpy().copy(), out['mask'].cpu().numpy().copy()
+
+    cache = {}
+    Kt = cu(K[None])
+    run(Kt, Kt.clone(), cache)
+    K2 = K.copy(); K2[0, 0] *= 1.3; K2[1, 1] *= 1.3
+    fresh = run(cu(K2[None]), cu(K2[None]), {})
+    # (1) in-place rescale of the cached tensors
+    K0 = cu(K[None]); K1 = K0.clone()
+    cache = {}
+    run(K0, K1, cache)
+    K0[:, 0, 0] *= 1.3; K0[:, 1, 1] *= 1.3; K1.copy_(K0)
+    got = run(K0, K1, cache)
+    np.testing.assert_array_equal(got[1], fresh[1]); np.testing.assert_allclose(got[0], fresh[0], atol=1e-12)
+    # (2) a replaced tensor at (very likely) the same address
+    cache = {}
+    K0 = cu(K[None]); K1 = K0.clone()
+    run(K0, K1, cache)
+    p = K0.data_ptr()
+    del K0
+    K0n = cu(K2[None])
+    got = run(K0n, cu(K2[None]), cache)
+    np.testing.assert_array_equal(got[1], fresh[1]); np.testing.assert_allclose(got[0], fresh[0], atol=1e-12)
+    # and an unchanged pair of tensors still hits
+    cache = {}
+    K0 = cu(K[None]); K1 = K0.clone()
+    run(K0, K1, cache)
+    kd = cache[('K', tuple(K0.shape), str(a.device))][3]
+    run(K0, K1, cache)
+    assert cache[('K', tuple(K0.shape), str(a.device))][3] is kd

@@ -295,3 +295,25 @@ def masked_coarse_inputs(seed=91, N=2, h=24, w=32, C=256):
     order = np.lexsort((np.array(ii), np.array(bb)))
     return {'f0': f0, 'f1': f1, 'mask0': m0, 'mask1': m1, 'spv_b_ids': np.array(bb, np.int64)[order],
             'spv_i_ids': np.array(ii, np.int64)[order], 'spv_j_ids': np.array(jj, np.int64)[order], 'h': h, 'w': w}
+
+
+# ---- golden G19 (the 8-Point-ViT shape of K2): the seeded weights / input both tools/make_golden_vit.py and the tests replay
+VIT_INTRINSICS = (13.7, 14.2, 12.0, 12.0)          # fx, fy, cx, cy on the 24 x 24 feature grid (model.py:120-129 rescales to it)
+
+
+def vit_seeded_fill(block, seed):
+    """Fills a CrossBlock-shaped module (parameters visited in sorted-name order) and returns the (2, 576, 192) input of one pair,
+    all from one seeded CPU generator: identical on every machine (torch's CPU generator is)."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in sorted(block.named_parameters()):
+            if name.endswith('norm1.weight') or name.endswith('norm2.weight'):
+                p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))
+            elif p.dim() == 1:
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+            else:
+                p.copy_(torch.randn(p.shape, generator=g) * (1.5 / p.shape[1] ** 0.5))
+        f0 = torch.randn(1, 576, 192, generator=g)
+        f1 = 0.5 * f0 + torch.randn(1, 576, 192, generator=g)
+    return torch.cat([f0, f1], 0)
