@@ -1,4 +1,6 @@
 """CPU tests of host-side logic that carries no kernel: solver dispatch, config, fail-loud behaviour."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -194,3 +196,17 @@ def test_kv_interleaved_weight_layout_is_what_far_linear_kv_expects():
     from far_amd._lib import FarHipError
     with pytest.raises(FarHipError):
         ops.kv_interleaved_weight(wk, wv[:64], H)
+
+
+def test_demo_without_a_gpu_exits_2_and_computes_nothing():
+    """BASELINE configs[0] says 'demo on CPU'; the product has no CPU path, so demo.py says so and exits 2 (tests/test_demo_gpu.py
+    runs it for real on the GPU box)."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip('a GPU is visible')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'demo.py'), '--synthetic'], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and 'no GPU visible' in r.stderr and 'predicted pose' not in r.stdout
