@@ -31,6 +31,9 @@ F32_MFMA_PEAK_TFLOPS = 157.3     # dense f32-input MFMA peak (same guide)
 F16_MFMA_PEAK_TFLOPS = 2500.0    # dense f16/bf16 MFMA peak (same guide; AMD headline figures include 2:1 sparsity)
 
 
+from far_amd import flags as _flags  # noqa: E402  (the registry of FAR_* switches)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -529,13 +532,13 @@ def bench_c3(a, dev, world, rank, dist):
     model = LoFTR(cfg['loftr'])
     synth.load_synthetic(model, seed=0)
     model = model.to(dev).train()
-    if os.environ.get('FAR_C3_PY_NODE') == '1':        # A/B aid: the layer node driven from Python instead of far_enc_layer_fwd / _bwd
+    if _flags.value('FAR_C3_PY_NODE') == '1':        # A/B aid: the layer node driven from Python instead of far_enc_layer_fwd / _bwd
         from far_amd.loftr.transformer import LoFTREncoderLayer as _L3
         _L3.native_node = False
-    if os.environ.get('FAR_C3_NO_OVERLAP') == '1':     # A/B aid: the layer node without side streams
+    if _flags.value('FAR_C3_NO_OVERLAP') == '1':     # A/B aid: the layer node without side streams
         from far_amd.loftr.transformer import LoFTREncoderLayer as _L2
         _L2.overlap = False
-    if os.environ.get('FAR_C3_PER_OP') == '1':         # A/B aid: one autograd node per operator (round-3 mid state) instead of per layer
+    if _flags.value('FAR_C3_PER_OP') == '1':         # A/B aid: one autograd node per operator (round-3 mid state) instead of per layer
         from far_amd import ops as _ops_ln
         from far_amd.loftr.transformer import LoFTREncoderLayer as _L
         _L.layer_node = False
@@ -563,7 +566,7 @@ def bench_c3(a, dev, world, rank, dist):
         fwd = DDP(model)
     # src/optimizers/__init__.py:5-16, default.py TRAINER.*: AdamW; K20 (one launch over all 189 tensors) unless --vendor-train
     from far_amd.optim import AdamW as _FarAdamW
-    opt = (torch.optim.AdamW if (a.vendor_train or os.environ.get('FAR_TORCH_ADAMW') == '1') else _FarAdamW)(model.parameters(), lr=1e-5, weight_decay=0.1)
+    opt = (torch.optim.AdamW if (a.vendor_train or _flags.value('FAR_TORCH_ADAMW') == '1') else _FarAdamW)(model.parameters(), lr=1e-5, weight_decay=0.1)
     # synthetic supervision: banded lateral disparities -> ground-truth coarse matches + warped grid (far_amd/synth.py)
     base = synth.synth_training_batch(B, seed=1234 + rank, device=dev)
     n_gt = int(base['spv_b_ids'].numel()) // B
@@ -765,9 +768,6 @@ def main():
             kw = dict(init_method=f'tcp://127.0.0.1:{_par.free_port()}', rank=0, world_size=1)
         dist.init_process_group(a.backend, device_id=dev if a.backend == 'nccl' else None, **kw)
         world = dist.get_world_size()            # the rank count the backend (RCCL) reports
-    if os.environ.get('FAR_NO_STACK') == '1':          # A/B aid (any workload): 'self' layers on the two images separately
-        from far_amd.loftr.transformer import LocalFeatureTransformer as _T0
-        _T0.stack_self = False
     if a.workload == 'c4':
         return bench_c4(a, dev, world, rank, dist)
     if a.workload == 'c3':
@@ -779,7 +779,7 @@ def main():
     from far_amd.loftr import LoFTR
     from far_amd.pipeline import test_step
 
-    if os.environ.get('FAR_CUDNN_BENCHMARK') == '1':
+    if _flags.value('FAR_CUDNN_BENCHMARK') == '1':
         torch.backends.cudnn.benchmark = True      # MIOpen exhaustive solver search (experiment switch)
     cfg = far_eval_config()
     model = LoFTR(cfg).eval()

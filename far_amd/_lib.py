@@ -6,10 +6,12 @@ non-GPU tensor, this module raises.  `load()` itself needs no GPU (the symbol-ex
 import ctypes
 import os
 
+from . import flags
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # FAR_HIP_LIB: another build of the same library (tools/ab_build.py writes lib/libfar_hip_base.so from a git revision, for
 # same-box A/B timings); the default is the in-tree build.
-LIB_PATH = os.environ.get('FAR_HIP_LIB') or os.path.join(_HERE, 'lib', 'libfar_hip.so')
+LIB_PATH = flags.value('FAR_HIP_LIB') or os.path.join(_HERE, 'lib', 'libfar_hip.so')
 
 c_p = ctypes.c_void_p
 c_i = ctypes.c_int
@@ -190,13 +192,13 @@ def load():
         fn.argtypes = args
     # provenance: the library travels outside git (built in-tree, snapshot-copied to the GPU box).  Its build id must equal the id of
     # the sources it is loaded next to; FAR_HIP_LIB (tools/ab_build.py: a library of another revision, on purpose) skips the check
-    if 'FAR_HIP_LIB' not in os.environ:
+    if not flags.value('FAR_HIP_LIB'):
         from . import build as _build
         want, have = _build.source_id(), lib.far_build_id().decode()
         if have != want:
             raise FarHipError(f'{LIB_PATH} was built from other sources (build id {have}, far_amd/csrc is {want}): rebuild it with '
                               '`python -m far_amd.build`')
-    for kv in filter(None, os.environ.get('FAR_TUNING', '').split(',')):      # A/B aid: FAR_TUNING="10=1,8=1" -> far_set_tuning(key, value)
+    for kv in filter(None, (flags.value('FAR_TUNING') or '').split(',')):      # A/B aid: FAR_TUNING="10=1,8=1" -> far_set_tuning(key, value)
         k, v = kv.split('=')
         lib.far_set_tuning(int(k), int(v))
     _lib = lib

@@ -8,13 +8,15 @@ import os
 import subprocess
 import sys
 
+from far_amd import flags
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libfar_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 BASE_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wno-unused-result', '-Wno-unused-value']
-EXTRA_FLAGS = os.environ.get('FAR_EXTRA_HIPCC_FLAGS', '').split()            # experiment builds (-DFAR_WINO_EXP=..., tools/)
+EXTRA_FLAGS = (flags.value('FAR_EXTRA_HIPCC_FLAGS') or '').split()            # experiment builds (-DFAR_WINO_EXP=..., tools/)
 FLAGS = BASE_FLAGS + ['-I', CSRC] + EXTRA_FLAGS
 
 

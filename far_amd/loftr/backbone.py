@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import ops
+from .. import flags, ops
 
 
 def _fold(bn):
@@ -65,7 +65,7 @@ def _pad16(c):
     return -(-c // 16) * 16
 
 
-PAD_CHANNELS = os.environ.get('FAR_NO_PAD', '0') in ('', '0')
+PAD_CHANNELS = not flags.off('FAR_NO_PAD')
 
 
 def _c1(i, o, s=1):

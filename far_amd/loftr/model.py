@@ -16,7 +16,7 @@ import os
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import flags, ops
 from ..pose6d import compute_normalized_6d, pose_mean_6d, pose_std_6d, rotation_6d_to_matrix
 from .backbone import build_backbone
 from .stages import CoarseMatching, FineMatching, FinePreprocess
@@ -100,7 +100,7 @@ class LoFTR(nn.Module):
         self.act_exp = 4
 
     PRECISIONS = ('fp32', 'fp16-fine', 'fp16', 'bf16')
-    head_prefetch = os.environ.get('FAR_NO_PREFETCH', '') != '1'   # inference: the head's feature stage enqueued behind K1 (see below)
+    head_prefetch = not flags.off('FAR_NO_PREFETCH')   # inference: the head's feature stage enqueued behind K1 (see below)
 
     def set_precision(self, mode):
         """Arithmetic of the backbone convolutions (everything else is unaffected):

@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from .. import autograd_ops as ag
-from .. import ops
+from .. import flags, ops
 
 
 # =====================================================================================================
@@ -206,7 +206,7 @@ class FinePreprocess(nn.Module):
             if p.dim() > 1:
                 nn.init.kaiming_normal_(p, mode="fan_out", nonlinearity="relu")
 
-    fused_gather = os.environ.get('FAR_NO_GATHER_FUSE', '') != '1'   # inference: merge_feat reads the fine map through the window indices
+    fused_gather = not flags.off('FAR_NO_GATHER_FUSE')   # inference: merge_feat reads the fine map through the window indices
 
     def _fused_gather_ok(self, f0, f1, feat_c0, data):
         """K9's gather mode applies: inference on the GPU with fine_concat_coarse_feat, and the two fine maps are the halves of one

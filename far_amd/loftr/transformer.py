@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 
 from .. import autograd_ops as ag
-from .. import ops
+from .. import flags, ops
 from ..pose6d import pose_mean_6d, pose_std_6d
 
 
@@ -56,8 +56,8 @@ class LoFTREncoderLayer(nn.Module):
     native_node = True           # layer node: launch sequences issued by the library (far_enc_layer_fwd / _bwd) instead of Python
     fused_mlp = True             # d_model 128, split operands: the MLP block as one K13 launch (False: two K9 launches)
     fused_attn = True            # d_model 128, sequences <= 32 tokens, no masks: the attention block as one K14 launch
-    fused_apply = os.environ.get('FAR_NO_QAPPLY', '') != '1'   # ... and the q projection + LinearAttention's second half in one launch
-    fused_kv = os.environ.get('FAR_NO_KV', '') != '1'    # d_model 256, 8 heads, no masks: k | v projection + K'^T V in one launch (k, v never stored)
+    fused_apply = not flags.off('FAR_NO_QAPPLY')   # ... and the q projection + LinearAttention's second half in one launch
+    fused_kv = not flags.off('FAR_NO_KV')    # d_model 256, 8 heads, no masks: k | v projection + K'^T V in one launch (k, v never stored)
 
     def __init__(self, d_model, nhead, attention='linear', use_num_corres=False):
         super().__init__()
@@ -182,7 +182,7 @@ def _halves_of_one_buffer(a, b):
 
 
 class LocalFeatureTransformer(nn.Module):
-    stack_self = True            # on the GPU: the two self-attention calls of a layer as one call on both images
+    stack_self = not flags.off('FAR_NO_STACK')            # on the GPU: the two self-attention calls of a layer as one call on both images
 
     def __init__(self, config):
         super().__init__()
@@ -376,8 +376,12 @@ class CrossAttention(nn.Module):
         else:                                                      # K9 (row-independent), both directions in one launch
             pk = self.__dict__.setdefault('_packs', ops.PackCache())
             pw, pb = self.proj_fundamental.weight, self.proj_fundamental.bias
-            pp = pk.get('proj', [pw, pb], lambda: ops.PackedConv(pw, None, pb))
-            f12 = ops.linear_f16s(torch.stack([f1, f2], 0).contiguous(), pp)
+            # K9 reads 16-byte channel groups: 280 input channels at mp3d's shape; the 8-Point-ViT's 210 (= 192 + 6 x 3) get two
+            # zero columns on both operands (exact)
+            pad = (-pw.shape[1]) % 4
+            pp = pk.get('proj', [pw, pb], lambda: ops.PackedConv(nn.functional.pad(pw.detach(), (0, pad)) if pad else pw, None, pb))
+            f12 = torch.stack([f1, f2], 0)
+            f12 = ops.linear_f16s(nn.functional.pad(f12, (0, pad)) if pad else f12.contiguous(), pp)
             f1, f2 = f12[0], f12[1]
         return f2, f1                                              # flipped on purpose (:301-303)
 

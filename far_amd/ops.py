@@ -9,7 +9,7 @@ import threading
 
 import torch
 
-from . import _lib
+from . import _lib, flags
 
 
 _TLS = threading.local()          # .side: the library side stream this thread's launches currently go to (ops.side), or absent
@@ -912,7 +912,7 @@ class _BatchNormActFn(torch.autograd.Function):
         return (dx, dgb[0] if weight is not None else None, dgb[1] if weight is not None else None, None, None, None, dres)
 
 
-USE_HIP_BATCHNORM_TRAIN = os.environ.get('FAR_NO_BN', '0') in ('', '0')      # False: nn.BatchNorm2d + torch activations under autograd (comparison leg, --vendor-train)
+USE_HIP_BATCHNORM_TRAIN = not flags.off('FAR_NO_BN')      # False: nn.BatchNorm2d + torch activations under autograd (comparison leg, --vendor-train)
 
 
 def bn_act_train(x, bn, act='none', slope=0.01, residual=None):
@@ -1161,7 +1161,7 @@ class PackedWino:
 
 WINO_MIN_ACT_EXP = 0        # K17 splits its operands unscaled (|a| <= 16376): used while the activation exponent is >= 0
 WINO_MIN_PIXELS = 1024      # per image; below, a 16x16-output workgroup tile is mostly padding
-USE_WINO = os.environ.get('FAR_NO_WINO', '0') in ('', '0')      # inference 3x3 stride-1 layers on K17 (conv_nhwc dispatches); False: K9 everywhere
+USE_WINO = not flags.off('FAR_NO_WINO')      # inference 3x3 stride-1 layers on K17 (conv_nhwc dispatches); False: K9 everywhere
 
 
 def conv3x3_wino(x, pw, residual=None, act='none', slope=0.01, out=None):
