@@ -41,12 +41,40 @@ constexpr int RING = 4;                  // round-5 form; the round-3 form (K14_
 constexpr int WAVES = 8;
 constexpr int XBUF = 4096;               // one 32-channel chunk of a window's rows
 constexpr int SMEM_NEW = RING * SLAB + WAVES * 2 * XBUF;      // 64 KiB + 64 KiB
-// Requests of one wave in program order: prologue X0 X1 W0 W1 W2; phase p (after its barrier): [X(j + 2) if the phase read chunk j
-// and j + 2 < 8] then [W(p + 3) if p + 3 < 16]; X = 4 pieces, W = 2 pieces.  Chunks are read in phases 0, 2, 4, 6 (source) and 8..11
-// (x).  VM_ALLOW[p] = pieces issued after the youngest request phase p reads (its slab W(p), its chunk): what may stay in flight
-// across barrier p.  (Generated by replaying exactly this schedule; a wrong entry shows as stale LDS reads -- the run-to-run
-// determinism and float64 tests of tests/test_attn_block_gpu.py catch that.)
-constexpr int VM_ALLOW[16] = {4, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 4, 4, 4, 2, 0};
+// Requests of one wave in program order (counted pipeline): prologue X0 X1 W0 .. W(D-1); phase p (after its barrier): [X(j + 2) if the
+// phase read chunk j and j + 2 < 8] then [W(p + D) if p + D < 16]; X = 4 pieces, W = 16 / waves pieces; D = ring slots - 1.  Chunks are read
+// in phases 0, 2, 4, 6 (source) and 8..11 (x).  vm_allow(p) = pieces issued after the youngest request phase p reads (its slab W(p),
+// its chunk) = what may stay in flight across barrier p -- computed by replaying exactly this schedule (8 waves, 4 slots:
+// 4 8 8 8 8 8 8 8 8 8 8 4 4 4 2 0).  A wrong entry shows as stale LDS reads: the run-to-run determinism and float64 tests of
+// tests/test_attn_block_gpu.py catch that.
+constexpr int chunk_read_in_phase(int p) { return (p < 8 && (p & 1) == 0) ? p / 2 : ((p >= 8 && p < 12) ? 4 + (p - 8) : -1); }
+constexpr int vm_allow(int p, int wp, int d) {
+    // kind 0 = X(id), 1 = W(id)
+    int kind[64] = {}, id[64] = {}, n[64] = {}, cnt = 0;
+    kind[cnt] = 0; id[cnt] = 0; n[cnt++] = 4;
+    kind[cnt] = 0; id[cnt] = 1; n[cnt++] = 4;
+    for (int s0 = 0; s0 < d; ++s0) { kind[cnt] = 1; id[cnt] = s0; n[cnt++] = wp; }
+    for (int q = 0; q < p; ++q) {
+        const int j = chunk_read_in_phase(q);
+        if (j >= 0 && j + 2 < 8) { kind[cnt] = 0; id[cnt] = j + 2; n[cnt++] = 4; }
+        if (q + d < NSLAB) { kind[cnt] = 1; id[cnt] = q + d; n[cnt++] = wp; }
+    }
+    const int jx = chunk_read_in_phase(p);
+    int last = -1;
+    for (int i = 0; i < cnt; ++i)
+        if ((kind[i] == 1 && id[i] == p) || (kind[i] == 0 && id[i] == jx)) last = i;
+    int after = 0;
+    for (int i = last + 1; i < cnt; ++i) after += n[i];
+    return after;
+}
+struct VmTable {
+    int a[NSLAB];
+    constexpr VmTable(int wp, int d) : a{} {
+        for (int p = 0; p < NSLAB; ++p) a[p] = vm_allow(p, wp, d);
+    }
+};
+static_assert(vm_allow(0, 2, 3) == 4 && vm_allow(1, 2, 3) == 8 && vm_allow(10, 2, 3) == 8 && vm_allow(11, 2, 3) == 4 &&
+              vm_allow(14, 2, 3) == 2 && vm_allow(15, 2, 3) == 0, "the 8-wave / 4-slot schedule");
 constexpr float ACT_SCALE = 16.0f;
 
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst_uniform) {
@@ -60,7 +88,11 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst_unifor
 // reads here -- whole windows wrong in ~3 % of the windows of every launch beyond the first round of workgroups -- whenever
 // six or more requests were allowed to stay in flight across a barrier of the k / v phases; the run-to-run determinism test
 // of tests/test_attn_block_gpu.py is what found it.
-__device__ __forceinline__ float elu1(float x) { return (x > 0.f ? x : expm1f(x)) + 1.f; }   // F.elu(x) + 1
+// F.elu(x) + 1 = x + 1 (x > 0), e^x otherwise, as 2^(x log2 e) on the hardware exponential (as K9's LinearAttention epilogues,
+// conv_igemm_f16s.hip:la_elu1): the rounding of the argument costs |x| e^x 2^-24 <= 2^-25 absolute -- half an ulp of 1.0, the size
+// of a K' -- where expm1f(x) + 1 rounds twice; 4 instructions instead of ~37 and two branches per value (round 5: the 128 expm1f
+// expansions were half of this kernel's 10.8 k instructions per window).
+__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x + 1.f : __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
 
 __device__ __forceinline__ void split_regs(const float (&v)[8], f16x8& hi, f16x8& lo) {
 #pragma unroll
@@ -94,13 +126,13 @@ struct Scales { float k, v, q, m; };     // accumulator -> value: 2^-(w_exp + 4)
 
 // vmcnt(n) with an immediate: the phase loops are fully unrolled, so `n` is a constant and the switch folds away
 __device__ __forceinline__ void wait_vm(int n) {
+#define FAR_VM_CASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
     switch (n) {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        FAR_VM_CASE(0) FAR_VM_CASE(1) FAR_VM_CASE(2) FAR_VM_CASE(3) FAR_VM_CASE(4) FAR_VM_CASE(5) FAR_VM_CASE(6) FAR_VM_CASE(7) FAR_VM_CASE(8)
+        FAR_VM_CASE(9) FAR_VM_CASE(10) FAR_VM_CASE(11) FAR_VM_CASE(12) FAR_VM_CASE(13) FAR_VM_CASE(14) FAR_VM_CASE(15) FAR_VM_CASE(16)
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
+#undef FAR_VM_CASE
 }
 
 // NW waves per workgroup, NR ring slots; CNT: the round-5 pipeline (counted waits, requests three phases ahead, double-buffered
@@ -189,7 +221,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_attn128(const float* __restrict_
     // phase p: slab p (and the chunk it reads) has landed for this wave -- then the barrier makes every wave's pieces visible and
     // frees the slot slab p - 1 used; after it the phase requests slab p + AHEAD into that slot
     auto begin_phase = [&](int p) {
-        wait_vm(CNT ? VM_ALLOW[p] : 0);
+        constexpr VmTable vmt(NPIECE, AHEAD);
+        wait_vm(CNT ? vmt.a[p] : 0);
         asm volatile("s_barrier" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -218,6 +251,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_attn128(const float* __restrict_
     // K' = elu(k) + 1, V = v / S on the rows of the window (registers: token mfma32_row(r, h); lane: channel 32 t + l31)
     float ksum[CT];
     const float fS = (float)S;
+    const float v_mul = sc.v * ACT_SCALE / fS;                  // values / v_length (linear_attention.py:43) folded with the accumulator scale: one
+                                                              // rounding of the factor (<= 1 ulp against the reference's two operations), no division per value
 #pragma unroll
     for (int t = 0; t < CT; ++t) {
         float s_ = 0.f;
@@ -226,7 +261,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_attn128(const float* __restrict_
             const bool ok = mfma32_row(r, h) < S;
             const float kk = ok ? elu1(ka[t][r] * sc.k) : 0.f;
             ka[t][r] = kk * ACT_SCALE;
-            va[t][r] = ok ? (va[t][r] * sc.v) / fS * ACT_SCALE : 0.f;      // values / v_length (linear_attention.py:43)
+            va[t][r] = ok ? va[t][r] * v_mul : 0.f;
             s_ += kk;
         }
         ksum[t] = s_ + shfl_xor_f(s_, 32);                      // lane l31 (either half): sum_s K'_s [channel 32 t + l31]
@@ -384,11 +419,19 @@ int far_attn_block_f16s(const float* x, const float* src, const void* packed, lo
         return FAR_EINVAL;
     const Scales sc{scale_k, scale_v, scale_q, scale_m};
     constexpr int SMEM_OLD = 3 * SLAB + 4 * XBUF;
+    constexpr int SMEM_44 = 3 * SLAB + 4 * 2 * XBUF;            // 80 KiB: two workgroups per CU
     bool cfg_failed = false;
     FAR_ONCE_PER_DEVICE(cfg_failed = hipFuncSetAttribute((const void*)k_attn128<WAVES, RING, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_NEW) != hipSuccess ||
+                                     hipFuncSetAttribute((const void*)k_attn128<4, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_44) != hipSuccess ||
                                      hipFuncSetAttribute((const void*)k_attn128<4, 3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_OLD) != hipSuccess);
     if (cfg_failed) return far_check_launch();
-    if (far_get_tuning(11) == 0) {
+    const int variant = far_get_tuning(11);
+    if (variant == 2) {                                        // 4-wave workgroups, two per CU, counted waits (3 slots: two phases ahead)
+        const long nb = (nwin + 3) / 4;
+        if (nb > 0x7fffffffL) return FAR_EINVAL;
+        hipLaunchKernelGGL((k_attn128<4, 3, true>), dim3((unsigned)nb), dim3(256), SMEM_44, stream, x, src,
+                           (const unsigned char*)packed, nwin, L, S, sc, attn_eps, gamma, beta, ln_eps, out, overflow);
+    } else if (variant == 0) {
         const long nb = (nwin + WAVES - 1) / WAVES;
         if (nb > 0x7fffffffL) return FAR_EINVAL;
         hipLaunchKernelGGL((k_attn128<WAVES, RING, true>), dim3((unsigned)nb), dim3(64 * WAVES), SMEM_NEW, stream, x, src,

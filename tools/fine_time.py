@@ -43,8 +43,8 @@ def main():
         for key, name in ((11, 'K14'), (14, 'K13')):
             fn = (lambda: ops.attn_block(x, s, pa, H, gam, bet, 1e-5)) if name == 'K14' else (lambda: ops.mlp_fused(x, s, pm, gam, bet, 1e-5))
             res = {}
-            for v in (0, 1):
-                if lib.far_set_tuning(key, v) != 0:
+            for v in (0, 1, 2):
+                if lib.far_set_tuning(key, v) != 0 or (v == 2 and key != 11):
                     continue
                 try:
                     y = fn()
@@ -52,8 +52,8 @@ def main():
                 finally:
                     lib.far_set_tuning(key, 0)
             same = torch.equal(res[0][1], res[1][1]) if 1 in res else None
-            out[name] = (res[0][0], res[1][0] if 1 in res else None, same)
-        print(f'windows {n}: ' + '  '.join(f'{k} {v[0]:.3f} ms (round-3 pipeline {v[1]:.3f} ms, bit-identical {v[2]})' for k, v in out.items()), flush=True)
+            out[name] = (res[0][0], res[1][0] if 1 in res else None, same, res[2][0] if 2 in res else None)
+        print(f'windows {n}: ' + '  '.join(f'{k} {v[0]:.3f} ms (round-3 pipeline {v[1]:.3f} ms, bit-identical {v[2]}' + (f'; variant 2: {v[3]:.3f} ms' if v[3] else '') + ')' for k, v in out.items()), flush=True)
 
 
 if __name__ == '__main__':
