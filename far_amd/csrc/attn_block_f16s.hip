@@ -135,8 +135,13 @@ __device__ __forceinline__ void wait_vm(int n) {
 #undef FAR_VM_CASE
 }
 
-// NW waves per workgroup, NR ring slots; CNT: the round-5 pipeline (counted waits, requests three phases ahead, double-buffered
-// input chunks); !CNT: the round-3 pipeline (every phase drains the queue; far_set_tuning(11, 1), kept for same-box A/Bs).
+// NW waves per workgroup, NR ring slots; CNT: counted waits, requests NR - 1 phases ahead, double-buffered input chunks (!CNT: every
+// phase drains the queue, one buffer).  ONE instantiation is launched: <8, 4, true>, one workgroup per CU.  Measured on 120 296
+// windows (tools/fine_time.py at commit 2f4e... of round 5, profiles/r05_fine_level.txt): the round-3 form <4, 3, false> and a counted
+// <4, 3, true> -- both TWO workgroups per CU -- were 4-5 % faster (2.17-2.18 vs 2.29 ms) but NOT run-to-run deterministic once the
+// elu got cheap (5 and 156 windows of 120 296 differing per launch, whole workgroups in the counted form); the 8-wave form is
+// (four launches bit-identical, the 50-launch test of tests/test_attn_block_gpu.py, and the bench-scale test added with it).
+// The cause was not isolated -- the same hand-synchronised ring is airtight with one workgroup per CU here and in K17.
 template <int NW, int NR, bool CNT>
 __global__ __launch_bounds__(64 * NW, 2) void k_attn128(const float* __restrict__ x, const float* __restrict__ src,
                                                         const unsigned char* __restrict__ wimg, long nwin, int L, int S, Scales sc,
@@ -418,30 +423,13 @@ int far_attn_block_f16s(const float* x, const float* src, const void* packed, lo
         d_model != DM || heads != 8 || out == x || out == src)
         return FAR_EINVAL;
     const Scales sc{scale_k, scale_v, scale_q, scale_m};
-    constexpr int SMEM_OLD = 3 * SLAB + 4 * XBUF;
-    constexpr int SMEM_44 = 3 * SLAB + 4 * 2 * XBUF;            // 80 KiB: two workgroups per CU
     bool cfg_failed = false;
-    FAR_ONCE_PER_DEVICE(cfg_failed = hipFuncSetAttribute((const void*)k_attn128<WAVES, RING, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_NEW) != hipSuccess ||
-                                     hipFuncSetAttribute((const void*)k_attn128<4, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_44) != hipSuccess ||
-                                     hipFuncSetAttribute((const void*)k_attn128<4, 3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_OLD) != hipSuccess);
+    FAR_ONCE_PER_DEVICE(cfg_failed = hipFuncSetAttribute((const void*)k_attn128<WAVES, RING, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_NEW) != hipSuccess);
     if (cfg_failed) return far_check_launch();
-    const int variant = far_get_tuning(11);
-    if (variant == 2) {                                        // 4-wave workgroups, two per CU, counted waits (3 slots: two phases ahead)
-        const long nb = (nwin + 3) / 4;
-        if (nb > 0x7fffffffL) return FAR_EINVAL;
-        hipLaunchKernelGGL((k_attn128<4, 3, true>), dim3((unsigned)nb), dim3(256), SMEM_44, stream, x, src,
-                           (const unsigned char*)packed, nwin, L, S, sc, attn_eps, gamma, beta, ln_eps, out, overflow);
-    } else if (variant == 0) {
-        const long nb = (nwin + WAVES - 1) / WAVES;
-        if (nb > 0x7fffffffL) return FAR_EINVAL;
-        hipLaunchKernelGGL((k_attn128<WAVES, RING, true>), dim3((unsigned)nb), dim3(64 * WAVES), SMEM_NEW, stream, x, src,
-                           (const unsigned char*)packed, nwin, L, S, sc, attn_eps, gamma, beta, ln_eps, out, overflow);
-    } else {                                                   // tuning 11 = 1: the round-3 pipeline (4 waves, 3 slots, drained phases)
-        const long nb = (nwin + 3) / 4;
-        if (nb > 0x7fffffffL) return FAR_EINVAL;
-        hipLaunchKernelGGL((k_attn128<4, 3, false>), dim3((unsigned)nb), dim3(256), SMEM_OLD, stream, x, src,
-                           (const unsigned char*)packed, nwin, L, S, sc, attn_eps, gamma, beta, ln_eps, out, overflow);
-    }
+    const long nb = (nwin + WAVES - 1) / WAVES;
+    if (nb > 0x7fffffffL) return FAR_EINVAL;
+    hipLaunchKernelGGL((k_attn128<WAVES, RING, true>), dim3((unsigned)nb), dim3(64 * WAVES), SMEM_NEW, stream, x, src,
+                       (const unsigned char*)packed, nwin, L, S, sc, attn_eps, gamma, beta, ln_eps, out, overflow);
     return far_check_launch();
 }
 

@@ -61,7 +61,6 @@ TUNING = [
     Tuning(8, 0, (1,), 'bitwise', 'K17 splits its operands with the five-instruction split2 instead of v_fma_mix (same values)'),
     Tuning(9, 0, (1,), 'bitwise', 'K17 runs a short last channel block on the full body'),
     Tuning(10, 0, (1,), 'bitwise', "K1's match pass without the tile prescreen"),
-    Tuning(11, 0, (1,), 'bitwise', 'K14 on its round-3 pipeline: 4-wave workgroups, 3-slot ring, every phase drains its requests (vmcnt(0))'),
     Tuning(12, 0, (1,), 'parity', "K10's inference form on the exact-f32 matrix instruction instead of split fp16"),
     Tuning(13, 0, (1,), 'bitwise', "K9's FPN-merge epilogue in its generic form everywhere"),
 ]
