@@ -151,7 +151,7 @@ __device__ unsigned long long g_wino_stamps2[4096 * 8 * 16];
 // only the first 32-channel tile is multiplied (12 MFMAs per interval), and the waves whose weight pieces belong to the second
 // tile (wave & 2: piece 4 j + wave = [xi & 1][nu][co tile][plane]) request none.
 template <bool Q, bool MIX, bool HALF>
-__device__ __forceinline__ void wino_body(const WinoArgs& p) {
+__device__ __forceinline__ void wino_body(const WinoArgs& p, long t, const int cb) {
     constexpr int NCT = HALF ? 1 : 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const Bs = smem;
@@ -161,17 +161,6 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p) {
     const int xi = wave >> 1, tb = wave & 1, xil = xi & 1;
     const int l31 = lane & 31, h = lane >> 5;
 
-    // ---- tile block / channel block of this workgroup: each XCD (block b -> XCD b % 8, speed only) gets a contiguous range of
-    // tile blocks and runs the channel blocks of a tile block back to back (they re-read the same pixels from its L2)
-    long t;
-    int cb;
-    {
-        const long b = blockIdx.x;
-        long seq = b, t0 = 0;
-        if ((p.ntb & 7) == 0) { seq = b >> 3; t0 = (b & 7) * (p.ntb >> 3); }
-        t = t0 + seq / p.ncb;
-        cb = (int)(seq % p.ncb);
-    }
     const int bx = (int)(t % p.tilesX);
     t /= p.tilesX;
     const int by = (int)(t % p.tilesY);
@@ -547,18 +536,29 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p) {
 #endif
 }
 
-template <bool MIX>
+// WALK = false: one workgroup per (tile block, channel block); each XCD (block b -> XCD b % 8, speed only) gets a contiguous range
+// of tile blocks and runs the channel blocks of a tile block back to back (siblings re-read the same pixels from its L2 -- but at
+// the same TIME, on neighbouring CUs: a sibling's request finds the line in flight and waits for the same HBM miss).
+// WALK = true (round 5; far_set_tuning(14, 1)): one workgroup per tile block walks the channel blocks in
+// sequence, so that only the first pass misses; the raw patches of the later passes are L2 hits.  The transform is NOT shared (V
+// of all k-steps of a tile block is 512 KiB, LDS holds 160): every pass requests and transforms its patches again.
+template <bool MIX, bool WALK>
 __global__ __launch_bounds__(512, 2) void k_wino(const WinoArgs p) {
-    // the workgroup's channel block (as wino_body maps it): the last one may hold at most 32 channels
-    const long seq = (p.ntb & 7) == 0 ? (long)blockIdx.x >> 3 : (long)blockIdx.x;
-    const int cb = (int)(seq % p.ncb);
-    const bool half = p.half_ok && cb == p.ncb - 1;            // workgroup-uniform
-    if (half) {
-        if (threadIdx.x >= 256) wino_body<true, MIX, true>(p);
-        else wino_body<false, MIX, true>(p);
-    } else {
-        if (threadIdx.x >= 256) wino_body<true, MIX, false>(p);
-        else wino_body<false, MIX, false>(p);
+    const long b = blockIdx.x;
+    long seq = b, t0 = 0;
+    if ((p.ntb & 7) == 0) { seq = b >> 3; t0 = (b & 7) * (p.ntb >> 3); }
+    const long t = WALK ? t0 + seq : t0 + seq / p.ncb;
+    const int cb0 = WALK ? 0 : (int)(seq % p.ncb), cb1 = WALK ? p.ncb : cb0 + 1;
+    for (int cb = cb0; cb < cb1; ++cb) {
+        if (WALK && cb > cb0) asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the epilogue's LDS image is read out, its stores are out of the counted queue
+        const bool half = p.half_ok && cb == p.ncb - 1;            // workgroup-uniform: the last block may hold at most 32 channels
+        if (half) {
+            if (threadIdx.x >= 256) wino_body<true, MIX, true>(p, t, cb);
+            else wino_body<false, MIX, true>(p, t, cb);
+        } else {
+            if (threadIdx.x >= 256) wino_body<true, MIX, false>(p, t, cb);
+            else wino_body<false, MIX, false>(p, t, cb);
+        }
     }
 }
 
@@ -678,15 +678,18 @@ int far_conv3x3_wino_f32(const far_conv_desc* desc, hipStream_t stream) {
     a.ntb = d.N * a.tilesX * a.tilesY;
     a.act = d.act; a.slope = d.slope; a.out_mul = 16.0f;
     a.half_ok = (d.Cout - 64 * (a.ncb - 1) <= 32 && far_get_tuning(9) == 0) ? 1 : 0;      // tuning 9: 1 = every block on the full body
-    const long nblk = a.ntb * a.ncb;
+    const bool walk = far_get_tuning(14) != 0;                  // tuning 14: 1 = one workgroup per tile block walks the channel blocks
+    const long nblk = walk ? a.ntb : a.ntb * a.ncb;
     if (nblk > 0x7fffffffL || (long)d.H * d.W * d.Cout > 0x7fffffffL) return FAR_EINVAL;
     const bool mix = far_get_tuning(8) == 0;
     bool cfg_failed = false;
-    FAR_ONCE_PER_DEVICE(cfg_failed = hipFuncSetAttribute((const void*)k_wino<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess ||
-                                     hipFuncSetAttribute((const void*)k_wino<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess);
+    FAR_ONCE_PER_DEVICE(cfg_failed = hipFuncSetAttribute((const void*)k_wino<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess ||
+                                     hipFuncSetAttribute((const void*)k_wino<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess ||
+                                     hipFuncSetAttribute((const void*)k_wino<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess);
     if (cfg_failed) return far_check_launch();
-    if (mix) hipLaunchKernelGGL(k_wino<true>, dim3((unsigned)nblk), dim3(512), SMEM, stream, a);
-    else hipLaunchKernelGGL(k_wino<false>, dim3((unsigned)nblk), dim3(512), SMEM, stream, a);
+    if (walk && mix) hipLaunchKernelGGL((k_wino<true, true>), dim3((unsigned)nblk), dim3(512), SMEM, stream, a);
+    else if (mix) hipLaunchKernelGGL((k_wino<true, false>), dim3((unsigned)nblk), dim3(512), SMEM, stream, a);
+    else hipLaunchKernelGGL((k_wino<false, false>), dim3((unsigned)nblk), dim3(512), SMEM, stream, a);
     return far_check_launch();
 }
 
