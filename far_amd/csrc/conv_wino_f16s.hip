@@ -86,6 +86,7 @@ struct WinoArgs {
     long ntb;                    // tile blocks = N * tilesX * tilesY
     int H, W, Cin, Cout, nk, ncb, tilesX, tilesY, act;
     int half_ok;                 // the last channel block holds at most 32 channels: its workgroups run the HALF body
+    int prio;                    // experiment (far_set_tuning 15): 1 = the multiplying group raises its issue priority, 2 = the transforming group does
     float slope, out_mul;
 };
 
@@ -266,6 +267,7 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p, long t, const int c
             }
             return;
         }
+        if (p.prio == 2) __builtin_amdgcn_s_setprio(2);
         const unsigned char* R0 = Rs + slot * RAWB;
         // Scalar fp32 instructions from inline asm on purpose: next to a wave that issues MFMAs, v_pk_fma_f32 waits for a gap in the
         // matrix pipe (tools/ubench/valu_cost.hip: 370 cycles per instruction against 5 alone) and the packed adds cost more than
@@ -305,6 +307,7 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p, long t, const int c
                 Ah[nu][pr] = __builtin_bit_cast(unsigned, h); Al[nu][pr] = __builtin_bit_cast(unsigned, l);
             }
         }
+        if (p.prio == 2) __builtin_amdgcn_s_setprio(0);
     };
 
     f32x16 acc[4][NCT];
@@ -324,6 +327,7 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p, long t, const int c
             for (int i = 0; i < NP; ++i) piece(i);
             return;
         }
+        if (p.prio == 1) __builtin_amdgcn_s_setprio(2);
         const unsigned char* B = Bs + slot * SLAB + b_lane;
         f16x8 bh[2][NCT], bl[2][NCT];
         auto read_b = [&](int nu) {
@@ -353,6 +357,7 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p, long t, const int c
                 if (any) __builtin_amdgcn_sched_barrier(0);        // the request stays behind this MFMA
             }
         }
+        if (p.prio == 1) __builtin_amdgcn_s_setprio(0);
     };
 
     // ---- prologue: slabs 0, 1, raw patches 0, 1; the xi = 0, 1 waves transform k-step 0
@@ -678,6 +683,7 @@ int far_conv3x3_wino_f32(const far_conv_desc* desc, hipStream_t stream) {
     a.ntb = d.N * a.tilesX * a.tilesY;
     a.act = d.act; a.slope = d.slope; a.out_mul = 16.0f;
     a.half_ok = (d.Cout - 64 * (a.ncb - 1) <= 32 && far_get_tuning(9) == 0) ? 1 : 0;      // tuning 9: 1 = every block on the full body
+    a.prio = far_get_tuning(15);                                // tuning 15: issue-priority experiment (speed only)
     const bool walk = far_get_tuning(14) != 0;                  // tuning 14: 1 = one workgroup per tile block walks the channel blocks
     const long nblk = walk ? a.ntb : a.ntb * a.ncb;
     if (nblk > 0x7fffffffL || (long)d.H * d.W * d.Cout > 0x7fffffffL) return FAR_EINVAL;
