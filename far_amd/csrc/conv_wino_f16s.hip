@@ -98,6 +98,13 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst_unifor
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
 }
 
+// the same request with the non-temporal hint (experiment, far_set_tuning 15 = 3 / 4: raw patches / weight slabs)
+__device__ __forceinline__ void glds16_nt(const void* gsrc, unsigned lds_dst_uniform) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
+}
+
 // hi = fp16(x), lo = fp16(x - hi) of two values: v_cvt_pk_f16_f32 + one v_fma_mix per lo half (the fp16 operand is widened,
 // subtracted in fp32 -- exactly -- and the result rounded to fp16 by the same instruction): 3 instructions per pair.
 template <bool MIX>
@@ -195,7 +202,10 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p, long t, const int c
     const bool wskip = HALF && (wsel & 2);            // wave-uniform
     auto b_piece = [&](const unsigned char* src0, int slot, int j) {          // piece j (0..7) of this wave
         if (wskip) return;
-        if (!(FAR_WINO_EXP & 4)) glds16(src0 + j * 4096, bs_base + slot * SLAB + j * 4096);
+        if (!(FAR_WINO_EXP & 4)) {
+            if (p.prio == 4) glds16_nt(src0 + j * 4096, bs_base + slot * SLAB + j * 4096);
+            else glds16(src0 + j * 4096, bs_base + slot * SLAB + j * 4096);
+        }
     };
 
     // ---- raw patch of a k-step (16 channels of the 18 x 18 pixels) in a 3-slot ring: 16-byte slot S = 4 index' + quad',
@@ -236,7 +246,10 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p, long t, const int c
             const char* f = reinterpret_cast<const char*>(p.x) + ((rpiece[j] * 1024 + (kk & 3) * 32768 + (threadIdx.x & 63) * 16) & 131071);
             glds16(f, rs_base + slot * RAWB + rpiece[j] * 1024);
         } else
-        if (!(FAR_WINO_EXP & 8)) glds16(s, rs_base + slot * RAWB + rpiece[j] * 1024);
+        if (!(FAR_WINO_EXP & 8)) {
+            if (p.prio == 3) glds16_nt(s, rs_base + slot * RAWB + rpiece[j] * 1024);
+            else glds16(s, rs_base + slot * RAWB + rpiece[j] * 1024);
+        }
     };
 
     // ---- transform addressing: lane (tile m = l31: row tyl = m >> 3 of the block's four, column tx = m & 7; k-group h)
