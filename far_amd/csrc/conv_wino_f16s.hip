@@ -86,7 +86,7 @@ struct WinoArgs {
     long ntb;                    // tile blocks = N * tilesX * tilesY
     int H, W, Cin, Cout, nk, ncb, tilesX, tilesY, act;
     int half_ok;                 // the last channel block holds at most 32 channels: its workgroups run the HALF body
-    int prio;                    // experiment (far_set_tuning 15): 1 = the multiplying group raises its issue priority, 2 = the transforming group does
+    int prio;                    // far_set_tuning 15: 0 (default) = the multiplying group raises its issue priority, 1 = nobody does (round 4), 2 = the transforming group, 3 / 4 = no priority + non-temporal requests
     float slope, out_mul;
 };
 
@@ -340,7 +340,7 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p, long t, const int c
             for (int i = 0; i < NP; ++i) piece(i);
             return;
         }
-        if (p.prio == 1) __builtin_amdgcn_s_setprio(2);
+        if (p.prio == 0) __builtin_amdgcn_s_setprio(2);       // the multiplying group wins the issue arbitration against its transforming partner (round 5: -2 ... -3 %)
         const unsigned char* B = Bs + slot * SLAB + b_lane;
         f16x8 bh[2][NCT], bl[2][NCT];
         auto read_b = [&](int nu) {
@@ -370,7 +370,7 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p, long t, const int c
                 if (any) __builtin_amdgcn_sched_barrier(0);        // the request stays behind this MFMA
             }
         }
-        if (p.prio == 1) __builtin_amdgcn_s_setprio(0);
+        if (p.prio == 0) __builtin_amdgcn_s_setprio(0);
     };
 
     // ---- prologue: slabs 0, 1, raw patches 0, 1; the xi = 0, 1 waves transform k-step 0
