@@ -76,6 +76,12 @@ def parse():
     return ap.parse_args()
 
 
+def _build_id():
+    """far_build_id() of the loaded library = sha256/16 of far_amd/csrc + flags it was built from (checked against the sources at load)."""
+    from far_amd import _lib
+    return _lib.load().far_build_id().decode()
+
+
 def event_time_ms(fn, iters=5, warm=2):
     """Average duration of fn() measured with HIP events on the stream the kernels are launched on
     (torch's current stream, which is the stream handed to every far_* call)."""
@@ -915,6 +921,7 @@ def main():
                        'parallelism': f'dp{world} (independent pairs, no data-path collective)'},
             'roofline': roof,
             'kernels': {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in kr.items()},
+            'build_id': _build_id(),
             'process_group': {'backend': dist.get_backend(), 'world_size': dist.get_world_size()} if dist is not None else None,
         }
         if world == 1 and a.precision == 'fp32' and not a.no_other_modes:

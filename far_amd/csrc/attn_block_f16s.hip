@@ -147,9 +147,6 @@ __global__ __launch_bounds__(64 * NW, 2) void k_attn128(const float* __restrict_
                                                         const unsigned char* __restrict__ wimg, long nwin, int L, int S, Scales sc,
                                                         float attn_eps, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         float ln_eps, float* __restrict__ out, int* __restrict__ overflow) {
-#ifdef FAR_STAGGER_F16S
-    stagger_priority_by_wave_slot(1);      // experiment build (round 5): static issue-priority stagger by hardware wave slot
-#endif
     constexpr int NPIECE = 16 / NW;                            // 1 KiB pieces of a slab per wave
     constexpr int AHEAD = NR - 1;                              // slab p + AHEAD is requested in phase p
     constexpr int XB = CNT ? 2 : 1;                            // input-chunk buffers per wave

@@ -1152,9 +1152,6 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p) {
 
 template <int KS, int MW, int NW, int NTW, bool SPLIT, int ST, int UP = 0, bool N7 = false, int EPI = 0>
 __global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const ConvArgs p) {
-#ifdef FAR_STAGGER_F16S
-    stagger_priority_by_wave_slot(1);      // experiment build (round 5): static issue-priority stagger by hardware wave slot
-#endif
     if constexpr (N7) {                       // two copies of the body, one per wave column: which tile a wave skips is static
         if (((threadIdx.x >> 6) % NW) == 1) conv_body<KS, MW, NW, NTW, SPLIT, ST, UP, N7, 1>(p);
         else conv_body<KS, MW, NW, NTW, SPLIT, ST, UP, N7, 0>(p);

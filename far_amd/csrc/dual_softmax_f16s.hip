@@ -175,9 +175,6 @@ __global__ __launch_bounds__(256, 2) void k1_rowstats(const _Float16* __restrict
                                                       float2* __restrict__ stat, float* __restrict__ dmax, float* __restrict__ dinv,
                                                       float* __restrict__ dthr, const float* __restrict__ othr,
                                                       int* __restrict__ cand_count, uint2* __restrict__ cand) {
-#ifdef FAR_STAGGER_F16S
-    stagger_priority_by_wave_slot(1);      // experiment build (round 5): static issue-priority stagger by hardware wave slot
-#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     int z, Ib;
@@ -354,9 +351,6 @@ __global__ __launch_bounds__(256, 2) void k1_match(const _Float16* __restrict__ 
                                                    const float* __restrict__ cinv, float* __restrict__ conf,
                                                    float* __restrict__ rowbest_v, int* __restrict__ rowbest_j,
                                                    unsigned* __restrict__ colbest, float thr, const uint8_t* __restrict__ tmask) {
-#ifdef FAR_STAGGER_F16S
-    stagger_priority_by_wave_slot(1);      // experiment build (round 5): static issue-priority stagger by hardware wave slot
-#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     const int nI = Lp / 128;

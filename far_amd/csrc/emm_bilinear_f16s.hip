@@ -230,9 +230,6 @@ __device__ __forceinline__ void rowstat_update(f32x16 (&acc)[2], float c1, int j
 __global__ __launch_bounds__(256, 2) void k_rowstats(const _Float16* __restrict__ ah, const _Float16* __restrict__ al,
                                                      const _Float16* __restrict__ bh, const _Float16* __restrict__ bl,
                                                      int Z, int N, int Np, float c1, float2* __restrict__ stat) {
-#ifdef FAR_STAGGER_F16S
-    stagger_priority_by_wave_slot(1);      // experiment build (round 5): static issue-priority stagger by hardware wave slot
-#endif
     __shared__ __attribute__((aligned(16))) unsigned char lds_all[2 * 2 * CT_PLANE];      // two stages
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     int z, Ib;
@@ -359,9 +356,6 @@ __global__ __launch_bounds__(256, 2) void k_pv(const _Float16* __restrict__ qh, 
                                                const _Float16* __restrict__ vh, const _Float16* __restrict__ vl,
                                                const int* __restrict__ cref, int Z, int N, int Np, float c1,
                                                float2* __restrict__ rowstat, float* __restrict__ T) {
-#ifdef FAR_STAGGER_F16S
-    stagger_priority_by_wave_slot(1);      // experiment build (round 5): static issue-priority stagger by hardware wave slot
-#endif
     // two stages of { key tile (hi, lo), v~^T tile (hi, lo) with the tile's column references in two of its padding rows }:
     // tile jt + 1 travels while tile jt is computed (asm LDS-DMA, one barrier per tile)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];

@@ -74,9 +74,6 @@ __global__ __launch_bounds__(256, 2) void k_mlp128(const float* __restrict__ x, 
                                                    const unsigned char* __restrict__ wimg, long R, float hscale, float oscale,
                                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                    float* __restrict__ out, int* __restrict__ overflow) {
-#ifdef FAR_STAGGER_F16S
-    stagger_priority_by_wave_slot(1);      // experiment build (round 5): static issue-priority stagger by hardware wave slot
-#endif
     __shared__ __attribute__((aligned(16))) unsigned char ring[RING * SLAB];
     __shared__ __attribute__((aligned(16))) unsigned char xs[WAVES * 4096];          // per wave: its 32 rows x 128 B of the current chunk
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
