@@ -158,7 +158,9 @@ __device__ unsigned long long g_wino_stamps2[4096 * 8 * 16];
 // HALF: the last channel block of a layer whose channel count leaves it at most 32 channels (196 / 208 outputs: 4 or 16 of 64) --
 // only the first 32-channel tile is multiplied (12 MFMAs per interval), and the waves whose weight pieces belong to the second
 // tile (wave & 2: piece 4 j + wave = [xi & 1][nu][co tile][plane]) request none.
-template <bool Q, bool MIX, bool HALF>
+// R8 (round-5 experiment, far_set_tuning 14 = 2): the raw-patch requests are spread over all eight waves (three pieces each, the
+// transforming group issues its three behind its transform) instead of six pieces on each multiplying wave of the xi = 0, 1 group.
+template <bool Q, bool MIX, bool HALF, bool R8 = false>
 __device__ __forceinline__ void wino_body(const WinoArgs& p, long t, const int cb) {
     constexpr int NCT = HALF ? 1 : 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -213,16 +215,16 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p, long t, const int c
     // the SOURCE address (the LDS image of a request is lane-linear).  Piece pc = 4 j + wsel, j < 6, of the xi = 0, 1 waves; a
     // wave's slots past the 21 pieces repeat its first piece (the same request twice: harmless, and every wave issues exactly six,
     // which the counted waits rely on).
-    constexpr int NRP = 6;
+    constexpr int NRP = R8 ? 3 : 6;
     const char* rsrc[NRP];
     int rinc[NRP], rpiece[NRP];
     unsigned rtailm = 0;                            // bit j: the lane's quad lies beyond Cin in the last k-step
     const int rem_ch = p.Cin - 16 * (nk - 1);       // channels of the last k-step (1..16)
-    if (!Q) {
+    if (!Q || R8) {
 #pragma unroll
         for (int j = 0; j < NRP; ++j) {
-            int pc = 4 * j + wsel;
-            if (pc >= RAW_PIECES) pc = wsel;
+            int pc = R8 ? 8 * j + wave : 4 * j + wsel;
+            if (pc >= RAW_PIECES) pc = R8 ? wave : wsel;
             rpiece[j] = pc;
             const int S = pc * 64 + lane;
             const int idx = S >> 2, sp = S & 3;
@@ -238,7 +240,7 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p, long t, const int c
         }
     }
     auto raw_piece = [&](int rk, int slot, int j) {                           // piece j (0..5) of raw patch rk
-        if (Q) return;
+        if (Q && !R8) return;
         const int kk = rk < nk ? rk : nk - 1;       // past the end: the last patch again, into a slot nobody reads
         const bool tail = kk == nk - 1 && ((rtailm >> j) & 1u);
         const char* s = tail ? reinterpret_cast<const char*>(p.zeros) : rsrc[j] + (long)kk * rinc[j];
@@ -340,6 +342,7 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p, long t, const int c
             for (int i = 0; i < NP; ++i) piece(i);
             return;
         }
+        if (p.prio == 5) __builtin_amdgcn_s_setprio(3);
         if (p.prio == 0) __builtin_amdgcn_s_setprio(2);       // the multiplying group wins the issue arbitration against its transforming partner (round 5: -2 ... -3 %)
         const unsigned char* B = Bs + slot * SLAB + b_lane;
         f16x8 bh[2][NCT], bl[2][NCT];
@@ -370,7 +373,7 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p, long t, const int c
                 if (any) __builtin_amdgcn_sched_barrier(0);        // the request stays behind this MFMA
             }
         }
-        if (p.prio == 0) __builtin_amdgcn_s_setprio(0);
+        if (p.prio == 0 || p.prio == 5) __builtin_amdgcn_s_setprio(0);
     };
 
     // ---- prologue: slabs 0, 1, raw patches 0, 1; the xi = 0, 1 waves transform k-step 0
@@ -405,12 +408,16 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p, long t, const int c
         const int slot_n = 3 - slot_e - slot_o;     // the third slot: slab 2k+2
         if (!Q) {
             const unsigned char* sn = slab_src(2 * k + 2);
-            mma(slot_e, std::integral_constant<int, 14>{}, [&](int i) {
+            mma(slot_e, std::integral_constant<int, 8 + NRP>{}, [&](int i) {
                 if (i < 8) b_piece(sn, slot_n, i);
                 else raw_piece(k + 2, rs2, i - 8);
             });
         } else {
             transform(rs0);
+            if (R8) {
+#pragma unroll
+                for (int j = 0; j < NRP; ++j) raw_piece(k + 2, rs2, j);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);          // the interval's work stays on this side of the barrier
         if (k < 14) FAR_WINO_STAMP(2 + 4 * k);
@@ -420,6 +427,10 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p, long t, const int c
         FAR_WINO_T2(k, 2);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #else
+        if (R8) {                                   // every wave: all but this interval's requests (Q: 3 raw; else 8 weight + 3 raw, or 3 when it skips the weights)
+            if (Q || wskip) asm volatile("s_waitcnt vmcnt(3)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(11)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        } else
         if (Q || (FAR_WINO_EXP & 32)) asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else if (wskip) asm volatile("s_waitcnt vmcnt(6)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // this interval's six raw requests only
         else asm volatile("s_waitcnt vmcnt(14)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -441,6 +452,9 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p, long t, const int c
         FAR_WINO_T2(k, 5);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #else
+        if (R8 && !Q) asm volatile("s_waitcnt vmcnt(3)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // its slab of the interval before has landed; its three raw pieces may fly
+        else if (R8) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else
         if (FAR_WINO_EXP & 32) asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else if (!Q) asm volatile("s_waitcnt vmcnt(6)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -560,7 +574,7 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p, long t, const int c
 // WALK = true (round 5; far_set_tuning(14, 1)): one workgroup per tile block walks the channel blocks in
 // sequence, so that only the first pass misses; the raw patches of the later passes are L2 hits.  The transform is NOT shared (V
 // of all k-steps of a tile block is 512 KiB, LDS holds 160): every pass requests and transforms its patches again.
-template <bool MIX, bool WALK>
+template <bool MIX, bool WALK, bool R8 = false>
 __global__ __launch_bounds__(512, 2) void k_wino(const WinoArgs p) {
     const long b = blockIdx.x;
     long seq = b, t0 = 0;
@@ -571,11 +585,11 @@ __global__ __launch_bounds__(512, 2) void k_wino(const WinoArgs p) {
         if (WALK && cb > cb0) asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the epilogue's LDS image is read out, its stores are out of the counted queue
         const bool half = p.half_ok && cb == p.ncb - 1;            // workgroup-uniform: the last block may hold at most 32 channels
         if (half) {
-            if (threadIdx.x >= 256) wino_body<true, MIX, true>(p, t, cb);
-            else wino_body<false, MIX, true>(p, t, cb);
+            if (threadIdx.x >= 256) wino_body<true, MIX, true, R8>(p, t, cb);
+            else wino_body<false, MIX, true, R8>(p, t, cb);
         } else {
-            if (threadIdx.x >= 256) wino_body<true, MIX, false>(p, t, cb);
-            else wino_body<false, MIX, false>(p, t, cb);
+            if (threadIdx.x >= 256) wino_body<true, MIX, false, R8>(p, t, cb);
+            else wino_body<false, MIX, false, R8>(p, t, cb);
         }
     }
 }
@@ -697,16 +711,19 @@ int far_conv3x3_wino_f32(const far_conv_desc* desc, hipStream_t stream) {
     a.act = d.act; a.slope = d.slope; a.out_mul = 16.0f;
     a.half_ok = (d.Cout - 64 * (a.ncb - 1) <= 32 && far_get_tuning(9) == 0) ? 1 : 0;      // tuning 9: 1 = every block on the full body
     a.prio = far_get_tuning(15);                                // tuning 15: issue-priority experiment (speed only)
-    const bool walk = far_get_tuning(14) != 0;                  // tuning 14: 1 = one workgroup per tile block walks the channel blocks
+    const bool r8 = far_get_tuning(14) == 2;                    // tuning 14 = 2: raw-patch requests spread over all eight waves
+    const bool walk = far_get_tuning(14) == 1;                  // tuning 14: 1 = one workgroup per tile block walks the channel blocks
     const long nblk = walk ? a.ntb : a.ntb * a.ncb;
     if (nblk > 0x7fffffffL || (long)d.H * d.W * d.Cout > 0x7fffffffL) return FAR_EINVAL;
     const bool mix = far_get_tuning(8) == 0;
     bool cfg_failed = false;
     FAR_ONCE_PER_DEVICE(cfg_failed = hipFuncSetAttribute((const void*)k_wino<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess ||
                                      hipFuncSetAttribute((const void*)k_wino<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess ||
-                                     hipFuncSetAttribute((const void*)k_wino<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess);
+                                     hipFuncSetAttribute((const void*)k_wino<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess ||
+                                     hipFuncSetAttribute((const void*)k_wino<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess);
     if (cfg_failed) return far_check_launch();
-    if (walk && mix) hipLaunchKernelGGL((k_wino<true, true>), dim3((unsigned)nblk), dim3(512), SMEM, stream, a);
+    if (r8 && mix) hipLaunchKernelGGL((k_wino<true, false, true>), dim3((unsigned)nblk), dim3(512), SMEM, stream, a);
+    else if (walk && mix) hipLaunchKernelGGL((k_wino<true, true>), dim3((unsigned)nblk), dim3(512), SMEM, stream, a);
     else if (mix) hipLaunchKernelGGL((k_wino<true, false>), dim3((unsigned)nblk), dim3(512), SMEM, stream, a);
     else hipLaunchKernelGGL((k_wino<false, false>), dim3((unsigned)nblk), dim3(512), SMEM, stream, a);
     return far_check_launch();
