@@ -41,6 +41,9 @@
 // No input scaling: |a| <= 16376 survives the split (|V| <= 4 |a|); beyond it the accumulators turn non-finite and the launch
 // raises the activation-overflow flag like K9 (the host then takes K9 with a lower activation exponent).
 //
+// Round 5 (profiles/r05_k17_ab.txt, docs/rounds/r05.md): three variants were built on this kernel and measured bit-identical but no
+// faster -- the channel blocks of a tile block walked inside one workgroup (+1.5 %), non-temporal requests (+3 %), the raw-patch
+// requests spread over all eight waves (+0.4 %) -- and removed again; the issue priority of the multiplying group stayed (-2 ... -3 %).
 // STATUS (round 4): dispatched by ops.conv_nhwc for the inference step's stride-1 3x3 layers (ops.USE_WINO): same-box step
 // 99.8 -> 94.5 ms.  Against K9 at 64 images (profiles/r04_k17_winograd.txt): 128 -> 128 @240x320 3.04 vs 3.39 ms (1.11x),
 // 196 -> 196 @240x320 8.83 vs 9.45 (1.07x), 196 -> 128 1.16x, 256 -> 256 @120x160 1.19x, 256 -> 256 @60x80 1.26x -- short of the
@@ -86,7 +89,7 @@ struct WinoArgs {
     long ntb;                    // tile blocks = N * tilesX * tilesY
     int H, W, Cin, Cout, nk, ncb, tilesX, tilesY, act;
     int half_ok;                 // the last channel block holds at most 32 channels: its workgroups run the HALF body
-    int prio;                    // far_set_tuning 15: 0 (default) = the multiplying group raises its issue priority, 1 = nobody does (round 4), 2 = the transforming group, 3 / 4 = no priority + non-temporal requests
+    int prio;                    // 1 (default; far_set_tuning(15, 1) clears it): the multiplying wave group raises its issue priority
     float slope, out_mul;
 };
 
@@ -95,13 +98,6 @@ struct WinoArgs {
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst_uniform) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
-}
-
-// the same request with the non-temporal hint (experiment, far_set_tuning 15 = 3 / 4: raw patches / weight slabs)
-__device__ __forceinline__ void glds16_nt(const void* gsrc, unsigned lds_dst_uniform) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
 }
 
@@ -158,10 +154,8 @@ __device__ unsigned long long g_wino_stamps2[4096 * 8 * 16];
 // HALF: the last channel block of a layer whose channel count leaves it at most 32 channels (196 / 208 outputs: 4 or 16 of 64) --
 // only the first 32-channel tile is multiplied (12 MFMAs per interval), and the waves whose weight pieces belong to the second
 // tile (wave & 2: piece 4 j + wave = [xi & 1][nu][co tile][plane]) request none.
-// R8 (round-5 experiment, far_set_tuning 14 = 2): the raw-patch requests are spread over all eight waves (three pieces each, the
-// transforming group issues its three behind its transform) instead of six pieces on each multiplying wave of the xi = 0, 1 group.
-template <bool Q, bool MIX, bool HALF, bool R8 = false>
-__device__ __forceinline__ void wino_body(const WinoArgs& p, long t, const int cb) {
+template <bool Q, bool MIX, bool HALF>
+__device__ __forceinline__ void wino_body(const WinoArgs& p) {
     constexpr int NCT = HALF ? 1 : 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const Bs = smem;
@@ -171,6 +165,17 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p, long t, const int c
     const int xi = wave >> 1, tb = wave & 1, xil = xi & 1;
     const int l31 = lane & 31, h = lane >> 5;
 
+    // ---- tile block / channel block of this workgroup: each XCD (block b -> XCD b % 8, speed only) gets a contiguous range of
+    // tile blocks and runs the channel blocks of a tile block back to back (they re-read the same pixels from its L2)
+    long t;
+    int cb;
+    {
+        const long b = blockIdx.x;
+        long seq = b, t0 = 0;
+        if ((p.ntb & 7) == 0) { seq = b >> 3; t0 = (b & 7) * (p.ntb >> 3); }
+        t = t0 + seq / p.ncb;
+        cb = (int)(seq % p.ncb);
+    }
     const int bx = (int)(t % p.tilesX);
     t /= p.tilesX;
     const int by = (int)(t % p.tilesY);
@@ -204,10 +209,7 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p, long t, const int c
     const bool wskip = HALF && (wsel & 2);            // wave-uniform
     auto b_piece = [&](const unsigned char* src0, int slot, int j) {          // piece j (0..7) of this wave
         if (wskip) return;
-        if (!(FAR_WINO_EXP & 4)) {
-            if (p.prio == 4) glds16_nt(src0 + j * 4096, bs_base + slot * SLAB + j * 4096);
-            else glds16(src0 + j * 4096, bs_base + slot * SLAB + j * 4096);
-        }
+        if (!(FAR_WINO_EXP & 4)) glds16(src0 + j * 4096, bs_base + slot * SLAB + j * 4096);
     };
 
     // ---- raw patch of a k-step (16 channels of the 18 x 18 pixels) in a 3-slot ring: 16-byte slot S = 4 index' + quad',
@@ -215,16 +217,16 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p, long t, const int c
     // the SOURCE address (the LDS image of a request is lane-linear).  Piece pc = 4 j + wsel, j < 6, of the xi = 0, 1 waves; a
     // wave's slots past the 21 pieces repeat its first piece (the same request twice: harmless, and every wave issues exactly six,
     // which the counted waits rely on).
-    constexpr int NRP = R8 ? 3 : 6;
+    constexpr int NRP = 6;
     const char* rsrc[NRP];
     int rinc[NRP], rpiece[NRP];
     unsigned rtailm = 0;                            // bit j: the lane's quad lies beyond Cin in the last k-step
     const int rem_ch = p.Cin - 16 * (nk - 1);       // channels of the last k-step (1..16)
-    if (!Q || R8) {
+    if (!Q) {
 #pragma unroll
         for (int j = 0; j < NRP; ++j) {
-            int pc = R8 ? 8 * j + wave : 4 * j + wsel;
-            if (pc >= RAW_PIECES) pc = R8 ? wave : wsel;
+            int pc = 4 * j + wsel;
+            if (pc >= RAW_PIECES) pc = wsel;
             rpiece[j] = pc;
             const int S = pc * 64 + lane;
             const int idx = S >> 2, sp = S & 3;
@@ -240,7 +242,7 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p, long t, const int c
         }
     }
     auto raw_piece = [&](int rk, int slot, int j) {                           // piece j (0..5) of raw patch rk
-        if (Q && !R8) return;
+        if (Q) return;
         const int kk = rk < nk ? rk : nk - 1;       // past the end: the last patch again, into a slot nobody reads
         const bool tail = kk == nk - 1 && ((rtailm >> j) & 1u);
         const char* s = tail ? reinterpret_cast<const char*>(p.zeros) : rsrc[j] + (long)kk * rinc[j];
@@ -248,10 +250,7 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p, long t, const int c
             const char* f = reinterpret_cast<const char*>(p.x) + ((rpiece[j] * 1024 + (kk & 3) * 32768 + (threadIdx.x & 63) * 16) & 131071);
             glds16(f, rs_base + slot * RAWB + rpiece[j] * 1024);
         } else
-        if (!(FAR_WINO_EXP & 8)) {
-            if (p.prio == 3) glds16_nt(s, rs_base + slot * RAWB + rpiece[j] * 1024);
-            else glds16(s, rs_base + slot * RAWB + rpiece[j] * 1024);
-        }
+        if (!(FAR_WINO_EXP & 8)) glds16(s, rs_base + slot * RAWB + rpiece[j] * 1024);
     };
 
     // ---- transform addressing: lane (tile m = l31: row tyl = m >> 3 of the block's four, column tx = m & 7; k-group h)
@@ -282,7 +281,6 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p, long t, const int c
             }
             return;
         }
-        if (p.prio == 2) __builtin_amdgcn_s_setprio(2);
         const unsigned char* R0 = Rs + slot * RAWB;
         // Scalar fp32 instructions from inline asm on purpose: next to a wave that issues MFMAs, v_pk_fma_f32 waits for a gap in the
         // matrix pipe (tools/ubench/valu_cost.hip: 370 cycles per instruction against 5 alone) and the packed adds cost more than
@@ -322,7 +320,6 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p, long t, const int c
                 Ah[nu][pr] = __builtin_bit_cast(unsigned, h); Al[nu][pr] = __builtin_bit_cast(unsigned, l);
             }
         }
-        if (p.prio == 2) __builtin_amdgcn_s_setprio(0);
     };
 
     f32x16 acc[4][NCT];
@@ -342,8 +339,10 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p, long t, const int c
             for (int i = 0; i < NP; ++i) piece(i);
             return;
         }
-        if (p.prio == 5) __builtin_amdgcn_s_setprio(3);
-        if (p.prio == 0) __builtin_amdgcn_s_setprio(2);       // the multiplying group wins the issue arbitration against its transforming partner (round 5: -2 ... -3 %)
+        // Round 5: the multiplying group runs its interval at raised issue priority, so that on every SIMD the wave that feeds the
+        // matrix pipe (and issues the interval's requests) wins the arbitration against its transforming partner: -2 ... -3.4 % on every
+        // shape (profiles/r05_k17_ab.txt; the transforming group at raised priority: +3 %; priority 3 instead of 2: no better)
+        if (p.prio) __builtin_amdgcn_s_setprio(2);
         const unsigned char* B = Bs + slot * SLAB + b_lane;
         f16x8 bh[2][NCT], bl[2][NCT];
         auto read_b = [&](int nu) {
@@ -373,7 +372,7 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p, long t, const int c
                 if (any) __builtin_amdgcn_sched_barrier(0);        // the request stays behind this MFMA
             }
         }
-        if (p.prio == 0 || p.prio == 5) __builtin_amdgcn_s_setprio(0);
+        if (p.prio) __builtin_amdgcn_s_setprio(0);
     };
 
     // ---- prologue: slabs 0, 1, raw patches 0, 1; the xi = 0, 1 waves transform k-step 0
@@ -408,16 +407,12 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p, long t, const int c
         const int slot_n = 3 - slot_e - slot_o;     // the third slot: slab 2k+2
         if (!Q) {
             const unsigned char* sn = slab_src(2 * k + 2);
-            mma(slot_e, std::integral_constant<int, 8 + NRP>{}, [&](int i) {
+            mma(slot_e, std::integral_constant<int, 14>{}, [&](int i) {
                 if (i < 8) b_piece(sn, slot_n, i);
                 else raw_piece(k + 2, rs2, i - 8);
             });
         } else {
             transform(rs0);
-            if (R8) {
-#pragma unroll
-                for (int j = 0; j < NRP; ++j) raw_piece(k + 2, rs2, j);
-            }
         }
         __builtin_amdgcn_sched_barrier(0);          // the interval's work stays on this side of the barrier
         if (k < 14) FAR_WINO_STAMP(2 + 4 * k);
@@ -427,10 +422,6 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p, long t, const int c
         FAR_WINO_T2(k, 2);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #else
-        if (R8) {                                   // every wave: all but this interval's requests (Q: 3 raw; else 8 weight + 3 raw, or 3 when it skips the weights)
-            if (Q || wskip) asm volatile("s_waitcnt vmcnt(3)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(11)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        } else
         if (Q || (FAR_WINO_EXP & 32)) asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else if (wskip) asm volatile("s_waitcnt vmcnt(6)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // this interval's six raw requests only
         else asm volatile("s_waitcnt vmcnt(14)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -452,9 +443,6 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p, long t, const int c
         FAR_WINO_T2(k, 5);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #else
-        if (R8 && !Q) asm volatile("s_waitcnt vmcnt(3)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // its slab of the interval before has landed; its three raw pieces may fly
-        else if (R8) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else
         if (FAR_WINO_EXP & 32) asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else if (!Q) asm volatile("s_waitcnt vmcnt(6)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -568,29 +556,18 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p, long t, const int c
 #endif
 }
 
-// WALK = false: one workgroup per (tile block, channel block); each XCD (block b -> XCD b % 8, speed only) gets a contiguous range
-// of tile blocks and runs the channel blocks of a tile block back to back (siblings re-read the same pixels from its L2 -- but at
-// the same TIME, on neighbouring CUs: a sibling's request finds the line in flight and waits for the same HBM miss).
-// WALK = true (round 5; far_set_tuning(14, 1)): one workgroup per tile block walks the channel blocks in
-// sequence, so that only the first pass misses; the raw patches of the later passes are L2 hits.  The transform is NOT shared (V
-// of all k-steps of a tile block is 512 KiB, LDS holds 160): every pass requests and transforms its patches again.
-template <bool MIX, bool WALK, bool R8 = false>
+template <bool MIX>
 __global__ __launch_bounds__(512, 2) void k_wino(const WinoArgs p) {
-    const long b = blockIdx.x;
-    long seq = b, t0 = 0;
-    if ((p.ntb & 7) == 0) { seq = b >> 3; t0 = (b & 7) * (p.ntb >> 3); }
-    const long t = WALK ? t0 + seq : t0 + seq / p.ncb;
-    const int cb0 = WALK ? 0 : (int)(seq % p.ncb), cb1 = WALK ? p.ncb : cb0 + 1;
-    for (int cb = cb0; cb < cb1; ++cb) {
-        if (WALK && cb > cb0) asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the epilogue's LDS image is read out, its stores are out of the counted queue
-        const bool half = p.half_ok && cb == p.ncb - 1;            // workgroup-uniform: the last block may hold at most 32 channels
-        if (half) {
-            if (threadIdx.x >= 256) wino_body<true, MIX, true, R8>(p, t, cb);
-            else wino_body<false, MIX, true, R8>(p, t, cb);
-        } else {
-            if (threadIdx.x >= 256) wino_body<true, MIX, false, R8>(p, t, cb);
-            else wino_body<false, MIX, false, R8>(p, t, cb);
-        }
+    // the workgroup's channel block (as wino_body maps it): the last one may hold at most 32 channels
+    const long seq = (p.ntb & 7) == 0 ? (long)blockIdx.x >> 3 : (long)blockIdx.x;
+    const int cb = (int)(seq % p.ncb);
+    const bool half = p.half_ok && cb == p.ncb - 1;            // workgroup-uniform
+    if (half) {
+        if (threadIdx.x >= 256) wino_body<true, MIX, true>(p);
+        else wino_body<false, MIX, true>(p);
+    } else {
+        if (threadIdx.x >= 256) wino_body<true, MIX, false>(p);
+        else wino_body<false, MIX, false>(p);
     }
 }
 
@@ -710,22 +687,16 @@ int far_conv3x3_wino_f32(const far_conv_desc* desc, hipStream_t stream) {
     a.ntb = d.N * a.tilesX * a.tilesY;
     a.act = d.act; a.slope = d.slope; a.out_mul = 16.0f;
     a.half_ok = (d.Cout - 64 * (a.ncb - 1) <= 32 && far_get_tuning(9) == 0) ? 1 : 0;      // tuning 9: 1 = every block on the full body
-    a.prio = far_get_tuning(15);                                // tuning 15: issue-priority experiment (speed only)
-    const bool r8 = far_get_tuning(14) == 2;                    // tuning 14 = 2: raw-patch requests spread over all eight waves
-    const bool walk = far_get_tuning(14) == 1;                  // tuning 14: 1 = one workgroup per tile block walks the channel blocks
-    const long nblk = walk ? a.ntb : a.ntb * a.ncb;
+    a.prio = far_get_tuning(15) == 0 ? 1 : 0;                   // tuning 15 = 1: no priority change (the round-4 kernel)
+    const long nblk = a.ntb * a.ncb;
     if (nblk > 0x7fffffffL || (long)d.H * d.W * d.Cout > 0x7fffffffL) return FAR_EINVAL;
     const bool mix = far_get_tuning(8) == 0;
     bool cfg_failed = false;
-    FAR_ONCE_PER_DEVICE(cfg_failed = hipFuncSetAttribute((const void*)k_wino<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess ||
-                                     hipFuncSetAttribute((const void*)k_wino<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess ||
-                                     hipFuncSetAttribute((const void*)k_wino<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess ||
-                                     hipFuncSetAttribute((const void*)k_wino<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess);
+    FAR_ONCE_PER_DEVICE(cfg_failed = hipFuncSetAttribute((const void*)k_wino<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess ||
+                                     hipFuncSetAttribute((const void*)k_wino<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess);
     if (cfg_failed) return far_check_launch();
-    if (r8 && mix) hipLaunchKernelGGL((k_wino<true, false, true>), dim3((unsigned)nblk), dim3(512), SMEM, stream, a);
-    else if (walk && mix) hipLaunchKernelGGL((k_wino<true, true>), dim3((unsigned)nblk), dim3(512), SMEM, stream, a);
-    else if (mix) hipLaunchKernelGGL((k_wino<true, false>), dim3((unsigned)nblk), dim3(512), SMEM, stream, a);
-    else hipLaunchKernelGGL((k_wino<false, false>), dim3((unsigned)nblk), dim3(512), SMEM, stream, a);
+    if (mix) hipLaunchKernelGGL(k_wino<true>, dim3((unsigned)nblk), dim3(512), SMEM, stream, a);
+    else hipLaunchKernelGGL(k_wino<false>, dim3((unsigned)nblk), dim3(512), SMEM, stream, a);
     return far_check_launch();
 }
 

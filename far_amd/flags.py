@@ -62,8 +62,7 @@ TUNING = [
     Tuning(9, 0, (1,), 'bitwise', 'K17 runs a short last channel block on the full body'),
     Tuning(10, 0, (1,), 'bitwise', "K1's match pass without the tile prescreen"),
     Tuning(12, 0, (1,), 'parity', "K10's inference form on the exact-f32 matrix instruction instead of split fp16"),
-    Tuning(14, 0, (1, 2), 'bitwise', 'K17 experiments: 1 = one workgroup per tile block walks the channel blocks in sequence; 2 = raw-patch requests spread over all eight waves'),
-    Tuning(15, 0, (1, 2, 3, 4, 5), 'bitwise', 'K17: 0 = the multiplying wave group raises its issue priority (s_setprio; default since round 5), 1 = nobody does (round 4), 2 = the transforming group, 3 / 4 = no priority + non-temporal LDS-DMA for the raw patches / weight slabs, 5 = priority 3 instead of 2'),
+    Tuning(15, 0, (1,), 'bitwise', 'K17: 1 = the multiplying wave group does NOT raise its issue priority (the round-4 kernel)'),
     Tuning(13, 0, (1,), 'bitwise', "K9's FPN-merge epilogue in its generic form everywhere"),
 ]
 
