@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Round-5 K17 A/Bs: the shipped kernel against far_set_tuning variants on the bench shapes (64 images), same
 process, interleaved rounds, minimum of three; outputs compared bit for bit.  Usage: python tools/wino_r05_ab.py KEY=VALUE [KEY=VALUE ...]
-(e.g. 14=1: one workgroup per tile block walks the channel blocks).  --padded: 208-channel storage of the 196-channel layers."""
+(e.g. 15=1: without the raised issue priority of the multiplying wave group; the round's other variants -- 14=1 channel-block walk, 14=2
+eight-wave raw requests, 15=3/4 non-temporal requests -- live in commits 7553697 / 6a00f47 / 041fb55, results in profiles/r05_k17_ab.txt)."""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
