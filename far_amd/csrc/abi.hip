@@ -18,7 +18,7 @@ extern "C" int far_last_hip_error(void) { return g_last_hip_error; }
 // wave-slot priority staggering (1 = k_stats, 2 = k_match, 4 = k_emm_pv); 1: K1 f32 tile variant; 2, 3: conf_matrix writer
 // variants; 4: 1 = K9 without the seven-tile mode / K5 windows on the generic path; 5: K5 apply tiles per unit; 6: K5 tokens per
 // KV chunk; 7: 1 = K9 Linear launches always on full-height tiles; 8: 1 = K17 (Winograd) splits its operands with the five-instruction
-// split2 instead of v_fma_mix (same values); 9: 1 = K17 runs a short last channel block on the full body; 10: 1 = K1's match pass without the tile prescreen; 12: 1 = K10's inference form on the exact-f32 matrix instruction.  13: 1 = K9's FPN merge epilogue in its generic form everywhere; 14: 1 = K17 runs the k-steps of channel block cb in an order rotated by 2 cb; 15: 1 = K17 without the raised issue priority of its multiplying wave group.
+// split2 instead of v_fma_mix (same values); 9: 1 = K17 runs a short last channel block on the full body; 10: 1 = K1's match pass without the tile prescreen; 12: 1 = K10's inference form on the exact-f32 matrix instruction.  13: 1 = K9's FPN merge epilogue in its generic form everywhere; 15: 1 = K17 without the raised issue priority of its multiplying wave group.
 // Process-global state of the library: these knobs (atomics, so that a tuning call from one thread is well-defined against
 // launches on another) and the per-device one-time kernel attribute setup; the side streams below are per host thread.
 static std::atomic<int> g_tuning[16] = {{3}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}};

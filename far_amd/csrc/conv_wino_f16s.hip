@@ -41,9 +41,10 @@
 // No input scaling: |a| <= 16376 survives the split (|V| <= 4 |a|); beyond it the accumulators turn non-finite and the launch
 // raises the activation-overflow flag like K9 (the host then takes K9 with a lower activation exponent).
 //
-// Round 5 (profiles/r05_k17_ab.txt, docs/rounds/r05.md): three variants were built on this kernel and measured bit-identical but no
+// Round 5 (profiles/r05_k17_ab.txt, docs/rounds/r05.md): four variants were built on this kernel and measured bit-identical but no
 // faster -- the channel blocks of a tile block walked inside one workgroup (+1.5 %), non-temporal requests (+3 %), the raw-patch
-// requests spread over all eight waves (+0.4 %) -- and removed again; the issue priority of the multiplying group stayed (-2 ... -3 %).
+// requests spread over all eight waves (+0.4 %), the k order rotated per channel block so that sibling workgroups prefetch for
+// each other (+1 %) -- and removed again; the issue priority of the multiplying group stayed (-2 ... -3 %).
 // STATUS (round 4): dispatched by ops.conv_nhwc for the inference step's stride-1 3x3 layers (ops.USE_WINO): same-box step
 // 99.8 -> 94.5 ms.  Against K9 at 64 images (profiles/r04_k17_winograd.txt): 128 -> 128 @240x320 3.04 vs 3.39 ms (1.11x),
 // 196 -> 196 @240x320 8.83 vs 9.45 (1.07x), 196 -> 128 1.16x, 256 -> 256 @120x160 1.19x, 256 -> 256 @60x80 1.26x -- short of the
@@ -89,7 +90,6 @@ struct WinoArgs {
     long ntb;                    // tile blocks = N * tilesX * tilesY
     int H, W, Cin, Cout, nk, ncb, tilesX, tilesY, act;
     int half_ok;                 // the last channel block holds at most 32 channels: its workgroups run the HALF body
-    int rot;                     // k-step rotation per channel block (see wino_body): 0 = off
     int prio;                    // 1 (default; far_set_tuning(15, 1) clears it): the multiplying wave group raises its issue priority
     float slope, out_mul;
 };
@@ -203,15 +203,8 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p) {
     const unsigned char* const wbase = p.w + (size_t)cb * nslab * SLAB + wsel * 1024 + lane * 16;
     const unsigned bs_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(lptr_t)(Bs + wsel * 1024));
     const unsigned rs_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(lptr_t)Rs);
-    // k-step order of this channel block, rotated by 2 cb (p.rot): the ncb workgroups of a tile block run at the same time on
-    // neighbouring CUs of one XCD and walk the SAME pixels; in the same k order they all miss on the same 128-byte line at the same
-    // moment (a pixel's 16 channels of two consecutive k-steps share a line, so every second k-step is a miss) and each waits out the
-    // whole HBM latency.  With the starts spread over the k range (p.rot = ~nk / ncb, even), each line is first touched by ONE of them
-    // and found in L2 by the others.  Only the order in which the k-steps are added to the accumulators changes (per channel block, fixed).
-    const int krot = p.rot ? (p.rot * cb) % nk : 0;
-    auto kmap = [&](int k) { const int e = k + krot; return e >= nk ? e - nk : e; };       // k < nk
     auto slab_src = [&](int slab) {                 // this lane's source of piece 0 of a slab (past the end: the last slab again)
-        const int i = slab < nslab ? 2 * kmap(slab >> 1) + (slab & 1) : nslab - 1;
+        const int i = slab < nslab ? slab : nslab - 1;
         return wbase + (size_t)i * SLAB;
     };
     const bool wskip = HALF && (wsel & 2);            // wave-uniform
@@ -251,7 +244,7 @@ __device__ __forceinline__ void wino_body(const WinoArgs& p) {
     }
     auto raw_piece = [&](int rk, int slot, int j) {                           // piece j (0..5) of raw patch rk
         if (Q) return;
-        const int kk = rk < nk ? kmap(rk) : nk - 1; // past the end: the last patch again, into a slot nobody reads
+        const int kk = rk < nk ? rk : nk - 1;       // past the end: the last patch again, into a slot nobody reads
         const bool tail = kk == nk - 1 && ((rtailm >> j) & 1u);
         const char* s = tail ? reinterpret_cast<const char*>(p.zeros) : rsrc[j] + (long)kk * rinc[j];
         if (FAR_WINO_EXP & 64) {         // experiment: every workgroup reads the same 128 KiB (cache hits), same request count and shape
@@ -695,10 +688,6 @@ int far_conv3x3_wino_f32(const far_conv_desc* desc, hipStream_t stream) {
     a.ntb = d.N * a.tilesX * a.tilesY;
     a.act = d.act; a.slope = d.slope; a.out_mul = 16.0f;
     a.half_ok = (d.Cout - 64 * (a.ncb - 1) <= 32 && far_get_tuning(9) == 0) ? 1 : 0;      // tuning 9: 1 = every block on the full body
-    // experiment (tuning 14 = 1): channel block cb starts its k loop at k = rot * cb, rot = the even number nearest below nk / ncb (>= 2):
-    // the ncb sibling workgroups of a tile block then each miss on about 1 / ncb of the lines and find the rest in L2
-    a.rot = 0;
-    if (far_get_tuning(14) == 1 && a.ncb > 1 && a.nk >= 4) { a.rot = (a.nk / a.ncb) & ~1; if (a.rot < 2) a.rot = 2; }
     a.prio = far_get_tuning(15) == 0 ? 1 : 0;                   // tuning 15 = 1: no priority change (the round-4 kernel)
     const long nblk = a.ntb * a.ncb;
     if (nblk > 0x7fffffffL || (long)d.H * d.W * d.Cout > 0x7fffffffL) return FAR_EINVAL;

@@ -62,7 +62,6 @@ TUNING = [
     Tuning(9, 0, (1,), 'bitwise', 'K17 runs a short last channel block on the full body'),
     Tuning(10, 0, (1,), 'bitwise', "K1's match pass without the tile prescreen"),
     Tuning(12, 0, (1,), 'parity', "K10's inference form on the exact-f32 matrix instruction instead of split fp16"),
-    Tuning(14, 0, (1,), 'parity', 'K17: 1 = the k-steps of channel block cb run in an order rotated by 2 cb (siblings prefetch for each other; another summation order)'),
     Tuning(15, 0, (1,), 'bitwise', 'K17: 1 = the multiplying wave group does NOT raise its issue priority (the round-4 kernel)'),
     Tuning(13, 0, (1,), 'bitwise', "K9's FPN-merge epilogue in its generic form everywhere"),
 ]
