@@ -194,7 +194,8 @@ def load():
     # the sources it is loaded next to; FAR_HIP_LIB (tools/ab_build.py: a library of another revision, on purpose) skips the check
     if not flags.value('FAR_HIP_LIB'):
         from . import build as _build
-        want, have = _build.source_id(), lib.far_build_id().decode()
+        have = lib.far_build_id().decode()
+        want = _build.source_id() if os.path.isdir(_build.CSRC) else have          # a deployment without the sources: nothing to compare with
         if have != want:
             raise FarHipError(f'{LIB_PATH} was built from other sources (build id {have}, far_amd/csrc is {want}): rebuild it with '
                               '`python -m far_amd.build`')
