@@ -349,6 +349,9 @@ class LoFTR(nn.Module):
         activations beyond the widest range leave the module exactly as it was and raise ActivationOverflow."""
         if device.type != 'cuda':
             return fn()
+        if getattr(self, '_in_sequence', False):           # inside guarded_sequence: ITS guard reads the flag, once, behind the whole sequence
+            with ops.activation_exponent(self.act_exp):
+                return fn()
         ops.overflow_flag(device).zero_()
         saved = None
         while True:
@@ -367,6 +370,24 @@ class LoFTR(nn.Module):
             except ops.ActivationOverflow:
                 self._restore_range_state(saved)             # nothing that did not yield finite outputs is kept
                 raise
+
+    def guarded_sequence(self, fn, device, inputs=()):
+        """fn() = a SEQUENCE of calls on one batch -- forward, forward_rt_prediction, the solver rounds in between (what
+        far_amd.pipeline.test_step replays) -- under ONE activation-range guard: the calls inside do not read the overflow flag
+        themselves (each read is a host synchronisation: the GPU then idles while the host enqueues the next stage, three times per
+        evaluation step), the flag is read once behind the whole sequence, and an overflow widens the range and runs the WHOLE sequence
+        again (fn must be re-runnable: it receives no arguments and rewrites every result it wrote).  Same guarantees as a guarded
+        single call: results are never silently out of range when this returns."""
+        if device.type != 'cuda' or getattr(self, '_in_sequence', False):
+            return fn()
+
+        def run():
+            self._in_sequence = True
+            try:
+                return fn()
+            finally:
+                self._in_sequence = False
+        return self._guarded(run, device, inputs)
 
     def check_activation_range(self, data):
         """For callers that drive forward_feature_extraction / forward_correspondence_prediction themselves: raises

@@ -16,27 +16,58 @@ from .config import RunCfg
 from .supervision import compute_supervision_RT, compute_supervision_coarse, compute_supervision_fine
 
 
+_MISSING = object()
+
+
+def _one_guard(matcher, batch, seq, device_key):
+    """Runs seq() -- a re-runnable sequence of matcher / solver / head calls on `batch` -- under ONE activation-range guard of the
+    LoFTR module (LoFTR.guarded_sequence: one host read of the overflow flag behind the whole step instead of one per call, so that
+    the host can enqueue the whole step behind the match-count read without waiting for the GPU three more times).  A caller-supplied
+    priorRT is restored before a re-run; wrappers (DistributedDataParallel) are looked through; anything without the guard runs plain."""
+    core = getattr(matcher, 'module', matcher)
+    t = batch.get(device_key)
+    if not hasattr(core, 'guarded_sequence') or not torch.is_tensor(t) or not t.is_cuda:
+        return seq()
+    prior0, pdev0 = batch.get('priorRT', _MISSING), batch.get('_priorRT_device', _MISSING)
+
+    def run():
+        if run.again:                                       # a re-run at a wider range starts from what the caller handed in
+            for k, v in (('priorRT', prior0), ('_priorRT_device', pdev0)):
+                if v is _MISSING:
+                    batch.pop(k, None)
+                else:
+                    batch[k] = v
+            core.invalidate_head_cache(batch)
+        run.again = True
+        return seq()
+    run.again = False
+    return core.guarded_sequence(run, t.device, tuple(batch[k] for k in ('image0', 'image1') if k in batch))
+
+
 @torch.no_grad()
 def test_step(matcher, batch, run_cfg=None, H=2048, seed=0):
     cfg = run_cfg or RunCfg(matcher.config['solver'], matcher.config.get('fine_pred_steps', 2))
-    if cfg.LOFTR.FINE_PRED_STEPS > 0:
-        # the head WILL be called on this batch: its feature stage may be enqueued behind the coarse matcher (LoFTR.head_prefetch)
-        batch['_far_head_follows'] = True
-    try:
-        out = matcher(batch)                                                        # :328
-    finally:
-        batch.pop('_far_head_follows', None)               # also when the matcher raised: a later matcher-only call must not prefetch
-    if isinstance(out, dict) and out is not batch:         # a wrapper that copied the dict (DDP with device_ids): merge its writes
-        batch.update(out)
-        batch.pop('_far_head_follows', None)
-    batch['translation_scale'] = None                                               # :335
-    compute_supervision_RT(batch, cfg, H=H, seed=seed)                              # :336
-    steps = cfg.LOFTR.FINE_PRED_STEPS
-    for i in range(steps):                                                          # :338
-        matcher.forward_rt_prediction(batch)                                        # :340
-        if i < steps - 1 and 'prior_ransac' in cfg.LOFTR.SOLVER:                    # :342
-            compute_supervision_RT(batch, cfg, H=H, seed=seed)                      # :343
-    return batch
+
+    def seq():
+        if cfg.LOFTR.FINE_PRED_STEPS > 0:
+            # the head WILL be called on this batch: its feature stage may be enqueued behind the coarse matcher (LoFTR.head_prefetch)
+            batch['_far_head_follows'] = True
+        try:
+            out = matcher(batch)                                                    # :328
+        finally:
+            batch.pop('_far_head_follows', None)           # also when the matcher raised: a later matcher-only call must not prefetch
+        if isinstance(out, dict) and out is not batch:     # a wrapper that copied the dict (DDP with device_ids): merge its writes
+            batch.update(out)
+            batch.pop('_far_head_follows', None)
+        batch['translation_scale'] = None                                           # :335
+        compute_supervision_RT(batch, cfg, H=H, seed=seed)                          # :336
+        steps = cfg.LOFTR.FINE_PRED_STEPS
+        for i in range(steps):                                                      # :338
+            matcher.forward_rt_prediction(batch)                                    # :340
+            if i < steps - 1 and 'prior_ransac' in cfg.LOFTR.SOLVER:                # :342
+                compute_supervision_RT(batch, cfg, H=H, seed=seed)                  # :343
+        return batch
+    return _one_guard(matcher, batch, seq, 'image0')
 
 
 @torch.no_grad()
@@ -49,15 +80,19 @@ def cached_step(matcher, batch, run_cfg=None, H=2048, seed=0):
         compute_supervision_RT -> [forward_rt_prediction -> compute_supervision_RT] x (FINE_PRED_STEPS - 1) -> forward_rt_prediction
     """
     cfg = run_cfg or RunCfg(matcher.config['solver'], matcher.config.get('fine_pred_steps', 2))
-    batch['translation_scale'] = None
     batch.pop('priorRT', None)
-    compute_supervision_RT(batch, cfg, H=H, seed=seed)
-    steps = cfg.LOFTR.FINE_PRED_STEPS
-    for i in range(steps):
-        matcher.forward_rt_prediction(batch)
-        if i < steps - 1 and 'prior_ransac' in cfg.LOFTR.SOLVER:
-            compute_supervision_RT(batch, cfg, H=H, seed=seed)
-    return batch
+    batch.pop('_priorRT_device', None)
+
+    def seq():
+        batch['translation_scale'] = None
+        compute_supervision_RT(batch, cfg, H=H, seed=seed)
+        steps = cfg.LOFTR.FINE_PRED_STEPS
+        for i in range(steps):
+            matcher.forward_rt_prediction(batch)
+            if i < steps - 1 and 'prior_ransac' in cfg.LOFTR.SOLVER:
+                compute_supervision_RT(batch, cfg, H=H, seed=seed)
+        return batch
+    return _one_guard(matcher, batch, seq, 'featmap0')
 
 
 def _trainval_inference(matcher, batch, loss_fn, cfg, train, H, seed, forward=None):

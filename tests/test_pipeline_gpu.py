@@ -781,3 +781,60 @@ def test_training_step_gradients_are_bit_identical_from_run_to_run(model):
     groups = sorted(set(k.rsplit('.', 2)[0] for k in differing))
     print(f'[determinism] {len(runs[0][1]) - len(differing)} of {len(runs[0][1])} parameter gradients bit-identical over 3 runs; differing: {groups}')
     assert not differing
+
+
+def test_step_runs_under_one_activation_range_guard(model):
+    """pipeline.test_step wraps matcher -> solver -> head -> solver -> head in ONE guard (LoFTR.guarded_sequence): the calls inside
+    do not read the overflow flag (three host synchronisations per step gone), the flag is read once behind the step.  (1) On a
+    normal checkpoint the results are bit-identical to the same calls under their own guards.  (2) On a checkpoint whose activations
+    leave the default range the WHOLE step is re-run at the widened range: finite results equal to a second (clean) run's, a
+    caller-supplied state (no priorRT at entry) restored before the re-run, the flag clear afterwards."""
+    import copy
+    import warnings
+    from far_amd import ops
+    from far_amd.config import RunCfg
+    from far_amd.pipeline import test_step
+    from far_amd.supervision import compute_supervision_RT
+    keys = ['b_ids', 'i_ids', 'j_ids', 'mconf', 'mkpts1_f', 'loftr_rt', 'regressed_rt']
+    d1, _, _ = _batch(2, 41)
+    d2 = {k: v for k, v in d1.items()}
+    calls = []
+    orig = ops.activation_overflowed
+    ops.activation_overflowed = lambda dev, reset=True: (calls.append(1), orig(dev, reset))[1]
+    try:
+        test_step(model, d1, H=256)
+        n_seq = len(calls)
+        cfg = RunCfg('prior_ransac', 2)
+        with torch.no_grad():                                   # the same calls, each under its own guard
+            model(d2)
+            d2['translation_scale'] = None
+            compute_supervision_RT(d2, cfg, H=256, seed=0)
+            model.forward_rt_prediction(d2)
+            compute_supervision_RT(d2, cfg, H=256, seed=0)
+            model.forward_rt_prediction(d2)
+        n_each = len(calls) - n_seq
+    finally:
+        ops.activation_overflowed = orig
+    assert n_seq == 1 and n_each == 3, (n_seq, n_each)
+    for k in keys:
+        assert torch.equal(d1[k], d2[k]), k
+    assert np.array_equal(d1['priorRT'], d2['priorRT'])
+    # (2) the range recovery through the one guard
+    big = copy.deepcopy(model)
+    with torch.no_grad():
+        big.backbone.bn1.weight.mul_(2.0 ** 13)
+        big.backbone.bn1.bias.mul_(2.0 ** 13)
+    d3, _, _ = _batch(1, 5)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter('always')
+        test_step(big, d3, H=256)
+    assert big.act_exp < 4 and any('activation' in str(w.message) for w in rec)
+    assert not ops.activation_overflowed('cuda')
+    d4, _, _ = _batch(1, 5)
+    with warnings.catch_warnings(record=True) as rec2:
+        warnings.simplefilter('always')
+        test_step(big, d4, H=256)                               # a clean run at the widened setting
+    assert not [w for w in rec2 if 'activation' in str(w.message)]
+    for k in keys:
+        assert torch.isfinite(d3[k].float()).all() and torch.equal(d3[k], d4[k]), k
+    assert len(d3['b_ids']) > 100
