@@ -24,8 +24,6 @@ SWITCHES = [
            'the 196-channel backbone maps stored with 196 channels instead of 208 (zero weights for the extra ones: exact zeros)'),
     Switch('FAR_NO_PREFETCH', 'far_amd.loftr.model:LoFTR', 'head_prefetch', False, 'bitwise', 'inference',
            "the head's feature stage computed inside forward_rt_prediction instead of enqueued behind K1"),
-    Switch('FAR_NO_SIDE_HEAD', 'far_amd.loftr.model:LoFTR', 'head_side_stream', False, 'bitwise', 'inference',
-           "the head's prefetched feature stage on the main stream (in front of the fine level) instead of a second stream next to it"),
     Switch('FAR_NO_GATHER_FUSE', 'far_amd.loftr.stages:FinePreprocess', 'fused_gather', False, 'bitwise', 'inference',
            'FinePreprocess.merge_feat on a materialised window tensor (K3 gather + K9) instead of K9 reading through the match indices'),
     Switch('FAR_NO_KV', 'far_amd.loftr.transformer:LoFTREncoderLayer', 'fused_kv', False, 'parity', 'inference',

@@ -101,8 +101,6 @@ class LoFTR(nn.Module):
 
     PRECISIONS = ('fp32', 'fp16-fine', 'fp16', 'bf16')
     head_prefetch = not flags.off('FAR_NO_PREFETCH')   # inference: the head's feature stage enqueued behind K1 (see below)
-    head_side_stream = not flags.off('FAR_NO_SIDE_HEAD')   # ... on a second stream, so that it runs NEXT TO the fine level and the first solver round
-    _side_streams = {}                                     # device -> torch.cuda.Stream (process-wide: a stream is cheap, but not free, to create)
 
     def set_precision(self, mode):
         """Arithmetic of the backbone convolutions (everything else is unaffected):
@@ -176,7 +174,7 @@ class LoFTR(nn.Module):
         overlap = None
         if (self.head_prefetch and data.get('_far_head_follows') and self.config['regress_rt'] and tok0.is_cuda and not train
                 and not torch.is_grad_enabled() and not self.training and getattr(self.loftr_regress, 'cache_features', True)):
-            overlap = lambda: self._prefetch_head(data, tok0, tok1)
+            overlap = lambda: self._head_features(data, tok0, tok1, None, None)
         self.coarse_matching(tok0, tok1, data, mask_c0=m0, mask_c1=m1, overlap=overlap)
         win0, win1 = self.fine_preprocess(data['featmap_f0'], data['featmap_f1'], tok0, tok1, data)
         if win0.size(0) != 0:
@@ -278,26 +276,6 @@ class LoFTR(nn.Module):
     def _tensor_stamp(t):
         return (id(t), t.data_ptr(), tuple(t.shape), ops.tensor_version(t))
 
-    def _prefetch_head(self, data, tok0, tok1):
-        """The head's feature stage behind K1.  head_side_stream: on a second stream -- it then runs next to the fine level and the
-        first solver round instead of in front of them (their latency-bound launches -- K4's hypothesis kernels, K3, the small
-        Linear layers -- disappear under K2); the consumer waits for the event recorded here (_head_features).  Everything the
-        side stream reads (the coarse tokens) was written on the main stream before the fork and lives in `data`; what it
-        allocates belongs to the side stream and is handed to the consumer with record_stream."""
-        if not self.head_side_stream:
-            self._head_features(data, tok0, tok1, None, None)
-            return
-        main = torch.cuda.current_stream(tok0.device)
-        side = self._side_streams.get(tok0.device)
-        if side is None:
-            side = self._side_streams.setdefault(tok0.device, torch.cuda.Stream(device=tok0.device))
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            self._head_features(data, tok0, tok1, None, None)
-            hit = data.get(self._HEAD_KEY)
-            if hit is not None:
-                data[self._HEAD_KEY] = hit + (side.record_event(), side)
-
     def _head_features(self, data, f0, f1, preds, inv_preds):
         head = self.loftr_regress
         if torch.is_grad_enabled() or not getattr(head, 'cache_features', True):
@@ -305,15 +283,6 @@ class LoFTR(nn.Module):
         stamp = (self._tensor_stamp(f0), self._tensor_stamp(f1), head.feature_stamp())
         hit = data.get(self._HEAD_KEY)
         if hit is not None and hit[0] == stamp and hit[2] is f0 and hit[3] is f1:
-            if len(hit) > 4:                               # computed on the side stream: this stream takes it over once
-                cur = torch.cuda.current_stream(f0.device)
-                if cur != hit[5]:
-                    cur.wait_event(hit[4])
-                    feats = hit[1]
-                    for t in ((feats.feats, feats.enc0, feats.moe0) if hasattr(feats, 'feats') else (feats,)):
-                        if torch.is_tensor(t):
-                            t.record_stream(cur)
-                data[self._HEAD_KEY] = hit[:4]
             return hit[1]
         features = head.compute_features(f0, f1, preds, inv_preds)
         data[self._HEAD_KEY] = (stamp, features, f0, f1)
