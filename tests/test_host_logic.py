@@ -210,3 +210,54 @@ def test_demo_without_a_gpu_exits_2_and_computes_nothing():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, 'demo.py'), '--synthetic'], capture_output=True, text=True, timeout=300)
     assert r.returncode == 2 and 'no GPU visible' in r.stderr and 'predicted pose' not in r.stdout
+
+
+def test_ransac_api_argument_checks_need_no_gpu():
+    """far_amd/ransac.py mirrors the reference's error behaviour (cv_geometry.py:786-794, essential.py:110-111, ransac.py:158-159,
+    :310-338) before anything touches the library, and refuses CPU tensors loudly (no CPU fallback exists)."""
+    from far_amd.ransac import RANSAC, decompose_essential_matrix, run_8point
+    p = torch.zeros(2, 9, 2)
+    with pytest.raises(AssertionError):
+        run_8point(p, torch.zeros(2, 8, 2))
+    with pytest.raises(AssertionError):
+        run_8point(p[:, :7], p[:, :7])
+    with pytest.raises(AssertionError):
+        run_8point(p, p, torch.ones(2, 5))
+    with pytest.raises(AssertionError):
+        decompose_essential_matrix(torch.zeros(4, 3, 2))
+    with pytest.raises(_lib.FarHipError, match='no CPU fallback'):
+        run_8point(p, p)
+    with pytest.raises(_lib.FarHipError, match='no CPU fallback'):
+        decompose_essential_matrix(torch.eye(3)[None])
+    with pytest.raises(NotImplementedError):
+        RANSAC(model_type='homography')
+    with pytest.raises(NotImplementedError, match='early stopping'):
+        RANSAC(model_type='fundamental', perform_early_stopping=True)
+    with pytest.raises(NotImplementedError, match='exp prior score'):
+        RANSAC(model_type='essential_cv2', prior_params={'RT': torch.eye(3, 4), 'pcl': torch.zeros(3, 3), 'lambda': 0.3, 'biased_sampling': 'biased'},
+               use_linear_bias_sampling=True, bias_sigma_sq=0.1, max_iter=1)
+    prior = {'RT': torch.tensor([[1., 0, 0, 2.0], [0, 1, 0, 0], [0, 0, 1, 0]]), 'pcl': torch.zeros(3, 3), 'lambda': 0.3, 'biased_sampling': 'biased'}
+    m = RANSAC(model_type='essential_cv2', prior_params=prior, use_noexp_prior_scoring=True, use_linear_bias_sampling=True, bias_sigma_sq=0.1,
+               max_iter=1, max_lo_iters=0, inl_th=3e-7)
+    assert m.use_prior and m.minimal == 8 and m.minimal_sample_size == 6
+    assert abs(float(torch.linalg.norm(prior['RT'][:, 3])) - 1.0) < 1e-6            # ransac.py:183 normalises the caller's tensor in place
+    with pytest.raises(ValueError):
+        m.forward(torch.zeros(5, 2), torch.zeros(5, 2))
+    with pytest.raises(_lib.FarHipError, match='no CPU fallback'):
+        m.forward(torch.zeros(20, 2), torch.zeros(20, 2))
+
+
+def test_build_id_ties_the_library_to_its_sources(tmp_path, monkeypatch):
+    """far_amd/_lib.py refuses a library whose far_build_id() differs from the id of far_amd/csrc next to it (the .so travels
+    outside git); FAR_HIP_LIB (another build, on purpose) skips the check."""
+    from far_amd import build as fb
+    lib = _lib.load()
+    assert lib.far_build_id().decode() == fb.source_id() and len(fb.source_id()) == 16
+    monkeypatch.setattr(fb, 'source_id', lambda: '0' * 16)
+    monkeypatch.setattr(_lib, '_lib', None)
+    with pytest.raises(_lib.FarHipError, match='built from other sources'):
+        _lib.load()
+    monkeypatch.setenv('FAR_HIP_LIB', _lib.LIB_PATH)
+    monkeypatch.setattr(_lib, '_lib', None)
+    assert _lib.load().far_abi_version() == _lib.EXPECTED_ABI
+    monkeypatch.setattr(_lib, '_lib', lib)
