@@ -185,6 +185,8 @@ def main():
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--pairs', type=int, default=32)
     ap.add_argument('--out', default=None)
+    ap.add_argument('--precision', default='fp32', help="LoFTR.set_precision mode ('fp16': plain fp16 operands in K9 -- the floors then still assume split operands: read the measured column only)")
+    ap.add_argument('--bf16-k1', action='store_true', help='with --precision fp16: the coarse matcher on its bf16 variant too')
     a = ap.parse_args()
     from far_amd import _lib, synth
     from far_amd.config import far_eval_config
@@ -200,6 +202,9 @@ def main():
     model_ = LoFTR(cfg).eval()
     synth.load_synthetic(model_, seed=0)
     model_ = model_.to(dev)
+    model_.set_precision(a.precision)
+    if a.bf16_k1:
+        model_.coarse_matching.bf16 = True
     im0, im1 = synth.synth_image_pair(a.pairs, seed=1234)
     K = torch.from_numpy(np.stack([synth.MP3D_K] * a.pairs)).to(dev)
     base = {'image0': torch.from_numpy(im0).to(dev), 'image1': torch.from_numpy(im1).to(dev), 'K0': K, 'K1': K.clone(), 'dataset_name': ['mp3d']}
