@@ -51,7 +51,7 @@ def parse():
                     help="c2: minimal solver of the RANSAC hypotheses: 8 = the normalized 8-point north_star names (default), 5 = Nister's "
                          "five-point for every pair -- the solver class the reference actually executes (OpenCV's five-point, "
                          "ransac.py:151-157)")
-    ap.add_argument('--precision', default='fp32', choices=['fp32', 'fp16-fine', 'fp16', 'bf16'],
+    ap.add_argument('--precision', default='fp32', choices=['fp32', 'fp16-fine', 'fp16', 'mixed16', 'bf16'],
                     help='backbone convolution arithmetic (far_amd.loftr.LoFTR.set_precision): fp32 = split-fp16 operand pairs (fp32-grade)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--skip-rooflines', action='store_true',
@@ -928,19 +928,26 @@ def main():
             # informational: the same step with plain fp16 matrix operands in every K9 launch (the precision class BASELINE
             # configs[1] names, 'bf16'); NOT the parity configuration and never `value` (match-set IoU > 0.95 vs parity,
             # tests/test_pipeline_gpu.py::test_precision_modes_deviation)
-            model.set_precision('fp16')
-            for _ in range(2):
-                step()
-            fence()
-            t1 = time.perf_counter()
-            for _ in range(3):
-                step()
-            fence()
-            dt16 = (time.perf_counter() - t1) / 3
-            model.set_precision('fp32')
+            def timed_mode(mode, n=5):
+                model.set_precision(mode)
+                for _ in range(2):
+                    step()
+                fence()
+                t1 = time.perf_counter()
+                for _ in range(n):
+                    step()
+                fence()
+                model.set_precision('fp32')
+                return (time.perf_counter() - t1) / n
+            dt16 = timed_mode('fp16')
+            dtm = timed_mode('mixed16')
             res['other_modes'] = {'fp16_operands': {'value': round(a.pairs / dt16, 3), 'ms_per_step': round(1000 * dt16, 3),
                                                     'note': 'plain fp16 operands in the backbone / encoder matrix products, fp32 tensors and '
-                                                            'accumulation; informational, not the parity line'}}
+                                                            'accumulation; informational, not the parity line'},
+                                  'mixed16': {'value': round(a.pairs / dtm, 3), 'ms_per_step': round(1000 * dtm, 3),
+                                              'note': 'plain-fp16 operands in the backbone K9, bf16 in K1, plain fp16 in K2; the encoder layers on '
+                                                      'their split-fp16 fused kernels; fp32 tensors and accumulation; the 16-bit-operand class '
+                                                      'BASELINE configs[1] runs the reference in; informational, not the parity line'}}
         if world == 1 and not a.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(a.cpu_pairs, a.hyp)
         if per_rank_peak is not None:

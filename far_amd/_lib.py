@@ -98,6 +98,7 @@ SIGNATURES = {
     'far_conv3x3_wino_f32': (c_i, [c_p, c_p]),                # (const far_conv_desc*, stream): K17
     'far_emm_pv_f16s_workspace_bytes': (c_sz, [c_i, c_i]),
     'far_emm_pv_f16s': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_i, c_l, c_l, c_i, c_p, c_p, c_p, c_p]),
+    'far_emm_pv_f16': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_i, c_l, c_l, c_i, c_p, c_p, c_p, c_p]),
     'far_emm_pv_f16s_copy_stats': (c_i, [c_p, c_i, c_i, c_p, c_p, c_p]),
     'far_emm_bwd_workspace_bytes': (c_sz, [c_i, c_i]),
     'far_emm_bwd_f16': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_p, c_p, c_p, c_p]),

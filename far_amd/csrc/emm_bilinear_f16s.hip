@@ -157,6 +157,8 @@ __device__ __forceinline__ void dma_col_tile_async(unsigned char* lds, const _Fl
 }
 
 // acc[ct] (32 tile columns x this wave's 32 rows, transposed: D[m = tile row 32 ct + ..][n = row i]) = x(col) . x(row)
+// SPLIT = false (round 5, far_emm_pv_f16): plain fp16 operands -- hi.hi only -- the 16-bit-operand precision class of BASELINE configs[1]
+template <bool SPLIT = true>
 __device__ __forceinline__ void score_tile(f32x16 (&acc)[2], const unsigned char* lds, const RowFrags& rf, int l31, int h) {
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
@@ -170,14 +172,16 @@ __device__ __forceinline__ void score_tile(f32x16 (&acc)[2], const unsigned char
             const int row = 32 * ct + l31;
             const int off = row * 128 + (((2 * s + h) ^ ((row >> 1) & 7)) * 16);
             ch[ct] = *reinterpret_cast<const f16x8*>(lds + off);
-            cl[ct] = *reinterpret_cast<const f16x8*>(lds + CT_PLANE + off);
+            if (SPLIT) cl[ct] = *reinterpret_cast<const f16x8*>(lds + CT_PLANE + off);
         }
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[ct], rf.hi[s], acc[ct], 0, 0, 0);
+        if (SPLIT) {
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[ct], rf.lo[s], acc[ct], 0, 0, 0);
+            for (int ct = 0; ct < 2; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[ct], rf.lo[s], acc[ct], 0, 0, 0);
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cl[ct], rf.hi[s], acc[ct], 0, 0, 0);
+            for (int ct = 0; ct < 2; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cl[ct], rf.hi[s], acc[ct], 0, 0, 0);
+        }
     }
 }
 
@@ -227,6 +231,7 @@ __device__ __forceinline__ void rowstat_update(f32x16 (&acc)[2], float c1, int j
     m = mn;
 }
 
+template <bool SPLIT>
 __global__ __launch_bounds__(256, 2) void k_rowstats(const _Float16* __restrict__ ah, const _Float16* __restrict__ al,
                                                      const _Float16* __restrict__ bh, const _Float16* __restrict__ bl,
                                                      int Z, int N, int Np, float c1, float2* __restrict__ stat) {
@@ -246,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void k_rowstats(const _Float16* __restrict_
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     f32x16 cur[2];
-    score_tile(cur, lds_all, rf, l31, h);
+    score_tile<SPLIT>(cur, lds_all, rf, l31, h);
     for (int jt = 0; jt + 1 < ntile; ++jt) {
         // cur = scores of tile jt.  Tile jt + 1 (requested an iteration ago) has landed; after the barrier nobody reads
         // tile jt's stage any more (its scores were formed before the previous barrier): tile jt + 2 goes there.
@@ -256,16 +261,16 @@ __global__ __launch_bounds__(256, 2) void k_rowstats(const _Float16* __restrict_
         const unsigned char* lds = lds_all + ((jt + 1) & 1) * (2 * CT_PLANE);
         f32x16 nxt[2];
         if ((jt + 1) * KT <= N) {                                     // wave-uniform: tile jt entirely inside the sequence
-            score_tile(nxt, lds, rf, l31, h);
+            score_tile<SPLIT>(nxt, lds, rf, l31, h);
             rowstat_update<false>(cur, c1, jt * KT, N, h, m, sum, comp);
 #pragma unroll
-            for (int i = 0; i < 24; ++i) {
+            for (int i = 0; i < (SPLIT ? 24 : 0); ++i) {
                 if (i < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // a fragment read (16 per tile), ahead of its MFMA
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);               // one MFMA of tile jt + 1
                 __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);               // softmax VALU of tile jt (~135 per tile, 33 of them exps)
             }
         } else {
-            score_tile(nxt, lds, rf, l31, h);
+            score_tile<SPLIT>(nxt, lds, rf, l31, h);
             rowstat_update<true>(cur, c1, jt * KT, N, h, m, sum, comp);
         }
 #pragma unroll
@@ -351,6 +356,7 @@ __device__ __forceinline__ float tile_rowmax(const f32x16 (&acc)[2], float c1, i
     return tm * c1;                       // c1 > 0
 }
 
+template <bool SPLIT>
 __global__ __launch_bounds__(256, 2) void k_pv(const _Float16* __restrict__ qh, const _Float16* __restrict__ ql,
                                                const _Float16* __restrict__ kh, const _Float16* __restrict__ kl,
                                                const _Float16* __restrict__ vh, const _Float16* __restrict__ vl,
@@ -400,7 +406,7 @@ __global__ __launch_bounds__(256, 2) void k_pv(const _Float16* __restrict__ qh, 
         const int* const lcr = reinterpret_cast<const int*>(ldv + CREF_ROW * 128);
 
         f32x16 acc[2];
-        score_tile(acc, lds, rf, l31, h);
+        score_tile<SPLIT>(acc, lds, rf, l31, h);
         // ---- row reference: ceil of the running maximum, agreed between the two half-waves
         const bool ragged = (jt + 1) * KT > N;                                   // wave-uniform
         const float tm = ragged ? tile_rowmax<true>(acc, c1, jt * KT, N, h) : tile_rowmax<false>(acc, c1, jt * KT, N, h);
@@ -450,7 +456,8 @@ __global__ __launch_bounds__(256, 2) void k_pv(const _Float16* __restrict__ qh, 
                     t2 += f32x2{e0, e1};
                     const f32x2 p2 = f32x2{e0, e1} * f32x2{ldexpf(e0, R - cmv[e] + 15), ldexpf(e1, R - cmv[e + 1] + 15)};
                     f16x2 h2, l2;
-                    split2(p2, h2, l2);
+                    if (SPLIT) split2(p2, h2, l2);
+                    else { h2 = __builtin_convertvector(p2, f16x2); l2 = h2; }
                     ph[e] = h2.x; ph[e + 1] = h2.y;
                     pl[e] = l2.x; pl[e + 1] = l2.y;
                 }
@@ -460,10 +467,12 @@ __global__ __launch_bounds__(256, 2) void k_pv(const _Float16* __restrict__ qh, 
                     const int b = 32 * bt + l31;
                     const int off = b * 128 + ((slot ^ ((b >> 1) & 7)) * 16);
                     const f16x8 bh = *reinterpret_cast<const f16x8*>(ldv + off);
-                    const f16x8 bl = *reinterpret_cast<const f16x8*>(ldv + VT_PLANE + off);
                     tacc[bt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, bh, tacc[bt], 0, 0, 0);
-                    tacc[bt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, bl, tacc[bt], 0, 0, 0);
-                    tacc[bt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, bh, tacc[bt], 0, 0, 0);
+                    if (SPLIT) {
+                        const f16x8 bl = *reinterpret_cast<const f16x8*>(ldv + VT_PLANE + off);
+                        tacc[bt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, bl, tacc[bt], 0, 0, 0);
+                        tacc[bt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, bh, tacc[bt], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -525,17 +534,12 @@ size_t far_emm_pv_f16s_workspace_bytes(int Z, int N) {
     return carve(nullptr, Z, N).bytes;
 }
 
-// T[z] = P[z] @ [v[z] | pos], P = softmax over keys * softmax over queries of s = (q k^T) * scale  -- the whole K2
-// operator (statistics included) on split-fp16 operands.  pos [N][6], T_out [Z][N][70] fp32; q, k, v: problem
-// z = p * heads + hh starts at  ptr + hh * head_stride + p' * prob_stride  floats and is [N][64] contiguous, with
-// p' = p for k, v and (p + q_rot) mod (Z / heads) for q  (contiguous [Z][N][64]: heads = 1, prob_stride = 64 N, q_rot = 0);
-// ws: far_emm_pv_f16s_workspace_bytes(Z, N) bytes.  overflow: device int or NULL, |= 1 when a q / k value is beyond the range
-// of the 2^4-scaled fp16 split (|x| > 4094): T is then inf / NaN (far_emm_pv_f32 has no such limit).
-// (v~ / colsum is at most 64 |v| in the split's units: |v| > 1023 would overflow it too; the head's v is a Linear of a
-// LayerNorm output, the caller's range check covers it through the projection's own K9 flag.)
-int far_emm_pv_f16s(const float* q, const float* k, const float* v, const float* pos, int Z, int N, int Dh, float scale,
-                    int heads, long head_stride, long prob_stride, int q_rot, void* ws, float* T_out, int* overflow,
-                    hipStream_t stream) {
+}  // extern "C"
+
+template <bool SPLIT>
+static int emm_pv_launch(const float* q, const float* k, const float* v, const float* pos, int Z, int N, int Dh, float scale,
+                         int heads, long head_stride, long prob_stride, int q_rot, void* ws, float* T_out, int* overflow,
+                         hipStream_t stream) {
     far_clear_errors();
     if (!q || !k || !v || !pos || !ws || !T_out || Z <= 0 || N <= 0 || Dh != D || heads < 1 || Z % heads || q_rot < 0 ||
         q_rot >= Z / heads)
@@ -551,14 +555,39 @@ int far_emm_pv_f16s(const float* q, const float* k, const float* v, const float*
     const dim3 grid((unsigned)(Np / 128) * Z);
     // softmax over queries (rows of the statistics kernel = keys); the softmax over keys is formed online inside k_pv
     const dim3 gstat((unsigned)(Np / 128) * Z);
-    hipLaunchKernelGGL(k_rowstats, gstat, dim3(256), 0, stream, w.kh, w.kl, w.qh, w.ql, Z, N, Np, c1, w.colstat);
+    hipLaunchKernelGGL(k_rowstats<SPLIT>, gstat, dim3(256), 0, stream, w.kh, w.kl, w.qh, w.ql, Z, N, Np, c1, w.colstat);
     hipLaunchKernelGGL(k_prep_v, dim3((unsigned)(Np / KT) * Z), dim3(256), 0, stream, v, lay, pos, w.colstat, Z, N, Np, w.vh, w.vl, w.cref);
     bool cfg_failed = false;
-    FAR_ONCE_PER_DEVICE(cfg_failed = hipFuncSetAttribute((const void*)k_pv, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PV_STAGE) != hipSuccess);
+    FAR_ONCE_PER_DEVICE(cfg_failed = hipFuncSetAttribute((const void*)k_pv<SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PV_STAGE) != hipSuccess);
     if (cfg_failed) return far_check_launch();
-    hipLaunchKernelGGL(k_pv, grid, dim3(256), 2 * PV_STAGE, stream, w.qh, w.ql, w.kh, w.kl, w.vh, w.vl, w.cref, Z, N, Np, c1,
+    hipLaunchKernelGGL(k_pv<SPLIT>, grid, dim3(256), 2 * PV_STAGE, stream, w.qh, w.ql, w.kh, w.kl, w.vh, w.vl, w.cref, Z, N, Np, c1,
                        w.rowstat, T_out);
     return far_check_launch();
+}
+
+extern "C" {
+
+// T[z] = P[z] @ [v[z] | pos], P = softmax over keys * softmax over queries of s = (q k^T) * scale  -- the whole K2
+// operator (statistics included) on split-fp16 operands.  pos [N][6], T_out [Z][N][70] fp32; q, k, v: problem
+// z = p * heads + hh starts at  ptr + hh * head_stride + p' * prob_stride  floats and is [N][64] contiguous, with
+// p' = p for k, v and (p + q_rot) mod (Z / heads) for q  (contiguous [Z][N][64]: heads = 1, prob_stride = 64 N, q_rot = 0);
+// ws: far_emm_pv_f16s_workspace_bytes(Z, N) bytes.  overflow: device int or NULL, |= 1 when a q / k value is beyond the range
+// of the 2^4-scaled fp16 split (|x| > 4094): T is then inf / NaN (far_emm_pv_f32 has no such limit).
+// (v~ / colsum is at most 64 |v| in the split's units: |v| > 1023 would overflow it too; the head's v is a Linear of a
+// LayerNorm output, the caller's range check covers it through the projection's own K9 flag.)
+int far_emm_pv_f16s(const float* q, const float* k, const float* v, const float* pos, int Z, int N, int Dh, float scale,
+                    int heads, long head_stride, long prob_stride, int q_rot, void* ws, float* T_out, int* overflow,
+                    hipStream_t stream) {
+    return emm_pv_launch<true>(q, k, v, pos, Z, N, Dh, scale, heads, head_stride, prob_stride, q_rot, ws, T_out, overflow, stream);
+}
+
+// The 16-bit-operand form (round 5): the same kernels with plain fp16 operands (one MFMA product per tile instead of the
+// three of the split form; fp32 accumulation and the fp32 softmax statistics unchanged).  Same arguments, workspace and
+// overflow flag as far_emm_pv_f16s; results agree with it to ~1e-3 relative (tests/test_emm_gpu.py).
+int far_emm_pv_f16(const float* q, const float* k, const float* v, const float* pos, int Z, int N, int Dh, float scale,
+                   int heads, long head_stride, long prob_stride, int q_rot, void* ws, float* T_out, int* overflow,
+                   hipStream_t stream) {
+    return emm_pv_launch<false>(q, k, v, pos, Z, N, Dh, scale, heads, head_stride, prob_stride, q_rot, ws, T_out, overflow, stream);
 }
 
 // The softmax statistics far_emm_pv_f16s left in its workspace, for the backward kernels (emm_bilinear_bwd_f16.hip):

@@ -99,7 +99,7 @@ class LoFTR(nn.Module):
         # |activation| <= 4094; lowered by _widen_activation_range when a launch reports an overflow
         self.act_exp = 4
 
-    PRECISIONS = ('fp32', 'fp16-fine', 'fp16', 'bf16')
+    PRECISIONS = ('fp32', 'fp16-fine', 'fp16', 'mixed16', 'bf16')
     head_prefetch = not flags.off('FAR_NO_PREFETCH')   # inference: the head's feature stage enqueued behind K1 (see below)
 
     def set_precision(self, mode):
@@ -109,16 +109,24 @@ class LoFTR(nn.Module):
                       bit-identical, only the sub-pixel refinement input changes;
           'fp16'      plain fp16 operands everywhere in K9 -- backbone and the encoder layers' Linear layers (fp32
                       accumulation, fp32 activations): the 16-bit-operand configuration of BASELINE configs[1];
+          'mixed16'   16-bit operands where they pay, the fused kernels elsewhere (round 5): plain-fp16 K9 in the backbone,
+                      bf16 operands in K1 (far_coarse_match_bf16), plain-fp16 operands in K2 (far_emm_pv_f16); the encoder
+                      layers stay on their split-fp16 fused kernels (K13 / K14 and the fused kv / q-apply epilogues are
+                      faster than the unfused plain-fp16 launches 'fp16' falls back to).  Same precision class as 'fp16';
           'bf16'      the vendor convolutions under bf16 autocast (reference-style modules), channels_last."""
         if mode not in self.PRECISIONS:
             raise ValueError(f'precision must be one of {self.PRECISIONS}')
         self.backbone_dtype = torch.bfloat16 if mode == 'bf16' else torch.float32
         self.backbone.trunk_split = mode in ('fp32', 'fp16-fine')
         self.backbone.fpn_split = mode == 'fp32'
-        from .transformer import LoFTREncoderLayer
+        from .transformer import CrossAttention, LoFTREncoderLayer
         for m in self.modules():
             if isinstance(m, LoFTREncoderLayer):
                 m.split_operands = mode != 'fp16'
+            if isinstance(m, CrossAttention):
+                m.plain16 = mode == 'mixed16'
+        if hasattr(self, 'coarse_matching'):
+            self.coarse_matching.bf16 = mode == 'mixed16'
         return self
 
     # -------------------------------------------------------------------------------------------------

@@ -317,6 +317,7 @@ def positional_table_vit(h=24, w=24, intrinsics=None):
 
 class CrossAttention(nn.Module):
     hip_training = True          # training on the GPU runs K2's forward + backward kernels; False: vendor ops + autograd
+    plain16 = False              # inference: K2 on plain fp16 operands (far_emm_pv_f16; LoFTR.set_precision('mixed16'))
     exact_f32 = False            # inference: K2 on the exact-f32 MFMA kernels (no operand range limit; LoFTR sets it after an
                                  # activation-range overflow of the split-fp16 variant, model.py:_widen_activation_range)
 
@@ -365,7 +366,7 @@ class CrossAttention(nn.Module):
                 F, _ = ops.emm_bilinear(qq, P[1].reshape(2 * B * h, N, d).contiguous(), P[2].reshape(2 * B * h, N, d).contiguous(),
                                         self.pos6, self.scale, exact_f32=True)
             else:
-                F, _ = ops.emm_bilinear_planes(planes, self.pos6, self.scale, B)         # (2Bh, 70, 70)
+                F, _ = ops.emm_bilinear_planes(planes, self.pos6, self.scale, B, plain16=self.plain16)         # (2Bh, 70, 70)
         F = F.view(2, B, h, d + 6, d + 6)
         # raw reshape of (B, h, 70, 70) to (B, 280, 70), then transpose (:294-295)
         f1 = F[0].reshape(B, C + 6 * h, (C + 6 * h) // h).transpose(-2, -1)
@@ -504,7 +505,7 @@ class LocalFeatureTransformerRegressor(nn.Module):
             mods += [self.encoder[0], self.moe_predictor[0]]
         ws = tuple((p.data_ptr(), ops.tensor_version(p)) for m in mods for p in m.parameters())
         prec = tuple(m.split_operands for m in self.modules() if isinstance(m, LoFTREncoderLayer))
-        return ws, prec, self.training, ops.activation_exponent_value(), self.emm.cross_attn.exact_f32
+        return ws, prec, self.training, ops.activation_exponent_value(), self.emm.cross_attn.exact_f32, self.emm.cross_attn.plain16
 
     def compute_features(self, feat0, feat1, loftr_preds=None, inv_loftr_preds=None):
         """(B, 35840) head features of transformer.py:488-497 + :424-428 (LoFTR layer(s), CrossBlock, LayerNorm)."""

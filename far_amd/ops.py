@@ -217,10 +217,11 @@ def coarse_pos_conf(f0, f1, pb, pi, pj, temperature):
     return _CoarsePosConf.apply(f0, f1, pb, pi, pj, temperature)
 
 
-def emm_bilinear(q, k, v, pos, scale, exact_f32=False):
+def emm_bilinear(q, k, v, pos, scale, exact_f32=False, plain16=False):
     """K2.  q, k, v: (Z, N, 64) fp32; pos: (N, 6).  Returns F (Z, 70, 70) = v~^T (P v~), v~ = [v | pos],
     P = softmax(s, -1) * softmax(s, -2), s = (q k^T) * scale   (transformer.py:275-292).
-    Default: split-fp16 operands on the f16 matrix cores (fp32-grade); exact_f32: the exact-f32 MFMA kernels."""
+    Default: split-fp16 operands on the f16 matrix cores (fp32-grade); exact_f32: the exact-f32 MFMA kernels;
+    plain16: plain fp16 operands (far_emm_pv_f16, the 16-bit-operand class)."""
     lib = _lib.load()
     Z, N, D = q.shape
     T = torch.empty(Z, N, 70, dtype=torch.float32, device=q.device)
@@ -231,9 +232,10 @@ def emm_bilinear(q, k, v, pos, scale, exact_f32=False):
         _lib.check(rc, 'far_emm_pv_f32')
     else:
         ws = _ws(lib.far_emm_pv_f16s_workspace_bytes(Z, N), q.device)
-        rc = lib.far_emm_pv_f16s(_p(q, torch.float32), _p(k, torch.float32), _p(v, torch.float32), _p(pos, torch.float32),
-                                 Z, N, D, float(scale), 1, 0, N * D, 0, _p(ws), _p(T), _p(overflow_flag(T.device)), _stream())
-        _lib.check(rc, 'far_emm_pv_f16s')
+        name = 'far_emm_pv_f16' if plain16 else 'far_emm_pv_f16s'
+        rc = getattr(lib, name)(_p(q, torch.float32), _p(k, torch.float32), _p(v, torch.float32), _p(pos, torch.float32),
+                                Z, N, D, float(scale), 1, 0, N * D, 0, _p(ws), _p(T), _p(overflow_flag(T.device)), _stream())
+        _lib.check(rc, name)
     return emm_contract(_p(v, torch.float32), 1, 0, N * D, pos, T), T
 
 
@@ -312,10 +314,11 @@ def emm_bilinear_train(q, k, v, pos, scale):
     return _EmmBilinearFn.apply(q, k, v, pos, scale)
 
 
-def emm_bilinear_planes(qkv, pos, scale, B):
+def emm_bilinear_planes(qkv, pos, scale, B, plain16=False):
     """K2 on the output of the head's fused q | k | v projection: qkv (12, 2B, N, 64) = (tensor t, head) planes of
     [image, pair][N][64] (ops.linear_f16s(..., out_planes=12)).  Problem z = (direction, pair, head); direction d pairs
     the queries of image 1 - d with the keys / values of image d (transformer.py:275-276, 291-292).
+    plain16: far_emm_pv_f16 (plain fp16 operands) instead of the split-fp16 far_emm_pv_f16s.
     Returns F (2 B h, 70, 70), T."""
     lib = _lib.load()
     P12, P, N, D = qkv.shape
@@ -325,9 +328,10 @@ def emm_bilinear_planes(qkv, pos, scale, B):
     ws = _ws(lib.far_emm_pv_f16s_workspace_bytes(Z, N), qkv.device)
     base = qkv.data_ptr()
     plane = P * N * D * 4
-    rc = lib.far_emm_pv_f16s(ctypes.c_void_p(base), ctypes.c_void_p(base + h * plane), ctypes.c_void_p(base + 2 * h * plane),
-                             _p(pos, torch.float32), Z, N, D, float(scale), h, P * N * D, N * D, B, _p(ws), _p(T), _p(overflow_flag(T.device)), _stream())
-    _lib.check(rc, 'far_emm_pv_f16s')
+    name = 'far_emm_pv_f16' if plain16 else 'far_emm_pv_f16s'
+    rc = getattr(lib, name)(ctypes.c_void_p(base), ctypes.c_void_p(base + h * plane), ctypes.c_void_p(base + 2 * h * plane),
+                            _p(pos, torch.float32), Z, N, D, float(scale), h, P * N * D, N * D, B, _p(ws), _p(T), _p(overflow_flag(T.device)), _stream())
+    _lib.check(rc, name)
     # F = [v | pos]^T T (transformer.py:291-295) straight from the v planes: no (Z, N, 70) concatenation, no vendor bmm
     return emm_contract(ctypes.c_void_p(base + 2 * h * plane), h, P * N * D, N * D, pos, T), T
 

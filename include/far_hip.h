@@ -174,6 +174,12 @@ size_t far_emm_pv_f16s_workspace_bytes(int Z, int N);
 int far_emm_pv_f16s(const float* q, const float* k, const float* v, const float* pos, int Z, int N, int D, float scale,
                     int heads, long head_stride, long prob_stride, int q_rot, void* ws, float* T_out, int* overflow,
                     far_stream_t stream);
+/* The 16-bit-operand form of the same operator (the precision class BASELINE configs[1] runs the reference in: fp16
+ * autocast, transformer.py:275-292 under torch.autocast): plain fp16 operands, one MFMA product per tile, fp32
+ * accumulation and fp32 softmax statistics.  Arguments, workspace and overflow flag exactly as far_emm_pv_f16s. */
+int far_emm_pv_f16(const float* q, const float* k, const float* v, const float* pos, int Z, int N, int D, float scale,
+                   int heads, long head_stride, long prob_stride, int q_rot, void* ws, float* T_out, int* overflow,
+                   far_stream_t stream);
 /* the statistics of the last far_emm_pv_f16s call on `ws`: rowstat / colstat [Z][N][2] = (max, sum) in the log2 domain */
 int far_emm_pv_f16s_copy_stats(const void* ws, int Z, int N, float* rowstat_out, float* colstat_out, far_stream_t stream);
 

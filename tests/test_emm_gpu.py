@@ -36,6 +36,31 @@ def test_emm_bilinear(Z, N, exact_f32):
           ' fp32-restatement vs f64:', np.abs(F32 - Fref).max() / np.abs(Fref).max())
 
 
+@pytest.mark.parametrize('Z,N', [(3, 192), (2, 221), (1, 4800)])
+def test_emm_bilinear_plain_fp16_operands(Z, N):
+    """far_emm_pv_f16 (round 5, LoFTR.set_precision('mixed16')): plain fp16 operands, fp32 accumulation and statistics.  Not the
+    parity variant: the bar is the 16-bit-operand class (1e-3 relative, north_star's regression-logit tolerance) against the
+    float64 oracle, and the kernel must be a different result from the split one (it really drops the low halves)."""
+    from far_amd import ops
+    from oracle import head as oh
+    q, k, v, pos = _inputs(Z, N, seed=N)
+    t = [torch.from_numpy(a).cuda() for a in (q, k, v, pos)]
+    F, T = ops.emm_bilinear(*t, 0.125, plain16=True)
+    Fs, Ts = ops.emm_bilinear(*t, 0.125)
+    torch.cuda.synchronize()
+    vt = np.concatenate([v, np.broadcast_to(pos, (Z, N, 6))], axis=2)
+    Fref, A = oh.bilinear_attention(q, k, vt, 0.125, dtype=np.float64)
+    Tref = A @ vt.astype(np.float64)
+    eT = np.abs(T.cpu().numpy() - Tref).max() / np.abs(Tref).max()
+    eF = np.abs(F.cpu().numpy() - Fref).max() / np.abs(Fref).max()
+    eFs = np.abs(Fs.cpu().numpy() - Fref).max() / np.abs(Fref).max()
+    print(f'plain fp16: max|T - f64|/max|T| = {eT:.3g}, max|F - f64|/max|F| = {eF:.3g} (split: {eFs:.3g})')
+    assert torch.isfinite(T).all()
+    assert eT < 3e-3 and eF < 3e-3
+    assert eF > eFs                       # the split variant is the tighter one
+    assert not torch.equal(T, Ts)
+
+
 def test_emm_variants_agree_on_peaked_scores():
     """Large score range (|s| up to ~60): the one-exp formulation of the split variant must not under/overflow."""
     from far_amd import ops

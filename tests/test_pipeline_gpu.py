@@ -614,6 +614,40 @@ def test_precision_modes_deviation(model):
     assert iou > 0.95
 
 
+def test_mixed16_mode_deviation(model):
+    """LoFTR.set_precision('mixed16') (plain-fp16 backbone K9, bf16 K1, plain-fp16 K2, split-fp16 fused encoder layers): the
+    16-bit-operand class, reported next to the parity line in bench.py's other_modes -- never the parity configuration.
+    Bars: match-set IoU > 0.95 against the fp32-grade path, the EMM feature block within 1e-2 of its scale on the same
+    coarse features, and the mode must really switch K1 / K2 (different bits) and switch back (identical bits)."""
+    import copy
+    m = copy.deepcopy(model)
+    d32, _, _ = _batch(4, 31)
+    dm, _, _ = _batch(4, 31)
+    d32b, _, _ = _batch(4, 31)
+    with torch.no_grad():
+        m(d32)
+        feats = torch.cat([d32['featmap0'], d32['featmap1']], 0).contiguous()      # the coarse tokens (2B, 4800, 256)
+        blk32 = m.loftr_regress.emm(feats)
+        m.set_precision('mixed16')
+        assert m.coarse_matching.bf16 and m.loftr_regress.emm.cross_attn.plain16 and not m.backbone.trunk_split
+        m(dm)
+        blk16 = m.loftr_regress.emm(feats)
+        m.set_precision('fp32')
+        assert not m.coarse_matching.bf16 and not m.loftr_regress.emm.cross_attn.plain16 and m.backbone.trunk_split
+        m(d32b)
+        blk32b = m.loftr_regress.emm(feats)
+    for k in ['b_ids', 'i_ids', 'j_ids', 'mconf', 'mkpts1_f']:
+        assert torch.equal(d32[k], d32b[k]), k
+    assert torch.equal(blk32, blk32b)
+    s32 = set(zip(d32['b_ids'].tolist(), d32['i_ids'].tolist(), d32['j_ids'].tolist()))
+    s16 = set(zip(dm['b_ids'].tolist(), dm['i_ids'].tolist(), dm['j_ids'].tolist()))
+    iou = len(s32 & s16) / len(s32 | s16)
+    dev = float((blk16 - blk32).abs().max() / blk32.abs().max())
+    print(f'mixed16: match-set IoU {iou:.4f}, EMM block max deviation / scale {dev:.3g}')
+    assert iou > 0.95
+    assert 0 < dev < 1e-2
+
+
 def test_activation_range_recovery_end_to_end(model):
     """A checkpoint whose activations leave the split-fp16 range of the default exponent (|a| > 4094): the stem's BatchNorm
     scale and shift are multiplied by 2^13, so the first feature map reaches ~3e4 and everything downstream grows with it.

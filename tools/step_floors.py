@@ -136,11 +136,12 @@ def model(name, a):
         conf = 4 * Z * L * S if a[19] else 0
         # k1_rowstats x2 (split: 3 MFMA terms each) + k1_screen (hi.hi: 1 term) + k1_match on the surviving ~3 % of the tiles
         return f'K1 coarse match Z={Z} L={L}', 4 * Z * (L + S) * C + conf + 40 * Z * L, 2.0 * Z * L * S * C * (6 + 1 + 0.09)
-    if name == 'far_emm_pv_f16s':
+    if name in ('far_emm_pv_f16s', 'far_emm_pv_f16'):
         Z, N = a[4], a[5]
         by = 4 * Z * N * (3 * 64 + 70)
-        stats = 2.0 * Z * N * N * 64 * 3
-        pv = Z * math.ceil(N / 128) * math.ceil(N / 64) * 60 * 4 * 32768.0          # per 128 queries x 64 keys: 24 + 36 MFMAs per wave, 4 waves
+        terms = 3 if name.endswith('s') else 1
+        stats = 2.0 * Z * N * N * 64 * terms
+        pv = Z * math.ceil(N / 128) * math.ceil(N / 64) * 20 * terms * 4 * 32768.0   # per 128 queries x 64 keys: (8 + 12) x terms MFMAs per wave, 4 waves
         return f'K2 bilinear attention Z={Z} N={N}', by, stats + pv
     if name == 'far_emm_contract_f32':
         Z = a[6]
