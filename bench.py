@@ -941,7 +941,11 @@ def main():
                 return (time.perf_counter() - t1) / n
             dt16 = timed_mode('fp16')
             dtm = timed_mode('mixed16')
-            res['other_modes'] = {'fp16_operands': {'value': round(a.pairs / dt16, 3), 'ms_per_step': round(1000 * dt16, 3),
+            dtf = timed_mode('fp16-fine')
+            res['other_modes'] = {'fp16_fine': {'value': round(a.pairs / dtf, 3), 'ms_per_step': round(1000 * dtf, 3),
+                                                'note': "plain fp16 operands in the FPN's fine branch only: every coarse decision (ids, mconf) "
+                                                        'bit-identical to the parity line, sub-pixel refinement deviates ~0.01 px'},
+                                  'fp16_operands': {'value': round(a.pairs / dt16, 3), 'ms_per_step': round(1000 * dt16, 3),
                                                     'note': 'plain fp16 operands in the backbone / encoder matrix products, fp32 tensors and '
                                                             'accumulation; informational, not the parity line'},
                                   'mixed16': {'value': round(a.pairs / dtm, 3), 'ms_per_step': round(1000 * dtm, 3),

@@ -110,9 +110,10 @@ class LoFTR(nn.Module):
           'fp16'      plain fp16 operands everywhere in K9 -- backbone and the encoder layers' Linear layers (fp32
                       accumulation, fp32 activations): the 16-bit-operand configuration of BASELINE configs[1];
           'mixed16'   16-bit operands where they pay, the fused kernels elsewhere (round 5): plain-fp16 K9 in the backbone,
-                      bf16 operands in K1 (far_coarse_match_bf16), plain-fp16 operands in K2 (far_emm_pv_f16); the encoder
-                      layers stay on their split-fp16 fused kernels (K13 / K14 and the fused kv / q-apply epilogues are
-                      faster than the unfused plain-fp16 launches 'fp16' falls back to).  Same precision class as 'fp16';
+                      bf16 operands in K1 (far_coarse_match_bf16), plain-fp16 operands in K2 (far_emm_pv_f16) and in the
+                      d_model-256 layers' merge / MLP launches; their fused k|v-state / q-apply launches and the fine
+                      level's K13 / K14 stay on split operands (those fused kernels are faster than the unfused
+                      plain-fp16 launches 'fp16' falls back to).  Same precision class as 'fp16';
           'bf16'      the vendor convolutions under bf16 autocast (reference-style modules), channels_last."""
         if mode not in self.PRECISIONS:
             raise ValueError(f'precision must be one of {self.PRECISIONS}')
@@ -123,6 +124,7 @@ class LoFTR(nn.Module):
         for m in self.modules():
             if isinstance(m, LoFTREncoderLayer):
                 m.split_operands = mode != 'fp16'
+                m.dense_split = mode != 'mixed16'
             if isinstance(m, CrossAttention):
                 m.plain16 = mode == 'mixed16'
         if hasattr(self, 'coarse_matching'):

@@ -50,6 +50,8 @@ class LinearAttention(nn.Module):
 
 class LoFTREncoderLayer(nn.Module):
     split_operands = True        # K9 operand precision of the Linear layers (False: plain fp16, LoFTR.set_precision)
+    dense_split = True           # ... of the launches that are plain Linear layers at d_model 256 (merge, mlp[0], mlp[2]): False =
+                                 # plain fp16 there while the fused k|v-state / q-apply launches stay split ('mixed16')
     hip_training = True          # training on the GPU runs K9 / K5 (forward + backward kernels); False: vendor ops + autograd
     layer_node = True            # ... as one autograd node per layer call (layer_train.py); False: one node per operator
     overlap = True               # layer node: weight gradients and the k / v projections on the library's side streams
@@ -110,8 +112,9 @@ class LoFTREncoderLayer(nn.Module):
         # kernel is chosen by the row count -- every output row depends on its input row only)
         pk = self.__dict__.setdefault('_packs', ops.PackCache())
         sp = self.split_operands
-        lin = lambda name, *mods: pk.get((name, sp), [m.weight for m in mods],
-                                         lambda: ops.PackedConv(torch.cat([m.weight for m in mods], 0), split=sp))
+        lin = lambda name, *mods, sp=sp: pk.get((name, sp), [m.weight for m in mods],
+                                                lambda: ops.PackedConv(torch.cat([m.weight for m in mods], 0), split=sp))
+        spd = sp and (self.dense_split or x.shape[-1] != 256)
         x = x.contiguous()
         heads = lambda t: t.view(bs, -1, self.nhead, self.dim)
         fuse = True     # measured: q | k | v (and k | v) in one launch pays at d_model 256 and, with 128-channel blocks, at 128
@@ -160,7 +163,7 @@ class LoFTREncoderLayer(nn.Module):
             q, k, v = heads(q), heads(k), heads(v)
             msg = self.attention(q, k, v, q_mask=x_mask, kv_mask=source_mask, loftr_preds=loftr_preds)
         # merge + norm1 (:60-61) in one launch: the LayerNorm runs in the Linear layer's epilogue
-        msg = ops.linear_f16s(msg.view(bs, -1, self.nhead * self.dim), lin('merge', self.merge),
+        msg = ops.linear_f16s(msg.view(bs, -1, self.nhead * self.dim), lin('merge', self.merge, sp=spd),
                               ln=(self.norm1.weight, self.norm1.bias, self.norm1.eps))
         if self.fused_mlp and sp and x.shape[-1] == 128:
             # d_model 128 (the fine-level windows: bandwidth-bound): mlp[0] + ReLU + mlp[2] + norm2 + residual (:64-67) in
@@ -169,9 +172,9 @@ class LoFTREncoderLayer(nn.Module):
                         lambda: ops.PackedMlp(self.mlp[0].weight, self.mlp[2].weight))
             return ops.mlp_fused(x, msg.contiguous(), pm, self.norm2.weight, self.norm2.bias, self.norm2.eps, out=out)
         # mlp[0](cat[x, msg]) reads both inputs in place (:64), ReLU in the epilogue
-        h = ops.linear_f16s(x, lin('mlp0', self.mlp[0]), act='relu', x2=msg)
+        h = ops.linear_f16s(x, lin('mlp0', self.mlp[0], sp=spd), act='relu', x2=msg)
         # mlp[2] + norm2 + the residual `x + message` (:65-67) in one launch
-        return ops.linear_f16s(h, lin('mlp2', self.mlp[2]), ln=(self.norm2.weight, self.norm2.bias, self.norm2.eps),
+        return ops.linear_f16s(h, lin('mlp2', self.mlp[2], sp=spd), ln=(self.norm2.weight, self.norm2.bias, self.norm2.eps),
                                post_residual=x, out=out)
 
 
@@ -504,7 +507,7 @@ class LocalFeatureTransformerRegressor(nn.Module):
         if self.config['regress']['use_simple_moe']:        # their feature-only part travels with the features (HeadFeatures)
             mods += [self.encoder[0], self.moe_predictor[0]]
         ws = tuple((p.data_ptr(), ops.tensor_version(p)) for m in mods for p in m.parameters())
-        prec = tuple(m.split_operands for m in self.modules() if isinstance(m, LoFTREncoderLayer))
+        prec = tuple((m.split_operands, m.dense_split) for m in self.modules() if isinstance(m, LoFTREncoderLayer))
         return ws, prec, self.training, ops.activation_exponent_value(), self.emm.cross_attn.exact_f32, self.emm.cross_attn.plain16
 
     def compute_features(self, feat0, feat1, loftr_preds=None, inv_loftr_preds=None):
