@@ -156,7 +156,7 @@ class EncLayer(ctypes.Structure):
                [(n, ctypes.c_void_p) for n in ('g1', 'b1', 'g2', 'b2', 'overflow')]
 
 
-EXPECTED_ABI = 6          # far_abi_version() of the library these signatures describe (include/far_hip.h)
+EXPECTED_ABI = 7          # far_abi_version() of the library these signatures describe (include/far_hip.h)
 _lib = None
 
 

@@ -4,7 +4,7 @@
 static thread_local int g_last_hip_error = 0;
 void far_record_hip_error(int e) { g_last_hip_error = e; }
 
-extern "C" int far_abi_version(void) { return 6; }
+extern "C" int far_abi_version(void) { return 7; }
 // The id of the sources this library was built from: sha256/16 over far_amd/csrc/* and the compiler flags (far_amd/build.py
 // source_id(), passed as -DFAR_BUILD_ID when this file is compiled).  "unknown" for a build that did not go through build.py.
 #ifndef FAR_BUILD_ID
