@@ -831,19 +831,20 @@ def main():
     # pose error of the solver and of the blended head output against the synthetic ground truth
     # (pure lateral translation, no rotation): informational -- the banded synthetic pairs carry the usual
     # small-baseline translation/rotation ambiguity; accuracy on Matterport needs the real checkpoint + data.
-    from far_amd import metrics as fm
-    from far_amd.pose6d import pose_mean_6d, pose_std_6d, rotation_6d_to_matrix
-    T_gt = torch.eye(4, dtype=torch.float64, device=dev).repeat(a.pairs, 1, 1)
-    T_gt[:, 0, 3] = -1.0
-    rt = last['loftr_rt'].reshape(-1, 3, 4)
-    te, Re, _ = fm.relative_pose_error_batch(T_gt, rt[:, :, :3], rt[:, :, 3])
-    reg = last['regressed_rt'].detach().float().cpu()
-    Rr = rotation_6d_to_matrix(reg[:, 3:] * pose_std_6d[3:] + pose_mean_6d[3:])
-    tr = reg[:, :3] * pose_std_6d[:3] + pose_mean_6d[:3]
-    te2, Re2, _ = fm.relative_pose_error_batch(T_gt.cpu(), Rr, tr)
-    pose_err = {'solver_median_R_deg': round(float(Re.median()), 3), 'solver_median_t_deg': round(float(te.median()), 3),
-                'head_median_R_deg': round(float(Re2.median()), 3), 'head_median_t_deg': round(float(te2.median()), 3),
-                'note': 'vs synthetic GT (R=I, t=-x); random-weight head; Matterport accuracy pending (no ckpt/data offline)'}
+    def pose_errors(out):
+        from far_amd import metrics as fm
+        from far_amd.pose6d import pose_mean_6d, pose_std_6d, rotation_6d_to_matrix
+        T_gt = torch.eye(4, dtype=torch.float64, device=dev).repeat(a.pairs, 1, 1)
+        T_gt[:, 0, 3] = -1.0
+        rt = out['loftr_rt'].reshape(-1, 3, 4)
+        te, Re, _ = fm.relative_pose_error_batch(T_gt, rt[:, :, :3], rt[:, :, 3])
+        reg = out['regressed_rt'].detach().float().cpu()
+        Rr = rotation_6d_to_matrix(reg[:, 3:] * pose_std_6d[3:] + pose_mean_6d[3:])
+        tr = reg[:, :3] * pose_std_6d[:3] + pose_mean_6d[:3]
+        te2, Re2, _ = fm.relative_pose_error_batch(T_gt.cpu(), Rr, tr)
+        return {'solver_median_R_deg': round(float(Re.median()), 3), 'solver_median_t_deg': round(float(te.median()), 3),
+                'head_median_R_deg': round(float(Re2.median()), 3), 'head_median_t_deg': round(float(te2.median()), 3)}
+    pose_err = dict(pose_errors(last), note='vs synthetic GT (R=I, t=-x); random-weight head; Matterport accuracy pending (no ckpt/data offline)')
 
     # N > 1: the dense-f16 MFMA rate every rank sustains right now (far_mfma_probe_f16 on all ranks at once): under one node's
     # power envelope a sub-linear scaling curve can then be told apart from ranks that simply clock lower together
@@ -935,23 +936,26 @@ def main():
                 fence()
                 t1 = time.perf_counter()
                 for _ in range(n):
-                    step()
+                    out = step()
                 fence()
+                dtm_ = (time.perf_counter() - t1) / n
                 model.set_precision('fp32')
-                return (time.perf_counter() - t1) / n
-            dt16 = timed_mode('fp16')
-            dtm = timed_mode('mixed16')
-            dtf = timed_mode('fp16-fine')
+                ids = set(zip(out['b_ids'].tolist(), out['i_ids'].tolist(), out['j_ids'].tolist()))
+                acc = dict(pose_errors(out), matches_per_pair=round(len(ids) / a.pairs, 1),
+                           match_set_iou_vs_parity_line=round(len(ids & ids32) / max(len(ids | ids32), 1), 4))
+                return dtm_, acc
+            ids32 = set(zip(last['b_ids'].tolist(), last['i_ids'].tolist(), last['j_ids'].tolist()))
+            (dt16, acc16), (dtm, accm), (dtf, accf) = timed_mode('fp16'), timed_mode('mixed16'), timed_mode('fp16-fine')
             res['other_modes'] = {'fp16_fine': {'value': round(a.pairs / dtf, 3), 'ms_per_step': round(1000 * dtf, 3),
                                                 'note': "plain fp16 operands in the FPN's fine branch only: every coarse decision (ids, mconf) "
-                                                        'bit-identical to the parity line, sub-pixel refinement deviates ~0.01 px'},
+                                                        'bit-identical to the parity line, sub-pixel refinement deviates ~0.01 px', 'accuracy': accf},
                                   'fp16_operands': {'value': round(a.pairs / dt16, 3), 'ms_per_step': round(1000 * dt16, 3),
                                                     'note': 'plain fp16 operands in the backbone / encoder matrix products, fp32 tensors and '
-                                                            'accumulation; informational, not the parity line'},
+                                                            'accumulation; informational, not the parity line', 'accuracy': acc16},
                                   'mixed16': {'value': round(a.pairs / dtm, 3), 'ms_per_step': round(1000 * dtm, 3),
                                               'note': 'plain-fp16 operands in the backbone K9, bf16 in K1, plain fp16 in K2; the encoder layers on '
                                                       'their split-fp16 fused kernels; fp32 tensors and accumulation; the 16-bit-operand class '
-                                                      'BASELINE configs[1] runs the reference in; informational, not the parity line'}}
+                                                      'BASELINE configs[1] runs the reference in; informational, not the parity line', 'accuracy': accm}}
         if world == 1 and not a.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(a.cpu_pairs, a.hyp)
         if per_rank_peak is not None:

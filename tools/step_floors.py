@@ -186,7 +186,7 @@ def main():
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--pairs', type=int, default=32)
     ap.add_argument('--out', default=None)
-    ap.add_argument('--precision', default='fp32', help="LoFTR.set_precision mode ('fp16': plain fp16 operands in K9 -- the floors then still assume split operands: read the measured column only)")
+    ap.add_argument('--precision', default='fp32', help="LoFTR.set_precision mode; the MFMA floors follow each launch's operand form (x3 for split pairs, x1 for plain fp16 / bf16)")
     ap.add_argument('--bf16-k1', action='store_true', help='with --precision fp16: the coarse matcher on its bf16 variant too')
     a = ap.parse_args()
     from far_amd import _lib, synth
@@ -271,7 +271,7 @@ def main():
     w('')
     w(f'## totals over the {n} calls')
     w(f'measured                         {tot_ms:8.2f} ms   (+ {max(unattributed, 0):.2f} ms outside the C ABI: ATen glue, idle)')
-    w(f'sum of max(hbm, mfma) floors     {sol_max:8.2f} ms   = the step\'s speed of light at fp32-grade if every launch overlapped its two floors perfectly')
+    w(f'sum of max(hbm, mfma) floors     {sol_max:8.2f} ms   = the step\'s speed of light in precision mode {a.precision!r} if every launch overlapped its two floors perfectly')
     w(f'sum of (hbm + mfma) floors       {sol_sum:8.2f} ms   = if no launch overlapped them at all')
     pairs = a.pairs
     w(f'pairs/s: measured {pairs / plain_ms * 1e3:.0f}; at sum-of-max {pairs / (sol_max + max(unattributed, 0)) * 1e3:.0f}; at sum-of-sum {pairs / (sol_sum + max(unattributed, 0)) * 1e3:.0f}'
