@@ -950,12 +950,13 @@ def main():
                                                 'note': "plain fp16 operands in the FPN's fine branch only: every coarse decision (ids, mconf) "
                                                         'bit-identical to the parity line, sub-pixel refinement deviates ~0.01 px', 'accuracy': accf},
                                   'fp16_operands': {'value': round(a.pairs / dt16, 3), 'ms_per_step': round(1000 * dt16, 3),
-                                                    'note': 'plain fp16 operands in the backbone / encoder matrix products, fp32 tensors and '
-                                                            'accumulation; informational, not the parity line', 'accuracy': acc16},
+                                                    'note': '16-bit operands in the large matrix products of the step (plain fp16 in K9 incl. the '
+                                                            'fused k|v-state / q-apply launches, K13 / K14, K2; bf16 in K1), fp32 tensors and accumulation: '
+                                                            'the precision class BASELINE configs[1] names; informational, not the parity line',
+                                                    'accuracy': acc16},
                                   'mixed16': {'value': round(a.pairs / dtm, 3), 'ms_per_step': round(1000 * dtm, 3),
-                                              'note': 'plain-fp16 operands in the backbone K9, bf16 in K1, plain fp16 in K2; the encoder layers on '
-                                                      'their split-fp16 fused kernels; fp32 tensors and accumulation; the 16-bit-operand class '
-                                                      'BASELINE configs[1] runs the reference in; informational, not the parity line', 'accuracy': accm}}
+                                              'note': "between the two: as fp16_operands, but the encoder layers' attention-state launches and the "
+                                                      'fine level (K13 / K14) on split-fp16 operands; informational, not the parity line', 'accuracy': accm}}
         if world == 1 and not a.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(a.cpu_pairs, a.hyp)
         if per_rank_peak is not None:

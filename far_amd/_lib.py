@@ -58,6 +58,8 @@ SIGNATURES = {
     'far_attn_block_f16s': (c_i, [c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_f, c_p, c_p, c_p]),
     'far_mlp_fused_packed_bytes': (c_sz, [c_i]),
     'far_mlp_fused_f16s': (c_i, [c_p, c_p, c_p, c_l, c_i, c_f, c_f, c_p, c_p, c_f, c_p, c_p, c_p]),
+    'far_mlp_fused_f16': (c_i, [c_p, c_p, c_p, c_l, c_i, c_f, c_f, c_p, c_p, c_f, c_p, c_p, c_p]),
+    'far_attn_block_f16': (c_i, [c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_f, c_p, c_p, c_p]),
     'far_affine_act_f32': (c_i, [c_p, c_p, c_p, c_p, c_l, c_i, c_l, c_i, c_i, c_f, c_p, c_p]),
     'far_upsample2x_add_f32': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     'far_upsample2x_bwd_f32': (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p]),

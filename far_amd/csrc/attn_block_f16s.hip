@@ -107,8 +107,11 @@ __device__ __forceinline__ void split8(const float4& u, const float4& v, float s
     const float x[8] = {u.x * scale, u.y * scale, u.z * scale, u.w * scale, v.x * scale, v.y * scale, v.z * scale, v.w * scale};
     split_regs(x, hi, lo);
 }
+// SPLIT = false (far_attn_block_f16, round 5): plain fp16 operands -- the hi.hi product only; the data movement is unchanged
+template <bool SPLIT>
 __device__ __forceinline__ f32x16 mma3(const f16x8& ah, const f16x8& al, const f16x8& bh, const f16x8& bl, f32x16 c) {
     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
+    if (!SPLIT) return c;
     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c, 0, 0, 0);
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);
 }
@@ -142,7 +145,7 @@ __device__ __forceinline__ void wait_vm(int n) {
 // elu got cheap (5 and 156 windows of 120 296 differing per launch, whole workgroups in the counted form); the 8-wave form is
 // (four launches bit-identical, the 50-launch test of tests/test_attn_block_gpu.py, and the bench-scale test added with it).
 // The cause was not isolated -- the same hand-synchronised ring is airtight with one workgroup per CU here and in K17.
-template <int NW, int NR, bool CNT>
+template <int NW, int NR, bool CNT, bool SPLIT>
 __global__ __launch_bounds__(64 * NW, 2) void k_attn128(const float* __restrict__ x, const float* __restrict__ src,
                                                         const unsigned char* __restrict__ wimg, long nwin, int L, int S, Scales sc,
                                                         float attn_eps, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -217,8 +220,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_attn128(const float* __restrict_
                 wl[(i + 2) % 3] = *reinterpret_cast<const f16x8*>(slab + (i + 2) * 2048 + 1024);
             }
             const int ks = i / CT, t = i % CT;
-            if (TR) acc[t] = mma3(wh[i % 3], wl[i % 3], xh[ks], xl[ks], acc[t]);
-            else acc[t] = mma3(xh[ks], xl[ks], wh[i % 3], wl[i % 3], acc[t]);
+            if (TR) acc[t] = mma3<SPLIT>(wh[i % 3], wl[i % 3], xh[ks], xl[ks], acc[t]);
+            else acc[t] = mma3<SPLIT>(xh[ks], xl[ks], wh[i % 3], wl[i % 3], acc[t]);
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
         }
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_attn128(const float* __restrict_
             f16x8 ah, al, bh, bl;
             split_regs(a8, ah, al);
             split_regs(b8, bh, bl);
-            kv[t] = mma3(ah, al, bh, bl, kv[t]);
+            kv[t] = mma3<SPLIT>(ah, al, bh, bl, kv[t]);
         }
     // kv[t][r]: d = mfma32_row(r, h), e = l31; drop the cross-head quarters (head = channel / 16) and the two 2^4 scales
 #pragma unroll
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_attn128(const float* __restrict_
             f16x8 ah, al, bh, bl;
             split_regs(a8, ah, al);
             split_regs(b8, bh, bl);
-            ma[t] = mma3(ah, al, bh, bl, ma[t]);
+            ma[t] = mma3<SPLIT>(ah, al, bh, bl, ma[t]);
         }
         // out = (Q KV) Z S, Z = 1 / (Q . ksum + eps)  (:46, :50); registers r < 8 belong to head 2 t, the others to 2 t + 1
         const float z0 = fS / (den0 + attn_eps), z1 = fS / (den1 + attn_eps);
@@ -364,7 +367,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_attn128(const float* __restrict_
                 bl[(i + 2) % 3] = *reinterpret_cast<const f16x8*>(slab + ((i + 2) * 2 + 1) * 1024);
             }
             const int u = i / CT, ct = i % CT;
-            mg[ct] = mma3(ah[u], al[u], bh[i % 3], bl[i % 3], mg[ct]);
+            mg[ct] = mma3<SPLIT>(ah[u], al[u], bh[i % 3], bl[i % 3], mg[ct]);
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
         }
@@ -411,12 +414,15 @@ extern "C" {
 
 size_t far_attn_block_packed_bytes(int d_model) { return d_model == DM ? (size_t)NSLAB * SLAB : 0; }
 
+}  // extern "C"
+
 // out [nwin][L][128] = norm1(merge(LinearAttention(q_proj(x), k_proj(src), v_proj(src))))   (transformer.py:51-61 at d_model = 128,
 // 8 heads of 16, sequences of at most 32 tokens: the fine-level windows).  x [nwin][L][128], src [nwin][S][128] fp32;
 // packed: the image far_amd/ops.py:PackedAttn builds; scale_* = 2^-(w_exp + 4) of Wk, Wv, Wq, Wm; out must not alias x / src.
-int far_attn_block_f16s(const float* x, const float* src, const void* packed, long nwin, int L, int S, int d_model, int heads,
-                        float scale_k, float scale_v, float scale_q, float scale_m, float attn_eps, const float* gamma,
-                        const float* beta, float ln_eps, float* out, int* overflow, hipStream_t stream) {
+template <bool SPLIT>
+static int attn_block_launch(const float* x, const float* src, const void* packed, long nwin, int L, int S, int d_model, int heads,
+                             float scale_k, float scale_v, float scale_q, float scale_m, float attn_eps, const float* gamma,
+                             const float* beta, float ln_eps, float* out, int* overflow, hipStream_t stream) {
     far_clear_errors();
     if (nwin == 0) return FAR_OK;
     if (!x || !src || !packed || !gamma || !beta || !out || nwin < 0 || L <= 0 || S <= 0 || L > 32 || S > 32 ||
@@ -424,13 +430,31 @@ int far_attn_block_f16s(const float* x, const float* src, const void* packed, lo
         return FAR_EINVAL;
     const Scales sc{scale_k, scale_v, scale_q, scale_m};
     bool cfg_failed = false;
-    FAR_ONCE_PER_DEVICE(cfg_failed = hipFuncSetAttribute((const void*)k_attn128<WAVES, RING, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_NEW) != hipSuccess);
+    FAR_ONCE_PER_DEVICE(cfg_failed = hipFuncSetAttribute((const void*)k_attn128<WAVES, RING, true, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_NEW) != hipSuccess);
     if (cfg_failed) return far_check_launch();
     const long nb = (nwin + WAVES - 1) / WAVES;
     if (nb > 0x7fffffffL) return FAR_EINVAL;
-    hipLaunchKernelGGL((k_attn128<WAVES, RING, true>), dim3((unsigned)nb), dim3(64 * WAVES), SMEM_NEW, stream, x, src,
+    hipLaunchKernelGGL((k_attn128<WAVES, RING, true, SPLIT>), dim3((unsigned)nb), dim3(64 * WAVES), SMEM_NEW, stream, x, src,
                        (const unsigned char*)packed, nwin, L, S, sc, attn_eps, gamma, beta, ln_eps, out, overflow);
     return far_check_launch();
+}
+
+extern "C" {
+
+int far_attn_block_f16s(const float* x, const float* src, const void* packed, long nwin, int L, int S, int d_model, int heads,
+                        float scale_k, float scale_v, float scale_q, float scale_m, float attn_eps, const float* gamma,
+                        const float* beta, float ln_eps, float* out, int* overflow, hipStream_t stream) {
+    return attn_block_launch<true>(x, src, packed, nwin, L, S, d_model, heads, scale_k, scale_v, scale_q, scale_m, attn_eps, gamma, beta,
+                                   ln_eps, out, overflow, stream);
+}
+
+// The same block on plain fp16 operands (one MFMA per product; the 16-bit-operand class, LoFTR.set_precision('fp16')): same
+// arguments, same packed image (its lo planes are loaded and not used), same activation-range flag.
+int far_attn_block_f16(const float* x, const float* src, const void* packed, long nwin, int L, int S, int d_model, int heads,
+                       float scale_k, float scale_v, float scale_q, float scale_m, float attn_eps, const float* gamma,
+                       const float* beta, float ln_eps, float* out, int* overflow, hipStream_t stream) {
+    return attn_block_launch<false>(x, src, packed, nwin, L, S, d_model, heads, scale_k, scale_v, scale_q, scale_m, attn_eps, gamma, beta,
+                                    ln_eps, out, overflow, stream);
 }
 
 }  // extern "C"

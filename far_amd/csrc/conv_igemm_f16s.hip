@@ -1697,8 +1697,15 @@ int conv_nhwc_impl(const far_conv_desc* desc, const KvMode* kvm, hipStream_t str
         return c.mw == 4 ? launch_conv<1, 4, 1, 4, true, 1, 0, false, 3>(a, grid, stream)
                          : launch_conv<1, 2, 2, 4, true, 1, 0, false, 3>(a, grid, stream);
     }
-    if (kvm) {                                     // (validated by far_linear_kv_f16s: 256-column blocks, split operands)
-        if (c.mw != 2 || !split) return FAR_EINVAL;
+    if (kvm) {                                     // (validated by far_linear_kv_f16s: 256-column blocks)
+        if (c.mw != 2) return FAR_EINVAL;
+        if (!split) {                              // plain fp16 operands in the projection's K loop; the epilogue's own small products stay split
+            if (kvm->epi == 2)
+                return small ? launch_conv<1, 1, 2, 4, false, 1, false, false, 2>(a, grid, stream)
+                             : launch_conv<1, 2, 2, 4, false, 1, false, false, 2>(a, grid, stream);
+            return small ? launch_conv<1, 1, 2, 4, false, 1, false, false, 1>(a, grid, stream)
+                         : launch_conv<1, 2, 2, 4, false, 1, false, false, 1>(a, grid, stream);
+        }
         if (kvm->epi == 2)
             return small ? launch_conv<1, 1, 2, 4, true, 1, false, false, 2>(a, grid, stream)
                          : launch_conv<1, 2, 2, 4, true, 1, false, false, 2>(a, grid, stream);
@@ -1732,7 +1739,7 @@ int far_linear_kv_f16s(const far_conv_desc* desc, int S, void* ws, float* kv, vo
     far_clear_errors();
     const long rows = d.N * d.H * d.W;
     if (rows == 0) return FAR_OK;
-    if (!ws || !kv || S < 64 || rows < 0 || rows % S || d.ksize != 1 || d.stride != 1 || !d.split || d.Cout != 512 ||
+    if (!ws || !kv || S < 64 || rows < 0 || rows % S || d.ksize != 1 || d.stride != 1 || d.Cout != 512 ||
         d.out_planes != 2 || d.act != 0 || d.res || d.ln_gamma || d.post_res || d.up || d.x2 || d.res_group != 1 || rows / S > 65535 ||
         d.act_scale_dev)
         return FAR_EINVAL;
@@ -1758,7 +1765,7 @@ int far_linear_q_apply_f16s(const far_conv_desc* desc, int L, int S, const void*
     far_clear_errors();
     const long rows = d.N * d.H * d.W;
     if (rows == 0) return FAR_OK;
-    if (!kv_img || !d.y || L < 64 || S <= 0 || rows < 0 || rows % L || d.ksize != 1 || d.stride != 1 || !d.split ||
+    if (!kv_img || !d.y || L < 64 || S <= 0 || rows < 0 || rows % L || d.ksize != 1 || d.stride != 1 ||
         d.Cout != 256 || d.out_planes != 1 || d.act != 0 || d.res || d.ln_gamma || d.post_res || d.up || d.x2 || d.res_group != 1 ||
         d.act_scale_dev)
         return FAR_EINVAL;

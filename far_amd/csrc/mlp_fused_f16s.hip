@@ -70,6 +70,8 @@ __device__ __forceinline__ float sum32(float v) {
 // one chunk ahead, so the youngest is a phase old (measured: no slower than counted waits; see attn_block_f16s.hip for why
 // the counted form was dropped).
 
+// SPLIT = false (far_mlp_fused_f16, round 5): plain fp16 operands, one MFMA per product; the data movement is unchanged
+template <bool SPLIT>
 __global__ __launch_bounds__(256, 2) void k_mlp128(const float* __restrict__ x, const float* __restrict__ msg,
                                                    const unsigned char* __restrict__ wimg, long R, float hscale, float oscale,
                                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
@@ -148,10 +150,12 @@ __global__ __launch_bounds__(256, 2) void k_mlp128(const float* __restrict__ x, 
                 al[(t + 2) % 3] = *reinterpret_cast<const f16x8*>(slab + (t + 2) * 2048 + 1024);
             }
             acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t % 3], bh, acc1[t], 0, 0, 0);
-            acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t % 3], bl, acc1[t], 0, 0, 0);
-            acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t % 3], bh, acc1[t], 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);     // the two reads of tile t + 2
-            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);     // the three MFMAs of tile t
+            if (SPLIT) {
+                acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t % 3], bl, acc1[t], 0, 0, 0);
+                acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t % 3], bh, acc1[t], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, SPLIT ? 2 : 1, 0);     // the reads of tile t + 2
+            __builtin_amdgcn_sched_group_barrier(0x008, SPLIT ? 3 : 1, 0);     // the MFMAs of tile t
         }
     }
 
@@ -197,10 +201,12 @@ __global__ __launch_bounds__(256, 2) void k_mlp128(const float* __restrict__ x, 
             }
             const int u = i / CT, ct = i % CT;
             acc2[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha[u], bh[i % 3], acc2[ct], 0, 0, 0);
-            acc2[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha[u], bl[i % 3], acc2[ct], 0, 0, 0);
-            acc2[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hl[u], bh[i % 3], acc2[ct], 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            if (SPLIT) {
+                acc2[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha[u], bl[i % 3], acc2[ct], 0, 0, 0);
+                acc2[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hl[u], bh[i % 3], acc2[ct], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, SPLIT ? 2 : 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, SPLIT ? 3 : 1, 0);
         }
     }
 
@@ -242,6 +248,19 @@ __global__ __launch_bounds__(256, 2) void k_mlp128(const float* __restrict__ x, 
     }
 }
 
+template <bool SPLIT>
+int mlp_fused_launch(const float* x, const float* msg, const void* packed, long R, int d_model, float hscale, float oscale,
+                     const float* gamma, const float* beta, float eps, float* out, int* overflow, hipStream_t stream) {
+    far_clear_errors();
+    if (R == 0) return FAR_OK;
+    if (!x || !msg || !packed || !gamma || !beta || !out || R < 0 || d_model != DM || out == x || out == msg) return FAR_EINVAL;
+    const long nb = (R + 32 * WAVES - 1) / (32 * WAVES);
+    if (nb > 0x7fffffffL) return FAR_EINVAL;
+    hipLaunchKernelGGL(k_mlp128<SPLIT>, dim3((unsigned)nb), dim3(64 * WAVES), 0, stream, x, msg, (const unsigned char*)packed, R, hscale,
+                       oscale, gamma, beta, eps, out, overflow);
+    return far_check_launch();
+}
+
 }  // namespace
 
 extern "C" {
@@ -255,14 +274,14 @@ size_t far_mlp_fused_packed_bytes(int d_model) { return d_model == DM ? (size_t)
 //   gamma, beta [128], eps: norm2.  out may not alias x or msg.
 int far_mlp_fused_f16s(const float* x, const float* msg, const void* packed, long R, int d_model, float hscale, float oscale,
                        const float* gamma, const float* beta, float eps, float* out, int* overflow, hipStream_t stream) {
-    far_clear_errors();
-    if (R == 0) return FAR_OK;
-    if (!x || !msg || !packed || !gamma || !beta || !out || R < 0 || d_model != DM || out == x || out == msg) return FAR_EINVAL;
-    const long nb = (R + 32 * WAVES - 1) / (32 * WAVES);
-    if (nb > 0x7fffffffL) return FAR_EINVAL;
-    hipLaunchKernelGGL(k_mlp128, dim3((unsigned)nb), dim3(64 * WAVES), 0, stream, x, msg, (const unsigned char*)packed, R, hscale,
-                       oscale, gamma, beta, eps, out, overflow);
-    return far_check_launch();
+    return mlp_fused_launch<true>(x, msg, packed, R, d_model, hscale, oscale, gamma, beta, eps, out, overflow, stream);
+}
+
+// The same block on plain fp16 operands (one MFMA per product; the 16-bit-operand class, LoFTR.set_precision('fp16')): same
+// arguments, same packed image (its lo planes are loaded and not used), same activation-range flag.
+int far_mlp_fused_f16(const float* x, const float* msg, const void* packed, long R, int d_model, float hscale, float oscale,
+                      const float* gamma, const float* beta, float eps, float* out, int* overflow, hipStream_t stream) {
+    return mlp_fused_launch<false>(x, msg, packed, R, d_model, hscale, oscale, gamma, beta, eps, out, overflow, stream);
 }
 
 }  // extern "C"

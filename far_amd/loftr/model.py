@@ -107,13 +107,17 @@ class LoFTR(nn.Module):
           'fp32'      K9 with split-fp16 operand pairs: fp32-grade -- the parity configuration (default);
           'fp16-fine' split trunk + plain-fp16 operands in the FPN branch: coarse features and match decisions stay
                       bit-identical, only the sub-pixel refinement input changes;
-          'fp16'      plain fp16 operands everywhere in K9 -- backbone and the encoder layers' Linear layers (fp32
-                      accumulation, fp32 activations): the 16-bit-operand configuration of BASELINE configs[1];
-          'mixed16'   16-bit operands where they pay, the fused kernels elsewhere (round 5): plain-fp16 K9 in the backbone,
+          'fp16'      16-bit operands in the step's large matrix products (fp32 accumulation, fp32 tensors): plain fp16 in K9
+                      (backbone, encoder layers incl. the fused k|v-state / q-apply launches, the head's qkv projection),
+                      K13 / K14 (far_mlp_fused_f16, far_attn_block_f16) and K2 (far_emm_pv_f16), bf16 in K1
+                      (far_coarse_match_bf16) -- the precision class BASELINE configs[1] names and the reference runs in
+                      under autocast; the fastest mode.  (FinePreprocess's two projections, the attention-state products
+                      inside the epilogues and the head's small dense layers keep fp32-grade products: < 2 % of the step);
+          'mixed16'   between the two (round 5): plain-fp16 K9 in the backbone,
                       bf16 operands in K1 (far_coarse_match_bf16), plain-fp16 operands in K2 (far_emm_pv_f16) and in the
                       d_model-256 layers' merge / MLP launches; their fused k|v-state / q-apply launches and the fine
-                      level's K13 / K14 stay on split operands (those fused kernels are faster than the unfused
-                      plain-fp16 launches 'fp16' falls back to).  Same precision class as 'fp16';
+                      level's K13 / K14 stay on split operands: the attention states and the sub-pixel refinement keep
+                      fp32-grade products;
           'bf16'      the vendor convolutions under bf16 autocast (reference-style modules), channels_last."""
         if mode not in self.PRECISIONS:
             raise ValueError(f'precision must be one of {self.PRECISIONS}')
@@ -126,9 +130,9 @@ class LoFTR(nn.Module):
                 m.split_operands = mode != 'fp16'
                 m.dense_split = mode != 'mixed16'
             if isinstance(m, CrossAttention):
-                m.plain16 = mode == 'mixed16'
+                m.plain16 = mode in ('mixed16', 'fp16')
         if hasattr(self, 'coarse_matching'):
-            self.coarse_matching.bf16 = mode == 'mixed16'
+            self.coarse_matching.bf16 = mode in ('mixed16', 'fp16')
         return self
 
     # -------------------------------------------------------------------------------------------------

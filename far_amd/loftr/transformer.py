@@ -119,21 +119,22 @@ class LoFTREncoderLayer(nn.Module):
         heads = lambda t: t.view(bs, -1, self.nhead, self.dim)
         fuse = True     # measured: q | k | v (and k | v) in one launch pays at d_model 256 and, with 128-channel blocks, at 128
         source = source.contiguous()
-        if (self.fused_attn and sp and x.shape[-1] == 128 and self.nhead == 8 and x.shape[1] <= 32 and source.shape[1] <= 32
+        if (self.fused_attn and x.shape[-1] == 128 and self.nhead == 8 and x.shape[1] <= 32 and source.shape[1] <= 32
                 and x_mask is None and source_mask is None):
             # d_model 128 on short sequences (the fine-level windows: bandwidth-bound): the whole layer in two launches --
             # K14 (q / k / v projections, linear attention, merge, norm1) and K13 (the MLP block, norm2, residual)
             pa = pk.get(('attn-fused',), [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight, self.merge.weight],
                         lambda: ops.PackedAttn(self.q_proj.weight, self.k_proj.weight, self.v_proj.weight, self.merge.weight))
-            msg = ops.attn_block(x, source, pa, self.nhead, self.norm1.weight, self.norm1.bias, self.norm1.eps, self.attention.eps)
+            msg = ops.attn_block(x, source, pa, self.nhead, self.norm1.weight, self.norm1.bias, self.norm1.eps, self.attention.eps,
+                                 plain16=not sp)
             if self.fused_mlp:
                 pm = pk.get(('mlp-fused',), [self.mlp[0].weight, self.mlp[2].weight],
                             lambda: ops.PackedMlp(self.mlp[0].weight, self.mlp[2].weight))
-                return ops.mlp_fused(x, msg, pm, self.norm2.weight, self.norm2.bias, self.norm2.eps, out=out)
+                return ops.mlp_fused(x, msg, pm, self.norm2.weight, self.norm2.bias, self.norm2.eps, out=out, plain16=not sp)
             h = ops.linear_f16s(x, lin('mlp0', self.mlp[0]), act='relu', x2=msg)
             return ops.linear_f16s(h, lin('mlp2', self.mlp[2]), ln=(self.norm2.weight, self.norm2.bias, self.norm2.eps),
                                    post_residual=x, out=out)
-        if (self.fused_kv and sp and x.shape[-1] == 256 and self.nhead == 8 and source.shape[1] >= 64 and x_mask is None
+        if (self.fused_kv and x.shape[-1] == 256 and self.nhead == 8 and source.shape[1] >= 64 and x_mask is None
                 and source_mask is None):
             # d_model 256 (the coarse level, the head's layers): the k | v projection ends in K'^T V (linear_attention.py:38-45)
             # instead of a store -- k and v (4 of the layer's 19 passes over a (rows, 256) tensor) never exist.  Partial sums are
@@ -165,12 +166,12 @@ class LoFTREncoderLayer(nn.Module):
         # merge + norm1 (:60-61) in one launch: the LayerNorm runs in the Linear layer's epilogue
         msg = ops.linear_f16s(msg.view(bs, -1, self.nhead * self.dim), lin('merge', self.merge, sp=spd),
                               ln=(self.norm1.weight, self.norm1.bias, self.norm1.eps))
-        if self.fused_mlp and sp and x.shape[-1] == 128:
+        if self.fused_mlp and x.shape[-1] == 128:
             # d_model 128 (the fine-level windows: bandwidth-bound): mlp[0] + ReLU + mlp[2] + norm2 + residual (:64-67) in
             # ONE launch (K13), the 256-channel hidden tensor stays in the accumulator registers
             pm = pk.get(('mlp-fused',), [self.mlp[0].weight, self.mlp[2].weight],
                         lambda: ops.PackedMlp(self.mlp[0].weight, self.mlp[2].weight))
-            return ops.mlp_fused(x, msg.contiguous(), pm, self.norm2.weight, self.norm2.bias, self.norm2.eps, out=out)
+            return ops.mlp_fused(x, msg.contiguous(), pm, self.norm2.weight, self.norm2.bias, self.norm2.eps, out=out, plain16=not sp)
         # mlp[0](cat[x, msg]) reads both inputs in place (:64), ReLU in the epilogue
         h = ops.linear_f16s(x, lin('mlp0', self.mlp[0], sp=spd), act='relu', x2=msg)
         # mlp[2] + norm2 + the residual `x + message` (:65-67) in one launch
@@ -355,7 +356,7 @@ class CrossAttention(nn.Module):
             # inference: the qkv Linear on K9 with one output plane per (tensor, head) -- the layout K2 reads in place
             pk = self.__dict__.setdefault('_packs', ops.PackCache())
             ts = [self.qkv.weight] + ([self.qkv.bias] if self.qkv.bias is not None else [])
-            pc = pk.get('qkv', ts, lambda: ops.PackedConv(self.qkv.weight, None, self.qkv.bias))
+            pc = pk.get(('qkv', self.plain16), ts, lambda: ops.PackedConv(self.qkv.weight, None, self.qkv.bias, split=not self.plain16))
             # the two images are the two halves of one (2B, N, C) buffer when they come from CrossBlock: no copy
             # (same storage, x2 right behind x1: neighbours in the allocator's pool do not qualify)
             adjacent = (x1.is_contiguous() and x2.is_contiguous() and x1.shape == x2.shape and

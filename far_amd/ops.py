@@ -1237,17 +1237,19 @@ class PackedMlp:
         self.oscale = 2.0 ** -(self.e2 + _CONV_ACT_EXP)   # accumulator of GEMM 2 -> output
 
 
-def mlp_fused(x, msg, pack, gamma, beta, eps, out=None):
-    """K13: x + LayerNorm(W2 relu(W0 [x | msg])) for (.., 128) fp32 tensors (transformer.py:64-67 at d_model = 128)."""
+def mlp_fused(x, msg, pack, gamma, beta, eps, out=None, plain16=False):
+    """K13: x + LayerNorm(W2 relu(W0 [x | msg])) for (.., 128) fp32 tensors (transformer.py:64-67 at d_model = 128).
+    plain16: plain fp16 operands (far_mlp_fused_f16) instead of split pairs."""
     lib = _lib.load()
     if x.shape != msg.shape or x.shape[-1] != pack.d:
         raise _lib.FarHipError('mlp_fused: x and msg must both be (..., 128)')
     R = x.numel() // pack.d
     y = torch.empty_like(x) if out is None else out
-    rc = lib.far_mlp_fused_f16s(_p(x, torch.float32), _p(msg, torch.float32), _p(pack.packed), R, pack.d, pack.hscale, pack.oscale,
-                                _p(gamma, torch.float32), _p(beta, torch.float32), float(eps), _p(y, torch.float32),
-                                _p(overflow_flag(x.device)), _stream())
-    _lib.check(rc, 'far_mlp_fused_f16s')
+    name = 'far_mlp_fused_f16' if plain16 else 'far_mlp_fused_f16s'
+    rc = getattr(lib, name)(_p(x, torch.float32), _p(msg, torch.float32), _p(pack.packed), R, pack.d, pack.hscale, pack.oscale,
+                            _p(gamma, torch.float32), _p(beta, torch.float32), float(eps), _p(y, torch.float32),
+                            _p(overflow_flag(x.device)), _stream())
+    _lib.check(rc, name)
     return y if out is None else _written(y)
 
 
@@ -1296,9 +1298,9 @@ class PackedAttn:
         self.scales = [2.0 ** -(ex + _CONV_ACT_EXP) for ex in self.exps]       # k, v, q, merge
 
 
-def attn_block(x, source, pack, nhead, gamma, beta, ln_eps, attn_eps=1e-6, out=None):
+def attn_block(x, source, pack, nhead, gamma, beta, ln_eps, attn_eps=1e-6, out=None, plain16=False):
     """K14: norm1(merge(LinearAttention(q_proj(x), k_proj(source), v_proj(source)))) for (N, L <= 32, 128) windows
-    (transformer.py:51-61 at d_model = 128, 8 heads)."""
+    (transformer.py:51-61 at d_model = 128, 8 heads).  plain16: plain fp16 operands (far_attn_block_f16)."""
     lib = _lib.load()
     N, L, d = x.shape
     S = source.shape[1]
@@ -1306,10 +1308,11 @@ def attn_block(x, source, pack, nhead, gamma, beta, ln_eps, attn_eps=1e-6, out=N
         raise _lib.FarHipError('attn_block: x (N, L, 128) and source (N, S, 128) expected')
     y = torch.empty_like(x) if out is None else out
     sk, sv, sq, sm = pack.scales
-    rc = lib.far_attn_block_f16s(_p(x, torch.float32), _p(source, torch.float32), _p(pack.packed), N, L, S, d, int(nhead), sk, sv, sq, sm,
-                                 float(attn_eps), _p(gamma, torch.float32), _p(beta, torch.float32), float(ln_eps), _p(y, torch.float32),
-                                 _p(overflow_flag(x.device)), _stream())
-    _lib.check(rc, 'far_attn_block_f16s')
+    name = 'far_attn_block_f16' if plain16 else 'far_attn_block_f16s'
+    rc = getattr(lib, name)(_p(x, torch.float32), _p(source, torch.float32), _p(pack.packed), N, L, S, d, int(nhead), sk, sv, sq, sm,
+                            float(attn_eps), _p(gamma, torch.float32), _p(beta, torch.float32), float(ln_eps), _p(y, torch.float32),
+                            _p(overflow_flag(x.device)), _stream())
+    _lib.check(rc, name)
     return y if out is None else _written(y)
 
 
@@ -1531,7 +1534,7 @@ def _linear_desc(x, pc, rows, y, out_planes, residual=None, res_group=1, act='no
     ptr = lambda t: _p(t, torch.float32).value
     return _lib.ConvDesc(x=ptr(x), x2=None, packed=_p(pc.packed).value, scale=ptr(pc.scale), shift=ptr(pc.shift), res=ptr(residual),
                          ln_gamma=None, ln_beta=None, post_res=None, up=None, y=ptr(y), N=1, H=1, W=rows, Cin=pc.Cin, Cin1=pc.Cin,
-                         Cout=pc.Cout, ksize=1, stride=1, act=_ACT[act], split=1, out_planes=out_planes, res_group=int(res_group),
+                         Cout=pc.Cout, ksize=1, stride=1, act=_ACT[act], split=int(pc.split), out_planes=out_planes, res_group=int(res_group),
                          slope=0.0, ln_eps=0.0, act_exp=activation_exponent_value(), overflow=overflow_flag(x.device).data_ptr(),
                          act_scale_dev=None)
 
@@ -1564,8 +1567,8 @@ def linear_kv_state(x, pc, S, want_image=False):
     rows = 1
     for d in x.shape[:-1]:
         rows *= d
-    if pc.Cout != 512 or pc.ksize != 1 or not pc.split or S < 64 or rows % S or x.shape[-1] != pc.Cin:
-        raise _lib.FarHipError('linear_kv_state: needs a split-operand 512-row k | v weight image and whole images of S >= 64 tokens')
+    if pc.Cout != 512 or pc.ksize != 1 or S < 64 or rows % S or x.shape[-1] != pc.Cin:
+        raise _lib.FarHipError('linear_kv_state: needs a 512-row k | v weight image and whole images of S >= 64 tokens')
     kv = torch.empty(rows // S, 256, 33, dtype=torch.float32, device=x.device)
     img = torch.empty(int(lib.far_linear_kv_image_bytes(rows // S)), dtype=torch.uint8, device=x.device) if want_image else None
     if rows:
@@ -1582,8 +1585,8 @@ def linear_q_apply(x, pc, image, S, eps=1e-6):
     message (N, L, 256); q is never stored.  L >= 64."""
     lib = _lib.load()
     N, L, K = x.shape
-    if pc.Cout != 256 or pc.ksize != 1 or not pc.split or K != pc.Cin or L < 64 or image.numel() != lib.far_linear_kv_image_bytes(N):
-        raise _lib.FarHipError('linear_q_apply: needs a split-operand 256-row Wq image, L >= 64 and the state image of N source images')
+    if pc.Cout != 256 or pc.ksize != 1 or K != pc.Cin or L < 64 or image.numel() != lib.far_linear_kv_image_bytes(N):
+        raise _lib.FarHipError('linear_q_apply: needs a 256-row Wq image, L >= 64 and the state image of N source images')
     out = torch.empty(N, L, 256, dtype=torch.float32, device=x.device)
     if N:
         d = _linear_desc(x, pc, N * L, out, 1)

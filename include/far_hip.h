@@ -30,7 +30,7 @@ typedef struct ihipStream_t* far_stream_t; /* == hipStream_t */
 
 /* ABI version of this header; bumped when a signature changes (2: activation exponent / overflow flag of K9, K13, K14; 3: the
  * far_wino_* / far_conv3x3_wino_f32 entry points, 16 tuning keys; 4: far_upsample2x_bwd_f32, far_fine_scatter_det_f32, far_bn_train_*, far_adamw_*; 5: far_linear_kv_f16s, far_linear_q_apply_f16s,
- * far_linear_gather_f16s, far_linear_attention_apply_f32, far_prior_from_pose_f32; 6: far_ransac_f64, far_eightpoint_f64, far_decompose_essential_f64, far_build_id; 7: far_emm_pv_f16).  far_amd/_lib.py refuses a library whose version differs. */
+ * far_linear_gather_f16s, far_linear_attention_apply_f32, far_prior_from_pose_f32; 6: far_ransac_f64, far_eightpoint_f64, far_decompose_essential_f64, far_build_id; 7: far_emm_pv_f16, far_attn_block_f16, far_mlp_fused_f16; far_linear_kv_f16s / far_linear_q_apply_f16s accept split = 0).  far_amd/_lib.py refuses a library whose version differs. */
 int far_abi_version(void);
 /* Id of the sources the library was built from: sha256/16 over far_amd/csrc/* and the compiler flags (far_amd/build.py
  * source_id()).  far_amd/_lib.py refuses a library whose id differs from the sources it sits next to. */
@@ -320,6 +320,13 @@ int far_attn_block_f16s(const float* x, const float* src, const void* packed, lo
 size_t far_mlp_fused_packed_bytes(int d_model);
 int far_mlp_fused_f16s(const float* x, const float* msg, const void* packed, long R, int d_model, float hscale, float oscale,
                        const float* gamma, const float* beta, float eps, float* out, int* overflow, far_stream_t stream);
+/* K14 / K13 on plain fp16 operands (one MFMA per product, fp32 accumulation; the 16-bit-operand class the reference runs in under
+ * autocast, LoFTR.set_precision('fp16')): same arguments, same packed images, same overflow flag as the _f16s entry points. */
+int far_attn_block_f16(const float* x, const float* src, const void* packed, long nwin, int L, int S, int d_model, int heads,
+                       float scale_k, float scale_v, float scale_q, float scale_m, float attn_eps, const float* gamma,
+                       const float* beta, float ln_eps, float* out, int* overflow, far_stream_t stream);
+int far_mlp_fused_f16(const float* x, const float* msg, const void* packed, long R, int d_model, float hscale, float oscale,
+                      const float* gamma, const float* beta, float eps, float* out, int* overflow, far_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * K7 / K8  backbone epilogues (inference): folded BatchNorm + residual + activation; FPN upsample + add

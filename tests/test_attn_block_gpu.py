@@ -49,6 +49,25 @@ def test_attn_block_matches_float64_and_the_separate_launches(N, L, S):
     assert torch.isfinite(y).all() and y.shape == x.shape
 
 
+@pytest.mark.parametrize('N,L,S', [(3, 25, 25), (777, 25, 25), (6, 17, 9)])
+def test_attn_block_plain_fp16_operands(N, L, S):
+    """far_attn_block_f16 (LoFTR.set_precision('fp16')): the same block on plain fp16 operands.  Not the parity kernel: the bar is the
+    16-bit-operand class (3e-3 of the output scale against float64), it must differ from the split result, and repeat bit for bit."""
+    from far_amd import ops
+    ws, gam, bet, g = _setup(N + L)
+    x = torch.randn(N, L, D, device='cuda', generator=g)
+    s = torch.randn(N, S, D, device='cuda', generator=g)
+    pa = ops.PackedAttn(*ws)
+    y = ops.attn_block(x, s, pa, H, gam, bet, 1e-5, plain16=True)
+    ys = ops.attn_block(x, s, pa, H, gam, bet, 1e-5)
+    ref = _ref64(x, s, ws, gam, bet)
+    sc = float(ref.abs().max())
+    e, es = float((y.double() - ref).abs().max()) / sc, float((ys.double() - ref).abs().max()) / sc
+    print(f'[k14 plain] N={N} L={L} S={S}: plain vs float64 {e:.2e} (split {es:.2e})')
+    assert torch.isfinite(y).all() and es < e < 3e-3
+    assert torch.equal(y, ops.attn_block(x, s, pa, H, gam, bet, 1e-5, plain16=True))
+
+
 def test_attn_block_self_attention_and_scales():
     """source = x (the 'self' layers), large / small weights and activations (power-of-two pre-scaling, elu on both sides)."""
     from far_amd import ops

@@ -136,6 +136,32 @@ def test_linear_kv_state_projection_fused_with_ktv(N, L, S):
         assert torch.equal(kv[n:n + 1], ops.linear_kv_state(cu(src[n:n + 1]), pkv, S)), f'image {n}'      # order whatever else is in the launch
 
 
+@pytest.mark.parametrize('N,L,S', [(3, 4800, 4800), (2, 77, 100), (3, 70, 130)])
+def test_linear_kv_state_and_q_apply_on_plain_fp16_operands(N, L, S):
+    """The same two launches with plain fp16 operands in the projections' K loops (PackedConv(split=False);
+    LoFTR.set_precision('fp16')): 16-bit-operand bar against float64, repeatable, images independent of the batch."""
+    from far_amd import ops
+    from oracle import attention as oa
+    rng = np.random.default_rng(S + L)
+    src = rng.standard_normal((N, S, 256)).astype(np.float32)
+    xq = rng.standard_normal((N, L, 256)).astype(np.float32)
+    wq, wk, wv = (rng.standard_normal((256, 256)).astype(np.float32) / 16 for _ in range(3))
+    cu = lambda a: torch.from_numpy(a).cuda()
+    pkv = ops.PackedConv(ops.kv_interleaved_weight(cu(wk), cu(wv), 8), split=False)
+    pq = ops.PackedConv(cu(wq), split=False)
+    kv, image = ops.linear_kv_state(cu(src), pkv, S, want_image=True)
+    msg = ops.linear_q_apply(cu(xq), pq, image, S)
+    k64, v64 = src.astype(np.float64) @ wk.T.astype(np.float64), src.astype(np.float64) @ wv.T.astype(np.float64)
+    ref = oa.linear_attention(xq.astype(np.float64) @ wq.T.astype(np.float64), k64, v64, 8, dtype=np.float64)
+    e = np.abs(msg.cpu().numpy() - ref).max() / np.abs(ref).max()
+    print(f'[kv state + q apply, plain fp16] N={N} L={L} S={S}: vs float64 {e:.2e}')
+    assert torch.isfinite(msg).all() and 1e-6 < e < 3e-3
+    assert torch.equal(msg, ops.linear_q_apply(cu(xq), pq, image, S))
+    kv1, im1 = ops.linear_kv_state(cu(src[N - 1:]), pkv, S, want_image=True)
+    assert torch.equal(kv1, kv[N - 1:])
+    assert torch.equal(ops.linear_q_apply(cu(xq[N - 1:]), pq, im1, S), msg[N - 1:])
+
+
 @pytest.mark.parametrize('N,L,S', [(700, 25, 25), (5, 32, 32), (7, 17, 9), (3, 1, 1), (4, 9, 30)])
 def test_linear_attention_short_windows_fused_kernel(N, L, S):
     """The one-kernel form used for short sequences with 16-channel heads (the fine-level windows): against the float64

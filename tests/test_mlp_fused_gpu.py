@@ -41,6 +41,25 @@ def test_mlp_fused_matches_float64_and_the_two_launch_path(rows):
     assert torch.isfinite(y).all() and y.shape == x.shape
 
 
+@pytest.mark.parametrize('rows', [31, 129, 25 * 777])
+def test_mlp_fused_plain_fp16_operands(rows):
+    """far_mlp_fused_f16 (LoFTR.set_precision('fp16')): plain fp16 operands; 16-bit-operand bar against float64, not the parity kernel."""
+    from far_amd import ops
+    w0, w2, gam, bet = _weights(rows)
+    g = torch.Generator(device='cuda').manual_seed(rows + 1)
+    x = torch.randn(1, rows, D, device='cuda', generator=g)
+    m = torch.randn(1, rows, D, device='cuda', generator=g)
+    pm = ops.PackedMlp(w0, w2)
+    y = ops.mlp_fused(x, m, pm, gam, bet, 1e-5, plain16=True)
+    ys = ops.mlp_fused(x, m, pm, gam, bet, 1e-5)
+    ref = _ref64(x, m, w0, w2, gam, bet, 1e-5)
+    sc = float(ref.abs().max())
+    e, es = float((y.double() - ref).abs().max()) / sc, float((ys.double() - ref).abs().max()) / sc
+    print(f'[k13 plain] rows={rows}: plain vs float64 {e:.2e} (split {es:.2e})')
+    assert torch.isfinite(y).all() and es < e < 3e-3
+    assert torch.equal(y, ops.mlp_fused(x, m, pm, gam, bet, 1e-5, plain16=True))
+
+
 def test_mlp_fused_weight_and_activation_scales():
     """Tiny / large weights (power-of-two pre-scaling per tensor), small activations, an all-negative pre-activation
     (ReLU -> zero hidden -> LayerNorm of a zero row = beta)."""

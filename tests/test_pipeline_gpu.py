@@ -614,8 +614,10 @@ def test_precision_modes_deviation(model):
     assert iou > 0.95
 
 
-def test_mixed16_mode_deviation(model):
-    """LoFTR.set_precision('mixed16') (plain-fp16 backbone K9, bf16 K1, plain-fp16 K2, split-fp16 fused encoder layers): the
+@pytest.mark.parametrize('mode', ['mixed16', 'fp16'])
+def test_mixed16_mode_deviation(model, mode):
+    """LoFTR.set_precision('mixed16') (plain-fp16 backbone K9, bf16 K1, plain-fp16 K2, split-fp16 fused encoder layers) and 'fp16'
+    (16-bit operands in the fused kernels too: far_attn_block_f16, far_mlp_fused_f16, plain k|v-state / q-apply projections): the
     16-bit-operand class, reported next to the parity line in bench.py's other_modes -- never the parity configuration.
     Bars: match-set IoU > 0.95 against the fp32-grade path, the EMM feature block within 1e-2 of its scale on the same
     coarse features, and the mode must really switch K1 / K2 (different bits) and switch back (identical bits)."""
@@ -628,7 +630,7 @@ def test_mixed16_mode_deviation(model):
         m(d32)
         feats = torch.cat([d32['featmap0'], d32['featmap1']], 0).contiguous()      # the coarse tokens (2B, 4800, 256)
         blk32 = m.loftr_regress.emm(feats)
-        m.set_precision('mixed16')
+        m.set_precision(mode)
         assert m.coarse_matching.bf16 and m.loftr_regress.emm.cross_attn.plain16 and not m.backbone.trunk_split
         m(dm)
         blk16 = m.loftr_regress.emm(feats)
@@ -643,7 +645,7 @@ def test_mixed16_mode_deviation(model):
     s16 = set(zip(dm['b_ids'].tolist(), dm['i_ids'].tolist(), dm['j_ids'].tolist()))
     iou = len(s32 & s16) / len(s32 | s16)
     dev = float((blk16 - blk32).abs().max() / blk32.abs().max())
-    print(f'mixed16: match-set IoU {iou:.4f}, EMM block max deviation / scale {dev:.3g}')
+    print(f'{mode}: match-set IoU {iou:.4f}, EMM block max deviation / scale {dev:.3g}')
     assert iou > 0.95
     assert 0 < dev < 1e-2
 

@@ -146,14 +146,14 @@ def model(name, a):
     if name == 'far_emm_contract_f32':
         Z = a[6]
         return f'K2 contraction v~^T T Z={Z}', None, None
-    if name == 'far_attn_block_f16s':
+    if name in ('far_attn_block_f16s', 'far_attn_block_f16'):
         nwin, L, S, dm = a[3], a[4], a[5], a[6]
         rows = nwin * L
         # k, v, q, merge projections (128 x 128 each) on rows x 128; the attention core itself is VALU / small
-        return f'K14 attention block d128 windows {nwin}', 4 * (nwin * (L + S) * dm + rows * dm + 4 * dm * dm), 2.0 * cN(rows, 32) * dm * dm * 4 * 3
-    if name == 'far_mlp_fused_f16s':
+        return f'K14 attention block d128 windows {nwin}', 4 * (nwin * (L + S) * dm + rows * dm + 4 * dm * dm), 2.0 * cN(rows, 32) * dm * dm * 4 * (3 if name.endswith('s') else 1)
+    if name in ('far_mlp_fused_f16s', 'far_mlp_fused_f16'):
         R, dm = a[3], a[4]
-        return f'K13 MLP block d128 rows {R}', 4 * (3 * R * dm + 6 * dm * dm), 2.0 * cN(R, 32) * (2 * dm * 2 * dm + 2 * dm * dm) * 3
+        return f'K13 MLP block d128 rows {R}', 4 * (3 * R * dm + 6 * dm * dm), 2.0 * cN(R, 32) * (2 * dm * 2 * dm + 2 * dm * dm) * (3 if name.endswith('s') else 1)
     if name == 'far_layernorm_f32':
         rows, C = a[4], a[5]
         return f'K6 LayerNorm rows {rows} C={C}', 4 * rows * C * (3 if a[3] else 2), None
