@@ -12,7 +12,7 @@ mkdir -p $R/gpurun_out
 (cd $R; timeout 400 python bench.py > gpurun_out/bench_plain.log 2> gpurun_out/bench_plain.err)
 cd /tmp; export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_bench -o bench -- python3 $R/bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-other-modes --no-other-workloads > $R/gpurun_out/bench_prof.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_mixed16 -o bench -- python3 $R/bench.py --precision mixed16 --steps 3 --warmup 3 --no-cpu-baseline --no-other-modes --no-other-workloads --skip-rooflines > $R/gpurun_out/bench_mixed16_prof.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_fp16 -o bench -- python3 $R/bench.py --precision fp16 --steps 3 --warmup 3 --no-cpu-baseline --no-other-modes --no-other-workloads --skip-rooflines > $R/gpurun_out/bench_fp16_prof.log 2>&1
 timeout 200 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/pmc_fetch -o f -- python3 $R/tools/kprobe.py pmc 32 2 > $R/gpurun_out/pmc_fetch.log 2>&1
 timeout 200 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/pmc_write -o w -- python3 $R/tools/kprobe.py pmc 32 2 > $R/gpurun_out/pmc_write.log 2>&1
 cd $R
@@ -26,7 +26,7 @@ timeout 300 python tools/stride_ab.py > gpurun_out/${TAG}_stride_ab.json 2> gpur
 python tools/profile_report.py /tmp/prof_c3/c3_results.db > gpurun_out/${TAG}_c3_trace.txt 2>&1
 python tools/aten_in_step.py /tmp/prof_c3/c3_results.db > gpurun_out/${TAG}_c3_vendor_kernels.txt 2>&1
 python tools/profile_report.py gpurun_out/prof_bench/bench_results.db > gpurun_out/${TAG}_trace.txt 2>&1
-python tools/profile_report.py gpurun_out/prof_mixed16/bench_results.db > gpurun_out/${TAG}_trace_mixed16.txt 2>&1
+python tools/profile_report.py gpurun_out/prof_fp16/bench_results.db > gpurun_out/${TAG}_trace_fp16.txt 2>&1
 FAR_COMMIT=${FAR_COMMIT:-unknown} python tools/pmc_traffic.py gpurun_out/pmc_fetch/f_results.db gpurun_out/pmc_write/w_results.db > gpurun_out/${TAG}_pmc_traffic.json 2> gpurun_out/pmc_err.log
-rm -rf gpurun_out/prof_bench gpurun_out/prof_mixed16 gpurun_out/pmc_fetch gpurun_out/pmc_write      # the databases exceed gpurun's 64 MiB copy-back limit
+rm -rf gpurun_out/prof_bench gpurun_out/prof_fp16 gpurun_out/pmc_fetch gpurun_out/pmc_write      # the databases exceed gpurun's 64 MiB copy-back limit
 tail -c 300 gpurun_out/bench_plain.log; echo; head -c 300 gpurun_out/${TAG}_pmc_traffic.json

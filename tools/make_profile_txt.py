@@ -71,18 +71,18 @@ if os.path.exists(G + f'{tag}_c3_trace.txt') and os.path.exists(G + 'bench_c3.lo
 if os.path.exists(G + 'bench_c5.log'):
     open(ROOT + f'/profiles/{tag}_bench_c5_line.json', 'w').write(last_json(G + 'bench_c5.log') + '\n')
 
-# ---- the 16-bit-operand mode (LoFTR.set_precision('mixed16')): informational line + its kernel trace
-if os.path.exists(G + f'{tag}_trace_mixed16.txt') and os.path.exists(G + 'bench_mixed16_prof.log'):
-    trm = open(G + f'{tag}_trace_mixed16.txt').read()
+# ---- the 16-bit-operand mode (LoFTR.set_precision('fp16')): informational line + its kernel trace
+if os.path.exists(G + f'{tag}_trace_fp16.txt') and os.path.exists(G + 'bench_fp16_prof.log'):
+    trm = open(G + f'{tag}_trace_fp16.txt').read()
     wholem, winm = trm.split('\n\n', 1)
-    outm = f"""# rocprofv3 --kernel-trace --stats -- python3 bench.py --precision mixed16 --steps 3 --warmup 3 --no-cpu-baseline --no-other-modes --no-other-workloads --skip-rooflines    (round {rnd}, 1x MI355X, commit {commit})
-# the 16-bit-operand class BASELINE configs[1] names: plain-fp16 K9 in the backbone and the d256 layers' merge / MLP launches, bf16 K1, plain-fp16 K2,
-# the fused split-fp16 kernels elsewhere.  NOT the parity configuration (match-set IoU ~0.997 vs it): bench.py reports it under other_modes, never as `value`.
+    outm = f"""# rocprofv3 --kernel-trace --stats -- python3 bench.py --precision fp16 --steps 3 --warmup 3 --no-cpu-baseline --no-other-modes --no-other-workloads --skip-rooflines    (round {rnd}, 1x MI355X, commit {commit})
+# the 16-bit-operand class BASELINE configs[1] names: plain fp16 operands in K9 (backbone, encoder layers), K13 / K14 and K2, bf16 in K1;
+# fp32 tensors and accumulation.  NOT the parity configuration (match-set IoU ~0.997 vs it): bench.py reports it under other_modes, never as `value`.
 # bench line of the profiled run:
-{last_json(G + 'bench_mixed16_prof.log')}
+{last_json(G + 'bench_fp16_prof.log')}
 
 ## one steady-state step (32 pairs): per kernel
 {winm.strip()}
 """
-    open(ROOT + f'/profiles/{tag}_bench_mixed16_kernel_trace.txt', 'w').write(outm)
-    print('wrote', f'profiles/{tag}_bench_mixed16_kernel_trace.txt')
+    open(ROOT + f'/profiles/{tag}_bench_fp16_kernel_trace.txt', 'w').write(outm)
+    print('wrote', f'profiles/{tag}_bench_fp16_kernel_trace.txt')
