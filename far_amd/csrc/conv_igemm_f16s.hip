@@ -124,9 +124,10 @@ __device__ __forceinline__ void split8(const float4& u, const float4& v, float a
 }
 
 // Register staging of one chunk's input pixels: item i = (pixel i >> 2, 8-channel group i & 3).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int ITERS>
 struct Stage {
-    float4 v[ITERS][2];
+    f32x4 v[ITERS][2];
 };
 
 struct TilePos {
@@ -134,9 +135,26 @@ struct TilePos {
     long pix0;
 };
 
+// 3x3: which input pixel (index into [N][H][W], -1 = outside the image / no item) each of this thread's staging items reads.  The same
+// for every chunk of the K loop: worked out once per workgroup (a division, four bounds tests and a 64-bit multiply-add per item and
+// chunk otherwise -- ~45 VALU instructions x ITERS in the phase that requests the pixels).
+template <int KS, int MW, int ST, int NTHR, int ITERS>
+__device__ __forceinline__ void stage_pixels(int (&pixv)[ITERS], const ConvArgs& p, const TilePos& tp, int tid) {
+    using G = Geo<KS, MW, ST>;
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int i = tid + NTHR * it;
+        const int hp = i >> 2;
+        const int hy = hp / G::HW, hx = hp - hy * G::HW;
+        const int iy = ST * tp.oy0 - KS / 2 + hy, ix = ST * tp.ox0 - KS / 2 + hx;
+        const bool ok = i < G::ITEMS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        pixv[it] = ok ? (tp.img * p.H + iy) * p.W + ix : -1;          // N H W < 2^31 (checked by the host)
+    }
+}
+
 template <int KS, int MW, int ST, int NTHR, int ITERS>
 __device__ __forceinline__ void stage_load(Stage<ITERS>& st, const ConvArgs& p, const TilePos& tp, int chunk, int tid, bool live = true,
-                                           const int* rowpix = nullptr) {
+                                           const int* rowpix = nullptr, const int* pixv = nullptr) {
     using G = Geo<KS, MW, ST>;
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
@@ -145,7 +163,10 @@ __device__ __forceinline__ void stage_load(Stage<ITERS>& st, const ConvArgs& p, 
         const int c0 = 32 * chunk + 8 * g;
         bool ok = live && i < G::ITEMS;          // !live: the request is still issued (no branch), to the zero row
         long pix;
-        if (KS == 1) {
+        if (KS != 1 && pixv) {
+            pix = pixv[it];
+            ok = live && pixv[it] >= 0;
+        } else if (KS == 1) {
             pix = tp.pix0 + hp;
             ok = ok && pix < p.npix;
             if (rowpix) {                        // gather mode: the input pixel of each row of the tile, from the workgroup's LDS table
@@ -180,20 +201,26 @@ __device__ __forceinline__ void stage_load(Stage<ITERS>& st, const ConvArgs& p, 
         const float* src0 = ok0 ? base : p.zeros;
         const float* src1 = ok1 ? base + 4 : p.zeros;
 #endif
-        st.v[it][0] = *reinterpret_cast<const float4*>(src0);
-        st.v[it][1] = *reinterpret_cast<const float4*>(src1);
+        // The loads are issued from `asm`: a load the compiler knows about makes it wait for the staged registers with vmcnt(0) at the
+        // chunk's end (with LDS-DMA requests pending it never counts), which drains the weight slabs requested since -- a full memory
+        // round trip exposed per chunk (every 2 phases in Linear mode).  stage_arrived waits for exactly these loads instead.
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(st.v[it][0]) : "v"(src0) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(st.v[it][1]) : "v"(src1) : "memory");
     }
 }
 
-// "Uses" the staged values (no instruction): the compiler's wait for the loads sits here, on every path, so that no
-// load is pending -- as far as its bookkeeping goes -- when the next chunk writes the staging registers again
-// (otherwise it drains all memory requests there, the weight-slab DMAs included).
-template <int ITERS>
+// Waits until the staged values have arrived: stage_load's requests are older than the YOUNGER weight-slab requests of the chunk
+// (the memory counter retires in order), so vmcnt(YOUNGER) is exact and leaves those slabs in flight.  The staged registers are
+// operands of the statement: nothing that reads them can be scheduled above it, and nothing touches them between the asm loads
+// and this wait (tools/k9_asm_check.py scans the generated code for exactly that).
+template <int YOUNGER, int ITERS>
 __device__ __forceinline__ void stage_arrived(Stage<ITERS>& st) {
+    static_assert(YOUNGER >= 0 && YOUNGER < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(YOUNGER) : "memory");
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
-        float4 &u = st.v[it][0], &w = st.v[it][1];
-        asm volatile("" : "+v"(u.x), "+v"(u.y), "+v"(u.z), "+v"(u.w), "+v"(w.x), "+v"(w.y), "+v"(w.z), "+v"(w.w));
+        f32x4 &u = st.v[it][0], &w = st.v[it][1];
+        asm volatile("" : "+v"(u), "+v"(w));
     }
 }
 
@@ -203,7 +230,8 @@ __device__ __forceinline__ void stage_store(const Stage<ITERS>& st, unsigned cha
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int i = tid + NTHR * it;
-        const float4 u = st.v[it][0], w = st.v[it][1];
+        const float4 u = make_float4(st.v[it][0].x, st.v[it][0].y, st.v[it][0].z, st.v[it][0].w);
+        const float4 w = make_float4(st.v[it][1].x, st.v[it][1].y, st.v[it][1].z, st.v[it][1].w);
         if (ITERS * NTHR == G::ITEMS || i < G::ITEMS) {
             const int hp = i >> 2, g = i & 3;
             int off;
@@ -900,6 +928,9 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p) {
         unsigned char* dst = Bs + pslot * B_BUF + wave * 1024;
 #pragma unroll
         for (int j = 0; j < B_ITERS; ++j)
+#if defined(FAR_K9_EXP) && (FAR_K9_EXP & 32)     // experiment: one slab request per eight (stale weights: wrong results)
+            if ((pidx & 7) == 0)
+#endif
             if ((j + 1) * NTHR * 16 <= B_BUF || j * NTHR * 16 + wave * 1024 < B_BUF)       // wave-uniform, static
                 __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + j * (NTHR * 16)), (lptr_t)(dst + j * (NTHR * 16)), 16, 0, 0);
         pslot = pslot == 2 ? 0 : pslot + 1;
@@ -969,9 +1000,12 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p) {
 
     // ---- prologue: pixels of chunk 0, weight slabs of phases 0 and 1 (the ring runs two phases ahead)
     Stage<ITERS> st;
-    stage_load<KS, MW, ST, NTHR, ITERS>(st, p, tp, 0, tid, true, rowpix);
+    int pixv[ITERS];
+    if constexpr (KS != 1) stage_pixels<KS, MW, ST, NTHR, ITERS>(pixv, p, tp, tid);
+    stage_load<KS, MW, ST, NTHR, ITERS>(st, p, tp, 0, tid, true, rowpix, KS != 1 ? pixv : nullptr);
     prefetch();
     prefetch();
+    stage_arrived<2 * B_ITERS>(st);
     stage_store<KS, MW, ST, NTHR, ITERS, SPLIT>(st, As, tid, act_scale);
     FAR_K9_STAMP(1);
 
@@ -996,6 +1030,9 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p) {
         const int half = grp & 1;
 #pragma unroll
         for (int q = 0; q < NH; ++q) {
+#if defined(FAR_K9_EXP) && (FAR_K9_EXP & 16)     // experiment: half the weight-fragment reads (wrong results)
+            if (q > 0) { bh[half][q] = bh[half][0]; bl[half][q] = bl[half][0]; continue; }
+#endif
             bh[half][q] = *reinterpret_cast<const f16x8*>(B + (grp * NH + q) * 32 * 32);
             bl[half][q] = *reinterpret_cast<const f16x8*>(B + B_PLANE + (grp * NH + q) * 32 * 32);
         }
@@ -1003,6 +1040,14 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p) {
     // (WN: the wave column as a compile-time constant in N7 mode -- the skipped tile depends on it -- and 0 otherwise)
     auto mma_half = [&](int grp) {
         const int half = grp & 1;
+#if defined(FAR_K9_EXP) && (FAR_K9_EXP & 64)     // experiment: no MFMAs (one fma per fragment pair keeps the reads alive; wrong results)
+#pragma unroll
+        for (int q = 0; q < NH; ++q)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                acc[mt][grp * NH + q][0] += (float)ah[mt][0] * (float)bh[half][q][0] + (float)al[mt][0] * (float)bl[half][q][0];
+        return;
+#endif
         // N7: wn = 0 leaves out (mt 1, tile 3), wn = 1 leaves out (mt 0, tile 0) -- the half of the shared tile the other column computes
         auto live = [&](int mt, int nt) { return !N7 || (WN == 0 ? !(mt == 1 && nt == 3) : !(mt == 0 && nt == 0)); };
 #pragma unroll
@@ -1059,7 +1104,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p) {
                 prefetch();
                 if (tap == LOAD_TAP && ks == 0) __builtin_amdgcn_sched_barrier(0);   // the slab's DMAs stay ahead of the pixel loads (the waits count on it)
                 if (tap == LOAD_TAP && ks == 0)            // unconditional (no branch in the body): the last chunk requests zeros
-                    stage_load<KS, MW, ST, NTHR, ITERS>(st, p, tp, chunk + 1, tid, chunk + 1 < nchunks, rowpix);
+                    stage_load<KS, MW, ST, NTHR, ITERS>(st, p, tp, chunk + 1, tid, chunk + 1 < nchunks, rowpix, KS != 1 ? pixv : nullptr);
 #pragma unroll
                 for (int grp = 0; grp < NGRP; ++grp) {
                     if (grp + 1 < NGRP) read_b(grp + 1, B);
@@ -1085,7 +1130,9 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p) {
                 slot = slot == 2 ? 0 : slot + 1;
             }
         }
-        stage_arrived(st);
+        // slab requests younger than the pixel loads of phase (LOAD_TAP, 0): one per later phase of the chunk (two phases per tap with
+        // split operands; a last chunk with one phase per tap has fewer, and its staged values are not used)
+        stage_arrived<((SPLIT ? 2 * (TAPS - LOAD_TAP) - 1 : TAPS - LOAD_TAP - 1)) * B_ITERS>(st);
         if (chunk + 1 < nchunks) {
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done with this chunk's pixels
             stage_store<KS, MW, ST, NTHR, ITERS, SPLIT>(st, As, tid, act_scale);
@@ -1641,6 +1688,7 @@ int conv_nhwc_impl(const far_conv_desc* desc, const KvMode* kvm, hipStream_t str
     if (!x || !packed || !scale || (!y && !(kvm && kvm->epi == 1)) || N < 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) || Cout <= 0 ||
         (ksize != 1 && ksize != 3) || stride < 1 || stride > 2 || act < 0 || act > 2 ||
         (sub2 && (kvm || up || x2 || res_group != 1 || N * (long)((H - 1) / 2 + 1) * ((W - 1) / 2 + 1) > 0x7fffffffL)) ||
+        (ksize == 3 && N * (long)H * W > 0x7fffffffL) ||          // 3x3: input pixel indices are 32-bit (stage_pixels)
         (act == 2 && !(slope >= 0.f && slope <= 1.f)) || x == y || (x2 && x2 == y) || out_planes < 1 || Cout % out_planes)
         return FAR_EINVAL;
     if (res_group < 1 || (res_group > 1 && (!res || ksize != 1 || out_planes != 1 || (N * H * W) % res_group))) return FAR_EINVAL;
