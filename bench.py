@@ -302,7 +302,9 @@ def other_workloads(a):
     import subprocess
     legs = [('c3_training_step', ['--workload', 'c3', '--steps', '12', '--warmup', '3']),
             ('c4_cached_path', ['--workload', 'c4', '--steps', '10', '--warmup', '2']),
+            ('c4_cached_path_fp16', ['--workload', 'c4', '--precision', 'fp16', '--steps', '10', '--warmup', '2']),
             ('c5_mapfree_544x720', ['--workload', 'c5', '--steps', '10', '--warmup', '3']),
+            ('c5_mapfree_544x720_fp16', ['--workload', 'c5', '--precision', 'fp16', '--steps', '10', '--warmup', '3']),
             ('c2_one_pair_latency', ['--pairs', '1', '--steps', '20', '--warmup', '5', '--skip-rooflines']),
             ('c2_five_point_solver', ['--minimal', '5', '--steps', '10', '--warmup', '3', '--skip-rooflines'])]
     out = {}
@@ -322,6 +324,11 @@ def other_workloads(a):
             for k in ('k4', 'k1', 'vendor_convolution'):
                 if k in r:
                     ent[k] = r[k]
+            if name == 'c4_cached_path_fp16':
+                ent['note'] = "the same leg under LoFTR.set_precision('fp16') (16-bit operands in the head's K9 / K2 launches); informational"
+            if name == 'c5_mapfree_544x720_fp16':
+                ent['note'] = ("BASELINE configs[4] names 'fp16 MFMA': the same leg under LoFTR.set_precision('fp16') (16-bit operands in K9 / K1, "
+                               "fp32 tensors and accumulation); the leg above is the fp32-grade form")
             if name == 'c2_five_point_solver':
                 ent['pose_error'] = r['config'].get('pose_error')
                 ent['note'] = ("the headline workload with Nister's five-point solver as the minimal solver of every pair (H = 2048 models "
@@ -452,6 +459,7 @@ def bench_c4(a, dev, world, rank, dist):
     sd = synth.synthetic_state_dict({k: tuple(v) for k, v in man.items() if k.startswith('loftr_regress.')})
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     model = model.to(dev)
+    model.set_precision(a.precision)
     g = torch.Generator(device=dev).manual_seed(4321 + rank)
     f0 = torch.randn(B, L, C, device=dev, generator=g)
     f1 = 0.5 * f0 + torch.randn(B, L, C, device=dev, generator=g)
@@ -503,7 +511,8 @@ def bench_c4(a, dev, world, rank, dist):
             'value': round(world * B * a.steps / dt, 3), 'unit': 'image-pairs/sec', 'n_gpus': world, 'steps': a.steps,
             'warmup': a.warmup, 'prime_steps': prime, 'ms_per_step': round(1000 * dt / a.steps, 3),
             'per_rank_ms_per_step': per_rank_ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32 (head: split-f16x3 operands, fp32 accumulate) / f64 (solver)', 'data': 'synthetic',
+            'dtype': ('f32 (head: split-f16x3 operands, fp32 accumulate) / f64 (solver)' if a.precision == 'fp32' else
+                      f'f32 tensors/accumulation, {a.precision} matrix operands (head) / f64 (solver)'), 'data': 'synthetic',
             'config': {'workload': 'InteriorNet-T-shaped cached-LoFTR path (BASELINE configs[3]): batch 256 pairs per GPU, cached '
                                    'coarse features + 800-2000 cached correspondences per pair (30 % outliers), GPU 8-pt prior-RANSAC '
                                    'solve (x2 rounds) + EMM head (x2), seeded random weights',

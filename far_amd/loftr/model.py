@@ -122,8 +122,9 @@ class LoFTR(nn.Module):
         if mode not in self.PRECISIONS:
             raise ValueError(f'precision must be one of {self.PRECISIONS}')
         self.backbone_dtype = torch.bfloat16 if mode == 'bf16' else torch.float32
-        self.backbone.trunk_split = mode in ('fp32', 'fp16-fine')
-        self.backbone.fpn_split = mode == 'fp32'
+        if hasattr(self, 'backbone'):                      # (the cached-prediction configuration builds the head only)
+            self.backbone.trunk_split = mode in ('fp32', 'fp16-fine')
+            self.backbone.fpn_split = mode == 'fp32'
         from .transformer import CrossAttention, LoFTREncoderLayer
         for m in self.modules():
             if isinstance(m, LoFTREncoderLayer):
