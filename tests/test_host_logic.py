@@ -261,3 +261,23 @@ def test_build_id_ties_the_library_to_its_sources(tmp_path, monkeypatch):
     monkeypatch.setattr(_lib, '_lib', None)
     assert _lib.load().far_abi_version() == _lib.EXPECTED_ABI
     monkeypatch.setattr(_lib, '_lib', lib)
+
+
+def test_build_asm_scan_catches_a_staged_register_touched_before_its_wait(tmp_path):
+    """far_amd/build.py scans K9's generated code for the property its asm pixel loads rely on; the scan itself on hand-made code:
+    a clean sequence, a copy of the staged register above the counted wait, and a wait whose count does not cover the load."""
+    from far_amd import build
+    head = '_ZN1x6k_convILi1EEEvv:\n'
+    load = '\t;;#ASMSTART\n\tglobal_load_dwordx4 v[10:13], v[2:3], off\n\t;;#ASMEND\n'
+    dma = '\tglobal_load_lds_dwordx4 v[4:5], off\n'
+    wait = lambda k: f'\t;;#ASMSTART\n\ts_waitcnt vmcnt({k})\n\t;;#ASMEND\n'
+    use = '\tv_cvt_pk_f16_f32 v20, v10, v11\n'
+    tail = '\ts_endpgm\n'
+    cases = {'clean': (head + load + dma * 4 + '\tv_add_f32 v30, v31, v32\n' + wait(4) + use + tail, 0),
+             'copy above the wait': (head + load + dma * 4 + '\tv_mov_b32 v40, v12\n' + wait(4) + use + tail, 1),
+             'wait that does not cover the load': (head + load + dma * 2 + wait(4) + use + tail, 1)}
+    for name, (text, nbad) in cases.items():
+        p = tmp_path / 'k.s'
+        p.write_text(text)
+        nfn, nld, bad = build.asm_check(str(p), 'k_conv')
+        assert (nfn, nld, len(bad)) == (1, 1, nbad), (name, bad)
