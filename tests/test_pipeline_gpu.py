@@ -699,6 +699,36 @@ def test_activation_range_recovery_end_to_end(model):
     assert not [w for w in rec2 if 'activation' in str(w.message)] and len(data2['b_ids']) > 100
 
 
+@pytest.mark.parametrize('mode', ['fp16', 'mixed16'])
+def test_activation_range_recovery_in_the_16_bit_modes(model, mode):
+    """The same oversized checkpoint under the 16-bit-operand modes: plain-fp16 K9 / K2 / K13 / K14 launches raise the same device flag
+    (|a| 2^act_exp beyond the fp16 range), the step is re-run at a wider range, the results are finite and the mode's settings
+    (bf16 K1, plain K2) are still in place afterwards."""
+    import copy
+    import warnings
+    from far_amd import ops
+    from far_amd.pipeline import test_step
+    big = copy.deepcopy(model).set_precision(mode)
+    with torch.no_grad():
+        big.backbone.bn1.weight.mul_(2.0 ** 13)
+        big.backbone.bn1.bias.mul_(2.0 ** 13)
+    d, _, _ = _batch(1, 5)
+    ops.overflow_flag('cuda').zero_()
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter('always')
+        test_step(big, d, H=256)
+    assert big.act_exp < 4 and any('activation' in str(w.message) for w in rec)
+    for key in ('feats_c', 'featmap0', 'mkpts1_f', 'mconf', 'regressed_rt'):
+        assert torch.isfinite(d[key]).all(), key
+    assert len(d['b_ids']) > 100 and not ops.activation_overflowed('cuda')
+    assert big.coarse_matching.bf16 and big.loftr_regress.emm.cross_attn.plain16
+    d2, _, _ = _batch(1, 6)
+    with warnings.catch_warnings(record=True) as rec2:
+        warnings.simplefilter('always')
+        test_step(big, d2, H=256)
+    assert not [w for w in rec2 if 'activation' in str(w.message)] and torch.isfinite(d2['regressed_rt']).all()
+
+
 def test_activation_range_guard_ignores_stale_flags_and_keeps_its_state_on_bad_inputs(model):
     """ADVICE r3 (medium).  (1) A flag left set by somebody else -- a backward launch with an inf gradient, another module --
     must not widen this module on its next clean forward: _guarded clears it on entry.  (2) Non-finite INPUTS raise the flag
