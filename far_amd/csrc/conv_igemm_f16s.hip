@@ -112,13 +112,6 @@ struct ConvArgs {
     int g_wc, g_W, g_stride, g_Hf, g_Wf;
 };
 
-// LDS-DMA from inline asm (as K13 / K14 / K17): invisible to the compiler's wait insertion; completion is counted by hand.
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst_uniform) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
-}
-
 __device__ __forceinline__ void split8(const float4& u, const float4& v, float act_scale, f16x8& hi, f16x8& lo) {
     const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -862,21 +855,14 @@ __device__ __forceinline__ void la_apply_epilogue(const ConvArgs& p, const f32x1
 // first 32-pixel tile (mt = 0) and by wn = 1 for its second (mt = 1), so that every wave issues 7 of the 8 MFMA triples of a
 // k-step: 12.5 % fewer MFMAs, evenly over the four SIMDs (dropping the all-padding eighth tile from the wn = 1 waves alone
 // leaves the SIMDs of the wn = 0 waves as the bottleneck: measured in round 1, -2 %).
-template <int KS, int MW, int NW, int NTW, bool SPLIT, int ST, int UP, bool N7, int WN, int EPI = 0, bool ADMA = false>
+template <int KS, int MW, int NW, int NTW, bool SPLIT, int ST, int UP, bool N7, int WN, int EPI = 0>
 __device__ __forceinline__ void conv_body(const ConvArgs& p) {
     using G = Geo<KS, MW, ST>;
     constexpr int NTHR = 64 * MW * NW;
     constexpr int PLANES = SPLIT ? 2 : 1;
     constexpr int TAPS = KS * KS;
     constexpr int NT = 32 * NTW * NW;                // output channels per workgroup
-    // ADMA (experiment): activations raw fp32 by LDS-DMA, 16 channels per step, RA ring slots; weight ring RB slots; both requested
-    // ring - 1 steps ahead; split into (hi, lo) in registers at the fragment read.
-    static_assert(!ADMA || (KS == 1 && SPLIT && ST == 1 && !UP && !N7 && EPI != 3), "ADMA: the Linear-mode kernels on split operands");
-    constexpr int A_SLOT = 64 * MW * 64;                                 // 64 MW rows x 16 fp32 channels
-    constexpr int RA = 4;
-    constexpr int RB = !ADMA ? 3 : (MW * NW == 8 ? 4 : 3);               // eight waves = one workgroup per CU: room for four slabs
-    constexpr int AI = 4 / NW;                                           // 1 KiB activation requests per wave and step
-    constexpr int A_BUF = ADMA ? RA * A_SLOT : PLANES * G::A_PLANE;
+    constexpr int A_BUF = PLANES * G::A_PLANE;
     // Plain operands (SPLIT = false): one phase per tap covers the whole 32-channel chunk (two MFMA k-steps), the slab
     // holds the two k-steps where the split slab holds the hi and lo planes: same LDS image size, same DMA pattern,
     // 16 instead of 8 MFMAs per barrier.
@@ -947,7 +933,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p) {
 #endif
             if ((j + 1) * NTHR * 16 <= B_BUF || j * NTHR * 16 + wave * 1024 < B_BUF)       // wave-uniform, static
                 __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + j * (NTHR * 16)), (lptr_t)(dst + j * (NTHR * 16)), 16, 0, 0);
-        pslot = pslot == RB - 1 ? 0 : pslot + 1;
+        pslot = pslot == 2 ? 0 : pslot + 1;
         const size_t adv = (SPLIT && pidx >= first_last && last_nks == 1) ? 2 * slab_stride : slab_stride;
         ++pidx;
         wsrc += pidx < nslab ? adv : 0;
@@ -976,11 +962,11 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p) {
     // worked out ONCE per workgroup (one thread per row: two index loads, three divisions) into a table behind the loop's LDS buffers
     // -- inside the epilogue's region, which is only used after the last staging pass
     const int* rowpix = nullptr;
-    if constexpr ((EPI == 1 || EPI == 2) && !ADMA) {
+    if constexpr (EPI == 1 || EPI == 2) {
         // the LinearAttention epilogues on image lengths that are no multiple of 64: the launch's rows are images padded to whole
         // 64-row blocks; the same kind of table says which input row (if any) each row of the tile is
         if (p.kv_valid != p.kv_S) {                      // launch-uniform
-            int* tab = reinterpret_cast<int*>(smem + A_BUF + RB * B_BUF);
+            int* tab = reinterpret_cast<int*>(smem + A_BUF + 3 * B_BUF);
             if (tid < 64 * MW) {
                 const long row = tp.pix0 + tid;
                 const long im = row / p.kv_S;
@@ -993,7 +979,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p) {
     }
     if constexpr (EPI == 3) {
         static_assert(KS == 1 && !UP && !N7, "gather mode is a Linear-mode input form");
-        int* tab = reinterpret_cast<int*>(smem + A_BUF + RB * B_BUF);
+        int* tab = reinterpret_cast<int*>(smem + A_BUF + 3 * B_BUF);
         if (tid < 64 * MW) {
             const long row = tp.pix0 + tid;
             int gp = -1;
@@ -1015,14 +1001,12 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p) {
     // ---- prologue: pixels of chunk 0, weight slabs of phases 0 and 1 (the ring runs two phases ahead)
     Stage<ITERS> st;
     int pixv[ITERS];
-    if constexpr (!ADMA) {
-        if constexpr (KS != 1) stage_pixels<KS, MW, ST, NTHR, ITERS>(pixv, p, tp, tid);
-        stage_load<KS, MW, ST, NTHR, ITERS>(st, p, tp, 0, tid, true, rowpix, KS != 1 ? pixv : nullptr);
-        prefetch();
-        prefetch();
-        stage_arrived<2 * B_ITERS>(st);
-        stage_store<KS, MW, ST, NTHR, ITERS, SPLIT>(st, As, tid, act_scale);
-    }
+    if constexpr (KS != 1) stage_pixels<KS, MW, ST, NTHR, ITERS>(pixv, p, tp, tid);
+    stage_load<KS, MW, ST, NTHR, ITERS>(st, p, tp, 0, tid, true, rowpix, KS != 1 ? pixv : nullptr);
+    prefetch();
+    prefetch();
+    stage_arrived<2 * B_ITERS>(st);
+    stage_store<KS, MW, ST, NTHR, ITERS, SPLIT>(st, As, tid, act_scale);
     FAR_K9_STAMP(1);
 
     // Fragment registers.  The pixel (A) fragments of a phase are read during the previous phase; the weight (B)
@@ -1095,136 +1079,63 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p) {
         }
     };
 
-    if constexpr (!ADMA) {
-        int slot = 0;
-        for (int chunk = 0; chunk < nchunks; ++chunk) {
-            const int nks = !SPLIT ? 1 : chunk == nchunks - 1 ? last_nks : 2;            // phases per tap
-    #pragma unroll
-            for (int tap = 0; tap < TAPS; ++tap) {
-    #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    if (ks >= nks) continue;                                      // between phases; the body is branch free
-                    const bool first = tap == 0 && ks == 0;                       // first phase of a chunk
-                    const bool last = tap == TAPS - 1 && ks == nks - 1;           // last phase of a chunk
-                    // This phase's slab has landed once only the requests issued after it are outstanding (vmcnt retires
-                    // in order): the younger slab's DMAs, and -- in the two phases after the pixel-load phase -- the next
-                    // chunk's pixel loads, which were issued behind this slab's DMAs and need not have arrived yet.
-                    const bool after_load = SPLIT ? (tap == LOAD_TAP && ks == 1) || (TAPS > 1 && tap == LOAD_TAP + 1 && ks == 0)
-                                                  : TAPS > 1 && (tap == LOAD_TAP + 1 || tap == LOAD_TAP + 2);
-                    if (after_load) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B_ITERS + 2 * ITERS) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B_ITERS) : "memory");
-                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                    const unsigned char* B = Bs + slot * B_BUF + b_off;
-                    read_b(0, B);
-                    if (first || !APRE) read_a(ah, al, tap, ks);
-                    __builtin_amdgcn_sched_barrier(0);
-                    prefetch();
-                    if (tap == LOAD_TAP && ks == 0) __builtin_amdgcn_sched_barrier(0);   // the slab's DMAs stay ahead of the pixel loads (the waits count on it)
-                    if (tap == LOAD_TAP && ks == 0)            // unconditional (no branch in the body): the last chunk requests zeros
-                        stage_load<KS, MW, ST, NTHR, ITERS>(st, p, tp, chunk + 1, tid, chunk + 1 < nchunks, rowpix, KS != 1 ? pixv : nullptr);
-    #pragma unroll
-                    for (int grp = 0; grp < NGRP; ++grp) {
-                        if (grp + 1 < NGRP) read_b(grp + 1, B);
-                        if (grp == NGRP - 1 && APRE && !(tap == TAPS - 1 && (ks == 1 || !SPLIT))) {   // pixel fragments of the next phase of this chunk
-                            const bool wrap = ks + 1 >= nks;           // (a skipped second k-step makes the next phase (tap + 1, 0))
-                            read_a(ahn, aln, wrap ? tap + 1 : tap, wrap ? 0 : 1);
-                        }
-                        mma_half(grp);
+    int slot = 0;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int nks = !SPLIT ? 1 : chunk == nchunks - 1 ? last_nks : 2;            // phases per tap
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                if (ks >= nks) continue;                                      // between phases; the body is branch free
+                const bool first = tap == 0 && ks == 0;                       // first phase of a chunk
+                const bool last = tap == TAPS - 1 && ks == nks - 1;           // last phase of a chunk
+                // This phase's slab has landed once only the requests issued after it are outstanding (vmcnt retires
+                // in order): the younger slab's DMAs, and -- in the two phases after the pixel-load phase -- the next
+                // chunk's pixel loads, which were issued behind this slab's DMAs and need not have arrived yet.
+                const bool after_load = SPLIT ? (tap == LOAD_TAP && ks == 1) || (TAPS > 1 && tap == LOAD_TAP + 1 && ks == 0)
+                                              : TAPS > 1 && (tap == LOAD_TAP + 1 || tap == LOAD_TAP + 2);
+                if (after_load) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B_ITERS + 2 * ITERS) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B_ITERS) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                const unsigned char* B = Bs + slot * B_BUF + b_off;
+                read_b(0, B);
+                if (first || !APRE) read_a(ah, al, tap, ks);
+                __builtin_amdgcn_sched_barrier(0);
+                prefetch();
+                if (tap == LOAD_TAP && ks == 0) __builtin_amdgcn_sched_barrier(0);   // the slab's DMAs stay ahead of the pixel loads (the waits count on it)
+                if (tap == LOAD_TAP && ks == 0)            // unconditional (no branch in the body): the last chunk requests zeros
+                    stage_load<KS, MW, ST, NTHR, ITERS>(st, p, tp, chunk + 1, tid, chunk + 1 < nchunks, rowpix, KS != 1 ? pixv : nullptr);
+#pragma unroll
+                for (int grp = 0; grp < NGRP; ++grp) {
+                    if (grp + 1 < NGRP) read_b(grp + 1, B);
+                    if (grp == NGRP - 1 && APRE && !(tap == TAPS - 1 && (ks == 1 || !SPLIT))) {   // pixel fragments of the next phase of this chunk
+                        const bool wrap = ks + 1 >= nks;           // (a skipped second k-step makes the next phase (tap + 1, 0))
+                        read_a(ahn, aln, wrap ? tap + 1 : tap, wrap ? 0 : 1);
                     }
-                    // issue order: one MFMA, then the other instructions of the phase (LDS reads, the DMA requests and
-                    // their address arithmetic) in the issue slots its 32-cycle pass leaves free
-    #pragma unroll
-                    for (int i = 0; i < (N7 ? (SPLIT ? 21 : 14) : (SPLIT ? 6 : 4) * NTW); ++i) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
-                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // DS read
-                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // VMEM read (LDS-DMA, pixel loads)
-                        __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);      // VALU / SALU
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    (void)last;
-    #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) if (APRE) { ah[mt] = ahn[mt]; al[mt] = aln[mt]; }
-                    slot = slot == 2 ? 0 : slot + 1;
+                    mma_half(grp);
                 }
-            }
-            // slab requests younger than the pixel loads of phase (LOAD_TAP, 0): one per later phase of the chunk (two phases per tap with
-            // split operands; a last chunk with one phase per tap has fewer, and its staged values are not used)
-            stage_arrived<((SPLIT ? 2 * (TAPS - LOAD_TAP) - 1 : TAPS - LOAD_TAP - 1)) * B_ITERS>(st);
-            if (chunk + 1 < nchunks) {
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done with this chunk's pixels
-                stage_store<KS, MW, ST, NTHR, ITERS, SPLIT>(st, As, tid, act_scale);
+                // issue order: one MFMA, then the other instructions of the phase (LDS reads, the DMA requests and
+                // their address arithmetic) in the issue slots its 32-cycle pass leaves free
+#pragma unroll
+                for (int i = 0; i < (N7 ? (SPLIT ? 21 : 14) : (SPLIT ? 6 : 4) * NTW); ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // DS read
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // VMEM read (LDS-DMA, pixel loads)
+                    __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);      // VALU / SALU
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                (void)last;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) if (APRE) { ah[mt] = ahn[mt]; al[mt] = aln[mt]; }
+                slot = slot == 2 ? 0 : slot + 1;
             }
         }
-    } else {
-        // Request r of this wave (r < AI) moves 16 rows x 64 B: lane = (row, 16-byte slot); slot s of row t holds source quad
-        // s ^ ((t >> 2) & 3) (lane-linear LDS image, swizzle on the SOURCE address): conflict-free fragment reads.
-        const int nsteps = p.Cin >> 4, n1 = p.Cin1 >> 4;
-        const char* ax[AI];
-        const char* ax2[AI];
-        int ainc[AI];
-#pragma unroll
-        for (int r = 0; r < AI; ++r) {
-            const int P = (wave * AI + r) * 64 + lane;
-            const int t = P >> 2, q = (P & 3) ^ ((t >> 2) & 3);
-            const long row = tp.pix0 + t;
-            const bool ok = row < p.npix;
-            ax[r] = ok ? reinterpret_cast<const char*>(p.x + row * p.Cin1 + 4 * q) : reinterpret_cast<const char*>(p.zeros);
-            ax2[r] = (ok && p.x2) ? reinterpret_cast<const char*>(p.x2 + row * (p.Cin - p.Cin1) + 4 * q) : reinterpret_cast<const char*>(p.zeros);
-            ainc[r] = ok ? 64 : 0;
-        }
-        const unsigned a_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(lptr_t)(As + wave * (AI * 1024)));
-        auto request_a = [&](int step) {
-            const int sp = step < nsteps ? step : nsteps - 1;           // past the end: the last step again, into a slot nobody reads
-            const unsigned dst = a_lds + (unsigned)((step % RA) * A_SLOT);
-#pragma unroll
-            for (int r = 0; r < AI; ++r) {
-                const char* src = sp < n1 ? ax[r] + (long)sp * ainc[r] : ax2[r] + (long)(sp - n1) * ainc[r];
-                glds16(src, dst + r * 1024);
-            }
-        };
-        int ar_off[2][2];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const int t = 64 * wm + 32 * mt + l31;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) ar_off[mt][j] = t * 64 + (((2 * h + j) ^ ((t >> 2) & 3)) * 16);
-        }
-        // Issue order per step: the slab RB - 1 steps ahead, then the activations RA - 1 = 3 steps ahead.
-        //   RB = 3: queue ... B(s) A(s+1) | B(s+1) A(s+2) | -> at step s the younger ones are A(s+1), B(s+1), A(s+2)
-        //   RB = 4: queue ... B(s) A(s) | B(s+1) A(s+1) | B(s+2) A(s+2) | -> younger: two whole steps
-        if (RB == 4) { prefetch(); request_a(0); prefetch(); request_a(1); prefetch(); request_a(2); }
-        else { request_a(0); prefetch(); request_a(1); prefetch(); request_a(2); }
-        int bslot = 0, aslot = 0;
-        for (int step = 0; step < nsteps; ++step) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RB == 4 ? 2 * (AI + B_ITERS) : 2 * AI + B_ITERS) : "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            const unsigned char* B = Bs + bslot * B_BUF + b_off;
-            const unsigned char* A = As + aslot * A_SLOT;
-            read_b(0, B);
-            float4 raw[2][2];
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) raw[mt][j] = *reinterpret_cast<const float4*>(A + ar_off[mt][j]);
-            __builtin_amdgcn_sched_barrier(0);
-            prefetch();
-            request_a(step + RA - 1);
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) split8(raw[mt][0], raw[mt][1], act_scale, ah[mt], al[mt]);
-#pragma unroll
-            for (int grp = 0; grp < NGRP; ++grp) {
-                if (grp + 1 < NGRP) read_b(grp + 1, B);
-                mma_half(grp);
-            }
-#pragma unroll
-            for (int i = 0; i < 6 * NTW; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x006, 6, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            bslot = bslot == RB - 1 ? 0 : bslot + 1;
-            aslot = aslot == RA - 1 ? 0 : aslot + 1;
+        // slab requests younger than the pixel loads of phase (LOAD_TAP, 0): one per later phase of the chunk (two phases per tap with
+        // split operands; a last chunk with one phase per tap has fewer, and its staged values are not used)
+        stage_arrived<((SPLIT ? 2 * (TAPS - LOAD_TAP) - 1 : TAPS - LOAD_TAP - 1)) * B_ITERS>(st);
+        if (chunk + 1 < nchunks) {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done with this chunk's pixels
+            stage_store<KS, MW, ST, NTHR, ITERS, SPLIT>(st, As, tid, act_scale);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the trailing (unused) slab requests must land before LDS is reused
@@ -1286,13 +1197,13 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p) {
 #endif
 }
 
-template <int KS, int MW, int NW, int NTW, bool SPLIT, int ST, int UP = 0, bool N7 = false, int EPI = 0, bool ADMA = false>
+template <int KS, int MW, int NW, int NTW, bool SPLIT, int ST, int UP = 0, bool N7 = false, int EPI = 0>
 __global__ __launch_bounds__(64 * MW * NW, (ST == 1 ? 2 : 1)) void k_conv(const ConvArgs p) {
     if constexpr (N7) {                       // two copies of the body, one per wave column: which tile a wave skips is static
         if (((threadIdx.x >> 6) % NW) == 1) conv_body<KS, MW, NW, NTW, SPLIT, ST, UP, N7, 1>(p);
         else conv_body<KS, MW, NW, NTW, SPLIT, ST, UP, N7, 0>(p);
     } else {
-        conv_body<KS, MW, NW, NTW, SPLIT, ST, UP, N7, 0, EPI, ADMA>(p);
+        conv_body<KS, MW, NW, NTW, SPLIT, ST, UP, N7, 0, EPI>(p);
     }
 }
 
@@ -1553,30 +1464,25 @@ inline TileCfg cfg_for(int Cout, int stride) {
     return (stride == 1 && pad128 < pad256) ? TileCfg{4, 1, 128} : TileCfg{2, 2, 256};
 }
 
-template <int KS, int MW, int NW, int NTW, bool SPLIT, int ST = 1, int UP = 0, bool N7 = false, int EPI = 0, bool ADMA = false>
+template <int KS, int MW, int NW, int NTW, bool SPLIT, int ST = 1, int UP = 0, bool N7 = false, int EPI = 0>
 int launch_conv(const ConvArgs& a, dim3 grid, hipStream_t stream) {
     using G = Geo<KS, MW, ST>;
     constexpr int PLANES = SPLIT ? 2 : 1;
-    constexpr int smem_loop = (ADMA ? 4 * 64 * MW * 64 : PLANES * G::A_PLANE) + (ADMA && MW * NW == 8 ? 4 : 3) * 2 * 32 * NTW * NW * 32;
-    static_assert(smem_loop <= (MW * NW == 8 ? 163840 : 81920) || !ADMA, "ADMA: the rings fit");
+    constexpr int smem_loop = PLANES * G::A_PLANE + 3 * 2 * 32 * NTW * NW * 32;
     constexpr int smem_epi = EPI == 2 ? MW * NW * 32 * LDW * 4        // la_apply_epilogue: padded rows
                                       : MW * NW * (32 * 128 * 4 + 32 * 4);  // conv_epilogue_wide: 16 KiB per wave + LayerNorm exchange
-    constexpr int smem_need = smem_loop + (EPI != 0 && !ADMA ? 64 * MW * 4 : 0);   // gather / padded modes: + the row table behind the loop buffers
+    constexpr int smem_need = smem_loop + (EPI != 0 ? 64 * MW * 4 : 0);            // gather / padded modes: + the row table behind the loop buffers
     constexpr int smem = smem_need > smem_epi ? smem_need : smem_epi;
     bool cfg_failed = false;
-    FAR_ONCE_PER_DEVICE(cfg_failed = hipFuncSetAttribute((const void*)k_conv<KS, MW, NW, NTW, SPLIT, ST, UP, N7, EPI, ADMA>,
+    FAR_ONCE_PER_DEVICE(cfg_failed = hipFuncSetAttribute((const void*)k_conv<KS, MW, NW, NTW, SPLIT, ST, UP, N7, EPI>,
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess);
     if (cfg_failed) return far_check_launch();
-    hipLaunchKernelGGL((k_conv<KS, MW, NW, NTW, SPLIT, ST, UP, N7, EPI, ADMA>), grid, dim3(64 * MW * NW), smem, stream, a);
+    hipLaunchKernelGGL((k_conv<KS, MW, NW, NTW, SPLIT, ST, UP, N7, EPI>), grid, dim3(64 * MW * NW), smem, stream, a);
     return far_check_launch();
 }
 
 template <int KS, bool SPLIT>
-int launch_cfg(const TileCfg& c, const ConvArgs& a, dim3 grid, hipStream_t stream, bool small = false, int adma = 0) {
-    if constexpr (KS == 1 && SPLIT) {
-        if (adma == 1 && c.mw == 2 && !small && !a.up) return launch_conv<1, 2, 2, 4, true, 1, 0, false, 0, true>(a, grid, stream);
-        if (adma == 2 && c.mw == 4 && c.nw == 2 && !a.up) return launch_conv<1, 4, 2, 4, true, 1, 0, false, 0, true>(a, grid, stream);
-    }
+int launch_cfg(const TileCfg& c, const ConvArgs& a, dim3 grid, hipStream_t stream, bool small = false) {
     if (KS == 1 && a.up) {                          // the FPN merge variant (fused 2x-upsample residual)
         // rows of whole 32-pixel tiles (the backbone's 320 / 160-pixel rows): the row-walking form of the merge epilogue (UP = 2)
         const bool rowwise = (a.Wo & 31) == 0 && far_get_tuning(13) == 0;
@@ -1799,13 +1705,7 @@ int conv_nhwc_impl(const far_conv_desc* desc, const KvMode* kvm, hipStream_t str
     a.H = H; a.W = W; a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1; a.Cin = Cin; a.Cout = Cout; a.Csub = Cout / out_planes;
     a.npix = N * a.Ho * a.Wo;
     if (kvm && kvm->epi != 3 && kvm->valid != kvm->S) a.npix = a.npix / kvm->valid * kvm->S;      // padded geometry: images x rounded-up length
-    TileCfg c = cfg_for(Cout, pstride);
-    // experiment (far_set_tuning(11, v)): Linear mode on split operands, 256-column blocks, whole 16-channel steps: 1 = activations by
-    // LDS-DMA on the shipped 4-wave tiles, 2 = the same on 8-wave workgroups (256 rows, one per CU) with a four-slab weight ring
-    int adma = 0;
-    if (split && ksize == 1 && !sub2 && !up && c.nt == 256 && (Cin & 15) == 0 && (Cin1 & 15) == 0 && !(kvm && (kvm->epi == 3 || kvm->valid != kvm->S)))
-        adma = far_get_tuning(11);
-    if (adma == 2 && N * (long)H * W >= 256 * 512) c = TileCfg{4, 2, 256}; else if (adma == 2) adma = 0;
+    const TileCfg c = cfg_for(Cout, pstride);
     if ((ln_gamma || post_res) && (!ln_gamma || !ln_beta || Cout != c.nt || out_planes != 1 || (Cout & 3) || post_res == y))
         return FAR_EINVAL;                    // the fused LayerNorm needs the whole channel row in one block (Cout 128 or 256)
     const int th = 4 * c.mw;
@@ -1846,7 +1746,7 @@ int conv_nhwc_impl(const far_conv_desc* desc, const KvMode* kvm, hipStream_t str
                          : launch_conv<1, 2, 2, 4, true, 1, 0, false, 3>(a, grid, stream);
     }
     if (kvm) {                                     // (validated by far_linear_kv_f16s: 256-column blocks)
-        if (c.mw != 2 && adma != 2) return FAR_EINVAL;
+        if (c.mw != 2) return FAR_EINVAL;
         if (!split) {                              // plain fp16 operands in the projection's K loop; the epilogue's own small products stay split
             if (kvm->epi == 2)
                 return small ? launch_conv<1, 1, 2, 4, false, 1, false, false, 2>(a, grid, stream)
@@ -1854,16 +1754,13 @@ int conv_nhwc_impl(const far_conv_desc* desc, const KvMode* kvm, hipStream_t str
             return small ? launch_conv<1, 1, 2, 4, false, 1, false, false, 1>(a, grid, stream)
                          : launch_conv<1, 2, 2, 4, false, 1, false, false, 1>(a, grid, stream);
         }
-        if (adma == 2 && c.mw == 4)
-            return kvm->epi == 2 ? launch_conv<1, 4, 2, 4, true, 1, 0, false, 2, true>(a, grid, stream)
-                                 : launch_conv<1, 4, 2, 4, true, 1, 0, false, 1, true>(a, grid, stream);
         if (kvm->epi == 2)
             return small ? launch_conv<1, 1, 2, 4, true, 1, false, false, 2>(a, grid, stream)
                          : launch_conv<1, 2, 2, 4, true, 1, false, false, 2>(a, grid, stream);
         return small ? launch_conv<1, 1, 2, 4, true, 1, false, false, 1>(a, grid, stream)
                      : launch_conv<1, 2, 2, 4, true, 1, false, false, 1>(a, grid, stream);
     }
-    return split ? launch_cfg<1, true>(c, a, grid, stream, small, adma) : launch_cfg<1, false>(c, a, grid, stream, small);
+    return split ? launch_cfg<1, true>(c, a, grid, stream, small) : launch_cfg<1, false>(c, a, grid, stream, small);
 }
 }  // namespace
 
