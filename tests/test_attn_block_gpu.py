@@ -171,10 +171,12 @@ def test_attn_block_overflow_is_reported():
     assert bool(torch.isfinite(y).all()) != ops.activation_overflowed('cuda')           # never silently non-finite
 
 
-def test_fused_fine_kernels_are_deterministic_at_bench_scale():
+@pytest.mark.parametrize('plain16', [False, True])
+def test_fused_fine_kernels_are_deterministic_at_bench_scale(plain16):
     """The fine level of the bench step runs K14 / K13 on 120 296 windows (60 148 matches, 'self' layers on both images): at that
     size the round-3 form of K14 (two 4-wave workgroups per CU) differed run to run in a handful of windows once its elu got cheap
-    (round 5; tools/fine_time.py).  Six launches each of the shipped kernels at that size, bit for bit, next to a busy second stream."""
+    (round 5; tools/fine_time.py).  Six launches each of the shipped kernels at that size, bit for bit, next to a busy second stream;
+    plain16: the plain-fp16-operand forms of the 'fp16' mode (same pipeline, a third of the MFMAs)."""
     from far_amd import ops
     ws, gam, bet, g = _setup(78)
     w0 = torch.randn(2 * D, 2 * D, device='cuda', generator=g) / 16
@@ -185,13 +187,13 @@ def test_fused_fine_kernels_are_deterministic_at_bench_scale():
     s = torch.randn(n, 25, D, device='cuda', generator=g)
     side = torch.cuda.Stream()
     junk = torch.empty(1 << 27, device='cuda')
-    a0 = ops.attn_block(x, s, pa, H, gam, bet, 1e-5)
-    m0 = ops.mlp_fused(x, a0, pm, gam, bet, 1e-5)
+    a0 = ops.attn_block(x, s, pa, H, gam, bet, 1e-5, plain16=plain16)
+    m0 = ops.mlp_fused(x, a0, pm, gam, bet, 1e-5, plain16=plain16)
     for it in range(6):
         with torch.cuda.stream(side):
             junk.add_(1.0)
-        a = ops.attn_block(x, s, pa, H, gam, bet, 1e-5)
-        m = ops.mlp_fused(x, a, pm, gam, bet, 1e-5)
+        a = ops.attn_block(x, s, pa, H, gam, bet, 1e-5, plain16=plain16)
+        m = ops.mlp_fused(x, a, pm, gam, bet, 1e-5, plain16=plain16)
         da = int(((a - a0).abs().flatten(1).max(1).values > 0).sum())
         dm = int(((m - m0).abs().flatten(1).max(1).values > 0).sum())
         assert da == 0, f'K14: {da} of {n} windows differ at launch {it}'
