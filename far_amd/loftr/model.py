@@ -103,7 +103,7 @@ class LoFTR(nn.Module):
     head_prefetch = not flags.off('FAR_NO_PREFETCH')   # inference: the head's feature stage enqueued behind K1 (see below)
 
     def set_precision(self, mode):
-        """Arithmetic of the backbone convolutions (everything else is unaffected):
+        """Operand precision of the matrix products (tensors stay fp32, accumulation stays fp32, the float64 solver is untouched):
           'fp32'      K9 with split-fp16 operand pairs: fp32-grade -- the parity configuration (default);
           'fp16-fine' split trunk + plain-fp16 operands in the FPN branch: coarse features and match decisions stay
                       bit-identical, only the sub-pixel refinement input changes;
