@@ -11,8 +11,9 @@
 // once and the normalised message written once.
 //
 // One wave = one window, padded to a 32-row MFMA tile (rows >= L / S are masked), so the attention never leaves the
-// wave; workgroup = 8 waves (round 5; 4 before) sharing the weight slabs (16 KiB each, 4-slot LDS ring, asm LDS-DMA THREE
-// phases ahead; the wave's input rows arrive by LDS-DMA as well, double-buffered, four phases ahead), one workgroup per CU.
+// wave; workgroup = 4 waves sharing the weight slabs (16 KiB each, 3-slot LDS ring, asm LDS-DMA TWO phases ahead; the wave's
+// input rows arrive by LDS-DMA as well, double-buffered), two workgroups per CU (round 6; round 5 shipped 8 waves / 4 slots / one
+// workgroup per CU -- still selectable, far_set_tuning(11, 1)).
 // Every request of the loop is waited for by hand with a COUNTED vmcnt (table VM_ALLOW below): a phase waits only for the
 // slab and the chunk it reads, 4-8 younger requests stay in flight across its barrier.  The round-3 form drained the queue
 // (vmcnt(0)) in front of each of its 16 barriers with requests only one to two phases old: 2.7 us per phase against 0.4 us
@@ -37,16 +38,16 @@ constexpr int DM = 128;                  // d_model
 constexpr int CT = DM / 32;              // 32-channel tiles (two 16-channel heads each)
 constexpr int SLAB = 16384;              // two k-steps x 4 tiles x 2 planes x 1 KiB
 constexpr int NSLAB = 16;                // [k c0][v c0][k c1][v c1][k c2][v c2][k c3][v c3][q c0..c3][merge t0..t3]
-constexpr int RING = 4;                  // round-5 form; the round-3 form (K14_OLD below): 3 slots, 4 waves
+constexpr int RING = 4;                  // the 8-wave form (far_set_tuning(11, 1)); the default form: 3 slots, 4 waves (attn_block_launch)
 constexpr int WAVES = 8;
 constexpr int XBUF = 4096;               // one 32-channel chunk of a window's rows
 constexpr int SMEM_NEW = RING * SLAB + WAVES * 2 * XBUF;      // 64 KiB + 64 KiB
 // Requests of one wave in program order (counted pipeline): prologue X0 X1 W0 .. W(D-1); phase p (after its barrier): [X(j + 2) if the
 // phase read chunk j and j + 2 < 8] then [W(p + D) if p + D < 16]; X = 4 pieces, W = 16 / waves pieces; D = ring slots - 1.  Chunks are read
 // in phases 0, 2, 4, 6 (source) and 8..11 (x).  vm_allow(p) = pieces issued after the youngest request phase p reads (its slab W(p),
-// its chunk) = what may stay in flight across barrier p -- computed by replaying exactly this schedule (8 waves, 4 slots:
-// 4 8 8 8 8 8 8 8 8 8 8 4 4 4 2 0).  A wrong entry shows as stale LDS reads: the run-to-run determinism and float64 tests of
-// tests/test_attn_block_gpu.py catch that.
+// its chunk) = what may stay in flight across barrier p -- computed by replaying exactly this schedule (4 waves, 3 slots:
+// 4 8 4 8 4 8 4 8 4 8 8 4 4 4 4 0; 8 waves, 4 slots: 4 8 8 8 8 8 8 8 8 8 8 4 4 4 2 0).  A wrong entry shows as stale LDS reads: the
+// float64 tests of tests/test_attn_block_gpu.py and the bench-scale determinism tests of tests/test_determinism_gpu.py catch that.
 constexpr int chunk_read_in_phase(int p) { return (p < 8 && (p & 1) == 0) ? p / 2 : ((p >= 8 && p < 12) ? 4 + (p - 8) : -1); }
 constexpr int vm_allow(int p, int wp, int d) {
     // kind 0 = X(id), 1 = W(id)
@@ -75,6 +76,8 @@ struct VmTable {
 };
 static_assert(vm_allow(0, 2, 3) == 4 && vm_allow(1, 2, 3) == 8 && vm_allow(10, 2, 3) == 8 && vm_allow(11, 2, 3) == 4 &&
               vm_allow(14, 2, 3) == 2 && vm_allow(15, 2, 3) == 0, "the 8-wave / 4-slot schedule");
+static_assert(vm_allow(0, 4, 2) == 4 && vm_allow(1, 4, 2) == 8 && vm_allow(2, 4, 2) == 4 && vm_allow(9, 4, 2) == 8 && vm_allow(10, 4, 2) == 8 &&
+              vm_allow(11, 4, 2) == 4 && vm_allow(14, 4, 2) == 4 && vm_allow(15, 4, 2) == 0, "the 4-wave / 3-slot schedule");
 constexpr float ACT_SCALE = 16.0f;
 
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst_uniform) {
@@ -82,12 +85,6 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst_unifor
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
 }
-// Every phase waits for ALL of this wave's outstanding requests (vmcnt(0)) before the barrier.  The requests are issued two
-// slabs / one chunk ahead, so the youngest is a phase old and the wait costs ~2 %.  Counting them instead (vmcnt(4) / (8):
-// "slab p and this phase's chunk have landed once only the younger requests remain") worked in K13 but gave stale LDS
-// reads here -- whole windows wrong in ~3 % of the windows of every launch beyond the first round of workgroups -- whenever
-// six or more requests were allowed to stay in flight across a barrier of the k / v phases; the run-to-run determinism test
-// of tests/test_attn_block_gpu.py is what found it.
 // F.elu(x) + 1 = x + 1 (x > 0), e^x otherwise, as 2^(x log2 e) on the hardware exponential (as K9's LinearAttention epilogues,
 // conv_igemm_f16s.hip:la_elu1): the rounding of the argument costs |x| e^x 2^-24 <= 2^-25 absolute -- half an ulp of 1.0, the size
 // of a K' -- where expm1f(x) + 1 rounds twice; 4 instructions instead of ~37 and two branches per value (round 5: the 128 expm1f
@@ -139,13 +136,15 @@ __device__ __forceinline__ void wait_vm(int n) {
 }
 
 // NW waves per workgroup, NR ring slots; CNT: counted waits, requests NR - 1 phases ahead, double-buffered input chunks (!CNT: every
-// phase drains the queue, one buffer).  ONE instantiation is launched: <8, 4, true>, one workgroup per CU.  Measured on 120 296
-// windows (tools/fine_time.py at commit 2f4e... of round 5, profiles/r05_fine_level.txt): the round-3 form <4, 3, false> and a counted
-// <4, 3, true> -- both TWO workgroups per CU -- were 4-5 % faster (2.17-2.18 vs 2.29 ms) but NOT run-to-run deterministic once the
-// elu got cheap (5 and 156 windows of 120 296 differing per launch, whole workgroups in the counted form); the 8-wave form is
-// (four launches bit-identical, the 50-launch test of tests/test_attn_block_gpu.py, and the bench-scale test added with it).
-// The cause was not isolated -- the same hand-synchronised ring is airtight with one workgroup per CU here and in K17.
-template <int NW, int NR, bool CNT, bool SPLIT>
+// phase drains the queue, one buffer).  History of the pipeline, because it cost two rounds: the round-3 form <4, 3, false> and a
+// counted <4, 3, true> -- both TWO workgroups per CU -- were 4-5 % faster than <8, 4, true> but differed run to run in round 5 once
+// the elu got cheap (5 and 156 windows of 120 296 per launch); round 5 shipped the 8-wave form "because it passed".  Round 6 found
+// the cause (common.h: ring_barrier; docs/rounds/r06.md section 1): the barrier lacked `s_waitcnt lgkmcnt(0)`, hipcc sank each phase's
+// last MFMAs and their lgkmcnt wait below it, and a sibling's re-request of the slot could overtake the two fragment reads still
+// queued.  EVERY form had the hole -- next to a busy second stream the shipped 8-wave form differed in 58 windows over 20 launches,
+// K13 in 1 437 (tools/ring_ab.py, profiles/r06_ring_race.txt); with the wait in place all forms are bit-identical over 20 launches
+// of 120 296 windows next to a busy stream, and the faster two-workgroups-per-CU counted form ships again.
+template <int NW, int NR, bool CNT, bool SPLIT, bool LGKM = true>
 __global__ __launch_bounds__(64 * NW, 2) void k_attn128(const float* __restrict__ x, const float* __restrict__ src,
                                                         const unsigned char* __restrict__ wimg, long nwin, int L, int S, Scales sc,
                                                         float attn_eps, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -231,7 +230,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_attn128(const float* __restrict_
     auto begin_phase = [&](int p) {
         constexpr VmTable vmt(NPIECE, AHEAD);
         wait_vm(CNT ? vmt.a[p] : 0);
-        asm volatile("s_barrier" ::: "memory");
+        ring_barrier<LGKM>();                                  // common.h: no LDS read of this wave in flight at the barrier
         __builtin_amdgcn_sched_barrier(0);
     };
     auto next_w = [&](int p) { if (p + AHEAD < NSLAB) request_w(p + AHEAD); };
@@ -429,14 +428,35 @@ static int attn_block_launch(const float* x, const float* src, const void* packe
         d_model != DM || heads != 8 || out == x || out == src)
         return FAR_EINVAL;
     const Scales sc{scale_k, scale_v, scale_q, scale_m};
-    bool cfg_failed = false;
-    FAR_ONCE_PER_DEVICE(cfg_failed = hipFuncSetAttribute((const void*)k_attn128<WAVES, RING, true, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_NEW) != hipSuccess);
-    if (cfg_failed) return far_check_launch();
-    const long nb = (nwin + WAVES - 1) / WAVES;
-    if (nb > 0x7fffffffL) return FAR_EINVAL;
-    hipLaunchKernelGGL((k_attn128<WAVES, RING, true, SPLIT>), dim3((unsigned)nb), dim3(64 * WAVES), SMEM_NEW, stream, x, src,
-                       (const unsigned char*)packed, nwin, L, S, sc, attn_eps, gamma, beta, ln_eps, out, overflow);
-    return far_check_launch();
+    auto launch = [&](auto kern, int waves, int smem) -> int {
+        bool cfg_failed = false;             // (a generic lambda: one flag per kernel instantiation)
+        FAR_ONCE_PER_DEVICE(cfg_failed = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess);
+        if (cfg_failed) return far_check_launch();
+        const long nb = (nwin + waves - 1) / waves;
+        if (nb > 0x7fffffffL) return FAR_EINVAL;
+        hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(64 * waves), smem, stream, x, src, (const unsigned char*)packed, nwin, L, S, sc,
+                           attn_eps, gamma, beta, ln_eps, out, overflow);
+        return far_check_launch();
+    };
+    // far_set_tuning(11, v): 0 (default) = <4 waves, 3 slots, counted waits>, two workgroups per CU; 1 = <8 waves, 4 slots, counted>,
+    // one workgroup per CU (round 5's form); 2 = <4, 3, vmcnt(0) per phase> (the field fallback without a wait table).  All
+    // three are bit-identical (tests/test_determinism_gpu.py, tests/test_flags_gpu.py).
+    constexpr int SMEM4 = 3 * SLAB + 4 * XBUF, SMEM4C = 3 * SLAB + 4 * 2 * XBUF;
+    const int v = far_get_tuning(11);
+#ifdef FAR_RING_EXP
+    // experiment build (tools/ring_ab.py): v & 4 = the barrier WITHOUT its lgkmcnt(0) -- the rounds-3..5 code that raced
+    switch (v & 7) {
+        case 4: return launch(k_attn128<4, 3, true, SPLIT, false>, 4, SMEM4C);
+        case 5: return launch(k_attn128<WAVES, RING, true, SPLIT, false>, WAVES, SMEM_NEW);
+        case 6: return launch(k_attn128<4, 3, false, SPLIT, false>, 4, SMEM4);
+        default: break;
+    }
+#endif
+    switch (v & 3) {
+        case 1: return launch(k_attn128<WAVES, RING, true, SPLIT>, WAVES, SMEM_NEW);
+        case 2: return launch(k_attn128<4, 3, false, SPLIT>, 4, SMEM4);
+        default: return launch(k_attn128<4, 3, true, SPLIT>, 4, SMEM4C);
+    }
 }
 
 extern "C" {

@@ -92,6 +92,21 @@ __device__ __forceinline__ void softmax_merge(float& m, float& s, float mo, floa
     m = mn;
 }
 
+// The barrier of a hand-synchronised LDS-DMA ring (K9, K13, K14, K17: asm global_load_lds_dwordx4 into a slot right behind the
+// barrier that follows the slot's last reader).  RULE: no LDS read of the wave may be outstanding when it arrives -- nothing orders
+// an LDS-DMA write behind a ds_read that is still queued, and `asm volatile("s_barrier")` pins memory instructions only: hipcc
+// sinks the last MFMAs of a phase and the s_waitcnt lgkmcnt in front of them below it, so without this explicit wait a wave crosses
+// the barrier with its last fragment reads still in the LDS queue and a sibling's (L2-hot) re-request of the slot can land first.
+// That was the run-to-run difference of K14's two-workgroups-per-CU forms in round 5 (single wrong windows; root cause and the
+// ring-only reproducer: docs/rounds/r06.md section 1, tools/ubench/ring_war.hip).  far_amd/build.py scans the generated code of every
+// kernel that issues LDS-DMA for a barrier with LDS reads outstanding and fails the build on one.
+// LGKM = false exists for the FAR_RING_EXP experiment builds only (the rounds-3..5 form, to reproduce the race).
+template <bool LGKM = true>
+__device__ __forceinline__ void ring_barrier() {
+    if (LGKM) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_barrier" ::: "memory");
+}
+
 // Vendor libraries (rocBLAS / hipBLASLt kernel lookups) can leave a benign error in HIP's per-thread "last error"
 // slot; every entry point clears it first so that far_check_launch() only reports this library's own launches.
 static inline void far_clear_errors() { (void)hipGetLastError(); }

@@ -66,12 +66,14 @@ __device__ __forceinline__ float sum32(float v) {
     return v + shfl_xor_f(v, 16);
 }
 
-// Every phase waits for all of this wave's outstanding requests (vmcnt(0)) before the barrier: they are issued two slabs /
-// one chunk ahead, so the youngest is a phase old (measured: no slower than counted waits; see attn_block_f16s.hip for why
-// the counted form was dropped).
+// Every phase waits for all of this wave's outstanding requests (vmcnt(0)) AND for its LDS reads (lgkmcnt(0): ring_barrier,
+// common.h) before the barrier.  The requests are issued two slabs / one chunk ahead, so the youngest is a phase old (measured:
+// no slower than counted waits).  Until round 6 the lgkmcnt(0) was missing: hipcc sinks the last MFMAs of a slab below the asm
+// barrier, a wave crossed it with two fragment reads queued and a sibling's re-request of the slot could land first -- 1 437
+// windows of 120 296 wrong over 20 launches next to a busy second stream (profiles/r06_ring_race.txt), none with the wait.
 
 // SPLIT = false (far_mlp_fused_f16, round 5): plain fp16 operands, one MFMA per product; the data movement is unchanged
-template <bool SPLIT>
+template <bool SPLIT, bool LGKM = true>
 __global__ __launch_bounds__(256, 2) void k_mlp128(const float* __restrict__ x, const float* __restrict__ msg,
                                                    const unsigned char* __restrict__ wimg, long R, float hscale, float oscale,
                                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp128(const float* __restrict__ x, 
 #pragma unroll
     for (int s = 0; s < NS1; ++s) {                            // unrolled: ring slots and chunk parity are immediates
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_barrier" ::: "memory");                               // all 16 pieces of slab s visible; slot (s + 2) % 3 is free
+        ring_barrier<LGKM>();                                                 // all 16 pieces of slab s visible; slot (s + 2) % 3 is free
         if ((s & 1) == 0) {                                   // a new chunk: read this lane's 64 bytes, split
             float4 raw[4];
 #pragma unroll
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp128(const float* __restrict__ x, 
     for (int t = 0; t < HT; ++t) {
         const int s = NS1 + t;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_barrier" ::: "memory");      
+        ring_barrier<LGKM>();
         if (s + 2 < NSLAB) request_w(s + 2);
         const unsigned char* slab = ring + (s % RING) * SLAB + lane * 16;
         // hidden = relu(acc * 2^-(w_exp + 4)), then x 2^4 for the split: hscale = 2^-w_exp.  Both k-steps' A operands first
@@ -256,6 +258,13 @@ int mlp_fused_launch(const float* x, const float* msg, const void* packed, long 
     if (!x || !msg || !packed || !gamma || !beta || !out || R < 0 || d_model != DM || out == x || out == msg) return FAR_EINVAL;
     const long nb = (R + 32 * WAVES - 1) / (32 * WAVES);
     if (nb > 0x7fffffffL) return FAR_EINVAL;
+#ifdef FAR_RING_EXP
+    if (far_get_tuning(11) & 4) {        // experiment build: the barrier without its lgkmcnt(0) (rounds 3-5)
+        hipLaunchKernelGGL((k_mlp128<SPLIT, false>), dim3((unsigned)nb), dim3(64 * WAVES), 0, stream, x, msg, (const unsigned char*)packed, R,
+                           hscale, oscale, gamma, beta, eps, out, overflow);
+        return far_check_launch();
+    }
+#endif
     hipLaunchKernelGGL(k_mlp128<SPLIT>, dim3((unsigned)nb), dim3(64 * WAVES), 0, stream, x, msg, (const unsigned char*)packed, R, hscale,
                        oscale, gamma, beta, eps, out, overflow);
     return far_check_launch();

@@ -39,7 +39,7 @@ SWITCHES = [
 ENV_ONLY = {
     'FAR_HIP_LIB': ('load', 'path of another build of libfar_hip.so (tools/ab_build.py: same-box A/B against a git revision); skips the build-id check'),
     'FAR_TUNING': ('load', 'comma-separated key=value pairs handed to far_set_tuning at load time, e.g. FAR_TUNING="10=1,8=1" (keys below)'),
-    'FAR_SKIP_ASM_CHECK': ('build', "1: far_amd/build.py does not scan K9's generated code (asm pixel loads) after recompiling it"),
+    'FAR_SKIP_ASM_CHECK': ('build', "1: far_amd/build.py does not scan the generated code (K9's asm pixel loads; the LDS-DMA ring rule of every kernel with global_load_lds) after recompiling"),
     'FAR_EXTRA_HIPCC_FLAGS': ('build', 'extra hipcc flags of an experiment build (-DFAR_WINO_EXP=..., tools/wino_exp.sh); part of the build id'),
     'FAR_COMMIT': ('tools', 'commit stamp tools/collect_profiles.sh / tools/step_floors.py write into the profile files'),
     'FAR_C3_PY_NODE': ('bench', "bench.py --workload c3: the encoder layer's autograd node driven from Python instead of far_enc_layer_fwd / _bwd"),
@@ -62,6 +62,7 @@ TUNING = [
     Tuning(8, 0, (1,), 'bitwise', 'K17 splits its operands with the five-instruction split2 instead of v_fma_mix (same values)'),
     Tuning(9, 0, (1,), 'bitwise', 'K17 runs a short last channel block on the full body'),
     Tuning(10, 0, (1,), 'bitwise', "K1's match pass without the tile prescreen"),
+    Tuning(11, 0, (1, 2), 'bitwise', "K14's pipeline: 0 = 4 waves / 3 slots / counted waits, two workgroups per CU; 1 = 8 waves / 4 slots / counted, one per CU (round 5's form); 2 = 4 waves / 3 slots / vmcnt(0) per phase (fallback without a wait table)"),
     Tuning(12, 0, (1,), 'parity', "K10's inference form on the exact-f32 matrix instruction instead of split fp16"),
     Tuning(15, 0, (1,), 'bitwise', 'K17: 1 = the multiplying wave group does NOT raise its issue priority (the round-4 kernel)'),
     Tuning(13, 0, (1,), 'bitwise', "K9's FPN-merge epilogue in its generic form everywhere"),

@@ -1,0 +1,154 @@
+"""Bench-scale run-to-run determinism of every kernel that synchronises an LDS-DMA ring by hand (K9, K13, K14, K17), next to a busy
+second stream -- the gate VERDICT r5 item 1 asks for.
+
+Why it exists: until round 6 the barriers of K13 / K14 lacked `s_waitcnt lgkmcnt(0)` (far_amd/csrc/common.h: ring_barrier).  hipcc
+sinks the last MFMAs of a phase below an `asm volatile` barrier, a wave crossed it with two fragment reads still queued and a
+sibling's re-request of the ring slot could overtake them: single wrong windows (errors 0.3-0.6), different ones in every launch,
+only at bench sizes and only with the LDS port busy (docs/rounds/r06.md section 1; tools/ubench/ring_war.hip is the ring-only
+reproducer, tools/ring_ab.py the A/B on the real kernels).  The 20 000-window test of round 4 never saw it and round 5's 120 296-window
+test passed the shipped form because its neighbour stream was one small kernel.  Here: the bench shapes (reference
+loftr_module/transformer.py:44-67 at 307 200 / 153 600 rows, backbone/resnet_fpn.py:101-119 at 64 x 240 x 320), >= 20 launches each,
+a neighbour that keeps HBM and the CUs busy, every output bit-identical to the first launch.  far_amd/build.py additionally scans
+the generated code of these kernels for a barrier with LDS reads outstanding at build time.
+"""
+import numpy as np
+import pytest
+import torch
+
+from far_amd import synth
+from far_amd.config import far_eval_config
+
+pytestmark = pytest.mark.gpu
+LAUNCHES = 20
+
+
+class Neighbour:
+    """A second stream that streams 256 MB through an elementwise kernel and a reduction per call."""
+
+    def __init__(self):
+        self.side = torch.cuda.Stream()
+        self.big = torch.randn(64 << 20, device='cuda')
+
+    def kick(self):
+        with torch.cuda.stream(self.side):
+            b = self.big * 1.0001
+            b.sum()
+
+    def done(self):
+        self.side.synchronize()
+        torch.cuda.synchronize()
+
+
+def _repeat(fn, what, rows_dim=None):
+    """fn() LAUNCHES + 1 times next to the neighbour; every output (tensor or tuple of tensors) bit-identical to the first."""
+    nb = Neighbour()
+    first = fn()
+    first = first if isinstance(first, (tuple, list)) else (first,)
+    first = [t.clone() for t in first]
+    for it in range(LAUNCHES):
+        nb.kick()
+        out = fn()
+        out = out if isinstance(out, (tuple, list)) else (out,)
+        for k, (a, b) in enumerate(zip(out, first)):
+            if not torch.equal(a, b):
+                d = (a - b).abs()
+                nbad = int((d.flatten(1).max(1).values > 0).sum()) if d.dim() > 1 else int((d > 0).sum())
+                raise AssertionError(f'{what}: output {k} differs at launch {it}: {nbad} rows of {a.shape[0]}, max |diff| {float(d.max()):.3e}')
+    nb.done()
+
+
+def test_fine_level_kernels_bench_scale_all_pipelines():
+    """K14 (all three pipelines of far_set_tuning key 11: the default two-workgroups-per-CU counted form, round 5's 8-wave form, the
+    vmcnt(0) fallback) and K13 on 120 296 windows: 20 launches each bit-identical, and the pipelines bit-identical to each other."""
+    from far_amd import _lib, ops
+    lib = _lib.load()
+    D, H = 128, 8
+    g = torch.Generator(device='cuda').manual_seed(78)
+    ws = [torch.randn(D, D, device='cuda', generator=g) / 11 for _ in range(4)]
+    gam, bet = torch.rand(D, device='cuda', generator=g) + 0.5, torch.randn(D, device='cuda', generator=g) * 0.1
+    w0 = torch.randn(2 * D, 2 * D, device='cuda', generator=g) / 16
+    w2 = torch.randn(D, 2 * D, device='cuda', generator=g) / 16
+    pa, pm = ops.PackedAttn(*ws), ops.PackedMlp(w0, w2)
+    n = 120296
+    x = torch.randn(n, 25, D, device='cuda', generator=g)
+    s = torch.randn(n, 25, D, device='cuda', generator=g)
+    outs = []
+    try:
+        for v in (0, 1, 2):
+            lib.far_set_tuning(11, v)
+            _repeat(lambda: ops.attn_block(x, s, pa, H, gam, bet, 1e-5), f'K14 pipeline {v}')
+            outs.append(ops.attn_block(x, s, pa, H, gam, bet, 1e-5))
+    finally:
+        lib.far_set_tuning(11, 0)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    _repeat(lambda: ops.mlp_fused(x, outs[0], pm, gam, bet, 1e-5), 'K13')
+    _repeat(lambda: ops.mlp_fused(x, outs[0], pm, gam, bet, 1e-5, plain16=True), 'K13 plain fp16')
+
+
+@pytest.mark.parametrize('kind', ['self', 'cross'])
+def test_linear_layers_of_a_d256_encoder_layer_bench_scale(kind):
+    """All five K9 Linear launch shapes of a d_model-256 LoFTR layer (k|v projection -> K'^T V state, q projection -> message,
+    merge + norm1, mlp[0] on cat[x, msg] + ReLU, mlp[2] + norm2 + residual) at the bench row counts: 'self' on both images stacked =
+    64 x 4800 = 307 200 rows, 'cross' = 153 600 rows per side."""
+    from far_amd.loftr.transformer import LoFTREncoderLayer
+    torch.manual_seed(3)
+    layer = LoFTREncoderLayer(256, 8).cuda().eval()
+    g = torch.Generator(device='cuda').manual_seed(11)
+    n = 64 if kind == 'self' else 32
+    x = torch.randn(n, 4800, 256, device='cuda', generator=g)
+    src = x if kind == 'self' else torch.randn(n, 4800, 256, device='cuda', generator=g)
+    with torch.no_grad():
+        _repeat(lambda: layer(x, src), f'K9 Linear, d256 layer ({kind}, {n * 4800} rows)')
+
+
+@pytest.mark.parametrize('cin,cout', [(128, 128), (208, 208)])
+def test_winograd_conv_bench_scale(cin, cout):
+    """K17 at the backbone's two widest stride-1 3x3 shapes: 64 images x 240 x 320, 128 and 208 (= 196 padded) channels."""
+    from far_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(cin)
+    x = torch.randn(64, 240, 320, cin, device='cuda', generator=g).relu_()
+    pw = ops.PackedWino(torch.randn(cout, cin, 3, 3, device='cuda', generator=g) * 0.03)
+    _repeat(lambda: ops.conv3x3_wino(x, pw, act='relu'), f'K17 {cin}->{cout} @ 64 x 240 x 320')
+
+
+@pytest.mark.parametrize('shape', [(64, 240, 320, 128, 196, 3, 2), (64, 120, 160, 196, 256, 3, 2), (64, 240, 320, 128, 196, 1, 1),
+                                   (64, 60, 80, 256, 256, 1, 1), (16, 240, 320, 128, 128, 3, 1)])
+def test_direct_conv_bench_scale(shape):
+    """K9 in convolution mode at the backbone's shapes: the stride-2 3x3 layers, 1x1 layers, and a stride-1 3x3 (the shape class K17
+    replaced on the parity line but the fp16 modes and training still run on K9)."""
+    from far_amd import ops
+    N, H, W, Cin, Cout, ks, st = shape
+    g = torch.Generator(device='cuda').manual_seed(H + Cin + ks)
+    x = torch.randn(N, H, W, Cin, device='cuda', generator=g)
+    for split in (True, False):
+        pc = ops.PackedConv(torch.randn(Cout, Cin, ks, ks, device='cuda', generator=g) * 0.03, split=split, stride=st)
+        _repeat(lambda: ops.conv_nhwc(x, pc, act='relu'), f'K9 conv {shape} split={split}')
+
+
+def test_whole_batch32_step_twice_bit_identical():
+    """One whole BASELINE configs[1] step (32 pairs @ 640 x 480: matcher, two solver rounds, two head calls) three times, the second
+    and third next to the busy neighbour: every output tensor bit-identical."""
+    from far_amd.loftr import LoFTR
+    from far_amd.pipeline import test_step
+    m = LoFTR(far_eval_config()).eval()
+    synth.load_synthetic(m, seed=0)
+    m = m.cuda()
+    im0, im1 = synth.synth_image_pair(32, seed=5)
+    K = torch.from_numpy(np.stack([synth.MP3D_K] * 32)).cuda()
+    keys = ('i_ids', 'j_ids', 'b_ids', 'mconf', 'mkpts0_f', 'mkpts1_f', 'expec_f', 'featmap0', 'featmap1', 'loftr_rt', 'solver_inlier_mask',
+            'regressed_rt', 'match_counts')
+    runs = []
+    nb = Neighbour()
+    for r in range(3):
+        data = {'image0': torch.from_numpy(im0).cuda(), 'image1': torch.from_numpy(im1).cuda(), 'K0': K, 'K1': K.clone(), 'dataset_name': ['mp3d']}
+        if r:
+            nb.kick()
+        test_step(m, data, H=512, seed=1)
+        torch.cuda.synchronize()
+        runs.append({k: data[k].clone() if torch.is_tensor(data[k]) else torch.as_tensor(np.asarray(data[k])) for k in keys})
+        runs[-1]['priorRT'] = torch.as_tensor(np.asarray(data['priorRT']))
+    nb.done()
+    assert int(runs[0]['match_counts'].sum()) > 32 * 1000
+    for r in (1, 2):
+        for k in runs[0]:
+            assert torch.equal(runs[0][k], runs[r][k]), f'run {r}: {k} differs'

@@ -33,7 +33,7 @@ def test_every_registered_name_is_used_and_every_used_name_is_registered():
     names = set()
     for p in list(_sources(('.py', '.sh'), ['far_amd', 'tools'])) + [os.path.join(ROOT, 'bench.py')]:
         names |= set(re.findall(r'\b(FAR_[A-Z0-9_]+)\b', open(p).read()))
-    compile_time = {n for n in names if n.startswith(('FAR_WINO_', 'FAR_K9_', 'FAR_ONCE', 'FAR_OK', 'FAR_EVAL_CONFIG', 'FAR_LS_', 'FAR_NO_X', 'FAR_DPP', 'FAR_BUILD_ID', 'FAR_SIDE'))
+    compile_time = {n for n in names if n.startswith(('FAR_WINO_', 'FAR_K9_', 'FAR_RING_', 'FAR_ONCE', 'FAR_OK', 'FAR_EVAL_CONFIG', 'FAR_LS_', 'FAR_NO_X', 'FAR_DPP', 'FAR_BUILD_ID', 'FAR_SIDE'))
                     or re.fullmatch(r'FAR_E[A-Z]+', n)}
     used = names - compile_time
     assert flags.known() <= used | {'FAR_COMMIT'}, sorted(flags.known() - used)
