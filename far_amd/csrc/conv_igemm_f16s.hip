@@ -869,6 +869,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p) {
     constexpr int B_PLANE = NT * 32;                 // one 16-channel k-step of the weight slab
     constexpr int B_BUF = 2 * B_PLANE;               // split: hi | lo of one k-step; plain: k-step 0 | k-step 1
     constexpr int B_ITERS = (B_BUF + NTHR * 16 - 1) / (NTHR * 16);   // DMA rounds per slab (the last may be partial)
+    static_assert(B_BUF % (NTHR * 16) == 0, "stage_arrived<N * B_ITERS> counts exactly B_ITERS LDS-DMA requests per wave and slab: a partial last round (wave-dependent) would make the counted vmcnt waits wrong");
     constexpr int ITERS = (G::ITEMS + NTHR - 1) / NTHR;
     constexpr int LOAD_TAP = TAPS >= 3 ? TAPS - 3 : 0;   // the next chunk's pixels are requested this early
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

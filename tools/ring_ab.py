@@ -2,10 +2,10 @@
 """Round 6, the LDS-DMA ring race on the REAL kernels (the ring-only reproducer is tools/ubench/ring_war.hip).
 
   python tools/ring_ab.py --build     (CPU) builds far_amd/lib/exp/libfar_ringexp.so: the product objects, with attn_block_f16s.hip
-                                      and mlp_fused_f16s.hip recompiled under -DFAR_RING_EXP (far_set_tuning(11, v) then selects
-                                      K14's pipelines v & 3 = 0 shipped <8 waves, 4 slots, counted>, 1 <4, 3, vmcnt(0)>, 2 <4, 3, counted>
-                                      -- the latter two run TWO workgroups per CU -- and v & 4 = the barrier WITHOUT its lgkmcnt(0),
-                                      i.e. the rounds-3..5 code; K13: v & 4 likewise)
+                                      and mlp_fused_f16s.hip recompiled under -DFAR_RING_EXP (far_set_tuning(11, v): v = 0 / 1 / 2 are the
+                                      product's K14 pipelines -- <4 waves, 3 slots, counted> and <4, 3, vmcnt(0)> run TWO workgroups
+                                      per CU, <8, 4, counted> one -- and v = 4 / 5 / 6 the same three with the barrier WITHOUT its
+                                      lgkmcnt(0), i.e. the rounds-3..5 code; K13: v & 4 likewise)
   FAR_HIP_LIB=far_amd/lib/exp/libfar_ringexp.so python tools/ring_ab.py [--windows 60148] [--launches 20]
                                       (GPU) every variant: event-timed, then `launches` launches next to a busy second stream, windows
                                       that differ from the first launch and from the shipped form counted.
@@ -75,12 +75,14 @@ def main():
     n = 2 * a.windows
     x = torch.randn(n, 25, D, device='cuda', generator=g)
     s = torch.randn(n, 25, D, device='cuda', generator=g)
-    names = {0: 'shipped <8 waves, 4 slots, counted>, 1 wg/CU', 1: '<4, 3, vmcnt(0)>, 2 wg/CU', 2: '<4, 3, counted>, 2 wg/CU'}
+    # far_set_tuning(11, v) as attn_block_launch reads it: v & 3 selects the pipeline; FAR_RING_EXP builds: v = 4 / 5 / 6 = pipeline 0 / 1 / 2
+    # with the barrier WITHOUT its lgkmcnt(0)
+    names = {0: '<4 waves, 3 slots, counted>, 2 wg/CU (default)', 1: '<8 waves, 4 slots, counted>, 1 wg/CU (round 5)', 2: '<4, 3, vmcnt(0)>, 2 wg/CU'}
     for kern in ('K14', 'K13'):
         fn = (lambda: ops.attn_block(x, s, pa, H, gam, bet, 1e-5)) if kern == 'K14' else (lambda: ops.mlp_fused(x, s, pm, gam, bet, 1e-5))
         lib.far_set_tuning(11, 0)
         ref = fn()
-        for v in ((0, 4, 1, 5, 2, 6) if kern == 'K14' else (0, 4)):
+        for v in ((1, 0, 4, 1, 5, 2, 6, 0) if kern == 'K14' else (0, 4, 0)):      # (the first entry warms the clocks up)
             lib.far_set_tuning(11, v)
             t = ev(torch, fn)
             first = fn()
