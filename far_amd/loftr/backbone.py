@@ -7,8 +7,8 @@ Inference in fp32 on the GPU runs `_forward_fused`: NHWC activations end to end,
 convolution on K9 (split-fp16 implicit GEMM with BatchNorm, activation and residual add fused into the epilogue), the
 FPN upsample-add on K8: no vendor convolution is left on the inference path.
 Training (gradients) on the GPU runs the same module graph with every 3x3 / 1x1 convolution on K9 forward and K9 dgrad
-(ops.conv_train; BatchNorm with batch statistics, activations and the FPN interpolation stay torch ops); CPU tensors and
-the optional half-precision modes run the plain torch modules.
+(ops.conv_train), BatchNorm with batch statistics + activation + shortcut add on K19; CPU tensors and `hip_training = False`
+need the test-side helper (far_amd/_vendor.py) -- the plain torch modules are then what runs.
 """
 import os
 
@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import flags, ops
+from .. import _vendor, flags, ops
 
 
 def _fold(bn):
@@ -104,7 +104,7 @@ class BasicBlock(nn.Module):
         self.relu = nn.ReLU(inplace=True)
         self.downsample = None if stride == 1 else nn.Sequential(_c1(in_planes, planes, stride), nn.BatchNorm2d(planes))
 
-    def forward(self, x):          # reference-style modules: training, CPU, autocast (inference runs _forward_fused)
+    def forward(self, x):          # the module graph of training (inference runs _forward_fused)
         if _bn_hip(self.bn1, x):   # training on the GPU: BatchNorm (batch statistics) + activation + shortcut add on K19 / K7
             h = ops.bn_act_train(_conv(self.conv1, x, self), self.bn1, 'relu')
             if self.downsample is not None:
@@ -207,6 +207,8 @@ class ResNetFPN_8_2(nn.Module):
     def forward(self, x):
         if _fused_ok(self, x) and x.shape[1] == 1:
             return self._forward_fused(x)
+        if not x.is_cuda or not ResNetFPN_8_2.hip_training:
+            _vendor.require('the backbone on CPU tensors or with hip_training = False (vendor convolutions)')
         if (ResNetFPN_8_2.hip_training and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and x.shape[1] == 1
                 and self.conv1.weight.requires_grad and self.conv1.out_channels in (64, 128)):
             x0 = ops.stem_train(x, self.conv1.weight)                                # K10 + its weight gradient

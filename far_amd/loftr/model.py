@@ -93,59 +93,69 @@ class LoFTR(nn.Module):
             self.fine_matching = FineMatching(config)
         if config['regress_rt']:
             self.loftr_regress = LocalFeatureTransformerRegressor(config)
-        # backbone arithmetic, see set_precision; fp32-grade = parity configuration
-        self.backbone_dtype = torch.float32
+        self.precision_stages = ()      # stages on 16-bit operands (set_precision); () = fp32-grade everywhere = the parity configuration
         # exponent of the power-of-two activation scale of the split-fp16 kernels (ops.activation_exponent): 4 covers
         # |activation| <= 4094; lowered by _widen_activation_range when a launch reports an overflow
         self.act_exp = 4
 
-    PRECISIONS = ('fp32', 'fp16-fine', 'fp16', 'mixed16', 'bf16')
+    # Operand precision of the matrix products, by stage.  Tensors stay fp32, accumulation stays fp32, the float64 solver is untouched.
+    # The reference computes in fp32 throughout (no mixed-precision region, no half / bfloat16 cast anywhere in /root/reference): 'fp32' -- split-fp16 operand pairs,
+    # fp32-grade products -- is the ONLY parity configuration.  Every 16-bit stage below changes results (ids are no longer bit-exact,
+    # the solver's pose error on the bench pairs grows: bench.py `other_modes` / `precision_stages` report it per stage); they exist
+    # because BASELINE configs[1] names a 16-bit operand class, and are never what `value` is measured on.
+    STAGES = ('trunk',          # backbone trunk (stem excluded): K9 on plain fp16 operands instead of K17 / K9 on split pairs
+              'fpn',            # the FPN's fine branch (layer1 / layer2 outconvs): coarse features and match decisions unchanged
+              'coarse_dense',   # d_model-256 layers (coarse transformer + the head's two): merge / MLP launches on plain fp16
+              'coarse_state',   # ... and their fused k|v-state / q-apply launches too (implies coarse_dense)
+              'fine_layers',    # the fine level's d_model-128 layers: K13 / K14 on plain fp16 (far_mlp_fused_f16 / far_attn_block_f16)
+              'k1',             # coarse matching on bf16 operands (far_coarse_match_bf16)
+              'k2')             # the head's CrossAttention: qkv projection and K2 on plain fp16 (far_emm_pv_f16)
+    MODES = {'fp32': (), 'fp16-fine': ('fpn',),
+             'mixed16': ('trunk', 'fpn', 'coarse_dense', 'k1', 'k2'),
+             'fp16': STAGES}
+    PRECISIONS = tuple(MODES)
     head_prefetch = not flags.off('FAR_NO_PREFETCH')   # inference: the head's feature stage enqueued behind K1 (see below)
 
     def set_precision(self, mode):
-        """Operand precision of the matrix products (tensors stay fp32, accumulation stays fp32, the float64 solver is untouched):
-          'fp32'      K9 with split-fp16 operand pairs: fp32-grade -- the parity configuration (default);
-          'fp16-fine' split trunk + plain-fp16 operands in the FPN branch: coarse features and match decisions stay
-                      bit-identical, only the sub-pixel refinement input changes;
-          'fp16'      16-bit operands in the step's large matrix products (fp32 accumulation, fp32 tensors): plain fp16 in K9
-                      (backbone, encoder layers incl. the fused k|v-state / q-apply launches, the head's qkv projection),
-                      K13 / K14 (far_mlp_fused_f16, far_attn_block_f16) and K2 (far_emm_pv_f16), bf16 in K1
-                      (far_coarse_match_bf16) -- the precision class BASELINE configs[1] names and the reference runs in
-                      under autocast; the fastest mode.  (FinePreprocess's two projections, the attention-state products
-                      inside the epilogues and the head's small dense layers keep fp32-grade products: < 2 % of the step);
-          'mixed16'   between the two (round 5): plain-fp16 K9 in the backbone,
-                      bf16 operands in K1 (far_coarse_match_bf16), plain-fp16 operands in K2 (far_emm_pv_f16) and in the
-                      d_model-256 layers' merge / MLP launches; their fused k|v-state / q-apply launches and the fine
-                      level's K13 / K14 stay on split operands: the attention states and the sub-pixel refinement keep
-                      fp32-grade products;
-          'bf16'      the vendor convolutions under bf16 autocast (reference-style modules), channels_last."""
-        if mode not in self.PRECISIONS:
-            raise ValueError(f'precision must be one of {self.PRECISIONS}')
-        self.backbone_dtype = torch.bfloat16 if mode == 'bf16' else torch.float32
+        """mode: a name of MODES or an iterable of STAGES names (the stages that run on 16-bit operands).
+          'fp32'      every product on split-fp16 operand pairs: fp32-grade, the parity configuration (default);
+          'fp16-fine' plain-fp16 operands in the FPN branch only: coarse features, ids and mconf bit-identical to 'fp32';
+          'mixed16'   16-bit operands where they pay most (backbone, K1, K2, the d256 layers' merge / MLP launches); the attention-state
+                      launches and the fine level keep fp32-grade products;
+          'fp16'      16-bit operands in every large matrix product of the step: the fastest mode and the least accurate
+                      (FinePreprocess's two projections, the small attention-state products inside the epilogues and the head's
+                      small dense layers keep fp32-grade products: < 2 % of the step)."""
+        if isinstance(mode, str):
+            if mode not in self.MODES:
+                raise ValueError(f'precision must be one of {self.PRECISIONS} or an iterable of {self.STAGES}')
+            st = set(self.MODES[mode])
+        else:
+            st = set(mode)
+            if not st <= set(self.STAGES):
+                raise ValueError(f'unknown precision stages {sorted(st - set(self.STAGES))}; known: {self.STAGES}')
+        self.precision_stages = tuple(s for s in self.STAGES if s in st)
         if hasattr(self, 'backbone'):                      # (the cached-prediction configuration builds the head only)
-            self.backbone.trunk_split = mode in ('fp32', 'fp16-fine')
-            self.backbone.fpn_split = mode == 'fp32'
+            self.backbone.trunk_split = 'trunk' not in st
+            self.backbone.fpn_split = 'fpn' not in st
         from .transformer import CrossAttention, LoFTREncoderLayer
+        fine = set(self.loftr_fine.modules()) if hasattr(self, 'loftr_fine') else set()
         for m in self.modules():
             if isinstance(m, LoFTREncoderLayer):
-                m.split_operands = mode != 'fp16'
-                m.dense_split = mode != 'mixed16'
+                if m in fine:
+                    m.split_operands, m.dense_split = 'fine_layers' not in st, True
+                else:
+                    m.split_operands, m.dense_split = 'coarse_state' not in st, 'coarse_dense' not in st
             if isinstance(m, CrossAttention):
-                m.plain16 = mode in ('mixed16', 'fp16')
+                m.plain16 = 'k2' in st
         if hasattr(self, 'coarse_matching'):
-            self.coarse_matching.bf16 = mode in ('mixed16', 'fp16')
+            self.coarse_matching.bf16 = 'k1' in st
         return self
 
     # -------------------------------------------------------------------------------------------------
     # stage 1: local feature CNN on both images at once (loftr.py:56-89)
     # -------------------------------------------------------------------------------------------------
     def _run_backbone(self, images):
-        half = self.backbone_dtype != torch.float32
-        if half:
-            images = images.to(self.backbone_dtype).contiguous(memory_format=torch.channels_last)
-        with torch.autocast('cuda', dtype=self.backbone_dtype, enabled=half):
-            coarse, fine = self.backbone(images)
-        return coarse.float(), fine.float()
+        return self.backbone(images)
 
     def forward_feature_extraction(self, data):
         with ops.activation_exponent(self.act_exp):

@@ -18,7 +18,8 @@ import os
 import torch
 import torch.nn as nn
 
-from .. import autograd_ops as ag
+from .. import _vendor as ag          # needs_grad + the door to the test-side vendor compositions
+from .. import train_glue
 from .. import flags, ops
 
 
@@ -51,6 +52,8 @@ class CoarseMatching(nn.Module):
         """feat_c0 [N, L, C], feat_c1 [N, S, C]; updates data with conf_matrix (optional), b_ids, i_ids,
         j_ids, gt_mask, m_bids, mkpts0_c, mkpts1_c, mconf (coarse_matching.py:144-147, :243-263).
         overlap (inference on the GPU): see ops.coarse_match -- work enqueued behind K1 while the host waits for the match count."""
+        if not feat_c0.is_cuda:
+            ag.require('CoarseMatching on CPU tensors')
         if self.training or ag.needs_grad(feat_c0, feat_c1):
             if overlap is not None:
                 overlap()
@@ -95,9 +98,9 @@ class CoarseMatching(nn.Module):
     # the dense matrix is NOT built: K1's fused kernels select the predicted matches (no grad, as in the reference
     # where get_coarse_match runs under no_grad) and ops.coarse_pos_conf gives the differentiable confidences at
     # spv_b/i/j_ids with a HIP backward (data['conf_pos']; data['conf_matrix'] is None).  far_amd.losses mirrors the
-    # loss on them.  `materialize_conf`, CPU tensors, padded masks or a feature width other than 256 fall back to the
-    # dense differentiable vendor-op form (far_amd/autograd_ops.py) -- explicitly, for drop-in use of the
-    # reference's own dense loss.
+    # loss on them.  Padded masks take the dense autograd composition of far_amd/train_glue.py; `materialize_conf`, CPU tensors or a
+    # feature width other than 256 need the test-side helper (far_amd/_vendor.py) -- explicitly, for drop-in use of the reference's
+    # own dense loss.
     # ------------------------------------------------------------------------------------------------------
     def _forward_train(self, feat_c0, feat_c1, data, mask_c0=None, mask_c1=None):
         # padded-mask batches (coarse_matching.py:28-43, 110-117, 199-204: images of different sizes padded to one grid) take the
@@ -105,7 +108,12 @@ class CoarseMatching(nn.Module):
         sparse = (feat_c0.is_cuda and feat_c0.shape[-1] == 256 and not self.materialize_conf and 'spv_b_ids' in data
                   and self.config.get('sparse_spvs', True) and 'mask0' not in data)
         if not sparse:
-            conf = ag.conf_matrix(feat_c0, feat_c1, self.temperature, mask_c0, mask_c1)
+            if feat_c0.is_cuda and not self.materialize_conf and 'mask0' in data:
+                # padded-mask batches on the GPU: the dense form as an autograd composition (far_amd/train_glue.py, accepted)
+                conf = train_glue.masked_conf_matrix(feat_c0, feat_c1, self.temperature, mask_c0, mask_c1)
+            else:       # CPU tensors, materialize_conf (the reference's own dense loss), other widths: test-side helper
+                conf = ag.require('the dense differentiable conf_matrix (CPU tensors / materialize_conf / sparse_spvs off / C != 256)').conf_matrix(
+                    feat_c0, feat_c1, self.temperature, mask_c0, mask_c1)
             data.update({'conf_matrix': conf})
             with torch.no_grad():
                 b_ids, i_ids, j_ids, mconf = self._select_dense(conf.detach(), data)
@@ -190,7 +198,7 @@ class CoarseMatching(nn.Module):
 # fine level
 # =====================================================================================================
 class FinePreprocess(nn.Module):
-    hip_training = True          # training on the GPU: K3 gather + its scatter backward; False: F.unfold + autograd
+    hip_training = True          # training on the GPU: K3 gather + its scatter backward; False: the test-side unfold composition
 
     def __init__(self, config):
         super().__init__()
@@ -221,6 +229,8 @@ class FinePreprocess(nn.Module):
 
     def forward(self, feat_f0, feat_f1, feat_c0, feat_c1, data):
         W = self.W
+        if not feat_f0.is_cuda:
+            ag.require('FinePreprocess on CPU tensors')
         stride = data['hw0_f'][0] // data['hw0_c'][0]
         data.update({'W': W})
         b, i, j = data['b_ids'], data['i_ids'], data['j_ids']
@@ -233,8 +243,9 @@ class FinePreprocess(nn.Module):
                 w0 = ops.fine_windows_train(feat_f0, b, i, data['hw0_c'][1], W, stride)
                 w1 = ops.fine_windows_train(feat_f1, b, j, data['hw1_c'][1], W, stride)
             else:
-                w0 = ag.fine_windows(feat_f0, b, i, W, stride)
-                w1 = ag.fine_windows(feat_f1, b, j, W, stride)
+                vend = ag.require('FinePreprocess under autograd on CPU tensors or with hip_training = False')
+                w0 = vend.fine_windows(feat_f0, b, i, W, stride)
+                w1 = vend.fine_windows(feat_f1, b, j, W, stride)
         elif self._fused_gather_ok(feat_f0, feat_f1, feat_c0, data):
             # the windows are never stored: merge_feat's Linear launch reads its rows through the window indices (K9 gather mode),
             # both images in one launch -- feat_f0 / feat_f1 are the halves of the backbone's one NHWC buffer
@@ -311,7 +322,9 @@ class FineMatching(nn.Module):
                          'mkpts0_f': data['mkpts0_c'], 'mkpts1_f': data['mkpts1_c']})
             return
         if ag.needs_grad(feat_f0, feat_f1):
-            coords, std = ag.fine_expect(feat_f0, feat_f1)
+            if not feat_f0.is_cuda:
+                ag.require('FineMatching on CPU tensors')
+            coords, std = train_glue.fine_expect(feat_f0, feat_f1)
             data.update({'expec_f': torch.cat([coords, std.unsqueeze(1)], -1)})
             if not self.config['regress_rt'] or not train or self.config['regress']['use_simple_moe']:
                 with torch.no_grad():

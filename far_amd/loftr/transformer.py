@@ -6,8 +6,7 @@ checkpoints load unchanged:
   CrossAttention :250-303, CrossBlock :305-348, LocalFeatureTransformerRegressor :350-499
 and of mp3d_loftr/src/loftr/loftr_module/vit_layers/mlp.py:8-28 (Mlp).
 The attention cores run in libfar_hip.so: K5 (linear attention) and K2 (bilinear dual-softmax, never
-materialising the (B, 4, 4800, 4800) score tensors), K6 (LayerNorm) and K9 (the encoder layers' Linear layers);
-the head's Linear / GELU stay on the vendor path.
+materialising the (B, 4, 4800, 4800) score tensors), K6 (LayerNorm) and K9 / K15 (every Linear layer of the inference path).
 
 Batch semantics: the reference head is batch-size-1 only (its pairing reshape :339-341 and the gate
 broadcasts :466-469 break for B > 1).  Here B pairs are processed as B
@@ -20,7 +19,7 @@ from functools import partial
 import torch
 import torch.nn as nn
 
-from .. import autograd_ops as ag
+from .. import _vendor as ag          # needs_grad + the door to the test-side vendor compositions (far_amd/_vendor.py)
 from .. import flags, ops
 from ..pose6d import pose_mean_6d, pose_std_6d
 
@@ -40,8 +39,9 @@ class LinearAttention(nn.Module):
             if queries.is_cuda and D in (16, 32):     # training on the GPU: K5 forward + K5 backward kernels
                 return ops.linear_attention_train(queries.reshape(N, L, H * D), keys.reshape(N, S, H * D),
                                                   values.reshape(N, S, H * D), H, q_mask, kv_mask, self.eps).view(N, L, H, D)
-            return ag.linear_attention(queries.reshape(N, L, H * D), keys.reshape(N, S, H * D),       # CPU: vendor ops
-                                       values.reshape(N, S, H * D), H, q_mask, kv_mask, self.eps).view(N, L, H, D)
+            vend = ag.require('LinearAttention under autograd on CPU tensors / head dims without a K5 backward')
+            return vend.linear_attention(queries.reshape(N, L, H * D), keys.reshape(N, S, H * D),
+                                         values.reshape(N, S, H * D), H, q_mask, kv_mask, self.eps).view(N, L, H, D)
         as_u8 = lambda m: None if m is None else m.to(torch.uint8).contiguous()
         out = ops.linear_attention(queries.reshape(N, L, H * D), keys.reshape(N, S, H * D),
                                    values.reshape(N, S, H * D), H, as_u8(q_mask), as_u8(kv_mask), self.eps)
@@ -101,13 +101,9 @@ class LoFTREncoderLayer(nn.Module):
                 msg = ops.layernorm_train(lin(msg.view(bs, -1, self.nhead * self.dim), self.merge, 'merge'), self.norm1)
                 msg = lin(torch.relu(lin(torch.cat([x, msg], dim=2), self.mlp[0], 'mlp0')), self.mlp[2], 'mlp2')
                 return ops.layernorm_train(msg, self.norm2, residual=x)          # x + norm2(msg): the add in K6's epilogue
-            q = self.q_proj(x).view(bs, -1, self.nhead, self.dim)                  # CPU: reference-style modules
-            k = self.k_proj(source).view(bs, -1, self.nhead, self.dim)
-            v = self.v_proj(source).view(bs, -1, self.nhead, self.dim)
-            msg = self.attention(q, k, v, q_mask=x_mask, kv_mask=source_mask, loftr_preds=loftr_preds)
-            msg = self.merge(msg.view(bs, -1, self.nhead * self.dim))
-            msg = self.norm2(self.mlp(torch.cat([x, self.norm1(msg)], dim=2)))                             # :61-66
-            return x + msg
+            # CPU tensors / hip_training = False: the reference-style module composition lives with the tests (tests/vendor_ops.py)
+            return ag.require('LoFTREncoderLayer on CPU tensors or with hip_training = False').encoder_layer(
+                self, x, source, x_mask, source_mask, loftr_preds)
         # inference: the five Linear layers on K9 (split-fp16 operands: fp32-grade, and -- unlike a vendor GEMM whose
         # kernel is chosen by the row count -- every output row depends on its input row only)
         pk = self.__dict__.setdefault('_packs', ops.PackCache())
@@ -255,7 +251,9 @@ class Mlp(nn.Module):
     def forward(self, x, residual=None):
         """fc2(act(fc1(x))) (+ residual).  Inference on the GPU: both Linear layers on K9 (every output row depends on its
         input row only), the activation as an elementwise torch op in between, the residual in fc2's epilogue."""
-        if ag.needs_grad(x, self.fc1.weight) or not x.is_cuda:
+        if not x.is_cuda:
+            ag.require('Mlp on CPU tensors')
+        if ag.needs_grad(x, self.fc1.weight) or not x.is_cuda:      # GPU training: autograd through the two parameter containers
             y = self.fc2(self.act(self.fc1(x)))
             return y if residual is None else residual + y
         pk = self.__dict__.setdefault('_packs', ops.PackCache())
@@ -337,6 +335,8 @@ class CrossAttention(nn.Module):
 
     def forward(self, x1, x2, intrinsics=None, loftr_preds=None, inv_loftr_preds=None):
         B, N, C = x1.shape
+        if not x1.is_cuda:
+            ag.require('CrossAttention on CPU tensors')
         h, d = self.num_heads, C // self.num_heads
         if self.pos6.shape[0] != N:
             raise ValueError(f'the positional table of this CrossAttention has {self.pos6.shape[0]} rows (mp3d: the 60x80 coarse grid, '
@@ -350,8 +350,8 @@ class CrossAttention(nn.Module):
             kk, vv = k.reshape(2 * B * h, N, d), v.reshape(2 * B * h, N, d)
             if x1.is_cuda and d == 64 and self.hip_training:       # K2 forward + backward kernels
                 F = ops.emm_bilinear_train(qq, kk, vv, self.pos6, self.scale)
-            else:                                                  # CPU: vendor ops + autograd (dense score tensors)
-                F = ag.bilinear_attention(qq, kk, vv, self.pos6, self.scale)
+            else:                                                  # CPU / hip_training = False: dense score tensors, test-side helper
+                F = ag.require('CrossAttention on CPU tensors or with hip_training = False').bilinear_attention(qq, kk, vv, self.pos6, self.scale)
         else:
             # inference: the qkv Linear on K9 with one output plane per (tensor, head) -- the layout K2 reads in place
             pk = self.__dict__.setdefault('_packs', ops.PackCache())
@@ -419,6 +419,8 @@ class CrossBlock(nn.Module):
 
     def forward(self, x, intrinsics=None, loftr_preds=None, inv_loftr_preds=None):
         """x = cat([feat0, feat1], dim=0): (2B, N, C).  Returns (2B, 70, C), rows (2b, 2b+1) = pair b."""
+        if not x.is_cuda:
+            ag.require('CrossBlock on CPU tensors')
         b_s, h_w, nf = x.shape
         B = b_s // 2
         x = x + self.pos_embed

@@ -92,7 +92,7 @@ def test_k1_sparse_conf_arbitrary_upstream_gradient_and_empty():
 
 def test_k1_training_path_in_model_matches_dense_autograd():
     """The whole matcher in training mode, coarse loss only: K1's sparse HIP path (no conf_matrix) against the dense
-    differentiable vendor-op form (CoarseMatching.materialize_conf = True -> far_amd/autograd_ops.py) on the same
+    differentiable vendor-op form (CoarseMatching.materialize_conf = True -> tests/vendor_ops.py) on the same
     model and pair: same loss, same parameter gradients."""
     from far_amd import synth
     from far_amd.config import far_eval_config
@@ -133,8 +133,8 @@ def test_k1_training_path_in_model_matches_dense_autograd():
 
 @pytest.mark.parametrize('N,L,S,H,D,masked', [(2, 4800, 4800, 8, 32, False), (3, 25, 25, 8, 16, False), (2, 700, 900, 8, 32, True)])
 def test_k5_linear_attention_backward(N, L, S, H, D, masked):
-    """far_linear_attention_bwd_f32 against float64 autograd of linear_attention.py:31-50 (far_amd/autograd_ops.py)."""
-    from far_amd import autograd_ops as ag
+    """far_linear_attention_bwd_f32 against float64 autograd of linear_attention.py:31-50 (tests/vendor_ops.py)."""
+    from tests import vendor_ops as ag
     from far_amd import ops
     rng = np.random.default_rng(L + S)
     mk = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32)).cuda()
@@ -191,8 +191,8 @@ def test_encoder_layer_training_on_hip_matches_vendor_autograd():
 @pytest.mark.parametrize('Z,N', [(2, 221), (4, 640), (8, 4800)])
 def test_k2_bilinear_attention_backward(Z, N):
     """far_emm_bwd_f16 (+ the torch-side N x 70 pieces) against float64 autograd of transformer.py:275-292
-    (far_amd/autograd_ops.py:bilinear_attention, the dense (Z, N, N) form) -- F, dq, dk, dv."""
-    from far_amd import autograd_ops as ag
+    (tests/vendor_ops.py:bilinear_attention, the dense (Z, N, N) form) -- F, dq, dk, dv."""
+    from tests import vendor_ops as ag
     from far_amd import ops
     rng = np.random.default_rng(N)
     mk = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32)).cuda()
@@ -271,7 +271,7 @@ def test_backward_kernels_keep_their_precision_at_any_gradient_scale(log2_scale)
     matrix cores, so each normalises by a power of two of its own first.  Scaling dL/dy by 2^k must reproduce the float64
     gradients to the same relative error as at scale 1 (K9 dgrad: 1e-6; K1: 1e-3; K2: 5e-3) -- found by the fine-level
     gradients of the training step, which are ~1e-7 and came out 4e-2 off before K9's dgrad normalised its input."""
-    from far_amd import autograd_ops as ag
+    from tests import vendor_ops as ag
     from far_amd import ops
     sc = 2.0 ** log2_scale
     rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
@@ -313,7 +313,7 @@ def test_backward_kernels_keep_their_precision_at_any_gradient_scale(log2_scale)
 def test_fine_window_gather_backward_matches_unfold_autograd():
     """K3a's scatter backward (far_fine_scatter_f32) against autograd through F.unfold + gather (fine_preprocess.py:40-47):
     same windows, same gradient of the fine map -- with cells sampled more than once and windows at the image border."""
-    from far_amd import autograd_ops as ag
+    from tests import vendor_ops as ag
     from far_amd import ops
     g = torch.Generator(device='cuda').manual_seed(8)
     N, C, Hf, Wf, W, stride = 2, 128, 24, 32, 5, 4

@@ -1,7 +1,7 @@
 """Training path (BASELINE configs[2]) on CPU: the differentiable vendor-op path of far_amd vs golden G10, which
 tools/make_goldens.py produced by running the REFERENCE's training-mode forward + backward.  Also a 2-rank gloo DDP
 step (gradient all-reduce = the one exchange step of the path).  On CPU tensors the modules run the differentiable
-vendor-op forms (far_amd/autograd_ops.py); on the GPU the same step runs K1 / K5 / K9-linear / K2 forward and backward
+vendor-op forms (tests/vendor_ops.py); on the GPU the same step runs K1 / K5 / K9-linear / K2 forward and backward
 kernels and is held to the same golden (tests/test_pipeline_gpu.py::test_training_step_on_gpu)."""
 import os
 import socket
@@ -62,7 +62,10 @@ def _free_port():
 def _ddp_worker(rank, world, port, q):
     import torch.distributed as dist
     from torch.nn.parallel import DistributedDataParallel as DDP
+    from far_amd import _vendor
     from far_amd.loftr import LoFTR
+    from tests import vendor_ops
+    _vendor.install(vendor_ops)                        # a spawned rank does not run conftest.py: the CPU compositions are test infrastructure
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)

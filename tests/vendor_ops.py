@@ -1,19 +1,13 @@
-"""Differentiable vendor-op forms of the fused operators (torch compositions, autograd supplies the backward).
+"""Torch / vendor-library compositions of far_amd's fused operators (autograd supplies the backward) -- TEST AND BENCHMARK
+INFRASTRUCTURE, not part of the product (moved out of far_amd/ in round 6).  far_amd reaches them only through
+far_amd._vendor after `far_amd._vendor.install(tests.vendor_ops)` (tests/conftest.py; bench.py --vendor-train; tools/make_goldens.py).
 
-Who uses them: (1) CPU tensors in training mode (the golden G10 / G18 / gloo DDP tests); (2) the explicit comparison legs
-`hip_training = False` / `materialize_conf = True` (bench.py --workload c3 --vendor-train); (3) on the GPU the pieces that have
-no HIP backward kernel: the dense coarse stage of padded-mask batches (`conf_matrix` with masks), the fine-window expectation,
-and -- as plain torch modules, not through this file -- BatchNorm with batch statistics and the FPN interpolation.  Everything
-else of the GPU training step has HIP forward + backward kernels: K1 (sparse positions), K2, K5, K6, K9 (Linear layers and the
-backbone's convolutions, forward + dgrad), K16 (every weight gradient), K10 (stem), K3 gather / scatter;
-the inference path never comes here (it raises on CPU tensors).  Citations as in the kernels they stand in for.
+Who uses them: (1) CPU tensors (the golden G10 / G18 tests, the world-size-2 gloo DDP tests: the package itself raises on CPU
+tensors); (2) the explicit comparison legs `hip_training = False` / `materialize_conf = True` (bench.py --workload c3 --vendor-train).
+Citations as in the kernels they stand in for.
 """
 import torch
 import torch.nn.functional as F
-
-
-def needs_grad(*tensors):
-    return torch.is_grad_enabled() and any(t is not None and torch.is_tensor(t) and t.requires_grad for t in tensors)
 
 
 def linear_attention(q, k, v, nhead, q_mask=None, kv_mask=None, eps=1e-6):
@@ -75,3 +69,16 @@ def bilinear_attention(q, k, v, pos, scale):
     A = attn.softmax(dim=-1) * attn.softmax(dim=-2)
     vt = torch.cat([v, pos.unsqueeze(0).expand(v.shape[0], -1, -1)], dim=2)
     return (vt.transpose(-2, -1) @ A) @ vt
+
+
+def encoder_layer(layer, x, source, x_mask=None, source_mask=None, loftr_preds=None):
+    """LoFTREncoderLayer.forward as the reference composes it from its modules (transformer.py:44-67): Linear projections,
+    LinearAttention, merge + norm1, MLP on cat[x, message] + norm2, residual."""
+    bs = x.size(0)
+    q = layer.q_proj(x).view(bs, -1, layer.nhead, layer.dim)
+    k = layer.k_proj(source).view(bs, -1, layer.nhead, layer.dim)
+    v = layer.v_proj(source).view(bs, -1, layer.nhead, layer.dim)
+    msg = layer.attention(q, k, v, q_mask=x_mask, kv_mask=source_mask, loftr_preds=loftr_preds)
+    msg = layer.merge(msg.view(bs, -1, layer.nhead * layer.dim))
+    msg = layer.norm2(layer.mlp(torch.cat([x, layer.norm1(msg)], dim=2)))                             # :61-66
+    return x + msg
