@@ -639,11 +639,14 @@ def bench_c3(a, dev, world, rank, dist):
             torch.cuda.synchronize()
     fence()
     t0 = time.perf_counter()
+    c0 = time.thread_time()
     for _ in range(a.steps):
         last = step()
+    host_cpu = time.thread_time() - c0
     fence()
     dt = time.perf_counter() - t0
     per_rank_ms = [round(1000 * x / a.steps, 3) for x in parallel.gather_floats(dt, device=dev)]
+    per_rank_host_ms = [round(1000 * x / a.steps, 3) for x in parallel.gather_floats(host_cpu, device=dev)]
     dt = parallel.max_over_ranks(dt, device=dev)
     # The path's one exchange step: the gradient all-reduce.  Reported two ways: a stand-alone all-reduce of
     # one flat fp32 buffer of the gradients' size (what the ring costs when nothing overlaps it), and the part of it that is
@@ -687,7 +690,7 @@ def bench_c3(a, dev, world, rank, dist):
             'metric': 'image-pairs/sec (training step: forward + backward + AdamW) -- BASELINE configs[2], not the headline metric',
             'value': round(world * B * a.steps / dt, 3), 'unit': 'image-pairs/sec', 'n_gpus': world, 'steps': a.steps,
             'warmup': a.warmup, 'prime_steps': prime, 'prime_cap': max(0, 3 - a.warmup) + a.warmup + SETTLE_EXTRA, 'ms_per_step': round(1000 * dt / a.steps, 3),
-            'per_rank_ms_per_step': per_rank_ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'per_rank_ms_per_step': per_rank_ms, 'host_ms_per_step': max(per_rank_host_ms), 'per_rank_host_ms_per_step': per_rank_host_ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
             'dtype_note': 'fp32 tensors and accumulation; K1 / K9 (Linear and backbone convolutions) / K2 forward on split-f16x3 operands, their '
                           'backward kernels on fp16 (K1, K2) or split-f16x3 (K9 dgrad, K16 wgrad) operands; stem forward + wgrad exact fp32 '
@@ -843,9 +846,9 @@ def main():
     from far_amd.config import RunCfg as _RunCfg
     run_cfg = _RunCfg(cfg['solver'], cfg.get('fine_pred_steps', 2), minimal_solver=a.minimal)
 
-    def step():
+    def step(seed=0):
         batch = dict(base)
-        test_step(model, batch, run_cfg=run_cfg, H=a.hyp, seed=0)
+        test_step(model, batch, run_cfg=run_cfg, H=a.hyp, seed=seed)
         return batch
 
     # the caching allocator still grows (multi-GB hipMallocs) during the first three steps: when fewer warm-up steps
@@ -863,12 +866,15 @@ def main():
 
     fence()
     t0 = time.perf_counter()
+    c0 = time.thread_time()
     for _ in range(a.steps):
         last = step()
+    host_cpu = time.thread_time() - c0          # CPU time of the enqueuing thread (blocked waits for the GPU do not count)
     fence()
     dt = time.perf_counter() - t0
     from far_amd import parallel
     per_rank_ms = [round(1000 * x / a.steps, 3) for x in parallel.gather_floats(dt, device=dev)]
+    per_rank_host_ms = [round(1000 * x / a.steps, 3) for x in parallel.gather_floats(host_cpu, device=dev)]
     dt = parallel.max_over_ranks(dt, device=dev)          # the slowest rank defines the step time
     matches = float(last['b_ids'].numel()) / a.pairs
     ok_frac = float(last['solver_status'].float().mean().item())
@@ -948,6 +954,9 @@ def main():
             'value': round(world * a.pairs * a.steps / dt, 3), 'unit': 'image-pairs/sec',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'prime_steps': prime, 'prime_cap': max(0, 3 - a.warmup) + a.warmup + SETTLE_EXTRA,
             'ms_per_step': round(1000 * dt / a.steps, 3), 'per_rank_ms_per_step': per_rank_ms,
+            # CPU time the step costs its host thread (Python + ctypes + the caching allocator; waiting for the GPU excluded): what N
+            # ranks on one host contend for
+            'host_ms_per_step': max(per_rank_host_ms), 'per_rank_host_ms_per_step': per_rank_host_ms,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32' if a.precision == 'fp32' else f'f32 tensors/accumulation, {a.precision} matrix operands',
             'dtype_note': ('f32 = fp32 tensors, fp32 accumulation; matrix products on the f16 MFMA pipe as split-f16x3 operand '
@@ -981,6 +990,10 @@ def main():
             k32, order32 = torch.sort(keys_of(last))
             mk32 = last['mkpts1_f'][order32]
             parity_err = pose_errors(last)
+            # the yardstick for everything below: the SAME fp32-grade step under other RANSAC sampling seeds.  On these synthetic
+            # pairs (small baseline, a random-weight head as the second round's prior) the median solver error moves by as much as
+            # the 16-bit modes move it -- which hypothesis wins is sensitive to any perturbation of the match set
+            seed_spread = [pose_errors(step(seed=sd)) for sd in (1, 2, 3, 4)]
 
             def timed_mode(mode, n=5):
                 model.set_precision(mode)
@@ -1012,6 +1025,10 @@ def main():
             (dt16, acc16), (dtm, accm), (dtf, accf) = timed_mode('fp16'), timed_mode('mixed16'), timed_mode('fp16-fine')
             res['other_modes'] = {
                 'parity_line_pose_error': parity_err,
+                'parity_line_pose_error_other_seeds': {'solver_median_R_deg': [e['solver_median_R_deg'] for e in seed_spread],
+                                                       'solver_median_t_deg': [e['solver_median_t_deg'] for e in seed_spread],
+                                                       'note': 'the parity line itself under RANSAC seeds 1-4: the noise floor of the solver errors '
+                                                               'quoted for the modes below (synthetic pairs; not an accuracy statement)'},
                 'fp16_fine': entry(dtf, accf, "plain fp16 operands in the FPN's fine branch only: every coarse decision (ids, mconf) bit-identical "
                                               'to the parity line, sub-pixel refinement deviates ~0.01 px'),
                 'fp16_operands': entry(dt16, acc16, '16-bit operands in the large matrix products of the step (plain fp16 in K9 incl. the fused k|v-state / '

@@ -380,10 +380,20 @@ class LoFTR(nn.Module):
         ops.overflow_flag(device).zero_()
         saved = None
         while True:
-            with ops.activation_exponent(self.act_exp):
-                out = fn()
-            if not ops.activation_overflowed(device):      # one host read per call
-                return out
+            try:
+                with ops.activation_exponent(self.act_exp):
+                    out = fn()
+            except ops.ActivationOverflow:
+                raise
+            except Exception:
+                # fn() may be a whole step (guarded_sequence): the stages behind an overflowed launch then ran on inf / NaN and may
+                # have raised on them (non-finite keypoints, degenerate match counts, host-side conversions) before the flag was
+                # read.  With the flag set that exception is a symptom of the overflow: widen and re-run; otherwise it is the caller's
+                if not ops.activation_overflowed(device):
+                    raise
+            else:
+                if not ops.activation_overflowed(device):      # one host read per call
+                    return out
             if saved is None:
                 saved = self._range_state()
                 bad = [t for t in inputs if torch.is_tensor(t) and t.is_floating_point() and not bool(torch.isfinite(t).all())]

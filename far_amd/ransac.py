@@ -9,12 +9,22 @@ model type) as the reference's, so that a caller importing them from `third_part
 arithmetic runs in float64 on the GPU (far_ransac_f64 / far_eightpoint_f64 / far_decompose_essential_f64, include/far_hip.h);
 results come back in the dtype of the inputs.  There is no CPU path: CPU tensors raise.
 
-What RANSAC.forward covers is what K4 implements, i.e. the configuration estimate_pose constructs (metrics.py:100-153):
-`essential*` / `fundamental` model types, Sampson error, one batch of `batch_size * max_iter` models, no local optimisation,
-the prior as biased sampling (exp(-d / 0.1)) + the no-exp prior score (-err^2 / lambda).  Anything else raises NotImplementedError
-instead of silently computing something different.  Documented deviations: the sampling hash replaces
-numpy / torch RNG draws; 'essential_cv2' (OpenCV's five-point on 6 points, not in this image) maps to the minimal solver named
-by `minimal` (default 8 = the normalized 8-point on 8 samples; 5 = Nister's five-point).
+What RANSAC.forward covers is what K4 implements, i.e. the configurations estimate_pose constructs (metrics.py:100-153:
+`essential_cv2`, max_iter = 1, max_lo_iters = 0, batch_size = 2048, with or without a prior): `essential*` model types, the squared
+Sampson error (ransac.py:151-157), one batch of `batch_size * max_iter` models, NO local optimisation, the prior as biased sampling
+(exp(-d / 0.1)) + the no-exp prior score (-err^2 / lambda).  Anything else raises NotImplementedError instead of silently computing
+something different:
+  * model_type = 'fundamental' -- the reference verifies it with symmetrical_epipolar_distance (ransac.py:141), K4 with Sampson:
+    other inlier sets at the same inl_th.  The 8-point minimal solver itself is available as `essential` / `essential_cv2` with
+    minimal = 8, and stand-alone as run_8point;
+  * max_lo_iters > 0 -- the reference polishes the best model with find_fundamental on its inliers (:413-424); K4 does not.  The
+    constructor default stays the reference's 5, so the argument must be passed as 0, as metrics.py does;
+  * 'homography*' models, early stopping, the exp prior score, a prior without linear biased sampling.
+prior_params['K1'] / ['K2'] are accepted and NOT used -- exactly as in the reference: fundamental_from_RT computes F from them and
+then returns E (ransac.py:63-71), so the bias weights are the symmetric epipolar distance to the prior's ESSENTIAL matrix on the
+(already K-normalised) points, which is what k_prepare evaluates.  Documented deviations: the sampling hash
+replaces numpy / torch RNG draws; 'essential_cv2' (OpenCV's five-point on 6 points, not in this image) maps to the minimal solver
+named by `minimal` (default 8 = the normalized 8-point on 8 samples; 5 = Nister's five-point).
 """
 import ctypes
 
@@ -74,14 +84,18 @@ def decompose_essential_matrix(E_mat):
 class RANSAC(torch.nn.Module):
     """ransac.py:74-159 (constructor: same parameter names and defaults) and :340-442 (forward)."""
 
-    _MODELS = {'fundamental': 8, 'essential': 5, 'essential_cv2': None}
+    _MODELS = {'essential': 5, 'essential_cv2': None}
 
     def __init__(self, model_type='homography', inl_th=2.0, batch_size=2048, max_iter=10, confidence=0.99, max_lo_iters=5,
                  prior_params={}, use_noexp_prior_scoring=False, use_linear_bias_sampling=False, bias_sigma_sq=1.0,
                  compute_stopping_inlier_only=False, perform_early_stopping=False, l1_dist=False, use_epipolar_error=False,
                  K=None, normalize=False, minimal=8, seed=0):
         super().__init__()
-        self.supported_models = ['fundamental', 'essential', 'essential_cv2']
+        self.supported_models = ['essential', 'essential_cv2']
+        if model_type == 'fundamental':
+            raise NotImplementedError("model_type='fundamental' is verified with the symmetric epipolar distance in the reference "
+                                      "(ransac.py:141); kernel K4 scores with the squared Sampson distance.  Use 'essential' / 'essential_cv2' "
+                                      "with minimal=8 for 8-point hypotheses, or run_8point for the solver alone.")
         if model_type not in self._MODELS:
             # the reference knows 'homography' / 'homography_from_linesegments' too; they are not on FAR's path (SURVEY.md 2.1 #13)
             raise NotImplementedError(f'{model_type} is unknown. Try one of {self.supported_models}')
@@ -91,13 +105,15 @@ class RANSAC(torch.nn.Module):
         self.compute_stopping_inlier_only, self.perform_early_stopping = compute_stopping_inlier_only, perform_early_stopping
         self.l1_dist, self.use_epipolar_error, self.K, self.normalize = l1_dist, use_epipolar_error, K, normalize
         self.minimal = self._MODELS[model_type] or int(minimal)
-        self.minimal_sample_size = {'fundamental': 8, 'essential': 5, 'essential_cv2': 6}[model_type]
+        self.minimal_sample_size = {'essential': 5, 'essential_cv2': 6}[model_type]
         self.seed = int(seed)
         self.prior_params = prior_params
         self.setup_prior(prior_params)
         unsupported = []
         if self.minimal not in (5, 8):
             unsupported.append(f'minimal={minimal}')
+        if self.max_lo_iters > 0:
+            unsupported.append(f'local optimisation (max_lo_iters={self.max_lo_iters}; pass max_lo_iters=0 as metrics.py:118 does)')
         if use_epipolar_error or l1_dist:
             unsupported.append('use_epipolar_error / l1_dist (K4 scores with the squared Sampson distance)')
         if perform_early_stopping or compute_stopping_inlier_only:

@@ -109,3 +109,53 @@ def test_cached_step_solver_plus_head_on_cached_correspondences(tmp_path):
     d2.update({'K0': K, 'K1': K.clone(), 'dataset_name': ['interiornet_streetlearn']})
     cached_step(m, d2, RunCfg('prior_ransac', 2), H=Hn, seed=seed)              # the full two-round schedule runs
     assert d2['loftr_rt'].shape == (B, 3, 4) and bool(torch.isfinite(d2['regressed_rt']).all())
+
+
+def test_eval_pairs_tool_walks_a_pair_list_and_prints_the_reference_table(tmp_path):
+    """tools/eval_pairs.py: a pair list with ground-truth poses -> pipeline.test_step in batches ->
+    far_amd.metrics.aggregate_metrics (pinned to the reference's own function by golden G16, tests/test_oracle_golden.py) -> the lines
+    test_epoch_end prints (lightning_loftr.py:483-492), for both minimal solvers.  Synthetic pairs (ground truth R = I, t = -x),
+    6 pairs in batches of 4 + 2: the per-pair errors the tool accumulates equal a direct evaluation of each pair alone, the table
+    is aggregate_metrics of them, and the command line prints the reference's keys."""
+    import subprocess
+    import sys
+    from far_amd import metrics as fm
+    from far_amd.config import RunCfg
+    from far_amd.loftr import LoFTR
+    from far_amd.pipeline import test_step
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'tools'))
+    import eval_pairs
+    n = 6
+    im0, im1 = synth.synth_image_pair(n, seed=21)
+    T = np.tile(np.eye(4), (n, 1, 1))
+    T[:, 0, 3] = -1.0
+    p = str(tmp_path / 'pairs.npz')
+    np.savez(p, image0=(im0[:, 0] * 255).round().astype(np.uint8), image1=(im1[:, 0] * 255).round().astype(np.uint8), K0=synth.MP3D_K,
+             K1=synth.MP3D_K, T_0to1=T, identifiers=np.array([f'scene_{i}' for i in range(n)]))
+    pairs = eval_pairs.load_pairs(p)
+    assert pairs['image0'].shape == (n, 1, 480, 640) and pairs['K0'].shape == (n, 3, 3) and float(pairs['image0'].max()) <= 1.0
+    m = LoFTR(far_eval_config()).eval()
+    synth.load_synthetic(m, seed=0)
+    m = m.cuda()
+    far, sol, acc = eval_pairs.evaluate(m, pairs, minimal=8, batch=4, hyp=512)
+    assert far['dset size'] == n and sol['dset size'] == n and acc['identifiers'] == [f'scene_{i}' for i in range(n)]
+    assert set(far) >= {'rot median err', 'rot mean err', 'tr rot median err', 'tr abs median err', 'pct successful fits', 'auc@5', 'auc@10', 'auc@20',
+                        'prec@5e-04'}
+    assert far == fm.aggregate_metrics(acc)
+    # pair 5 alone (batch 32 = 32 x batch 1 bit for bit, and the sampling hash is keyed by the pair's index in its batch: pair 5 is
+    # index 1 of the second batch -> seed ^ 1 reproduces its samples at index 0)
+    d = {'image0': torch.from_numpy(pairs['image0'][5:6]).cuda(), 'image1': torch.from_numpy(pairs['image1'][5:6]).cuda(),
+         'K0': torch.from_numpy(pairs['K0'][5:6]).float().cuda(), 'K1': torch.from_numpy(pairs['K1'][5:6]).float().cuda(),
+         'T_0to1': torch.from_numpy(T[5:6]).cuda(), 'dataset_name': ['mp3d']}
+    cfg = RunCfg('prior_ransac', 2, minimal_solver=8)
+    test_step(m, d, run_cfg=cfg, H=512, seed=0 ^ 1)
+    fm.compute_pose_errors(d, cfg, H=512, seed=0 ^ 1)
+    assert abs(d['R_errs'][0] - acc['R_errs'][5]) < 1e-9 and abs(d['t_errs'][0] - acc['t_errs'][5]) < 1e-9
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'eval_pairs.py'), '--pairs', p, '--batch', '4', '--hyp', '512',
+                          '--out', str(tmp_path / 't.json')], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    for key in ('minimal solver 8: FAR pose', 'minimal solver 5: solver pose alone', 'rot median err', 'tr rot median err', 'auc@20', 'dset size 6'):
+        assert key in out.stdout, (key, out.stdout)
+    tab = json.load(open(tmp_path / 't.json'))
+    assert tab['minimal_8']['far']['rot median err'] == float(far['rot median err']) and 'minimal_5' in tab

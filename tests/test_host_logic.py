@@ -232,10 +232,14 @@ def test_ransac_api_argument_checks_need_no_gpu():
     with pytest.raises(NotImplementedError):
         RANSAC(model_type='homography')
     with pytest.raises(NotImplementedError, match='early stopping'):
-        RANSAC(model_type='fundamental', perform_early_stopping=True)
+        RANSAC(model_type='essential', perform_early_stopping=True, max_lo_iters=0)
+    with pytest.raises(NotImplementedError, match='symmetric epipolar'):      # the reference verifies it with another error function
+        RANSAC(model_type='fundamental', max_lo_iters=0)
+    with pytest.raises(NotImplementedError, match='local optimisation'):      # the reference's default of 5 polishing rounds is not silently dropped
+        RANSAC(model_type='essential')
     with pytest.raises(NotImplementedError, match='exp prior score'):
         RANSAC(model_type='essential_cv2', prior_params={'RT': torch.eye(3, 4), 'pcl': torch.zeros(3, 3), 'lambda': 0.3, 'biased_sampling': 'biased'},
-               use_linear_bias_sampling=True, bias_sigma_sq=0.1, max_iter=1)
+               use_linear_bias_sampling=True, bias_sigma_sq=0.1, max_iter=1, max_lo_iters=0)
     prior = {'RT': torch.tensor([[1., 0, 0, 2.0], [0, 1, 0, 0], [0, 0, 1, 0]]), 'pcl': torch.zeros(3, 3), 'lambda': 0.3, 'biased_sampling': 'biased'}
     m = RANSAC(model_type='essential_cv2', prior_params=prior, use_noexp_prior_scoring=True, use_linear_bias_sampling=True, bias_sigma_sq=0.1,
                max_iter=1, max_lo_iters=0, inl_th=3e-7)

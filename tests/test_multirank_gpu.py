@@ -13,13 +13,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _run(extra):
+def _run(extra, gpus=2):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
-    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--share-gpu', '--steps', '1',
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(gpus), '--backend', 'gloo', '--share-gpu', '--steps', '1',
            '--warmup', '1', '--no-cpu-baseline'] + extra
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1, r.stdout[-2000:]                       # rank 0 prints the one JSON line
@@ -41,6 +41,31 @@ def test_two_ranks_training_step_under_ddp():
     assert res['n_gpus'] == 2 and len(res['per_rank_ms_per_step']) == 2
     assert res['config']['parallelism'].startswith('ddp2')
     assert all(v == v and abs(v) < 1e4 for v in res['config']['losses'].values())      # finite losses after DDP steps
+
+
+@pytest.mark.timeout(1800)
+def test_eight_ranks_eval_step_rehearsal():
+    """N = 8 rehearsed on the one GPU a box has: `bench.py --gpus 8 --share-gpu --backend gloo --pairs 1` -- eight
+    launcher children (started before anything touches the GPU), eight seeds, the barrier / max-over-ranks / eight-way gather of the
+    timing rule, one JSON line with n_gpus 8 and eight per-rank entries (step time and host CPU time).  Timings mean nothing here."""
+    res = _run(['--pairs', '1', '--hyp', '256', '--no-other-modes', '--no-other-workloads', '--skip-rooflines'], gpus=8)
+    assert res['n_gpus'] == 8 and len(res['per_rank_ms_per_step']) == 8 and len(res['per_rank_host_ms_per_step']) == 8
+    assert res['value'] > 0 and res['config']['pairs_per_gpu'] == 1 and res['config']['parallelism'].startswith('dp8')
+    assert res['host_ms_per_step'] == max(res['per_rank_host_ms_per_step']) > 0
+    assert res['prime_steps'] <= res['prime_cap']
+    assert res['process_group'] == {'backend': 'gloo', 'world_size': 8}
+
+
+@pytest.mark.timeout(1800)
+def test_eight_ranks_training_step_under_ddp_rehearsal():
+    """The training workload at eight ranks on one GPU: DDP's bucketed gradient all-reduce across eight ranks through the HIP autograd
+    Functions, priming steps whose stop decision is collective (bench.settle: every rank leaves after the same step count -- ranks
+    that left at different counts would un-pair DDP's all-reduces and hang here)."""
+    res = _run(['--workload', 'c3', '--pairs', '1', '--hyp', '256'], gpus=8)
+    assert res['n_gpus'] == 8 and len(res['per_rank_ms_per_step']) == 8 and len(res['per_rank_host_ms_per_step']) == 8
+    assert res['config']['parallelism'].startswith('ddp8')
+    assert all(v == v and abs(v) < 1e4 for v in res['config']['losses'].values())
+    assert res['prime_steps'] <= res['prime_cap']
 
 
 @pytest.mark.timeout(900)

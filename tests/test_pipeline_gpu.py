@@ -904,3 +904,33 @@ def test_step_runs_under_one_activation_range_guard(model):
     for k in keys:
         assert torch.isfinite(d3[k].float()).all() and torch.equal(d3[k], d4[k]), k
     assert len(d3['b_ids']) > 100
+
+
+def test_guard_treats_an_exception_behind_an_overflow_as_the_overflow(model):
+    """ADVICE r5: with one guard per step the solver rounds and the head run on the matcher's inf / NaN outputs before the flag is read;
+    an exception they raise on that garbage (zero matches, non-finite keypoints) must widen the range and re-run like the plain
+    overflow does -- and an exception WITHOUT the flag is the caller's and propagates unchanged."""
+    import copy
+    import warnings
+    from far_amd import ops
+    m = copy.deepcopy(model)
+    dev = torch.device('cuda', torch.cuda.current_device())
+    runs = []
+
+    def fn():
+        runs.append(m.act_exp)
+        if len(runs) == 1:
+            ops.overflow_flag(dev).fill_(1)                 # what an out-of-range launch leaves behind ...
+            raise ValueError('degenerate match set')        # ... and what a later stage makes of its outputs
+        return 'clean'
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter('always')
+        assert m.guarded_sequence(fn, dev) == 'clean'
+    assert runs == [4, 0] and m.act_exp == 0 and any('activation' in str(w.message) for w in rec)
+    assert not ops.activation_overflowed(dev)
+
+    def plain():
+        raise KeyError('not an overflow')
+    with pytest.raises(KeyError):
+        m.guarded_sequence(plain, dev)
+    assert m.act_exp == 0

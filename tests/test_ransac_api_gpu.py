@@ -155,8 +155,8 @@ def test_ransac_forward_matches_the_reference_loop(tag):
 
 
 def test_ransac_own_sampling_and_error_behaviour():
-    """Without explicit samples the hash sampler runs: a two-view scene with 30 % outliers is solved ('fundamental' = 8-point,
-    'essential' = five-point), too few points raise ValueError as the reference's validate_inputs, unknown model types
+    """Without explicit samples the hash sampler runs: a two-view scene with 30 % outliers is solved ('essential_cv2' with minimal = 8:
+    8-point hypotheses; 'essential' = five-point), the masks are the squared Sampson distance at inl_th; too few points raise ValueError as the reference's validate_inputs, unknown model types
     NotImplementedError, options K4 does not implement NotImplementedError (never a silently different computation), CPU tensors
     FarHipError."""
     from far_amd import _lib
@@ -166,22 +166,26 @@ def test_ransac_own_sampling_and_error_behaviour():
     k0, k1, K, R_gt, t_gt = two_view_scene(600, seed=5, outlier_frac=0.3)[:5]
     kn0, kn1 = osv.normalize_keypoints(k0, k1, K, K)
     a, b = cu(kn0.astype(np.float32)), cu(kn1.astype(np.float32))
-    for mt in ('fundamental', 'essential'):
+    for mt in ('essential_cv2', 'essential'):
         E, inl, tight, ultra = RANSAC(model_type=mt, inl_th=3e-7, batch_size=512, max_iter=1, max_lo_iters=0).forward(a, b)
         assert 200 < int(inl.sum()) <= 600 and int(ultra.sum()) <= int(tight.sum()) <= int(inl.sum())
         samp = osv.sampson_distance(kn0.astype(np.float32).astype(np.float64), kn1.astype(np.float32).astype(np.float64), E.double().cpu().numpy()[None])[0]
         np.testing.assert_array_equal(inl.cpu().numpy(), samp <= 3e-7)
     with pytest.raises(ValueError):
-        RANSAC(model_type='fundamental', inl_th=3e-7, batch_size=64, max_iter=1).forward(a[:7], b[:7])
+        RANSAC(model_type='essential', inl_th=3e-7, batch_size=64, max_iter=1, max_lo_iters=0).forward(a[:4], b[:4])
     with pytest.raises(NotImplementedError):
         RANSAC(model_type='homography')
     with pytest.raises(NotImplementedError):
-        RANSAC(model_type='essential', perform_early_stopping=True)
+        RANSAC(model_type='essential', perform_early_stopping=True, max_lo_iters=0)
+    with pytest.raises(NotImplementedError):              # verified with the symmetric epipolar distance in the reference, not Sampson
+        RANSAC(model_type='fundamental', max_lo_iters=0)
+    with pytest.raises(NotImplementedError):              # the reference's default local optimisation is not silently dropped
+        RANSAC(model_type='essential', inl_th=3e-7)
     with pytest.raises(_lib.FarHipError):
-        RANSAC(model_type='fundamental', inl_th=3e-7, batch_size=64, max_iter=1).forward(a.cpu(), b.cpu())
+        RANSAC(model_type='essential_cv2', inl_th=3e-7, batch_size=64, max_iter=1, max_lo_iters=0).forward(a.cpu(), b.cpu())
     # an unsolvable input: zeros(3, 3) and empty masks (ransac.py:354-355), no exception
     z = torch.zeros(20, 2, device='cuda')
-    E, inl, _, _ = RANSAC(model_type='fundamental', inl_th=3e-7, batch_size=64, max_iter=1).forward(z, z)
+    E, inl, _, _ = RANSAC(model_type='essential_cv2', inl_th=3e-7, batch_size=64, max_iter=1, max_lo_iters=0).forward(z, z)
     assert float(E.abs().sum()) == 0.0 and int(inl.sum()) == 0
 
 
