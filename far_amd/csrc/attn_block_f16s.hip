@@ -417,7 +417,7 @@ size_t far_attn_block_packed_bytes(int d_model) { return d_model == DM ? (size_t
 
 // out [nwin][L][128] = norm1(merge(LinearAttention(q_proj(x), k_proj(src), v_proj(src))))   (transformer.py:51-61 at d_model = 128,
 // 8 heads of 16, sequences of at most 32 tokens: the fine-level windows).  x [nwin][L][128], src [nwin][S][128] fp32;
-// packed: the image far_amd/ops.py:PackedAttn builds; scale_* = 2^-(w_exp + 4) of Wk, Wv, Wq, Wm; out must not alias x / src.
+// packed: the image far_amd/ops/fine.py:PackedAttn builds; scale_* = 2^-(w_exp + 4) of Wk, Wv, Wq, Wm; out must not alias x / src.
 template <bool SPLIT>
 static int attn_block_launch(const float* x, const float* src, const void* packed, long nwin, int L, int S, int d_model, int heads,
                              float scale_k, float scale_v, float scale_q, float scale_m, float attn_eps, const float* gamma,

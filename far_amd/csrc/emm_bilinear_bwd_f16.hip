@@ -7,7 +7,7 @@
 //     dP_ab = A_a . v~_b                      u_a = A_a . T_a      v_b = B_b . T'_b          (row / column sums of dP * P)
 //     ds_ab = 2 P_ab dP_ab - R_ab u_a - C_ab v_b          (R: softmax over keys, C: softmax over queries, P = R C)
 //     dq = scale ds k,   dk = scale ds^T q,   dv~ = T dF^T + T' dF
-// T' is the forward kernel with q and k exchanged; A, B, u, v, dv~ are (N x 70)-sized torch expressions (far_amd/ops.py).
+// T' is the forward kernel with q and k exchanged; A, B, u, v, dv~ are (N x 70)-sized torch expressions (far_amd/ops/head.py).
 // What needs a kernel is ds contracted with k (and ds^T with q): k2_bwd recomputes a 32 x 32 tile of s AND of dP on the f16
 // matrix core (transposed: a lane owns one row), forms ds from the forward's statistics with two exp2 per entry, and feeds
 // it from the accumulator registers into the third MFMA as its A operand (other side's tile channel-major, columns

@@ -105,7 +105,7 @@ Grads grads_layout(const far_enc_layer& d) {
     return g;
 }
 
-inline long wgrad_ws(long rows, int K, int N) {               // as far_amd/ops.py:linear_wgrad factors the rows
+inline long wgrad_ws(long rows, int K, int N) {               // as far_amd/ops/conv.py:linear_wgrad factors the rows
     const int h = rows % 32 == 0 ? (int)(rows / 32) : 1;
     return far_conv_wgrad_ws_bytes(1, h, (int)(rows / h), K, N, 1, 1);
 }

@@ -274,7 +274,7 @@ int mlp_fused_launch(const float* x, const float* msg, const void* packed, long 
 
 extern "C" {
 
-// bytes of the packed weight image of far_mlp_fused_f16s (24 slabs of 16 KiB; layout in far_amd/ops.py:PackedMlp)
+// bytes of the packed weight image of far_mlp_fused_f16s (24 slabs of 16 KiB; layout in far_amd/ops/fine.py:PackedMlp)
 size_t far_mlp_fused_packed_bytes(int d_model) { return d_model == DM ? (size_t)NSLAB * SLAB : 0; }
 
 // out [R][128] = x + LayerNorm(W2 relu(W0 [x | msg]))   (transformer.py:64-67 at d_model = 128)

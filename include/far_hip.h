@@ -300,14 +300,14 @@ int far_enc_layer_bwd(const far_enc_layer* d, const float* x, const float* sourc
  * K13  the MLP block of a LoFTR encoder layer at d_model = 128 (the fine-level transformer) in one launch
  * replaces src/loftr/loftr_module/transformer.py:64-67:  x + norm2(mlp(cat[x, message]))  with
  *          mlp = Linear(2d, 2d, no bias) -> ReLU -> Linear(2d, d, no bias); the hidden tensor never reaches memory.
- *   x, msg [R][128] fp32; packed = the image far_amd/ops.py:PackedMlp builds (far_mlp_fused_packed_bytes bytes: W0 scaled by
+ *   x, msg [R][128] fp32; packed = the image far_amd/ops/fine.py:PackedMlp builds (far_mlp_fused_packed_bytes bytes: W0 scaled by
  *   2^e0, W2 by 2^e2, fp16 hi / lo planes in execution order); hscale = 2^-e0, oscale = 2^-(e2 + 4); gamma, beta [128], eps:
  *   norm2.  out [R][128] must not alias x or msg.  Arithmetic as K9 (three f16 MFMAs per fp32-grade product).
  * --------------------------------------------------------------------------------------------------- */
 /* K14  the attention block of a LoFTR encoder layer at d_model = 128 on sequences of <= 32 tokens (the fine-level windows)
  * replaces src/loftr/loftr_module/transformer.py:51-61 with linear_attention.py:31-50:
  *          norm1(merge(LinearAttention(q_proj(x), k_proj(src), v_proj(src))))      8 heads of 16 channels
- *   x [nwin][L][128], src [nwin][S][128] fp32 (L, S <= 32); packed = the image far_amd/ops.py:PackedAttn builds
+ *   x [nwin][L][128], src [nwin][S][128] fp32 (L, S <= 32); packed = the image far_amd/ops/fine.py:PackedAttn builds
  *   (far_attn_block_packed_bytes bytes); scale_k / _v / _q / _m = 2^-(w_exp + 4) of the four weight tensors; attn_eps: the
  *   1e-6 of LinearAttention; gamma, beta [128], ln_eps: norm1.  out [nwin][L][128] must not alias x or src.
  *   overflow (both kernels; device int or NULL): OR-ed with 1 when an input or an intermediate left the range of the
@@ -400,7 +400,7 @@ int far_conv_pack_f32(const float* w, int Cin, int Cout, int ksize, int stride, 
  *   far_conv_pack_view_f32: packs the weight read through element strides (s_co, s_ci, s_tap; w = the element of tap 0 in
  *   execution order) times scale_in[0].  Forward image of a contiguous [Cout][Cin][k][k] weight: (Cin k k, k k, 1).  Its dgrad
  *   image (the 'same' stride-1 convolution of the output gradient that gives the input gradient, resnet_fpn.py:5-12 under
- *   autograd): Cin / Cout exchanged, strides (k k, Cout_fwd... see far_amd/ops.py:PackedConv.dgrad_view), taps reversed -- the
+ *   autograd): Cin / Cout exchanged, strides (k k, Cout_fwd... see far_amd/ops/packs.py:PackedConv.dgrad_view), taps reversed -- the
  *   same tensor, no flipped / transposed copy.  A Linear layer's transposed weight W^T: (1, K_fwd, 0). */
 int far_weight_scale_f32(const float* w, long n, float* scale_out, far_stream_t stream);
 int far_conv_pack_view_f32(const float* w, long s_co, long s_ci, long s_tap, int Cin, int Cout, int ksize, int stride, int split,

@@ -14,5 +14,14 @@ ws = torch.empty(lib.far_emm_pv_f16s_workspace_bytes(Z, L), dtype=torch.uint8, d
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 def run():
     lib.far_emm_pv_f16s(q.data_ptr(), k.data_ptr(), v.data_ptr(), pos.data_ptr(), Z, L, 64, ctypes.c_float(0.125), 1, 0, L * 64, 0, ws.data_ptr(), T.data_ptr(), None, st)
-t = min(bench.event_time_ms(run, iters=3, warm=1) for _ in range(3))
-print(f'far_emm_pv_f16s all passes: {t:.3f} ms   checksum {float(T.double().sum()):.6e}')
+ref = None
+for v14 in (1, 0, 1, 0):                  # far_set_tuning(14, 1) = k_pv (rounds 3-5), 0 = k_pv8 (round 6); interleaved
+    lib.far_set_tuning(14, v14)
+    t = min(bench.event_time_ms(run, iters=3, warm=1) for _ in range(3))
+    run()
+    out = T.clone()
+    if ref is None:
+        ref = out
+    print(f'far_emm_pv_f16s all passes, tuning 14={v14} ({"k_pv" if v14 else "k_pv8"}): {t:.3f} ms   bit-identical to the first run: {bool(torch.equal(out, ref))}   '
+          f'checksum {float(out.double().sum()):.6e}', flush=True)
+lib.far_set_tuning(14, 0)
