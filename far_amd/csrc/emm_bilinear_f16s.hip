@@ -503,211 +503,6 @@ __global__ __launch_bounds__(256, 2) void k_pv(const _Float16* __restrict__ qh, 
     }
 }
 
-// One 32-key half (ct) of score_tile: 12 MFMAs, 8 fragment reads.  k_pv8 computes the next tile's scores half by half, each into the
-// accumulator registers the current tile's half has just left.
-template <bool SPLIT = true>
-__device__ __forceinline__ void score_half(f32x16& acc, const unsigned char* lds, const RowFrags& rf, int ct, int l31, int h) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const int row = 32 * ct + l31;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const int off = row * 128 + (((2 * s + h) ^ ((row >> 1) & 7)) * 16);
-        const f16x8 ch = *reinterpret_cast<const f16x8*>(lds + off);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch, rf.hi[s], acc, 0, 0, 0);
-        if (SPLIT) {
-            const f16x8 cl = *reinterpret_cast<const f16x8*>(lds + CT_PLANE + off);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch, rf.lo[s], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cl, rf.hi[s], acc, 0, 0, 0);
-        }
-    }
-}
-
-// ---- k_pv8 (round 6): k_pv with the score pass of tile jt + 1 SOFTWARE-PIPELINED under the exponentials and the
-// P v~ products of tile jt inside every wave.  k_pv's stream per tile is  24 score MFMAs -> row maximum + ~200 VALU of exponentials ->
-// 36 P v~ MFMAs: the matrix pipe idles while a wave forms its P operands, and its partner wave on the SIMD is in the same phase (one
-// barrier per tile keeps a workgroup's waves in step).  Here the scores of the NEXT tile (independent of everything but the key tile)
-// are issued between the VALU groups of the current one -- half by half, each half into the accumulator registers the current tile's
-// half has just left (a second score tile would not fit the register file next to the 48 output accumulators and the query fragments)
-// -- so that every wave has matrix work for the whole tile.  That needs tile jt + 1's keys in LDS one iteration earlier: a three-slot key ring next to the
-// two-slot v~ ring (96 KiB), hence ONE workgroup of 8 waves = 256 queries per CU instead of two of 4 (the same 2 waves per SIMD; key
-// and v~ tiles are shared by twice as many rows: half the L2 -> LDS traffic per query).  Same arithmetic in the same order per row:
-// bit-identical to k_pv.  Rings as everywhere since round 6: requests from asm, completion by vmcnt(0) at the top of the iteration
-// (they were issued an iteration ago), ring_barrier (no LDS read of the wave in flight at the barrier).  Needs Np % 256 == 0.
-constexpr int PV8_WAVES = 8;
-constexpr int PV8_SMEM = 3 * 2 * CT_PLANE + 2 * 2 * VT_PLANE;      // 48 KiB + 48 KiB
-template <bool SPLIT>
-__global__ __launch_bounds__(512, 2) void k_pv8(const _Float16* __restrict__ qh, const _Float16* __restrict__ ql,
-                                                const _Float16* __restrict__ kh, const _Float16* __restrict__ kl,
-                                                const _Float16* __restrict__ vh, const _Float16* __restrict__ vl,
-                                                int Z, int N, int Np, float c1, float2* __restrict__ rowstat, float* __restrict__ T) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];
-    unsigned char* const kring = lds_all;                              // 3 x { hi, lo } key tiles
-    unsigned char* const vring = lds_all + 3 * 2 * CT_PLANE;           // 2 x { hi, lo } v~^T tiles (the column references ride in row CREF_ROW)
-    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int z, Ib;
-    tile_coords(Np / 256, Z, z, Ib);
-    const int i0 = Ib * 256 + 32 * wave;
-    const int irow = i0 + l31;
-    RowFrags rf;
-    rf.load(qh, ql, (size_t)z * Np + irow, irow, h);
-    rf.arrived();
-
-    f32x16 tacc[3];
-#pragma unroll
-    for (int bt = 0; bt < 3; ++bt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) tacc[bt][r] = 0.f;
-    int R = ROW_REF0;
-    float sum = 0.f, comp = 0.f;
-
-    const int ntile = Np / KT;
-    const unsigned char* ksrc_h = reinterpret_cast<const unsigned char*>(kh + (size_t)z * Np * D) + lane * 16;
-    const unsigned char* ksrc_l = reinterpret_cast<const unsigned char*>(kl + (size_t)z * Np * D) + lane * 16;
-    const unsigned char* vsrc_h = reinterpret_cast<const unsigned char*>(vh + (size_t)z * ntile * DVP * KT) + lane * 16;
-    const unsigned char* vsrc_l = reinterpret_cast<const unsigned char*>(vl + (size_t)z * ntile * DVP * KT) + lane * 16;
-    const unsigned kbase = lds_addr_uniform(kring), vbase = lds_addr_uniform(vring);
-    // key tile jt -> ring slot jt % 3: 16 pieces of 1 KiB (hi 0..7, lo 8..15), wave w takes w and w + 8
-    auto request_k = [&](int jt) {
-        const unsigned dst = kbase + (unsigned)((jt % 3) * 2 * CT_PLANE) + wave * 1024;
-        glds16(ksrc_h + (size_t)jt * CT_PLANE + wave * 1024, dst);
-        glds16(ksrc_l + (size_t)jt * CT_PLANE + wave * 1024, dst + CT_PLANE);
-    };
-    // v~^T tile jt -> ring slot jt % 2: 24 pieces (hi 0..11, lo 12..23), wave w takes w, w + 8, w + 16
-    auto request_v = [&](int jt) {
-        const unsigned dst = vbase + (unsigned)((jt & 1) * 2 * VT_PLANE);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int pc = wave + 8 * j;                               // wave-uniform
-            const bool lo = pc >= 12;
-            const int q = lo ? pc - 12 : pc;
-            glds16((lo ? vsrc_l : vsrc_h) + (size_t)jt * VT_PLANE + q * 1024, dst + (lo ? VT_PLANE : 0) + q * 1024);
-        }
-    };
-    request_k(0);
-    request_v(0);
-    if (ntile > 1) request_k(1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    ring_barrier();
-    f32x16 cur[2];
-    score_tile<SPLIT>(cur, kring, rf, l31, h);
-    for (int jt = 0; jt < ntile; ++jt) {
-        // keys jt + 1 and v~ jt (requested an iteration ago) have landed; behind the barrier nobody reads key slot (jt + 2) % 3 (tile
-        // jt - 1, scored two iterations ago) nor v~ slot (jt + 1) % 2 (tile jt - 1, multiplied in the last iteration) any more
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        ring_barrier();
-        if (jt + 2 < ntile) request_k(jt + 2);
-        if (jt + 1 < ntile) request_v(jt + 1);
-        const unsigned char* const ldv = vring + (jt & 1) * 2 * VT_PLANE;
-        const int* const lcr = reinterpret_cast<const int*>(ldv + CREF_ROW * 128);
-        const unsigned char* const ldk = kring + ((jt + 1) % 3) * 2 * CT_PLANE;
-        const bool have_next = jt + 1 < ntile;                                   // workgroup-uniform
-
-        // ---- row reference of tile jt: ceil of the running maximum, agreed between the two half-waves
-        const bool ragged = (jt + 1) * KT > N;                                   // wave-uniform
-        const float tm = ragged ? tile_rowmax<true>(cur, c1, jt * KT, N, h) : tile_rowmax<false>(cur, c1, jt * KT, N, h);
-        int Rn = (int)ceilf(fminf(fmaxf(tm, -1.0e6f), 1.0e6f));
-        Rn = Rn > R ? Rn : R;
-        const int Ro = __shfl_xor(Rn, 32, 64);
-        Rn = Rn > Ro ? Rn : Ro;
-        if (__any(Rn != R)) {                                                    // rare after the first tiles
-            int d = R - Rn;
-            d = d < -200 ? -200 : d;
-            sum = ldexpf(sum, d);
-            comp = ldexpf(comp, d);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int dr = __shfl(d, mfma32_row(r, h), 64);
-#pragma unroll
-                for (int bt = 0; bt < 3; ++bt) tacc[bt][r] = ldexpf(tacc[bt][r], dr);
-            }
-            R = Rn;
-        }
-        const float nR = -(float)R;
-        f32x2 t2 = {0.f, 0.f};
-        auto pv_tile = [&](auto ragged_c, auto next_c) {
-        constexpr bool RAGGED = decltype(ragged_c)::value;
-        constexpr bool NEXT = decltype(next_c)::value;
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                f16x8 ph, pl;
-                const int4 cA = *reinterpret_cast<const int4*>(lcr + 32 * ct + 16 * u + 4 * h);
-                const int4 cB = *reinterpret_cast<const int4*>(lcr + 32 * ct + 16 * u + 8 + 4 * h);
-                const int cmv[8] = {cA.x, cA.y, cA.z, cA.w, cB.x, cB.y, cB.z, cB.w};
-#pragma unroll
-                for (int e = 0; e < 8; e += 2) {
-                    const int r = 8 * u + e;
-                    const f32x2 x2 = __builtin_elementwise_fma(f32x2{cur[ct][r], cur[ct][r + 1]}, f32x2{c1, c1}, f32x2{nR, nR});
-                    float e0 = __builtin_amdgcn_exp2f(x2.x);
-                    float e1 = __builtin_amdgcn_exp2f(x2.y);
-                    if (RAGGED) {
-                        if (jt * KT + 32 * ct + mfma32_row(r, h) >= N) e0 = 0.f;
-                        if (jt * KT + 32 * ct + mfma32_row(r + 1, h) >= N) e1 = 0.f;
-                    }
-                    t2 += f32x2{e0, e1};
-                    const f32x2 p2 = f32x2{e0, e1} * f32x2{ldexpf(e0, R - cmv[e] + 15), ldexpf(e1, R - cmv[e + 1] + 15)};
-                    f16x2 h2, l2;
-                    if (SPLIT) split2(p2, h2, l2);
-                    else { h2 = __builtin_convertvector(p2, f16x2); l2 = h2; }
-                    ph[e] = h2.x; ph[e + 1] = h2.y;
-                    pl[e] = l2.x; pl[e + 1] = l2.y;
-                }
-                // this half of the current tile has been read out (u == 1): the next tile's half takes its registers -- 12 MFMAs that
-                // need nothing of this iteration and cover the VALU of the P operands that follow
-                if (NEXT && u == 1) score_half<SPLIT>(cur[ct], ldk, rf, ct, l31, h);
-                const int slot = 4 * ct + 2 * u + h;
-#pragma unroll
-                for (int bt = 0; bt < 3; ++bt) {
-                    const int b = 32 * bt + l31;
-                    const int off = b * 128 + ((slot ^ ((b >> 1) & 7)) * 16);
-                    const f16x8 bh = *reinterpret_cast<const f16x8*>(ldv + off);
-                    tacc[bt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, bh, tacc[bt], 0, 0, 0);
-                    if (SPLIT) {
-                        const f16x8 bl = *reinterpret_cast<const f16x8*>(ldv + VT_PLANE + off);
-                        tacc[bt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, bl, tacc[bt], 0, 0, 0);
-                        tacc[bt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, bh, tacc[bt], 0, 0, 0);
-                    }
-                }
-            }
-        }
-        if (false && NEXT && SPLIT && !RAGGED) {
-            // issue order of the block: per group one fragment read while there are any, one MFMA, the VALU that fits under its
-            // pass -- 60 MFMAs (24 of tile jt + 1's scores, 36 P v~) against ~260 VALU instructions (32 of them exponentials)
-#pragma unroll
-            for (int i = 0; i < 60; ++i) {
-                if (i < 48) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
-            }
-        }
-        };
-        if (ragged) { if (have_next) pv_tile(std::true_type{}, std::true_type{}); else pv_tile(std::true_type{}, std::false_type{}); }
-        else { if (have_next) pv_tile(std::false_type{}, std::true_type{}); else pv_tile(std::false_type{}, std::false_type{}); }
-        const float y = (t2.x + t2.y) - comp;
-        const float ns = sum + y;
-        comp = (ns - sum) - y;
-        sum = ns;
-    }
-    sum -= comp;
-    const float rsum = sum + shfl_xor_f(sum, 32);
-    if (h == 0 && irow < N) rowstat[(size_t)z * N + irow] = make_float2((float)R, rsum);
-    const float oscale = (3.0517578125e-05f / V_PRESCALE) / rsum;
-#pragma unroll
-    for (int bt = 0; bt < 3; ++bt) {
-        const int b = 32 * bt + l31;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rr = mfma32_row(r, h);
-            const float sc = __shfl(oscale, rr, 64);
-            const int i = i0 + rr;
-            if (b < DV && i < N) T[((size_t)z * N + i) * DV + b] = tacc[bt][r] * sc;
-        }
-    }
-}
-
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 struct EmmWs {
     _Float16 *qh, *ql, *kh, *kl, *vh, *vl;
@@ -763,16 +558,8 @@ static int emm_pv_launch(const float* q, const float* k, const float* v, const f
     hipLaunchKernelGGL(k_rowstats<SPLIT>, gstat, dim3(256), 0, stream, w.kh, w.kl, w.qh, w.ql, Z, N, Np, c1, w.colstat);
     hipLaunchKernelGGL(k_prep_v, dim3((unsigned)(Np / KT) * Z), dim3(256), 0, stream, v, lay, pos, w.colstat, Z, N, Np, w.vh, w.vl, w.cref);
     bool cfg_failed = false;
-    FAR_ONCE_PER_DEVICE(cfg_failed = hipFuncSetAttribute((const void*)k_pv<SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PV_STAGE) != hipSuccess ||
-                                     hipFuncSetAttribute((const void*)k_pv8<SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, PV8_SMEM) != hipSuccess);
+    FAR_ONCE_PER_DEVICE(cfg_failed = hipFuncSetAttribute((const void*)k_pv<SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PV_STAGE) != hipSuccess);
     if (cfg_failed) return far_check_launch();
-    // far_set_tuning(14, 1): k_pv (rounds 3-5: 4 waves, two workgroups per CU, no in-wave pipeline) everywhere; default: the 8-wave
-    // software-pipelined form when the padded length is a multiple of 256 (bit-identical)
-    if (Np % 256 == 0 && far_get_tuning(14) == 0) {
-        hipLaunchKernelGGL(k_pv8<SPLIT>, dim3((unsigned)(Np / 256) * Z), dim3(512), PV8_SMEM, stream, w.qh, w.ql, w.kh, w.kl, w.vh, w.vl, Z, N, Np, c1,
-                           w.rowstat, T_out);
-        return far_check_launch();
-    }
     hipLaunchKernelGGL(k_pv<SPLIT>, grid, dim3(256), 2 * PV_STAGE, stream, w.qh, w.ql, w.kh, w.kl, w.vh, w.vl, w.cref, Z, N, Np, c1,
                        w.rowstat, T_out);
     return far_check_launch();

@@ -64,7 +64,6 @@ TUNING = [
     Tuning(10, 0, (1,), 'bitwise', "K1's match pass without the tile prescreen"),
     Tuning(11, 0, (1, 2), 'bitwise', "K14's pipeline: 0 = 4 waves / 3 slots / counted waits, two workgroups per CU; 1 = 8 waves / 4 slots / counted, one per CU (round 5's form); 2 = 4 waves / 3 slots / vmcnt(0) per phase (fallback without a wait table)"),
     Tuning(12, 0, (1,), 'parity', "K10's inference form on the exact-f32 matrix instruction instead of split fp16"),
-    Tuning(14, 0, (1,), 'bitwise', "K2's P v~ pass: 1 = k_pv (4 waves, two workgroups per CU) instead of k_pv8 (8 waves, the next tile's scores pipelined under the exponentials)"),
     Tuning(15, 0, (1,), 'bitwise', 'K17: 1 = the multiplying wave group does NOT raise its issue priority (the round-4 kernel)'),
     Tuning(13, 0, (1,), 'bitwise', "K9's FPN-merge epilogue in its generic form everywhere"),
 ]

@@ -1,4 +1,5 @@
-"""K2 (far_emm_pv_f16s, all passes) at the bench shape: 256 problems of 4800 x 4800 x 64.  Usage: [FAR_HIP_LIB=...] python tools/k2_time.py"""
+"""K2 (far_emm_pv_f16s, all passes) at the bench shape: 256 problems of 4800 x 4800 x 64, the shipped k_pv against far_set_tuning(14, 0 / 1) of a
+library built with tools/experiments/k2_pv8_pipelined.patch (round 6; on the product library both settings run k_pv).  Usage: [FAR_HIP_LIB=...] python tools/k2_time.py"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
