@@ -650,6 +650,35 @@ def test_mixed16_mode_deviation(model, mode):
     assert 0 < dev < 1e-2
 
 
+def test_precision_by_stage(model):
+    """LoFTR.set_precision accepts a set of stage names (round 6).  The stages that cannot touch a match decision -- the FPN's fine
+    branch, the fine-level layers, the head's attention -- keep b_ids / i_ids / j_ids / mconf bit-identical to the parity line when
+    they run on 16-bit operands; the trunk, the coarse layers and K1 do not.  Names are checked; the removed vendor 'bf16' mode (MIOpen
+    under autocast) is no longer a mode of the package."""
+    import copy
+    m = copy.deepcopy(model)
+    d32, _, _ = _batch(2, 33)
+    with torch.no_grad():
+        m(d32)
+        for st, exact in ((('fpn', 'fine_layers', 'k2'), True), (('trunk',), False), (('coarse_dense',), False), (('k1',), False)):
+            m.set_precision(st)
+            assert m.precision_stages == tuple(s for s in m.STAGES if s in st)
+            d, _, _ = _batch(2, 33)
+            m(d)
+            same = all(d[k].shape == d32[k].shape and torch.equal(d[k], d32[k]) for k in ('b_ids', 'i_ids', 'j_ids', 'mconf'))
+            assert same == exact, (st, same)
+        m.set_precision('fp32')
+        assert m.precision_stages == () and m.backbone.trunk_split and m.backbone.fpn_split
+        d, _, _ = _batch(2, 33)
+        m(d)
+    for k in ('b_ids', 'i_ids', 'j_ids', 'mconf', 'mkpts1_f'):
+        assert torch.equal(d[k], d32[k]), k
+    with pytest.raises(ValueError):
+        m.set_precision('bf16')
+    with pytest.raises(ValueError):
+        m.set_precision(('trunk', 'no_such_stage'))
+
+
 def test_activation_range_recovery_end_to_end(model):
     """A checkpoint whose activations leave the split-fp16 range of the default exponent (|a| > 4094): the stem's BatchNorm
     scale and shift are multiplied by 2^13, so the first feature map reaches ~3e4 and everything downstream grows with it.
