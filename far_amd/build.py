@@ -19,6 +19,14 @@ HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 BASE_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wno-unused-result', '-Wno-unused-value']
 EXTRA_FLAGS = (flags.value('FAR_EXTRA_HIPCC_FLAGS') or '').split()            # experiment builds (-DFAR_WINO_EXP=..., tools/)
 FLAGS = BASE_FLAGS + ['-I', CSRC] + EXTRA_FLAGS
+# Per-file flags (part of the build id).  emm_bilinear_f16s.hip (K2) is compiled WITHOUT the packed fp32 instructions: v_pk_fma / add /
+# mul_f32 of one wave wait for gaps in the matrix pipe while its SIMD partner issues MFMAs (tools/ubench/valu_cost.hip: 370 cycles per
+# instruction against 5 alone -- K17's transform uses scalar asm for that reason since round 4), and K2's softmax arithmetic is 409 of
+# them: counters showed MFMA-busy 47 % + VALU-busy 45 % = no overlap (profiles/r06_k2_pipelined.txt).  Scalar forms: the same bits, K2
+# 9.00 -> 8.51 ms per step (round 6, same box, three interleaved runs).  The other kernel files measured equal or slower without them
+# (K17 +0.9 %: its epilogue's packed adds run when no MFMA is in flight).
+NO_PACKED_FP32 = ['-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
+PER_FILE_FLAGS = {'emm_bilinear_f16s.hip': NO_PACKED_FP32}
 
 
 def flags_skip_asm_check():
@@ -51,7 +59,8 @@ def source_id():
     Compiled into the library (far_build_id()); _lib.load() recomputes it from the sources next to the library and refuses a
     library built from other sources -- the .so travels outside git, this is what ties it to the tree it is loaded from."""
     files = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hip', '.h', '.inc'))]
-    return _digest(files, ' '.join(BASE_FLAGS + EXTRA_FLAGS))[:16]
+    per_file = ' '.join(f'{k}:{" ".join(v)}' for k, v in sorted(PER_FILE_FLAGS.items()))
+    return _digest(files, ' '.join(BASE_FLAGS + EXTRA_FLAGS) + ' | ' + per_file)[:16]
 
 
 # ---- K9's asm pixel loads (conv_igemm_f16s.hip: stage_load / stage_arrived) rely on one property of the GENERATED code: between an
@@ -216,7 +225,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(LIBDIR, os.path.basename(src)[:-4] + '.o')
         objs.append(obj)
         is_abi = os.path.basename(src) == 'abi.hip'
-        flags = FLAGS + ([f'-DFAR_BUILD_ID="{bid}"'] if is_abi else [])          # abi.hip carries the id: it recompiles with every change
+        flags = FLAGS + PER_FILE_FLAGS.get(os.path.basename(src), []) + ([f'-DFAR_BUILD_ID="{bid}"'] if is_abi else [])   # abi.hip carries the id: it recompiles with every change
         want = _digest([src] + hdrs, ' '.join(flags).replace(CSRC, '<csrc>'))
         side = obj + '.hash'
         have = open(side).read().strip() if os.path.exists(side) and os.path.exists(obj) else None
