@@ -992,6 +992,9 @@ def main():
             # host time of a step without its waits for the GPU (host_work_ms: Python + ctypes + the caching allocator), measured on
             # three extra untimed steps: what N ranks on one host contend for
             'host_ms_per_step': max(per_rank_host_ms), 'per_rank_host_ms_per_step': per_rank_host_ms,
+            # normal hosts: ~5 ms.  A box whose host is an order of magnitude slower (seen once in ~15 runs of round 6: 42.9 ms, step 113.5 ms
+            # with unchanged kernels) cannot keep the GPU fed behind the step's match-count read: the line then measures the host
+            'host_bound': bool(max(per_rank_host_ms) > 0.2 * 1000 * dt / a.steps),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32' if a.precision == 'fp32' else f'f32 tensors/accumulation, {a.precision} matrix operands',
             'dtype_note': ('f32 = fp32 tensors, fp32 accumulation; matrix products on the f16 MFMA pipe as split-f16x3 operand '
