@@ -238,8 +238,16 @@ def build(force=False, verbose=True):
                 asm = obj[:-2] + '.s'
                 chk = (asm, subprocess.Popen([HIPCC] + [f for f in flags if f != '-fPIC'] + ['--cuda-device-only', '-S', src, '-o', asm],
                                              stderr=subprocess.DEVNULL))
-            procs.append((src, subprocess.Popen(cmd), side, want, chk))
+            # (a per-file -target-feature also reaches the HOST pass of hipcc, which answers "not a recognized feature for this target
+            # (ignoring feature)": filtered from its stderr, everything else is passed through)
+            quiet = os.path.basename(src) in PER_FILE_FLAGS
+            procs.append((src, subprocess.Popen(cmd, stderr=subprocess.PIPE if quiet else None, text=quiet or None), side, want, chk))
     for src, p, side, want, chk in procs:
+        if p.stderr is not None:
+            err = p.communicate()[1] or ''
+            keep = [ln for ln in err.splitlines() if 'is not a recognized feature for this target' not in ln]
+            if keep:
+                print('\n'.join(keep), file=sys.stderr, flush=True)
         if p.wait() != 0:
             raise RuntimeError(f'hipcc failed on {src}')
         if chk is not None:
