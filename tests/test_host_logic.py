@@ -287,6 +287,40 @@ def test_build_asm_scan_catches_a_staged_register_touched_before_its_wait(tmp_pa
         assert (nfn, nld, len(bad)) == (1, 1, nbad), (name, bad)
 
 
+def test_build_ring_scan_flags_a_barrier_crossed_with_lds_reads_outstanding(tmp_path):
+    """far_amd/build.py: lds_ring_check -- the build gate behind the round-6 root cause (common.h: ring_barrier).  On hand-made code:
+    the rounds-3..5 shape of K13 / K14 (two fragment reads, vmcnt wait, barrier, THEN the lgkmcnt wait hipcc sank below it) is flagged;
+    the same with s_waitcnt lgkmcnt(0) in front of the barrier is clean; a partial wait that leaves a read in flight is flagged; a
+    kernel without LDS-DMA is not this scan's business; the staged-store ADVICE case of _asm_scan (a store that reads a staged register
+    before its wait) is a violation too."""
+    from far_amd import build
+    head = '_ZN1x5k_ringILi4EEEvv:\n'
+    dma = '\tglobal_load_lds_dwordx4 v[4:5], off\n'
+    reads = '\tds_read_b128 v[6:9], v137 offset:15360\n\tds_read_b128 v[2:5], v137 offset:14336\n'
+    mfma = '\tv_mfma_f32_32x32x16_f16 v[66:81], v[178:181], v[2:5], v[66:81]\n'
+    tail = '\ts_endpgm\n'
+    cases = {
+        'rounds 3-5: the wait sunk below the barrier': (head + dma + reads + '\ts_waitcnt vmcnt(8)\n\ts_barrier\n' + mfma + '\ts_waitcnt lgkmcnt(0)\n' + mfma + dma + tail, 1),
+        'round 6: lgkmcnt(0) + barrier': (head + dma + reads + '\ts_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier\n' + mfma + dma + tail, 0),
+        'combined wait': (head + dma + reads + '\ts_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier\n' + dma + tail, 0),
+        'partial wait leaves one read in flight': (head + dma + reads + '\ts_waitcnt lgkmcnt(1)\n\ts_barrier\n' + dma + tail, 1),
+        'no LDS-DMA in the kernel': (head + reads + '\ts_barrier\n' + tail, 0),
+    }
+    for name, (text, nbad) in cases.items():
+        p = tmp_path / 'r.s'
+        p.write_text(text)
+        nfn, nbar, bad = build.lds_ring_check(str(p))
+        assert len(bad) == nbad, (name, bad)
+        assert nbar == (0 if 'no LDS-DMA' in name else 1), name
+    # _asm_scan: a store that READS a staged register in front of the counted wait is a violation, not "a younger request"
+    k9 = ('_ZN1x6k_convILi1EEEvv:\n\t;;#ASMSTART\n\tglobal_load_dwordx4 v[10:13], v[2:3], off\n\t;;#ASMEND\n' + dma * 2 +
+          '\tscratch_store_dword off, v11, off offset:16\n\t;;#ASMSTART\n\ts_waitcnt vmcnt(3)\n\t;;#ASMEND\n\tv_cvt_pk_f16_f32 v20, v10, v11\n' + tail)
+    p = tmp_path / 'k.s'
+    p.write_text(k9)
+    nfn, nld, bad = build.asm_check(str(p), 'k_conv')
+    assert (nfn, nld) == (1, 1) and len(bad) == 1 and 'scratch_store' in bad[0], bad
+
+
 def test_package_raises_on_cpu_tensors_without_the_test_side_helper():
     """far_amd has no CPU / eager / vendor path of its own (far_amd/_vendor.py): the torch compositions live in tests/vendor_ops.py and
     are installed by conftest.py.  With the helper uninstalled -- the product's state -- CPU tensors raise FarHipError."""
