@@ -24,6 +24,12 @@ SWITCHES = [
            'the 196-channel backbone maps stored with 196 channels instead of 208 (zero weights for the extra ones: exact zeros)'),
     Switch('FAR_NO_PREFETCH', 'far_amd.loftr.model:LoFTR', 'head_prefetch', False, 'bitwise', 'inference',
            "the head's feature stage computed inside forward_rt_prediction instead of enqueued behind K1"),
+    Switch('FAR_NO_SIDE_STREAM', 'far_amd.loftr.model:LoFTR', 'head_side_stream', False, 'bitwise', 'inference',
+           "the head's feature stage on the step's own stream behind K1 (rounds 2-5) instead of on a second stream next to K1 and the fine level"),
+    Switch('FAR_FPN_STREAM', 'far_amd.loftr.model:LoFTR', 'fpn_side_stream', True, 'bitwise', 'inference',
+           "OPT-IN (1 switches it ON; default off): the FPN's fine branch on a side stream next to the coarse transformer and K1 (-0.6 ms per 32 "
+           "pairs; off by default because the roofline launch -- K17 208 -> 208 @ 240x320 -- then shares the GPU and its in-step duration "
+           "in a kernel trace is no longer its own)"),
     Switch('FAR_NO_GATHER_FUSE', 'far_amd.loftr.stages:FinePreprocess', 'fused_gather', False, 'bitwise', 'inference',
            'FinePreprocess.merge_feat on a materialised window tensor (K3 gather + K9) instead of K9 reading through the match indices'),
     Switch('FAR_NO_KV', 'far_amd.loftr.transformer:LoFTREncoderLayer', 'fused_kv', False, 'parity', 'inference',

@@ -174,17 +174,37 @@ class ResNetFPN_8_2(nn.Module):
             res = ops.conv_nhwc(x, pk.get(name + '.down', blk.downsample[0], blk.downsample[1], sp), in_stride=2)   # x[:, ::2, ::2] in place
         return ops.conv_nhwc(y, pk.get(name + '.conv2', blk.conv2, blk.bn2, sp), residual=res, act='relu')
 
-    def _forward_fused(self, x):
+    def _forward_fused(self, x, side=None):
         pk = self.__dict__.setdefault('_packs', _PackCache())
         # only the middle level may need padding: the stem's and the two returned maps' channel counts are what the callers see
         b = self.config['block_dims']
         pk.pad = PAD_CHANNELS and self.config['initial_dim'] % 16 == 0 and b[0] % 16 == 0 and b[2] % 16 == 0
         sp = self.trunk_split
+        # (the returned maps are (N, C, H, W)-shaped views of NHWC buffers: downstream 'n c h w -> n (h w) c' is then a free view)
         x0 = ops.stem7x7(x, self.conv1.weight, *_fold(self.bn1))
         x1 = self._block_fused('layer1.1', self.layer1[1], self._block_fused('layer1.0', self.layer1[0], x0, pk), pk)
         x2 = self._block_fused('layer2.1', self.layer2[1], self._block_fused('layer2.0', self.layer2[0], x1, pk), pk)
         x3 = self._block_fused('layer3.1', self.layer3[1], self._block_fused('layer3.0', self.layer3[0], x2, pk), pk)
         x3_out = ops.conv_nhwc(x3, pk.get('layer3_outconv', self.layer3_outconv, None, sp))
+        if side is None:
+            return [x3_out.permute(0, 3, 1, 2), self._fpn_fused(x1, x2, x3_out, pk).permute(0, 3, 1, 2)]
+        # The FPN's fine branch (21 of the backbone's 48 ms per 32 pairs) feeds the fine level only; the coarse transformer and K1
+        # need x3_out alone.  With a side stream from the caller the branch forks off here and the caller joins it (the returned
+        # event) in front of its first reader.  Tensors that cross streams are recorded with the allocator on the other side.
+        main = torch.cuda.current_stream()
+        fork = torch.cuda.Event()
+        fork.record()
+        side.wait_event(fork)
+        with torch.cuda.stream(side):
+            x1_out = self._fpn_fused(x1, x2, x3_out, pk)
+            done = torch.cuda.Event()
+            done.record()
+        for t in (x1, x2, x3_out):
+            t.record_stream(side)
+        x1_out.record_stream(main)
+        return [x3_out.permute(0, 3, 1, 2), x1_out.permute(0, 3, 1, 2)], done
+
+    def _fpn_fused(self, x1, x2, x3_out, pk):
         sp = self.fpn_split
         o2, o1 = self.layer2_outconv2, self.layer1_outconv2
         # FPN merge (:108-109, :113-114): lateral 1x1 convolution + 2x bilinear upsampling of the coarser level, in the
@@ -200,13 +220,15 @@ class ResNetFPN_8_2(nn.Module):
         x2_out = ops.conv_nhwc(y, pk.get('o2.3', o2[3], None, sp))
         y = merge('layer1_outconv', self.layer1_outconv, x1, x2_out)
         y = ops.conv_nhwc(y, pk.get('o1.0', o1[0], o1[1], sp), act='leaky', slope=o1[2].negative_slope)
-        x1_out = ops.conv_nhwc(y, pk.get('o1.3', o1[3], None, sp))
-        # (N, C, H, W)-shaped views of the NHWC buffers: downstream 'n c h w -> n (h w) c' is then a free view
-        return [x3_out.permute(0, 3, 1, 2), x1_out.permute(0, 3, 1, 2)]
+        return ops.conv_nhwc(y, pk.get('o1.3', o1[3], None, sp))
 
-    def forward(self, x):
+    def forward(self, x, side=None):
+        """side (inference on the GPU only): a HIP stream for the FPN's fine branch; the call then returns ([coarse, fine], event) and
+        `fine` may be read only behind the event."""
         if _fused_ok(self, x) and x.shape[1] == 1:
-            return self._forward_fused(x)
+            return self._forward_fused(x, side)
+        if side is not None:
+            raise ValueError('a side stream is a mode of the fused inference path')
         if not x.is_cuda or not ResNetFPN_8_2.hip_training:
             _vendor.require('the backbone on CPU tensors or with hip_training = False (vendor convolutions)')
         if (ResNetFPN_8_2.hip_training and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and x.shape[1] == 1

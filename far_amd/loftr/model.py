@@ -61,6 +61,15 @@ def _tokens(fmap, pos_enc):
 
 
 _POSE_STATS = {}
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device, which=0):
+    """The side streams of `device` (per process and device): 0 = the head's feature stage, 1 = the FPN's fine branch."""
+    key = (str(device), which)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device)
+    return _SIDE_STREAMS[key]
 
 
 def _pose_stats(device):
@@ -115,6 +124,8 @@ class LoFTR(nn.Module):
              'fp16': STAGES}
     PRECISIONS = tuple(MODES)
     head_prefetch = not flags.off('FAR_NO_PREFETCH')   # inference: the head's feature stage enqueued behind K1 (see below)
+    head_side_stream = not flags.off('FAR_NO_SIDE_STREAM')   # ... on a second HIP stream, next to K1 and the fine level
+    fpn_side_stream = flags.off('FAR_FPN_STREAM')            # opt-in: the FPN's fine branch on a side stream, next to the coarse transformer
 
     def set_precision(self, mode):
         """mode: a name of MODES or an iterable of STAGES names (the stages that run on 16-bit operands).
@@ -154,19 +165,28 @@ class LoFTR(nn.Module):
     # -------------------------------------------------------------------------------------------------
     # stage 1: local feature CNN on both images at once (loftr.py:56-89)
     # -------------------------------------------------------------------------------------------------
-    def _run_backbone(self, images):
+    def _run_backbone(self, images, side_ok=False):
+        from .backbone import _fused_ok
+        if side_ok and self.fpn_side_stream and _fused_ok(self.backbone, images) and images.shape[1] == 1:
+            # the FPN's fine branch on a second stream, next to the coarse transformer and K1 (backbone.py: _forward_fused);
+            # _correspondence_prediction joins it in front of FinePreprocess, the guards in front of their flag read
+            self._join_side()
+            feats, self._fpn_pending = self.backbone(images, side=_side_stream(images.device, 1))
+            return feats
         return self.backbone(images)
 
     def forward_feature_extraction(self, data):
         with ops.activation_exponent(self.act_exp):
             self._feature_extraction(data)
 
-    def _feature_extraction(self, data):
+    def _feature_extraction(self, data, side_ok=False):
+        """side_ok: the caller runs _correspondence_prediction next (forward): the fine maps may still be in flight on the side stream
+        when this returns.  The public forward_feature_extraction hands out finished maps."""
         im0, im1 = data['image0'], data['image1']
         n = im0.size(0)
         data.update(bs=n, hw0_i=im0.shape[2:], hw1_i=im1.shape[2:])
         if im0.shape[2:] == im1.shape[2:]:
-            feats_c, feats_f = self._run_backbone(torch.cat([im0, im1], dim=0))
+            feats_c, feats_f = self._run_backbone(torch.cat([im0, im1], dim=0), side_ok)
             c0, c1 = feats_c.split(n)
             f0, f1 = feats_f.split(n)
         else:                                                                  # different input shapes (:76-77)
@@ -196,11 +216,33 @@ class LoFTR(nn.Module):
         # (_head_features: same tensors, same stamps).  It runs inside this call's activation-range guard like everything else here.
         # Only when the caller says the head follows (far_amd.pipeline.test_step sets data['_far_head_follows']): a matcher-only
         # caller (Map-free: match + solve at another resolution) must not pay for -- or trip over -- a stage it never runs.
+        # On a SECOND stream (head_side_stream): the stage forks off where the coarse tokens are complete -- in front of K1 -- and
+        # joins where its features are first read (_head_features) or where an activation-range guard reads its flag, whichever
+        # comes first.  K1, the fine level and the first solver round are one branch of the step's dependency graph, this stage the
+        # other (12.7 against 13.1 ms per 32 pairs alone); side by side the workgroups of one fill the ramps, tails and launch gaps of
+        # the other -- ~40 launches of 0.1-0.5 ms each on either side.  No buffer is shared between the branches: workspaces are
+        # per-call allocations of the (stream-aware) caching allocator, the library's scratch slots are handed out per launch
+        # (conv_igemm_f16s.hip: g_amax_slots), the overflow flag is an atomic OR.  Results are bit-identical (tests/test_flags_gpu.py).
         overlap = None
         if (self.head_prefetch and data.get('_far_head_follows') and self.config['regress_rt'] and tok0.is_cuda and not train
                 and not torch.is_grad_enabled() and not self.training and getattr(self.loftr_regress, 'cache_features', True)):
-            overlap = lambda: self._head_features(data, tok0, tok1, None, None)
+            if self.head_side_stream:
+                side, main = _side_stream(tok0.device), torch.cuda.current_stream()
+                fork = torch.cuda.Event()
+                fork.record()                              # tok0 / tok1 are complete here; K1 is not enqueued yet
+
+                def overlap():
+                    self._join_side('_side_pending')       # a stage nobody consumed (should not happen; keeps one event pending at most)
+                    side.wait_event(fork)
+                    with torch.cuda.stream(side):
+                        self._head_features(data, tok0, tok1, None, None, join=False, reader=main)
+                        done = torch.cuda.Event()
+                        done.record()
+                    self._side_pending = done
+            else:
+                overlap = lambda: self._head_features(data, tok0, tok1, None, None)
         self.coarse_matching(tok0, tok1, data, mask_c0=m0, mask_c1=m1, overlap=overlap)
+        self._join_side('_fpn_pending')                    # the fine maps: first read here
         win0, win1 = self.fine_preprocess(data['featmap_f0'], data['featmap_f1'], tok0, tok1, data)
         if win0.size(0) != 0:
             win0, win1 = self.loftr_fine(win0, win1)
@@ -301,8 +343,18 @@ class LoFTR(nn.Module):
     def _tensor_stamp(t):
         return (id(t), t.data_ptr(), tuple(t.shape), ops.tensor_version(t))
 
-    def _head_features(self, data, f0, f1, preds, inv_preds):
+    def _join_side(self, *which):
+        """The current stream waits for what is in flight on the side streams: the head's feature stage ('_side_pending'), the FPN's
+        fine branch ('_fpn_pending'); no names = both."""
+        for name in which or ('_fpn_pending', '_side_pending'):
+            ev = self.__dict__.pop(name, None)
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
+
+    def _head_features(self, data, f0, f1, preds, inv_preds, join=True, reader=None):
         head = self.loftr_regress
+        if join:
+            self._join_side()
         if torch.is_grad_enabled() or not getattr(head, 'cache_features', True):
             return None                                    # training / caching disabled: the head computes them itself
         stamp = (self._tensor_stamp(f0), self._tensor_stamp(f1), head.feature_stamp())
@@ -310,6 +362,11 @@ class LoFTR(nn.Module):
         if hit is not None and hit[0] == stamp and hit[2] is f0 and hit[3] is f1:
             return hit[1]
         features = head.compute_features(f0, f1, preds, inv_preds)
+        if not join:
+            # allocated on the side stream, read on the caller's: the allocator must not hand the blocks out again (to side-stream
+            # work of the next batch) before the reader's launches are done with them
+            for t in ((features.feats, features.enc0, features.moe0) if hasattr(features, 'enc0') else (features,)):
+                t.record_stream(reader)
         data[self._HEAD_KEY] = (stamp, features, f0, f1)
         return features
 
@@ -386,12 +443,14 @@ class LoFTR(nn.Module):
             except ops.ActivationOverflow:
                 raise
             except Exception:
+                self._join_side()
                 # fn() may be a whole step (guarded_sequence): the stages behind an overflowed launch then ran on inf / NaN and may
                 # have raised on them (non-finite keypoints, degenerate match counts, host-side conversions) before the flag was
                 # read.  With the flag set that exception is a symptom of the overflow: widen and re-run; otherwise it is the caller's
                 if not ops.activation_overflowed(device):
                     raise
             else:
+                self._join_side()                              # the flag read below must see the side stream's launches too
                 if not ops.activation_overflowed(device):      # one host read per call
                     return out
             if saved is None:
@@ -427,6 +486,7 @@ class LoFTR(nn.Module):
     def check_activation_range(self, data):
         """For callers that drive forward_feature_extraction / forward_correspondence_prediction themselves: raises
         ops.ActivationOverflow if a launch since the last check left the split-fp16 range (outputs contain inf / NaN)."""
+        self._join_side()
         ops.check_activation_range(data['image0'].device, 'LoFTR')
 
     def forward(self, data, train=False):
@@ -434,7 +494,8 @@ class LoFTR(nn.Module):
         wrapper that copies dict arguments on the way in (DistributedDataParallel built with device_ids) would otherwise
         leave the caller with a dict the module never wrote to; far_amd.pipeline merges a returned copy back."""
         def run():
-            self.forward_feature_extraction(data)
+            with ops.activation_exponent(self.act_exp):
+                self._feature_extraction(data, side_ok=True)
             self.forward_correspondence_prediction(data, train=train)
         self._guarded(run, data['image0'].device, (data['image0'], data['image1']))
         return data

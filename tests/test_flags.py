@@ -44,7 +44,8 @@ def test_switch_targets_exist_and_default_on():
     import far_amd.loftr  # noqa: F401
     for sw in flags.SWITCHES:
         obj, attr = flags.target(sw)
-        assert getattr(obj, attr) is True or os.environ.get(sw.env), sw.env          # the product default: every feature on
+        # the product default: every feature on -- except an opt-in switch (off_value True: FAR_FPN_STREAM), which defaults off
+        assert getattr(obj, attr) is (not sw.off_value) or os.environ.get(sw.env), sw.env
         assert sw.neutral in ('bitwise', 'parity') and sw.scope in ('inference', 'training')
 
 

@@ -542,6 +542,38 @@ def test_step_on_a_side_stream_equals_the_default_stream(model):
         assert torch.equal(data[k], ref[k]), k
 
 
+def test_side_streams_change_nothing(model):
+    """The head's feature stage on a second stream (LoFTR.head_side_stream, default on) and the FPN's fine branch on a third
+    (LoFTR.fpn_side_stream, opt-in): independent branches of the step's dependency graph -- the same results to the bit in every
+    combination, on the default stream and with the whole step on a caller's stream, twice in a row (the second step reuses the
+    blocks the first one's side streams freed)."""
+    from far_amd.pipeline import test_step
+    keys = ('b_ids', 'i_ids', 'j_ids', 'mconf', 'mkpts0_f', 'mkpts1_f', 'loftr_rt', 'regressed_rt', 'solver_inlier_mask', 'priorRT')
+
+    def run(head, fpn, stream=None):
+        model.head_side_stream, model.fpn_side_stream = head, fpn
+        try:
+            outs = []
+            for _ in range(2):
+                d, _, _ = _batch(8, 21)
+                torch.cuda.synchronize()
+                with torch.cuda.stream(stream or torch.cuda.current_stream()):
+                    test_step(model, d, H=256)
+                torch.cuda.synchronize()
+                assert '_side_pending' not in model.__dict__ and '_fpn_pending' not in model.__dict__      # everything joined
+                outs.append({k: (d[k].clone() if torch.is_tensor(d[k]) else np.array(d[k])) for k in keys})
+            return outs
+        finally:
+            del model.head_side_stream, model.fpn_side_stream
+
+    ref = run(False, False)[0]
+    for head, fpn, stream in ((True, False, None), (False, True, None), (True, True, None), (True, True, torch.cuda.Stream())):
+        for got in run(head, fpn, stream):
+            for k in keys:
+                a, b = ref[k], got[k]
+                assert (torch.equal(a, b) if torch.is_tensor(a) else np.array_equal(a, b)), (head, fpn, stream is not None, k)
+
+
 def test_non_contiguous_inputs_are_accepted(model):
     """Images that are strided views (a pair tensor (N, 2, H, W) sliced per view, as a dataloader may hand them over) and
     intrinsics that are views of a larger tensor: same results as with packed copies."""

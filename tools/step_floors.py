@@ -215,14 +215,21 @@ def main():
     probe = bench.mfma_sustained_peak()
     sustained = probe['operands_from_lds']['tflops'] * 1e12
     sustained_reg = probe['operands_in_registers']['tflops'] * 1e12
-    # un-instrumented step time (events around whole steps)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(5):
-        test_step(model_, dict(base), H=2048, seed=0)
-    e1.record()
-    e1.synchronize()
-    plain_ms = e0.elapsed_time(e1) / 5
+    # un-instrumented step time (events around whole steps): the product configuration first (the head's feature stage on its side
+    # stream), then with every launch on the step's own stream -- the configuration the per-call times below are taken in (a call
+    # that shares the GPU with another stream's launches has no duration of its own)
+    def plain():
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            test_step(model_, dict(base), H=2048, seed=0)
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / 5
+    product_ms = plain()
+    model_.head_side_stream = model_.fpn_side_stream = False
+    test_step(model_, dict(base), H=2048, seed=0)
+    plain_ms = plain()
     steps = []
     step_ms = []
     for _ in range(a.steps):
@@ -252,7 +259,8 @@ def main():
     tot_ms = sum(r['ms'] for r in rows)
     w(f'# tools/step_floors.py: one steady-state step of the headline workload ({a.pairs} pairs @ 640x480, match + 2 solver rounds + 2 head calls),')
     w(f'# mean of {a.steps} recorded steps; library build id {real.far_build_id().decode()}, commit {os.environ.get("FAR_COMMIT", "?")}')
-    w(f'# step time: {plain_ms:.2f} ms un-instrumented (events around 5 steps); {sum(step_ms) / len(step_ms):.2f} ms with an event pair around each of the {n} C-ABI calls;')
+    w(f'# step time: {product_ms:.2f} ms in the product configuration (the head\'s feature stage on a side stream next to K1 and the fine level);')
+    w(f'#   on ONE stream (LoFTR.head_side_stream = False, as everything below): {plain_ms:.2f} ms un-instrumented (events around 5 steps); {sum(step_ms) / len(step_ms):.2f} ms with an event pair around each of the {n} C-ABI calls;')
     w(f'#   sum of the calls {tot_ms:.2f} ms, the rest = ATen glue kernels + idle')
     w(f'# floors: HBM at {HBM_ACHIEVABLE / 1e12:.1f} TB/s (achievable; nominal 8); MFMA at the dense-f16 rate far_mfma_probe_f16 sustained in this run with operands')
     w(f'#   from LDS: {sustained / 1e12:.0f} TFLOP/s (operands in registers: {sustained_reg / 1e12:.0f}; nominal 2 500)')
