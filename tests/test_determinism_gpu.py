@@ -139,16 +139,66 @@ def test_whole_batch32_step_twice_bit_identical():
             'regressed_rt', 'match_counts')
     runs = []
     nb = Neighbour()
-    for r in range(3):
+    for r in range(5):
         data = {'image0': torch.from_numpy(im0).cuda(), 'image1': torch.from_numpy(im1).cuda(), 'K0': K, 'K1': K.clone(), 'dataset_name': ['mp3d']}
-        if r:
+        if r in (1, 2):
             nb.kick()
+        # runs 3 and 4: every launch on ONE stream / the FPN branch on a third -- the same bits as the product's two streams (runs 0-2)
+        m.head_side_stream, m.fpn_side_stream = r != 3, r == 4
         test_step(m, data, H=512, seed=1)
         torch.cuda.synchronize()
         runs.append({k: data[k].clone() if torch.is_tensor(data[k]) else torch.as_tensor(np.asarray(data[k])) for k in keys})
         runs[-1]['priorRT'] = torch.as_tensor(np.asarray(data['priorRT']))
     nb.done()
     assert int(runs[0]['match_counts'].sum()) > 32 * 1000
-    for r in (1, 2):
+    for r in (1, 2, 3, 4):
         for k in runs[0]:
             assert torch.equal(runs[0][k], runs[r][k]), f'run {r}: {k} differs'
+
+
+def test_kernels_sharing_a_cu_with_another_streams_kernels():
+    """Round 6: K15 (far_rows_linear_f32) computed wrong sums -- lanes 48..63 of every second accumulator, 30 launches of 30 -- whenever
+    its waves shared a CU with waves of K13 / K14 / K9 launched on another stream: its v_pk_fma_f32 chains went wrong next to them
+    (docs/rounds/r06.md section 2f; far_amd/build.py compiles every file that can share a CU without the packed fp32 instructions
+    since).  Here: each kernel that leaves room on its CUs runs on a side stream next to each of the others on the first, every
+    output bit-identical to the launch that ran alone."""
+    from far_amd import ops
+    from far_amd.loftr.transformer import LoFTREncoderLayer
+    g = torch.Generator(device='cuda').manual_seed(78)
+    D, H = 128, 8
+    ws = [torch.randn(D, D, device='cuda', generator=g) / 11 for _ in range(4)]
+    gam, bet = torch.rand(D, device='cuda', generator=g) + 0.5, torch.randn(D, device='cuda', generator=g) * 0.1
+    pa = ops.PackedAttn(*ws)
+    pm = ops.PackedMlp(torch.randn(2 * D, 2 * D, device='cuda', generator=g) / 16, torch.randn(D, 2 * D, device='cuda', generator=g) / 16)
+    x = torch.randn(30000, 25, D, device='cuda', generator=g)
+    s = torch.randn(30000, 25, D, device='cuda', generator=g)
+    pr = ops.PackedRows(torch.randn(1024, 35840, device='cuda', generator=g) / 190)
+    feats = torch.randn(8, 35840, device='cuda', generator=g)
+    torch.manual_seed(3)
+    layer = LoFTREncoderLayer(256, 8).cuda().eval()
+    xl = torch.randn(8, 4800, 256, device='cuda', generator=g)
+    lnw, lnb = torch.ones(256, device='cuda'), torch.zeros(256, device='cuda')
+    kernels = {'K15 rows linear': lambda: ops.rows_linear(feats, pr),
+               'K14': lambda: ops.attn_block(x, s, pa, H, gam, bet, 1e-5),
+               'K13': lambda: ops.mlp_fused(x, s, pm, gam, bet, 1e-5),
+               'K9 linears of a d256 layer': lambda: layer(xl, xl),
+               'K6 layernorm': lambda: ops.layernorm(xl, lnw, lnb, 1e-5)}
+    side = torch.cuda.Stream()
+    with torch.no_grad():
+        alone = {}
+        for name, fn in kernels.items():
+            alone[name] = fn().clone()
+            torch.cuda.synchronize()
+        for vname, victim in kernels.items():
+            for aname, aggressor in kernels.items():
+                if aname == vname:
+                    continue
+                for it in range(5):
+                    for _ in range(2):
+                        aggressor()
+                    with torch.cuda.stream(side):
+                        y = victim()
+                    for _ in range(2):
+                        aggressor()
+                    torch.cuda.synchronize()
+                    assert torch.equal(y, alone[vname]), f'{vname} next to {aname} (launch {it}): {int((y != alone[vname]).sum())} outputs differ'
