@@ -30,9 +30,9 @@ FLAGS = BASE_FLAGS + ['-I', CSRC] + EXTRA_FLAGS
 #  * speed: a packed instruction of one wave waits for gaps in the matrix pipe while its SIMD partner issues MFMAs
 #    (tools/ubench/valu_cost.hip: 370 cycles per instruction against 5 alone); K2: 9.00 -> 8.51 ms per step without them, the others equal.
 # K17 keeps them (its epilogue's packed adds run when no MFMA is in flight: +0.9 % without) -- one workgroup of it fills a CU's register
-# file, no other wave can be resident next to it.
+# file, no other wave can be resident next to it.  (K9 without them was what exposed the missing wait state of common.h's split2, r06 2g.)
 NO_PACKED_FP32 = ['-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
-PACKED_FP32_FILES = {'conv_wino_f16s.hip', 'conv_igemm_f16s.hip'}
+PACKED_FP32_FILES = {'conv_wino_f16s.hip'}
 
 
 class _PerFile(dict):

@@ -111,6 +111,8 @@ __device__ __forceinline__ void split_pair(float a, float b, f16x2& hi, f16x2& l
         const unsigned h = __builtin_bit_cast(unsigned, hi);
         unsigned l;
         asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(a));
+        // (no wait state behind the half-register write, unlike common.h's split2: every consumer of `lo` in this kernel is an LDS store,
+        // which reads the register file, not the VALU's forwarding path the hazard lives in)
         asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(b));
         lo = __builtin_bit_cast(f16x2, l);
     } else {
