@@ -1,5 +1,10 @@
+"""What K15's k_rows_partial needs to go wrong next to K13 on another stream (docs/rounds/r06.md section 2f): the kernel's source is
+recompiled four ways on the GPU box -- as it was (packed fp32), without the packed instructions, with a static store loop (no
+s_set_gpr_idx), with computed instead of streamed weights -- and each runs 15 times on a side stream next to the real K13.
+Round 6: 14-15 / 0 / 15 / 0 of 15 launches differ.  (The shipped library is built without the packed instructions: far_amd/build.py.)
+python tools/k15_victim_variants.py"""
 import os, sys, ctypes, subprocess
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 ctypes.CDLL(os.path.join(ROOT, 'far_amd', 'lib', 'libfar_hip.so'), mode=ctypes.RTLD_GLOBAL)
 import numpy as np, torch

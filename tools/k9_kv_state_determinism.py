@@ -1,5 +1,9 @@
+"""K9's plain Linear launch and its k | v-state launch (EPI 1: la_kv_pass) ten times each, outputs compared bit for bit -- the
+check behind docs/rounds/r06.md section 2g (the half-register write of the fp16 split one slot in front of an MFMA).  Run it on a build
+variant with FAR_HIP_LIB=...; on the shipped library both lines must say 0.
+python tools/k9_kv_state_determinism.py"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from far_amd import ops
 from far_amd.loftr.transformer import LoFTREncoderLayer
