@@ -21,6 +21,13 @@ variants = {
     'C packed, static store loop (no s_set_gpr_idx)': (src.replace(STORE, "#pragma unroll\n        for (int b = 0; b < RBT; ++b) if (b < B) partial[((size_t)s * B + b) * N + n] = acc[b];"), []),
     'D packed, weights computed (no global loads in the loop)': (src.replace(WLOAD, "                const float4 w = make_float4(1e-3f * (n & 63) + 1e-4f * (k4 & 31), 0.5f, 0.25f - 1e-3f * (n & 7), 0.125f);"), []),
 }
+# E: the LDS tile written once in front of the loop (no barrier / ds_write inside it); F: no LDS reads in the loop (x from registers)
+FILL = "        __syncthreads();\n        for (int i = threadIdx.x; i < RBT * KT4; i += 256) {"
+assert FILL in src
+XS = "                    const float4 v = xs[b][q];                      // same address in every lane: an LDS broadcast"
+assert XS in src
+variants['E packed, tile written once (no barrier in the loop)'] = (src.replace(FILL, "        if (sub == 0) __syncthreads();\n        for (int i = threadIdx.x; sub == 0 && i < RBT * KT4; i += 256) {"), [])
+variants['F packed, x from registers (no LDS read in the loop)'] = (src.replace(XS, "                    const float4 v = make_float4(0.01f * b + 0.001f * q, 0.5f, 0.25f - 0.01f * b, 0.125f);"), [])
 g = torch.Generator(device='cuda').manual_seed(78)
 D, H = 128, 8
 w0 = torch.randn(2 * D, 2 * D, device='cuda', generator=g) / 16

@@ -164,6 +164,38 @@ __global__ __launch_bounds__(256) void aggressor_valu_big(float* __restrict__ si
     if (t == 1234.5f) sink[0] = t;
 }
 
+// Half-register writes only: the fp16 split's v_cvt_pk_f16_f32 + v_fma_mixlo / mixhi_f16 triple in a loop (what K9 / K13 / K14 issue
+// thousands of times per tile next to their MFMAs), optionally with MFMAs consuming the results
+template <bool WITH_MFMA>
+__global__ __launch_bounds__(256) void aggressor_mix(float* __restrict__ sink, int iters) {
+    float x0 = 0.001f * threadIdx.x, x1 = 0.5f + 0.002f * threadIdx.x;
+    unsigned acc = 0;
+    f32x16 c;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) c[i] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+        unsigned lo4[4], hi4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned h, l;
+            asm volatile("v_cvt_pk_f16_f32 %0, %2, %3\n\tv_fma_mixlo_f16 %1, %0, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+                         "v_fma_mixhi_f16 %1, %0, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=&v"(h), "=&v"(l) : "v"(x0), "v"(x1));
+            hi4[j] = h; lo4[j] = l;
+            x0 += 0.25f; x1 -= 0.125f;
+        }
+        if (WITH_MFMA) {
+            const u32x4 a = u32x4{hi4[0], hi4[1], hi4[2], hi4[3]}, b = u32x4{lo4[0], lo4[1], lo4[2], lo4[3]};
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+        } else {
+            acc += hi4[0] ^ lo4[1] ^ hi4[2] ^ lo4[3];
+        }
+    }
+    float t = (float)acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += c[i];
+    if (t == 1234.5f) sink[0] = t;
+}
+
 __device__ __forceinline__ void glds16_restore(const void* gsrc, unsigned lds_dst_uniform);
 // The shape of K9 / K13 / K14: LDS-DMA ring pieces, fragments read back with ds_read_b128, fed to MFMAs (VARIANT 0); 1 = without the
 // DMA (the LDS tile is written once with ds_write); 2 = without the MFMAs (reads xor-ed); 3 = MFMAs on register operands + the DMA + reads unused
@@ -272,6 +304,13 @@ static void run_victim(hipStream_t st, unsigned* out, unsigned* err, int blocks,
     hipLaunchKernelGGL(victim<REGS>, dim3(blocks), dim3(256), 0, st, out, err, iters);
 }
 
+// -DAS_LIB: the fp32 victim as a shared library for tools/k15_synthetic_victim.py (next to the REAL K13 of libfar_hip.so)
+extern "C" int launch_victim_f32(float* out, int iters, const void* wp, int blocks, hipStream_t st) {
+    hipLaunchKernelGGL(victim_f32, dim3(blocks), dim3(256), 0, st, out, iters, (const float4*)wp);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+#ifndef AS_LIB
 int main() {
     const int VB = 4096, AB = 8192, VIT = 40, AIT = 60;
     unsigned *out, *ref, *err, *sink;
@@ -354,10 +393,11 @@ int main() {
         CK(hipFuncSetAttribute((const void*)aggressor_gemm<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 49152));
         CK(hipFuncSetAttribute((const void*)aggressor_gemm<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 49152));
         CK(hipFuncSetAttribute((const void*)aggressor_gemm<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 49152));
-        const char* an[9] = {"nothing", "asm dwordx4 LDS-DMA", "MFMA only (no memory traffic)", "LDS-DMA ring -> ds_read_b128 -> MFMA (K9 / K13 / K14's shape)",
+        const char* an[11] = {"nothing", "asm dwordx4 LDS-DMA", "MFMA only (no memory traffic)", "LDS-DMA ring -> ds_read_b128 -> MFMA (K9 / K13 / K14's shape)",
                              "ds_read_b128 -> MFMA, no DMA", "LDS-DMA ring -> ds_read_b128, no MFMA", "LDS-DMA ring + reads + MFMA on register operands",
-                             "MFMA only, 200+ registers per wave", "VALU only, 200+ registers per wave"};
-        for (int mode = 0; mode < 9; ++mode)
+                             "MFMA only, 200+ registers per wave", "VALU only, 200+ registers per wave",
+                              "fp16 split triples (half-register writes) only", "fp16 split triples feeding MFMAs"};
+        for (int mode = 0; mode < 11; ++mode)
             for (int rep = 0; rep < 2; ++rep) {
                 CK(hipMemset(fo, 0, n * 4));
                 CK(hipDeviceSynchronize());
@@ -366,6 +406,8 @@ int main() {
                 if (mode == 3) hipLaunchKernelGGL(aggressor_gemm<0>, dim3(AB), dim3(256), 49152, sa, src, fsink, AIT);
                 if (mode == 4) hipLaunchKernelGGL(aggressor_gemm<1>, dim3(AB), dim3(256), 49152, sa, src, fsink, 4 * AIT);
                 if (mode == 5) hipLaunchKernelGGL(aggressor_gemm<2>, dim3(AB), dim3(256), 49152, sa, src, fsink, AIT);
+                if (mode == 9) hipLaunchKernelGGL(aggressor_mix<false>, dim3(16384), dim3(256), 0, sa, fsink, 6000);
+                if (mode == 10) hipLaunchKernelGGL(aggressor_mix<true>, dim3(16384), dim3(256), 0, sa, fsink, 3000);
                 if (mode == 7) hipLaunchKernelGGL(aggressor_mfma_big, dim3(16384), dim3(256), 0, sa, fsink, 1500);
                 if (mode == 8) hipLaunchKernelGGL(aggressor_valu_big, dim3(16384), dim3(256), 0, sa, fsink, 300);
                 if (mode == 6) hipLaunchKernelGGL(aggressor_gemm<3>, dim3(AB), dim3(256), 49152, sa, src, fsink, AIT);
@@ -386,3 +428,4 @@ int main() {
     }
     return 0;
 }
+#endif
