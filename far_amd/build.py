@@ -151,15 +151,13 @@ def _asm_scan(lines, name):
 
 
 def _functions(text, pattern=r'\w*'):
-    """(name, lines) of every function of a -S output whose mangled name matches; a function runs to the LAST s_endpgm in front of
-    the next function label (early exits do not end the scan)."""
+    """(name, lines) of every function of a -S output whose mangled name matches; a function runs to its `.Lfunc_end` label (code may
+    follow the last s_endpgm: hipcc places cold blocks -- K9's LinearAttention epilogues -- behind the exit they branch back to)."""
     starts = [(i, l.split(':')[0]) for i, l in enumerate(text) if re.match(r'^_Z' + pattern + r':', l)]
-    every = [i for i, l in enumerate(text) if re.match(r'^_Z\w*:', l)] + [len(text)]
+    ends = [i for i, l in enumerate(text) if l.startswith('.Lfunc_end')] + [len(text)]
     out = []
     for i, name in starts:
-        nxt = min(j for j in every if j > i)
-        ends = [j for j in range(i, nxt) if text[j].strip().startswith('s_endpgm')]
-        out.append((name, text[i + 1:(ends[-1] if ends else nxt - 1) + 1]))
+        out.append((name, text[i + 1:min(j for j in ends if j > i)]))
     return out
 
 
@@ -229,8 +227,81 @@ def lds_ring_check(path):
     return nfn, nbar, bad
 
 
+# ---- A half-register write from inline asm and its first reader (round 6, docs/rounds/r06.md section 2g).  v_fma_mixhi_f16 (the fp16
+# split of common.h / conv_wino_f16s.hip) writes the upper 16 bits of its destination; on gfx950 a matrix (or VALU) instruction that
+# reads the register too soon still sees the old half: `mixhi, <one instruction>, mfma` did (K9's k | v-state epilogue, run-to-run
+# differences), two instructions in between do not.  hipcc pads the hazard for instructions it emits itself, not behind an asm
+# statement.  Checked on the generated code of every file that is compiled to assembly anyway: behind every half-register write that
+# comes from an asm block, the first instruction that reads the register is either a memory instruction (LDS / global store: they read
+# the register file, not the forwarding path) or at least PARTIAL_WRITE_GAP instructions (s_nop N counts N + 1) away.
+_PARTIAL_WRITE = re.compile(r'^(v_fma_mixhi_f16|v_cvt_\w+_sdwa|v_\w+_sdwa)\s+(v\d+)\b')
+PARTIAL_WRITE_GAP = 2
+
+
+def _regs_of(tok):
+    m = re.match(r'[va]\[(\d+):(\d+)\]', tok)
+    if m:
+        return {f'v{i}' for i in range(int(m.group(1)), int(m.group(2)) + 1)}
+    m = re.match(r'(v\d+)\b', tok)
+    return {m.group(1)} if m else set()
+
+
+def _partial_write_scan(lines, name):
+    """-> (#half-register writes from asm blocks, [problems]) for one function."""
+    body = []                       # (text, inside an asm block)
+    in_asm = False
+    for ln in lines:
+        if '#ASMSTART' in ln:
+            in_asm = True
+            continue
+        if '#ASMEND' in ln:
+            in_asm = False
+            continue
+        t = ln.split(';')[0].strip()
+        if t and not t.startswith('.') and not t.endswith(':'):
+            body.append((t, in_asm))
+    n, problems = 0, []
+    for i, (t, ia) in enumerate(body):
+        m = _PARTIAL_WRITE.match(t) if ia else None
+        if not m:
+            continue
+        n += 1
+        reg, gap = m.group(2), 0
+        for t2, _ in body[i + 1:i + 40]:
+            ops = t2.split(None, 1)
+            srcs = set()
+            if len(ops) > 1:
+                toks = [x.strip() for x in ops[1].split(',')]
+                writes_first = not re.match(r'(ds_write|ds_store|global_store|buffer_store|flat_store|scratch_store|s_|v_cmp)', ops[0])
+                for tk in (toks[1:] if writes_first else toks):
+                    srcs |= _regs_of(tk)
+            if reg in srcs:
+                if gap < PARTIAL_WRITE_GAP and not re.match(r'(ds_|global_|buffer_|flat_|scratch_)', ops[0]):
+                    problems.append(f'{name}: `{t2}` reads {reg} {gap} wait state(s) behind the asm `{t}`')
+                break
+            m2 = re.match(r's_nop\s+(\d+)', t2)
+            gap += int(m2.group(1)) + 1 if m2 else 1
+    return n, problems
+
+
+def partial_write_check(path):
+    text = open(path).read().splitlines()
+    n, bad = 0, []
+    for name, lines in _functions(text):
+        k, pr = _partial_write_scan(lines, name)
+        n += k
+        bad += pr
+    return n, bad
+
+
 def uses_lds_dma(src):
     return 'global_load_lds' in open(src).read()
+
+
+def uses_split_asm(src):
+    """Files whose kernels form fp16 operand pairs with common.h's asm split (or their own copy): scanned for the half-register hazard."""
+    txt = open(src).read()
+    return os.path.basename(src) != 'abi.hip' and bool(re.search(r'\bsplit2\(|\bsplit8\(|v_fma_mixhi_f16', txt))
 
 
 def build(force=False, verbose=True):
@@ -254,7 +325,7 @@ def build(force=False, verbose=True):
             if verbose:
                 print(' '.join(cmd), flush=True)
             chk = None
-            if (os.path.basename(src) in ASM_CHECKED or uses_lds_dma(src)) and not flags_skip_asm_check():
+            if (os.path.basename(src) in ASM_CHECKED or uses_lds_dma(src) or uses_split_asm(src)) and not flags_skip_asm_check():
                 asm = obj[:-2] + '.s'
                 chk = (asm, subprocess.Popen([HIPCC] + [f for f in flags if f != '-fPIC'] + ['--cuda-device-only', '-S', src, '-o', asm],
                                              stderr=subprocess.DEVNULL))
@@ -287,6 +358,11 @@ def build(force=False, verbose=True):
                     print(f'{base}: {nfn} kernels with LDS-DMA, {nbar} barriers checked for outstanding LDS reads, {len(bad)} problems', flush=True)
                 if bad and 'FAR_RING_EXP' not in ' '.join(EXTRA_FLAGS):
                     raise RuntimeError(f'{src}: a barrier of an LDS-DMA kernel is crossed with LDS reads outstanding (common.h: ring_barrier):\n  ' + '\n  '.join(bad[:10]))
+            nhw, bad = partial_write_check(asm)
+            if verbose and nhw:
+                print(f'{base}: {nhw} half-register writes from asm; first readers checked, {len(bad)} problems', flush=True)
+            if bad:
+                raise RuntimeError(f'{src}: a half-register write from inline asm is read by a VALU / matrix instruction too soon (common.h: split2):\n  ' + '\n  '.join(bad[:10]))
             os.remove(asm)
         with open(side, 'w') as f:
             f.write(want + '\n')

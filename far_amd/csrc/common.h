@@ -29,11 +29,12 @@ __device__ __forceinline__ void split2(f32x2 x, f16x2& hi, f16x2& lo) {
     unsigned l;
     asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(x.x));
     // The trailing s_nop is part of the instruction's contract here: v_fma_mixhi_f16 writes HALF a register (op_sel hi), and on gfx950 a
-    // VALU / MFMA instruction that reads such a register in the very next issue slot still sees the old upper half (the destination-select
-    // forwarding hazard; hipcc pads it for instructions it knows, an asm statement it cannot see into).  Round 6 found it as K9's k | v
-    // state epilogue returning different sums from launch to launch in one particular build (docs/rounds/r06.md section 2g): the MFMA
-    // behind the last split of an operand read it one slot too early.  One wait state per pair, < 0.5 % of any kernel's VALU time.
-    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\ts_nop 0" : "+v"(l) : "v"(h), "v"(x.y));
+    // matrix instruction that reads such a register too soon still sees the old upper half (the destination-select forwarding hazard;
+    // hipcc pads it for instructions it knows, an asm statement it cannot see into).  Round 6 found it as K9's k | v state epilogue
+    // returning different sums from launch to launch in one particular build (docs/rounds/r06.md section 2g): `mixhi, <one instruction>,
+    // mfma` reads the stale half, two instructions in between do not.  Two wait states per pair, < 1 % of any kernel's VALU time;
+    // far_amd/build.py checks the distance to the first VALU / MFMA reader on the generated code.
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\ts_nop 1" : "+v"(l) : "v"(h), "v"(x.y));
     lo = __builtin_bit_cast(f16x2, l);
 #endif
 }

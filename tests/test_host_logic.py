@@ -287,6 +287,35 @@ def test_build_asm_scan_catches_a_staged_register_touched_before_its_wait(tmp_pa
         assert (nfn, nld, len(bad)) == (1, 1, nbad), (name, bad)
 
 
+def test_build_scan_flags_a_half_register_write_read_too_soon(tmp_path):
+    """far_amd/build.py: partial_write_check -- the gate behind round 6's second root cause (common.h: split2; docs/rounds/r06.md 2g).
+    On hand-made code: `mixhi, one instruction, mfma` (what made K9's k | v-state epilogue differ from launch to launch) is flagged, also
+    when it sits in a cold block BEHIND the function's s_endpgm (where hipcc had put that epilogue); the asm statement with its own
+    s_nop 1 is clean; an LDS store may read the register at once (K17's transform); a half-register write hipcc emitted itself (no asm
+    markers) is the compiler's business."""
+    from far_amd import build
+    head = '_ZN1x6k_convILi1EEEvv:\n'
+    mix = lambda tail='': ('\t;;#ASMSTART\n\tv_fma_mixlo_f16 v39, v35, -1.0, v89 op_sel_hi:[1,0,0]\n\t;;#ASMEND\n'
+                           '\t;;#ASMSTART\n\tv_fma_mixhi_f16 v39, v35, -1.0, v1 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n' + tail + '\t;;#ASMEND\n')
+    mfma = '\tv_mfma_f32_32x32x16_f16 v[66:81], v[38:41], v[50:53], v[66:81]\n'
+    end = '\ts_endpgm\n'
+    fend = '.Lfunc_end0:\n'
+    cases = {
+        'one instruction in between': (head + mix() + '\ts_nop 0\n' + mfma + end + fend, 1),
+        'the same in a cold block behind s_endpgm': (head + end + '.LBB0_7:\n' + mix() + '\ts_nop 0\n' + mfma + '\ts_branch .LBB0_1\n' + fend, 1),
+        'the next issue slot': (head + mix() + mfma + end + fend, 1),
+        'the asm carries s_nop 1': (head + mix('\ts_nop 1\n') + mfma + end + fend, 0),
+        'two other instructions in between': (head + mix() + '\tv_add_u32_e32 v1, v2, v3\n\tv_mul_f32_e32 v4, v5, v6\n' + mfma + end + fend, 0),
+        'an LDS store reads it at once': (head + mix() + '\tds_write_b128 v138, v[38:41] offset:10240\n' + end + fend, 0),
+        'not from asm': (head + '\tv_fma_mixhi_f16 v39, v35, -1.0, v1 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n' + mfma + end + fend, 0),
+    }
+    for name, (text, nbad) in cases.items():
+        p = tmp_path / 'h.s'
+        p.write_text(text)
+        n, bad = build.partial_write_check(str(p))
+        assert len(bad) == nbad and n == (0 if name == 'not from asm' else 1), (name, n, bad)
+
+
 def test_build_ring_scan_flags_a_barrier_crossed_with_lds_reads_outstanding(tmp_path):
     """far_amd/build.py: lds_ring_check -- the build gate behind the round-6 root cause (common.h: ring_barrier).  On hand-made code:
     the rounds-3..5 shape of K13 / K14 (two fragment reads, vmcnt wait, barrier, THEN the lgkmcnt wait hipcc sank below it) is flagged;

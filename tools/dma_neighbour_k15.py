@@ -4,7 +4,7 @@ Round 6 (docs/rounds/r06.md section 2f): with v_pk_fma_f32 in k_rows_partial it 
 (far_amd/build.py: PACKED_FP32_FILES).  This script is the check on the shipped library: every line must say 0.
 python tools/dma_neighbour_k15.py"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from far_amd import ops, _lib
 lib = _lib.load()
