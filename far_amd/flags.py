@@ -45,7 +45,7 @@ SWITCHES = [
 ENV_ONLY = {
     'FAR_HIP_LIB': ('load', 'path of another build of libfar_hip.so (tools/ab_build.py: same-box A/B against a git revision); skips the build-id check'),
     'FAR_TUNING': ('load', 'comma-separated key=value pairs handed to far_set_tuning at load time, e.g. FAR_TUNING="10=1,8=1" (keys below)'),
-    'FAR_SKIP_ASM_CHECK': ('build', "1: far_amd/build.py does not scan the generated code (K9's asm pixel loads; the LDS-DMA ring rule of every kernel with global_load_lds) after recompiling"),
+    'FAR_SKIP_ASM_CHECK': ('build', "1: far_amd/build.py does not scan the generated code (K9's asm pixel loads; the LDS-DMA ring rule of every kernel with global_load_lds; the half-register writes of the asm fp16 split) after recompiling"),
     'FAR_EXTRA_HIPCC_FLAGS': ('build', 'extra hipcc flags of an experiment build (-DFAR_WINO_EXP=..., tools/wino_exp.sh); part of the build id'),
     'FAR_COMMIT': ('tools', 'commit stamp tools/collect_profiles.sh / tools/step_floors.py write into the profile files'),
     'FAR_C3_PY_NODE': ('bench', "bench.py --workload c3: the encoder layer's autograd node driven from Python instead of far_enc_layer_fwd / _bwd"),
