@@ -295,52 +295,63 @@ def rocprof_launch_ms(kernel_label):
     return None
 
 
+class _BlockedTime:
+    """Context: accumulates (in .blocked, seconds) the wall time the thread spends inside the calls that wait for the device -- the tensor
+    methods .item / .cpu / .tolist / .numpy and the explicit synchronize calls."""
+
+    def __enter__(self):
+        import torch
+        self.blocked, depth = 0.0, [0]
+
+        def wrap(fn):
+            def w(*a, **k):
+                if depth[0]:
+                    return fn(*a, **k)
+                depth[0] += 1
+                t = time.perf_counter()
+                try:
+                    return fn(*a, **k)
+                finally:
+                    self.blocked += time.perf_counter() - t
+                    depth[0] -= 1
+            return w
+        self.saved = [(torch.Tensor, nm, getattr(torch.Tensor, nm)) for nm in ('item', 'cpu', 'tolist', 'numpy')]
+        self.saved += [(torch.cuda, 'synchronize', torch.cuda.synchronize), (torch.cuda.Event, 'synchronize', torch.cuda.Event.synchronize),
+                       (torch.cuda.Stream, 'synchronize', torch.cuda.Stream.synchronize)]
+        for obj, nm, fn in self.saved:
+            setattr(obj, nm, wrap(fn))
+        return self
+
+    def __exit__(self, *exc):
+        for obj, nm, fn in self.saved:
+            setattr(obj, nm, fn)
+
+
 def host_work_ms(step, n=3):
     """Host time a step costs its enqueuing thread, WITHOUT the time it spends blocked on the GPU: wall time of n steps (no final
-    synchronisation) minus the wall time inside the tensor methods that wait for the device (.item / .cpu / .tolist / .numpy) and the
-    explicit synchronize calls.  What is left is Python + ctypes + the caching allocator -- the quantity N ranks on one host contend
-    for.  (time.thread_time() is useless here: the HIP runtime spin-waits, so CPU time = wall time.)  Untimed extra steps."""
+    synchronisation) minus the wall time inside the calls that wait for the device (_BlockedTime).  What is left is Python + ctypes + the
+    caching allocator -- the quantity N ranks on one host contend for.  (time.thread_time() is useless here: the HIP runtime spin-waits,
+    so CPU time = wall time.)  Untimed extra steps."""
     import torch
-    blocked = [0.0]
-    depth = [0]
-
-    def wrap(fn):
-        def w(*a, **k):
-            if depth[0]:
-                return fn(*a, **k)
-            depth[0] += 1
-            t = time.perf_counter()
-            try:
-                return fn(*a, **k)
-            finally:
-                blocked[0] += time.perf_counter() - t
-                depth[0] -= 1
-        return w
-    saved = [(torch.Tensor, nm, getattr(torch.Tensor, nm)) for nm in ('item', 'cpu', 'tolist', 'numpy')]
-    saved += [(torch.cuda, 'synchronize', torch.cuda.synchronize), (torch.cuda.Event, 'synchronize', torch.cuda.Event.synchronize),
-              (torch.cuda.Stream, 'synchronize', torch.cuda.Stream.synchronize)]
     torch.cuda.synchronize()
-    for obj, nm, fn in saved:
-        setattr(obj, nm, wrap(fn))
-    try:
+    with _BlockedTime() as b:
         t0 = time.perf_counter()
         for _ in range(n):
             step()
         wall = time.perf_counter() - t0
-    finally:
-        for obj, nm, fn in saved:
-            setattr(obj, nm, fn)
     torch.cuda.synchronize()
-    return 1000.0 * (wall - blocked[0]) / n
+    return 1000.0 * (wall - b.blocked) / n
 
 
-SETTLE_EXTRA = 12        # priming steps settle() may add beyond the requested --warmup (stated constant; VERDICT r5 item 7)
+SETTLE_EXTRA = 24        # priming steps settle() may add beyond the requested --warmup (stated constant; VERDICT r5 item 7)
 
 
-def settle(step, warmup=0, device='cpu', max_seconds=10.0):
-    """Untimed priming steps until the step time has settled (the last three within 2 % of each other and of the best seen): the
-    first process on a fresh box runs its first 10-20 s with a slow host (page-in of the image; 113 ms steps were measured there
-    against 85 ms a few seconds later).  Bounded: at most `warmup + SETTLE_EXTRA` steps / `max_seconds`.  The stop decision is
+def settle(step, warmup=0, device='cpu', max_seconds=30.0):
+    """Untimed priming steps until the step time has settled (the last three within 2 % of each other and of the best seen, host work
+    below a fifth of the step): the
+    first process on a fresh box runs its first 10-60 s with a slow host (page-in of the image; 113-117 ms steps were measured there
+    against 83-85 ms in the next process on the same box -- round 6's profile run caught one such line: 274 pairs/s, then 383 under the
+    profiler a minute later).  Bounded: at most `warmup + SETTLE_EXTRA` steps / `max_seconds`; a settled box leaves after three steps.  The stop decision is
     COLLECTIVE when a process group is up: `step` may contain collectives (DDP gradient all-reduce, SyncBatchNorm), so
     every rank all-reduces its continue flag (MAX) after every step and all ranks leave the loop after the same step count.
     Returns the number of steps run -- reported as `prime_steps` next to `prime_cap`, never timed."""
@@ -350,11 +361,15 @@ def settle(step, warmup=0, device='cpu', max_seconds=10.0):
     ts, t_begin = [], time.perf_counter()
     while True:
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        step()
+        with _BlockedTime() as b:
+            t0 = time.perf_counter()
+            step()
+            host = time.perf_counter() - t0 - b.blocked          # this step's host work (host_work_ms on one step)
         torch.cuda.synchronize()
         ts.append(time.perf_counter() - t0)
-        settled = len(ts) >= 3 and max(ts[-3:]) < 1.02 * min(ts[-3:]) and min(ts[-3:]) < 1.02 * min(ts)
+        # ... and the host must not be the bottleneck: a box still paging the image in runs CONSISTENTLY slow steps (45 ms of host work
+        # against 5), which the time criterion alone would accept as settled
+        settled = len(ts) >= 3 and max(ts[-3:]) < 1.02 * min(ts[-3:]) and min(ts[-3:]) < 1.02 * min(ts) and host < 0.2 * ts[-1]
         go_on = 0.0 if (settled or len(ts) >= cap or time.perf_counter() - t_begin >= max_seconds) else 1.0
         if parallel.max_over_ranks(go_on, device=device) <= 0.0:          # (a plain float at world size 1 without a group)
             break
