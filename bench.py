@@ -1074,7 +1074,10 @@ def main():
                 return dtm_, acc
 
             def entry(dtm_, acc, note):
-                return {'value': round(a.pairs / dtm_, 3), 'ms_per_step': round(1000 * dtm_, 3), 'note': note, 'accuracy': acc}
+                # host_bound: the host work of a step (the same in every mode, measured above) against THIS mode's step time -- a fast mode
+                # on a box with a slow host measures the host (seen in round 6: 35 ms of host work, fp16 at 105 ms next to fp32 at 82)
+                return {'value': round(a.pairs / dtm_, 3), 'ms_per_step': round(1000 * dtm_, 3),
+                        'host_bound': bool(res['host_ms_per_step'] > 0.2 * 1000 * dtm_), 'note': note, 'accuracy': acc}
             (dt16, acc16), (dtm, accm), (dtf, accf) = timed_mode('fp16'), timed_mode('mixed16'), timed_mode('fp16-fine')
             res['other_modes'] = {
                 'parity_line_pose_error': parity_err,

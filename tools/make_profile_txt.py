@@ -27,6 +27,9 @@ out = f"""# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --war
 {c4}
 
 ## one steady-state step (32 pairs): per kernel
+# (two streams since round 6: the head's feature stage -- the encoder-layer k_conv launches behind K1, k_pv, k_emm_contract, k_rows_partial --
+#  overlaps K1 and the fine level, so kernel-busy time exceeds the wall time of the window, and the durations of k_attn128 / k_mlp128 /
+#  k_pv here are those of kernels that SHARE the GPU: their own durations are in profiles/{tag}_step_floors.txt, taken on one stream)
 {win.strip()}
 
 ## whole process (includes the warm-up steps and the isolated kernel timings of bench.kernel_rooflines)
