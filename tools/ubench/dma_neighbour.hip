@@ -310,6 +310,34 @@ extern "C" int launch_victim_f32(float* out, int iters, const void* wp, int bloc
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// ... and the synthetic aggressors for tools/k15_synthetic_aggressors.py (next to the REAL packed K15)
+extern "C" int launch_aggressor(int mode, const void* src, void* sink, hipStream_t st) {
+    static bool once = false;
+    if (!once) {
+        once = true;
+        hipFuncSetAttribute((const void*)aggressor<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 49152);
+        hipFuncSetAttribute((const void*)aggressor<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 49152);
+        hipFuncSetAttribute((const void*)aggressor_gemm<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 49152);
+        hipFuncSetAttribute((const void*)aggressor_gemm<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 49152);
+        hipFuncSetAttribute((const void*)aggressor_gemm<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 49152);
+    }
+    const unsigned char* s8 = (const unsigned char*)src;
+    switch (mode) {
+        case 0: hipLaunchKernelGGL(aggressor<0>, dim3(2048), dim3(256), 49152, st, s8, (unsigned*)sink, 600); break;             // LDS-DMA ring + reads
+        case 1: hipLaunchKernelGGL(aggressor<4>, dim3(2048), dim3(256), 49152, st, s8, (unsigned*)sink, 600); break;             // loads + ds_write + reads
+        case 2: hipLaunchKernelGGL(aggressor_mfma, dim3(4096), dim3(256), 0, st, (float*)sink, 3000); break;                    // MFMA only
+        case 3: hipLaunchKernelGGL(aggressor_mfma_big, dim3(4096), dim3(256), 0, st, (float*)sink, 1200); break;                // MFMA, 200 registers
+        case 4: hipLaunchKernelGGL(aggressor_valu_big, dim3(4096), dim3(256), 0, st, (float*)sink, 200); break;                 // VALU, 256 registers
+        case 5: hipLaunchKernelGGL(aggressor_gemm<0>, dim3(2048), dim3(256), 49152, st, s8, (float*)sink, 600); break;          // DMA ring -> reads -> MFMA
+        case 6: hipLaunchKernelGGL(aggressor_gemm<1>, dim3(2048), dim3(256), 49152, st, s8, (float*)sink, 1600); break;         // reads -> MFMA, no DMA
+        case 7: hipLaunchKernelGGL(aggressor_gemm<2>, dim3(2048), dim3(256), 49152, st, s8, (float*)sink, 600); break;          // DMA ring -> reads, no MFMA
+        case 8: hipLaunchKernelGGL(aggressor_mix<false>, dim3(4096), dim3(256), 0, st, (float*)sink, 4000); break;              // fp16 split triples
+        case 9: hipLaunchKernelGGL(aggressor_mix<true>, dim3(4096), dim3(256), 0, st, (float*)sink, 2000); break;               // split triples -> MFMA
+        default: return -2;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 #ifndef AS_LIB
 int main() {
     const int VB = 4096, AB = 8192, VIT = 40, AIT = 60;
