@@ -15,7 +15,7 @@ import os
 from collections import namedtuple
 
 Switch = namedtuple('Switch', 'env module attr off_value neutral scope doc')
-# env: set to 1 to switch the feature OFF; module.attr: the Python flag it initialises (tests flip the attribute directly);
+# env: set to 1 to switch the feature OFF (one opt-in exception, off_value True: FAR_FPN_STREAM=1 switches it ON); module.attr: the Python flag it initialises (tests flip the attribute directly);
 # scope: 'inference' (the headline step), 'training' (BASELINE configs[2]), 'bench' (bench.py only), 'load' (library selection)
 SWITCHES = [
     Switch('FAR_NO_WINO', 'far_amd.ops', 'USE_WINO', False, 'parity', 'inference',
