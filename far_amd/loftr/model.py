@@ -291,11 +291,14 @@ class LoFTR(nn.Module):
         if not self.config['regress_rt']:
             return
 
+        # (the re-run flag lives in a list, not on the function: `run.again` would make the closure refer to itself -- a reference
+        # cycle that kept the whole `data` dict, gigabytes of device tensors, alive until Python's cyclic collector came by)
+        again = [False]
+
         def run():
-            data.pop(self._HEAD_KEY, None) if run.again else None      # a re-run must not reuse features with inf / NaN in them
-            run.again = True
+            data.pop(self._HEAD_KEY, None) if again[0] else None       # a re-run must not reuse features with inf / NaN in them
+            again[0] = True
             self._rt_prediction(data)
-        run.again = False
         self._guarded(run, data['featmap0'].device)
 
     def _rt_prediction(self, data):

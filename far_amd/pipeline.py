@@ -30,17 +30,19 @@ def _one_guard(matcher, batch, seq, device_key):
         return seq()
     prior0, pdev0 = batch.get('priorRT', _MISSING), batch.get('_priorRT_device', _MISSING)
 
+    again = [False]                                         # (not `run.again`: a function that refers to itself is a reference cycle that
+                                                            # keeps `batch` -- the step's device tensors -- alive until the cyclic collector runs)
+
     def run():
-        if run.again:                                       # a re-run at a wider range starts from what the caller handed in
+        if again[0]:                                        # a re-run at a wider range starts from what the caller handed in
             for k, v in (('priorRT', prior0), ('_priorRT_device', pdev0)):
                 if v is _MISSING:
                     batch.pop(k, None)
                 else:
                     batch[k] = v
             core.invalidate_head_cache(batch)
-        run.again = True
+        again[0] = True
         return seq()
-    run.again = False
     return core.guarded_sequence(run, t.device, tuple(batch[k] for k in ('image0', 'image1') if k in batch))
 
 
