@@ -10,6 +10,34 @@ from far_amd.config import far_eval_config
 from far_amd.loftr import LoFTR
 from far_amd.pipeline import test_step
 m = LoFTR(far_eval_config()).eval(); synth.load_synthetic(m, seed=0); m = m.cuda()
+if len(sys.argv) > 1 and sys.argv[1] == 'train':
+    # the training step (BASELINE configs[2] shape: one pair): forward + backward + AdamW with the collector disabled
+    import copy
+    from far_amd.config import far_train_config, RunCfg
+    from far_amd.losses import LoFTRLoss
+    from far_amd.pipeline import train_step
+    mt = copy.deepcopy(m).train()
+    loss_fn = LoFTRLoss(far_train_config()).train()
+    opt = torch.optim.AdamW(mt.parameters(), lr=1e-5)
+    base = synth.synth_training_batch(1, seed=78, device='cuda')
+
+    def tstep():
+        batch = dict(base)
+        train_step(mt, batch, loss_fn, RunCfg('prior_ransac', 2), H=256, seed=0)
+        batch['loss'].backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        torch.cuda.synchronize()
+    for _ in range(3):
+        tstep()
+    gc.collect(); gc.disable()
+    mem = []
+    for i in range(10):
+        tstep()
+        mem.append(torch.cuda.memory_allocated() / 2**30)
+    print('training step: allocated after each step (GiB), collector disabled:', ' '.join(f'{x:.3f}' for x in mem))
+    print('unreachable objects found by a collection now:', gc.collect())
+    sys.exit(0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 im0, im1 = synth.synth_image_pair(n, seed=1234)
 K = torch.from_numpy(np.stack([synth.MP3D_K] * n)).cuda()
