@@ -565,7 +565,7 @@ def bench_c4(a, dev, world, rank, dist):
     for _ in range(prime + a.warmup):
         last = step()
     # (host_frac only for the batched headline shape: a one-pair step is host-bound in its steady state)
-    prime += settle(step, a.warmup, dev, max_seconds=30.0 if a.pairs >= 8 else 10.0, host_frac=0.2 if a.pairs >= 8 else None)
+    prime += settle(step, a.warmup, dev, max_seconds=30.0 if a.pairs >= 8 else 10.0, host_frac=0.3 if a.pairs >= 8 else None)
 
     def fence():
         torch.cuda.synchronize()
@@ -688,7 +688,7 @@ def bench_c3(a, dev, world, rank, dist):
     for _ in range(prime + a.warmup):
         last = step()
     # (host_frac only for the batched headline shape: a one-pair step is host-bound in its steady state)
-    prime += settle(step, a.warmup, dev, max_seconds=30.0 if a.pairs >= 8 else 10.0, host_frac=0.2 if a.pairs >= 8 else None)
+    prime += settle(step, a.warmup, dev, max_seconds=30.0 if a.pairs >= 8 else 10.0, host_frac=0.3 if a.pairs >= 8 else None)
 
     def fence():
         torch.cuda.synchronize()
@@ -808,7 +808,7 @@ def bench_c5(a, dev, world, rank, dist):
     for _ in range(prime + a.warmup):
         last = step()
     # (host_frac only for the batched headline shape: a one-pair step is host-bound in its steady state)
-    prime += settle(step, a.warmup, dev, max_seconds=30.0 if a.pairs >= 8 else 10.0, host_frac=0.2 if a.pairs >= 8 else None)
+    prime += settle(step, a.warmup, dev, max_seconds=30.0 if a.pairs >= 8 else 10.0, host_frac=0.3 if a.pairs >= 8 else None)
 
     def fence():
         torch.cuda.synchronize()
@@ -914,7 +914,7 @@ def main():
     for _ in range(prime + a.warmup):
         last = step()
     # (host_frac only for the batched headline shape: a one-pair step is host-bound in its steady state)
-    prime += settle(step, a.warmup, dev, max_seconds=30.0 if a.pairs >= 8 else 10.0, host_frac=0.2 if a.pairs >= 8 else None)
+    prime += settle(step, a.warmup, dev, max_seconds=30.0 if a.pairs >= 8 else 10.0, host_frac=0.3 if a.pairs >= 8 else None)
 
     def fence():
         torch.cuda.synchronize()
@@ -1058,7 +1058,7 @@ def main():
                 model.set_precision(mode)
                 for _ in range(2):
                     step()
-                settle(step, 0, dev, host_frac=0.3 if a.pairs >= 8 else None)
+                settle(step, 0, dev, host_frac=0.45 if a.pairs >= 8 else None)
                 fence()
                 t1 = time.perf_counter()
                 for _ in range(n):
